@@ -1,0 +1,236 @@
+#!/usr/bin/env python
+"""bench.py -- feature-raster fwd+bwd views/s (BASELINE.json metric) on N GPUs of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = the harness counterpart of train.py:134-174 on ONE view per
+GPU: render(cam, gaussians, pipe, bg, feature_mode=True) -> loss = <render, G> with a fixed
+random cotangent G -> loss.backward() -> (N>1) sum of d loss/d _semantic_feature over ranks
+(RCCL).  Inputs are synthetic (gags_amd/synthetic.py), resident in HBM before the timed
+region.  Workload at N=1 = BASELINE.json configs[2] "C3": 1.5 M Gaussians, 1920x1080, D=512 --
+the configuration the metric is quoted on; it fits one MI355X.
+
+Prints ONE JSON line (rank 0) with the driver's contract keys plus `roofline` (dominant
+kernel, measured with HIP events inside the timed region) and `cpu_baseline` (the CPU oracle
+timed on a bounded tile sample of the same workload, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA == fp32 vector peak (dense)
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+class _CotangentLoss(torch.autograd.Function):
+    """loss = <x, G>; terminal loss of the harness: backward hands G itself to the rasterizer
+    (d loss / d x = G exactly), so no extra elementwise kernels sit inside the timed region."""
+
+    @staticmethod
+    def forward(ctx, x, G):
+        ctx.save_for_backward(G)
+        return torch.dot(x.reshape(-1), G.reshape(-1))
+
+    @staticmethod
+    def backward(ctx, g):
+        (G,) = ctx.saved_tensors
+        return G, None
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C5"])
+    ap.add_argument("--n", type=int, default=None)
+    ap.add_argument("--d", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
+    ap.add_argument("--no-allreduce", action="store_true", help="(debug) skip the gradient reduction at N>1")
+    ap.add_argument("--raster-flags", type=int, default=0)
+    return ap.parse_args()
+
+
+def cpu_baseline(pc, cam, d, width, height, target_s):
+    """Time the CPU oracle (oracle/gags_oracle.c, kind 'port': the reference has no CPU path and
+    no compilable native source) on the same C3 inputs: projection + binning in
+    full, raster fwd + colours-only bwd on every `tile_step`-th tile, scaled to the whole view."""
+    import numpy as np
+    from oracle import oracle as orc
+    from gags_amd import synthetic as syn
+    orc.build()
+    vm, K = syn.camera_matrices(cam)
+    means = pc.get_xyz.detach().cpu().numpy()
+    quats = pc.get_rotation.detach().cpu().numpy()
+    scales = pc.get_scaling.detach().cpu().numpy()
+    opac = pc.get_opacity.detach().cpu().numpy().reshape(-1)
+    feats = pc.get_semantic_feature.detach().cpu().numpy()
+    bg = np.zeros(d, np.float32)
+    t0 = time.perf_counter()
+    radii, means2d, depths, conics = orc.project_fwd(means, quats, scales, vm.cpu().numpy(), K, width, height)
+    b = orc.tile_bin(means2d, radii, depths, width, height)
+    t_bin = time.perf_counter() - t0
+    n_tiles = b["tile_width"] * b["tile_height"]
+    rng = np.random.default_rng(1)
+
+    def sample(step):
+        v_out = np.zeros((height, width, d), np.float32)
+        # cotangent only where the sampled tiles are (others are never read)
+        t1 = time.perf_counter()
+        out, alphas, last, st = orc.raster_fwd(means2d, conics, opac, feats, bg, width, height, b["isect_offsets"],
+                                               b["flatten_ids"], 0, step)
+        t_f = time.perf_counter() - t1
+        v_out[:] = 1.0
+        t2 = time.perf_counter()
+        orc.raster_bwd(means2d, conics, opac, feats, bg, width, height, b["isect_offsets"], b["flatten_ids"],
+                       alphas, last, v_out, None, colors_only=True, tile_begin=0, tile_step=step)
+        t_b = time.perf_counter() - t2
+        return t_f + t_b
+
+    step = max(1, n_tiles // 64)
+    t_s = sample(step)            # pilot (also warms the page cache / allocator)
+    n_s = len(range(0, n_tiles, step))
+    per_tile = t_s / n_s
+    want = max(1, min(n_tiles, int(target_s / max(per_tile, 1e-9))))
+    step2 = max(1, n_tiles // want)
+    if step2 < step:
+        t_s = sample(step2)
+        step = step2
+        n_s = len(range(0, n_tiles, step))
+    t_view = t_bin + t_s * (n_tiles / n_s)
+    return {
+        "value": 1.0 / t_view, "unit": "views/s", "cores": orc.max_threads(), "kind": "port",
+        "sample": (f"oracle/gags_oracle.c (OpenMP, fp32): projection+binning of the full view ({t_bin:.2f} s) + raster "
+                   f"fwd + colours-only bwd on every {step}-th tile ({n_s} of {n_tiles} tiles, {t_s:.2f} s), "
+                   f"raster time scaled by {n_tiles / n_s:.1f}x"),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from gags_amd import _lib, profiler, synthetic as syn
+    from gags_amd.gaussian_renderer import render
+    from gags_amd.dist import reduce_feature_grad
+    _lib.load()
+
+    cfg = dict(syn.CONFIGS[args.config])
+    if args.n:
+        cfg["n"] = args.n
+    if args.d:
+        cfg["d"] = args.d
+    n, d, width, height = cfg["n"], cfg["d"], cfg["width"], cfg["height"]
+
+    # replicated Gaussians (same seed on every rank), one yawed view per rank (C4's cameras)
+    pc = syn.make_model(n, d, width, height, seed=0, device=dev, gen_device=dev)
+    pc.training_setup()
+    cam = syn.make_camera(width, height, view=(rank % 8) if world > 1 else None, device=dev)
+    bg = torch.zeros(3, device=dev)
+    G = syn.make_cotangent(d, height, width, seed=1, device=dev)  # [D,H,W] view of [H,W,D] memory
+
+    def step():
+        pc._semantic_feature.grad = None
+        pkg = render(cam, pc, None, bg, feature_mode=True, raster_flags=args.raster_flags)
+        loss = _CotangentLoss.apply(pkg["render"].permute(1, 2, 0), G.permute(1, 2, 0))
+        loss.backward()
+        if world > 1 and not args.no_allreduce:
+            reduce_feature_grad(pc._semantic_feature.grad)
+        return pkg
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        pkg = step()
+    torch.cuda.synchronize()
+    info = pkg["info"]
+    n_isects = info["n_isects"]
+    n_visible = int((pkg["radii"] > 0).sum().item())
+
+    # workload statistics for the roofline model (outside the timed region)
+    counts = torch.zeros(2, dtype=torch.int64, device=dev)
+    _lib.check(_lib.load().gags_raster_stats(width, height, _lib.ptr(info["means2d"][0]), _lib.ptr(info["conics"][0]),
+                                             _lib.ptr(info["opacities"][0].contiguous()),
+                                             _lib.ptr(info["isect_offsets"]), _lib.ptr(info["flatten_ids"]),
+                                             n_isects, _lib.ptr(counts), None), "gags_raster_stats")
+    torch.cuda.synchronize()
+    q_eval, q_blend = (int(v) for v in counts.tolist())
+    del pkg, info
+
+    profiler.enable(True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    stages = profiler.summary()
+    profiler.enable(False)
+
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t.item())
+    ms_per_step = 1e3 * dt / args.steps
+    value = world * args.steps / dt  # every rank renders one view per step (weak scaling)
+
+    if rank == 0:
+        # dominant kernel and its roofline.  Algorithmic flops per launch (DESIGN.md "Roofline"):
+        #   raster fwd           : 14*Q_eval + 2*D*Q_blend
+        #   raster bwd (colours) : 14*Q_eval + 2*D*Q_blend
+        dom = max(("raster_fwd", "raster_bwd"), key=lambda k: stages.get(k, (0, 0))[0])
+        dom_ms = stages[dom][0]
+        flops = 14.0 * q_eval + 2.0 * d * q_blend
+        achieved = flops / (dom_ms * 1e-3) / 1e12
+        pix = width * height
+        alg_bytes = {"raster_fwd": 12.0 * n_isects + 4.0 * n_visible * d + pix * (4.0 * d + 8),
+                     "raster_bwd": 12.0 * n_isects + pix * (4.0 * d + 8) + 4.0 * n_visible * d}[dom]
+        line = {
+            "metric": "feature-raster fwd+bwd views/s",
+            "value": value, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {n} Gaussians, {width}x{height}, D={d}, 1 view/GPU/step",
+                       "n_gaussians": n, "width": width, "height": height, "feature_dim": d,
+                       "visible": n_visible, "n_isects": n_isects, "pairs_evaluated": q_eval,
+                       "pairs_blended": q_blend, "parallelism": f"view-dp{world}"},
+            "roofline": {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
+                         "avg_launch_ms": dom_ms, "algorithmic_flops": flops,
+                         "hbm_frac_of_same_kernel": alg_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "stages_ms": {k: round(v[0], 4) for k, v in sorted(stages.items())},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(pc, cam, d, width, height, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,90 @@
+"""ctypes binding of libgags_hip.so (C ABI: include/gags_raster.h).
+
+The library is the product: there is NO fallback.  If it is missing or fails to load,
+every op raises -- nothing silently routes to PyTorch or to the CPU oracle.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libgags_hip.so")
+
+_vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+# name -> (restype, argtypes); must list every symbol include/gags_raster.h declares
+SIGNATURES = {
+    "gags_abi_version": (_i32, []),
+    "gags_strerror": (ctypes.c_char_p, [_i32]),
+    "gags_device_count": (_i32, []),
+    "gags_project_fwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _f32,
+                                _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gags_scan_scratch_bytes": (_i64, [_i32]),
+    "gags_cumsum_i32": (_i32, [_i32, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "gags_read_i32": (_i32, [_vp, _vp, _vp]),
+    "gags_tile_emit": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "gags_sort_scratch_bytes": (_i64, [_i64]),
+    "gags_sort_pairs": (_i32, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "gags_tile_offsets": (_i32, [_i64, _vp, _i32, _vp, _vp]),
+    "gags_raster_fwd": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp]),
+    "gags_raster_bwd": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
+                               _vp, _vp, _vp, _vp, _i32, _vp]),
+    "gags_raster_stats": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "gags_project_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp,
+                                _vp, _vp, _vp, _vp]),
+    "gags_sh_fwd": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gags_sh_bwd": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gags_ed_normalize": (_i32, [_i64, _i32, _vp, _vp, _vp]),
+}
+
+GAGS_BWD_COLORS_ONLY = 1
+GAGS_FWD_NO_MFMA = 2
+
+_lib = None
+
+
+class GagsLibraryError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile gags_amd/csrc/*.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", CSRC, "-j8", "libgags_hip.so"], stdout=out)
+    return LIB_PATH
+
+
+def load():
+    """dlopen the library and type every entry point.  Raises GagsLibraryError when absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GagsLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C gags_amd/csrc`.  gags_amd has no CPU / PyTorch fallback.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise GagsLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise GagsLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().gags_strerror(code)
+        raise RuntimeError(f"{what} failed: {msg.decode() if msg else code} ({code})")
+
+
+def ptr(t):
+    """Raw device pointer of a tensor (or NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())

@@ -1,0 +1,47 @@
+// Dispatch of the two raster entry points onto the VALU (narrow D) and MFMA (wide D) kernels.
+#include "common.h"
+
+int gags_raster_fwd_valu(int d, int width, int height, const float *means2d, const float *conics,
+                         const float *opacities, const float *colors, const float *backgrounds,
+                         const int32_t *offsets, const int32_t *flat, int n_isects, float *out, float *alphas,
+                         int32_t *last_ids, hipStream_t st);
+int gags_raster_bwd_valu(int d, int width, int height, const float *means2d, const float *conics,
+                         const float *opacities, const float *colors, const float *backgrounds,
+                         const int32_t *offsets, const int32_t *flat, int n_isects, const float *alphas,
+                         const int32_t *last_ids, const float *v_out, const float *v_alpha, float *v_colors,
+                         float *v_opac, float *v_m2d, float *v_con, bool geom, hipStream_t st);
+
+extern "C" int gags_raster_fwd(int d, int width, int height, const float *means2d, const float *conics,
+                               const float *opacities, const float *colors, const float *backgrounds,
+                               const int32_t *isect_offsets, const int32_t *flatten_ids, int64_t n_isects,
+                               float *render_colors, float *render_alphas, int32_t *last_ids, int flags,
+                               void *stream)
+{
+    (void)flags;
+    if (d <= 0 || width <= 0 || height <= 0 || n_isects < 0 || n_isects >= (1ll << 31)) return GAGS_EINVAL;
+    if (!isect_offsets || !render_colors || !render_alphas || !last_ids) return GAGS_EINVAL;
+    if (n_isects > 0 && (!means2d || !conics || !opacities || !colors || !flatten_ids)) return GAGS_EINVAL;
+    return gags_raster_fwd_valu(d, width, height, means2d, conics, opacities, colors, backgrounds, isect_offsets,
+                                flatten_ids, (int)n_isects, render_colors, render_alphas, last_ids,
+                                (hipStream_t)stream);
+}
+
+extern "C" int gags_raster_bwd(int d, int width, int height, const float *means2d, const float *conics,
+                               const float *opacities, const float *colors, const float *backgrounds,
+                               const int32_t *isect_offsets, const int32_t *flatten_ids, int64_t n_isects,
+                               const float *render_alphas, const int32_t *last_ids, const float *v_render_colors,
+                               const float *v_render_alphas, float *v_colors, float *v_opacities, float *v_means2d,
+                               float *v_conics, int flags, void *stream)
+{
+    if (d <= 0 || width <= 0 || height <= 0 || n_isects < 0 || n_isects >= (1ll << 31)) return GAGS_EINVAL;
+    if (n_isects == 0) return GAGS_OK;
+    if (!means2d || !conics || !opacities || !colors || !isect_offsets || !flatten_ids || !render_alphas ||
+        !last_ids || !v_render_colors || !v_colors)
+        return GAGS_EINVAL;
+    const bool geom = !(flags & GAGS_BWD_COLORS_ONLY);
+    if (geom && (!v_opacities || !v_means2d || !v_conics)) return GAGS_EINVAL;
+    return gags_raster_bwd_valu(d, width, height, means2d, conics, opacities, colors, backgrounds, isect_offsets,
+                                flatten_ids, (int)n_isects, render_alphas, last_ids, v_render_colors,
+                                v_render_alphas, v_colors, v_opacities, v_means2d, v_conics, geom,
+                                (hipStream_t)stream);
+}

@@ -1,0 +1,59 @@
+// Shared device helpers for the gfx950 kernels of libgags_hip.so.
+// Numerical contract (DESIGN.md "Numerics"): fp32, no implicit FMA contraction (the build
+// passes -ffp-contract=off; fmaf() is written where a fused op is part of the algorithm),
+// IEEE divide/sqrt, exp(-sigma) by an explicit polynomial so that index tensors and forward
+// renders are reproducible bit-for-bit on any IEEE machine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gags_raster.h"
+
+#define GAGS_ALPHA_MAX 0.999f
+#define GAGS_ALPHA_MIN (1.0f / 255.0f)
+#define GAGS_T_STOP 1e-4f
+
+#define GAGS_CHECK_LAUNCH()                       \
+    do {                                          \
+        hipError_t e__ = hipGetLastError();       \
+        if (e__ != hipSuccess) return GAGS_ELAUNCH; \
+    } while (0)
+
+// exp(-sigma) = 2^t, t = -sigma*log2(e) = n + f, n = rint(t), f in [-.5,.5];
+// 2^f by a degree-6 polynomial (max rel. error 1.4 ulp), scaled with ldexp.
+// 1 mul, 1 max, 1 rndne, 1 sub, 6 fma, 1 cvt, 1 ldexp -- all full-rate VALU on gfx950.
+__device__ __forceinline__ float gags_exp_neg(float sigma)
+{
+    float t = sigma * -1.44269504088896341f;
+    t = fmaxf(t, -125.0f);
+    const float n = __builtin_rintf(t);
+    const float f = t - n;
+    float p = 0x1.444p-13f;
+    p = __builtin_fmaf(p, f, 0x1.5f48cp-10f);
+    p = __builtin_fmaf(p, f, 0x1.3b2a1cp-7f);
+    p = __builtin_fmaf(p, f, 0x1.c6aeccp-5f);
+    p = __builtin_fmaf(p, f, 0x1.ebfbep-3f);
+    p = __builtin_fmaf(p, f, 0x1.62e43p-1f);
+    p = __builtin_fmaf(p, f, 1.0f);
+    return __builtin_ldexpf(p, (int)n);
+}
+
+__device__ __forceinline__ void gags_tile_aabb(float mx, float my, int radius, int tile_w, int tile_h,
+                                               int &x0, int &x1, int &y0, int &y1)
+{
+    const float tr = (float)radius / (float)GAGS_TILE;
+    const float tx = mx / (float)GAGS_TILE, ty = my / (float)GAGS_TILE;
+    x0 = (int)fminf(fmaxf(floorf(tx - tr), 0.f), (float)tile_w);
+    x1 = (int)fminf(fmaxf(ceilf(tx + tr), 0.f), (float)tile_w);
+    y0 = (int)fminf(fmaxf(floorf(ty - tr), 0.f), (float)tile_h);
+    y1 = (int)fminf(fmaxf(ceilf(ty + tr), 0.f), (float)tile_h);
+}
+
+// XCD-aware tile remap: the dispatcher places workgroup b on XCD b % 8 (speed only, never
+// correctness).  Give each XCD a contiguous run of tiles so neighbouring tiles -- which
+// share Gaussians, hence feature rows -- hit the same 4 MiB L2.  Bijective for any count.
+__device__ __forceinline__ int gags_xcd_remap(int bid, int nwg)
+{
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}

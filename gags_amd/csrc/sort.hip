@@ -1,0 +1,158 @@
+// K7: stable LSD radix sort of (int64 key, int32 value) pairs on key bits [0, 32+tile_bits).
+//
+// Hand-written for gfx950 wave64 (no library): 8-bit digits, three kernels per pass
+//   1. histogram   : per-block digit counts (LDS atomics), written digit-major
+//   2. scan        : device-wide exclusive scan over [digit][block] -> global scatter bases
+//   3. scatter     : each block re-reads its tile, ranks keys STABLY (wave-level match via
+//                    per-digit ballots, wave-ordered LDS counters) and writes pairs out
+// Traffic per pass: read 12 B + write 12 B per pair + one extra 8 B key read for the
+// histogram = 32 B/pair; 45-bit keys at 1080p (13 tile bits) need 6 passes.
+// HBM-bound integer work: nothing here is reshaped into a GEMM.
+#include "common.h"
+#include "scan.h"
+
+namespace {
+
+constexpr int RS_THREADS = 256;
+constexpr int RS_ITEMS = 8;
+constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // 2048 pairs per block
+constexpr int RS_RADIX = 256;
+
+__global__ __launch_bounds__(RS_THREADS) void rs_histogram(int64_t n, int shift, const uint64_t *__restrict__ keys,
+                                                           uint32_t *__restrict__ hist /*[RADIX][nblocks]*/,
+                                                           int nblocks)
+{
+    __shared__ uint32_t h[RS_RADIX];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; ++k) {
+        const int64_t i = base + k * RS_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 0xff], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// Stable scatter.  Items are laid out blocked-by-wave so that (wave, item, lane) order is the
+// input order: wave w owns [w*512, (w+1)*512) of the tile, item k covers 64 consecutive keys.
+__global__ __launch_bounds__(RS_THREADS) void rs_scatter(int64_t n, int shift, const uint64_t *__restrict__ keys_in,
+                                                         const int32_t *__restrict__ vals_in,
+                                                         uint64_t *__restrict__ keys_out,
+                                                         int32_t *__restrict__ vals_out,
+                                                         const uint32_t *__restrict__ hist, int nblocks)
+{
+    __shared__ uint32_t cnt_s[4][RS_RADIX];  // per-wave digit counts, then per-wave bases
+    volatile uint32_t(*cnt)[RS_RADIX] = cnt_s;
+    __shared__ uint32_t gbase[RS_RADIX];    // global base of each digit for this block
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cnt[k][threadIdx.x] = 0;
+    gbase[threadIdx.x] = hist[(size_t)threadIdx.x * nblocks + blockIdx.x];
+    __syncthreads();
+
+    const int64_t wbase = (int64_t)blockIdx.x * RS_TILE + (int64_t)w * (64 * RS_ITEMS);
+    uint64_t key[RS_ITEMS];
+    int32_t val[RS_ITEMS];
+    uint32_t rank[RS_ITEMS];  // rank of the key among same-digit keys of THIS wave (input order)
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; ++k) {
+        const int64_t i = wbase + k * 64 + lane;
+        const bool ok = i < n;
+        key[k] = ok ? keys_in[i] : ~0ull;
+        val[k] = ok ? vals_in[i] : 0;
+        const uint32_t dgt = ok ? (uint32_t)((key[k] >> shift) & 0xff) : 0xffffffffu;
+        // match-any over the wave: mask of lanes holding the same digit (8 ballots)
+        uint64_t m = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t bal = __ballot((dgt >> b) & 1u);
+            m &= ((dgt >> b) & 1u) ? bal : ~bal;
+        }
+        const uint64_t lower = m & ((1ull << lane) - 1ull);
+        const uint32_t before = (uint32_t)__popcll(lower);
+        uint32_t prev = 0;
+        if (ok) {
+            prev = cnt[w][dgt];  // same value for all lanes of the group (read before the write below)
+        }
+        // the read above must complete in every lane before the leader bumps the counter
+        __builtin_amdgcn_wave_barrier();
+        if (ok && lower == 0) cnt[w][dgt] = prev + (uint32_t)__popcll(m);
+        __builtin_amdgcn_wave_barrier();
+        rank[k] = prev + before;
+    }
+    __syncthreads();
+    // per-digit exclusive scan across the 4 waves -> base of (wave, digit) inside the digit run
+    {
+        const int d = threadIdx.x;
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t c = cnt[k][d];
+            cnt[k][d] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; ++k) {
+        const int64_t i = wbase + k * 64 + lane;
+        if (i < n) {
+            const uint32_t dgt = (uint32_t)((key[k] >> shift) & 0xff);
+            const uint32_t pos = gbase[dgt] + cnt[w][dgt] + rank[k];
+            keys_out[pos] = key[k];
+            vals_out[pos] = val[k];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t gags_sort_scratch_bytes(int64_t n_isects)
+{
+    const int64_t n = n_isects > 0 ? n_isects : 1;
+    const int64_t nblocks = (n + RS_TILE - 1) / RS_TILE;
+    // ping-pong pair buffers (keys + values) + histogram
+    const int64_t keys = ((n * 8 + 255) / 256) * 256, vals = ((n * 4 + 255) / 256) * 256;
+    const int64_t hist = ((nblocks * RS_RADIX * 4 + 255) / 256) * 256;
+    return keys + vals + hist + gags_scan::scratch_bytes(nblocks * RS_RADIX);
+}
+
+extern "C" int gags_sort_pairs(int64_t n, int tile_bits, const int64_t *keys_in, const int32_t *vals_in,
+                               int64_t *keys_out, int32_t *vals_out, void *scratch, int64_t scratch_bytes,
+                               void *stream)
+{
+    if (n < 0 || tile_bits < 0 || tile_bits > 31) return GAGS_EINVAL;
+    if (n == 0) return GAGS_OK;
+    if (n >= (1ll << 31)) return GAGS_EINVAL;
+    if (!keys_in || !vals_in || !keys_out || !vals_out || !scratch) return GAGS_EINVAL;
+    if (scratch_bytes < gags_sort_scratch_bytes(n)) return GAGS_ESCRATCH;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblocks = (int)((n + RS_TILE - 1) / RS_TILE);
+    const int64_t keys_b = ((n * 8 + 255) / 256) * 256, vals_b = ((n * 4 + 255) / 256) * 256;
+    uint64_t *ktmp = (uint64_t *)scratch;
+    int32_t *vtmp = (int32_t *)((char *)scratch + keys_b);
+    uint32_t *hist = (uint32_t *)((char *)scratch + keys_b + vals_b);
+    const int64_t hist_b = (((int64_t)nblocks * RS_RADIX * 4 + 255) / 256) * 256;
+    int32_t *scan_tmp = (int32_t *)((char *)scratch + keys_b + vals_b + hist_b);
+
+    const int nbits = 32 + tile_bits;
+    const int passes = (nbits + 7) / 8;
+    // arrange the ping-pong so the last pass lands in keys_out/vals_out
+    const uint64_t *src_k = (const uint64_t *)keys_in;
+    const int32_t *src_v = vals_in;
+    for (int p = 0; p < passes; ++p) {
+        const bool to_out = ((passes - 1 - p) % 2) == 0;
+        uint64_t *dst_k = to_out ? (uint64_t *)keys_out : ktmp;
+        int32_t *dst_v = to_out ? vals_out : vtmp;
+        hipLaunchKernelGGL(rs_histogram, dim3(nblocks), dim3(RS_THREADS), 0, st, n, p * 8, src_k, hist, nblocks);
+        gags_scan::launch<true>(RS_RADIX * nblocks, (const int32_t *)hist, (int32_t *)hist, nullptr, scan_tmp, st);
+        hipLaunchKernelGGL(rs_scatter, dim3(nblocks), dim3(RS_THREADS), 0, st, n, p * 8, src_k, src_v, dst_k, dst_v,
+                           hist, nblocks);
+        src_k = dst_k;
+        src_v = dst_v;
+    }
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}

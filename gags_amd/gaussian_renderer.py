@@ -1,0 +1,80 @@
+"""Drop-in for /root/reference/gaussian_renderer/__init__.py: `render(...)`.
+
+Same signature, same attribute reads on `viewpoint_camera` (FoVx, FoVy, image_width,
+image_height, world_view_transform) and `pc` (get_xyz, get_opacity, get_scaling,
+get_rotation, get_semantic_feature, get_features, active_sh_degree), same returned dict
+(`render` [D',H,W] as a permuted view of [H,W,D'], `viewspace_points` [1,N,2],
+`visibility_filter` [N] bool, `radii` [N] int32).  `pipe` is accepted and ignored, as in the
+reference (its PipelineParams are never read on this path).  The only difference is what
+executes underneath: gags_amd.rasterization instead of gsplat.rasterization.
+"""
+import math
+
+import torch
+
+from .rasterization import rasterization
+
+# The reference re-uploads K with torch.tensor(..., device="cuda") on every call
+# (gaussian_renderer/__init__.py:31-38).  K depends only on (FoVx, FoVy, W, H); keep the
+# device copy resident instead of paying a pageable H2D copy per iteration.
+_K_CACHE = {}
+
+
+def _intrinsics(viewpoint_camera, device):
+    key = (float(viewpoint_camera.FoVx), float(viewpoint_camera.FoVy), int(viewpoint_camera.image_width),
+           int(viewpoint_camera.image_height), str(device))
+    K = _K_CACHE.get(key)
+    if K is None:
+        tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
+        tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
+        focal_length_x = viewpoint_camera.image_width / (2 * tanfovx)
+        focal_length_y = viewpoint_camera.image_height / (2 * tanfovy)
+        K = torch.tensor(
+            [[focal_length_x, 0, viewpoint_camera.image_width / 2.0],
+             [0, focal_length_y, viewpoint_camera.image_height / 2.0],
+             [0, 0, 1]], device=device)
+        if len(_K_CACHE) > 4096:
+            _K_CACHE.clear()
+        _K_CACHE[key] = K
+    return K
+
+
+def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, feature_mode=True, scaling_modifier=1.0,
+           override_color=None, render_mode="RGB", raster_flags=0):
+    """Render the scene.  Background tensor (bg_color) must be on GPU!"""
+    means3D = pc.get_xyz
+    K = _intrinsics(viewpoint_camera, means3D.device)
+    opacity = pc.get_opacity
+    scales = pc.get_scaling * scaling_modifier
+    rotations = pc.get_rotation
+    if feature_mode:
+        colors = pc.get_semantic_feature  # [N, D]
+        sh_degree = None
+        bg_color = bg_color[0].repeat(colors.shape[-1])
+    elif override_color is not None:
+        colors = override_color  # [N, 3]
+        sh_degree = None
+    else:
+        colors = pc.get_features  # [N, K, 3]
+        sh_degree = pc.active_sh_degree
+
+    viewmat = viewpoint_camera.world_view_transform.transpose(0, 1)  # [4, 4]
+    render_colors, render_alphas, info = rasterization(
+        means=means3D, quats=rotations, scales=scales, opacities=opacity.squeeze(-1), colors=colors,
+        viewmats=viewmat[None], Ks=K[None], backgrounds=bg_color[None],
+        width=int(viewpoint_camera.image_width), height=int(viewpoint_camera.image_height),
+        packed=False, sh_degree=sh_degree, render_mode=render_mode, raster_flags=raster_flags)
+
+    # squeeze (not [0]): its backward is a view, [0]'s is a zero-fill + copy of the whole map
+    rendered_image = render_colors.squeeze(0).permute(2, 0, 1)  # [1,H,W,D'] -> [D',H,W]
+    radii = info["radii"].squeeze(0)  # [N,]
+    try:
+        info["means2d"].retain_grad()  # [1, N, 2]
+    except Exception:
+        pass
+    return {"render": rendered_image,
+            "viewspace_points": info["means2d"],
+            "visibility_filter": radii > 0,
+            "radii": radii,
+            "alphas": render_alphas[0, ..., 0],
+            "info": info}

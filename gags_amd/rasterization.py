@@ -1,0 +1,272 @@
+"""`rasterization(...)`: the operator the reference imports from gsplat
+(/root/reference/gaussian_renderer/__init__.py:17,56-70), re-implemented on hand-written
+gfx950 kernels behind the C ABI of include/gags_raster.h.
+
+Same names, argument meaning, return triple and `info` keys as the call the reference makes:
+    render_colors [1,H,W,D'], render_alphas [1,H,W,1], info = rasterization(
+        means=[N,3], quats=[N,4] wxyz, scales=[N,3], opacities=[N], colors=[N,D] | [N,K,3],
+        viewmats=[1,4,4], Ks=[1,3,3], backgrounds=[1,D], width=, height=, packed=False,
+        sh_degree=None|int, render_mode="RGB"|"D"|"ED"|"RGB+D"|"RGB+ED")
+Defaults the reference relies on by not passing them are gsplat's: near_plane=0.01,
+far_plane=1e10, radius_clip=0, eps2d=0.3, tile_size=16, rasterize_mode="classic".
+
+Autograd is split in the same places gsplat splits it, so that `info["means2d"]` is a
+non-leaf tensor callers can `retain_grad()` (gaussian_renderer/__init__.py:75-78):
+    _Project (K1/K2)  ->  [_SH (K3)]  ->  _Rasterize (K4-K10)
+When only `colors` requires grad -- the GAD flow, scene/gaussian_model.py:192-208 -- the
+backward launches the colours-only kernel and nothing else.
+PyTorch supplies device memory, streams and autograd plumbing; all arithmetic is in HIP.
+"""
+import ctypes
+
+import torch
+
+from . import _lib, profiler
+from ._lib import check, ptr
+
+TILE = 16
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("gags_amd.rasterization: all tensors must live on the GPU "
+                               "(there is no CPU path; see oracle/ for the test-only CPU restatement)")
+
+
+def _c(t):
+    return t if (t.is_contiguous() and t.dtype == torch.float32) else t.contiguous().float()
+
+
+class _Project(torch.autograd.Function):
+    """K1 + K4 forward, K2 backward."""
+
+    @staticmethod
+    def forward(ctx, means, quats, scales, viewmat, K, width, height, eps2d, near, far, radius_clip):
+        lib = _lib.load()
+        means, quats, scales, viewmat, K = _c(means), _c(quats), _c(scales), _c(viewmat), _c(K)
+        n = means.shape[0]
+        dev = means.device
+        radii = torch.empty(n, dtype=torch.int32, device=dev)
+        means2d = torch.empty(n, 2, dtype=torch.float32, device=dev)
+        depths = torch.empty(n, dtype=torch.float32, device=dev)
+        conics = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        tiles = torch.empty(n, dtype=torch.int32, device=dev)
+        with profiler.stage("project_fwd"):
+            check(lib.gags_project_fwd(n, ptr(means), ptr(quats), ptr(scales), ptr(viewmat), ptr(K), width, height,
+                                       eps2d, near, far, radius_clip, ptr(radii), ptr(means2d), ptr(depths),
+                                       ptr(conics), ptr(tiles), _stream()), "gags_project_fwd")
+        ctx.save_for_backward(means, quats, scales, viewmat, K, radii, conics)
+        ctx.cfg = (width, height, eps2d)
+        ctx.mark_non_differentiable(radii, tiles)
+        return radii, means2d, depths, conics, tiles
+
+    @staticmethod
+    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, _v_tiles):
+        lib = _lib.load()
+        means, quats, scales, viewmat, K, radii, conics = ctx.saved_tensors
+        width, height, eps2d = ctx.cfg
+        n = means.shape[0]
+        dev = means.device
+        v_means2d = torch.zeros(n, 2, device=dev) if v_means2d is None else _c(v_means2d)
+        v_conics = torch.zeros(n, 3, device=dev) if v_conics is None else _c(v_conics)
+        v_depths = None if v_depths is None else _c(v_depths)
+        v_means = torch.empty(n, 3, device=dev)
+        v_quats = torch.empty(n, 4, device=dev)
+        v_scales = torch.empty(n, 3, device=dev)
+        check(lib.gags_project_bwd(n, ptr(means), ptr(quats), ptr(scales), ptr(viewmat), ptr(K), width, height,
+                                   eps2d, ptr(radii), ptr(conics), ptr(v_means2d), ptr(v_depths), ptr(v_conics),
+                                   ptr(v_means), ptr(v_quats), ptr(v_scales), _stream()), "gags_project_bwd")
+        return v_means, v_quats, v_scales, None, None, None, None, None, None, None, None
+
+
+class _SH(torch.autograd.Function):
+    """K3: SH colour; directions are constants (as in the reference flow, where this branch
+    only runs with frozen geometry or under no_grad)."""
+
+    @staticmethod
+    def forward(ctx, coeffs, means, campos, radii, degree):
+        lib = _lib.load()
+        coeffs, means, campos = _c(coeffs), _c(means), _c(campos)
+        n, kc = coeffs.shape[0], coeffs.shape[1]
+        out = torch.empty(n, 3, device=coeffs.device)
+        check(lib.gags_sh_fwd(n, kc, degree, ptr(means), ptr(campos), ptr(coeffs), ptr(radii), ptr(out), _stream()),
+              "gags_sh_fwd")
+        ctx.save_for_backward(means, campos, radii, out)
+        ctx.cfg = (kc, degree)
+        return out
+
+    @staticmethod
+    def backward(ctx, v_out):
+        lib = _lib.load()
+        means, campos, radii, out = ctx.saved_tensors
+        kc, degree = ctx.cfg
+        n = means.shape[0]
+        v_coeffs = torch.empty(n, kc, 3, device=means.device)
+        check(lib.gags_sh_bwd(n, kc, degree, ptr(means), ptr(campos), ptr(radii), ptr(out), ptr(_c(v_out)),
+                              ptr(v_coeffs), _stream()), "gags_sh_bwd")
+        return v_coeffs, None, None, None, None
+
+
+def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height):
+    """K5-K8 on device.  One host readback (n_isects), as in gsplat.  Returns
+    (isect_ids sorted [I] int64, flatten_ids sorted [I] int32, isect_offsets [th,tw] int32, n_isects)."""
+    lib = _lib.load()
+    st = _stream()
+    dev = means2d.device
+    n = radii.shape[0]
+    tile_w, tile_h = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
+    n_tiles = tile_w * tile_h
+    tile_bits = max(1, (n_tiles - 1).bit_length())
+    cum = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.int32, device=dev)
+    sb = lib.gags_scan_scratch_bytes(n)
+    scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
+    check(lib.gags_cumsum_i32(n, ptr(tiles_per_gauss), ptr(cum), ptr(total), ptr(scratch), sb, st), "gags_cumsum_i32")
+    host = ctypes.c_int32(0)
+    check(lib.gags_read_i32(ptr(total), ctypes.byref(host), st), "gags_read_i32")
+    n_isects = int(host.value)
+    offsets = torch.empty(tile_h, tile_w, dtype=torch.int32, device=dev)
+    ids = torch.empty(max(n_isects, 1), dtype=torch.int64, device=dev)
+    flat = torch.empty(max(n_isects, 1), dtype=torch.int32, device=dev)
+    ids_s = torch.empty_like(ids)
+    flat_s = torch.empty_like(flat)
+    if n_isects > 0:
+        check(lib.gags_tile_emit(n, ptr(means2d), ptr(radii), ptr(depths), ptr(cum), tile_w, tile_h, ptr(ids),
+                                 ptr(flat), st), "gags_tile_emit")
+        ssb = lib.gags_sort_scratch_bytes(n_isects)
+        sscratch = torch.empty(ssb, dtype=torch.uint8, device=dev)
+        check(lib.gags_sort_pairs(n_isects, tile_bits, ptr(ids), ptr(flat), ptr(ids_s), ptr(flat_s), ptr(sscratch),
+                                  ssb, st), "gags_sort_pairs")
+    check(lib.gags_tile_offsets(n_isects, ptr(ids_s), n_tiles, ptr(offsets), st), "gags_tile_offsets")
+    return ids_s[:n_isects], flat_s[:n_isects], offsets, n_isects
+
+
+class _Rasterize(torch.autograd.Function):
+    """K9 forward / K10 backward over pre-binned intersections."""
+
+    @staticmethod
+    def forward(ctx, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, width, height, flags):
+        lib = _lib.load()
+        means2d, conics, colors, opacities = _c(means2d), _c(conics), _c(colors), _c(opacities)
+        backgrounds = None if backgrounds is None else _c(backgrounds)
+        d = colors.shape[1]
+        dev = colors.device
+        n_isects = flatten_ids.shape[0]
+        out = torch.empty(height, width, d, device=dev)
+        alphas = torch.empty(height, width, device=dev)
+        last_ids = torch.empty(height, width, dtype=torch.int32, device=dev)
+        with profiler.stage("raster_fwd"):
+            check(lib.gags_raster_fwd(d, width, height, ptr(means2d), ptr(conics), ptr(opacities), ptr(colors),
+                                      ptr(backgrounds), ptr(offsets), ptr(flatten_ids), n_isects, ptr(out),
+                                      ptr(alphas), ptr(last_ids), flags, _stream()), "gags_raster_fwd")
+        ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, alphas, last_ids)
+        ctx.cfg = (width, height, flags)
+        ctx.mark_non_differentiable(last_ids)
+        return out, alphas, last_ids
+
+    @staticmethod
+    def backward(ctx, v_out, v_alphas, _v_last):
+        lib = _lib.load()
+        means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, alphas, last_ids = ctx.saved_tensors
+        width, height, flags = ctx.cfg
+        n, d = colors.shape
+        dev = colors.device
+        n_isects = flatten_ids.shape[0]
+        need_geom = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[3]
+        v_out = torch.zeros(height, width, d, device=dev) if v_out is None else _c(v_out)
+        v_alphas = None if v_alphas is None else _c(v_alphas)
+        v_colors = torch.zeros(n, d, device=dev)
+        if need_geom:
+            v_opac = torch.zeros(n, device=dev)
+            v_m2d = torch.zeros(n, 2, device=dev)
+            v_con = torch.zeros(n, 3, device=dev)
+            bflags = flags
+        else:
+            v_opac = v_m2d = v_con = None
+            bflags = flags | _lib.GAGS_BWD_COLORS_ONLY
+        with profiler.stage("raster_bwd"):
+            check(lib.gags_raster_bwd(d, width, height, ptr(means2d), ptr(conics), ptr(opacities), ptr(colors),
+                                      ptr(backgrounds), ptr(offsets), ptr(flatten_ids), n_isects, ptr(alphas),
+                                      ptr(last_ids), ptr(v_out), ptr(v_alphas), ptr(v_colors), ptr(v_opac),
+                                      ptr(v_m2d), ptr(v_con), bflags, _stream()), "gags_raster_bwd")
+        v_bg = None
+        if backgrounds is not None and ctx.needs_input_grad[4]:
+            v_bg = ((1.0 - alphas)[..., None] * v_out).sum(dim=(0, 1))
+        return v_m2d, v_con, v_colors, v_opac, v_bg, None, None, None, None, None
+
+
+def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, height,
+                  near_plane=0.01, far_plane=1e10, radius_clip=0.0, eps2d=0.3, sh_degree=None, packed=False,
+                  tile_size=16, backgrounds=None, render_mode="RGB", sparse_grad=False, absgrad=False,
+                  rasterize_mode="classic", channel_chunk=32, distributed=False, camera_model="pinhole",
+                  covars=None, raster_flags=0):
+    """See module docstring.  `channel_chunk` is accepted and ignored: any D is composited in a
+    single pass over the sorted lists (SURVEY A12 shows this is identical per channel)."""
+    if tile_size != TILE:
+        raise NotImplementedError("tile_size must be 16 (the gsplat default the reference relies on)")
+    if rasterize_mode != "classic" or camera_model != "pinhole" or covars is not None or distributed or absgrad:
+        raise NotImplementedError("only the options the reference uses are implemented "
+                                  "(classic mode, pinhole camera, quats+scales)")
+    if render_mode not in ("RGB", "D", "ED", "RGB+D", "RGB+ED"):
+        raise ValueError(f"unknown render_mode {render_mode}")
+    if viewmats.dim() != 3 or viewmats.shape[0] != 1 or Ks.shape[0] != 1:
+        raise NotImplementedError("one camera per call (the reference renders one view per iteration, train.py:134-142)")
+    n = means.shape[0]
+    if quats.shape != (n, 4) or scales.shape != (n, 3) or opacities.shape != (n,):
+        raise ValueError("means [N,3], quats [N,4], scales [N,3], opacities [N] expected")
+    _need_cuda(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds)
+    width, height = int(width), int(height)
+    viewmat, K = viewmats[0], Ks[0]
+
+    radii, means2d, depths, conics, tiles = _Project.apply(means, quats, scales, viewmat, K, width, height,
+                                                           float(eps2d), float(near_plane), float(far_plane),
+                                                           float(radius_clip))
+    # [1,N,2] node callers may retain_grad() on (gaussian_renderer/__init__.py:75-78); the
+    # rasterizer consumes a view of it so its .grad receives d loss / d means2d.
+    means2d_c = means2d[None]
+    means2d = means2d_c[0]
+    if sh_degree is not None:
+        if colors.dim() != 3 or colors.shape[2] != 3:
+            raise ValueError("SH colours must be [N,K,3]")
+        campos = torch.inverse(viewmat.double())[:3, 3].float()
+        cols = _SH.apply(colors, means, campos, radii, int(sh_degree))
+    else:
+        if colors.dim() != 2 or colors.shape[0] != n:
+            raise ValueError("colors must be [N,D] when sh_degree is None")
+        cols = colors
+    bg = None if backgrounds is None else backgrounds.reshape(-1)
+    if render_mode in ("RGB+D", "RGB+ED"):
+        cols = torch.cat([cols, depths[:, None]], dim=-1)
+        if bg is not None:
+            bg = torch.cat([bg, torch.zeros(1, device=bg.device)])
+    elif render_mode in ("D", "ED"):
+        cols = depths[:, None]
+        bg = None if bg is None else torch.zeros(1, device=bg.device)
+
+    with torch.no_grad(), profiler.stage("binning"):
+        isect_ids, flatten_ids, isect_offsets, n_isects = tile_binning(means2d, radii, depths, tiles, width, height)
+
+    out, alphas, last_ids = _Rasterize.apply(means2d, conics, cols, opacities, bg, isect_offsets, flatten_ids,
+                                             width, height, int(raster_flags))
+    if render_mode in ("ED", "RGB+ED"):
+        if out.requires_grad:
+            out = torch.cat([out[..., :-1], out[..., -1:] / alphas[..., None].clamp(min=1e-10)], dim=-1)
+        else:  # K12 in place
+            check(_lib.load().gags_ed_normalize(height * width, out.shape[-1], ptr(out), ptr(alphas), _stream()),
+                  "gags_ed_normalize")
+
+    tile_w, tile_h = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
+    info = {
+        "camera_ids": None, "gaussian_ids": None,
+        "radii": radii[None], "means2d": means2d_c, "depths": depths[None], "conics": conics[None],
+        "opacities": opacities[None], "tile_width": tile_w, "tile_height": tile_h,
+        "tiles_per_gauss": tiles[None], "isect_ids": isect_ids, "flatten_ids": flatten_ids,
+        "isect_offsets": isect_offsets[None], "last_ids": last_ids, "width": width, "height": height,
+        "tile_size": TILE, "n_cameras": 1, "n_isects": n_isects,
+    }
+    return out[None], alphas[None, ..., None], info

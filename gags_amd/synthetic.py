@@ -1,0 +1,95 @@
+"""Deterministic synthetic Gaussians / cameras for tests and bench.py.
+
+There is no dataset or checkpoint access, so the harness counterpart of train.py:134-174
+ draws its inputs here.  The distribution follows SURVEY 8d's intent
+(few-pixel splats: median 3-sigma radius ~7 px and ~4-5 tile intersections per visible
+Gaussian at 1080p, ~5 % of the means off-screen to exercise culling); the scale constant is
+the one that meets that intent (SURVEY's literal `0.004*z_mean` gives ~20 px radii, i.e.
+I/V ~ 13, which contradicts the I ~ 5N the byte model in BASELINE.md assumes).
+
+Named workloads = BASELINE.json `configs`:
+  C1 10k / 256x256 / D=3        C2 500k / 1280x720 / D=128
+  C3 1.5M / 1920x1080 / D=512   (C4 = C3 x 8 yawed views; C5 = 4M / 1080p / 512)
+"""
+import math
+
+import numpy as np
+import torch
+
+from .scene import Camera, GaussianModel, focal2fov
+
+CONFIGS = {
+    "C1": dict(n=10_000, width=256, height=256, d=3),
+    "C2": dict(n=500_000, width=1280, height=720, d=128),
+    "C3": dict(n=1_500_000, width=1920, height=1080, d=512),
+    "C5": dict(n=4_000_000, width=1920, height=1080, d=512),
+}
+
+Z_NEAR, Z_FAR = 2.0, 12.0
+SCALE0 = 0.0009 * 0.5 * (Z_NEAR + Z_FAR)  # world-space median std-dev of a Gaussian axis
+
+
+def make_camera(width, height, view=None, n_views=8, device="cuda"):
+    """Pinhole camera at the origin looking down +z, fx = fy = 0.9 W.  `view` in [0, n_views)
+    yaws it by (view - (n_views-1)/2) * 5 degrees about y (C4's eight cameras); None = no yaw."""
+    fx = fy = 0.9 * width
+    fovx, fovy = focal2fov(fx, width), focal2fov(fy, height)
+    yaw = 0.0 if view is None else math.radians((view - 0.5 * (n_views - 1)) * 5.0)
+    c, s = math.cos(yaw), math.sin(yaw)
+    # camera-to-world rotation; the reference stores R such that W2C[:3,:3] = R^T
+    R = np.array([[c, 0.0, s], [0.0, 1.0, 0.0], [-s, 0.0, c]])
+    T = np.zeros(3)
+    return Camera(R, T, fovx, fovy, width, height, device=device, uid=0 if view is None else view)
+
+
+def make_gaussians(n, d, width, height, seed=0, device="cpu", sh_degree=3, scale0=SCALE0, feature_dtype=torch.float32):
+    """Raw (pre-activation) parameters in the reference layout.  Generated with a generator on
+    `device`; use device='cpu' wherever CPU/GPU agreement matters (tests), 'cuda' for C3-size."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+
+    def rnd(*shape):
+        return torch.randn(*shape, generator=g, device=device)
+
+    def uni(*shape):
+        return torch.rand(*shape, generator=g, device=device)
+
+    fx = 0.9 * width
+    tanx, tany = 0.5 * width / fx, 0.5 * height / fx
+    z = Z_NEAR + (Z_FAR - Z_NEAR) * uni(n)
+    x = (2 * uni(n) - 1) * 1.05 * z * tanx
+    y = (2 * uni(n) - 1) * 1.05 * z * tany
+    xyz = torch.stack([x, y, z], dim=1)
+    scaling_log = math.log(scale0) + 0.5 * rnd(n, 3)
+    rotation = rnd(n, 4)
+    opacity_logit = 1.5 * rnd(n, 1)
+    f_dc = rnd(n, 1, 3)
+    f_rest = 0.1 * rnd(n, (sh_degree + 1) ** 2 - 1, 3)
+    feat = (rnd(n, d) / math.sqrt(d)).to(feature_dtype) if d > 0 else None
+    return dict(xyz=xyz, scaling_log=scaling_log, rotation=rotation, opacity_logit=opacity_logit,
+                features_dc=f_dc, features_rest=f_rest, semantic_feature=feat)
+
+
+def make_model(n, d, width, height, seed=0, device="cuda", gen_device=None, sh_degree=3, scale0=SCALE0):
+    p = make_gaussians(n, d, width, height, seed=seed, device=gen_device or "cpu", sh_degree=sh_degree, scale0=scale0)
+    p = {k: (v.to(device) if v is not None else None) for k, v in p.items()}
+    return GaussianModel.from_tensors(p["xyz"], p["scaling_log"], p["rotation"], p["opacity_logit"],
+                                      p["features_dc"], p["features_rest"], p["semantic_feature"], sh_degree=sh_degree)
+
+
+def make_cotangent(d, height, width, seed=1, device="cpu"):
+    """Fixed random cotangent G ~ N(0,1) of the [D,H,W] render: loss = (render * G).sum()."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    return torch.randn(height, width, d, generator=g, device=device).permute(2, 0, 1)
+
+
+def camera_matrices(cam):
+    """(viewmat [4,4] row-major W2C, K [3,3]) exactly as gaussian_renderer/__init__.py:27-38,55."""
+    tanfovx = math.tan(cam.FoVx * 0.5)
+    tanfovy = math.tan(cam.FoVy * 0.5)
+    fx = cam.image_width / (2 * tanfovx)
+    fy = cam.image_height / (2 * tanfovy)
+    K = np.array([[fx, 0, cam.image_width / 2.0], [0, fy, cam.image_height / 2.0], [0, 0, 1]], dtype=np.float32)
+    viewmat = cam.world_view_transform.transpose(0, 1).contiguous()
+    return viewmat, K

@@ -1,0 +1,148 @@
+/*
+ * gags_raster.h -- C ABI of the MI355X-native GAGS feature rasterizer (libgags_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of WHU-USI3DV/GAGS: the operator
+ *     gsplat.rasterization(means, quats, scales, opacities, colors, viewmats, Ks,
+ *                          backgrounds, width, height, packed=False, sh_degree, render_mode)
+ * exactly as the reference calls it at gaussian_renderer/__init__.py:56-70, plus the
+ * backward pass autograd runs for it under train.py:174 (`loss.backward()`).
+ * Each entry point below is one stage of that operator; the stage <-> reference mapping
+ *  is given per function.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes; no torch / C++ types cross the boundary.
+ *  - every pointer is a DEVICE pointer unless its name ends in _host.
+ *  - the caller owns all memory (outputs and scratch); nothing here allocates or frees
+ *    caller-visible memory, and there is no global mutable state (re-entrant per stream).
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls only
+ *    enqueue work; they never synchronize, except gags_read_i32 which is the one
+ *    explicit device->host readback (n_isects), mirroring gsplat's own sync.
+ *  - return value: GAGS_OK (0) or a negative GAGS_E* code; gags_strerror() names it.
+ *  - all floating point is fp32; indices are int32; intersection keys are int64
+ *    (tile_id << 32 | float_bits(depth)), as in the reference's rasterizer.
+ *  - tile size is fixed at 16 (GAGS_TILE), the gsplat default the reference relies on.
+ */
+#ifndef GAGS_RASTER_H
+#define GAGS_RASTER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GAGS_TILE 16
+
+#define GAGS_OK 0
+#define GAGS_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported D) */
+#define GAGS_ELAUNCH (-2)  /* HIP launch / runtime error (hipGetLastError != success) */
+#define GAGS_ESCRATCH (-3) /* scratch buffer too small */
+#define GAGS_ENODEV (-4)   /* no usable gfx950 device */
+
+/* raster flags */
+#define GAGS_BWD_COLORS_ONLY 1 /* backward: only v_colors (all the GAD flow consumes) */
+#define GAGS_FWD_NO_MFMA 2     /* force the VALU kernels even when D allows the MFMA path */
+
+int gags_abi_version(void);
+const char *gags_strerror(int code);
+/* number of HIP devices visible, or a negative error; never throws */
+int gags_device_count(void);
+
+/* K1 + K4: fused projection and tile counting.
+ * Replaces the projection stage of gsplat.rasterization reached from
+ * gaussian_renderer/__init__.py:56-63 (means, quats wxyz, scales, viewmats, Ks) and the
+ * first pass of its tile intersection.  viewmat: row-major 4x4 world-to-camera (the
+ * reference's world_view_transform.transpose(0,1), :55); K: row-major 3x3 (:31-38).
+ * Outputs: radii[N] (0 = culled), means2d[N,2], depths[N], conics[N,3],
+ * tiles_per_gauss[N].  Culled Gaussians get zeros everywhere. */
+int gags_project_fwd(int n, const float *means, const float *quats, const float *scales,
+                     const float *viewmat, const float *K, int width, int height,
+                     float eps2d, float near_plane, float far_plane, float radius_clip,
+                     int32_t *radii, float *means2d, float *depths, float *conics,
+                     int32_t *tiles_per_gauss, void *stream);
+
+/* K5: inclusive prefix sum of tiles_per_gauss -> cum[N]; the grand total (n_isects) is
+ * also written to total[0].  scratch: gags_scan_scratch_bytes(n) bytes. */
+int64_t gags_scan_scratch_bytes(int n);
+int gags_cumsum_i32(int n, const int32_t *in, int32_t *cum, int32_t *total,
+                    void *scratch, int64_t scratch_bytes, void *stream);
+
+/* the single device->host readback of the path (n_isects); synchronizes `stream`. */
+int gags_read_i32(const int32_t *src, int32_t *dst_host, void *stream);
+
+/* K6: emit (key, value) per (Gaussian, tile) intersection in Gaussian-major order.
+ * isect_ids[n_isects] int64, flatten_ids[n_isects] int32. */
+int gags_tile_emit(int n, const float *means2d, const int32_t *radii, const float *depths,
+                   const int32_t *cum, int tile_w, int tile_h,
+                   int64_t *isect_ids, int32_t *flatten_ids, void *stream);
+
+/* K7: stable radix sort of the pairs on key bits [0, 32 + tile_bits).
+ * scratch: gags_sort_scratch_bytes(n_isects) bytes. */
+int64_t gags_sort_scratch_bytes(int64_t n_isects);
+int gags_sort_pairs(int64_t n_isects, int tile_bits,
+                    const int64_t *keys_in, const int32_t *vals_in,
+                    int64_t *keys_out, int32_t *vals_out,
+                    void *scratch, int64_t scratch_bytes, void *stream);
+
+/* K8: isect_offsets[tile_h*tile_w] = first sorted index of each tile. */
+int gags_tile_offsets(int64_t n_isects, const int64_t *sorted_ids, int n_tiles,
+                      int32_t *isect_offsets, void *stream);
+
+/* K9 (+K11): rasterize forward, any D >= 1 in ONE pass over the sorted lists (no 32-wide
+ * re-walks).  Replaces the compositing stage of gsplat.rasterization for
+ * colors[N,D] / backgrounds[D] (gaussian_renderer/__init__.py:61,64).
+ * backgrounds may be NULL.  Outputs render_colors[H,W,D], render_alphas[H,W],
+ * last_ids[H,W] (sorted index of the last blended Gaussian per pixel). */
+int gags_raster_fwd(int d, int width, int height, const float *means2d, const float *conics,
+                    const float *opacities, const float *colors, const float *backgrounds,
+                    const int32_t *isect_offsets, const int32_t *flatten_ids, int64_t n_isects,
+                    float *render_colors, float *render_alphas, int32_t *last_ids,
+                    int flags, void *stream);
+
+/* K10: rasterize backward (what autograd runs under train.py:174).
+ * v_colors[N,D] (and, unless GAGS_BWD_COLORS_ONLY, v_opacities[N], v_means2d[N,2],
+ * v_conics[N,3]) must be zero-filled by the caller; results are accumulated with
+ * float atomics.  v_render_alphas may be NULL (treated as zeros). */
+int gags_raster_bwd(int d, int width, int height, const float *means2d, const float *conics,
+                    const float *opacities, const float *colors, const float *backgrounds,
+                    const int32_t *isect_offsets, const int32_t *flatten_ids, int64_t n_isects,
+                    const float *render_alphas, const int32_t *last_ids,
+                    const float *v_render_colors, const float *v_render_alphas,
+                    float *v_colors, float *v_opacities, float *v_means2d, float *v_conics,
+                    int flags, void *stream);
+
+/* Diagnostics (roofline model): counts[0] += (pixel,Gaussian) pairs evaluated
+ * before each pixel's stop, counts[1] += pairs blended.  counts[2] int64, zeroed by caller. */
+int gags_raster_stats(int width, int height, const float *means2d, const float *conics,
+                      const float *opacities, const int32_t *isect_offsets, const int32_t *flatten_ids,
+                      int64_t n_isects, int64_t *counts, void *stream);
+
+/* K2: projection backward: chain rule of gags_project_fwd for Gaussians with radii>0.
+ * Inputs v_means2d[N,2], v_depths[N] (may be NULL), v_conics[N,3];
+ * outputs (overwritten) v_means[N,3], v_quats[N,4], v_scales[N,3]. */
+int gags_project_bwd(int n, const float *means, const float *quats, const float *scales,
+                     const float *viewmat, const float *K, int width, int height, float eps2d,
+                     const int32_t *radii, const float *conics,
+                     const float *v_means2d, const float *v_depths, const float *v_conics,
+                     float *v_means, float *v_quats, float *v_scales, void *stream);
+
+/* K3: spherical-harmonics colour, used when feature_mode=False and no override colour
+ * (gaussian_renderer/__init__.py:51-53).  coeffs[N,kc,3], campos[3] (device),
+ * out[N,3] = max(SH(dir) + 0.5, 0) where radii>0, zeros elsewhere.  Basis and signs as
+ * utils/sh_utils.py:57-112. */
+int gags_sh_fwd(int n, int kc, int degree, const float *means, const float *campos,
+                const float *coeffs, const int32_t *radii, float *out, void *stream);
+/* v_coeffs[N,kc,3] overwritten; directions are treated as constants (geometry frozen). */
+int gags_sh_bwd(int n, int kc, int degree, const float *means, const float *campos,
+                const int32_t *radii, const float *colors_out, const float *v_out,
+                float *v_coeffs, void *stream);
+
+/* K12: expected-depth normalisation of the last channel: c[...,d-1] /= max(alpha,1e-10)
+ * (render_mode "RGB+ED", the only consumer is render.py:118,127-133). */
+int gags_ed_normalize(int64_t n_pix, int d, float *render_colors, const float *render_alphas,
+                      void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAGS_RASTER_H */

@@ -1,0 +1,182 @@
+"""HIP path vs CPU oracle on identical seeded inputs, through the C ABI (via the Python
+mirror of gsplat.rasterization).  Index tensors (radii, tiles_per_gauss, isect_ids,
+flatten_ids, isect_offsets, last_ids) must be BIT-EXACT; forward renders are bit-exact too on
+the fp32 paths (same op order, explicit exp polynomial, fmaf accumulation in sorted order);
+gradients are accumulated with float atomics, so they are compared with rel-L2 <= 2e-5
+against the oracle's double-accumulated sums."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_l2, scene_arrays, to_dev
+
+pytestmark = pytest.mark.gpu
+
+GRAD_TOL = 2e-5
+
+
+def _run_gpu(s, width, height, colors, bg, render_mode="RGB", sh_degree=None, need_geom=False, flags=0,
+             v_out=None, v_alpha=None):
+    from gags_amd.rasterization import rasterization
+    means, quats, scales = to_dev(s["means"]), to_dev(s["quats"]), to_dev(s["scales"])
+    opac, cols = to_dev(s["opacities"]), to_dev(colors)
+    leaves = [cols]
+    if need_geom:
+        leaves += [means, quats, scales, opac]
+    for t in leaves:
+        t.requires_grad_(True)
+    out, alphas, info = rasterization(means, quats, scales, opac, cols, to_dev(s["viewmat"])[None],
+                                      to_dev(s["K"])[None], width, height,
+                                      backgrounds=None if bg is None else to_dev(bg)[None],
+                                      sh_degree=sh_degree, render_mode=render_mode, raster_flags=flags)
+    grads = None
+    if v_out is not None:
+        loss = (out[0] * to_dev(v_out)).sum()
+        if v_alpha is not None:
+            loss = loss + (alphas[0, ..., 0] * to_dev(v_alpha)).sum()
+        if need_geom:
+            info["means2d"].retain_grad()
+        loss.backward()
+        grads = dict(colors=cols.grad.cpu().numpy())
+        if need_geom:
+            grads.update(means=means.grad.cpu().numpy(), quats=quats.grad.cpu().numpy(),
+                         scales=scales.grad.cpu().numpy(), opacities=opac.grad.cpu().numpy(),
+                         means2d=info["means2d"].grad[0].cpu().numpy())
+    torch.cuda.synchronize()
+    return out[0].detach().cpu().numpy(), alphas[0, ..., 0].detach().cpu().numpy(), info, grads
+
+
+def _check_indices(info, oinfo):
+    np.testing.assert_array_equal(info["radii"][0].cpu().numpy(), oinfo["radii"])
+    np.testing.assert_array_equal(info["tiles_per_gauss"][0].cpu().numpy(), oinfo["tiles_per_gauss"])
+    assert info["n_isects"] == oinfo["n_isects"]
+    np.testing.assert_array_equal(info["isect_ids"].cpu().numpy(), oinfo["isect_ids"])
+    np.testing.assert_array_equal(info["flatten_ids"].cpu().numpy(), oinfo["flatten_ids"])
+    np.testing.assert_array_equal(info["isect_offsets"][0].cpu().numpy(), oinfo["isect_offsets"])
+    np.testing.assert_array_equal(info["means2d"][0].detach().cpu().numpy(), oinfo["means2d"])
+    np.testing.assert_array_equal(info["conics"][0].detach().cpu().numpy(), oinfo["conics"])
+    np.testing.assert_array_equal(info["depths"][0].detach().cpu().numpy(), oinfo["depths"])
+    np.testing.assert_array_equal(info["last_ids"].cpu().numpy(), oinfo["last_ids"])
+
+
+@pytest.mark.parametrize("n,w,h,d,seed,view,mult,bgv", [
+    (3000, 200, 152, 16, 0, None, 4.0, 0.0),   # reference default width (train.py:68)
+    (3000, 200, 152, 3, 1, 2, 4.0, 1.0),       # RGB-like, white background, yawed camera
+    (2000, 97, 61, 33, 2, 5, 6.0, 0.3),        # ragged image (not a multiple of 16), D=33 -> 2 chunks
+    (5000, 256, 256, 4, 3, None, 2.0, None),   # no background
+    (1500, 64, 48, 1, 4, 0, 8.0, 0.0),
+    (4000, 160, 120, 64, 5, None, 4.0, 0.5),
+])
+def test_forward_and_colour_grad(oracle, n, w, h, d, seed, view, mult, bgv):
+    s = scene_arrays(n, d, w, h, seed=seed, view=view, scale_mult=mult)
+    bg = None if bgv is None else np.full(d, bgv, np.float32)
+    rng = np.random.default_rng(seed + 100)
+    v_out = rng.standard_normal((h, w, d)).astype(np.float32)
+    o_out, o_alpha, oinfo = oracle.rasterization(s["means"], s["quats"], s["scales"], s["opacities"], s["colors"],
+                                                 s["viewmat"], s["K"], bg, w, h)
+    out, alpha, info, grads = _run_gpu(s, w, h, s["colors"], bg, v_out=v_out)
+    _check_indices(info, oinfo)
+    np.testing.assert_array_equal(alpha, o_alpha)
+    np.testing.assert_array_equal(out, o_out)  # bit-exact forward
+    o_vc, _, _, _ = oracle.raster_bwd(oinfo["means2d"], oinfo["conics"], s["opacities"], s["colors"], bg, w, h,
+                                      oinfo["isect_offsets"], oinfo["flatten_ids"], o_alpha, oinfo["last_ids"],
+                                      v_out, None, colors_only=True)
+    assert rel_l2(grads["colors"], o_vc) <= GRAD_TOL
+
+
+@pytest.mark.parametrize("n,w,h,d,seed,view", [(2500, 128, 96, 16, 7, 3), (2000, 100, 70, 3, 8, None)])
+def test_full_backward(oracle, n, w, h, d, seed, view):
+    s = scene_arrays(n, d, w, h, seed=seed, view=view, scale_mult=5.0)
+    bg = np.full(d, 0.25, np.float32)
+    rng = np.random.default_rng(seed)
+    v_out = rng.standard_normal((h, w, d)).astype(np.float32)
+    v_alpha = rng.standard_normal((h, w)).astype(np.float32)
+    o_out, o_alpha, oinfo = oracle.rasterization(s["means"], s["quats"], s["scales"], s["opacities"], s["colors"],
+                                                 s["viewmat"], s["K"], bg, w, h)
+    o_vc, o_vo, o_vm2, o_vcon = oracle.raster_bwd(oinfo["means2d"], oinfo["conics"], s["opacities"], s["colors"], bg,
+                                                  w, h, oinfo["isect_offsets"], oinfo["flatten_ids"], o_alpha,
+                                                  oinfo["last_ids"], v_out, v_alpha)
+    o_vmeans, o_vq, o_vs = oracle.project_bwd(s["means"], s["quats"], s["scales"], s["viewmat"], s["K"], w, h,
+                                              oinfo["radii"], o_vm2, None, o_vcon)
+    out, alpha, info, g = _run_gpu(s, w, h, s["colors"], bg, need_geom=True, v_out=v_out, v_alpha=v_alpha)
+    np.testing.assert_array_equal(out, o_out)
+    assert rel_l2(g["colors"], o_vc) <= GRAD_TOL
+    assert rel_l2(g["opacities"], o_vo) <= 1e-4
+    assert rel_l2(g["means2d"], o_vm2) <= 1e-4
+    assert rel_l2(g["means"], o_vmeans) <= 1e-4
+    assert rel_l2(g["quats"], o_vq) <= 1e-4
+    assert rel_l2(g["scales"], o_vs) <= 1e-4
+
+
+def test_render_modes_and_sh(oracle):
+    n, w, h = 3000, 160, 120
+    s = scene_arrays(n, 3, w, h, seed=11, view=1, scale_mult=4.0)
+    bg = np.array([0.1, 0.2, 0.3], np.float32)
+    # RGB+ED through explicit colours
+    o_out, o_alpha, oinfo = oracle.rasterization(s["means"], s["quats"], s["scales"], s["opacities"], s["colors"],
+                                                 s["viewmat"], s["K"], bg, w, h, render_mode="RGB+ED")
+    out, alpha, info, _ = _run_gpu(s, w, h, s["colors"], bg, render_mode="RGB+ED")
+    assert out.shape == (h, w, 4)
+    np.testing.assert_array_equal(out[..., :3], o_out[..., :3])
+    np.testing.assert_allclose(out[..., 3], o_out[..., 3], rtol=1e-6, atol=0)
+    # SH colours, degree 3
+    o_out, o_alpha, oinfo = oracle.rasterization(s["means"], s["quats"], s["scales"], s["opacities"], s["sh"],
+                                                 s["viewmat"], s["K"], bg, w, h, sh_degree=3)
+    out, alpha, info, _ = _run_gpu(s, w, h, s["sh"], bg, sh_degree=3)
+    np.testing.assert_array_equal(alpha, o_alpha)
+    assert rel_l2(out, o_out) <= 1e-6
+
+
+def test_empty_and_culled(oracle):
+    from gags_amd.rasterization import rasterization
+    w, h, d = 64, 48, 8
+    s = scene_arrays(50, d, w, h, seed=3)
+    means = s["means"].copy()
+    means[:, 2] = -5.0  # everything behind the camera -> all culled, zero intersections
+    s2 = dict(s, means=means)
+    bg = np.full(d, 0.5, np.float32)
+    out, alpha, info, grads = _run_gpu(s2, w, h, s["colors"], bg, v_out=np.ones((h, w, d), np.float32))
+    assert info["n_isects"] == 0
+    assert (info["radii"].cpu().numpy() == 0).all()
+    np.testing.assert_array_equal(out, np.broadcast_to(bg, (h, w, d)))
+    np.testing.assert_array_equal(alpha, np.zeros((h, w), np.float32))
+    assert np.abs(grads["colors"]).max() == 0.0
+    with pytest.raises(RuntimeError):
+        rasterization(torch.zeros(4, 3), torch.zeros(4, 4), torch.zeros(4, 3), torch.zeros(4), torch.zeros(4, 3),
+                      torch.eye(4)[None], torch.eye(3)[None], 16, 16)  # CPU tensors: no fallback, must raise
+
+
+def test_render_boundary_matches_reference_contract(oracle):
+    """render(...) keeps the reference's signature, reads and return dict
+    (gaussian_renderer/__init__.py:19-85) and equals the oracle on the same inputs."""
+    from gags_amd import synthetic as syn
+    from gags_amd.gaussian_renderer import render
+    w, h, n, d = 176, 130, 4000, 16
+    cam = syn.make_camera(w, h, view=6, device="cuda")
+    pc = syn.make_model(n, d, w, h, seed=21, device="cuda", scale0=syn.SCALE0 * 4)
+    pc.training_setup()
+    bg = torch.tensor([1.0, 1.0, 1.0], device="cuda")
+    pkg = render(cam, pc, None, bg, feature_mode=True)
+    assert pkg["render"].shape == (d, h, w)
+    assert pkg["viewspace_points"].shape == (1, n, 2)
+    assert pkg["visibility_filter"].dtype == torch.bool and pkg["radii"].dtype == torch.int32
+    G = syn.make_cotangent(d, h, w, seed=1).cuda()
+    (pkg["render"] * G).sum().backward()
+    vm, K = syn.camera_matrices(cam)
+    o_out, o_alpha, oinfo = oracle.rasterization(
+        pc.get_xyz.detach().cpu().numpy(), pc.get_rotation.detach().cpu().numpy(),
+        pc.get_scaling.detach().cpu().numpy(), pc.get_opacity.detach().cpu().numpy().reshape(-1),
+        pc.get_semantic_feature.detach().cpu().numpy(), vm.cpu().numpy(), K, np.ones(d, np.float32), w, h)
+    np.testing.assert_array_equal(pkg["radii"].cpu().numpy(), oinfo["radii"])
+    np.testing.assert_array_equal(pkg["render"].permute(1, 2, 0).detach().cpu().numpy(), o_out)
+    o_vc, _, _, _ = oracle.raster_bwd(oinfo["means2d"], oinfo["conics"], oinfo["opacities"], oinfo["colors"],
+                                      np.ones(d, np.float32), w, h, oinfo["isect_offsets"], oinfo["flatten_ids"],
+                                      o_alpha, oinfo["last_ids"], G.permute(1, 2, 0).cpu().numpy(), None,
+                                      colors_only=True)
+    assert rel_l2(pc._semantic_feature.grad.cpu().numpy(), o_vc) <= GRAD_TOL
+    # RGB branches: override colour and SH
+    pkg2 = render(cam, pc, None, bg, feature_mode=False, override_color=torch.rand(n, 3, device="cuda"))
+    assert pkg2["render"].shape == (3, h, w)
+    with torch.no_grad():
+        pkg3 = render(cam, pc, None, bg, feature_mode=False, render_mode="RGB+ED")
+    assert pkg3["render"].shape == (4, h, w)
