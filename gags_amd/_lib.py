@@ -7,6 +7,13 @@ import ctypes
 import os
 import subprocess
 
+# torch must be imported BEFORE libgags_hip.so is dlopen'ed: the torch wheel bundles its own
+# libamdhip64.so (soname libamdhip64.so.7) and resolves it by path.  If our library pulled in
+# /opt/rocm's copy first, the process would hold two HIP runtimes and every launch on a torch
+# pointer/stream would fail.  Loaded in this order, the dynamic linker binds our DT_NEEDED
+# libamdhip64.so.7 to the runtime torch already loaded.
+import torch  # noqa: F401  (load order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libgags_hip.so")

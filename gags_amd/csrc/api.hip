@@ -17,6 +17,7 @@ extern "C" int gags_raster_fwd(int d, int width, int height, const float *means2
                                float *render_colors, float *render_alphas, int32_t *last_ids, int flags,
                                void *stream)
 {
+    GAGS_CLEAR_ERR();
     (void)flags;
     if (d <= 0 || width <= 0 || height <= 0 || n_isects < 0 || n_isects >= (1ll << 31)) return GAGS_EINVAL;
     if (!isect_offsets || !render_colors || !render_alphas || !last_ids) return GAGS_EINVAL;
@@ -33,6 +34,7 @@ extern "C" int gags_raster_bwd(int d, int width, int height, const float *means2
                                const float *v_render_alphas, float *v_colors, float *v_opacities, float *v_means2d,
                                float *v_conics, int flags, void *stream)
 {
+    GAGS_CLEAR_ERR();
     if (d <= 0 || width <= 0 || height <= 0 || n_isects < 0 || n_isects >= (1ll << 31)) return GAGS_EINVAL;
     if (n_isects == 0) return GAGS_OK;
     if (!means2d || !conics || !opacities || !colors || !isect_offsets || !flatten_ids || !render_alphas ||

@@ -78,6 +78,7 @@ extern "C" const char *gags_strerror(int code)
 
 extern "C" int gags_device_count(void)
 {
+    GAGS_CLEAR_ERR();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return GAGS_ENODEV;
     return n;
@@ -91,6 +92,7 @@ extern "C" int64_t gags_scan_scratch_bytes(int n)
 extern "C" int gags_cumsum_i32(int n, const int32_t *in, int32_t *cum, int32_t *total, void *scratch,
                                int64_t scratch_bytes, void *stream)
 {
+    GAGS_CLEAR_ERR();
     if (n < 0) return GAGS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) {
@@ -107,6 +109,7 @@ extern "C" int gags_cumsum_i32(int n, const int32_t *in, int32_t *cum, int32_t *
 
 extern "C" int gags_read_i32(const int32_t *src, int32_t *dst_host, void *stream)
 {
+    GAGS_CLEAR_ERR();
     if (!src || !dst_host) return GAGS_EINVAL;
     if (hipMemcpyAsync(dst_host, src, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess)
         return GAGS_ELAUNCH;
@@ -118,6 +121,7 @@ extern "C" int gags_tile_emit(int n, const float *means2d, const int32_t *radii,
                               const int32_t *cum, int tile_w, int tile_h, int64_t *isect_ids,
                               int32_t *flatten_ids, void *stream)
 {
+    GAGS_CLEAR_ERR();
     if (n < 0 || tile_w <= 0 || tile_h <= 0) return GAGS_EINVAL;
     if (n == 0) return GAGS_OK;
     if (!means2d || !radii || !depths || !cum || !isect_ids || !flatten_ids) return GAGS_EINVAL;
@@ -130,6 +134,7 @@ extern "C" int gags_tile_emit(int n, const float *means2d, const int32_t *radii,
 extern "C" int gags_tile_offsets(int64_t n_isects, const int64_t *sorted_ids, int n_tiles, int32_t *isect_offsets,
                                  void *stream)
 {
+    GAGS_CLEAR_ERR();
     if (n_isects < 0 || n_tiles <= 0 || !isect_offsets) return GAGS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (n_isects == 0) {
@@ -147,6 +152,7 @@ extern "C" int gags_tile_offsets(int64_t n_isects, const int64_t *sorted_ids, in
 extern "C" int gags_ed_normalize(int64_t n_pix, int d, float *render_colors, const float *render_alphas,
                                  void *stream)
 {
+    GAGS_CLEAR_ERR();
     if (n_pix < 0 || d <= 0) return GAGS_EINVAL;
     if (n_pix == 0) return GAGS_OK;
     if (!render_colors || !render_alphas) return GAGS_EINVAL;

@@ -12,6 +12,10 @@
 #define GAGS_ALPHA_MIN (1.0f / 255.0f)
 #define GAGS_T_STOP 1e-4f
 
+// torch (or any other HIP user in the process) may leave a benign sticky error behind;
+// clear it on entry so that GAGS_CHECK_LAUNCH reports only our own launches.
+#define GAGS_CLEAR_ERR() (void)hipGetLastError()
+
 #define GAGS_CHECK_LAUNCH()                       \
     do {                                          \
         hipError_t e__ = hipGetLastError();       \

@@ -136,6 +136,7 @@ extern "C" int gags_project_fwd(int n, const float *means, const float *quats, c
                                 int32_t *radii, float *means2d, float *depths, float *conics,
                                 int32_t *tiles_per_gauss, void *stream)
 {
+    GAGS_CLEAR_ERR();
     if (n < 0 || width <= 0 || height <= 0) return GAGS_EINVAL;
     if (n == 0) return GAGS_OK;
     if (!means || !quats || !scales || !viewmat || !K || !radii || !means2d || !depths || !conics ||
@@ -280,6 +281,7 @@ extern "C" int gags_project_bwd(int n, const float *means, const float *quats, c
                                 const float *v_depths, const float *v_conics, float *v_means, float *v_quats,
                                 float *v_scales, void *stream)
 {
+    GAGS_CLEAR_ERR();
     (void)conics;  // recomputed in-kernel with the forward's operation order
     if (n < 0 || width <= 0 || height <= 0) return GAGS_EINVAL;
     if (n == 0) return GAGS_OK;

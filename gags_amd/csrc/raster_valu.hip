@@ -354,6 +354,7 @@ int gags_raster_fwd_valu(int d, int width, int height, const float *means2d, con
                          const int32_t *offsets, const int32_t *flat, int n_isects, float *out, float *alphas,
                          int32_t *last_ids, hipStream_t st)
 {
+    GAGS_CLEAR_ERR();
 #define ARGS d, width, height, means2d, conics, opacities, colors, backgrounds, offsets, flat, n_isects, out, alphas, last_ids, st
     if (d <= 4) return launch_fwd<4>(ARGS);
     if (d <= 16) return launch_fwd<16>(ARGS);
@@ -367,6 +368,7 @@ int gags_raster_bwd_valu(int d, int width, int height, const float *means2d, con
                          const int32_t *last_ids, const float *v_out, const float *v_alpha, float *v_colors,
                          float *v_opac, float *v_m2d, float *v_con, bool geom, hipStream_t st)
 {
+    GAGS_CLEAR_ERR();
 #define ARGS d, width, height, means2d, conics, opacities, colors, backgrounds, offsets, flat, n_isects, alphas, last_ids, v_out, v_alpha, v_colors, v_opac, v_m2d, v_con, st
     if (geom) {
         if (d <= 4) return launch_bwd<4, true>(ARGS);
@@ -383,6 +385,7 @@ extern "C" int gags_raster_stats(int width, int height, const float *means2d, co
                                  const float *opacities, const int32_t *isect_offsets, const int32_t *flatten_ids,
                                  int64_t n_isects, int64_t *counts, void *stream)
 {
+    GAGS_CLEAR_ERR();
     if (width <= 0 || height <= 0 || n_isects < 0 || n_isects >= (1ll << 31) || !isect_offsets || !counts)
         return GAGS_EINVAL;
     if (n_isects == 0) return GAGS_OK;

@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(int n, int kc, int deg, con
 extern "C" int gags_sh_fwd(int n, int kc, int degree, const float *means, const float *campos, const float *coeffs,
                            const int32_t *radii, float *out, void *stream)
 {
+    GAGS_CLEAR_ERR();
     if (n < 0 || degree < 0 || degree > 3 || kc < (degree + 1) * (degree + 1)) return GAGS_EINVAL;
     if (n == 0) return GAGS_OK;
     if (!means || !campos || !coeffs || !out) return GAGS_EINVAL;
@@ -104,6 +105,7 @@ extern "C" int gags_sh_fwd(int n, int kc, int degree, const float *means, const 
 extern "C" int gags_sh_bwd(int n, int kc, int degree, const float *means, const float *campos, const int32_t *radii,
                            const float *colors_out, const float *v_out, float *v_coeffs, void *stream)
 {
+    GAGS_CLEAR_ERR();
     if (n < 0 || degree < 0 || degree > 3 || kc < (degree + 1) * (degree + 1)) return GAGS_EINVAL;
     if (n == 0) return GAGS_OK;
     if (!means || !campos || !colors_out || !v_out || !v_coeffs) return GAGS_EINVAL;

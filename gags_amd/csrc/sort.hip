@@ -123,6 +123,7 @@ extern "C" int gags_sort_pairs(int64_t n, int tile_bits, const int64_t *keys_in,
                                int64_t *keys_out, int32_t *vals_out, void *scratch, int64_t scratch_bytes,
                                void *stream)
 {
+    GAGS_CLEAR_ERR();
     if (n < 0 || tile_bits < 0 || tile_bits > 31) return GAGS_EINVAL;
     if (n == 0) return GAGS_OK;
     if (n >= (1ll << 31)) return GAGS_EINVAL;
