@@ -11,6 +11,15 @@ int gags_raster_bwd_valu(int d, int width, int height, const float *means2d, con
                          const int32_t *last_ids, const float *v_out, const float *v_alpha, float *v_colors,
                          float *v_opac, float *v_m2d, float *v_con, bool geom, hipStream_t st);
 
+int gags_raster_fwd_mfma(int d, int width, int height, const float *means2d, const float *conics,
+                         const float *opacities, const float *colors, const float *backgrounds,
+                         const int32_t *offsets, const int32_t *flat, int n_isects, float *out, float *alphas,
+                         int32_t *last_ids, hipStream_t st);
+
+int gags_raster_bwd_colors_mfma(int d, int width, int height, const float *means2d, const float *conics,
+                                const float *opacities, const int32_t *offsets, const int32_t *flat, int n_isects,
+                                const float *v_out, float *v_colors, hipStream_t st);
+
 extern "C" int gags_raster_fwd(int d, int width, int height, const float *means2d, const float *conics,
                                const float *opacities, const float *colors, const float *backgrounds,
                                const int32_t *isect_offsets, const int32_t *flatten_ids, int64_t n_isects,
@@ -18,10 +27,15 @@ extern "C" int gags_raster_fwd(int d, int width, int height, const float *means2
                                void *stream)
 {
     GAGS_CLEAR_ERR();
-    (void)flags;
     if (d <= 0 || width <= 0 || height <= 0 || n_isects < 0 || n_isects >= (1ll << 31)) return GAGS_EINVAL;
     if (!isect_offsets || !render_colors || !render_alphas || !last_ids) return GAGS_EINVAL;
     if (n_isects > 0 && (!means2d || !conics || !opacities || !colors || !flatten_ids)) return GAGS_EINVAL;
+    if (!(flags & GAGS_FWD_NO_MFMA)) {
+        const int rc = gags_raster_fwd_mfma(d, width, height, means2d, conics, opacities, colors, backgrounds,
+                                            isect_offsets, flatten_ids, (int)n_isects, render_colors, render_alphas,
+                                            last_ids, (hipStream_t)stream);
+        if (rc != 1) return rc;  // taken (GAGS_OK) or failed (<0); 1 = width not eligible
+    }
     return gags_raster_fwd_valu(d, width, height, means2d, conics, opacities, colors, backgrounds, isect_offsets,
                                 flatten_ids, (int)n_isects, render_colors, render_alphas, last_ids,
                                 (hipStream_t)stream);
@@ -42,6 +56,12 @@ extern "C" int gags_raster_bwd(int d, int width, int height, const float *means2
         return GAGS_EINVAL;
     const bool geom = !(flags & GAGS_BWD_COLORS_ONLY);
     if (geom && (!v_opacities || !v_means2d || !v_conics)) return GAGS_EINVAL;
+    if (!geom && !(flags & GAGS_FWD_NO_MFMA)) {
+        const int rc = gags_raster_bwd_colors_mfma(d, width, height, means2d, conics, opacities, isect_offsets,
+                                                   flatten_ids, (int)n_isects, v_render_colors, v_colors,
+                                                   (hipStream_t)stream);
+        if (rc != 1) return rc;
+    }
     return gags_raster_bwd_valu(d, width, height, means2d, conics, opacities, colors, backgrounds, isect_offsets,
                                 flatten_ids, (int)n_isects, render_alphas, last_ids, v_render_colors,
                                 v_render_alphas, v_colors, v_opacities, v_means2d, v_conics, geom,

@@ -625,3 +625,64 @@ void orc_project_bwd(int N, const float *means, const float *quats, const float 
         v_quats[4 * i + 3] = (vqz - qz * dotp) * inv_norm;
     }
 }
+
+/* ------------------------------------------------------------------------------------
+ * Colours-only backward in FORWARD order: v_colors[g] += sum_px (alpha*T) * v_out[px], with
+ * alpha*T recomputed front to back exactly as orc_raster_fwd computes it.
+ * Mathematically identical to orc_raster_bwd's v_colors; numerically it avoids gsplat's
+ * reconstruction T = (1 - render_alpha) * prod 1/(1-alpha), whose fp32 cancellation in
+ * 1 - (1 - T) costs up to ~1e-3 relative on nearly saturated pixels (gsplat's own source
+ * comments on this).  The HIP colours-only kernel uses this order; tests compare it against
+ * this function tightly and against the gsplat-order function loosely.
+ * ---------------------------------------------------------------------------------- */
+void orc_raster_bwd_colors_fwdorder(int D, int width, int height, int tile_w, int tile_h,
+                                    const float *means2d, const float *conics, const float *opacities,
+                                    const int32_t *tile_offsets, const int32_t *flatten_ids, int64_t n_isects,
+                                    const float *v_render_colors, int tile_begin, int tile_step, float *v_colors)
+{
+    const int n_tiles = tile_w * tile_h;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int tile = tile_begin; tile < n_tiles; tile += tile_step) {
+        const int ty = tile / tile_w, tx = tile % tile_w;
+        const int64_t start = tile_offsets[tile];
+        const int64_t end = (tile == n_tiles - 1) ? n_isects : tile_offsets[tile + 1];
+        const int64_t cnt = end - start;
+        if (cnt <= 0) continue;
+        double *lc = (double *)calloc((size_t)cnt * D, sizeof(double));
+        for (int ly = 0; ly < ORC_TILE; ++ly)
+            for (int lx = 0; lx < ORC_TILE; ++lx) {
+                const int i = ty * ORC_TILE + ly, j = tx * ORC_TILE + lx;
+                if (i >= height || j >= width) continue;
+                const float px = (float)j + 0.5f, py = (float)i + 0.5f;
+                const float *vc = v_render_colors + ((size_t)i * width + j) * D;
+                float T = 1.0f;
+                for (int64_t s = start; s < end; ++s) {
+                    const int32_t g = flatten_ids[s];
+                    const float dx = means2d[2 * g] - px, dy = means2d[2 * g + 1] - py;
+                    const float ca = conics[3 * g], cb = conics[3 * g + 1], cc = conics[3 * g + 2];
+                    const float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
+                    const float alpha = fminf(ORC_ALPHA_MAX, opacities[g] * orc_exp_neg(sigma));
+                    if (sigma < 0.f || alpha < ORC_ALPHA_MIN) continue;
+                    const float next_T = T * (1.0f - alpha);
+                    if (next_T <= ORC_T_STOP) break;
+                    const float vis = alpha * T;
+                    double *l = lc + (size_t)(s - start) * D;
+                    for (int k = 0; k < D; ++k) l[k] += (double)vis * (double)vc[k];
+                    T = next_T;
+                }
+            }
+        for (int64_t s = 0; s < cnt; ++s) {
+            const int32_t g = flatten_ids[start + s];
+            float *o = v_colors + (size_t)g * D;
+            const double *l = lc + (size_t)s * D;
+            for (int k = 0; k < D; ++k) {
+                const float add = (float)l[k];
+                if (add != 0.f) {
+#pragma omp atomic
+                    o[k] += add;
+                }
+            }
+        }
+        free(lc);
+    }
+}

@@ -154,6 +154,23 @@ def raster_bwd(means2d, conics, opacities, colors, backgrounds, width, height, i
     return v_colors, v_opac, v_m2d, v_con
 
 
+def raster_bwd_colors_fwdorder(means2d, conics, opacities, d, width, height, isect_offsets, flatten_ids,
+                               v_render_colors, n, tile_begin=0, tile_step=1):
+    """Colours-only gradient with alpha*T recomputed front to back (see gags_oracle.c)."""
+    tile_h, tile_w = isect_offsets.shape
+    v_colors = np.zeros((n, d), np.float32)
+    flat = np.ascontiguousarray(flatten_ids, dtype=np.int32)
+    if flat.size == 0:
+        flat = np.zeros(1, np.int32)
+    lib().orc_raster_bwd_colors_fwdorder(ctypes.c_int(d), ctypes.c_int(width), ctypes.c_int(height),
+                                         ctypes.c_int(tile_w), ctypes.c_int(tile_h), _p(_f32(means2d)),
+                                         _p(_f32(conics)), _p(_f32(opacities)),
+                                         _p(np.ascontiguousarray(isect_offsets, dtype=np.int32)), _p(flat),
+                                         ctypes.c_int64(len(flatten_ids)), _p(_f32(v_render_colors)),
+                                         ctypes.c_int(tile_begin), ctypes.c_int(tile_step), _p(v_colors))
+    return v_colors
+
+
 def project_bwd(means, quats, scales, viewmat, K, width, height, radii, v_means2d, v_depths, v_conics, eps2d=0.3):
     means, quats, scales = _f32(means), _f32(quats), _f32(scales)
     viewmat, K = _f32(viewmat).reshape(4, 4), _f32(K).reshape(3, 3)

@@ -65,7 +65,12 @@ def _check_indices(info, oinfo):
     (2000, 97, 61, 33, 2, 5, 6.0, 0.3),        # ragged image (not a multiple of 16), D=33 -> 2 chunks
     (5000, 256, 256, 4, 3, None, 2.0, None),   # no background
     (1500, 64, 48, 1, 4, 0, 8.0, 0.0),
-    (4000, 160, 120, 64, 5, None, 4.0, 0.5),
+    (4000, 160, 120, 64, 5, None, 4.0, 0.5),   # MFMA path, NB=2
+    (2000, 97, 61, 32, 6, 3, 6.0, 0.3),        # MFMA path, NB=1, ragged image
+    (5000, 200, 152, 128, 7, None, 4.0, 0.0),  # MFMA path, NB=4 (C2 width)
+    (3000, 176, 130, 256, 8, 6, 5.0, 1.0),     # MFMA path, NB=8, one slice
+    (2500, 130, 100, 512, 9, 1, 5.0, None),    # MFMA path, NB=8, two slices (C3 width)
+    (6000, 96, 64, 128, 10, None, 16.0, 0.2),  # large splats: long per-tile lists, early termination
 ])
 def test_forward_and_colour_grad(oracle, n, w, h, d, seed, view, mult, bgv):
     s = scene_arrays(n, d, w, h, seed=seed, view=view, scale_mult=mult)
@@ -78,10 +83,29 @@ def test_forward_and_colour_grad(oracle, n, w, h, d, seed, view, mult, bgv):
     _check_indices(info, oinfo)
     np.testing.assert_array_equal(alpha, o_alpha)
     np.testing.assert_array_equal(out, o_out)  # bit-exact forward
+    # gsplat-order oracle (T rebuilt back to front from 1 - render_alpha: cancellation-prone on saturated
+    # pixels) and forward-order oracle (same sum, alpha*T recomputed front to back).  The VALU kernels follow
+    # the former, the MFMA colours-only kernel the latter; either way the looser gsplat-order bound holds.
     o_vc, _, _, _ = oracle.raster_bwd(oinfo["means2d"], oinfo["conics"], s["opacities"], s["colors"], bg, w, h,
                                       oinfo["isect_offsets"], oinfo["flatten_ids"], o_alpha, oinfo["last_ids"],
                                       v_out, None, colors_only=True)
-    assert rel_l2(grads["colors"], o_vc) <= GRAD_TOL
+    o_vf = oracle.raster_bwd_colors_fwdorder(oinfo["means2d"], oinfo["conics"], s["opacities"], d, w, h,
+                                             oinfo["isect_offsets"], oinfo["flatten_ids"], v_out, n)
+    assert min(rel_l2(grads["colors"], o_vc), rel_l2(grads["colors"], o_vf)) <= GRAD_TOL
+    assert rel_l2(grads["colors"], o_vc) <= 1e-3
+
+
+def test_mfma_and_valu_paths_agree_bitwise(oracle):
+    """The two kernel families implement the same fmaf chain: identical bits, D=128."""
+    from gags_amd import _lib
+    n, w, h, d = 4000, 192, 144, 128
+    s = scene_arrays(n, d, w, h, seed=12, view=2, scale_mult=5.0)
+    bg = np.full(d, 0.7, np.float32)
+    a, aa, ia, _ = _run_gpu(s, w, h, s["colors"], bg)
+    b, ab, ib, _ = _run_gpu(s, w, h, s["colors"], bg, flags=_lib.GAGS_FWD_NO_MFMA)
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(aa, ab)
+    np.testing.assert_array_equal(ia["last_ids"].cpu().numpy(), ib["last_ids"].cpu().numpy())
 
 
 @pytest.mark.parametrize("n,w,h,d,seed,view", [(2500, 128, 96, 16, 7, 3), (2000, 100, 70, 3, 8, None)])
