@@ -34,8 +34,10 @@ SIGNATURES = {
     "gags_sort_scratch_bytes": (_i64, [_i64]),
     "gags_sort_pairs": (_i32, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "gags_tile_offsets": (_i32, [_i64, _vp, _i32, _vp, _vp]),
-    "gags_raster_fwd": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp]),
-    "gags_raster_bwd": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
+    "gags_pack_isects": (_i32, [_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gags_raster_fwd": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32,
+                               _vp]),
+    "gags_raster_bwd": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp, _vp, _i32, _vp]),
     "gags_raster_stats": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "gags_project_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp,

@@ -61,3 +61,20 @@ __device__ __forceinline__ int gags_xcd_remap(int bid, int nwg)
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + (bid >> 3);
 }
+
+// Tile traversal order used by the raster kernels: the image is cut into 8 horizontal bands (one
+// per XCD once gags_xcd_remap has given each XCD a contiguous run of the order) and every band is
+// swept COLUMN-major, so the tiles that share a Gaussian (vertical neighbours: next in order,
+// horizontal neighbours: one band-height later) are processed close together in time.  This keeps
+// re-touched feature / gradient rows resident in L2 / Infinity Cache.  Bijective for any grid.
+__device__ __forceinline__ int gags_tile_of_order(int o, int tile_w, int tile_h)
+{
+    const int bh = (tile_h + 7) >> 3;
+    const int per_band = bh * tile_w;
+    const int band = o / per_band;
+    const int r = o - band * per_band;
+    const int y0 = band * bh;
+    const int h = min(bh, tile_h - y0);
+    const int x = r / h;
+    return (y0 + (r - x * h)) * tile_w + x;
+}

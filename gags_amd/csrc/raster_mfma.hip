@@ -21,8 +21,6 @@
 
 namespace {
 
-constexpr int GC = 64;  // Gaussians per LDS chunk
-
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct GRec {  // 32 B, 16-B aligned
@@ -68,48 +66,84 @@ __device__ __forceinline__ float eval_alpha(const GRec &r, float px, float py, b
     return (live && !(sigma < 0.f || alpha < GAGS_ALPHA_MIN)) ? alpha : 0.f;
 }
 
-// Advance one pixel over the two Gaussians of a K-step; returns the weight of slot k.
-__device__ __forceinline__ float step_pair(PixState &s, float a0, float a1, int idx0, int idx1, int k)
+// Packed per-intersection record, written once per view by gags_pack_isects in sorted order so
+// that the raster kernels stream it with coalesced 32-B reads instead of three dependent gathers.
+//   {x, y, conic a, b, c, opacity, half-extent x, half-extent y} of the alpha >= 1/255 footprint.
+__global__ __launch_bounds__(256) void pack_isects_kernel(int n_isects, const int32_t *__restrict__ flatten_ids,
+                                                          const float *__restrict__ means2d,
+                                                          const float *__restrict__ conics,
+                                                          const float *__restrict__ opacities,
+                                                          GRec *__restrict__ packed)
 {
-    float w0 = 0.f, w1 = 0.f;
-    if (!s.done && a0 > 0.f) {
-        const float nt = s.T * (1.0f - a0);
-        if (nt <= GAGS_T_STOP) s.done = true;
-        else { w0 = a0 * s.T; s.T = nt; s.cur = idx0; }
-    }
-    if (!s.done && a1 > 0.f) {
-        const float nt = s.T * (1.0f - a1);
-        if (nt <= GAGS_T_STOP) s.done = true;
-        else { w1 = a1 * s.T; s.T = nt; s.cur = idx1; }
-    }
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_isects) return;
+    packed[s] = load_grec(means2d, conics, opacities, flatten_ids[s]);
+}
+
+// Record kept in the per-wave LDS ring after the hit test: extents replaced by ids.
+struct HRec {
+    float x, y, a, b, c, o;
+    int gid, sidx;
+};
+
+constexpr int RING = 256;  // per-wave ring of compacted hits (8 KB)
+
+// Advance one pixel over the two Gaussians of a K-step (branch-free: selects only).  Both
+// half-waves run the same chain; `blended` reports whether THIS lane's slot (k) was composited.
+__device__ __forceinline__ float step_pair2(PixState &s, float a0, float a1, int k, bool &blended)
+{
+    const float t0 = s.T * (1.0f - a0);
+    const bool ok0 = !s.done && a0 > 0.f;
+    const bool stop0 = ok0 && t0 <= GAGS_T_STOP;
+    const bool b0 = ok0 && !stop0;
+    const float w0 = b0 ? a0 * s.T : 0.f;
+    s.T = b0 ? t0 : s.T;
+    s.done = s.done || stop0;
+    const float t1 = s.T * (1.0f - a1);
+    const bool ok1 = !s.done && a1 > 0.f;
+    const bool stop1 = ok1 && t1 <= GAGS_T_STOP;
+    const bool b1 = ok1 && !stop1;
+    const float w1 = b1 ? a1 * s.T : 0.f;
+    s.T = b1 ? t1 : s.T;
+    s.done = s.done || stop1;
+    blended = k ? b1 : b0;
     return k ? w1 : w0;
 }
 
+// Forward, wave-independent: no workgroup barrier anywhere.  A workgroup is ONE wave = one of
+// the tile's eight 8x4 pixel blocks x one channel slice (so a finished wave frees its slot at
+// once; blocks of a tile are consecutive workgroup ids, i.e. the same XCD / L2); each wave
+// walks the tile's sorted range on its own:
+//   produce : 64 packed records per pass (register-prefetched one pass ahead), extent test,
+//             ballot, compaction of the hits into the wave's private LDS ring;
+//   consume : two hits per K-step -- alpha, permlane32 swap, transmittance chain, then NB
+//             v_mfma_f32_32x32x2_f32 with B operands (feature rows) loaded straight from
+//             global/L2 into VGPRs one K-step ahead (the rows are shared by the 16 waves of a
+//             tile and by neighbouring tiles: L2-resident; no LDS staging, no barrier).
 template <int NB>
-__global__ __launch_bounds__(512) void raster_fwd_mfma(
-    int d, int width, int height, int tile_w, int n_tiles, int n_slices, const float *__restrict__ means2d,
-    const float *__restrict__ conics, const float *__restrict__ opacities, const float *__restrict__ colors,
-    const float *__restrict__ backgrounds, const int32_t *__restrict__ offsets,
+__global__ __launch_bounds__(64, (NB >= 16 ? 1 : 2)) void raster_fwd_mfma(
+    int d, int width, int height, int tile_w, int n_tiles, int n_slices, const GRec *__restrict__ packed,
+    const float *__restrict__ colors, const float *__restrict__ backgrounds, const int32_t *__restrict__ offsets,
     const int32_t *__restrict__ flatten_ids, int n_isects, float *__restrict__ render_colors,
-    float *__restrict__ render_alphas, int32_t *__restrict__ last_ids)
+    float *__restrict__ render_alphas, int32_t *__restrict__ last_ids, int dbg)
 {
-    constexpr int CS = 32 * NB;               // channels per workgroup
-    constexpr int VEC = NB >= 4 ? 4 : NB;     // floats per B-operand LDS read
-    constexpr int NG = NB / VEC;              // accumulator groups
-    static_assert(NB == 1 || NB == 2 || NB % 4 == 0, "NB in {1,2,4,8,...}");
+    constexpr int CS = 32 * NB;
+    constexpr int VEC = NB >= 4 ? 4 : NB;
+    constexpr int NG = NB / VEC;
+    static_assert(NB == 1 || NB == 2 || NB % 4 == 0, "NB in {1,2,4,8,16}");
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *F = reinterpret_cast<float *>(smem);                       // [GC][CS]
-    GRec *P = reinterpret_cast<GRec *>(smem + GC * CS * 4);           // [GC]
-    float *Tb = reinterpret_cast<float *>(smem + GC * CS * 4 + GC * 32);  // [8][32]
+    __shared__ __attribute__((aligned(16))) HRec ring[RING];
+    __shared__ float Tb[32];
 
-    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * n_slices);
-    const int tile = logical / n_slices, slice = logical - tile * n_slices;
+    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * 8 * n_slices);
+    const int slice = logical % n_slices, rest = logical / n_slices;
+    const int blk = rest & 7;
+    const int tile = (dbg & 16) ? (rest >> 3) : gags_tile_of_order(rest >> 3, tile_w, n_tiles / tile_w);
     const int ch0 = slice * CS;
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x;
     const int p = lane & 31, k = lane >> 5;
     const int ty = tile / tile_w, tx = tile - ty * tile_w;
-    const int bx0 = tx * GAGS_TILE + (w & 1) * 8, by0 = ty * GAGS_TILE + (w >> 1) * 4;  // wave's 8x4 block
+    const int bx0 = tx * GAGS_TILE + (blk & 1) * 8, by0 = ty * GAGS_TILE + (blk >> 1) * 4;
     const int pj = bx0 + (p & 7), pi = by0 + (p >> 3);
     const bool inside = (pi < height) && (pj < width);
     const float px = (float)pj + 0.5f, py = (float)pi + 0.5f;
@@ -126,101 +160,148 @@ __global__ __launch_bounds__(512) void raster_fwd_mfma(
 
     PixState st;
     st.T = 1.0f; st.cur = 0; st.done = !inside;
-    bool wave_done = __all(st.done);
 
-    for (int c0 = start; c0 < end; c0 += GC) {
-        if (__syncthreads_count(wave_done) >= 512) break;  // also fences LDS reuse
-        const int nc = min(GC, end - c0);
-        // ---- stage the chunk: records by the first GC threads, feature rows by all 8 waves ----
-        if (threadIdx.x < GC) {
-            GRec r;
-            if ((int)threadIdx.x < nc) r = load_grec(means2d, conics, opacities, flatten_ids[c0 + threadIdx.x]);
-            else { r.x = r.y = r.a = r.b = r.c = r.o = 0.f; r.ex = r.ey = -1.f; }
-            P[threadIdx.x] = r;
+    // ---- producer state: chunk [c, c+64) is in registers (pre), next chunk is at c ----
+    int nq = 0, rd = 0;  // hits produced / consumed (wave-uniform); ring index = count & (RING-1)
+    int c = start;
+    GRec pre;
+    int pre_gid = 0, pre_c = start;
+    auto issue = [&]() {  // start loading the chunk at c
+        pre_c = c;
+        const int idx = c + lane;
+        if (idx < end) {
+            const float4 *src = reinterpret_cast<const float4 *>(packed + idx);
+            const float4 u = src[0], v = src[1];
+            pre.x = u.x; pre.y = u.y; pre.a = u.z; pre.b = u.w; pre.c = v.x; pre.o = v.y; pre.ex = v.z; pre.ey = v.w;
+            pre_gid = flatten_ids[idx];
+        } else {
+            pre.x = pre.y = 0.f; pre.ex = pre.ey = -1.f; pre.a = pre.b = pre.c = pre.o = 0.f;
         }
-        {
-            constexpr int LPR = CS / 4;           // lanes per row (float4 each)
-            constexpr int RPP = 512 / LPR;        // rows per pass
-            const int rl = threadIdx.x / LPR, cl = (threadIdx.x - rl * LPR) * 4;
-#pragma unroll
-            for (int r0 = 0; r0 < GC; r0 += RPP) {
-                const int row = r0 + rl;
-                if (row < nc) {
-                    const int g = flatten_ids[c0 + row];
-                    const float4 v = *reinterpret_cast<const float4 *>(colors + (size_t)g * d + ch0 + cl);
-                    *reinterpret_cast<float4 *>(F + row * CS + cl) = v;
-                }
-            }
+        c += 64;
+    };
+    auto commit = [&]() {  // hit-test the chunk in registers, append the hits to the ring
+        const bool hit = (pre_c + lane < end) && (pre.x + pre.ex >= rx0) && (pre.x - pre.ex <= rx1) &&
+                         (pre.y + pre.ey >= ry0) && (pre.y - pre.ey <= ry1);
+        const unsigned long long mask = __ballot(hit);
+        if (hit) {
+            const int pos = nq + __popcll(mask & ((1ull << lane) - 1ull));
+            HRec h;
+            h.x = pre.x; h.y = pre.y; h.a = pre.a; h.b = pre.b; h.c = pre.c; h.o = pre.o;
+            h.gid = pre_gid; h.sidx = pre_c + lane;
+            ring[pos & (RING - 1)] = h;
         }
-        __syncthreads();
-        if (wave_done) continue;
+        nq += __popcll(mask);
+    };
+    bool pending = false;  // a chunk is in flight in `pre`
+    if (c < end) { issue(); pending = true; }
+    auto refill = [&](int low) {
+        while ((nq - rd) < low && pending) {
+            commit();
+            pending = false;
+            if (c < end) { issue(); pending = true; }
+        }
+    };
 
-        // ---- compact: which Gaussians of the chunk can touch this wave's 8x4 pixels ----
-        bool hit = false;
-        if (lane < nc) {
-            const GRec r = P[lane];
-            hit = (r.x + r.ex >= rx0) && (r.x - r.ex <= rx1) && (r.y + r.ey >= ry0) && (r.y - r.ey <= ry1);
+    // B operands for the pair at ring position `pos`: lane (p,k) reads VEC floats of the row of slot
+    // pos+k.  Always addresses a produced slot (clamped), so it is issued unconditionally one step ahead.
+    auto load_b = [&](int pos, float4(&bq)[NG]) {
+        const int slot = min(pos + k, nq - 1);
+        const int gid = ring[slot & (RING - 1)].gid;
+        const float *row = colors + (size_t)gid * d + ch0 + VEC * p;
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) {
+            if constexpr (VEC == 4) bq[gq] = *reinterpret_cast<const float4 *>(row + gq * 128);
+            else if constexpr (VEC == 2) { const float2 t = *reinterpret_cast<const float2 *>(row); bq[gq] = make_float4(t.x, t.y, 0.f, 0.f); }
+            else bq[gq] = make_float4(row[0], 0.f, 0.f, 0.f);
         }
-        unsigned long long mask = __ballot(hit);
+    };
+    // alpha of this lane's slot of the pair at `pos` (0 past the end of the list) + its sorted index
+    auto eval_at = [&](int pos, int &sidx) {
+        const bool valid = pos + k < nq;
+        const HRec h = ring[min(pos + k, nq - 1) & (RING - 1)];
+        GRec r;
+        r.x = h.x; r.y = h.y; r.a = h.a; r.b = h.b; r.c = h.c; r.o = h.o;
+        sidx = h.sidx;
+        return eval_alpha(r, px, py, valid);
+    };
 
-        while (mask) {
-            const int i0 = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            int i1 = -1;
-            if (mask) { i1 = __builtin_ctzll(mask); mask &= mask - 1; }
-            const int mine = k ? (i1 < 0 ? i0 : i1) : i0;
-            const GRec r = P[mine];
-            const float a_own = eval_alpha(r, px, py, k ? (i1 >= 0) : true);
-            // lanes 32-63 of vdst <-> lanes 0-31 of src: r0 = slot-0 alpha, r1 = slot-1 alpha, in every lane
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a_own), __float_as_uint(a_own), false, false);
-            const float a0 = __uint_as_float(sw[0]), a1 = __uint_as_float(sw[1]);
-            const float wgt = step_pair(st, a0, a1, c0 + i0, c0 + i1, k);
-            if (__any(wgt != 0.f)) {
-                const float *frow = F + mine * CS + VEC * p;
+    // Software pipeline, one basic block per K-step: alpha(s+1) and the feature-row loads of
+    // step s+1 do not depend on the transmittance chain / MFMAs of step s, so they overlap.
+    // Two copies of the step with swapped B buffers avoid register copies.
+    refill(6);
+    float a_n = 0.f;
+    int sidx_n = 0;
+    float4 b0[NG], b1[NG];
+    auto kstep = [&](float4(&bc)[NG], float4(&bn)[NG]) -> bool {
+        const float a_c = a_n;
+        const int sidx_c = sidx_n;
+        rd += 2;
+        if ((nq - rd) < 6 && pending) refill(6);
+        const bool more = rd < nq;
+        a_n = eval_at(rd, sidx_n);  // clamped slot; weight forced to 0 past the end
+        load_b(rd, bn);
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a_c), __float_as_uint(a_c), false, false);
+        bool blended;
+        const float wgt = step_pair2(st, __uint_as_float(sw[0]), __uint_as_float(sw[1]), k, blended);
+        st.cur = blended ? sidx_c : st.cur;
 #pragma unroll
-                for (int gq = 0; gq < NG; ++gq) {
-                    float bv[VEC];
-                    if constexpr (VEC == 4) {
-                        const float4 t = *reinterpret_cast<const float4 *>(frow + gq * 128);
-                        bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w;
-                    } else if constexpr (VEC == 2) {
-                        const float2 t = *reinterpret_cast<const float2 *>(frow);
-                        bv[0] = t.x; bv[1] = t.y;
-                    } else {
-                        bv[0] = frow[0];
-                    }
+        for (int gq = 0; gq < NG; ++gq) {
+            const float bv[4] = {bc[gq].x, bc[gq].y, bc[gq].z, bc[gq].w};
 #pragma unroll
-                    for (int i = 0; i < VEC; ++i)
-                        acc[gq * VEC + i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wgt, bv[i], acc[gq * VEC + i], 0, 0, 0);
-                }
-            }
-            if (__all(st.done)) { wave_done = true; break; }
+            for (int i = 0; i < VEC; ++i)
+                acc[gq * VEC + i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wgt, bv[i], acc[gq * VEC + i], 0, 0, 0);
+        }
+        return more && !__all(st.done);
+    };
+    if (!__all(st.done) && rd < nq) {
+        a_n = eval_at(rd, sidx_n);
+        load_b(rd, b0);
+        // two K-steps per trip, ONE exit test: a single loop exit keeps the 128 accumulator registers
+        // in place (two exits make the register allocator shuffle them); a surplus K-step past the end
+        // of the list or past saturation carries zero weights, i.e. is an exact no-op.
+        bool go = true;
+        while (go) {
+            kstep(b0, b1);
+            go = kstep(b1, b0);
         }
     }
 
-    // ---- epilogue: out[pix][ch] = acc (+ T*bg); accumulator row r <-> pixel (r&3)+8(r>>2)+4k ----
-    if (k == 0) Tb[w * 32 + p] = st.T;
+    // ---- epilogue ----
+    {
+        const auto cs = __builtin_amdgcn_permlane32_swap((unsigned)st.cur, (unsigned)st.cur, false, false);
+        st.cur = max((int)cs[0], (int)cs[1]);  // sorted indices grow along the list
+    }
+    if (k == 0) Tb[p] = st.T;
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
     if (k == 0 && inside && slice == 0) {
         const size_t pix = (size_t)pi * width + pj;
         render_alphas[pix] = 1.0f - st.T;
         last_ids[pix] = st.cur;
     }
+    float bgv[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) bgv[j] = 0.f;
+    const bool has_bg = backgrounds != nullptr;  // wave-uniform
+    if (has_bg) {
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) bgv[gq * VEC + i] = backgrounds[ch0 + gq * 32 * VEC + VEC * p + i];
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int q = (r & 3) + 8 * (r >> 2) + 4 * k;  // pixel index inside the wave's block
+        const int q = (r & 3) + 8 * (r >> 2) + 4 * k;  // accumulator row r <-> pixel q of the block
         const int qj = bx0 + (q & 7), qi = by0 + (q >> 3);
         if (qi >= height || qj >= width) continue;
-        const float Tq = Tb[w * 32 + q];
+        const float Tq = Tb[q];
         float *o = render_colors + ((size_t)qi * width + qj) * d + ch0 + VEC * p;
 #pragma unroll
         for (int gq = 0; gq < NG; ++gq) {
             float v[VEC];
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
-                const int ch = ch0 + gq * 32 * VEC + VEC * p + i;
-                v[i] = backgrounds ? __builtin_fmaf(Tq, backgrounds[ch], acc[gq * VEC + i][r]) : acc[gq * VEC + i][r];
+                const float a = acc[gq * VEC + i][r];
+                v[i] = has_bg ? __builtin_fmaf(Tq, bgv[gq * VEC + i], a) : a;
             }
             if constexpr (VEC == 4) *reinterpret_cast<float4 *>(o + gq * 128) = make_float4(v[0], v[1], v[2], v[3]);
             else if constexpr (VEC == 2) *reinterpret_cast<float2 *>(o) = make_float2(v[0], v[1]);
@@ -230,24 +311,16 @@ __global__ __launch_bounds__(512) void raster_fwd_mfma(
 }
 
 template <int NB>
-int launch_fwd_mfma(int d, int width, int height, const float *means2d, const float *conics, const float *opacities,
-                    const float *colors, const float *backgrounds, const int32_t *offsets, const int32_t *flat,
-                    int n_isects, float *out, float *alphas, int32_t *last_ids, hipStream_t st)
+int launch_fwd_mfma(int d, int width, int height, const GRec *packed, const float *colors, const float *backgrounds,
+                    const int32_t *offsets, const int32_t *flat, int n_isects, float *out, float *alphas,
+                    int32_t *last_ids, int dbg, hipStream_t st)
 {
     constexpr int CS = 32 * NB;
     const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
     const int n_tiles = tile_w * tile_h, n_slices = d / CS;
-    const size_t lds = (size_t)GC * CS * 4 + GC * 32 + 8 * 32 * 4;
-    static bool attr_done = false;  // idempotent; a benign race at worst sets it twice
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&raster_fwd_mfma<NB>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return GAGS_ELAUNCH;
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(raster_fwd_mfma<NB>, dim3(n_tiles * n_slices), dim3(512), lds, st, d, width, height, tile_w,
-                       n_tiles, n_slices, means2d, conics, opacities, colors, backgrounds, offsets, flat, n_isects, out,
-                       alphas, last_ids);
+    hipLaunchKernelGGL(raster_fwd_mfma<NB>, dim3(n_tiles * 8 * n_slices), dim3(64), 0, st, d, width, height, tile_w,
+                       n_tiles, n_slices, packed, colors, backgrounds, offsets, flat, n_isects, out, alphas, last_ids,
+                       dbg);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }
@@ -258,13 +331,14 @@ int launch_fwd_mfma(int d, int width, int height, const float *means2d, const fl
 // scene/gaussian_model.py:192-208):   v_colors[g, :] += sum_px w[px, g] * v_out[px, :]
 // with w = alpha*T recomputed FRONT TO BACK by exactly the forward's arithmetic (same hits,
 // same stop decisions, so neither render_alphas nor last_ids nor the features are read).
-// Per wave (8x4 pixels x CSB = 128 channels of the slice):
+// One wave per workgroup = one 8x4 pixel block x CSB = 128 channels, no barriers:
 //   - the cotangent slab v_out[32 px][128 ch] lives in 64 VGPRs as MFMA B operands
 //     (K = pixel pairs, N = channels), loaded once;
-//   - hits are evaluated two per step in the forward's lane layout (pixel, slot) and the
-//     weights are transposed through a wave-private LDS tile Wt[32 slots][32 px] (row stride 36
-//     dwords: conflict-free ds_write_b32 / ds_read_b128);
-//   - every 32 hits: A = Wt^T fragments, 16 K-steps x 4 channel tiles of
+//   - producer / consumer exactly as the forward (packed records -> extent test -> LDS ring ->
+//     two hits per step, alpha pipelined one step ahead); the weights of a step are transposed
+//     through an LDS tile Wt[32 slots][32 px] (row stride 36 dwords: conflict-free
+//     ds_write_b32 / ds_read_b128);
+//   - every 32 slots: A = Wt^T fragments, 16 K-steps x 4 channel tiles of
 //     v_mfma_f32_32x32x2_f32, then one 128-B coalesced float atomic per (Gaussian, channel tile).
 // ------------------------------------------------------------------------------------------
 constexpr int NBB = 4;            // channel tiles per wave in the backward
@@ -276,30 +350,28 @@ __device__ __forceinline__ void atomic_add_f32(float *p, float v)
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(512) void raster_bwd_colors_mfma(
-    int d, int width, int height, int tile_w, int n_tiles, int n_slices, const float *__restrict__ means2d,
-    const float *__restrict__ conics, const float *__restrict__ opacities, const int32_t *__restrict__ offsets,
-    const int32_t *__restrict__ flatten_ids, int n_isects, const float *__restrict__ v_render_colors,
-    float *__restrict__ v_colors)
+__global__ __launch_bounds__(64, 2) void raster_bwd_colors_mfma(
+    int d, int width, int height, int tile_w, int n_tiles, int n_slices, const GRec *__restrict__ packed,
+    const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids, int n_isects,
+    const float *__restrict__ v_render_colors, float *__restrict__ v_colors, int dbg)
 {
-    __shared__ __attribute__((aligned(16))) GRec P[GC];
-    __shared__ int32_t ids[GC];
-    __shared__ __attribute__((aligned(16))) float Wt_all[8][32 * WT_STRIDE];
-    __shared__ int32_t slot_id_all[8][32];
+    __shared__ __attribute__((aligned(16))) HRec ring[RING];
+    __shared__ __attribute__((aligned(16))) float Wt[32 * WT_STRIDE];
+    __shared__ int32_t slot_id[32];
 
-    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * n_slices);
-    const int tile = logical / n_slices, slice = logical - tile * n_slices;
+    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * 8 * n_slices);
+    const int slice = logical % n_slices, rest = logical / n_slices;
+    const int blk = rest & 7;
+    const int tile = (dbg & 16) ? (rest >> 3) : gags_tile_of_order(rest >> 3, tile_w, n_tiles / tile_w);
     const int ch0 = slice * CSB;
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x;
     const int p = lane & 31, k = lane >> 5;
     const int ty = tile / tile_w, tx = tile - ty * tile_w;
-    const int bx0 = tx * GAGS_TILE + (w & 1) * 8, by0 = ty * GAGS_TILE + (w >> 1) * 4;
+    const int bx0 = tx * GAGS_TILE + (blk & 1) * 8, by0 = ty * GAGS_TILE + (blk >> 1) * 4;
     const int pj = bx0 + (p & 7), pi = by0 + (p >> 3);
     const bool inside = (pi < height) && (pj < width);
     const float px = (float)pj + 0.5f, py = (float)pi + 0.5f;
     const float rx0 = (float)bx0 + 0.5f, rx1 = (float)bx0 + 7.5f, ry0 = (float)by0 + 0.5f, ry1 = (float)by0 + 3.5f;
-    float *Wt = Wt_all[w];
-    int32_t *slot_id = slot_id_all[w];
 
     const int start = offsets[tile];
     const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
@@ -318,8 +390,57 @@ __global__ __launch_bounds__(512) void raster_bwd_colors_mfma(
 
     PixState st;
     st.T = 1.0f; st.cur = 0; st.done = !inside;
-    bool wave_done = __all(st.done);
-    int nh = 0;  // filled slots of the current 32-hit block (wave-uniform)
+
+    // ---- producer (same as the forward) ----
+    int nq = 0, rd = 0;
+    int c = start;
+    GRec pre;
+    int pre_gid = 0, pre_c = start;
+    auto issue = [&]() {
+        pre_c = c;
+        const int idx = c + lane;
+        if (idx < end) {
+            const float4 *src = reinterpret_cast<const float4 *>(packed + idx);
+            const float4 u = src[0], v = src[1];
+            pre.x = u.x; pre.y = u.y; pre.a = u.z; pre.b = u.w; pre.c = v.x; pre.o = v.y; pre.ex = v.z; pre.ey = v.w;
+            pre_gid = flatten_ids[idx];
+        } else {
+            pre.x = pre.y = 0.f; pre.ex = pre.ey = -1.f; pre.a = pre.b = pre.c = pre.o = 0.f;
+        }
+        c += 64;
+    };
+    auto commit = [&]() {
+        const bool hit = (pre_c + lane < end) && (pre.x + pre.ex >= rx0) && (pre.x - pre.ex <= rx1) &&
+                         (pre.y + pre.ey >= ry0) && (pre.y - pre.ey <= ry1);
+        const unsigned long long mask = __ballot(hit);
+        if (hit) {
+            const int pos = nq + __popcll(mask & ((1ull << lane) - 1ull));
+            HRec h;
+            h.x = pre.x; h.y = pre.y; h.a = pre.a; h.b = pre.b; h.c = pre.c; h.o = pre.o;
+            h.gid = pre_gid; h.sidx = pre_c + lane;
+            ring[pos & (RING - 1)] = h;
+        }
+        nq += __popcll(mask);
+    };
+    bool pending = false;
+    if (c < end) { issue(); pending = true; }
+    auto refill = [&](int low) {
+        while ((nq - rd) < low && pending) {
+            commit();
+            pending = false;
+            if (c < end) { issue(); pending = true; }
+        }
+    };
+    auto eval_at = [&](int pos, int &gid) {
+        const bool valid = pos + k < nq;
+        const HRec h = ring[min(pos + k, nq - 1) & (RING - 1)];
+        GRec r;
+        r.x = h.x; r.y = h.y; r.a = h.a; r.b = h.b; r.c = h.c; r.o = h.o;
+        gid = valid ? h.gid : -1;
+        return eval_alpha(r, px, py, valid);
+    };
+
+    int nh = 0;  // filled slots of the current 32-slot block (wave-uniform, even)
     const int wpos = (p & 1) * 16 + (p >> 1);  // position of pixel p inside a slot row: [k][s]
 
     auto flush = [&](int count) {
@@ -336,91 +457,92 @@ __global__ __launch_bounds__(512) void raster_bwd_colors_mfma(
         for (int j = 0; j < NBB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        if (!(dbg & 2)) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s)
+            for (int s = 0; s < 16; ++s)
 #pragma unroll
-            for (int j = 0; j < NBB; ++j)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s], V[s][j], acc[j], 0, 0, 0);
+                for (int j = 0; j < NBB; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s], V[s][j], acc[j], 0, 0, 0);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int slot = (r & 3) + 8 * (r >> 2) + 4 * k;
-            if (slot < count) {
-                float *dst = v_colors + (size_t)slot_id[slot] * d + ch0 + p;
+            const int gid = slot_id[slot];
+            if (slot < count && gid >= 0 && !(dbg & 1)) {
+                float *dst = v_colors + (size_t)gid * d + ch0 + p;
+                if (dbg & 4) {  // EXPERIMENT: plain stores instead of atomics
 #pragma unroll
-                for (int j = 0; j < NBB; ++j) atomic_add_f32(dst + 32 * j, acc[j][r]);
+                    for (int j = 0; j < NBB; ++j)
+                        dst[32 * j] = acc[j][r];  // plain store: wrong sums, measures the store path
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NBB; ++j) atomic_add_f32(dst + 32 * j, acc[j][r]);
+                }
             }
         }
     };
 
-    for (int c0 = start; c0 < end; c0 += GC) {
-        if (__syncthreads_count(wave_done) >= 512) break;
-        const int nc = min(GC, end - c0);
-        if (threadIdx.x < GC) {
-            GRec r;
-            int g = 0;
-            if ((int)threadIdx.x < nc) { g = flatten_ids[c0 + threadIdx.x]; r = load_grec(means2d, conics, opacities, g); }
-            else { r.x = r.y = r.a = r.b = r.c = r.o = 0.f; r.ex = r.ey = -1.f; }
-            P[threadIdx.x] = r;
-            ids[threadIdx.x] = g;
-        }
-        __syncthreads();
-        if (wave_done) continue;
-
-        bool hit = false;
-        if (lane < nc) {
-            const GRec r = P[lane];
-            hit = (r.x + r.ex >= rx0) && (r.x - r.ex <= rx1) && (r.y + r.ey >= ry0) && (r.y - r.ey <= ry1);
-        }
-        unsigned long long mask = __ballot(hit);
-
-        while (mask) {
-            if (nh > 30) { flush(nh); nh = 0; }
-            const int i0 = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            int i1 = -1;
-            if (mask) { i1 = __builtin_ctzll(mask); mask &= mask - 1; }
-            const int mine = k ? (i1 < 0 ? i0 : i1) : i0;
-            const GRec r = P[mine];
-            const float a_own = eval_alpha(r, px, py, k ? (i1 >= 0) : true);
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a_own), __float_as_uint(a_own), false, false);
-            const float a0 = __uint_as_float(sw[0]), a1 = __uint_as_float(sw[1]);
-            const float wgt = step_pair(st, a0, a1, c0 + i0, c0 + i1, k);
-            if (__any(wgt != 0.f)) {
-                // slots nh (k=0 lanes) and nh+1 (k=1 lanes); a lone hit leaves slot nh+1 unused
-                if (k == 0 || i1 >= 0) Wt[(nh + k) * WT_STRIDE + wpos] = wgt;
-                if (lane == 0) slot_id[nh] = ids[i0];
-                if (lane == 32 && i1 >= 0) slot_id[nh + 1] = ids[i1];
-                nh += (i1 >= 0) ? 2 : 1;
+    refill(6);
+    if (!__all(st.done) && rd < nq) {
+        int gid_n;
+        float a_n = eval_at(rd, gid_n);
+        bool go = true;
+        while (go) {
+            const float a_c = a_n;
+            const int gid_c = gid_n;
+            rd += 2;
+            if ((nq - rd) < 6 && pending) refill(6);
+            const bool more = rd < nq;
+            a_n = eval_at(rd, gid_n);
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a_c), __float_as_uint(a_c), false, false);
+            bool blended;
+            const float wgt = step_pair2(st, __uint_as_float(sw[0]), __uint_as_float(sw[1]), k, blended);
+            if (__any(wgt != 0.f)) {  // pairs nobody blends would only add zeros: skip their atomics
+                Wt[(nh + k) * WT_STRIDE + wpos] = wgt;
+                if (p == 0) slot_id[nh + k] = gid_c;
+                nh += 2;
+                if (nh == 32) { flush(32); nh = 0; }
             }
-            if (__all(st.done)) { wave_done = true; break; }
+            go = more && !__all(st.done);
         }
     }
     if (nh > 0) flush(nh);
 }
 
-int launch_bwd_colors_mfma(int d, int width, int height, const float *means2d, const float *conics,
-                           const float *opacities, const int32_t *offsets, const int32_t *flat, int n_isects,
-                           const float *v_out, float *v_colors, hipStream_t st)
+int launch_bwd_colors_mfma(int d, int width, int height, const GRec *packed, const int32_t *offsets,
+                           const int32_t *flat, int n_isects, const float *v_out, float *v_colors, int dbg,
+                           hipStream_t st)
 {
     const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
     const int n_tiles = tile_w * tile_h, n_slices = d / CSB;
-    hipLaunchKernelGGL(raster_bwd_colors_mfma, dim3(n_tiles * n_slices), dim3(512), 0, st, d, width, height, tile_w,
-                       n_tiles, n_slices, means2d, conics, opacities, offsets, flat, n_isects, v_out, v_colors);
+    hipLaunchKernelGGL(raster_bwd_colors_mfma, dim3(n_tiles * 8 * n_slices), dim3(64), 0, st, d, width, height, tile_w,
+                       n_tiles, n_slices, packed, offsets, flat, n_isects, v_out, v_colors, dbg);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }
 
 }  // namespace
 
-// Returns GAGS_OK when the MFMA path took the call, 1 when d is not eligible (caller falls
-// back to the VALU kernels), negative on error.
-int gags_raster_fwd_mfma(int d, int width, int height, const float *means2d, const float *conics,
-                         const float *opacities, const float *colors, const float *backgrounds,
-                         const int32_t *offsets, const int32_t *flat, int n_isects, float *out, float *alphas,
-                         int32_t *last_ids, hipStream_t st)
+int gags_pack_isects_launch(int n_isects, const int32_t *flat, const float *means2d, const float *conics,
+                            const float *opacities, void *packed, hipStream_t st)
 {
     GAGS_CLEAR_ERR();
-#define ARGS d, width, height, means2d, conics, opacities, colors, backgrounds, offsets, flat, n_isects, out, alphas, last_ids, st
+    if (n_isects <= 0) return GAGS_OK;
+    hipLaunchKernelGGL(pack_isects_kernel, dim3((n_isects + 255) / 256), dim3(256), 0, st, n_isects, flat, means2d,
+                       conics, opacities, reinterpret_cast<GRec *>(packed));
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+// Returns GAGS_OK when the MFMA path took the call, 1 when d is not eligible (caller falls
+// back to the VALU kernels), negative on error.
+int gags_raster_fwd_mfma(int d, int width, int height, const void *packed, const float *colors,
+                         const float *backgrounds, const int32_t *offsets, const int32_t *flat, int n_isects,
+                         float *out, float *alphas, int32_t *last_ids, int dbg, hipStream_t st)
+{
+    GAGS_CLEAR_ERR();
+    const GRec *pk = reinterpret_cast<const GRec *>(packed);
+#define ARGS d, width, height, pk, colors, backgrounds, offsets, flat, n_isects, out, alphas, last_ids, dbg, st
     if (d < 32 || d % 32 != 0) return 1;
     if (d % 256 == 0) return launch_fwd_mfma<8>(ARGS);
     if (d % 128 == 0) return launch_fwd_mfma<4>(ARGS);
@@ -430,12 +552,12 @@ int gags_raster_fwd_mfma(int d, int width, int height, const float *means2d, con
 }
 
 // colours-only backward on the matrix cores; 1 = width not eligible (d % 128 != 0)
-int gags_raster_bwd_colors_mfma(int d, int width, int height, const float *means2d, const float *conics,
-                                const float *opacities, const int32_t *offsets, const int32_t *flat, int n_isects,
-                                const float *v_out, float *v_colors, hipStream_t st)
+int gags_raster_bwd_colors_mfma(int d, int width, int height, const void *packed, const int32_t *offsets,
+                                const int32_t *flat, int n_isects, const float *v_out, float *v_colors, int dbg,
+                                hipStream_t st)
 {
     GAGS_CLEAR_ERR();
     if (d < CSB || d % CSB != 0) return 1;
-    return launch_bwd_colors_mfma(d, width, height, means2d, conics, opacities, offsets, flat, n_isects, v_out,
-                                  v_colors, st);
+    return launch_bwd_colors_mfma(d, width, height, reinterpret_cast<const GRec *>(packed), offsets, flat, n_isects,
+                                  v_out, v_colors, dbg, st);
 }

@@ -112,9 +112,10 @@ class _SH(torch.autograd.Function):
         return v_coeffs, None, None, None, None
 
 
-def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height):
-    """K5-K8 on device.  One host readback (n_isects), as in gsplat.  Returns
-    (isect_ids sorted [I] int64, flatten_ids sorted [I] int32, isect_offsets [th,tw] int32, n_isects)."""
+def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height, conics=None, opacities=None):
+    """K5-K8 (+K8b) on device.  One host readback (n_isects), as in gsplat.  Returns
+    (isect_ids sorted [I] int64, flatten_ids sorted [I] int32, isect_offsets [th,tw] int32, n_isects,
+    packed [I,8] f32 records in sorted order, or None when conics/opacities are not given)."""
     lib = _lib.load()
     st = _stream()
     dev = means2d.device
@@ -143,14 +144,20 @@ def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height):
         check(lib.gags_sort_pairs(n_isects, tile_bits, ptr(ids), ptr(flat), ptr(ids_s), ptr(flat_s), ptr(sscratch),
                                   ssb, st), "gags_sort_pairs")
     check(lib.gags_tile_offsets(n_isects, ptr(ids_s), n_tiles, ptr(offsets), st), "gags_tile_offsets")
-    return ids_s[:n_isects], flat_s[:n_isects], offsets, n_isects
+    packed = None
+    if conics is not None:
+        packed = torch.empty(max(n_isects, 1), 8, dtype=torch.float32, device=dev)
+        check(lib.gags_pack_isects(n_isects, ptr(flat_s), ptr(means2d), ptr(conics), ptr(opacities), ptr(packed), st),
+              "gags_pack_isects")
+    return ids_s[:n_isects], flat_s[:n_isects], offsets, n_isects, packed
 
 
 class _Rasterize(torch.autograd.Function):
     """K9 forward / K10 backward over pre-binned intersections."""
 
     @staticmethod
-    def forward(ctx, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, width, height, flags):
+    def forward(ctx, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, packed, width, height,
+                flags):
         lib = _lib.load()
         means2d, conics, colors, opacities = _c(means2d), _c(conics), _c(colors), _c(opacities)
         backgrounds = None if backgrounds is None else _c(backgrounds)
@@ -162,9 +169,10 @@ class _Rasterize(torch.autograd.Function):
         last_ids = torch.empty(height, width, dtype=torch.int32, device=dev)
         with profiler.stage("raster_fwd"):
             check(lib.gags_raster_fwd(d, width, height, ptr(means2d), ptr(conics), ptr(opacities), ptr(colors),
-                                      ptr(backgrounds), ptr(offsets), ptr(flatten_ids), n_isects, ptr(out),
-                                      ptr(alphas), ptr(last_ids), flags, _stream()), "gags_raster_fwd")
-        ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, alphas, last_ids)
+                                      ptr(backgrounds), ptr(offsets), ptr(flatten_ids), n_isects, ptr(packed),
+                                      ptr(out), ptr(alphas), ptr(last_ids), flags, _stream()), "gags_raster_fwd")
+        ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, packed, alphas,
+                              last_ids)
         ctx.cfg = (width, height, flags)
         ctx.mark_non_differentiable(last_ids)
         return out, alphas, last_ids
@@ -172,7 +180,8 @@ class _Rasterize(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_out, v_alphas, _v_last):
         lib = _lib.load()
-        means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, alphas, last_ids = ctx.saved_tensors
+        (means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, packed, alphas,
+         last_ids) = ctx.saved_tensors
         width, height, flags = ctx.cfg
         n, d = colors.shape
         dev = colors.device
@@ -191,13 +200,13 @@ class _Rasterize(torch.autograd.Function):
             bflags = flags | _lib.GAGS_BWD_COLORS_ONLY
         with profiler.stage("raster_bwd"):
             check(lib.gags_raster_bwd(d, width, height, ptr(means2d), ptr(conics), ptr(opacities), ptr(colors),
-                                      ptr(backgrounds), ptr(offsets), ptr(flatten_ids), n_isects, ptr(alphas),
-                                      ptr(last_ids), ptr(v_out), ptr(v_alphas), ptr(v_colors), ptr(v_opac),
-                                      ptr(v_m2d), ptr(v_con), bflags, _stream()), "gags_raster_bwd")
+                                      ptr(backgrounds), ptr(offsets), ptr(flatten_ids), n_isects, ptr(packed),
+                                      ptr(alphas), ptr(last_ids), ptr(v_out), ptr(v_alphas), ptr(v_colors),
+                                      ptr(v_opac), ptr(v_m2d), ptr(v_con), bflags, _stream()), "gags_raster_bwd")
         v_bg = None
         if backgrounds is not None and ctx.needs_input_grad[4]:
             v_bg = ((1.0 - alphas)[..., None] * v_out).sum(dim=(0, 1))
-        return v_m2d, v_con, v_colors, v_opac, v_bg, None, None, None, None, None
+        return v_m2d, v_con, v_colors, v_opac, v_bg, None, None, None, None, None, None
 
 
 def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, height,
@@ -249,10 +258,12 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
         bg = None if bg is None else torch.zeros(1, device=bg.device)
 
     with torch.no_grad(), profiler.stage("binning"):
-        isect_ids, flatten_ids, isect_offsets, n_isects = tile_binning(means2d, radii, depths, tiles, width, height)
+        wide = cols.shape[-1] >= 32 and cols.shape[-1] % 32 == 0  # matrix-core path wants packed records
+        isect_ids, flatten_ids, isect_offsets, n_isects, packed = tile_binning(
+            means2d, radii, depths, tiles, width, height, conics if wide else None, _c(opacities) if wide else None)
 
     out, alphas, last_ids = _Rasterize.apply(means2d, conics, cols, opacities, bg, isect_offsets, flatten_ids,
-                                             width, height, int(raster_flags))
+                                             packed, width, height, int(raster_flags))
     if render_mode in ("ED", "RGB+ED"):
         if out.requires_grad:
             out = torch.cat([out[..., :-1], out[..., -1:] / alphas[..., None].clamp(min=1e-10)], dim=-1)

@@ -88,14 +88,24 @@ int gags_sort_pairs(int64_t n_isects, int tile_bits,
 int gags_tile_offsets(int64_t n_isects, const int64_t *sorted_ids, int n_tiles,
                       int32_t *isect_offsets, void *stream);
 
+/* K8b: gather each intersection's 2-D parameters into sorted order: one 32-byte record
+ * {x, y, conic a, b, c, opacity, ex, ey} per sorted intersection, (ex, ey) being the conservative
+ * half-extent of the alpha >= 1/255 footprint.  The wide-D (MFMA) raster kernels stream this
+ * array instead of gathering means2d/conics/opacities per tile.  packed: n_isects * 32 bytes. */
+#define GAGS_PACKED_BYTES 32
+int gags_pack_isects(int64_t n_isects, const int32_t *flatten_ids, const float *means2d,
+                     const float *conics, const float *opacities, void *packed, void *stream);
+
 /* K9 (+K11): rasterize forward, any D >= 1 in ONE pass over the sorted lists (no 32-wide
  * re-walks).  Replaces the compositing stage of gsplat.rasterization for
  * colors[N,D] / backgrounds[D] (gaussian_renderer/__init__.py:61,64).
  * backgrounds may be NULL.  Outputs render_colors[H,W,D], render_alphas[H,W],
- * last_ids[H,W] (sorted index of the last blended Gaussian per pixel). */
+ * last_ids[H,W] (sorted index of the last blended Gaussian per pixel).
+ * D % 32 == 0 with `packed` given runs on the matrix cores, anything else on the VALU kernels. */
 int gags_raster_fwd(int d, int width, int height, const float *means2d, const float *conics,
                     const float *opacities, const float *colors, const float *backgrounds,
                     const int32_t *isect_offsets, const int32_t *flatten_ids, int64_t n_isects,
+                    const void *packed /* from gags_pack_isects, or NULL: VALU kernels only */,
                     float *render_colors, float *render_alphas, int32_t *last_ids,
                     int flags, void *stream);
 
@@ -106,6 +116,7 @@ int gags_raster_fwd(int d, int width, int height, const float *means2d, const fl
 int gags_raster_bwd(int d, int width, int height, const float *means2d, const float *conics,
                     const float *opacities, const float *colors, const float *backgrounds,
                     const int32_t *isect_offsets, const int32_t *flatten_ids, int64_t n_isects,
+                    const void *packed /* from gags_pack_isects, or NULL */,
                     const float *render_alphas, const int32_t *last_ids,
                     const float *v_render_colors, const float *v_render_alphas,
                     float *v_colors, float *v_opacities, float *v_means2d, float *v_conics,

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Collect rocprofv3 PMC counters for bench.py in separate passes (counters only + kernel trace:
+# never combined with sys/runtime traces).  Usage: tools/pmc_passes.sh <outdir> [bench args...]
+set -u
+OUT=$1; shift
+R=$(cd "$(dirname "$0")/.." && pwd)
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+i=0
+while read -r CTRS; do
+  [ -z "$CTRS" ] && continue
+  i=$((i+1))
+  timeout 600 rocprofv3 --kernel-trace --pmc $CTRS -d "$OUT/pass$i" -o pmc --output-format csv -- \
+      python "$R/bench.py" --no-cpu-baseline "$@" > "$OUT/pass$i.log" 2>&1
+done <<'LIST'
+SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE
+SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU
+FETCH_SIZE TCC_ATOMIC
+WRITE_SIZE TCC_HIT TCC_MISS
+TCC_EA0_RDREQ TCC_EA0_WRREQ TCC_EA0_ATOMIC TCC_REQ
+LIST
+python "$R/tools/pmc_summary.py" "$OUT" > "$OUT/summary.txt" 2>&1
+cat "$OUT/summary.txt"

@@ -1,0 +1,41 @@
+#!/usr/bin/env python
+"""Summarise rocprofv3 --pmc passes: per kernel (short name) mean counter value per dispatch."""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    m = re.match(r"([\w:]+(?:<[^()]{0,40}>)?)", name)
+    return (m.group(1) if m else name)[:60]
+
+
+def main():
+    root = sys.argv[1]
+    want = re.compile(sys.argv[2] if len(sys.argv) > 2 else r"raster_|rs_|project|tile_|scan_")
+    acc = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv"), recursive=True):
+        per_dispatch = defaultdict(dict)
+        for row in csv.DictReader(open(f)):
+            k = short(row["Kernel_Name"])
+            if not want.search(k):
+                continue
+            per_dispatch[(k, row["Dispatch_Id"])][row["Counter_Name"]] = \
+                per_dispatch[(k, row["Dispatch_Id"])].get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+        for (k, _), ctrs in per_dispatch.items():
+            for c, v in ctrs.items():
+                acc[k][c].append(v)
+    for k in sorted(acc):
+        print(k)
+        for c in sorted(acc[k]):
+            vals = acc[k][c]
+            print(f"    {c:34s} mean/dispatch {sum(vals) / len(vals):18.1f}   (n={len(vals)})")
+
+
+if __name__ == "__main__":
+    main()
