@@ -35,8 +35,11 @@ SIGNATURES = {
     "gags_sort_pairs": (_i32, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "gags_tile_offsets": (_i32, [_i64, _vp, _i32, _vp, _vp]),
     "gags_pack_isects": (_i32, [_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "gags_raster_fwd": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32,
-                               _vp]),
+    "gags_raster_fwd": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
+                               _i32, _vp]),
+    "gags_bwd_staged_scratch_bytes": (_i64, [_i64, _i32, _i32]),
+    "gags_raster_bwd_colors_staged": (_i32, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp,
+                                             _i64, _vp, _vp]),
     "gags_raster_bwd": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp, _vp, _i32, _vp]),
     "gags_raster_stats": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
@@ -49,6 +52,7 @@ SIGNATURES = {
 
 GAGS_BWD_COLORS_ONLY = 1
 GAGS_FWD_NO_MFMA = 2
+GAGS_BWD_ATOMIC = 4  # python-side: use the atomic colours-only backward instead of the staged one
 
 _lib = None
 

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(64, (NB >= 16 ? 1 : 2)) void raster_fwd_mfma(
     int d, int width, int height, int tile_w, int n_tiles, int n_slices, const GRec *__restrict__ packed,
     const float *__restrict__ colors, const float *__restrict__ backgrounds, const int32_t *__restrict__ offsets,
     const int32_t *__restrict__ flatten_ids, int n_isects, float *__restrict__ render_colors,
-    float *__restrict__ render_alphas, int32_t *__restrict__ last_ids, int dbg)
+    float *__restrict__ render_alphas, int32_t *__restrict__ last_ids, int32_t *__restrict__ blk_rows, int dbg)
 {
     constexpr int CS = 32 * NB;
     constexpr int VEC = NB >= 4 ? 4 : NB;
@@ -231,6 +231,7 @@ __global__ __launch_bounds__(64, (NB >= 16 ? 1 : 2)) void raster_fwd_mfma(
     refill(6);
     float a_n = 0.f;
     int sidx_n = 0;
+    int nrows = 0;  // K-steps that blended anything, x2: the staged backward's row slots for this block
     float4 b0[NG], b1[NG];
     auto kstep = [&](float4(&bc)[NG], float4(&bn)[NG]) -> bool {
         const float a_c = a_n;
@@ -244,6 +245,7 @@ __global__ __launch_bounds__(64, (NB >= 16 ? 1 : 2)) void raster_fwd_mfma(
         bool blended;
         const float wgt = step_pair2(st, __uint_as_float(sw[0]), __uint_as_float(sw[1]), k, blended);
         st.cur = blended ? sidx_c : st.cur;
+        nrows += __any(wgt != 0.f) ? 2 : 0;
 #pragma unroll
         for (int gq = 0; gq < NG; ++gq) {
             const float bv[4] = {bc[gq].x, bc[gq].y, bc[gq].z, bc[gq].w};
@@ -278,6 +280,7 @@ __global__ __launch_bounds__(64, (NB >= 16 ? 1 : 2)) void raster_fwd_mfma(
         render_alphas[pix] = 1.0f - st.T;
         last_ids[pix] = st.cur;
     }
+    if (blk_rows && slice == 0 && lane == 0) blk_rows[tile * 8 + blk] = nrows;
     float bgv[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) bgv[j] = 0.f;
@@ -313,14 +316,14 @@ __global__ __launch_bounds__(64, (NB >= 16 ? 1 : 2)) void raster_fwd_mfma(
 template <int NB>
 int launch_fwd_mfma(int d, int width, int height, const GRec *packed, const float *colors, const float *backgrounds,
                     const int32_t *offsets, const int32_t *flat, int n_isects, float *out, float *alphas,
-                    int32_t *last_ids, int dbg, hipStream_t st)
+                    int32_t *last_ids, int32_t *blk_rows, int dbg, hipStream_t st)
 {
     constexpr int CS = 32 * NB;
     const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
     const int n_tiles = tile_w * tile_h, n_slices = d / CS;
     hipLaunchKernelGGL(raster_fwd_mfma<NB>, dim3(n_tiles * 8 * n_slices), dim3(64), 0, st, d, width, height, tile_w,
                        n_tiles, n_slices, packed, colors, backgrounds, offsets, flat, n_isects, out, alphas, last_ids,
-                       dbg);
+                       blk_rows, dbg);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }
@@ -509,6 +512,297 @@ __global__ __launch_bounds__(64, 2) void raster_bwd_colors_mfma(
     if (nh > 0) flush(nh);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Staged (atomic-free, deterministic) colours-only backward.
+// Float atomics on this multi-XCD part are executed at the memory side (~1.2 TB/s measured,
+// TCC_EA0_ATOMIC == TCC_ATOMIC) while plain stores of the same rows are ~free, so the partial
+// sums are STORED as rows and reduced by a second pass instead:
+//   A  one wave per (tile, 8x4 block): alpha once (not once per channel slice), weights kept as
+//      A-operand tiles wt[row][32 px] in global (L2-hot for pass B), row -> Gaussian map, and the
+//      first 128-channel slice's rows; row slots were counted by the forward (blk_rows) and
+//      prefix-summed, so every row has a fixed address: no atomics, bit-reproducible;
+//   B  one wave per (tile, block, slice >= 1): pure streaming -- weight tile, 64 MFMAs, 32 rows;
+//   C  rows sorted by Gaussian id (radix sort, 32-bit keys), per-Gaussian offsets;
+//   D  v_colors[g] = sum of its rows (written once: no zero-fill of v_colors needed).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64, 2) void raster_bwd_rows_a(
+    int d, int width, int height, int tile_w, int n_tiles, int n_gauss, const GRec *__restrict__ packed,
+    const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids, int n_isects,
+    const float *__restrict__ v_render_colors, const int32_t *__restrict__ blk_rows,
+    const int32_t *__restrict__ row_end /* inclusive cumsum of blk_rows */, float *__restrict__ wt,
+    uint32_t *__restrict__ row_key, int32_t *__restrict__ row_idx, float *__restrict__ prow)
+{
+    __shared__ __attribute__((aligned(16))) HRec ring[RING];
+    __shared__ __attribute__((aligned(16))) float Wt[32 * WT_STRIDE];
+
+    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * 8);
+    const int blk = logical & 7;
+    const int tile = gags_tile_of_order(logical >> 3, tile_w, n_tiles / tile_w);
+    const int cnt = blk_rows[tile * 8 + blk];
+    if (cnt == 0) return;
+    const int base = row_end[tile * 8 + blk] - cnt;
+    const int lane = threadIdx.x;
+    const int p = lane & 31, k = lane >> 5;
+    const int ty = tile / tile_w, tx = tile - ty * tile_w;
+    const int bx0 = tx * GAGS_TILE + (blk & 1) * 8, by0 = ty * GAGS_TILE + (blk >> 1) * 4;
+    const int pj = bx0 + (p & 7), pi = by0 + (p >> 3);
+    const bool inside = (pi < height) && (pj < width);
+    const float px = (float)pj + 0.5f, py = (float)pi + 0.5f;
+    const float rx0 = (float)bx0 + 0.5f, rx1 = (float)bx0 + 7.5f, ry0 = (float)by0 + 0.5f, ry1 = (float)by0 + 3.5f;
+
+    const int start = offsets[tile];
+    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+
+    float V[16][NBB];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int q = 2 * s + k;
+        const int qj = bx0 + (q & 7), qi = by0 + (q >> 3);
+        const bool ok = (qi < height) && (qj < width);
+        const float *src = v_render_colors + ((size_t)(ok ? qi : 0) * width + (ok ? qj : 0)) * d + p;
+#pragma unroll
+        for (int j = 0; j < NBB; ++j) V[s][j] = ok ? src[32 * j] : 0.f;
+    }
+
+    PixState st;
+    st.T = 1.0f; st.cur = 0; st.done = !inside;
+
+    int nq = 0, rd = 0;
+    int c = start;
+    GRec pre;
+    int pre_gid = 0, pre_c = start;
+    auto issue = [&]() {
+        pre_c = c;
+        const int idx = c + lane;
+        if (idx < end) {
+            const float4 *src = reinterpret_cast<const float4 *>(packed + idx);
+            const float4 u = src[0], v = src[1];
+            pre.x = u.x; pre.y = u.y; pre.a = u.z; pre.b = u.w; pre.c = v.x; pre.o = v.y; pre.ex = v.z; pre.ey = v.w;
+            pre_gid = flatten_ids[idx];
+        } else {
+            pre.x = pre.y = 0.f; pre.ex = pre.ey = -1.f; pre.a = pre.b = pre.c = pre.o = 0.f;
+        }
+        c += 64;
+    };
+    auto commit = [&]() {
+        const bool hit = (pre_c + lane < end) && (pre.x + pre.ex >= rx0) && (pre.x - pre.ex <= rx1) &&
+                         (pre.y + pre.ey >= ry0) && (pre.y - pre.ey <= ry1);
+        const unsigned long long mask = __ballot(hit);
+        if (hit) {
+            const int pos = nq + __popcll(mask & ((1ull << lane) - 1ull));
+            HRec h;
+            h.x = pre.x; h.y = pre.y; h.a = pre.a; h.b = pre.b; h.c = pre.c; h.o = pre.o;
+            h.gid = pre_gid; h.sidx = pre_c + lane;
+            ring[pos & (RING - 1)] = h;
+        }
+        nq += __popcll(mask);
+    };
+    bool pending = false;
+    if (c < end) { issue(); pending = true; }
+    auto refill = [&](int low) {
+        while ((nq - rd) < low && pending) {
+            commit();
+            pending = false;
+            if (c < end) { issue(); pending = true; }
+        }
+    };
+    auto eval_at = [&](int pos, int &gid) {
+        const bool valid = pos + k < nq;
+        const HRec h = ring[min(pos + k, nq - 1) & (RING - 1)];
+        GRec r;
+        r.x = h.x; r.y = h.y; r.a = h.a; r.b = h.b; r.c = h.c; r.o = h.o;
+        gid = valid ? h.gid : n_gauss;  // the unused slot of a lone last hit sorts behind every Gaussian
+        return eval_alpha(r, px, py, valid);
+    };
+
+    int nh = 0;    // slots filled in the current 32-slot tile
+    int row0 = base;  // first row of the current tile
+    const int wpos = (p & 1) * 16 + (p >> 1);
+
+    auto flush = [&](int count) {
+        float A[16];
+        const float4 *rowp = reinterpret_cast<const float4 *>(Wt + p * WT_STRIDE + k * 16);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float4 v = rowp[t];
+            A[4 * t] = v.x; A[4 * t + 1] = v.y; A[4 * t + 2] = v.z; A[4 * t + 3] = v.w;
+        }
+        f32x16 acc[NBB];
+#pragma unroll
+        for (int j = 0; j < NBB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int j = 0; j < NBB; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s], V[s][j], acc[j], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int slot = (r & 3) + 8 * (r >> 2) + 4 * k;
+            if (slot < count) {
+                float *dst = prow + (size_t)(row0 + slot) * d + p;
+#pragma unroll
+                for (int j = 0; j < NBB; ++j) dst[32 * j] = acc[j][r];
+            }
+        }
+        row0 += 32;
+    };
+
+    refill(6);
+    if (!__all(st.done) && rd < nq) {
+        int gid_n;
+        float a_n = eval_at(rd, gid_n);
+        auto kstep = [&]() -> bool {
+            const float a_c = a_n;
+            const int gid_c = gid_n;
+            rd += 2;
+            if ((nq - rd) < 6 && pending) refill(6);
+            const bool more = rd < nq;
+            a_n = eval_at(rd, gid_n);
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a_c), __float_as_uint(a_c), false, false);
+            bool blended;
+            const float wgt = step_pair2(st, __uint_as_float(sw[0]), __uint_as_float(sw[1]), k, blended);
+            if (__any(wgt != 0.f)) {  // same predicate as the forward's row count
+                const int row = row0 + nh + k;
+                Wt[(nh + k) * WT_STRIDE + wpos] = wgt;
+                wt[(size_t)row * 32 + wpos] = wgt;  // A-operand image for pass B: 2 x 128 B per step
+                if (p == 0) { row_key[row] = (uint32_t)gid_c; row_idx[row] = row; }
+                nh += 2;
+                if (nh == 32) { flush(32); nh = 0; }
+            }
+            return more && !__all(st.done);
+        };
+        bool go = true;
+        while (go) {  // mirrors the forward's two-steps-per-trip loop so the row counts agree
+            kstep();
+            go = kstep();
+        }
+    }
+    if (nh > 0) flush(nh);
+}
+
+__global__ __launch_bounds__(64, 2) void raster_bwd_rows_b(
+    int d, int width, int height, int tile_w, int n_tiles, int n_slices_b, const float *__restrict__ v_render_colors,
+    const int32_t *__restrict__ blk_rows, const int32_t *__restrict__ row_end, const float *__restrict__ wt,
+    float *__restrict__ prow)
+{
+    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * 8 * n_slices_b);
+    const int slice = 1 + logical % n_slices_b, rest = logical / n_slices_b;
+    const int blk = rest & 7;
+    const int tile = gags_tile_of_order(rest >> 3, tile_w, n_tiles / tile_w);
+    const int cnt = blk_rows[tile * 8 + blk];
+    if (cnt == 0) return;
+    const int base = row_end[tile * 8 + blk] - cnt;
+    const int ch0 = slice * CSB;
+    const int lane = threadIdx.x;
+    const int p = lane & 31, k = lane >> 5;
+    const int ty = tile / tile_w, tx = tile - ty * tile_w;
+    const int bx0 = tx * GAGS_TILE + (blk & 1) * 8, by0 = ty * GAGS_TILE + (blk >> 1) * 4;
+
+    float V[16][NBB];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int q = 2 * s + k;
+        const int qj = bx0 + (q & 7), qi = by0 + (q >> 3);
+        const bool ok = (qi < height) && (qj < width);
+        const float *src = v_render_colors + ((size_t)(ok ? qi : 0) * width + (ok ? qj : 0)) * d + ch0 + p;
+#pragma unroll
+        for (int j = 0; j < NBB; ++j) V[s][j] = ok ? src[32 * j] : 0.f;
+    }
+    // weight tile of M-block m: rows base+32m .. +31, lane (i=p, k) owns 16 consecutive floats
+    auto load_a = [&](int m, float4(&a)[4]) {
+        const float4 *src = reinterpret_cast<const float4 *>(wt + (size_t)(base + 32 * m + p) * 32 + k * 16);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = src[t];
+    };
+    const int nblocks = (cnt + 31) >> 5;
+    float4 an[4];
+    load_a(0, an);
+    for (int m = 0; m < nblocks; ++m) {
+        float A[16];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { A[4 * t] = an[t].x; A[4 * t + 1] = an[t].y; A[4 * t + 2] = an[t].z; A[4 * t + 3] = an[t].w; }
+        load_a(min(m + 1, nblocks - 1), an);  // prefetch
+        f32x16 acc[NBB];
+#pragma unroll
+        for (int j = 0; j < NBB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int j = 0; j < NBB; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s], V[s][j], acc[j], 0, 0, 0);
+        const int count = min(32, cnt - 32 * m);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int slot = (r & 3) + 8 * (r >> 2) + 4 * k;
+            if (slot < count) {
+                float *dst = prow + (size_t)(base + 32 * m + slot) * d + ch0 + p;
+#pragma unroll
+                for (int j = 0; j < NBB; ++j) dst[32 * j] = acc[j][r];
+            }
+        }
+    }
+}
+
+// seg[g] = first sorted position whose key is >= g, for g in [0, n_keys]; seg[n_keys] = n (keys < n_keys valid)
+__global__ __launch_bounds__(256) void seg_offsets_kernel(int n, const uint32_t *__restrict__ sorted_keys, int n_keys,
+                                                          int32_t *__restrict__ seg)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int cur = min((int)sorted_keys[i], n_keys);
+    if (i == 0) {
+        for (int g = 0; g <= cur; ++g) seg[g] = 0;
+    } else {
+        const int prev = min((int)sorted_keys[i - 1], n_keys);
+        for (int g = prev + 1; g <= cur; ++g) seg[g] = i;
+    }
+    if (i == n - 1)
+        for (int g = cur + 1; g <= n_keys; ++g) seg[g] = n;
+}
+
+__global__ void seg_fill_kernel(int n_keys, int32_t *__restrict__ seg)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g <= n_keys) seg[g] = 0;
+}
+
+// v_colors[g, :] = sum over the Gaussian's rows (in sorted = deterministic order); float4 per lane
+__global__ __launch_bounds__(256) void reduce_rows_kernel(int n_gauss, int d, const int32_t *__restrict__ seg,
+                                                          const int32_t *__restrict__ sorted_rows,
+                                                          const float *__restrict__ prow, float *__restrict__ v_colors)
+{
+    const int lpg = d >> 2;                       // lanes per Gaussian
+    const int gpb = 256 / lpg;                    // Gaussians per block
+    const int gl = threadIdx.x / lpg;
+    const int g = blockIdx.x * gpb + gl;
+    const int cl = (threadIdx.x % lpg) * 4;
+    if (gl >= gpb || g >= n_gauss) return;
+    const int b = seg[g], e = seg[g + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int i = b;
+    for (; i + 3 < e; i += 4) {
+        const int r0 = sorted_rows[i], r1 = sorted_rows[i + 1], r2 = sorted_rows[i + 2], r3 = sorted_rows[i + 3];
+        const float4 v0 = *reinterpret_cast<const float4 *>(prow + (size_t)r0 * d + cl);
+        const float4 v1 = *reinterpret_cast<const float4 *>(prow + (size_t)r1 * d + cl);
+        const float4 v2 = *reinterpret_cast<const float4 *>(prow + (size_t)r2 * d + cl);
+        const float4 v3 = *reinterpret_cast<const float4 *>(prow + (size_t)r3 * d + cl);
+        acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+        acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+        acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+        acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+    }
+    for (; i < e; ++i) {
+        const float4 v0 = *reinterpret_cast<const float4 *>(prow + (size_t)sorted_rows[i] * d + cl);
+        acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+    }
+    *reinterpret_cast<float4 *>(v_colors + (size_t)g * d + cl) = acc;
+}
+
 int launch_bwd_colors_mfma(int d, int width, int height, const GRec *packed, const int32_t *offsets,
                            const int32_t *flat, int n_isects, const float *v_out, float *v_colors, int dbg,
                            hipStream_t st)
@@ -538,11 +832,11 @@ int gags_pack_isects_launch(int n_isects, const int32_t *flat, const float *mean
 // back to the VALU kernels), negative on error.
 int gags_raster_fwd_mfma(int d, int width, int height, const void *packed, const float *colors,
                          const float *backgrounds, const int32_t *offsets, const int32_t *flat, int n_isects,
-                         float *out, float *alphas, int32_t *last_ids, int dbg, hipStream_t st)
+                         float *out, float *alphas, int32_t *last_ids, int32_t *blk_rows, int dbg, hipStream_t st)
 {
     GAGS_CLEAR_ERR();
     const GRec *pk = reinterpret_cast<const GRec *>(packed);
-#define ARGS d, width, height, pk, colors, backgrounds, offsets, flat, n_isects, out, alphas, last_ids, dbg, st
+#define ARGS d, width, height, pk, colors, backgrounds, offsets, flat, n_isects, out, alphas, last_ids, blk_rows, dbg, st
     if (d < 32 || d % 32 != 0) return 1;
     if (d % 256 == 0) return launch_fwd_mfma<8>(ARGS);
     if (d % 128 == 0) return launch_fwd_mfma<4>(ARGS);
@@ -560,4 +854,75 @@ int gags_raster_bwd_colors_mfma(int d, int width, int height, const void *packed
     if (d < CSB || d % CSB != 0) return 1;
     return launch_bwd_colors_mfma(d, width, height, reinterpret_cast<const GRec *>(packed), offsets, flat, n_isects,
                                   v_out, v_colors, dbg, st);
+}
+
+int64_t gags_sort_u32_scratch_bytes(int64_t n);
+int gags_sort_pairs_u32(int64_t n, int nbits, const uint32_t *keys_in, const int32_t *vals_in, uint32_t *keys_out,
+                        int32_t *vals_out, void *scratch, int64_t scratch_bytes, hipStream_t st);
+
+namespace {
+struct StagedLayout {
+    int64_t wt, key, idx, key_s, idx_s, seg, sort, prow, total;
+};
+inline int64_t al256(int64_t x) { return (x + 255) / 256 * 256; }
+inline StagedLayout staged_layout(int64_t rows, int n_gauss, int d)
+{
+    StagedLayout L;
+    int64_t o = 0;
+    L.wt = o; o += al256((rows + 64) * 128);          // A-operand tiles, 128 B per row (+ slack for the prefetch)
+    L.key = o; o += al256(rows * 4);
+    L.idx = o; o += al256(rows * 4);
+    L.key_s = o; o += al256(rows * 4);
+    L.idx_s = o; o += al256(rows * 4);
+    L.seg = o; o += al256(((int64_t)n_gauss + 2) * 4);
+    L.sort = o; o += al256(gags_sort_u32_scratch_bytes(rows));
+    L.prow = o; o += al256(rows * (int64_t)d * 4);
+    L.total = o;
+    return L;
+}
+}  // namespace
+
+int64_t gags_bwd_staged_scratch_bytes_impl(int64_t rows, int n_gauss, int d)
+{
+    return staged_layout(rows > 0 ? rows : 1, n_gauss, d).total;
+}
+
+// 1 = not eligible (d % 128 != 0)
+int gags_raster_bwd_colors_staged(int d, int width, int height, int n_gauss, const void *packed,
+                                  const int32_t *offsets, const int32_t *flat, int n_isects, const float *v_out,
+                                  const int32_t *blk_rows, const int32_t *row_end, int64_t rows, void *scratch,
+                                  int64_t scratch_bytes, float *v_colors, hipStream_t st)
+{
+    GAGS_CLEAR_ERR();
+    if (d < CSB || d % CSB != 0 || d > 1024) return 1;
+    const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
+    const int n_tiles = tile_w * tile_h, n_slices = d / CSB;
+    const StagedLayout L = staged_layout(rows > 0 ? rows : 1, n_gauss, d);
+    if (scratch_bytes < L.total) return GAGS_ESCRATCH;
+    char *sb = (char *)scratch;
+    float *wt = (float *)(sb + L.wt);
+    uint32_t *key = (uint32_t *)(sb + L.key), *key_s = (uint32_t *)(sb + L.key_s);
+    int32_t *idx = (int32_t *)(sb + L.idx), *idx_s = (int32_t *)(sb + L.idx_s), *seg = (int32_t *)(sb + L.seg);
+    float *prow = (float *)(sb + L.prow);
+    const GRec *pk = reinterpret_cast<const GRec *>(packed);
+    if (rows > 0) {
+        hipLaunchKernelGGL(raster_bwd_rows_a, dim3(n_tiles * 8), dim3(64), 0, st, d, width, height, tile_w, n_tiles,
+                           n_gauss, pk, offsets, flat, n_isects, v_out, blk_rows, row_end, wt, key, idx, prow);
+        if (n_slices > 1)
+            hipLaunchKernelGGL(raster_bwd_rows_b, dim3(n_tiles * 8 * (n_slices - 1)), dim3(64), 0, st, d, width, height,
+                               tile_w, n_tiles, n_slices - 1, v_out, blk_rows, row_end, wt, prow);
+        int nbits = 1;
+        while ((1ll << nbits) <= n_gauss) ++nbits;  // keys in [0, n_gauss]
+        const int rc = gags_sort_pairs_u32(rows, nbits, key, idx, key_s, idx_s, sb + L.sort, L.prow - L.sort, st);
+        if (rc != GAGS_OK) return rc;
+        hipLaunchKernelGGL(seg_offsets_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, (int)rows, key_s,
+                           n_gauss, seg);
+    } else {
+        hipLaunchKernelGGL(seg_fill_kernel, dim3((n_gauss + 1 + 255) / 256), dim3(256), 0, st, n_gauss, seg);
+    }
+    const int gpb = 256 / (d >> 2);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((n_gauss + gpb - 1) / gpb), dim3(256), 0, st, n_gauss, d, seg, idx_s,
+                       prow, v_colors);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
 }

@@ -18,7 +18,8 @@ constexpr int RS_ITEMS = 8;
 constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // 2048 pairs per block
 constexpr int RS_RADIX = 256;
 
-__global__ __launch_bounds__(RS_THREADS) void rs_histogram(int64_t n, int shift, const uint64_t *__restrict__ keys,
+template <typename K>
+__global__ __launch_bounds__(RS_THREADS) void rs_histogram(int64_t n, int shift, const K *__restrict__ keys,
                                                            uint32_t *__restrict__ hist /*[RADIX][nblocks]*/,
                                                            int nblocks)
 {
@@ -37,9 +38,10 @@ __global__ __launch_bounds__(RS_THREADS) void rs_histogram(int64_t n, int shift,
 
 // Stable scatter.  Items are laid out blocked-by-wave so that (wave, item, lane) order is the
 // input order: wave w owns [w*512, (w+1)*512) of the tile, item k covers 64 consecutive keys.
-__global__ __launch_bounds__(RS_THREADS) void rs_scatter(int64_t n, int shift, const uint64_t *__restrict__ keys_in,
+template <typename K>
+__global__ __launch_bounds__(RS_THREADS) void rs_scatter(int64_t n, int shift, const K *__restrict__ keys_in,
                                                          const int32_t *__restrict__ vals_in,
-                                                         uint64_t *__restrict__ keys_out,
+                                                         K *__restrict__ keys_out,
                                                          int32_t *__restrict__ vals_out,
                                                          const uint32_t *__restrict__ hist, int nblocks)
 {
@@ -53,14 +55,14 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(int64_t n, int shift, c
     __syncthreads();
 
     const int64_t wbase = (int64_t)blockIdx.x * RS_TILE + (int64_t)w * (64 * RS_ITEMS);
-    uint64_t key[RS_ITEMS];
+    K key[RS_ITEMS];
     int32_t val[RS_ITEMS];
     uint32_t rank[RS_ITEMS];  // rank of the key among same-digit keys of THIS wave (input order)
 #pragma unroll
     for (int k = 0; k < RS_ITEMS; ++k) {
         const int64_t i = wbase + k * 64 + lane;
         const bool ok = i < n;
-        key[k] = ok ? keys_in[i] : ~0ull;
+        key[k] = ok ? keys_in[i] : (K)~(K)0;
         val[k] = ok ? vals_in[i] : 0;
         const uint32_t dgt = ok ? (uint32_t)((key[k] >> shift) & 0xff) : 0xffffffffu;
         // match-any over the wave: mask of lanes holding the same digit (8 ballots)
@@ -107,17 +109,63 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(int64_t n, int shift, c
     }
 }
 
-}  // namespace
-
-extern "C" int64_t gags_sort_scratch_bytes(int64_t n_isects)
+template <typename K>
+int64_t sort_scratch_bytes_t(int64_t n_in)
 {
-    const int64_t n = n_isects > 0 ? n_isects : 1;
+    const int64_t n = n_in > 0 ? n_in : 1;
     const int64_t nblocks = (n + RS_TILE - 1) / RS_TILE;
-    // ping-pong pair buffers (keys + values) + histogram
-    const int64_t keys = ((n * 8 + 255) / 256) * 256, vals = ((n * 4 + 255) / 256) * 256;
+    const int64_t keys = ((n * (int64_t)sizeof(K) + 255) / 256) * 256, vals = ((n * 4 + 255) / 256) * 256;
     const int64_t hist = ((nblocks * RS_RADIX * 4 + 255) / 256) * 256;
     return keys + vals + hist + gags_scan::scratch_bytes(nblocks * RS_RADIX);
 }
+
+// stable LSD sort of (key, value) pairs on key bits [0, nbits); ping-pongs through `scratch` so that the
+// last pass lands in keys_out / vals_out.
+template <typename K>
+int sort_pairs_t(int64_t n, int nbits, const K *keys_in, const int32_t *vals_in, K *keys_out, int32_t *vals_out,
+                 void *scratch, int64_t scratch_bytes, hipStream_t st)
+{
+    if (n == 0) return GAGS_OK;
+    if (n < 0 || n >= (1ll << 31) || nbits <= 0 || nbits > (int)(8 * sizeof(K))) return GAGS_EINVAL;
+    if (!keys_in || !vals_in || !keys_out || !vals_out || !scratch) return GAGS_EINVAL;
+    if (scratch_bytes < sort_scratch_bytes_t<K>(n)) return GAGS_ESCRATCH;
+    const int nblocks = (int)((n + RS_TILE - 1) / RS_TILE);
+    const int64_t keys_b = ((n * (int64_t)sizeof(K) + 255) / 256) * 256, vals_b = ((n * 4 + 255) / 256) * 256;
+    K *ktmp = (K *)scratch;
+    int32_t *vtmp = (int32_t *)((char *)scratch + keys_b);
+    uint32_t *hist = (uint32_t *)((char *)scratch + keys_b + vals_b);
+    const int64_t hist_b = (((int64_t)nblocks * RS_RADIX * 4 + 255) / 256) * 256;
+    int32_t *scan_tmp = (int32_t *)((char *)scratch + keys_b + vals_b + hist_b);
+    const int passes = (nbits + 7) / 8;
+    const K *src_k = keys_in;
+    const int32_t *src_v = vals_in;
+    for (int p = 0; p < passes; ++p) {
+        const bool to_out = ((passes - 1 - p) % 2) == 0;
+        K *dst_k = to_out ? keys_out : ktmp;
+        int32_t *dst_v = to_out ? vals_out : vtmp;
+        hipLaunchKernelGGL(rs_histogram<K>, dim3(nblocks), dim3(RS_THREADS), 0, st, n, p * 8, src_k, hist, nblocks);
+        gags_scan::launch<true>(RS_RADIX * nblocks, (const int32_t *)hist, (int32_t *)hist, nullptr, scan_tmp, st);
+        hipLaunchKernelGGL(rs_scatter<K>, dim3(nblocks), dim3(RS_THREADS), 0, st, n, p * 8, src_k, src_v, dst_k, dst_v,
+                           hist, nblocks);
+        src_k = dst_k;
+        src_v = dst_v;
+    }
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+}  // namespace
+
+// internal: 32-bit-key flavour used by the staged backward (rows sorted by Gaussian id)
+int64_t gags_sort_u32_scratch_bytes(int64_t n) { return sort_scratch_bytes_t<uint32_t>(n); }
+int gags_sort_pairs_u32(int64_t n, int nbits, const uint32_t *keys_in, const int32_t *vals_in, uint32_t *keys_out,
+                        int32_t *vals_out, void *scratch, int64_t scratch_bytes, hipStream_t st)
+{
+    GAGS_CLEAR_ERR();
+    return sort_pairs_t<uint32_t>(n, nbits, keys_in, vals_in, keys_out, vals_out, scratch, scratch_bytes, st);
+}
+
+extern "C" int64_t gags_sort_scratch_bytes(int64_t n_isects) { return sort_scratch_bytes_t<uint64_t>(n_isects); }
 
 extern "C" int gags_sort_pairs(int64_t n, int tile_bits, const int64_t *keys_in, const int32_t *vals_in,
                                int64_t *keys_out, int32_t *vals_out, void *scratch, int64_t scratch_bytes,
@@ -125,35 +173,6 @@ extern "C" int gags_sort_pairs(int64_t n, int tile_bits, const int64_t *keys_in,
 {
     GAGS_CLEAR_ERR();
     if (n < 0 || tile_bits < 0 || tile_bits > 31) return GAGS_EINVAL;
-    if (n == 0) return GAGS_OK;
-    if (n >= (1ll << 31)) return GAGS_EINVAL;
-    if (!keys_in || !vals_in || !keys_out || !vals_out || !scratch) return GAGS_EINVAL;
-    if (scratch_bytes < gags_sort_scratch_bytes(n)) return GAGS_ESCRATCH;
-    hipStream_t st = (hipStream_t)stream;
-    const int nblocks = (int)((n + RS_TILE - 1) / RS_TILE);
-    const int64_t keys_b = ((n * 8 + 255) / 256) * 256, vals_b = ((n * 4 + 255) / 256) * 256;
-    uint64_t *ktmp = (uint64_t *)scratch;
-    int32_t *vtmp = (int32_t *)((char *)scratch + keys_b);
-    uint32_t *hist = (uint32_t *)((char *)scratch + keys_b + vals_b);
-    const int64_t hist_b = (((int64_t)nblocks * RS_RADIX * 4 + 255) / 256) * 256;
-    int32_t *scan_tmp = (int32_t *)((char *)scratch + keys_b + vals_b + hist_b);
-
-    const int nbits = 32 + tile_bits;
-    const int passes = (nbits + 7) / 8;
-    // arrange the ping-pong so the last pass lands in keys_out/vals_out
-    const uint64_t *src_k = (const uint64_t *)keys_in;
-    const int32_t *src_v = vals_in;
-    for (int p = 0; p < passes; ++p) {
-        const bool to_out = ((passes - 1 - p) % 2) == 0;
-        uint64_t *dst_k = to_out ? (uint64_t *)keys_out : ktmp;
-        int32_t *dst_v = to_out ? vals_out : vtmp;
-        hipLaunchKernelGGL(rs_histogram, dim3(nblocks), dim3(RS_THREADS), 0, st, n, p * 8, src_k, hist, nblocks);
-        gags_scan::launch<true>(RS_RADIX * nblocks, (const int32_t *)hist, (int32_t *)hist, nullptr, scan_tmp, st);
-        hipLaunchKernelGGL(rs_scatter, dim3(nblocks), dim3(RS_THREADS), 0, st, n, p * 8, src_k, src_v, dst_k, dst_v,
-                           hist, nblocks);
-        src_k = dst_k;
-        src_v = dst_v;
-    }
-    GAGS_CHECK_LAUNCH();
-    return GAGS_OK;
+    return sort_pairs_t<uint64_t>(n, 32 + tile_bits, (const uint64_t *)keys_in, vals_in, (uint64_t *)keys_out, vals_out,
+                                  scratch, scratch_bytes, (hipStream_t)stream);
 }

@@ -167,12 +167,20 @@ class _Rasterize(torch.autograd.Function):
         out = torch.empty(height, width, d, device=dev)
         alphas = torch.empty(height, width, device=dev)
         last_ids = torch.empty(height, width, dtype=torch.int32, device=dev)
+        # row-slot counts for the staged (atomic-free) colours-only backward: only when the matrix-core
+        # path runs, the width fits it, and someone will ask for d loss / d colors
+        blk_rows = None
+        staged_ok = (packed is not None and d % 128 == 0 and d <= 1024 and ctx.needs_input_grad[2]
+                     and not (flags & (_lib.GAGS_FWD_NO_MFMA | _lib.GAGS_BWD_ATOMIC)))
+        if staged_ok:
+            blk_rows = torch.zeros(offsets.numel() * 8, dtype=torch.int32, device=dev)
         with profiler.stage("raster_fwd"):
             check(lib.gags_raster_fwd(d, width, height, ptr(means2d), ptr(conics), ptr(opacities), ptr(colors),
                                       ptr(backgrounds), ptr(offsets), ptr(flatten_ids), n_isects, ptr(packed),
-                                      ptr(out), ptr(alphas), ptr(last_ids), flags, _stream()), "gags_raster_fwd")
+                                      ptr(out), ptr(alphas), ptr(last_ids), ptr(blk_rows), flags & 0xffffff03,
+                                      _stream()), "gags_raster_fwd")
         ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, packed, alphas,
-                              last_ids)
+                              last_ids, blk_rows)
         ctx.cfg = (width, height, flags)
         ctx.mark_non_differentiable(last_ids)
         return out, alphas, last_ids
@@ -181,7 +189,7 @@ class _Rasterize(torch.autograd.Function):
     def backward(ctx, v_out, v_alphas, _v_last):
         lib = _lib.load()
         (means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, packed, alphas,
-         last_ids) = ctx.saved_tensors
+         last_ids, blk_rows) = ctx.saved_tensors
         width, height, flags = ctx.cfg
         n, d = colors.shape
         dev = colors.device
@@ -189,6 +197,9 @@ class _Rasterize(torch.autograd.Function):
         need_geom = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[3]
         v_out = torch.zeros(height, width, d, device=dev) if v_out is None else _c(v_out)
         v_alphas = None if v_alphas is None else _c(v_alphas)
+        if not need_geom and blk_rows is not None:
+            return _Rasterize._backward_staged(lib, ctx, packed, offsets, flatten_ids, blk_rows, v_out, n, d, width,
+                                               height, backgrounds, alphas)
         v_colors = torch.zeros(n, d, device=dev)
         if need_geom:
             v_opac = torch.zeros(n, device=dev)
@@ -207,6 +218,37 @@ class _Rasterize(torch.autograd.Function):
         if backgrounds is not None and ctx.needs_input_grad[4]:
             v_bg = ((1.0 - alphas)[..., None] * v_out).sum(dim=(0, 1))
         return v_m2d, v_con, v_colors, v_opac, v_bg, None, None, None, None, None, None
+
+
+def _backward_staged(lib, ctx, packed, offsets, flatten_ids, blk_rows, v_out, n, d, width, height, backgrounds, alphas):
+    """Colours-only backward without atomics: rows counted by the forward -> prefix sum -> one 4-byte
+    readback (total rows) -> stored partial rows -> sort by Gaussian -> segmented sum."""
+    dev = v_out.device
+    st = _stream()
+    nb = blk_rows.numel()
+    row_end = torch.empty(nb, dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.int32, device=dev)
+    sb = lib.gags_scan_scratch_bytes(nb)
+    stmp = torch.empty(sb, dtype=torch.uint8, device=dev)
+    with profiler.stage("raster_bwd"):
+        check(lib.gags_cumsum_i32(nb, ptr(blk_rows), ptr(row_end), ptr(total), ptr(stmp), sb, st), "gags_cumsum_i32")
+        host = ctypes.c_int32(0)
+        check(lib.gags_read_i32(ptr(total), ctypes.byref(host), st), "gags_read_i32")
+        rows = int(host.value)
+        nbytes = lib.gags_bwd_staged_scratch_bytes(rows, n, d)
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        v_colors = torch.empty(n, d, device=dev)
+        check(lib.gags_raster_bwd_colors_staged(d, width, height, n, ptr(packed), ptr(offsets), ptr(flatten_ids),
+                                                flatten_ids.shape[0], ptr(v_out), ptr(blk_rows), ptr(row_end), rows,
+                                                ptr(scratch), nbytes, ptr(v_colors), st),
+              "gags_raster_bwd_colors_staged")
+    v_bg = None
+    if backgrounds is not None and ctx.needs_input_grad[4]:
+        v_bg = ((1.0 - alphas)[..., None] * v_out).sum(dim=(0, 1))
+    return None, None, v_colors, None, v_bg, None, None, None, None, None, None
+
+
+_Rasterize._backward_staged = staticmethod(_backward_staged)
 
 
 def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, height,

@@ -107,6 +107,8 @@ int gags_raster_fwd(int d, int width, int height, const float *means2d, const fl
                     const int32_t *isect_offsets, const int32_t *flatten_ids, int64_t n_isects,
                     const void *packed /* from gags_pack_isects, or NULL: VALU kernels only */,
                     float *render_colors, float *render_alphas, int32_t *last_ids,
+                    int32_t *blk_rows /* optional [tile_h*tile_w*8]: row slots the staged backward
+                                         will need per 8x4 pixel block (MFMA path only), or NULL */,
                     int flags, void *stream);
 
 /* K10: rasterize backward (what autograd runs under train.py:174).
@@ -121,6 +123,18 @@ int gags_raster_bwd(int d, int width, int height, const float *means2d, const fl
                     const float *v_render_colors, const float *v_render_alphas,
                     float *v_colors, float *v_opacities, float *v_means2d, float *v_conics,
                     int flags, void *stream);
+
+/* K10, staged flavour: colours-only backward WITHOUT atomics (deterministic).  Needs the
+ * blk_rows written by gags_raster_fwd, their inclusive prefix sum row_end (gags_cumsum_i32) and
+ * its total `rows` (gags_read_i32).  Partial sums are stored as rows, sorted by Gaussian and
+ * reduced; v_colors[N,D] is written in full (no zero-fill needed).  D % 128 == 0, D <= 1024.
+ * scratch: gags_bwd_staged_scratch_bytes(rows, n, d) bytes.  Returns 1 when D is not eligible. */
+int64_t gags_bwd_staged_scratch_bytes(int64_t rows, int n, int d);
+int gags_raster_bwd_colors_staged(int d, int width, int height, int n, const void *packed,
+                                  const int32_t *isect_offsets, const int32_t *flatten_ids,
+                                  int64_t n_isects, const float *v_render_colors,
+                                  const int32_t *blk_rows, const int32_t *row_end, int64_t rows,
+                                  void *scratch, int64_t scratch_bytes, float *v_colors, void *stream);
 
 /* Diagnostics (roofline model): counts[0] += (pixel,Gaussian) pairs evaluated
  * before each pixel's stop, counts[1] += pairs blended.  counts[2] int64, zeroed by caller. */
