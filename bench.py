@@ -199,16 +199,33 @@ def main():
     value = world * args.steps / dt  # every rank renders one view per step (weak scaling)
 
     if rank == 0:
-        # dominant kernel and its roofline.  Algorithmic flops per launch (DESIGN.md "Roofline"):
-        #   raster fwd           : 14*Q_eval + 2*D*Q_blend
-        #   raster bwd (colours) : 14*Q_eval + 2*D*Q_blend
-        dom = max(("raster_fwd", "raster_bwd"), key=lambda k: stages.get(k, (0, 0))[0])
-        dom_ms = stages[dom][0]
-        flops = 14.0 * q_eval + 2.0 * d * q_blend
-        achieved = flops / (dom_ms * 1e-3) / 1e12
-        pix = width * height
-        alg_bytes = {"raster_fwd": 12.0 * n_isects + 4.0 * n_visible * d + pix * (4.0 * d + 8),
-                     "raster_bwd": 12.0 * n_isects + pix * (4.0 * d + 8) + 4.0 * n_visible * d}[dom]
+        # Per-kernel roofline.  Each entry is ONE kernel bracketed by HIP events on the
+        # launch stream; algorithmic work per launch:
+        #   raster_fwd  : 14*Q_eval + 2*D*Q_blend flops              (fp32 MFMA bound)
+        #   bwd_rows_a  : 14*Q_eval + 2*128*Q_blend flops            (alpha once + first 128-channel slice)
+        #   bwd_rows_b  : 2*(D-128)*Q_blend flops                    (remaining slices, pure MFMA + row stores)
+        #   bwd_reduce  : rows*D*4 read + N*D*4 written bytes        (HBM bound segmented sum)
+        #   raster_bwd  : 14*Q_eval + 2*D*Q_blend flops              (single-kernel atomic backward, if used)
+        rows = profiler.notes().get("bwd_rows", 0)
+        work = {
+            "raster_fwd": ("mfma", 14.0 * q_eval + 2.0 * d * q_blend),
+            "bwd_rows_a": ("mfma", 14.0 * q_eval + 2.0 * min(d, 128) * q_blend),
+            "bwd_rows_b": ("mfma", 2.0 * max(d - 128, 0) * q_blend),
+            "bwd_reduce": ("hbm", 4.0 * d * (rows + n)),
+            "raster_bwd": ("mfma", 14.0 * q_eval + 2.0 * d * q_blend),
+        }
+        kernels = {}
+        for name, (bound, amount) in work.items():
+            if name in stages and stages[name][0] > 0:
+                ms = stages[name][0]
+                if bound == "mfma":
+                    ach, peak, unit = amount / (ms * 1e-3) / 1e12, FP32_MATRIX_PEAK_TFLOPS, "TFLOP/s"
+                else:
+                    ach, peak, unit = amount / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+                kernels[name] = {"bound": bound, "avg_launch_ms": ms, "achieved": ach, "peak": peak, "unit": unit,
+                                 "frac": ach / peak}
+        dom = max(kernels, key=lambda k_: kernels[k_]["avg_launch_ms"])
+        roof = dict(kernels[dom], kernel=dom, traffic=None)
         line = {
             "metric": "feature-raster fwd+bwd views/s",
             "value": value, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -217,11 +234,9 @@ def main():
             "config": {"workload": f"{args.config}: {n} Gaussians, {width}x{height}, D={d}, 1 view/GPU/step",
                        "n_gaussians": n, "width": width, "height": height, "feature_dim": d,
                        "visible": n_visible, "n_isects": n_isects, "pairs_evaluated": q_eval,
-                       "pairs_blended": q_blend, "parallelism": f"view-dp{world}"},
-            "roofline": {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
-                         "avg_launch_ms": dom_ms, "algorithmic_flops": flops,
-                         "hbm_frac_of_same_kernel": alg_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                       "pairs_blended": q_blend, "bwd_rows": rows, "parallelism": f"view-dp{world}"},
+            "roofline": roof,
+            "kernels": kernels,
             "stages_ms": {k: round(v[0], 4) for k, v in sorted(stages.items())},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -18,7 +18,7 @@ int64_t gags_bwd_staged_scratch_bytes_impl(int64_t rows, int n_gauss, int d);
 int gags_raster_bwd_colors_staged(int d, int width, int height, int n_gauss, const void *packed,
                                   const int32_t *offsets, const int32_t *flat, int n_isects, const float *v_out,
                                   const int32_t *blk_rows, const int32_t *row_end, int64_t rows, void *scratch,
-                                  int64_t scratch_bytes, float *v_colors, hipStream_t st);
+                                  int64_t scratch_bytes, float *v_colors, int stage, hipStream_t st);
 int gags_pack_isects_launch(int n_isects, const int32_t *flat, const float *means2d, const float *conics,
                             const float *opacities, void *packed, hipStream_t st);
 
@@ -95,15 +95,15 @@ extern "C" int gags_raster_bwd_colors_staged(int d, int width, int height, int n
                                              const int32_t *isect_offsets, const int32_t *flatten_ids,
                                              int64_t n_isects, const float *v_render_colors, const int32_t *blk_rows,
                                              const int32_t *row_end, int64_t rows, void *scratch,
-                                             int64_t scratch_bytes, float *v_colors, void *stream)
+                                             int64_t scratch_bytes, float *v_colors, int stage, void *stream)
 {
     if (d <= 0 || width <= 0 || height <= 0 || n < 0 || n_isects < 0 || n_isects >= (1ll << 31) || rows < 0 ||
-        rows >= (1ll << 31))
+        rows >= (1ll << 31) || stage < 0 || stage > 4)
         return GAGS_EINVAL;
     if (n == 0) return GAGS_OK;
     if (!isect_offsets || !blk_rows || !row_end || !scratch || !v_colors || !v_render_colors) return GAGS_EINVAL;
     if (rows > 0 && (!packed || !flatten_ids)) return GAGS_EINVAL;
     return gags_raster_bwd_colors_staged(d, width, height, n, packed, isect_offsets, flatten_ids, (int)n_isects,
                                          v_render_colors, blk_rows, row_end, rows, scratch, scratch_bytes, v_colors,
-                                         (hipStream_t)stream);
+                                         stage, (hipStream_t)stream);
 }

@@ -891,10 +891,13 @@ int64_t gags_bwd_staged_scratch_bytes_impl(int64_t rows, int n_gauss, int d)
 int gags_raster_bwd_colors_staged(int d, int width, int height, int n_gauss, const void *packed,
                                   const int32_t *offsets, const int32_t *flat, int n_isects, const float *v_out,
                                   const int32_t *blk_rows, const int32_t *row_end, int64_t rows, void *scratch,
-                                  int64_t scratch_bytes, float *v_colors, hipStream_t st)
+                                  int64_t scratch_bytes, float *v_colors, int stage, hipStream_t st)
 {
+    // stage: 0 = everything; 1 = rows A, 2 = rows B, 3 = sort + segment offsets, 4 = reduce (profiling)
     GAGS_CLEAR_ERR();
     if (d < CSB || d % CSB != 0 || d > 1024) return 1;
+    const bool sA = stage == 0 || stage == 1, sB = stage == 0 || stage == 2, sS = stage == 0 || stage == 3,
+               sR = stage == 0 || stage == 4;
     const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
     const int n_tiles = tile_w * tile_h, n_slices = d / CSB;
     const StagedLayout L = staged_layout(rows > 0 ? rows : 1, n_gauss, d);
@@ -906,23 +909,28 @@ int gags_raster_bwd_colors_staged(int d, int width, int height, int n_gauss, con
     float *prow = (float *)(sb + L.prow);
     const GRec *pk = reinterpret_cast<const GRec *>(packed);
     if (rows > 0) {
-        hipLaunchKernelGGL(raster_bwd_rows_a, dim3(n_tiles * 8), dim3(64), 0, st, d, width, height, tile_w, n_tiles,
-                           n_gauss, pk, offsets, flat, n_isects, v_out, blk_rows, row_end, wt, key, idx, prow);
-        if (n_slices > 1)
+        if (sA)
+            hipLaunchKernelGGL(raster_bwd_rows_a, dim3(n_tiles * 8), dim3(64), 0, st, d, width, height, tile_w, n_tiles,
+                               n_gauss, pk, offsets, flat, n_isects, v_out, blk_rows, row_end, wt, key, idx, prow);
+        if (sB && n_slices > 1)
             hipLaunchKernelGGL(raster_bwd_rows_b, dim3(n_tiles * 8 * (n_slices - 1)), dim3(64), 0, st, d, width, height,
                                tile_w, n_tiles, n_slices - 1, v_out, blk_rows, row_end, wt, prow);
-        int nbits = 1;
-        while ((1ll << nbits) <= n_gauss) ++nbits;  // keys in [0, n_gauss]
-        const int rc = gags_sort_pairs_u32(rows, nbits, key, idx, key_s, idx_s, sb + L.sort, L.prow - L.sort, st);
-        if (rc != GAGS_OK) return rc;
-        hipLaunchKernelGGL(seg_offsets_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, (int)rows, key_s,
-                           n_gauss, seg);
-    } else {
+        if (sS) {
+            int nbits = 1;
+            while ((1ll << nbits) <= n_gauss) ++nbits;  // keys in [0, n_gauss]
+            const int rc = gags_sort_pairs_u32(rows, nbits, key, idx, key_s, idx_s, sb + L.sort, L.prow - L.sort, st);
+            if (rc != GAGS_OK) return rc;
+            hipLaunchKernelGGL(seg_offsets_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, (int)rows,
+                               key_s, n_gauss, seg);
+        }
+    } else if (sS) {
         hipLaunchKernelGGL(seg_fill_kernel, dim3((n_gauss + 1 + 255) / 256), dim3(256), 0, st, n_gauss, seg);
     }
-    const int gpb = 256 / (d >> 2);
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((n_gauss + gpb - 1) / gpb), dim3(256), 0, st, n_gauss, d, seg, idx_s,
-                       prow, v_colors);
+    if (sR) {
+        const int gpb = 256 / (d >> 2);
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((n_gauss + gpb - 1) / gpb), dim3(256), 0, st, n_gauss, d, seg,
+                           idx_s, prow, v_colors);
+    }
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }

@@ -31,6 +31,19 @@ def stage(name):
         _events[name].append((a, b))
 
 
+_notes = {}
+
+
+def note(key, value):
+    """Remember a scalar fact about the last call (e.g. row count of the staged backward)."""
+    if ENABLED:
+        _notes[key] = value
+
+
+def notes():
+    return dict(_notes)
+
+
 def summary():
     """{stage: (mean_ms, count)}; synchronizes."""
     torch.cuda.synchronize()

@@ -230,18 +230,28 @@ def _backward_staged(lib, ctx, packed, offsets, flatten_ids, blk_rows, v_out, n,
     total = torch.empty(1, dtype=torch.int32, device=dev)
     sb = lib.gags_scan_scratch_bytes(nb)
     stmp = torch.empty(sb, dtype=torch.uint8, device=dev)
-    with profiler.stage("raster_bwd"):
+    with profiler.stage("bwd_rowcount"):
         check(lib.gags_cumsum_i32(nb, ptr(blk_rows), ptr(row_end), ptr(total), ptr(stmp), sb, st), "gags_cumsum_i32")
         host = ctypes.c_int32(0)
         check(lib.gags_read_i32(ptr(total), ctypes.byref(host), st), "gags_read_i32")
-        rows = int(host.value)
-        nbytes = lib.gags_bwd_staged_scratch_bytes(rows, n, d)
-        scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        v_colors = torch.empty(n, d, device=dev)
+    rows = int(host.value)
+    nbytes = lib.gags_bwd_staged_scratch_bytes(rows, n, d)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    v_colors = torch.empty(n, d, device=dev)
+
+    def run(stage):
         check(lib.gags_raster_bwd_colors_staged(d, width, height, n, ptr(packed), ptr(offsets), ptr(flatten_ids),
                                                 flatten_ids.shape[0], ptr(v_out), ptr(blk_rows), ptr(row_end), rows,
-                                                ptr(scratch), nbytes, ptr(v_colors), st),
+                                                ptr(scratch), nbytes, ptr(v_colors), stage, st),
               "gags_raster_bwd_colors_staged")
+
+    if profiler.ENABLED:  # one event pair per kernel group, for the roofline line of bench.py
+        for stage, name in ((1, "bwd_rows_a"), (2, "bwd_rows_b"), (3, "bwd_sort"), (4, "bwd_reduce")):
+            with profiler.stage(name):
+                run(stage)
+    else:
+        run(0)
+    profiler.note("bwd_rows", rows)
     v_bg = None
     if backgrounds is not None and ctx.needs_input_grad[4]:
         v_bg = ((1.0 - alphas)[..., None] * v_out).sum(dim=(0, 1))

@@ -134,7 +134,9 @@ int gags_raster_bwd_colors_staged(int d, int width, int height, int n, const voi
                                   const int32_t *isect_offsets, const int32_t *flatten_ids,
                                   int64_t n_isects, const float *v_render_colors,
                                   const int32_t *blk_rows, const int32_t *row_end, int64_t rows,
-                                  void *scratch, int64_t scratch_bytes, float *v_colors, void *stream);
+                                  void *scratch, int64_t scratch_bytes, float *v_colors,
+                                  int stage /* 0 = all; 1..4 = rows A, rows B, sort, reduce (for per-kernel timing) */,
+                                  void *stream);
 
 /* Diagnostics (roofline model): counts[0] += (pixel,Gaussian) pairs evaluated
  * before each pixel's stop, counts[1] += pairs blended.  counts[2] int64, zeroed by caller. */
