@@ -37,7 +37,7 @@ SIGNATURES = {
     "gags_pack_isects": (_i32, [_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_raster_fwd": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
                                _i32, _vp]),
-    "gags_bwd_staged_scratch_bytes": (_i64, [_i64, _i32, _i32]),
+    "gags_bwd_staged_scratch_bytes": (_i64, [_i64, _i64, _i32, _i32]),
     "gags_raster_bwd_colors_staged": (_i32, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp,
                                              _i64, _vp, _i32, _vp]),
     "gags_raster_bwd": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
@@ -53,6 +53,8 @@ SIGNATURES = {
 GAGS_BWD_COLORS_ONLY = 1
 GAGS_FWD_NO_MFMA = 2
 GAGS_BWD_ATOMIC = 4  # python-side: use the atomic colours-only backward instead of the staged one
+GAGS_BWD_MERGED = 8  # python-side: EXPERIMENTAL staged backward that merges a tile's rows in LDS (slower today:
+                     # ds_add_f32 runs at ~1 lane/clk/CU and position windows leave the MFMA tiles 30 % full)
 
 _lib = None
 

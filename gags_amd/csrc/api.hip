@@ -14,7 +14,7 @@ int gags_raster_bwd_valu(int d, int width, int height, const float *means2d, con
 int gags_raster_fwd_mfma(int d, int width, int height, const void *packed, const float *colors,
                          const float *backgrounds, const int32_t *offsets, const int32_t *flat, int n_isects,
                          float *out, float *alphas, int32_t *last_ids, int32_t *blk_rows, int dbg, hipStream_t st);
-int64_t gags_bwd_staged_scratch_bytes_impl(int64_t rows, int n_gauss, int d);
+int64_t gags_bwd_staged_scratch_bytes_impl(int64_t rows, int64_t n_isects, int n_gauss, int d);
 int gags_raster_bwd_colors_staged(int d, int width, int height, int n_gauss, const void *packed,
                                   const int32_t *offsets, const int32_t *flat, int n_isects, const float *v_out,
                                   const int32_t *blk_rows, const int32_t *row_end, int64_t rows, void *scratch,
@@ -85,10 +85,10 @@ extern "C" int gags_pack_isects(int64_t n_isects, const int32_t *flatten_ids, co
                                    (hipStream_t)stream);
 }
 
-extern "C" int64_t gags_bwd_staged_scratch_bytes(int64_t rows, int n, int d)
+extern "C" int64_t gags_bwd_staged_scratch_bytes(int64_t rows, int64_t n_isects, int n, int d)
 {
-    if (rows < 0 || n < 0 || d <= 0) return 0;
-    return gags_bwd_staged_scratch_bytes_impl(rows, n, d);
+    if (rows < 0 || n_isects < 0 || n < 0 || d <= 0) return 0;
+    return gags_bwd_staged_scratch_bytes_impl(rows, n_isects, n, d);
 }
 
 extern "C" int gags_raster_bwd_colors_staged(int d, int width, int height, int n, const void *packed,
@@ -98,7 +98,7 @@ extern "C" int gags_raster_bwd_colors_staged(int d, int width, int height, int n
                                              int64_t scratch_bytes, float *v_colors, int stage, void *stream)
 {
     if (d <= 0 || width <= 0 || height <= 0 || n < 0 || n_isects < 0 || n_isects >= (1ll << 31) || rows < 0 ||
-        rows >= (1ll << 31) || stage < 0 || stage > 4)
+        rows >= (1ll << 31) || stage < 0 || (stage & 15) > 4)
         return GAGS_EINVAL;
     if (n == 0) return GAGS_OK;
     if (!isect_offsets || !blk_rows || !row_end || !scratch || !v_colors || !v_render_colors) return GAGS_EINVAL;

@@ -803,6 +803,273 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(int n_gauss, int d, co
     *reinterpret_cast<float4 *>(v_colors + (size_t)g * d + cl) = acc;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Staged backward, tile-merged flavour (default).  Same idea as rows A/B, but the partial sums of
+// the eight 8x4 blocks of a tile are merged in LDS before they are stored, so a row exists per
+// (tile, list position) instead of per (block, hit): ~2.1x fewer row bytes written and re-read.
+//   W  one wave per (tile, block): alpha ONCE, no MFMA: weight tiles wt[slot][32 px] + the list
+//      position of every slot (slots are in list order);
+//   M  one 8-wave workgroup per (tile, 64-channel slice): the tile's list is walked in windows
+//      of 64 positions; each wave runs the MFMAs of its block's slots inside the window and adds
+//      the result rows into an LDS accumulator [64 positions][64 ch] with ds_add_f32; after a
+//      barrier the touched rows are stored (coalesced, plain) at prow[sorted index] and flagged;
+//   then: intersections sorted by Gaussian id, per-Gaussian sum of its touched rows.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64, 4) void raster_bwd_weights(
+    int width, int height, int tile_w, int n_tiles, const GRec *__restrict__ packed,
+    const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids, int n_isects,
+    const int32_t *__restrict__ blk_rows, const int32_t *__restrict__ row_end, float *__restrict__ wt,
+    int32_t *__restrict__ row_pos)
+{
+    __shared__ __attribute__((aligned(16))) HRec ring[RING];
+
+    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * 8);
+    const int blk = logical & 7;
+    const int tile = gags_tile_of_order(logical >> 3, tile_w, n_tiles / tile_w);
+    const int cnt = blk_rows[tile * 8 + blk];
+    if (cnt == 0) return;
+    const int base = row_end[tile * 8 + blk] - cnt;
+    const int lane = threadIdx.x;
+    const int p = lane & 31, k = lane >> 5;
+    const int ty = tile / tile_w, tx = tile - ty * tile_w;
+    const int bx0 = tx * GAGS_TILE + (blk & 1) * 8, by0 = ty * GAGS_TILE + (blk >> 1) * 4;
+    const int pj = bx0 + (p & 7), pi = by0 + (p >> 3);
+    const bool inside = (pi < height) && (pj < width);
+    const float px = (float)pj + 0.5f, py = (float)pi + 0.5f;
+    const float rx0 = (float)bx0 + 0.5f, rx1 = (float)bx0 + 7.5f, ry0 = (float)by0 + 0.5f, ry1 = (float)by0 + 3.5f;
+
+    const int start = offsets[tile];
+    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+
+    PixState st;
+    st.T = 1.0f; st.cur = 0; st.done = !inside;
+
+    int nq = 0, rd = 0;
+    int c = start;
+    GRec pre;
+    int pre_c = start;
+    auto issue = [&]() {
+        pre_c = c;
+        const int idx = c + lane;
+        if (idx < end) {
+            const float4 *src = reinterpret_cast<const float4 *>(packed + idx);
+            const float4 u = src[0], v = src[1];
+            pre.x = u.x; pre.y = u.y; pre.a = u.z; pre.b = u.w; pre.c = v.x; pre.o = v.y; pre.ex = v.z; pre.ey = v.w;
+        } else {
+            pre.x = pre.y = 0.f; pre.ex = pre.ey = -1.f; pre.a = pre.b = pre.c = pre.o = 0.f;
+        }
+        c += 64;
+    };
+    auto commit = [&]() {
+        const bool hit = (pre_c + lane < end) && (pre.x + pre.ex >= rx0) && (pre.x - pre.ex <= rx1) &&
+                         (pre.y + pre.ey >= ry0) && (pre.y - pre.ey <= ry1);
+        const unsigned long long mask = __ballot(hit);
+        if (hit) {
+            const int pos = nq + __popcll(mask & ((1ull << lane) - 1ull));
+            HRec h;
+            h.x = pre.x; h.y = pre.y; h.a = pre.a; h.b = pre.b; h.c = pre.c; h.o = pre.o;
+            h.gid = 0; h.sidx = pre_c + lane - start;  // position inside the tile's list
+            ring[pos & (RING - 1)] = h;
+        }
+        nq += __popcll(mask);
+    };
+    bool pending = false;
+    if (c < end) { issue(); pending = true; }
+    auto refill = [&](int low) {
+        while ((nq - rd) < low && pending) {
+            commit();
+            pending = false;
+            if (c < end) { issue(); pending = true; }
+        }
+    };
+    // alpha of this lane's slot of the pair at `pos`; a lone last hit's partner slot inherits its position
+    // (its weights are all zero, so it adds nothing to that row)
+    auto eval_at = [&](int pos, int &lpos) {
+        const bool valid = pos + k < nq;
+        const HRec h = ring[min(pos + k, nq - 1) & (RING - 1)];
+        GRec r;
+        r.x = h.x; r.y = h.y; r.a = h.a; r.b = h.b; r.c = h.c; r.o = h.o;
+        lpos = h.sidx;
+        return eval_alpha(r, px, py, valid);
+    };
+
+    int row = base;
+    const int wpos = (p & 1) * 16 + (p >> 1);
+    refill(6);
+    if (!__all(st.done) && rd < nq) {
+        int pos_n;
+        float a_n = eval_at(rd, pos_n);
+        auto kstep = [&]() -> bool {
+            const float a_c = a_n;
+            const int pos_c = pos_n;
+            rd += 2;
+            if ((nq - rd) < 6 && pending) refill(6);
+            const bool more = rd < nq;
+            a_n = eval_at(rd, pos_n);
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a_c), __float_as_uint(a_c), false, false);
+            bool blended;
+            const float wgt = step_pair2(st, __uint_as_float(sw[0]), __uint_as_float(sw[1]), k, blended);
+            if (__any(wgt != 0.f)) {  // same predicate as the forward's row count
+                wt[(size_t)(row + k) * 32 + wpos] = wgt;  // A-operand image: 2 x 128 B per step
+                if (p == 0) row_pos[row + k] = pos_c;
+                row += 2;
+            }
+            return more && !__all(st.done);
+        };
+        bool go = true;
+        while (go) {  // mirrors the forward's two-steps-per-trip loop so the row counts agree
+            kstep();
+            go = kstep();
+        }
+    }
+}
+
+template <int NBM>
+__global__ __launch_bounds__(512, 4) void raster_bwd_merge(
+    int d, int width, int height, int tile_w, int n_tiles, int n_slices, const float *__restrict__ v_render_colors,
+    const int32_t *__restrict__ offsets, const int32_t *__restrict__ blk_rows, const int32_t *__restrict__ row_end,
+    const float *__restrict__ wt, const int32_t *__restrict__ row_pos, float *__restrict__ prow,
+    uint8_t *__restrict__ touched)
+{
+    constexpr int CSM = 32 * NBM;  // channels per workgroup
+    constexpr int WIN = 64;        // list positions per window
+    __shared__ __attribute__((aligned(16))) float accum[WIN][CSM];
+    __shared__ int posb[8][64];
+    __shared__ unsigned long long maskw[2];
+
+    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * n_slices);
+    const int slice = logical % n_slices;
+    const int tile = gags_tile_of_order(logical / n_slices, tile_w, n_tiles / tile_w);
+    const int ch0 = slice * CSM;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = lane & 31, k = lane >> 5;
+    const int cnt = blk_rows[tile * 8 + w];
+    const int base = row_end[tile * 8 + w] - cnt;
+    const int ty = tile / tile_w, tx = tile - ty * tile_w;
+    const int bx0 = tx * GAGS_TILE + (w & 1) * 8, by0 = ty * GAGS_TILE + (w >> 1) * 4;
+    const int tstart = offsets[tile];
+
+    // cotangent slab of this wave's 8x4 block as B operands: V[s][j] = v_out[pixel 2s+k][ch0 + 32j + p]
+    float V[16][NBM];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int q = 2 * s + k;
+        const int qj = bx0 + (q & 7), qi = by0 + (q >> 3);
+        const bool ok = (qi < height) && (qj < width);
+        const float *src = v_render_colors + ((size_t)(ok ? qi : 0) * width + (ok ? qj : 0)) * d + ch0 + p;
+#pragma unroll
+        for (int j = 0; j < NBM; ++j) V[s][j] = ok ? src[32 * j] : 0.f;
+    }
+    for (int i = threadIdx.x; i < WIN * CSM; i += 512) (&accum[0][0])[i] = 0.f;
+    if (threadIdx.x < 2) maskw[threadIdx.x] = 0ull;
+
+    int cursor = 0;
+    for (int w0 = 0, it = 0;; w0 += WIN, ++it) {
+        if (!__syncthreads_or(cursor < cnt)) break;  // also: previous window's stores / zeroing are done
+        const int remaining = cnt - cursor;
+        const int mypos = (lane < remaining) ? row_pos[base + cursor + lane] : 0x7fffffff;
+        const bool inwin = mypos < w0 + WIN;  // slots are in list order: the in-window ones are a prefix
+        const int n_in = __popcll(__ballot(inwin));
+        posb[w][lane] = mypos - w0;
+        if (n_in > 0) {
+            // 64-bit OR over the wave of the window bits this block touches
+            unsigned long long bits = inwin ? (1ull << (mypos - w0)) : 0ull;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) bits |= __shfl_xor(bits, o, 64);
+            if (lane == 0) atomicOr(&maskw[it & 1], bits);
+        }
+        for (int mb = 0; mb * 32 < n_in; ++mb) {
+            const int nb = min(32, n_in - 32 * mb);
+            float A[16];
+            {
+                const float4 *src = reinterpret_cast<const float4 *>(wt + (size_t)(base + cursor + 32 * mb + p) * 32 + k * 16);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float4 v = (p < nb) ? src[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    A[4 * t] = v.x; A[4 * t + 1] = v.y; A[4 * t + 2] = v.z; A[4 * t + 3] = v.w;
+                }
+            }
+            f32x16 acc[NBM];
+#pragma unroll
+            for (int j = 0; j < NBM; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+#pragma unroll
+                for (int j = 0; j < NBM; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s], V[s][j], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int slot = (r & 3) + 8 * (r >> 2) + 4 * k;
+                if (slot < nb) {
+                    float *dst = &accum[posb[w][32 * mb + slot]][p];
+#pragma unroll
+                    for (int j = 0; j < NBM; ++j) atomicAdd(dst + 32 * j, acc[j][r]);  // ds_add_f32
+                }
+            }
+        }
+        cursor += n_in;
+        __syncthreads();
+        // ---- store the touched rows of this window, clear them for the next one ----
+        const unsigned long long mask = maskw[it & 1];
+        constexpr int F4_PER_ROW = CSM / 4;
+#pragma unroll
+        for (int i = threadIdx.x; i < WIN * F4_PER_ROW; i += 512) {
+            const int row = i / F4_PER_ROW, c4 = i - row * F4_PER_ROW;
+            if ((mask >> row) & 1ull) {
+                float4 *src = reinterpret_cast<float4 *>(&accum[row][4 * c4]);
+                *reinterpret_cast<float4 *>(prow + (size_t)(tstart + w0 + row) * d + ch0 + 4 * c4) = *src;
+                *src = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        if (slice == 0 && threadIdx.x < WIN && ((mask >> threadIdx.x) & 1ull)) touched[tstart + w0 + threadIdx.x] = 1;
+        if (threadIdx.x == 0) maskw[(it + 1) & 1] = 0ull;  // nobody touches the other parity until the next barrier
+    }
+}
+
+__global__ __launch_bounds__(256) void iota_keys_kernel(int n, const int32_t *__restrict__ flatten_ids,
+                                                        uint32_t *__restrict__ keys, int32_t *__restrict__ idx)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { keys[i] = (uint32_t)flatten_ids[i]; idx[i] = i; }
+}
+
+// v_colors[g, :] = sum over the Gaussian's touched rows (sorted = deterministic order); float4 per lane
+__global__ __launch_bounds__(256) void reduce_merged_kernel(int n_gauss, int d, const int32_t *__restrict__ seg,
+                                                            const int32_t *__restrict__ sorted_pos,
+                                                            const uint8_t *__restrict__ touched,
+                                                            const float *__restrict__ prow,
+                                                            float *__restrict__ v_colors)
+{
+    const int lpg = d >> 2;
+    const int gpb = 256 / lpg;
+    const int gl = threadIdx.x / lpg;
+    const int g = blockIdx.x * gpb + gl;
+    const int cl = (threadIdx.x % lpg) * 4;
+    if (gl >= gpb || g >= n_gauss) return;
+    const int b = seg[g], e = seg[g + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = b; i < e; i += 4) {
+        int sp[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ok[u] = i + u < e;
+            sp[u] = ok[u] ? sorted_pos[i + u] : 0;
+            ok[u] = ok[u] && touched[sp[u]];
+        }
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            v[u] = ok[u] ? *reinterpret_cast<const float4 *>(prow + (size_t)sp[u] * d + cl) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+    *reinterpret_cast<float4 *>(v_colors + (size_t)g * d + cl) = acc;
+}
+
 int launch_bwd_colors_mfma(int d, int width, int height, const GRec *packed, const int32_t *offsets,
                            const int32_t *flat, int n_isects, const float *v_out, float *v_colors, int dbg,
                            hipStream_t st)
@@ -862,52 +1129,97 @@ int gags_sort_pairs_u32(int64_t n, int nbits, const uint32_t *keys_in, const int
 
 namespace {
 struct StagedLayout {
-    int64_t wt, key, idx, key_s, idx_s, seg, sort, prow, total;
+    int64_t wt, key, idx, key_s, idx_s, seg, sort, prow, pos, touched, total;
 };
 inline int64_t al256(int64_t x) { return (x + 255) / 256 * 256; }
-inline StagedLayout staged_layout(int64_t rows, int n_gauss, int d)
+// merged = 1: rows per sorted intersection (n_isects of them); 0: rows per (block, hit) slot
+inline StagedLayout staged_layout(int64_t rows, int64_t n_isects, int n_gauss, int d, bool merged)
 {
     StagedLayout L;
+    const int64_t nsort = merged ? (n_isects > 0 ? n_isects : 1) : rows;
     int64_t o = 0;
-    L.wt = o; o += al256((rows + 64) * 128);          // A-operand tiles, 128 B per row (+ slack for the prefetch)
-    L.key = o; o += al256(rows * 4);
-    L.idx = o; o += al256(rows * 4);
-    L.key_s = o; o += al256(rows * 4);
-    L.idx_s = o; o += al256(rows * 4);
+    L.wt = o; o += al256((rows + 64) * 128);          // A-operand tiles, 128 B per slot (+ slack for the prefetch)
+    L.pos = o; o += al256((rows + 64) * 4);
+    L.key = o; o += al256(nsort * 4);
+    L.idx = o; o += al256(nsort * 4);
+    L.key_s = o; o += al256(nsort * 4);
+    L.idx_s = o; o += al256(nsort * 4);
     L.seg = o; o += al256(((int64_t)n_gauss + 2) * 4);
-    L.sort = o; o += al256(gags_sort_u32_scratch_bytes(rows));
-    L.prow = o; o += al256(rows * (int64_t)d * 4);
+    L.sort = o; o += al256(gags_sort_u32_scratch_bytes(nsort));
+    L.touched = o; o += al256(nsort);
+    L.prow = o; o += al256(nsort * (int64_t)d * 4);
     L.total = o;
     return L;
 }
 }  // namespace
 
-int64_t gags_bwd_staged_scratch_bytes_impl(int64_t rows, int n_gauss, int d)
+int64_t gags_bwd_staged_scratch_bytes_impl(int64_t rows, int64_t n_isects, int n_gauss, int d)
 {
-    return staged_layout(rows > 0 ? rows : 1, n_gauss, d).total;
+    const int64_t a = staged_layout(rows > 0 ? rows : 1, n_isects, n_gauss, d, true).total;
+    const int64_t b = staged_layout(rows > 0 ? rows : 1, n_isects, n_gauss, d, false).total;
+    return a > b ? a : b;
 }
 
 // 1 = not eligible (d % 128 != 0)
 int gags_raster_bwd_colors_staged(int d, int width, int height, int n_gauss, const void *packed,
                                   const int32_t *offsets, const int32_t *flat, int n_isects, const float *v_out,
                                   const int32_t *blk_rows, const int32_t *row_end, int64_t rows, void *scratch,
-                                  int64_t scratch_bytes, float *v_colors, int stage, hipStream_t st)
+                                  int64_t scratch_bytes, float *v_colors, int stage_arg, hipStream_t st)
 {
-    // stage: 0 = everything; 1 = rows A, 2 = rows B, 3 = sort + segment offsets, 4 = reduce (profiling)
+    // stage (low 4 bits): 0 = everything; 1 = weights / rows A, 2 = merge / rows B, 3 = sort + segment
+    // offsets, 4 = reduce (per-kernel timing).  bit 4 set = per-(block,hit) rows instead of tile-merged rows.
     GAGS_CLEAR_ERR();
     if (d < CSB || d % CSB != 0 || d > 1024) return 1;
+    const int stage = stage_arg & 15;
+    const bool merged = !(stage_arg & 16);
     const bool sA = stage == 0 || stage == 1, sB = stage == 0 || stage == 2, sS = stage == 0 || stage == 3,
                sR = stage == 0 || stage == 4;
     const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
     const int n_tiles = tile_w * tile_h, n_slices = d / CSB;
-    const StagedLayout L = staged_layout(rows > 0 ? rows : 1, n_gauss, d);
+    const StagedLayout L = staged_layout(rows > 0 ? rows : 1, n_isects, n_gauss, d, merged);
     if (scratch_bytes < L.total) return GAGS_ESCRATCH;
     char *sb = (char *)scratch;
     float *wt = (float *)(sb + L.wt);
     uint32_t *key = (uint32_t *)(sb + L.key), *key_s = (uint32_t *)(sb + L.key_s);
     int32_t *idx = (int32_t *)(sb + L.idx), *idx_s = (int32_t *)(sb + L.idx_s), *seg = (int32_t *)(sb + L.seg);
+    int32_t *pos = (int32_t *)(sb + L.pos);
+    uint8_t *touched = (uint8_t *)(sb + L.touched);
     float *prow = (float *)(sb + L.prow);
     const GRec *pk = reinterpret_cast<const GRec *>(packed);
+    int nbits = 1;
+    while ((1ll << nbits) <= n_gauss) ++nbits;  // keys in [0, n_gauss]
+    const int gpb = 256 / (d >> 2);
+    if (merged) {
+        constexpr int NBM = 2;
+        const int n_slices_m = d / (32 * NBM);
+        if (rows > 0 && n_isects > 0) {
+            if (sA) {
+                if (hipMemsetAsync(touched, 0, (size_t)n_isects, st) != hipSuccess) return GAGS_ELAUNCH;
+                hipLaunchKernelGGL(raster_bwd_weights, dim3(n_tiles * 8), dim3(64), 0, st, width, height, tile_w, n_tiles,
+                                   pk, offsets, flat, n_isects, blk_rows, row_end, wt, pos);
+            }
+            if (sB)
+                hipLaunchKernelGGL(raster_bwd_merge<NBM>, dim3(n_tiles * n_slices_m), dim3(512), 0, st, d, width, height,
+                                   tile_w, n_tiles, n_slices_m, v_out, offsets, blk_rows, row_end, wt, pos, prow,
+                                   touched);
+            if (sS) {
+                hipLaunchKernelGGL(iota_keys_kernel, dim3((n_isects + 255) / 256), dim3(256), 0, st, n_isects, flat, key,
+                                   idx);
+                const int rc = gags_sort_pairs_u32(n_isects, nbits, key, idx, key_s, idx_s, sb + L.sort,
+                                                   L.touched - L.sort, st);
+                if (rc != GAGS_OK) return rc;
+                hipLaunchKernelGGL(seg_offsets_kernel, dim3((n_isects + 255) / 256), dim3(256), 0, st, n_isects, key_s,
+                                   n_gauss, seg);
+            }
+        } else if (sS) {
+            hipLaunchKernelGGL(seg_fill_kernel, dim3((n_gauss + 1 + 255) / 256), dim3(256), 0, st, n_gauss, seg);
+        }
+        if (sR)
+            hipLaunchKernelGGL(reduce_merged_kernel, dim3((n_gauss + gpb - 1) / gpb), dim3(256), 0, st, n_gauss, d, seg,
+                               idx_s, touched, prow, v_colors);
+        GAGS_CHECK_LAUNCH();
+        return GAGS_OK;
+    }
     if (rows > 0) {
         if (sA)
             hipLaunchKernelGGL(raster_bwd_rows_a, dim3(n_tiles * 8), dim3(64), 0, st, d, width, height, tile_w, n_tiles,
@@ -916,9 +1228,7 @@ int gags_raster_bwd_colors_staged(int d, int width, int height, int n_gauss, con
             hipLaunchKernelGGL(raster_bwd_rows_b, dim3(n_tiles * 8 * (n_slices - 1)), dim3(64), 0, st, d, width, height,
                                tile_w, n_tiles, n_slices - 1, v_out, blk_rows, row_end, wt, prow);
         if (sS) {
-            int nbits = 1;
-            while ((1ll << nbits) <= n_gauss) ++nbits;  // keys in [0, n_gauss]
-            const int rc = gags_sort_pairs_u32(rows, nbits, key, idx, key_s, idx_s, sb + L.sort, L.prow - L.sort, st);
+            const int rc = gags_sort_pairs_u32(rows, nbits, key, idx, key_s, idx_s, sb + L.sort, L.touched - L.sort, st);
             if (rc != GAGS_OK) return rc;
             hipLaunchKernelGGL(seg_offsets_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, (int)rows,
                                key_s, n_gauss, seg);
@@ -926,11 +1236,9 @@ int gags_raster_bwd_colors_staged(int d, int width, int height, int n_gauss, con
     } else if (sS) {
         hipLaunchKernelGGL(seg_fill_kernel, dim3((n_gauss + 1 + 255) / 256), dim3(256), 0, st, n_gauss, seg);
     }
-    if (sR) {
-        const int gpb = 256 / (d >> 2);
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3((n_gauss + gpb - 1) / gpb), dim3(256), 0, st, n_gauss, d, seg,
-                           idx_s, prow, v_colors);
-    }
+    if (sR)
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((n_gauss + gpb - 1) / gpb), dim3(256), 0, st, n_gauss, d, seg, idx_s,
+                           prow, v_colors);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }

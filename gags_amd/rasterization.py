@@ -177,7 +177,7 @@ class _Rasterize(torch.autograd.Function):
         with profiler.stage("raster_fwd"):
             check(lib.gags_raster_fwd(d, width, height, ptr(means2d), ptr(conics), ptr(opacities), ptr(colors),
                                       ptr(backgrounds), ptr(offsets), ptr(flatten_ids), n_isects, ptr(packed),
-                                      ptr(out), ptr(alphas), ptr(last_ids), ptr(blk_rows), flags & 0xffffff03,
+                                      ptr(out), ptr(alphas), ptr(last_ids), ptr(blk_rows), flags & ~0xfc,
                                       _stream()), "gags_raster_fwd")
         ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, packed, alphas,
                               last_ids, blk_rows)
@@ -235,18 +235,20 @@ def _backward_staged(lib, ctx, packed, offsets, flatten_ids, blk_rows, v_out, n,
         host = ctypes.c_int32(0)
         check(lib.gags_read_i32(ptr(total), ctypes.byref(host), st), "gags_read_i32")
     rows = int(host.value)
-    nbytes = lib.gags_bwd_staged_scratch_bytes(rows, n, d)
+    nbytes = lib.gags_bwd_staged_scratch_bytes(rows, flatten_ids.shape[0], n, d)
+    legacy = 0 if (ctx.cfg[2] & _lib.GAGS_BWD_MERGED) else 16  # default: rows per (block, hit)
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     v_colors = torch.empty(n, d, device=dev)
 
     def run(stage):
         check(lib.gags_raster_bwd_colors_staged(d, width, height, n, ptr(packed), ptr(offsets), ptr(flatten_ids),
                                                 flatten_ids.shape[0], ptr(v_out), ptr(blk_rows), ptr(row_end), rows,
-                                                ptr(scratch), nbytes, ptr(v_colors), stage, st),
+                                                ptr(scratch), nbytes, ptr(v_colors), stage | legacy, st),
               "gags_raster_bwd_colors_staged")
 
     if profiler.ENABLED:  # one event pair per kernel group, for the roofline line of bench.py
-        for stage, name in ((1, "bwd_rows_a"), (2, "bwd_rows_b"), (3, "bwd_sort"), (4, "bwd_reduce")):
+        names = (("bwd_rows_a", "bwd_rows_b") if legacy else ("bwd_weights", "bwd_merge")) + ("bwd_sort", "bwd_reduce")
+        for stage, name in enumerate(names, start=1):
             with profiler.stage(name):
                 run(stage)
     else:

@@ -128,14 +128,15 @@ int gags_raster_bwd(int d, int width, int height, const float *means2d, const fl
  * blk_rows written by gags_raster_fwd, their inclusive prefix sum row_end (gags_cumsum_i32) and
  * its total `rows` (gags_read_i32).  Partial sums are stored as rows, sorted by Gaussian and
  * reduced; v_colors[N,D] is written in full (no zero-fill needed).  D % 128 == 0, D <= 1024.
- * scratch: gags_bwd_staged_scratch_bytes(rows, n, d) bytes.  Returns 1 when D is not eligible. */
-int64_t gags_bwd_staged_scratch_bytes(int64_t rows, int n, int d);
+ * scratch: gags_bwd_staged_scratch_bytes(rows, n_isects, n, d) bytes.  Returns 1 when D is not eligible. */
+int64_t gags_bwd_staged_scratch_bytes(int64_t rows, int64_t n_isects, int n, int d);
 int gags_raster_bwd_colors_staged(int d, int width, int height, int n, const void *packed,
                                   const int32_t *isect_offsets, const int32_t *flatten_ids,
                                   int64_t n_isects, const float *v_render_colors,
                                   const int32_t *blk_rows, const int32_t *row_end, int64_t rows,
                                   void *scratch, int64_t scratch_bytes, float *v_colors,
-                                  int stage /* 0 = all; 1..4 = rows A, rows B, sort, reduce (for per-kernel timing) */,
+                                  int stage /* low 4 bits: 0 = all, 1..4 = weights, merge, sort, reduce (per-kernel timing);
+                                               bit 4: per-(block,hit) rows instead of tile-merged rows */,
                                   void *stream);
 
 /* Diagnostics (roofline model): counts[0] += (pixel,Gaussian) pairs evaluated
