@@ -201,20 +201,15 @@ def main():
     if rank == 0:
         # Per-kernel roofline.  Each entry is ONE kernel bracketed by HIP events on the
         # launch stream; algorithmic work per launch:
-        #   raster_fwd  : 14*Q_eval + 2*D*Q_blend flops              (fp32 MFMA bound)
-        #   bwd_rows_a  : 14*Q_eval + 2*128*Q_blend flops            (alpha once + first 128-channel slice)
-        #   bwd_rows_b  : 2*(D-128)*Q_blend flops                    (remaining slices: weight tile, MFMA, row stores)
-        #   bwd_weights / bwd_merge : the experimental tile-merged flavour (GAGS_BWD_MERGED)
+        #   raster_fwd  : 14*Q_eval + 2*D*Q_blend flops              (weights + feature passes; fp32 MFMA bound)
+        #   bwd_rows    : 2*D*Q_blend flops                           (weight tile, MFMA, row stores)
         #   bwd_reduce  : (V + N)*D*4 bytes: every visible Gaussian's gradient read at least once + written
         #                 (HBM bound; the kernel actually reads one row per touched (tile, Gaussian))
         #   raster_bwd  : 14*Q_eval + 2*D*Q_blend flops              (single-kernel atomic backward, if used)
         rows = profiler.notes().get("bwd_rows", 0)
         work = {
             "raster_fwd": ("mfma", 14.0 * q_eval + 2.0 * d * q_blend),
-            "bwd_rows_a": ("mfma", 14.0 * q_eval + 2.0 * min(d, 128) * q_blend),
-            "bwd_rows_b": ("mfma", 2.0 * max(d - 128, 0) * q_blend),
-            "bwd_weights": ("mfma", 14.0 * q_eval),
-            "bwd_merge": ("mfma", 2.0 * d * q_blend),
+            "bwd_rows": ("mfma", 2.0 * d * q_blend),
             "bwd_reduce": ("hbm", 4.0 * d * (n_visible + n)),
             "raster_bwd": ("mfma", 14.0 * q_eval + 2.0 * d * q_blend),
         }

@@ -35,13 +35,14 @@ SIGNATURES = {
     "gags_sort_pairs": (_i32, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "gags_tile_offsets": (_i32, [_i64, _vp, _i32, _vp, _vp]),
     "gags_pack_isects": (_i32, [_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "gags_raster_fwd": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
-                               _i32, _vp]),
-    "gags_bwd_staged_scratch_bytes": (_i64, [_i64, _i64, _i32, _i32]),
-    "gags_raster_bwd_colors_staged": (_i32, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp,
-                                             _i64, _vp, _i32, _vp]),
+    "gags_raster_fwd_scratch_bytes": (_i64, [_i64, _i32, _i32]),
+    "gags_raster_fwd": (_i32, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
+                               _vp, _i64, _vp, _i32, _vp]),
     "gags_raster_bwd": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp, _vp, _i32, _vp]),
+    "gags_bwd_staged_scratch_bytes": (_i64, [_i64, _i32, _i32]),
+    "gags_raster_bwd_colors_staged": (_i32, [_i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
+                                             _i64, _vp, _i32, _vp]),
     "gags_raster_stats": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "gags_project_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _vp, _vp]),
@@ -53,8 +54,7 @@ SIGNATURES = {
 GAGS_BWD_COLORS_ONLY = 1
 GAGS_FWD_NO_MFMA = 2
 GAGS_BWD_ATOMIC = 4  # python-side: use the atomic colours-only backward instead of the staged one
-GAGS_BWD_MERGED = 8  # python-side: EXPERIMENTAL staged backward that merges a tile's rows in LDS (slower today:
-                     # ds_add_f32 runs at ~1 lane/clk/CU and position windows leave the MFMA tiles 30 % full)
+GAGS_FWD_FUSED = 8  # python-side: single-kernel matrix-core forward (no scratch) instead of weights + features
 
 _lib = None
 

@@ -1,6 +1,8 @@
-// Dispatch of the two raster entry points onto the VALU (narrow D) and MFMA (wide D) kernels.
+// C-ABI entry points of the raster stages: argument validation + dispatch onto the VALU kernels
+// (narrow / odd D, full geometry gradients) and the matrix-core kernels (D % 32 == 0).
 #include "common.h"
 
+// raster_valu.hip
 int gags_raster_fwd_valu(int d, int width, int height, const float *means2d, const float *conics,
                          const float *opacities, const float *colors, const float *backgrounds,
                          const int32_t *offsets, const int32_t *flat, int n_isects, float *out, float *alphas,
@@ -10,70 +12,50 @@ int gags_raster_bwd_valu(int d, int width, int height, const float *means2d, con
                          const int32_t *offsets, const int32_t *flat, int n_isects, const float *alphas,
                          const int32_t *last_ids, const float *v_out, const float *v_alpha, float *v_colors,
                          float *v_opac, float *v_m2d, float *v_con, bool geom, hipStream_t st);
-
-int gags_raster_fwd_mfma(int d, int width, int height, const void *packed, const float *colors,
-                         const float *backgrounds, const int32_t *offsets, const int32_t *flat, int n_isects,
-                         float *out, float *alphas, int32_t *last_ids, int32_t *blk_rows, int dbg, hipStream_t st);
-int64_t gags_bwd_staged_scratch_bytes_impl(int64_t rows, int64_t n_isects, int n_gauss, int d);
-int gags_raster_bwd_colors_staged(int d, int width, int height, int n_gauss, const void *packed,
-                                  const int32_t *offsets, const int32_t *flat, int n_isects, const float *v_out,
-                                  const int32_t *blk_rows, const int32_t *row_end, int64_t rows, void *scratch,
-                                  int64_t scratch_bytes, float *v_colors, int stage, hipStream_t st);
+// raster_weights.hip
 int gags_pack_isects_launch(int n_isects, const int32_t *flat, const float *means2d, const float *conics,
                             const float *opacities, void *packed, hipStream_t st);
+int gags_raster_weights_launch(int width, int height, int n_gauss, const void *packed, const int32_t *offsets,
+                               const int32_t *flat, int n_isects, float *wt, int32_t *gid_s, int32_t *blk_rows,
+                               float *Tbuf, float *alphas, int32_t *last_ids, hipStream_t st);
+// raster_fwd_mfma.hip
+int gags_raster_fwd_feat_launch(int d, int width, int height, int n_gauss, const float *colors,
+                                const float *backgrounds, const int32_t *offsets, int n_isects,
+                                const int32_t *blk_rows, const float *wt, const int32_t *gid_s, const float *Tbuf,
+                                float *out, hipStream_t st);
+int gags_raster_fwd_fused_launch(int d, int width, int height, const void *packed, const float *colors,
+                                 const float *backgrounds, const int32_t *offsets, const int32_t *flat, int n_isects,
+                                 float *out, float *alphas, int32_t *last_ids, hipStream_t st);
+// raster_bwd_mfma.hip
+int64_t gags_bwd_staged_scratch_bytes_impl(int64_t rows, int n_gauss, int d);
+int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, const int32_t *offsets, int n_isects,
+                                  const float *v_out, const int32_t *blk_rows, const int32_t *row_end, int64_t rows,
+                                  const float *wt, const int32_t *gid_s, void *scratch, int64_t scratch_bytes,
+                                  float *v_colors, int stage, hipStream_t st);
+int gags_raster_bwd_atomic_launch(int d, int width, int height, const void *packed, const int32_t *offsets,
+                                  const int32_t *flat, int n_isects, const float *v_out, float *v_colors,
+                                  hipStream_t st);
 
-int gags_raster_bwd_colors_mfma(int d, int width, int height, const void *packed, const int32_t *offsets,
-                                const int32_t *flat, int n_isects, const float *v_out, float *v_colors, int dbg,
-                                hipStream_t st);
-
-extern "C" int gags_raster_fwd(int d, int width, int height, const float *means2d, const float *conics,
-                               const float *opacities, const float *colors, const float *backgrounds,
-                               const int32_t *isect_offsets, const int32_t *flatten_ids, int64_t n_isects,
-                               const void *packed, float *render_colors, float *render_alphas, int32_t *last_ids,
-                               int32_t *blk_rows, int flags, void *stream)
+namespace {
+inline int64_t al256(int64_t x) { return (x + 255) / 256 * 256; }
+struct FwdScratch {
+    int64_t wt, gid, tbuf, total;
+};
+// slot space: 8 * (n_isects + n_tiles) slots (+ slack so that the backward may read a whole 32-slot tile)
+inline FwdScratch fwd_layout(int64_t n_isects, int width, int height)
 {
-    GAGS_CLEAR_ERR();
-    if (d <= 0 || width <= 0 || height <= 0 || n_isects < 0 || n_isects >= (1ll << 31)) return GAGS_EINVAL;
-    if (!isect_offsets || !render_colors || !render_alphas || !last_ids) return GAGS_EINVAL;
-    if (n_isects > 0 && (!means2d || !conics || !opacities || !colors || !flatten_ids)) return GAGS_EINVAL;
-    if (!(flags & GAGS_FWD_NO_MFMA) && (packed || n_isects == 0)) {
-        const int rc = gags_raster_fwd_mfma(d, width, height, packed, colors, backgrounds, isect_offsets, flatten_ids,
-                                            (int)n_isects, render_colors, render_alphas, last_ids, blk_rows,
-                                            flags >> 8, (hipStream_t)stream);
-        if (rc != 1) return rc;  // taken (GAGS_OK) or failed (<0); 1 = width not eligible
-    }
-    return gags_raster_fwd_valu(d, width, height, means2d, conics, opacities, colors, backgrounds, isect_offsets,
-                                flatten_ids, (int)n_isects, render_colors, render_alphas, last_ids,
-                                (hipStream_t)stream);
+    const int64_t tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
+    const int64_t slots = 8 * (n_isects + tile_w * tile_h) + 64;
+    FwdScratch L;
+    int64_t o = 0;
+    L.wt = o; o += al256(slots * 128);
+    L.gid = o; o += al256(slots * 4);
+    L.tbuf = o; o += al256((int64_t)width * height * 4);
+    L.total = o;
+    return L;
 }
-
-extern "C" int gags_raster_bwd(int d, int width, int height, const float *means2d, const float *conics,
-                               const float *opacities, const float *colors, const float *backgrounds,
-                               const int32_t *isect_offsets, const int32_t *flatten_ids, int64_t n_isects,
-                               const void *packed, const float *render_alphas, const int32_t *last_ids,
-                               const float *v_render_colors,
-                               const float *v_render_alphas, float *v_colors, float *v_opacities, float *v_means2d,
-                               float *v_conics, int flags, void *stream)
-{
-    GAGS_CLEAR_ERR();
-    if (d <= 0 || width <= 0 || height <= 0 || n_isects < 0 || n_isects >= (1ll << 31)) return GAGS_EINVAL;
-    if (n_isects == 0) return GAGS_OK;
-    if (!means2d || !conics || !opacities || !colors || !isect_offsets || !flatten_ids || !render_alphas ||
-        !last_ids || !v_render_colors || !v_colors)
-        return GAGS_EINVAL;
-    const bool geom = !(flags & GAGS_BWD_COLORS_ONLY);
-    if (geom && (!v_opacities || !v_means2d || !v_conics)) return GAGS_EINVAL;
-    if (!geom && !(flags & GAGS_FWD_NO_MFMA) && packed) {
-        const int rc = gags_raster_bwd_colors_mfma(d, width, height, packed, isect_offsets, flatten_ids,
-                                                   (int)n_isects, v_render_colors, v_colors, flags >> 8,
-                                                   (hipStream_t)stream);
-        if (rc != 1) return rc;
-    }
-    return gags_raster_bwd_valu(d, width, height, means2d, conics, opacities, colors, backgrounds, isect_offsets,
-                                flatten_ids, (int)n_isects, render_alphas, last_ids, v_render_colors,
-                                v_render_alphas, v_colors, v_opacities, v_means2d, v_conics, geom,
-                                (hipStream_t)stream);
-}
+inline bool mfma_width(int d) { return d >= 32 && d % 32 == 0; }
+}  // namespace
 
 extern "C" int gags_pack_isects(int64_t n_isects, const int32_t *flatten_ids, const float *means2d,
                                 const float *conics, const float *opacities, void *packed, void *stream)
@@ -85,25 +67,90 @@ extern "C" int gags_pack_isects(int64_t n_isects, const int32_t *flatten_ids, co
                                    (hipStream_t)stream);
 }
 
-extern "C" int64_t gags_bwd_staged_scratch_bytes(int64_t rows, int64_t n_isects, int n, int d)
+extern "C" int64_t gags_raster_fwd_scratch_bytes(int64_t n_isects, int width, int height)
 {
-    if (rows < 0 || n_isects < 0 || n < 0 || d <= 0) return 0;
-    return gags_bwd_staged_scratch_bytes_impl(rows, n_isects, n, d);
+    if (n_isects < 0 || width <= 0 || height <= 0) return 0;
+    return fwd_layout(n_isects, width, height).total;
 }
 
-extern "C" int gags_raster_bwd_colors_staged(int d, int width, int height, int n, const void *packed,
-                                             const int32_t *isect_offsets, const int32_t *flatten_ids,
-                                             int64_t n_isects, const float *v_render_colors, const int32_t *blk_rows,
-                                             const int32_t *row_end, int64_t rows, void *scratch,
-                                             int64_t scratch_bytes, float *v_colors, int stage, void *stream)
+extern "C" int gags_raster_fwd(int d, int n, int width, int height, const float *means2d, const float *conics,
+                               const float *opacities, const float *colors, const float *backgrounds,
+                               const int32_t *isect_offsets, const int32_t *flatten_ids, int64_t n_isects,
+                               const void *packed, float *render_colors, float *render_alphas, int32_t *last_ids,
+                               void *scratch, int64_t scratch_bytes, int32_t *blk_rows, int flags, void *stream)
 {
-    if (d <= 0 || width <= 0 || height <= 0 || n < 0 || n_isects < 0 || n_isects >= (1ll << 31) || rows < 0 ||
-        rows >= (1ll << 31) || stage < 0 || (stage & 15) > 4)
+    if (d <= 0 || n < 0 || width <= 0 || height <= 0 || n_isects < 0 || n_isects >= (1ll << 27)) return GAGS_EINVAL;
+    if (!isect_offsets || !render_colors || !render_alphas || !last_ids) return GAGS_EINVAL;
+    if (n_isects > 0 && (!means2d || !conics || !opacities || !colors || !flatten_ids)) return GAGS_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (!(flags & GAGS_FWD_NO_MFMA) && mfma_width(d) && (packed || n_isects == 0) && n > 0) {
+        if (scratch && blk_rows) {  // split forward: weights once, then the feature stream
+            const FwdScratch L = fwd_layout(n_isects, width, height);
+            if (scratch_bytes < L.total) return GAGS_ESCRATCH;
+            char *sb = (char *)scratch;
+            float *wt = (float *)(sb + L.wt);
+            int32_t *gid_s = (int32_t *)(sb + L.gid);
+            float *tbuf = (float *)(sb + L.tbuf);
+            int rc = gags_raster_weights_launch(width, height, n, packed, isect_offsets, flatten_ids, (int)n_isects, wt,
+                                                gid_s, blk_rows, tbuf, render_alphas, last_ids, st);
+            if (rc != GAGS_OK) return rc;
+            return gags_raster_fwd_feat_launch(d, width, height, n, colors, backgrounds, isect_offsets, (int)n_isects,
+                                               blk_rows, wt, gid_s, tbuf, render_colors, st);
+        }
+        return gags_raster_fwd_fused_launch(d, width, height, packed, colors, backgrounds, isect_offsets, flatten_ids,
+                                            (int)n_isects, render_colors, render_alphas, last_ids, st);
+    }
+    return gags_raster_fwd_valu(d, width, height, means2d, conics, opacities, colors, backgrounds, isect_offsets,
+                                flatten_ids, (int)n_isects, render_colors, render_alphas, last_ids, st);
+}
+
+extern "C" int gags_raster_bwd(int d, int width, int height, const float *means2d, const float *conics,
+                               const float *opacities, const float *colors, const float *backgrounds,
+                               const int32_t *isect_offsets, const int32_t *flatten_ids, int64_t n_isects,
+                               const void *packed, const float *render_alphas, const int32_t *last_ids,
+                               const float *v_render_colors, const float *v_render_alphas, float *v_colors,
+                               float *v_opacities, float *v_means2d, float *v_conics, int flags, void *stream)
+{
+    if (d <= 0 || width <= 0 || height <= 0 || n_isects < 0 || n_isects >= (1ll << 27)) return GAGS_EINVAL;
+    if (n_isects == 0) return GAGS_OK;
+    if (!means2d || !conics || !opacities || !colors || !isect_offsets || !flatten_ids || !render_alphas ||
+        !last_ids || !v_render_colors || !v_colors)
+        return GAGS_EINVAL;
+    const bool geom = !(flags & GAGS_BWD_COLORS_ONLY);
+    if (geom && (!v_opacities || !v_means2d || !v_conics)) return GAGS_EINVAL;
+    if (!geom && !(flags & GAGS_FWD_NO_MFMA) && packed) {
+        const int rc = gags_raster_bwd_atomic_launch(d, width, height, packed, isect_offsets, flatten_ids,
+                                                     (int)n_isects, v_render_colors, v_colors, (hipStream_t)stream);
+        if (rc != 1) return rc;
+    }
+    return gags_raster_bwd_valu(d, width, height, means2d, conics, opacities, colors, backgrounds, isect_offsets,
+                                flatten_ids, (int)n_isects, render_alphas, last_ids, v_render_colors,
+                                v_render_alphas, v_colors, v_opacities, v_means2d, v_conics, geom,
+                                (hipStream_t)stream);
+}
+
+extern "C" int64_t gags_bwd_staged_scratch_bytes(int64_t rows, int n, int d)
+{
+    if (rows < 0 || n < 0 || d <= 0) return 0;
+    return gags_bwd_staged_scratch_bytes_impl(rows, n, d);
+}
+
+extern "C" int gags_raster_bwd_colors_staged(int d, int n, int width, int height, const int32_t *isect_offsets,
+                                             int64_t n_isects, const float *v_render_colors, const int32_t *blk_rows,
+                                             const int32_t *row_end, int64_t rows, const void *fwd_scratch,
+                                             int64_t fwd_scratch_bytes, void *scratch, int64_t scratch_bytes,
+                                             float *v_colors, int stage, void *stream)
+{
+    if (d <= 0 || width <= 0 || height <= 0 || n < 0 || n_isects < 0 || n_isects >= (1ll << 27) || rows < 0 ||
+        rows >= (1ll << 31) || stage < 0 || stage > 3)
         return GAGS_EINVAL;
     if (n == 0) return GAGS_OK;
-    if (!isect_offsets || !blk_rows || !row_end || !scratch || !v_colors || !v_render_colors) return GAGS_EINVAL;
-    if (rows > 0 && (!packed || !flatten_ids)) return GAGS_EINVAL;
-    return gags_raster_bwd_colors_staged(d, width, height, n, packed, isect_offsets, flatten_ids, (int)n_isects,
-                                         v_render_colors, blk_rows, row_end, rows, scratch, scratch_bytes, v_colors,
-                                         stage, (hipStream_t)stream);
+    if (!isect_offsets || !blk_rows || !row_end || !fwd_scratch || !scratch || !v_colors || !v_render_colors)
+        return GAGS_EINVAL;
+    const FwdScratch L = fwd_layout(n_isects, width, height);
+    if (fwd_scratch_bytes < L.total) return GAGS_ESCRATCH;
+    const char *fs = (const char *)fwd_scratch;
+    return gags_raster_bwd_staged_launch(d, width, height, n, isect_offsets, (int)n_isects, v_render_colors, blk_rows,
+                                         row_end, rows, (const float *)(fs + L.wt), (const int32_t *)(fs + L.gid),
+                                         scratch, scratch_bytes, v_colors, stage, (hipStream_t)stream);
 }

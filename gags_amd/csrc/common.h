@@ -78,3 +78,13 @@ __device__ __forceinline__ int gags_tile_of_order(int o, int tile_w, int tile_h)
     const int x = r / h;
     return (y0 + (r - x * h)) * tile_w + x;
 }
+
+// Slot space of the matrix-core rasterizer (raster_weights.hip): every (tile, 8x4 block) owns a fixed
+// region of K-step slots sized by the tile's list length, so no counting pass is needed.
+//   base(tile, blk) = 8*(start + tile) + blk * even(L),  capacity even(L),  L = end - start
+// Total slot count for a view: 8 * (n_isects + n_tiles).
+__host__ __device__ __forceinline__ int gags_slot_base(int start, int end, int tile, int blk)
+{
+    const int lp = (end - start + 1) & ~1;
+    return 8 * (start + tile) + blk * lp;
+}

@@ -1,0 +1,358 @@
+// K10 colours-only backward on the matrix cores (the GAD flow consumes only d loss / d colors:
+// scene/gaussian_model.py:192-208):     v_colors[g, :] = sum_px w[px, g] * v_out[px, :],  w = alpha*T.
+//
+// Per wave the cotangent slab v_out[32 px][128 ch] lives in 64 VGPRs as MFMA B operands (K = pixel
+// pairs, N = channels); A operands are 32-slot weight tiles (rows = slots); every tile costs 16 K-steps x
+// 4 channel tiles of v_mfma_f32_32x32x2_f32 and yields 32 partial gradient rows of 128 channels.
+//
+// What happens to those rows is the whole story on this part: float atomics are executed at the memory
+// side on a multi-XCD MI355X (TCC_EA0_ATOMIC == TCC_ATOMIC, ~1.2 TB/s measured) while plain stores of the
+// same rows are almost free.  So the default ("staged") path has NO atomics and is bit-reproducible:
+//   rows    one wave per (tile, block, 128-channel slice): weight tile from the forward's scratch (wt),
+//           64 MFMAs, 32 rows stored at fixed addresses (prefix sum of the forward's slot counts);
+//   sort    (Gaussian id, row) pairs, radix sort on 32-bit keys; per-Gaussian offsets;
+//   reduce  v_colors[g] = sum of its rows, written once (no zero-fill of v_colors needed).
+// The single-kernel atomic variant (recomputes alpha itself; needs neither scratch nor the forward's
+// slot counts) is kept as the fallback.
+#include "raster_mfma_common.h"
+
+using namespace gags_mfma;
+
+int64_t gags_sort_u32_scratch_bytes(int64_t n);
+int gags_sort_pairs_u32(int64_t n, int nbits, const uint32_t *keys_in, const int32_t *vals_in, uint32_t *keys_out,
+                        int32_t *vals_out, void *scratch, int64_t scratch_bytes, hipStream_t st);
+
+namespace {
+
+constexpr int NBB = 4;         // channel tiles per wave
+constexpr int CSB = 32 * NBB;  // 128 channels per wave
+
+__device__ __forceinline__ void atomic_add_f32(float *p, float v)
+{
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// cotangent slab as B operands in the "strided-4" channel order: V[s][j] = v_out[pixel 2s+k][ch0 + 4p + j]
+// (channel tile j holds channels {4n+j}): one float4 load per K-step and float4 row stores afterwards
+__device__ __forceinline__ void load_slab4(float (&V)[16][NBB], const float *__restrict__ v_out, const BlockGeom &g,
+                                           int width, int height, int d, int ch0)
+{
+    static_assert(NBB == 4, "float4 slab");
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int q = 2 * s + g.k;
+        const int qj = g.bx0 + (q & 7), qi = g.by0 + (q >> 3);
+        const bool ok = (qi < height) && (qj < width);
+        const float4 v = ok ? *reinterpret_cast<const float4 *>(v_out + ((size_t)qi * width + qj) * d + ch0 + 4 * g.p)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        V[s][0] = v.x; V[s][1] = v.y; V[s][2] = v.z; V[s][3] = v.w;
+    }
+}
+
+// cotangent slab as B operands: V[s][j] = v_out[pixel q = 2s+k][ch0 + 32j + p]
+__device__ __forceinline__ void load_slab(float (&V)[16][NBB], const float *__restrict__ v_out, const BlockGeom &g,
+                                          int width, int height, int d, int ch0)
+{
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int q = 2 * s + g.k;
+        const int qj = g.bx0 + (q & 7), qi = g.by0 + (q >> 3);
+        const bool ok = (qi < height) && (qj < width);
+        const float *src = v_out + ((size_t)(ok ? qi : 0) * width + (ok ? qj : 0)) * d + ch0 + g.p;
+#pragma unroll
+        for (int j = 0; j < NBB; ++j) V[s][j] = ok ? src[32 * j] : 0.f;
+    }
+}
+
+__device__ __forceinline__ void tile_mfma(f32x16 (&acc)[NBB], const float (&A)[16], const float (&V)[16][NBB])
+{
+#pragma unroll
+    for (int j = 0; j < NBB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int j = 0; j < NBB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s], V[s][j], acc[j], 0, 0, 0);
+}
+
+// ---- staged: rows ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64, 2) void raster_bwd_rows(
+    int d, int width, int height, int tile_w, int n_tiles, int n_slices, const float *__restrict__ v_render_colors,
+    const int32_t *__restrict__ offsets, int n_isects, const int32_t *__restrict__ blk_rows,
+    const int32_t *__restrict__ row_end, const float *__restrict__ wt, const int32_t *__restrict__ gid_s,
+    float *__restrict__ prow, uint32_t *__restrict__ row_key, int32_t *__restrict__ row_idx)
+{
+    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * 8 * n_slices);
+    const int slice = logical % n_slices, rest = logical / n_slices;
+    const int blk = rest & 7;
+    const int tile = gags_tile_of_order(rest >> 3, tile_w, n_tiles / tile_w);
+    const int cnt = blk_rows[tile * 8 + blk];
+    if (cnt == 0) return;
+    const int base = row_end[tile * 8 + blk] - cnt;  // first compact row of the block
+    const int start = offsets[tile];
+    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+    const int sb = gags_slot_base(start, end, tile, blk);
+    const int ch0 = slice * CSB;
+    const int lane = threadIdx.x;
+    BlockGeom g;
+    g.init(tile, blk, tile_w, width, height, lane);
+    const int p = g.p, k = g.k;
+
+    float V[16][NBB];
+    load_slab4(V, v_render_colors, g, width, height, d, ch0);
+
+    // weight tile m: slots sb+32m .. +31; lane (i = p, k) owns 16 consecutive floats of row i (pixels 2s+k)
+    auto load_a = [&](int m, float4(&a)[4]) {
+        const float4 *src = reinterpret_cast<const float4 *>(wt + (size_t)(sb + 32 * m + p) * 32 + k * 16);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = src[t];
+    };
+    const int nblocks = (cnt + 31) >> 5;
+    float4 an[4];
+    load_a(0, an);
+    for (int m = 0; m < nblocks; ++m) {
+        float A[16];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { A[4 * t] = an[t].x; A[4 * t + 1] = an[t].y; A[4 * t + 2] = an[t].z; A[4 * t + 3] = an[t].w; }
+        load_a(min(m + 1, nblocks - 1), an);  // prefetch
+        const int count = min(32, cnt - 32 * m);
+        if (slice == 0 && k == 0 && p < count) {  // row -> Gaussian map for the sort
+            row_key[base + 32 * m + p] = (uint32_t)gid_s[sb + 32 * m + p];
+            row_idx[base + 32 * m + p] = base + 32 * m + p;
+        }
+        f32x16 acc[NBB];
+        tile_mfma(acc, A, V);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int slot = (r & 3) + 8 * (r >> 2) + 4 * k;
+            if (slot < count)  // 32 lanes x 16 B = the row's 512 contiguous bytes of this slice
+                *reinterpret_cast<float4 *>(prow + (size_t)(base + 32 * m + slot) * d + ch0 + 4 * p) =
+                    make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+        }
+    }
+}
+
+// seg[g] = first sorted position whose key is >= g, for g in [0, n_keys]
+__global__ __launch_bounds__(256) void seg_offsets_kernel(int n, const uint32_t *__restrict__ sorted_keys, int n_keys,
+                                                          int32_t *__restrict__ seg)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int cur = min((int)sorted_keys[i], n_keys);
+    if (i == 0) {
+        for (int g = 0; g <= cur; ++g) seg[g] = 0;
+    } else {
+        const int prev = min((int)sorted_keys[i - 1], n_keys);
+        for (int g = prev + 1; g <= cur; ++g) seg[g] = i;
+    }
+    if (i == n - 1)
+        for (int g = cur + 1; g <= n_keys; ++g) seg[g] = n;
+}
+
+__global__ void seg_fill_kernel(int n_keys, int32_t *__restrict__ seg)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g <= n_keys) seg[g] = 0;
+}
+
+// v_colors[g, :] = sum over the Gaussian's rows, in sorted (= deterministic) order; float4 per lane
+__global__ __launch_bounds__(256) void reduce_rows_kernel(int n_gauss, int d, const int32_t *__restrict__ seg,
+                                                          const int32_t *__restrict__ sorted_rows,
+                                                          const float *__restrict__ prow, float *__restrict__ v_colors)
+{
+    const int lpg = d >> 2;  // lanes per Gaussian
+    const int gpb = 256 / lpg;
+    const int gl = threadIdx.x / lpg;
+    const int g = blockIdx.x * gpb + gl;
+    const int cl = (threadIdx.x % lpg) * 4;
+    if (gl >= gpb || g >= n_gauss) return;
+    const int b = seg[g], e = seg[g + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int i = b;
+    for (; i + 3 < e; i += 4) {
+        const int r0 = sorted_rows[i], r1 = sorted_rows[i + 1], r2 = sorted_rows[i + 2], r3 = sorted_rows[i + 3];
+        const float4 v0 = *reinterpret_cast<const float4 *>(prow + (size_t)r0 * d + cl);
+        const float4 v1 = *reinterpret_cast<const float4 *>(prow + (size_t)r1 * d + cl);
+        const float4 v2 = *reinterpret_cast<const float4 *>(prow + (size_t)r2 * d + cl);
+        const float4 v3 = *reinterpret_cast<const float4 *>(prow + (size_t)r3 * d + cl);
+        acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+        acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+        acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+        acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+    }
+    for (; i < e; ++i) {
+        const float4 v0 = *reinterpret_cast<const float4 *>(prow + (size_t)sorted_rows[i] * d + cl);
+        acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+    }
+    *reinterpret_cast<float4 *>(v_colors + (size_t)g * d + cl) = acc;
+}
+
+// ---- fallback: single kernel, float atomics ------------------------------------------------------------
+__global__ __launch_bounds__(64, 2) void raster_bwd_atomic(
+    int d, int width, int height, int tile_w, int n_tiles, int n_slices, const GRec *__restrict__ packed,
+    const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids, int n_isects,
+    const float *__restrict__ v_render_colors, float *__restrict__ v_colors)
+{
+    __shared__ __attribute__((aligned(16))) HRec ring[RING];
+    __shared__ __attribute__((aligned(16))) float Wt[32 * WT_STRIDE];
+    __shared__ int32_t slot_id[32];
+
+    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * 8 * n_slices);
+    const int slice = logical % n_slices, rest = logical / n_slices;
+    const int blk = rest & 7;
+    const int tile = gags_tile_of_order(rest >> 3, tile_w, n_tiles / tile_w);
+    const int ch0 = slice * CSB;
+    const int lane = threadIdx.x;
+    BlockGeom g;
+    g.init(tile, blk, tile_w, width, height, lane);
+    const int p = g.p, k = g.k;
+    const int start = offsets[tile];
+    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+
+    float V[16][NBB];
+    load_slab(V, v_render_colors, g, width, height, d, ch0);
+
+    PixState st;
+    st.T = 1.0f; st.cur = 0; st.done = !g.inside;
+    HitStream hs;
+    hs.init(ring, packed, flatten_ids, start, end, lane, g);
+
+    int nh = 0;
+    const int wpos = (p & 1) * 16 + (p >> 1);
+    auto flush = [&](int count) {
+        float A[16];
+        const float4 *rowp = reinterpret_cast<const float4 *>(Wt + p * WT_STRIDE + k * 16);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float4 v = rowp[t];
+            A[4 * t] = v.x; A[4 * t + 1] = v.y; A[4 * t + 2] = v.z; A[4 * t + 3] = v.w;
+        }
+        f32x16 acc[NBB];
+        tile_mfma(acc, A, V);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int slot = (r & 3) + 8 * (r >> 2) + 4 * k;
+            const int gid = slot_id[slot];
+            if (slot < count && gid >= 0) {
+                float *dst = v_colors + (size_t)gid * d + ch0 + p;
+#pragma unroll
+                for (int j = 0; j < NBB; ++j) atomic_add_f32(dst + 32 * j, acc[j][r]);
+            }
+        }
+    };
+
+    hs.refill(6);
+    if (!__all(st.done) && hs.rd < hs.nq) {
+        bool v_n;
+        HRec h_n = hs.at(hs.rd, k, v_n);
+        float a_n = eval_alpha(h_n, g.px, g.py, v_n);
+        int gid_n = v_n ? h_n.gid : -1;
+        bool go = true;
+        while (go) {
+            const float a_c = a_n;
+            const int gid_c = gid_n;
+            hs.rd += 2;
+            if ((hs.nq - hs.rd) < 6 && hs.pending) hs.refill(6);
+            const bool more = hs.rd < hs.nq;
+            h_n = hs.at(hs.rd, k, v_n);
+            a_n = eval_alpha(h_n, g.px, g.py, v_n);
+            gid_n = v_n ? h_n.gid : -1;
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a_c), __float_as_uint(a_c), false, false);
+            bool blended;
+            const float wgt = step_pair(st, __uint_as_float(sw[0]), __uint_as_float(sw[1]), k, blended);
+            if (__any(wgt != 0.f)) {
+                Wt[(nh + k) * WT_STRIDE + wpos] = wgt;
+                if (p == 0) slot_id[nh + k] = gid_c;
+                nh += 2;
+                if (nh == 32) { flush(32); nh = 0; }
+            }
+            go = more && !__all(st.done);
+        }
+    }
+    if (nh > 0) flush(nh);
+}
+
+struct StagedLayout {
+    int64_t key, idx, key_s, idx_s, seg, sort, prow, total;
+};
+inline int64_t al256(int64_t x) { return (x + 255) / 256 * 256; }
+inline StagedLayout staged_layout(int64_t rows, int n_gauss, int d)
+{
+    StagedLayout L;
+    int64_t o = 0;
+    L.key = o; o += al256(rows * 4);
+    L.idx = o; o += al256(rows * 4);
+    L.key_s = o; o += al256(rows * 4);
+    L.idx_s = o; o += al256(rows * 4);
+    L.seg = o; o += al256(((int64_t)n_gauss + 2) * 4);
+    L.sort = o; o += al256(gags_sort_u32_scratch_bytes(rows));
+    L.prow = o; o += al256(rows * (int64_t)d * 4);
+    L.total = o;
+    return L;
+}
+
+}  // namespace
+
+int64_t gags_bwd_staged_scratch_bytes_impl(int64_t rows, int n_gauss, int d)
+{
+    return staged_layout(rows > 0 ? rows : 1, n_gauss, d).total;
+}
+
+// 1 = width not eligible
+int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, const int32_t *offsets, int n_isects,
+                                  const float *v_out, const int32_t *blk_rows, const int32_t *row_end, int64_t rows,
+                                  const float *wt, const int32_t *gid_s, void *scratch, int64_t scratch_bytes,
+                                  float *v_colors, int stage, hipStream_t st)
+{
+    // stage: 0 = everything; 1 = rows, 2 = sort + segment offsets, 3 = reduce (per-kernel timing)
+    GAGS_CLEAR_ERR();
+    if (d < CSB || d % CSB != 0 || d > 1024) return 1;
+    const bool sA = stage == 0 || stage == 1, sS = stage == 0 || stage == 2, sR = stage == 0 || stage == 3;
+    const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
+    const int n_tiles = tile_w * tile_h, n_slices = d / CSB;
+    const StagedLayout L = staged_layout(rows > 0 ? rows : 1, n_gauss, d);
+    if (scratch_bytes < L.total) return GAGS_ESCRATCH;
+    char *sb = (char *)scratch;
+    uint32_t *key = (uint32_t *)(sb + L.key), *key_s = (uint32_t *)(sb + L.key_s);
+    int32_t *idx = (int32_t *)(sb + L.idx), *idx_s = (int32_t *)(sb + L.idx_s), *seg = (int32_t *)(sb + L.seg);
+    float *prow = (float *)(sb + L.prow);
+    if (rows > 0) {
+        if (sA)
+            hipLaunchKernelGGL(raster_bwd_rows, dim3(n_tiles * 8 * n_slices), dim3(64), 0, st, d, width, height, tile_w,
+                               n_tiles, n_slices, v_out, offsets, n_isects, blk_rows, row_end, wt, gid_s, prow, key, idx);
+        if (sS) {
+            int nbits = 1;
+            while ((1ll << nbits) <= n_gauss) ++nbits;  // keys in [0, n_gauss]
+            const int rc = gags_sort_pairs_u32(rows, nbits, key, idx, key_s, idx_s, sb + L.sort, L.prow - L.sort, st);
+            if (rc != GAGS_OK) return rc;
+            hipLaunchKernelGGL(seg_offsets_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, (int)rows,
+                               key_s, n_gauss, seg);
+        }
+    } else if (sS) {
+        hipLaunchKernelGGL(seg_fill_kernel, dim3((n_gauss + 1 + 255) / 256), dim3(256), 0, st, n_gauss, seg);
+    }
+    if (sR) {
+        const int gpb = 256 / (d >> 2);
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((n_gauss + gpb - 1) / gpb), dim3(256), 0, st, n_gauss, d, seg,
+                           idx_s, prow, v_colors);
+    }
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+// 1 = width not eligible (d % 128 != 0)
+int gags_raster_bwd_atomic_launch(int d, int width, int height, const void *packed, const int32_t *offsets,
+                                  const int32_t *flat, int n_isects, const float *v_out, float *v_colors,
+                                  hipStream_t st)
+{
+    GAGS_CLEAR_ERR();
+    if (d < CSB || d % CSB != 0) return 1;
+    const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
+    const int n_tiles = tile_w * tile_h, n_slices = d / CSB;
+    hipLaunchKernelGGL(raster_bwd_atomic, dim3(n_tiles * 8 * n_slices), dim3(64), 0, st, d, width, height, tile_w,
+                       n_tiles, n_slices, reinterpret_cast<const GRec *>(packed), offsets, flat, n_isects, v_out,
+                       v_colors);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}

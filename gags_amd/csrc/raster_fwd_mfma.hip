@@ -1,0 +1,297 @@
+// K9 on the matrix cores (D % 32 == 0), exact fp32: v_mfma_f32_32x32x2_f32 is bit-for-bit a
+// k-ordered fmaf chain and zero weights are exact no-ops, so both kernels below are bit-identical
+// to the sequential definition (and to each other and to the VALU kernels).
+//
+//  raster_fwd_feat<NB>   default; needs the scratch written by raster_weights.hip.
+//      One wave per (tile, 8x4 block, slice of 32*NB channels): a pure stream.  Per K-step one dword
+//      of weights per lane (the 32x2 A operand, read column-wise from wt), two feature rows as float4
+//      per lane (the B operands, straight from global/L2 into VGPRs, one step ahead) and NB MFMAs.
+//      No alpha work, no LDS, no barrier.
+//  raster_fwd_fused<NB>  fallback when the caller provides no scratch: same decomposition, but every
+//      wave also runs the HitStream / alpha / transmittance pipeline itself (repeated per slice).
+//
+// Accumulator tile i of a group of 4 holds channels {4n+i}: one float4 load feeds 4 tiles and the
+// epilogue stores 16 B per lane.  All D channels of a slice are composited in ONE walk of the list
+// (gsplat re-walks it ceil(D/32) times).
+#include "raster_mfma_common.h"
+
+using namespace gags_mfma;
+
+namespace {
+
+template <int NB>
+struct FwdCfg {
+    static constexpr int CS = 32 * NB;
+    static constexpr int VEC = NB >= 4 ? 4 : NB;
+    static constexpr int NG = NB / VEC;
+    static_assert(NB == 1 || NB == 2 || NB % 4 == 0, "NB in {1,2,4,8,16}");
+};
+
+// two feature rows (slot k's row for this half-wave) as B operands
+template <int NB>
+__device__ __forceinline__ void load_rows(const float *__restrict__ colors, int gid, int d, int ch0, int p,
+                                          float4 (&bq)[FwdCfg<NB>::NG])
+{
+    constexpr int VEC = FwdCfg<NB>::VEC, NG = FwdCfg<NB>::NG;
+    const float *row = colors + (size_t)gid * d + ch0 + VEC * p;
+#pragma unroll
+    for (int gq = 0; gq < NG; ++gq) {
+        if constexpr (VEC == 4) bq[gq] = *reinterpret_cast<const float4 *>(row + gq * 128);
+        else if constexpr (VEC == 2) { const float2 t = *reinterpret_cast<const float2 *>(row); bq[gq] = make_float4(t.x, t.y, 0.f, 0.f); }
+        else bq[gq] = make_float4(row[0], 0.f, 0.f, 0.f);
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void mfma_step(f32x16 (&acc)[NB], float wgt, const float4 (&bc)[FwdCfg<NB>::NG])
+{
+    constexpr int VEC = FwdCfg<NB>::VEC, NG = FwdCfg<NB>::NG;
+#pragma unroll
+    for (int gq = 0; gq < NG; ++gq) {
+        const float bv[4] = {bc[gq].x, bc[gq].y, bc[gq].z, bc[gq].w};
+#pragma unroll
+        for (int i = 0; i < VEC; ++i)
+            acc[gq * VEC + i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wgt, bv[i], acc[gq * VEC + i], 0, 0, 0);
+    }
+}
+
+// out[pix][ch] = acc (+ T*bg); accumulator row r of lane (p,k) <-> pixel q = (r&3) + 8(r>>2) + 4k of the block.
+// Tq(q) returns the final transmittance of pixel q (only called for in-image pixels).
+template <int NB, typename TF>
+__device__ __forceinline__ void epilogue(const f32x16 (&acc)[NB], const BlockGeom &g, int width, int height, int d,
+                                         int ch0, const float *__restrict__ backgrounds,
+                                         float *__restrict__ render_colors, TF Tq)
+{
+    constexpr int VEC = FwdCfg<NB>::VEC, NG = FwdCfg<NB>::NG;
+    float bgv[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) bgv[j] = 0.f;
+    const bool has_bg = backgrounds != nullptr;  // wave-uniform
+    if (has_bg) {
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) bgv[gq * VEC + i] = backgrounds[ch0 + gq * 32 * VEC + VEC * g.p + i];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int q = (r & 3) + 8 * (r >> 2) + 4 * g.k;
+        const int qj = g.bx0 + (q & 7), qi = g.by0 + (q >> 3);
+        if (qi >= height || qj >= width) continue;
+        const float T = Tq(q, qi, qj);
+        float *o = render_colors + ((size_t)qi * width + qj) * d + ch0 + VEC * g.p;
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) {
+            float v[VEC];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float a = acc[gq * VEC + i][r];
+                v[i] = has_bg ? __builtin_fmaf(T, bgv[gq * VEC + i], a) : a;
+            }
+            if constexpr (VEC == 4) *reinterpret_cast<float4 *>(o + gq * 128) = make_float4(v[0], v[1], v[2], v[3]);
+            else if constexpr (VEC == 2) *reinterpret_cast<float2 *>(o) = make_float2(v[0], v[1]);
+            else o[0] = v[0];
+        }
+    }
+}
+
+template <int NB>
+__global__ __launch_bounds__(64, (NB >= 16 ? 1 : 2)) void raster_fwd_feat(
+    int d, int width, int height, int tile_w, int n_tiles, int n_slices, int n_gauss,
+    const float *__restrict__ colors, const float *__restrict__ backgrounds, const int32_t *__restrict__ offsets,
+    int n_isects, const int32_t *__restrict__ blk_rows, const float *__restrict__ wt,
+    const int32_t *__restrict__ gid_s, const float *__restrict__ Tbuf, float *__restrict__ render_colors)
+{
+    constexpr int CS = FwdCfg<NB>::CS, NG = FwdCfg<NB>::NG;
+    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * 8 * n_slices);
+    const int slice = logical % n_slices, rest = logical / n_slices;
+    const int blk = rest & 7;
+    const int tile = gags_tile_of_order(rest >> 3, tile_w, n_tiles / tile_w);
+    const int ch0 = slice * CS;
+    const int lane = threadIdx.x;
+    BlockGeom g;
+    g.init(tile, blk, tile_w, width, height, lane);
+    const int p = g.p, k = g.k;
+    const int start = offsets[tile];
+    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+    const int sb = gags_slot_base(start, end, tile, blk);
+    const int cnt = blk_rows[tile * 8 + blk];
+    const int steps = cnt >> 1;
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    if (steps > 0) {
+        const int wpos = (p & 1) * 16 + (p >> 1);
+        // this lane's slot of step s, clamped to the block's last pair (surplus steps carry weight 0)
+        auto slot_of = [&](int s) { return sb + 2 * min(s, steps - 1) + k; };
+        auto gid_of = [&](int s) { return min(gid_s[slot_of(s)], n_gauss - 1); };  // partner of a lone hit: any valid row
+        // PD-deep software pipeline: the feature rows of step s+PD are requested while step s runs its
+        // MFMAs (rows mostly come from L2 / Infinity Cache: ~1-2 us), the ids another PD steps earlier.
+        constexpr int PD = 4;
+        float a[PD];
+        float4 b[PD][NG];
+        int gq[PD];
+#pragma unroll
+        for (int i = 0; i < PD; ++i) {
+            a[i] = wt[(size_t)slot_of(i) * 32 + wpos];
+            load_rows<NB>(colors, gid_of(i), d, ch0, p, b[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < PD; ++i) gq[i] = gid_of(PD + i);
+        for (int s = 0; s < steps; s += PD) {
+#pragma unroll
+            for (int i = 0; i < PD; ++i) {
+                const float a_c = (s + i < steps) ? a[i] : 0.f;
+                mfma_step<NB>(acc, a_c, b[i]);
+                a[i] = wt[(size_t)slot_of(s + PD + i) * 32 + wpos];
+                load_rows<NB>(colors, gq[i], d, ch0, p, b[i]);
+                gq[i] = gid_of(s + 2 * PD + i);
+            }
+        }
+    }
+    epilogue<NB>(acc, g, width, height, d, ch0, backgrounds, render_colors,
+                 [&](int, int qi, int qj) { return Tbuf[(size_t)qi * width + qj]; });
+}
+
+template <int NB>
+__global__ __launch_bounds__(64, (NB >= 16 ? 1 : 2)) void raster_fwd_fused(
+    int d, int width, int height, int tile_w, int n_tiles, int n_slices, const GRec *__restrict__ packed,
+    const float *__restrict__ colors, const float *__restrict__ backgrounds, const int32_t *__restrict__ offsets,
+    const int32_t *__restrict__ flatten_ids, int n_isects, float *__restrict__ render_colors,
+    float *__restrict__ render_alphas, int32_t *__restrict__ last_ids)
+{
+    constexpr int CS = FwdCfg<NB>::CS, NG = FwdCfg<NB>::NG;
+    __shared__ __attribute__((aligned(16))) HRec ring[RING];
+    __shared__ float Tb[32];
+
+    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * 8 * n_slices);
+    const int slice = logical % n_slices, rest = logical / n_slices;
+    const int blk = rest & 7;
+    const int tile = gags_tile_of_order(rest >> 3, tile_w, n_tiles / tile_w);
+    const int ch0 = slice * CS;
+    const int lane = threadIdx.x;
+    BlockGeom g;
+    g.init(tile, blk, tile_w, width, height, lane);
+    const int p = g.p, k = g.k;
+    const int start = offsets[tile];
+    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    PixState st;
+    st.T = 1.0f; st.cur = 0; st.done = !g.inside;
+    HitStream hs;
+    hs.init(ring, packed, flatten_ids, start, end, lane, g);
+    hs.refill(6);
+    if (!__all(st.done) && hs.rd < hs.nq) {
+        bool v_n;
+        HRec h_n = hs.at(hs.rd, k, v_n);
+        float a_n = eval_alpha(h_n, g.px, g.py, v_n);
+        int sidx_n = h_n.sidx;
+        float4 b0[NG], b1[NG];
+        load_rows<NB>(colors, h_n.gid, d, ch0, p, b0);
+        auto kstep = [&](float4(&bc)[NG], float4(&bn)[NG]) -> bool {
+            const float a_c = a_n;
+            const int sidx_c = sidx_n;
+            hs.rd += 2;
+            if ((hs.nq - hs.rd) < 6 && hs.pending) hs.refill(6);
+            const bool more = hs.rd < hs.nq;
+            h_n = hs.at(hs.rd, k, v_n);
+            a_n = eval_alpha(h_n, g.px, g.py, v_n);
+            sidx_n = h_n.sidx;
+            load_rows<NB>(colors, h_n.gid, d, ch0, p, bn);
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a_c), __float_as_uint(a_c), false, false);
+            bool blended;
+            const float wgt = step_pair(st, __uint_as_float(sw[0]), __uint_as_float(sw[1]), k, blended);
+            st.cur = blended ? sidx_c : st.cur;
+            mfma_step<NB>(acc, wgt, bc);
+            return more && !__all(st.done);
+        };
+        // two K-steps per trip, ONE exit test (a second loop exit makes the register allocator shuffle the
+        // accumulators); a surplus step past the end / past saturation carries zero weights = exact no-op
+        bool go = true;
+        while (go) {
+            kstep(b0, b1);
+            go = kstep(b1, b0);
+        }
+    }
+    {
+        const auto cs = __builtin_amdgcn_permlane32_swap((unsigned)st.cur, (unsigned)st.cur, false, false);
+        st.cur = max((int)cs[0], (int)cs[1]);
+    }
+    if (k == 0) Tb[p] = st.T;
+    __builtin_amdgcn_wave_barrier();
+    if (k == 0 && g.inside && slice == 0) {
+        const size_t pix = (size_t)g.pi * width + g.pj;
+        render_alphas[pix] = 1.0f - st.T;
+        last_ids[pix] = st.cur;
+    }
+    epilogue<NB>(acc, g, width, height, d, ch0, backgrounds, render_colors, [&](int q, int, int) { return Tb[q]; });
+}
+
+template <int NB>
+int launch_feat(int d, int width, int height, int n_gauss, const float *colors, const float *backgrounds,
+                const int32_t *offsets, int n_isects, const int32_t *blk_rows, const float *wt, const int32_t *gid_s,
+                const float *Tbuf, float *out, hipStream_t st)
+{
+    const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
+    const int n_tiles = tile_w * tile_h, n_slices = d / (32 * NB);
+    hipLaunchKernelGGL(raster_fwd_feat<NB>, dim3(n_tiles * 8 * n_slices), dim3(64), 0, st, d, width, height, tile_w,
+                       n_tiles, n_slices, n_gauss, colors, backgrounds, offsets, n_isects, blk_rows, wt, gid_s, Tbuf,
+                       out);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+template <int NB>
+int launch_fused(int d, int width, int height, const GRec *packed, const float *colors, const float *backgrounds,
+                 const int32_t *offsets, const int32_t *flat, int n_isects, float *out, float *alphas,
+                 int32_t *last_ids, hipStream_t st)
+{
+    const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
+    const int n_tiles = tile_w * tile_h, n_slices = d / (32 * NB);
+    hipLaunchKernelGGL(raster_fwd_fused<NB>, dim3(n_tiles * 8 * n_slices), dim3(64), 0, st, d, width, height, tile_w,
+                       n_tiles, n_slices, packed, colors, backgrounds, offsets, flat, n_isects, out, alphas, last_ids);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+}  // namespace
+
+// feature pass of the split forward (after gags_raster_weights_launch)
+int gags_raster_fwd_feat_launch(int d, int width, int height, int n_gauss, const float *colors,
+                                const float *backgrounds, const int32_t *offsets, int n_isects,
+                                const int32_t *blk_rows, const float *wt, const int32_t *gid_s, const float *Tbuf,
+                                float *out, hipStream_t st)
+{
+    GAGS_CLEAR_ERR();
+#define ARGS d, width, height, n_gauss, colors, backgrounds, offsets, n_isects, blk_rows, wt, gid_s, Tbuf, out, st
+    if (d % 256 == 0) return launch_feat<8>(ARGS);
+    if (d % 128 == 0) return launch_feat<4>(ARGS);
+    if (d % 64 == 0) return launch_feat<2>(ARGS);
+    return launch_feat<1>(ARGS);
+#undef ARGS
+}
+
+// single-kernel forward (no scratch)
+int gags_raster_fwd_fused_launch(int d, int width, int height, const void *packed, const float *colors,
+                                 const float *backgrounds, const int32_t *offsets, const int32_t *flat, int n_isects,
+                                 float *out, float *alphas, int32_t *last_ids, hipStream_t st)
+{
+    GAGS_CLEAR_ERR();
+    const GRec *pk = reinterpret_cast<const GRec *>(packed);
+#define ARGS d, width, height, pk, colors, backgrounds, offsets, flat, n_isects, out, alphas, last_ids, st
+    if (d % 256 == 0) return launch_fused<8>(ARGS);
+    if (d % 128 == 0) return launch_fused<4>(ARGS);
+    if (d % 64 == 0) return launch_fused<2>(ARGS);
+    return launch_fused<1>(ARGS);
+#undef ARGS
+}

@@ -153,7 +153,11 @@ def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height, conics=
 
 
 class _Rasterize(torch.autograd.Function):
-    """K9 forward / K10 backward over pre-binned intersections."""
+    """K9 forward / K10 backward over pre-binned intersections.
+
+    Matrix-core widths (D % 32 == 0) run the split forward: one weights pass (alpha, transmittance,
+    stop rule: once per view) that leaves weight tiles in a scratch buffer, then the feature stream.
+    The same scratch feeds the staged, atomic-free colours-only backward."""
 
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, packed, width, height,
@@ -161,26 +165,28 @@ class _Rasterize(torch.autograd.Function):
         lib = _lib.load()
         means2d, conics, colors, opacities = _c(means2d), _c(conics), _c(colors), _c(opacities)
         backgrounds = None if backgrounds is None else _c(backgrounds)
-        d = colors.shape[1]
+        n, d = colors.shape
         dev = colors.device
         n_isects = flatten_ids.shape[0]
         out = torch.empty(height, width, d, device=dev)
         alphas = torch.empty(height, width, device=dev)
         last_ids = torch.empty(height, width, dtype=torch.int32, device=dev)
-        # row-slot counts for the staged (atomic-free) colours-only backward: only when the matrix-core
-        # path runs, the width fits it, and someone will ask for d loss / d colors
-        blk_rows = None
-        staged_ok = (packed is not None and d % 128 == 0 and d <= 1024 and ctx.needs_input_grad[2]
-                     and not (flags & (_lib.GAGS_FWD_NO_MFMA | _lib.GAGS_BWD_ATOMIC)))
-        if staged_ok:
-            blk_rows = torch.zeros(offsets.numel() * 8, dtype=torch.int32, device=dev)
+        split = packed is not None and not (flags & (_lib.GAGS_FWD_NO_MFMA | _lib.GAGS_FWD_FUSED))
+        scratch = blk_rows = None
+        nbytes = 0
+        if split:
+            nbytes = lib.gags_raster_fwd_scratch_bytes(n_isects, width, height)
+            scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            blk_rows = torch.empty(offsets.numel() * 8, dtype=torch.int32, device=dev)
         with profiler.stage("raster_fwd"):
-            check(lib.gags_raster_fwd(d, width, height, ptr(means2d), ptr(conics), ptr(opacities), ptr(colors),
+            check(lib.gags_raster_fwd(d, n, width, height, ptr(means2d), ptr(conics), ptr(opacities), ptr(colors),
                                       ptr(backgrounds), ptr(offsets), ptr(flatten_ids), n_isects, ptr(packed),
-                                      ptr(out), ptr(alphas), ptr(last_ids), ptr(blk_rows), flags & ~0xfc,
-                                      _stream()), "gags_raster_fwd")
+                                      ptr(out), ptr(alphas), ptr(last_ids), ptr(scratch), nbytes, ptr(blk_rows),
+                                      flags & 3, _stream()), "gags_raster_fwd")
+        staged = (split and d % 128 == 0 and d <= 1024 and ctx.needs_input_grad[2]
+                  and not (flags & _lib.GAGS_BWD_ATOMIC))
         ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, packed, alphas,
-                              last_ids, blk_rows)
+                              last_ids, scratch if staged else None, blk_rows if staged else None)
         ctx.cfg = (width, height, flags)
         ctx.mark_non_differentiable(last_ids)
         return out, alphas, last_ids
@@ -189,7 +195,7 @@ class _Rasterize(torch.autograd.Function):
     def backward(ctx, v_out, v_alphas, _v_last):
         lib = _lib.load()
         (means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, packed, alphas,
-         last_ids, blk_rows) = ctx.saved_tensors
+         last_ids, fwd_scratch, blk_rows) = ctx.saved_tensors
         width, height, flags = ctx.cfg
         n, d = colors.shape
         dev = colors.device
@@ -197,31 +203,31 @@ class _Rasterize(torch.autograd.Function):
         need_geom = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[3]
         v_out = torch.zeros(height, width, d, device=dev) if v_out is None else _c(v_out)
         v_alphas = None if v_alphas is None else _c(v_alphas)
+        v_bg = None
+        if backgrounds is not None and ctx.needs_input_grad[4]:
+            v_bg = ((1.0 - alphas)[..., None] * v_out).sum(dim=(0, 1))
         if not need_geom and blk_rows is not None:
-            return _Rasterize._backward_staged(lib, ctx, packed, offsets, flatten_ids, blk_rows, v_out, n, d, width,
-                                               height, backgrounds, alphas)
+            v_colors = _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height)
+            return None, None, v_colors, None, v_bg, None, None, None, None, None, None
         v_colors = torch.zeros(n, d, device=dev)
         if need_geom:
             v_opac = torch.zeros(n, device=dev)
             v_m2d = torch.zeros(n, 2, device=dev)
             v_con = torch.zeros(n, 3, device=dev)
-            bflags = flags
+            bflags = flags & 3
         else:
             v_opac = v_m2d = v_con = None
-            bflags = flags | _lib.GAGS_BWD_COLORS_ONLY
+            bflags = (flags & 3) | _lib.GAGS_BWD_COLORS_ONLY
         with profiler.stage("raster_bwd"):
             check(lib.gags_raster_bwd(d, width, height, ptr(means2d), ptr(conics), ptr(opacities), ptr(colors),
                                       ptr(backgrounds), ptr(offsets), ptr(flatten_ids), n_isects, ptr(packed),
                                       ptr(alphas), ptr(last_ids), ptr(v_out), ptr(v_alphas), ptr(v_colors),
                                       ptr(v_opac), ptr(v_m2d), ptr(v_con), bflags, _stream()), "gags_raster_bwd")
-        v_bg = None
-        if backgrounds is not None and ctx.needs_input_grad[4]:
-            v_bg = ((1.0 - alphas)[..., None] * v_out).sum(dim=(0, 1))
         return v_m2d, v_con, v_colors, v_opac, v_bg, None, None, None, None, None, None
 
 
-def _backward_staged(lib, ctx, packed, offsets, flatten_ids, blk_rows, v_out, n, d, width, height, backgrounds, alphas):
-    """Colours-only backward without atomics: rows counted by the forward -> prefix sum -> one 4-byte
+def _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height):
+    """Colours-only backward without atomics: slot counts of the forward -> prefix sum -> one 4-byte
     readback (total rows) -> stored partial rows -> sort by Gaussian -> segmented sum."""
     dev = v_out.device
     st = _stream()
@@ -235,32 +241,24 @@ def _backward_staged(lib, ctx, packed, offsets, flatten_ids, blk_rows, v_out, n,
         host = ctypes.c_int32(0)
         check(lib.gags_read_i32(ptr(total), ctypes.byref(host), st), "gags_read_i32")
     rows = int(host.value)
-    nbytes = lib.gags_bwd_staged_scratch_bytes(rows, flatten_ids.shape[0], n, d)
-    legacy = 0 if (ctx.cfg[2] & _lib.GAGS_BWD_MERGED) else 16  # default: rows per (block, hit)
+    nbytes = lib.gags_bwd_staged_scratch_bytes(rows, n, d)
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     v_colors = torch.empty(n, d, device=dev)
 
     def run(stage):
-        check(lib.gags_raster_bwd_colors_staged(d, width, height, n, ptr(packed), ptr(offsets), ptr(flatten_ids),
-                                                flatten_ids.shape[0], ptr(v_out), ptr(blk_rows), ptr(row_end), rows,
-                                                ptr(scratch), nbytes, ptr(v_colors), stage | legacy, st),
+        check(lib.gags_raster_bwd_colors_staged(d, n, width, height, ptr(offsets), n_isects, ptr(v_out), ptr(blk_rows),
+                                                ptr(row_end), rows, ptr(fwd_scratch), fwd_scratch.numel(),
+                                                ptr(scratch), nbytes, ptr(v_colors), stage, st),
               "gags_raster_bwd_colors_staged")
 
-    if profiler.ENABLED:  # one event pair per kernel group, for the roofline line of bench.py
-        names = (("bwd_rows_a", "bwd_rows_b") if legacy else ("bwd_weights", "bwd_merge")) + ("bwd_sort", "bwd_reduce")
-        for stage, name in enumerate(names, start=1):
+    if profiler.ENABLED:  # one event pair per kernel (group), for the roofline line of bench.py
+        for stage, name in enumerate(("bwd_rows", "bwd_sort", "bwd_reduce"), start=1):
             with profiler.stage(name):
                 run(stage)
     else:
         run(0)
     profiler.note("bwd_rows", rows)
-    v_bg = None
-    if backgrounds is not None and ctx.needs_input_grad[4]:
-        v_bg = ((1.0 - alphas)[..., None] * v_out).sum(dim=(0, 1))
-    return None, None, v_colors, None, v_bg, None, None, None, None, None, None
-
-
-_Rasterize._backward_staged = staticmethod(_backward_staged)
+    return v_colors
 
 
 def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, height,

@@ -101,14 +101,18 @@ int gags_pack_isects(int64_t n_isects, const int32_t *flatten_ids, const float *
  * colors[N,D] / backgrounds[D] (gaussian_renderer/__init__.py:61,64).
  * backgrounds may be NULL.  Outputs render_colors[H,W,D], render_alphas[H,W],
  * last_ids[H,W] (sorted index of the last blended Gaussian per pixel).
- * D % 32 == 0 with `packed` given runs on the matrix cores, anything else on the VALU kernels. */
-int gags_raster_fwd(int d, int width, int height, const float *means2d, const float *conics,
+ * Kernel choice: D % 32 == 0 with `packed` given runs on the matrix cores -- as the split
+ * weights + feature passes when `scratch` (gags_raster_fwd_scratch_bytes) and `blk_rows`
+ * ([tile_h*tile_w*8] int32, written) are provided, else as one fused kernel; anything else runs the
+ * VALU kernels.  The scratch and blk_rows of a split forward are what
+ * gags_raster_bwd_colors_staged consumes, so keep them alive until the backward. */
+int64_t gags_raster_fwd_scratch_bytes(int64_t n_isects, int width, int height);
+int gags_raster_fwd(int d, int n, int width, int height, const float *means2d, const float *conics,
                     const float *opacities, const float *colors, const float *backgrounds,
                     const int32_t *isect_offsets, const int32_t *flatten_ids, int64_t n_isects,
                     const void *packed /* from gags_pack_isects, or NULL: VALU kernels only */,
                     float *render_colors, float *render_alphas, int32_t *last_ids,
-                    int32_t *blk_rows /* optional [tile_h*tile_w*8]: row slots the staged backward
-                                         will need per 8x4 pixel block (MFMA path only), or NULL */,
+                    void *scratch, int64_t scratch_bytes, int32_t *blk_rows,
                     int flags, void *stream);
 
 /* K10: rasterize backward (what autograd runs under train.py:174).
@@ -124,19 +128,18 @@ int gags_raster_bwd(int d, int width, int height, const float *means2d, const fl
                     float *v_colors, float *v_opacities, float *v_means2d, float *v_conics,
                     int flags, void *stream);
 
-/* K10, staged flavour: colours-only backward WITHOUT atomics (deterministic).  Needs the
- * blk_rows written by gags_raster_fwd, their inclusive prefix sum row_end (gags_cumsum_i32) and
- * its total `rows` (gags_read_i32).  Partial sums are stored as rows, sorted by Gaussian and
- * reduced; v_colors[N,D] is written in full (no zero-fill needed).  D % 128 == 0, D <= 1024.
- * scratch: gags_bwd_staged_scratch_bytes(rows, n_isects, n, d) bytes.  Returns 1 when D is not eligible. */
-int64_t gags_bwd_staged_scratch_bytes(int64_t rows, int64_t n_isects, int n, int d);
-int gags_raster_bwd_colors_staged(int d, int width, int height, int n, const void *packed,
-                                  const int32_t *isect_offsets, const int32_t *flatten_ids,
+/* K10, staged flavour: colours-only backward WITHOUT atomics (deterministic), D % 128 == 0,
+ * D <= 1024.  Consumes the scratch + blk_rows of a split gags_raster_fwd, the inclusive prefix
+ * sum row_end of blk_rows (gags_cumsum_i32) and its total `rows` (gags_read_i32).  Partial sums
+ * are stored as rows, sorted by Gaussian and reduced; v_colors[N,D] is written in full (no
+ * zero-fill needed).  scratch: gags_bwd_staged_scratch_bytes(rows, n, d) bytes.
+ * stage: 0 = all, 1..3 = rows, sort, reduce (per-kernel timing).  Returns 1 when D is not eligible. */
+int64_t gags_bwd_staged_scratch_bytes(int64_t rows, int n, int d);
+int gags_raster_bwd_colors_staged(int d, int n, int width, int height, const int32_t *isect_offsets,
                                   int64_t n_isects, const float *v_render_colors,
                                   const int32_t *blk_rows, const int32_t *row_end, int64_t rows,
-                                  void *scratch, int64_t scratch_bytes, float *v_colors,
-                                  int stage /* low 4 bits: 0 = all, 1..4 = weights, merge, sort, reduce (per-kernel timing);
-                                               bit 4: per-(block,hit) rows instead of tile-merged rows */,
+                                  const void *fwd_scratch, int64_t fwd_scratch_bytes,
+                                  void *scratch, int64_t scratch_bytes, float *v_colors, int stage,
                                   void *stream);
 
 /* Diagnostics (roofline model): counts[0] += (pixel,Gaussian) pairs evaluated

@@ -96,21 +96,22 @@ def test_forward_and_colour_grad(oracle, n, w, h, d, seed, view, mult, bgv):
 
 
 def test_mfma_and_valu_paths_agree_bitwise(oracle):
-    """The two kernel families implement the same fmaf chain: identical bits, D=128."""
+    """The kernel families implement the same fmaf chain: identical bits, D=128 (split, fused, VALU)."""
     from gags_amd import _lib
     n, w, h, d = 4000, 192, 144, 128
     s = scene_arrays(n, d, w, h, seed=12, view=2, scale_mult=5.0)
     bg = np.full(d, 0.7, np.float32)
     a, aa, ia, _ = _run_gpu(s, w, h, s["colors"], bg)
-    b, ab, ib, _ = _run_gpu(s, w, h, s["colors"], bg, flags=_lib.GAGS_FWD_NO_MFMA)
-    np.testing.assert_array_equal(a, b)
-    np.testing.assert_array_equal(aa, ab)
-    np.testing.assert_array_equal(ia["last_ids"].cpu().numpy(), ib["last_ids"].cpu().numpy())
+    for flags in (_lib.GAGS_FWD_NO_MFMA, _lib.GAGS_FWD_FUSED):
+        b, ab, ib, _ = _run_gpu(s, w, h, s["colors"], bg, flags=flags)
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(aa, ab)
+        np.testing.assert_array_equal(ia["last_ids"].cpu().numpy(), ib["last_ids"].cpu().numpy())
 
 
 def test_backward_flavours_agree_and_staged_is_deterministic(oracle):
-    """Colours-only backward at D=256: tile-merged staged (default), per-block staged and the float-atomic
-    kernel compute the same sum; the staged ones use no atomics, so two runs are bit-identical."""
+    """Colours-only backward at D=256: the staged (default) and the float-atomic kernels compute the same sum,
+    after the split and after the fused forward; the staged one uses no atomics, so two runs are bit-identical."""
     from gags_amd import _lib
     n, w, h, d = 6000, 208, 160, 256
     s = scene_arrays(n, d, w, h, seed=14, view=5, scale_mult=6.0)
@@ -121,13 +122,14 @@ def test_backward_flavours_agree_and_staged_is_deterministic(oracle):
     o_vf = oracle.raster_bwd_colors_fwdorder(oinfo["means2d"], oinfo["conics"], s["opacities"], d, w, h,
                                              oinfo["isect_offsets"], oinfo["flatten_ids"], v_out, n)
     g = {}
-    for name, flags in (("merged", _lib.GAGS_BWD_MERGED), ("block", 0), ("block2", 0), ("atomic", _lib.GAGS_BWD_ATOMIC)):
+    for name, flags in (("block", 0), ("block2", 0), ("atomic", _lib.GAGS_BWD_ATOMIC),
+                        ("fused_atomic", _lib.GAGS_FWD_FUSED)):
         _, _, _, gr = _run_gpu(s, w, h, s["colors"], bg, flags=flags, v_out=v_out)
         g[name] = gr["colors"]
         assert rel_l2(g[name], o_vf) <= GRAD_TOL, name
     np.testing.assert_array_equal(g["block"], g["block2"])  # no atomics anywhere: reproducible bits
     culled = oinfo["radii"] == 0
-    assert np.all(g["merged"][culled] == 0) and np.all(g["block"][culled] == 0)  # v_colors written in full
+    assert np.all(g["block"][culled] == 0)  # v_colors written in full
 
 
 @pytest.mark.parametrize("n,w,h,d,seed,view", [(2500, 128, 96, 16, 7, 3), (2000, 100, 70, 3, 8, None)])
