@@ -56,11 +56,12 @@ __device__ __forceinline__ void mfma_step(f32x16 (&acc)[NB], float wgt, const fl
 }
 
 // out[pix][ch] = acc (+ T*bg); accumulator row r of lane (p,k) <-> pixel q = (r&3) + 8(r>>2) + 4k of the block.
-// Tq(q) returns the final transmittance of pixel q (only called for in-image pixels).
-template <int NB, typename TF>
+// Tq[r] = final transmittance of that pixel (fetched by the caller BEFORE this loop, unconditionally:
+// a load inside the per-row in-image branch would cost one serialized L2 round trip per row).
+template <int NB>
 __device__ __forceinline__ void epilogue(const f32x16 (&acc)[NB], const BlockGeom &g, int width, int height, int d,
                                          int ch0, const float *__restrict__ backgrounds,
-                                         float *__restrict__ render_colors, TF Tq)
+                                         float *__restrict__ render_colors, const float (&Tq)[16])
 {
     constexpr int VEC = FwdCfg<NB>::VEC, NG = FwdCfg<NB>::NG;
     float bgv[NB];
@@ -78,7 +79,6 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[NB], const BlockGeo
         const int q = (r & 3) + 8 * (r >> 2) + 4 * g.k;
         const int qj = g.bx0 + (q & 7), qi = g.by0 + (q >> 3);
         if (qi >= height || qj >= width) continue;
-        const float T = Tq(q, qi, qj);
         float *o = render_colors + ((size_t)qi * width + qj) * d + ch0 + VEC * g.p;
 #pragma unroll
         for (int gq = 0; gq < NG; ++gq) {
@@ -86,7 +86,7 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[NB], const BlockGeo
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 const float a = acc[gq * VEC + i][r];
-                v[i] = has_bg ? __builtin_fmaf(T, bgv[gq * VEC + i], a) : a;
+                v[i] = has_bg ? __builtin_fmaf(Tq[r], bgv[gq * VEC + i], a) : a;
             }
             if constexpr (VEC == 4) *reinterpret_cast<float4 *>(o + gq * 128) = make_float4(v[0], v[1], v[2], v[3]);
             else if constexpr (VEC == 2) *reinterpret_cast<float2 *>(o) = make_float2(v[0], v[1]);
@@ -128,33 +128,50 @@ __global__ __launch_bounds__(64, (NB >= 16 ? 1 : 2)) void raster_fwd_feat(
         const int wpos = (p & 1) * 16 + (p >> 1);
         // this lane's slot of step s, clamped to the block's last pair (surplus steps carry weight 0)
         auto slot_of = [&](int s) { return sb + 2 * min(s, steps - 1) + k; };
-        auto gid_of = [&](int s) { return min(gid_s[slot_of(s)], n_gauss - 1); };  // partner of a lone hit: any valid row
+        // raw id of the slot; clamped only when it is USED (a lone hit's partner slot carries N): touching the
+        // loaded value earlier would make the compiler wait for the load right after issuing it
+        auto gid_of = [&](int s) { return gid_s[slot_of(s)]; };
+        const int gmax = n_gauss - 1;
         // PD-deep software pipeline: the feature rows of step s+PD are requested while step s runs its
         // MFMAs (rows mostly come from L2 / Infinity Cache: ~1-2 us), the ids another PD steps earlier.
         constexpr int PD = 4;
         float a[PD];
         float4 b[PD][NG];
         int gq[PD];
+        // prologue: issue the loads in exactly the order of the steady state (rows, id, weight per step) so
+        // that the compiler's counted vmcnt waits agree on both edges into the loop
+        int g0[PD];
+#pragma unroll
+        for (int i = 0; i < PD; ++i) g0[i] = gid_of(i);
 #pragma unroll
         for (int i = 0; i < PD; ++i) {
+            load_rows<NB>(colors, min(g0[i], gmax), d, ch0, p, b[i]);
+            gq[i] = gid_of(PD + i);
             a[i] = wt[(size_t)slot_of(i) * 32 + wpos];
-            load_rows<NB>(colors, gid_of(i), d, ch0, p, b[i]);
+            __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int i = 0; i < PD; ++i) gq[i] = gid_of(PD + i);
         for (int s = 0; s < steps; s += PD) {
 #pragma unroll
             for (int i = 0; i < PD; ++i) {
                 const float a_c = (s + i < steps) ? a[i] : 0.f;
                 mfma_step<NB>(acc, a_c, b[i]);
-                a[i] = wt[(size_t)slot_of(s + PD + i) * 32 + wpos];
-                load_rows<NB>(colors, gq[i], d, ch0, p, b[i]);
+                load_rows<NB>(colors, min(gq[i], gmax), d, ch0, p, b[i]);
                 gq[i] = gid_of(s + 2 * PD + i);
+                a[i] = wt[(size_t)slot_of(s + PD + i) * 32 + wpos];
+                // the machine scheduler would otherwise sink these loads to just before their use PD steps
+                // later (it minimises register pressure), collapsing the pipeline to depth 1
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
-    epilogue<NB>(acc, g, width, height, d, ch0, backgrounds, render_colors,
-                 [&](int, int qi, int qj) { return Tbuf[(size_t)qi * width + qj]; });
+    float Tq[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int q = (r & 3) + 8 * (r >> 2) + 4 * k;
+        const int qj = min(g.bx0 + (q & 7), width - 1), qi = min(g.by0 + (q >> 3), height - 1);
+        Tq[r] = Tbuf[(size_t)qi * width + qj];
+    }
+    epilogue<NB>(acc, g, width, height, d, ch0, backgrounds, render_colors, Tq);
 }
 
 template <int NB>
@@ -234,7 +251,10 @@ __global__ __launch_bounds__(64, (NB >= 16 ? 1 : 2)) void raster_fwd_fused(
         render_alphas[pix] = 1.0f - st.T;
         last_ids[pix] = st.cur;
     }
-    epilogue<NB>(acc, g, width, height, d, ch0, backgrounds, render_colors, [&](int q, int, int) { return Tb[q]; });
+    float Tq[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Tq[r] = Tb[(r & 3) + 8 * (r >> 2) + 4 * k];
+    epilogue<NB>(acc, g, width, height, d, ch0, backgrounds, render_colors, Tq);
 }
 
 template <int NB>
