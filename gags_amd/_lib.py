@@ -34,7 +34,7 @@ SIGNATURES = {
     "gags_sort_scratch_bytes": (_i64, [_i64]),
     "gags_sort_pairs": (_i32, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "gags_tile_offsets": (_i32, [_i64, _vp, _i32, _vp, _vp]),
-    "gags_pack_isects": (_i32, [_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gags_pack_isects": (_i32, [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_raster_fwd_scratch_bytes": (_i64, [_i64, _i32, _i32]),
     "gags_raster_fwd": (_i32, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
                                _vp, _i64, _vp, _i32, _vp]),

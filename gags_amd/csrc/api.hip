@@ -13,8 +13,8 @@ int gags_raster_bwd_valu(int d, int width, int height, const float *means2d, con
                          const int32_t *last_ids, const float *v_out, const float *v_alpha, float *v_colors,
                          float *v_opac, float *v_m2d, float *v_con, bool geom, hipStream_t st);
 // raster_weights.hip
-int gags_pack_isects_launch(int n_isects, const int32_t *flat, const float *means2d, const float *conics,
-                            const float *opacities, void *packed, hipStream_t st);
+int gags_pack_isects_launch(int n, int n_isects, const int32_t *flat, const float *means2d, const float *conics,
+                            const float *opacities, const int32_t *radii, void *grec, void *packed, hipStream_t st);
 int gags_raster_weights_launch(int width, int height, int n_gauss, const void *packed, const int32_t *offsets,
                                const int32_t *flat, int n_isects, float *wt, int32_t *gid_s, int32_t *blk_rows,
                                float *Tbuf, float *alphas, int32_t *last_ids, hipStream_t st);
@@ -41,14 +41,15 @@ inline int64_t al256(int64_t x) { return (x + 255) / 256 * 256; }
 struct FwdScratch {
     int64_t wt, gid, tbuf, total;
 };
-// slot space: 8 * (n_isects + n_tiles) slots (+ slack so that the backward may read a whole 32-slot tile)
+// slot space: GAGS_BLOCKS_PER_TILE * (n_isects + n_tiles) slots of 64 weights (+ slack so that the backward may
+// read a whole 32-slot tile)
 inline FwdScratch fwd_layout(int64_t n_isects, int width, int height)
 {
     const int64_t tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
-    const int64_t slots = 8 * (n_isects + tile_w * tile_h) + 64;
+    const int64_t slots = GAGS_BLOCKS_PER_TILE * (n_isects + tile_w * tile_h) + 64;
     FwdScratch L;
     int64_t o = 0;
-    L.wt = o; o += al256(slots * 128);
+    L.wt = o; o += al256(slots * 256);
     L.gid = o; o += al256(slots * 4);
     L.tbuf = o; o += al256((int64_t)width * height * 4);
     L.total = o;
@@ -57,13 +58,14 @@ inline FwdScratch fwd_layout(int64_t n_isects, int width, int height)
 inline bool mfma_width(int d) { return d >= 32 && d % 32 == 0; }
 }  // namespace
 
-extern "C" int gags_pack_isects(int64_t n_isects, const int32_t *flatten_ids, const float *means2d,
-                                const float *conics, const float *opacities, void *packed, void *stream)
+extern "C" int gags_pack_isects(int n, int64_t n_isects, const int32_t *flatten_ids, const float *means2d,
+                                const float *conics, const float *opacities, const int32_t *radii, void *grec,
+                                void *packed, void *stream)
 {
-    if (n_isects < 0 || n_isects >= (1ll << 31)) return GAGS_EINVAL;
+    if (n < 0 || n_isects < 0 || n_isects >= (1ll << 31)) return GAGS_EINVAL;
     if (n_isects == 0) return GAGS_OK;
     if (!flatten_ids || !means2d || !conics || !opacities || !packed) return GAGS_EINVAL;
-    return gags_pack_isects_launch((int)n_isects, flatten_ids, means2d, conics, opacities, packed,
+    return gags_pack_isects_launch(n, (int)n_isects, flatten_ids, means2d, conics, opacities, radii, grec, packed,
                                    (hipStream_t)stream);
 }
 

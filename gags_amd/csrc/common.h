@@ -79,12 +79,13 @@ __device__ __forceinline__ int gags_tile_of_order(int o, int tile_w, int tile_h)
     return (y0 + (r - x * h)) * tile_w + x;
 }
 
-// Slot space of the matrix-core rasterizer (raster_weights.hip): every (tile, 8x4 block) owns a fixed
+// Slot space of the matrix-core rasterizer (raster_weights.hip): every (tile, 8x8 block) owns a fixed
 // region of K-step slots sized by the tile's list length, so no counting pass is needed.
-//   base(tile, blk) = 8*(start + tile) + blk * even(L),  capacity even(L),  L = end - start
-// Total slot count for a view: 8 * (n_isects + n_tiles).
+//   base(tile, blk) = 4*(start + tile) + blk * even(L),  capacity even(L),  L = end - start,  blk in 0..3
+// Total slot count for a view: 4 * (n_isects + n_tiles).  A slot holds 64 weights (256 B).
+#define GAGS_BLOCKS_PER_TILE 4
 __host__ __device__ __forceinline__ int gags_slot_base(int start, int end, int tile, int blk)
 {
     const int lp = (end - start + 1) & ~1;
-    return 8 * (start + tile) + blk * lp;
+    return GAGS_BLOCKS_PER_TILE * (start + tile) + blk * lp;
 }

@@ -1,8 +1,8 @@
 // K10 colours-only backward on the matrix cores (the GAD flow consumes only d loss / d colors:
 // scene/gaussian_model.py:192-208):     v_colors[g, :] = sum_px w[px, g] * v_out[px, :],  w = alpha*T.
 //
-// Per wave the cotangent slab v_out[32 px][128 ch] lives in 64 VGPRs as MFMA B operands (K = pixel
-// pairs, N = channels); A operands are 32-slot weight tiles (rows = slots); every tile costs 16 K-steps x
+// Per wave the cotangent slab of its pixel block x 128 channels lives in VGPRs as MFMA B operands (K = pixel
+// pairs, N = channels); A operands are 32-slot weight tiles (rows = slots); a tile costs (pixels/2) K-steps x
 // 4 channel tiles of v_mfma_f32_32x32x2_f32 and yields 32 partial gradient rows of 128 channels.
 //
 // What happens to those rows is the whole story on this part: float atomics are executed at the memory
@@ -30,23 +30,6 @@ constexpr int CSB = 32 * NBB;  // 128 channels per wave
 __device__ __forceinline__ void atomic_add_f32(float *p, float v)
 {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// cotangent slab as B operands in the "strided-4" channel order: V[s][j] = v_out[pixel 2s+k][ch0 + 4p + j]
-// (channel tile j holds channels {4n+j}): one float4 load per K-step and float4 row stores afterwards
-__device__ __forceinline__ void load_slab4(float (&V)[16][NBB], const float *__restrict__ v_out, const BlockGeom &g,
-                                           int width, int height, int d, int ch0)
-{
-    static_assert(NBB == 4, "float4 slab");
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        const int q = 2 * s + g.k;
-        const int qj = g.bx0 + (q & 7), qi = g.by0 + (q >> 3);
-        const bool ok = (qi < height) && (qj < width);
-        const float4 v = ok ? *reinterpret_cast<const float4 *>(v_out + ((size_t)qi * width + qj) * d + ch0 + 4 * g.p)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
-        V[s][0] = v.x; V[s][1] = v.y; V[s][2] = v.z; V[s][3] = v.w;
-    }
 }
 
 // cotangent slab as B operands: V[s][j] = v_out[pixel q = 2s+k][ch0 + 32j + p]
@@ -77,52 +60,68 @@ __device__ __forceinline__ void tile_mfma(f32x16 (&acc)[NBB], const float (&A)[1
 }
 
 // ---- staged: rows ------------------------------------------------------------------------------------
+// One wave per (tile, 8x8 block, 128-channel slice).  K = the block's 64 pixels: K-step t pairs pixel t of
+// the upper 8x4 half (k = 0) with pixel t of the lower half (k = 1), exactly the [upper | lower] row layout
+// raster_weights wrote.  The cotangent slab (64 px x 128 ch) sits in 128 VGPRs as B operands.
 __global__ __launch_bounds__(64, 2) void raster_bwd_rows(
     int d, int width, int height, int tile_w, int n_tiles, int n_slices, const float *__restrict__ v_render_colors,
     const int32_t *__restrict__ offsets, int n_isects, const int32_t *__restrict__ blk_rows,
     const int32_t *__restrict__ row_end, const float *__restrict__ wt, const int32_t *__restrict__ gid_s,
     float *__restrict__ prow, uint32_t *__restrict__ row_key, int32_t *__restrict__ row_idx)
 {
-    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * 8 * n_slices);
+    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * GAGS_BLOCKS_PER_TILE * n_slices);
     const int slice = logical % n_slices, rest = logical / n_slices;
-    const int blk = rest & 7;
-    const int tile = gags_tile_of_order(rest >> 3, tile_w, n_tiles / tile_w);
-    const int cnt = blk_rows[tile * 8 + blk];
+    const int blk = rest & 3;
+    const int tile = gags_tile_of_order(rest >> 2, tile_w, n_tiles / tile_w);
+    const int cnt = blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk];
     if (cnt == 0) return;
-    const int base = row_end[tile * 8 + blk] - cnt;  // first compact row of the block
+    const int base = row_end[tile * GAGS_BLOCKS_PER_TILE + blk] - cnt;  // first compact row of the block
     const int start = offsets[tile];
     const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
     const int sb = gags_slot_base(start, end, tile, blk);
     const int ch0 = slice * CSB;
     const int lane = threadIdx.x;
-    BlockGeom g;
+    BlockGeom64 g;
     g.init(tile, blk, tile_w, width, height, lane);
     const int p = g.p, k = g.k;
 
-    float V[16][NBB];
-    load_slab4(V, v_render_colors, g, width, height, d, ch0);
+    // V[t][j] = v_out[pixel t of half k][ch0 + 4p + j]  ("strided-4" channel tiles: float4 loads / stores)
+    float V[32][NBB];
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+        const int qj = g.bx0 + (t & 7), qi = g.by0 + 4 * k + (t >> 3);
+        const bool ok = (qi < height) && (qj < width);
+        const float4 v = *reinterpret_cast<const float4 *>(
+            v_render_colors + ((size_t)min(qi, height - 1) * width + min(qj, width - 1)) * d + ch0 + 4 * p);
+        V[t][0] = ok ? v.x : 0.f; V[t][1] = ok ? v.y : 0.f; V[t][2] = ok ? v.z : 0.f; V[t][3] = ok ? v.w : 0.f;
+    }
 
-    // weight tile m: slots sb+32m .. +31; lane (i = p, k) owns 16 consecutive floats of row i (pixels 2s+k)
-    auto load_a = [&](int m, float4(&a)[4]) {
-        const float4 *src = reinterpret_cast<const float4 *>(wt + (size_t)(sb + 32 * m + p) * 32 + k * 16);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) a[t] = src[t];
-    };
     const int nblocks = (cnt + 31) >> 5;
-    float4 an[4];
-    load_a(0, an);
     for (int m = 0; m < nblocks; ++m) {
-        float A[16];
+        // weight tile m: slots sb+32m .. +31; lane (i = p, k) owns the 32 floats of half k of row i
+        float A[32];
+        {
+            const float4 *src = reinterpret_cast<const float4 *>(wt + (size_t)(sb + 32 * m + p) * 64 + k * 32);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { A[4 * t] = an[t].x; A[4 * t + 1] = an[t].y; A[4 * t + 2] = an[t].z; A[4 * t + 3] = an[t].w; }
-        load_a(min(m + 1, nblocks - 1), an);  // prefetch
+            for (int t = 0; t < 8; ++t) {
+                const float4 v = src[t];
+                A[4 * t] = v.x; A[4 * t + 1] = v.y; A[4 * t + 2] = v.z; A[4 * t + 3] = v.w;
+            }
+        }
         const int count = min(32, cnt - 32 * m);
         if (slice == 0 && k == 0 && p < count) {  // row -> Gaussian map for the sort
             row_key[base + 32 * m + p] = (uint32_t)gid_s[sb + 32 * m + p];
             row_idx[base + 32 * m + p] = base + 32 * m + p;
         }
         f32x16 acc[NBB];
-        tile_mfma(acc, A, V);
+#pragma unroll
+        for (int j = 0; j < NBB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 32; ++t)
+#pragma unroll
+            for (int j = 0; j < NBB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[t], V[t][j], acc[j], 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int slot = (r & 3) + 8 * (r >> 2) + 4 * k;
@@ -319,7 +318,7 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
     float *prow = (float *)(sb + L.prow);
     if (rows > 0) {
         if (sA)
-            hipLaunchKernelGGL(raster_bwd_rows, dim3(n_tiles * 8 * n_slices), dim3(64), 0, st, d, width, height, tile_w,
+            hipLaunchKernelGGL(raster_bwd_rows, dim3(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices), dim3(64), 0, st, d, width, height, tile_w,
                                n_tiles, n_slices, v_out, offsets, n_isects, blk_rows, row_end, wt, gid_s, prow, key, idx);
         if (sS) {
             int nbits = 1;

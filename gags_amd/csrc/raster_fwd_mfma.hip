@@ -3,10 +3,10 @@
 // to the sequential definition (and to each other and to the VALU kernels).
 //
 //  raster_fwd_feat<NB>   default; needs the scratch written by raster_weights.hip.
-//      One wave per (tile, 8x4 block, slice of 32*NB channels): a pure stream.  Per K-step one dword
-//      of weights per lane (the 32x2 A operand, read column-wise from wt), two feature rows as float4
-//      per lane (the B operands, straight from global/L2 into VGPRs, one step ahead) and NB MFMAs.
-//      No alpha work, no LDS, no barrier.
+//      One wave per (tile, 8x8 block, slice of 32*NB <= 128 channels): a pure stream.  Per K-step two
+//      dwords of weights per lane (the two 32x2 A operands of the block's upper / lower half, read
+//      column-wise from wt), two feature rows as one float4 per lane (the B operands, straight from
+//      global/L2 into VGPRs, four steps ahead) and 2*NB MFMAs.  No alpha work, no LDS, no barrier.
 //  raster_fwd_fused<NB>  fallback when the caller provides no scratch: same decomposition, but every
 //      wave also runs the HitStream / alpha / transmittance pipeline itself (repeated per slice).
 //
@@ -95,37 +95,39 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[NB], const BlockGeo
     }
 }
 
+// Feature pass over 8x8 pixel blocks: each lane owns two pixels (upper / lower half of the block), i.e. the
+// wave holds TWO 32-row accumulator sets of NB channel tiles each (NB = 4: 128 channels, 128 VGPRs).
 template <int NB>
-__global__ __launch_bounds__(64, (NB >= 16 ? 1 : 2)) void raster_fwd_feat(
+__global__ __launch_bounds__(64, 2) void raster_fwd_feat(
     int d, int width, int height, int tile_w, int n_tiles, int n_slices, int n_gauss,
     const float *__restrict__ colors, const float *__restrict__ backgrounds, const int32_t *__restrict__ offsets,
     int n_isects, const int32_t *__restrict__ blk_rows, const float *__restrict__ wt,
     const int32_t *__restrict__ gid_s, const float *__restrict__ Tbuf, float *__restrict__ render_colors)
 {
+    static_assert(NB == 1 || NB == 2 || NB == 4, "one float4 (or less) of channels per lane");
     constexpr int CS = FwdCfg<NB>::CS, NG = FwdCfg<NB>::NG;
-    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * 8 * n_slices);
+    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * GAGS_BLOCKS_PER_TILE * n_slices);
     const int slice = logical % n_slices, rest = logical / n_slices;
-    const int blk = rest & 7;
-    const int tile = gags_tile_of_order(rest >> 3, tile_w, n_tiles / tile_w);
+    const int blk = rest & 3;
+    const int tile = gags_tile_of_order(rest >> 2, tile_w, n_tiles / tile_w);
     const int ch0 = slice * CS;
     const int lane = threadIdx.x;
-    BlockGeom g;
+    BlockGeom64 g;
     g.init(tile, blk, tile_w, width, height, lane);
     const int p = g.p, k = g.k;
     const int start = offsets[tile];
     const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
     const int sb = gags_slot_base(start, end, tile, blk);
-    const int cnt = blk_rows[tile * 8 + blk];
+    const int cnt = blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk];
     const int steps = cnt >> 1;
 
-    f32x16 acc[NB];
+    f32x16 accA[NB], accB[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) { accA[j][r] = 0.f; accB[j][r] = 0.f; }
 
     if (steps > 0) {
-        const int wpos = (p & 1) * 16 + (p >> 1);
         // this lane's slot of step s, clamped to the block's last pair (surplus steps carry weight 0)
         auto slot_of = [&](int s) { return sb + 2 * min(s, steps - 1) + k; };
         // raw id of the slot; clamped only when it is USED (a lone hit's partner slot carries N): touching the
@@ -135,10 +137,10 @@ __global__ __launch_bounds__(64, (NB >= 16 ? 1 : 2)) void raster_fwd_feat(
         // PD-deep software pipeline: the feature rows of step s+PD are requested while step s runs its
         // MFMAs (rows mostly come from L2 / Infinity Cache: ~1-2 us), the ids another PD steps earlier.
         constexpr int PD = 4;
-        float a[PD];
+        float aA[PD], aB[PD];
         float4 b[PD][NG];
         int gq[PD];
-        // prologue: issue the loads in exactly the order of the steady state (rows, id, weight per step) so
+        // prologue: issue the loads in exactly the order of the steady state (rows, id, weights per step) so
         // that the compiler's counted vmcnt waits agree on both edges into the loop
         int g0[PD];
 #pragma unroll
@@ -147,31 +149,41 @@ __global__ __launch_bounds__(64, (NB >= 16 ? 1 : 2)) void raster_fwd_feat(
         for (int i = 0; i < PD; ++i) {
             load_rows<NB>(colors, min(g0[i], gmax), d, ch0, p, b[i]);
             gq[i] = gid_of(PD + i);
-            a[i] = wt[(size_t)slot_of(i) * 32 + wpos];
+            const float *w = wt + (size_t)slot_of(i) * 64 + p;
+            aA[i] = w[0]; aB[i] = w[32];
             __builtin_amdgcn_sched_barrier(0);
         }
         for (int s = 0; s < steps; s += PD) {
 #pragma unroll
             for (int i = 0; i < PD; ++i) {
-                const float a_c = (s + i < steps) ? a[i] : 0.f;
-                mfma_step<NB>(acc, a_c, b[i]);
+                const bool live = s + i < steps;
+                mfma_step<NB>(accA, live ? aA[i] : 0.f, b[i]);
+                mfma_step<NB>(accB, live ? aB[i] : 0.f, b[i]);
                 load_rows<NB>(colors, min(gq[i], gmax), d, ch0, p, b[i]);
                 gq[i] = gid_of(s + 2 * PD + i);
-                a[i] = wt[(size_t)slot_of(s + PD + i) * 32 + wpos];
+                const float *w = wt + (size_t)slot_of(s + PD + i) * 64 + p;
+                aA[i] = w[0]; aB[i] = w[32];
                 // the machine scheduler would otherwise sink these loads to just before their use PD steps
                 // later (it minimises register pressure), collapsing the pipeline to depth 1
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
+    // accumulator row r of lane (p,k) <-> pixel q = (r&3) + 8(r>>2) + 4k of a 8x4 half
     float Tq[16];
+    BlockGeom half;
+    half.p = p; half.k = k; half.bx0 = g.bx0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int q = (r & 3) + 8 * (r >> 2) + 4 * k;
-        const int qj = min(g.bx0 + (q & 7), width - 1), qi = min(g.by0 + (q >> 3), height - 1);
-        Tq[r] = Tbuf[(size_t)qi * width + qj];
+    for (int hb = 0; hb < 2; ++hb) {
+        half.by0 = g.by0 + 4 * hb;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = (r & 3) + 8 * (r >> 2) + 4 * k;
+            const int qj = min(half.bx0 + (q & 7), width - 1), qi = min(half.by0 + (q >> 3), height - 1);
+            Tq[r] = Tbuf[(size_t)qi * width + qj];
+        }
+        epilogue<NB>(hb ? accB : accA, half, width, height, d, ch0, backgrounds, render_colors, Tq);
     }
-    epilogue<NB>(acc, g, width, height, d, ch0, backgrounds, render_colors, Tq);
 }
 
 template <int NB>
@@ -264,7 +276,7 @@ int launch_feat(int d, int width, int height, int n_gauss, const float *colors, 
 {
     const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
     const int n_tiles = tile_w * tile_h, n_slices = d / (32 * NB);
-    hipLaunchKernelGGL(raster_fwd_feat<NB>, dim3(n_tiles * 8 * n_slices), dim3(64), 0, st, d, width, height, tile_w,
+    hipLaunchKernelGGL(raster_fwd_feat<NB>, dim3(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices), dim3(64), 0, st, d, width, height, tile_w,
                        n_tiles, n_slices, n_gauss, colors, backgrounds, offsets, n_isects, blk_rows, wt, gid_s, Tbuf,
                        out);
     GAGS_CHECK_LAUNCH();
@@ -294,7 +306,6 @@ int gags_raster_fwd_feat_launch(int d, int width, int height, int n_gauss, const
 {
     GAGS_CLEAR_ERR();
 #define ARGS d, width, height, n_gauss, colors, backgrounds, offsets, n_isects, blk_rows, wt, gid_s, Tbuf, out, st
-    if (d % 256 == 0) return launch_feat<8>(ARGS);
     if (d % 128 == 0) return launch_feat<4>(ARGS);
     if (d % 64 == 0) return launch_feat<2>(ARGS);
     return launch_feat<1>(ARGS);

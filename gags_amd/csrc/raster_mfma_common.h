@@ -112,6 +112,27 @@ struct BlockGeom {
     }
 };
 
+// Geometry of a wave's 8x8 pixel block (the split forward / staged backward): a tile = four such blocks.
+// Lane (p, k) owns TWO pixels of the block: "A" = pixel p of its upper 8x4 half, "B" = pixel p of its
+// lower half (row + 4); they are the two 32-row MFMA blocks of the wave.
+struct BlockGeom64 {
+    int bx0, by0, pj, piA, piB, p, k;
+    bool insideA, insideB;
+    float px, pyA, pyB, rx0, rx1, ry0, ry1;
+    __device__ __forceinline__ void init(int tile, int blk, int tile_w, int width, int height, int lane)
+    {
+        p = lane & 31; k = lane >> 5;
+        const int ty = tile / tile_w, tx = tile - ty * tile_w;
+        bx0 = tx * GAGS_TILE + (blk & 1) * 8;
+        by0 = ty * GAGS_TILE + (blk >> 1) * 8;
+        pj = bx0 + (p & 7); piA = by0 + (p >> 3); piB = piA + 4;
+        insideA = (piA < height) && (pj < width);
+        insideB = (piB < height) && (pj < width);
+        px = (float)pj + 0.5f; pyA = (float)piA + 0.5f; pyB = (float)piB + 0.5f;
+        rx0 = (float)bx0 + 0.5f; rx1 = (float)bx0 + 7.5f; ry0 = (float)by0 + 0.5f; ry1 = (float)by0 + 7.5f;
+    }
+};
+
 // Producer half of the per-wave pipeline (see the header comment).
 struct HitStream {
     HRec *ring;
@@ -153,8 +174,9 @@ struct HitStream {
         }
         nq += __popcll(mask);
     }
+    template <typename Geom>
     __device__ __forceinline__ void init(HRec *ring_, const GRec *packed_, const int32_t *flat_, int start_, int end_,
-                                         int lane_, const BlockGeom &g)
+                                         int lane_, const Geom &g)
     {
         ring = ring_; packed = packed_; flat = flat_; start = start_; end = end_; lane = lane_;
         rx0 = g.rx0; rx1 = g.rx1; ry0 = g.ry0; ry1 = g.ry1;

@@ -1,17 +1,20 @@
 // K8b + the WEIGHTS pass of the matrix-core rasterizer.
 //
-// raster_weights: one wave per (tile, 8x4 pixel block).  It does ALL the per-(pixel, Gaussian)
+// raster_weights: one wave per (tile, 8x8 pixel block; each lane owns two pixels).  It does ALL the per-(pixel, Gaussian)
 // scalar work of the view exactly once -- alpha, skip rule, transmittance chain, stop rule --
 // independent of the feature width, at high occupancy (no accumulators: ~45 VGPRs), and leaves
 // behind what the feature-width-proportional passes need as pure streams:
-//   wt[slot][32]   : alpha*T of the block's pixels for every K-step slot that blended anything,
-//                    stored as the MFMA A-operand image of the BACKWARD (row = slot, columns in
-//                    [k][s] pixel order); the forward reads the same rows column-wise;
+//   wt[slot][64]   : alpha*T of the block's 64 pixels for every K-step slot that blended anything
+//                    ([upper 8x4 half | lower 8x4 half]): row-wise it is the MFMA A operand of the
+//                    BACKWARD (K-step t pairs pixel t of the upper half with pixel t of the lower half),
+//                    column-wise the two A operands of the forward;
 //   gid[slot]      : Gaussian id of the slot (N for the unused partner of a lone last hit);
 //   blk_rows[blk]  : number of slots of the block (even);
 //   Tbuf / render_alphas / last_ids : per-pixel results of the chain.
 // Slots of a block live in a fixed, sparse region of the slot space (no counting pre-pass):
-//   region(tile, blk) = 8*(offsets[tile] + tile) + blk * even(L_tile), capacity even(L_tile).
+//   region(tile, blk) = 4*(offsets[tile] + tile) + blk * even(L_tile), capacity even(L_tile).
+// 8x8 rather than 8x4 blocks: a Gaussian then leaves ~36 % fewer (block, slot) rows, and those rows are the
+// backward's HBM traffic; the price is ~30 % more zero weights inside the MFMA tiles.
 #include "raster_mfma_common.h"
 
 using namespace gags_mfma;
@@ -29,6 +32,30 @@ __global__ __launch_bounds__(256) void pack_isects_kernel(int n_isects, const in
     packed[s] = make_grec(means2d, conics, opacities, flatten_ids[s]);
 }
 
+// two-step packing: the record (incl. the log / sqrt of the extent) is built once per GAUSSIAN, then the
+// per-intersection pass is a pure 32-byte gather (5x fewer transcendental evaluations at I/N ~ 5)
+__global__ __launch_bounds__(256) void make_grec_kernel(int n, const float *__restrict__ means2d,
+                                                        const float *__restrict__ conics,
+                                                        const float *__restrict__ opacities,
+                                                        const int32_t *__restrict__ radii, GRec *__restrict__ grec)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= n) return;
+    if (radii && radii[g] <= 0) return;  // never referenced by an intersection
+    grec[g] = make_grec(means2d, conics, opacities, g);
+}
+
+__global__ __launch_bounds__(256) void gather_grec_kernel(int n_isects, const int32_t *__restrict__ flatten_ids,
+                                                          const GRec *__restrict__ grec, GRec *__restrict__ packed)
+{
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_isects) return;
+    const float4 *src = reinterpret_cast<const float4 *>(grec + flatten_ids[s]);
+    float4 *dst = reinterpret_cast<float4 *>(packed + s);
+    const float4 u = src[0], v = src[1];
+    dst[0] = u; dst[1] = v;
+}
+
 __global__ __launch_bounds__(64, 4) void raster_weights_kernel(
     int width, int height, int tile_w, int n_tiles, int n_gauss, const GRec *__restrict__ packed,
     const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids, int n_isects,
@@ -37,11 +64,11 @@ __global__ __launch_bounds__(64, 4) void raster_weights_kernel(
 {
     __shared__ __attribute__((aligned(16))) HRec ring[RING];
 
-    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * 8);
-    const int blk = logical & 7;
-    const int tile = gags_tile_of_order(logical >> 3, tile_w, n_tiles / tile_w);
+    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * GAGS_BLOCKS_PER_TILE);
+    const int blk = logical & 3;
+    const int tile = gags_tile_of_order(logical >> 2, tile_w, n_tiles / tile_w);
     const int lane = threadIdx.x;
-    BlockGeom g;
+    BlockGeom64 g;
     g.init(tile, blk, tile_w, width, height, lane);
     const int p = g.p, k = g.k;
 
@@ -49,65 +76,82 @@ __global__ __launch_bounds__(64, 4) void raster_weights_kernel(
     const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
     const int sb = gags_slot_base(start, end, tile, blk);
 
-    PixState st;
-    st.T = 1.0f; st.cur = 0; st.done = !g.inside;
+    PixState sA, sB;  // the lane's two pixels (upper / lower half of the 8x8 block)
+    sA.T = 1.0f; sA.cur = 0; sA.done = !g.insideA;
+    sB.T = 1.0f; sB.cur = 0; sB.done = !g.insideB;
 
     HitStream hs;
     hs.init(ring, packed, flatten_ids, start, end, lane, g);
 
     int row = sb;
-    const int wpos = (p & 1) * 16 + (p >> 1);  // pixel p inside a slot row, [k][s] order (p = 2s + k)
     hs.refill(6);
-    if (!__all(st.done) && hs.rd < hs.nq) {
+    if (!__all(sA.done && sB.done) && hs.rd < hs.nq) {
         bool v_n;
         HRec h_n = hs.at(hs.rd, k, v_n);
-        float a_n = eval_alpha(h_n, g.px, g.py, v_n);
+        float aA_n = eval_alpha(h_n, g.px, g.pyA, v_n), aB_n = eval_alpha(h_n, g.px, g.pyB, v_n);
         int gid_n = v_n ? h_n.gid : n_gauss, sidx_n = h_n.sidx;
         auto kstep = [&]() -> bool {
-            const float a_c = a_n;
+            const float aA_c = aA_n, aB_c = aB_n;
             const int gid_c = gid_n, sidx_c = sidx_n;
             hs.rd += 2;
             if ((hs.nq - hs.rd) < 6 && hs.pending) hs.refill(6);
             const bool more = hs.rd < hs.nq;
             h_n = hs.at(hs.rd, k, v_n);
-            a_n = eval_alpha(h_n, g.px, g.py, v_n);  // one step ahead of the chain below
+            aA_n = eval_alpha(h_n, g.px, g.pyA, v_n);  // one step ahead of the chains below
+            aB_n = eval_alpha(h_n, g.px, g.pyB, v_n);
             gid_n = v_n ? h_n.gid : n_gauss;
             sidx_n = h_n.sidx;
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a_c), __float_as_uint(a_c), false, false);
-            bool blended;
-            const float wgt = step_pair(st, __uint_as_float(sw[0]), __uint_as_float(sw[1]), k, blended);
-            st.cur = blended ? sidx_c : st.cur;
-            if (__any(wgt != 0.f)) {  // steps nobody blends leave no slot
-                wt[(size_t)(row + k) * 32 + wpos] = wgt;  // 2 x 128 B per step
+            const auto swA = __builtin_amdgcn_permlane32_swap(__float_as_uint(aA_c), __float_as_uint(aA_c), false, false);
+            const auto swB = __builtin_amdgcn_permlane32_swap(__float_as_uint(aB_c), __float_as_uint(aB_c), false, false);
+            bool blA, blB;
+            const float wA = step_pair(sA, __uint_as_float(swA[0]), __uint_as_float(swA[1]), k, blA);
+            const float wB = step_pair(sB, __uint_as_float(swB[0]), __uint_as_float(swB[1]), k, blB);
+            sA.cur = blA ? sidx_c : sA.cur;
+            sB.cur = blB ? sidx_c : sB.cur;
+            if (__any(wA != 0.f || wB != 0.f)) {  // steps nobody blends leave no slot
+                float *dst = wt + (size_t)(row + k) * 64 + p;  // row = [upper 32 px | lower 32 px]
+                dst[0] = wA;
+                dst[32] = wB;
                 if (p == 0) gid_s[row + k] = gid_c;
                 row += 2;
             }
-            return more && !__all(st.done);
+            return more && !__all(sA.done && sB.done);
         };
         while (kstep()) {}
     }
-    if (lane == 0) blk_rows[tile * 8 + blk] = row - sb;
+    if (lane == 0) blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk] = row - sb;
     {
-        const auto cs = __builtin_amdgcn_permlane32_swap((unsigned)st.cur, (unsigned)st.cur, false, false);
-        st.cur = max((int)cs[0], (int)cs[1]);  // sorted indices grow along the list
+        const auto cA = __builtin_amdgcn_permlane32_swap((unsigned)sA.cur, (unsigned)sA.cur, false, false);
+        const auto cB = __builtin_amdgcn_permlane32_swap((unsigned)sB.cur, (unsigned)sB.cur, false, false);
+        sA.cur = max((int)cA[0], (int)cA[1]);  // sorted indices grow along the list
+        sB.cur = max((int)cB[0], (int)cB[1]);
     }
-    if (k == 0 && g.inside) {
-        const size_t pix = (size_t)g.pi * width + g.pj;
-        Tbuf[pix] = st.T;
-        render_alphas[pix] = 1.0f - st.T;
-        last_ids[pix] = st.cur;
+    if (k == 0 && g.insideA) {
+        const size_t pix = (size_t)g.piA * width + g.pj;
+        Tbuf[pix] = sA.T; render_alphas[pix] = 1.0f - sA.T; last_ids[pix] = sA.cur;
+    }
+    if (k == 0 && g.insideB) {
+        const size_t pix = (size_t)g.piB * width + g.pj;
+        Tbuf[pix] = sB.T; render_alphas[pix] = 1.0f - sB.T; last_ids[pix] = sB.cur;
     }
 }
 
 }  // namespace
 
-int gags_pack_isects_launch(int n_isects, const int32_t *flat, const float *means2d, const float *conics,
-                            const float *opacities, void *packed, hipStream_t st)
+int gags_pack_isects_launch(int n, int n_isects, const int32_t *flat, const float *means2d, const float *conics,
+                            const float *opacities, const int32_t *radii, void *grec, void *packed, hipStream_t st)
 {
     GAGS_CLEAR_ERR();
     if (n_isects <= 0) return GAGS_OK;
-    hipLaunchKernelGGL(pack_isects_kernel, dim3((n_isects + 255) / 256), dim3(256), 0, st, n_isects, flat, means2d,
-                       conics, opacities, reinterpret_cast<GRec *>(packed));
+    if (grec) {
+        hipLaunchKernelGGL(make_grec_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, means2d, conics, opacities,
+                           radii, reinterpret_cast<GRec *>(grec));
+        hipLaunchKernelGGL(gather_grec_kernel, dim3((n_isects + 255) / 256), dim3(256), 0, st, n_isects, flat,
+                           reinterpret_cast<const GRec *>(grec), reinterpret_cast<GRec *>(packed));
+    } else {
+        hipLaunchKernelGGL(pack_isects_kernel, dim3((n_isects + 255) / 256), dim3(256), 0, st, n_isects, flat, means2d,
+                           conics, opacities, reinterpret_cast<GRec *>(packed));
+    }
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }
@@ -119,7 +163,7 @@ int gags_raster_weights_launch(int width, int height, int n_gauss, const void *p
     GAGS_CLEAR_ERR();
     const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
     const int n_tiles = tile_w * tile_h;
-    hipLaunchKernelGGL(raster_weights_kernel, dim3(n_tiles * 8), dim3(64), 0, st, width, height, tile_w, n_tiles,
+    hipLaunchKernelGGL(raster_weights_kernel, dim3(n_tiles * GAGS_BLOCKS_PER_TILE), dim3(64), 0, st, width, height, tile_w, n_tiles,
                        n_gauss, reinterpret_cast<const GRec *>(packed), offsets, flat, n_isects, wt, gid_s, blk_rows,
                        Tbuf, alphas, last_ids);
     GAGS_CHECK_LAUNCH();

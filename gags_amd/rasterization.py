@@ -147,8 +147,9 @@ def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height, conics=
     packed = None
     if conics is not None:
         packed = torch.empty(max(n_isects, 1), 8, dtype=torch.float32, device=dev)
-        check(lib.gags_pack_isects(n_isects, ptr(flat_s), ptr(means2d), ptr(conics), ptr(opacities), ptr(packed), st),
-              "gags_pack_isects")
+        grec = torch.empty(max(n, 1), 8, dtype=torch.float32, device=dev)
+        check(lib.gags_pack_isects(n, n_isects, ptr(flat_s), ptr(means2d), ptr(conics), ptr(opacities), ptr(radii),
+                                   ptr(grec), ptr(packed), st), "gags_pack_isects")
     return ids_s[:n_isects], flat_s[:n_isects], offsets, n_isects, packed
 
 
@@ -177,7 +178,7 @@ class _Rasterize(torch.autograd.Function):
         if split:
             nbytes = lib.gags_raster_fwd_scratch_bytes(n_isects, width, height)
             scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            blk_rows = torch.empty(offsets.numel() * 8, dtype=torch.int32, device=dev)
+            blk_rows = torch.empty(offsets.numel() * 4, dtype=torch.int32, device=dev)  # per 8x8 pixel block
         with profiler.stage("raster_fwd"):
             check(lib.gags_raster_fwd(d, n, width, height, ptr(means2d), ptr(conics), ptr(opacities), ptr(colors),
                                       ptr(backgrounds), ptr(offsets), ptr(flatten_ids), n_isects, ptr(packed),

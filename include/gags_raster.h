@@ -91,10 +91,13 @@ int gags_tile_offsets(int64_t n_isects, const int64_t *sorted_ids, int n_tiles,
 /* K8b: gather each intersection's 2-D parameters into sorted order: one 32-byte record
  * {x, y, conic a, b, c, opacity, ex, ey} per sorted intersection, (ex, ey) being the conservative
  * half-extent of the alpha >= 1/255 footprint.  The wide-D (MFMA) raster kernels stream this
- * array instead of gathering means2d/conics/opacities per tile.  packed: n_isects * 32 bytes. */
+ * array instead of gathering means2d/conics/opacities per tile.  packed: n_isects * 32 bytes.
+ * grec (optional scratch, n * 32 bytes): when given, the record is built once per Gaussian
+ * (radii > 0 only, radii may be NULL = all) and the per-intersection pass is a pure gather. */
 #define GAGS_PACKED_BYTES 32
-int gags_pack_isects(int64_t n_isects, const int32_t *flatten_ids, const float *means2d,
-                     const float *conics, const float *opacities, void *packed, void *stream);
+int gags_pack_isects(int n, int64_t n_isects, const int32_t *flatten_ids, const float *means2d,
+                     const float *conics, const float *opacities, const int32_t *radii, void *grec,
+                     void *packed, void *stream);
 
 /* K9 (+K11): rasterize forward, any D >= 1 in ONE pass over the sorted lists (no 32-wide
  * re-walks).  Replaces the compositing stage of gsplat.rasterization for
@@ -103,7 +106,7 @@ int gags_pack_isects(int64_t n_isects, const int32_t *flatten_ids, const float *
  * last_ids[H,W] (sorted index of the last blended Gaussian per pixel).
  * Kernel choice: D % 32 == 0 with `packed` given runs on the matrix cores -- as the split
  * weights + feature passes when `scratch` (gags_raster_fwd_scratch_bytes) and `blk_rows`
- * ([tile_h*tile_w*8] int32, written) are provided, else as one fused kernel; anything else runs the
+ * ([tile_h*tile_w*4] int32, written: slots per 8x8 pixel block) are provided, else as one fused kernel; anything else runs the
  * VALU kernels.  The scratch and blk_rows of a split forward are what
  * gags_raster_bwd_colors_staged consumes, so keep them alive until the backward. */
 int64_t gags_raster_fwd_scratch_bytes(int64_t n_isects, int width, int height);
