@@ -144,7 +144,7 @@ extern "C" int gags_raster_bwd_colors_staged(int d, int n, int width, int height
                                              float *v_colors, int stage, void *stream)
 {
     if (d <= 0 || width <= 0 || height <= 0 || n < 0 || n_isects < 0 || n_isects >= (1ll << 27) || rows < 0 ||
-        rows >= (1ll << 31) || stage < 0 || stage > 3)
+        rows >= (1ll << 31) || stage < 0 || (stage & 15) > 3)
         return GAGS_EINVAL;
     if (n == 0) return GAGS_OK;
     if (!isect_offsets || !blk_rows || !row_end || !fwd_scratch || !scratch || !v_colors || !v_render_colors)

@@ -208,7 +208,8 @@ class _Rasterize(torch.autograd.Function):
         if backgrounds is not None and ctx.needs_input_grad[4]:
             v_bg = ((1.0 - alphas)[..., None] * v_out).sum(dim=(0, 1))
         if not need_geom and blk_rows is not None:
-            v_colors = _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height)
+            v_colors = _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height,
+                                        flags & 16)
             return None, None, v_colors, None, v_bg, None, None, None, None, None, None
         v_colors = torch.zeros(n, d, device=dev)
         if need_geom:
@@ -227,7 +228,7 @@ class _Rasterize(torch.autograd.Function):
         return v_m2d, v_con, v_colors, v_opac, v_bg, None, None, None, None, None, None
 
 
-def _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height):
+def _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height, xflag=0):
     """Colours-only backward without atomics: slot counts of the forward -> prefix sum -> one 4-byte
     readback (total rows) -> stored partial rows -> sort by Gaussian -> segmented sum."""
     dev = v_out.device
@@ -249,7 +250,7 @@ def _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d,
     def run(stage):
         check(lib.gags_raster_bwd_colors_staged(d, n, width, height, ptr(offsets), n_isects, ptr(v_out), ptr(blk_rows),
                                                 ptr(row_end), rows, ptr(fwd_scratch), fwd_scratch.numel(),
-                                                ptr(scratch), nbytes, ptr(v_colors), stage, st),
+                                                ptr(scratch), nbytes, ptr(v_colors), stage | xflag, st),
               "gags_raster_bwd_colors_staged")
 
     if profiler.ENABLED:  # one event pair per kernel (group), for the roofline line of bench.py
