@@ -117,6 +117,25 @@ def cpu_baseline(pc, cam, d, width, height, target_s):
     }
 
 
+# kernels behind each bracketed stage, by their short rocprofv3 names (tools/pmc_summary.py)
+STAGE_KERNELS = {
+    "raster_fwd": ("raster_weights_kernel", "raster_fwd_feat<4>"),
+    "bwd_rows": ("raster_bwd_rows<false>",),
+    "bwd_reduce": ("reduce_rows_kernel",),
+}
+
+
+def pmc_traffic(args):
+    """Per-kernel HBM bytes per launch measured with rocprofv3 --pmc on the default workload; None elsewhere."""
+    import glob
+    if args.config != "C3" or args.n or args.d or args.raster_flags:
+        return {}, None
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_c3_pmc_traffic.json")))
+    if not files:
+        return {}, None
+    return json.load(open(files[-1])), os.path.join("profiles", os.path.basename(files[-1]))
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -223,8 +242,15 @@ def main():
                     ach, peak, unit = amount / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
                 kernels[name] = {"bound": bound, "avg_launch_ms": ms, "achieved": ach, "peak": peak, "unit": unit,
                                  "frac": ach / peak}
+        # HBM traffic per launch from the committed rocprofv3 PMC passes of this very command
+        # (tools/pmc_passes.sh -> profiles/*_pmc_traffic.json: 2*FETCH_SIZE + WRITE_SIZE, separate passes)
+        traffic, traffic_src = pmc_traffic(args)
+        for name, members in STAGE_KERNELS.items():
+            if name in kernels:
+                tb = [traffic[m]["hbm_bytes"] for m in members if m in traffic]
+                kernels[name]["traffic"] = sum(tb) if len(tb) == len(members) else None
         dom = max(kernels, key=lambda k_: kernels[k_]["avg_launch_ms"])
-        roof = dict(kernels[dom], kernel=dom, traffic=None)
+        roof = dict(kernels[dom], kernel=dom, traffic_source=traffic_src)
         line = {
             "metric": "feature-raster fwd+bwd views/s",
             "value": value, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

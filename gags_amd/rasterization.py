@@ -209,7 +209,7 @@ class _Rasterize(torch.autograd.Function):
             v_bg = ((1.0 - alphas)[..., None] * v_out).sum(dim=(0, 1))
         if not need_geom and blk_rows is not None:
             v_colors = _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height,
-                                        flags & 16)
+                                        flags & _lib.GAGS_BWD_TRACE)
             return None, None, v_colors, None, v_bg, None, None, None, None, None, None
         v_colors = torch.zeros(n, d, device=dev)
         if need_geom:

@@ -136,7 +136,9 @@ int gags_raster_bwd(int d, int width, int height, const float *means2d, const fl
  * sum row_end of blk_rows (gags_cumsum_i32) and its total `rows` (gags_read_i32).  Partial sums
  * are stored as rows, sorted by Gaussian and reduced; v_colors[N,D] is written in full (no
  * zero-fill needed).  scratch: gags_bwd_staged_scratch_bytes(rows, n, d) bytes.
- * stage: 0 = all, 1..3 = rows, sort, reduce (per-kernel timing).  Returns 1 when D is not eligible. */
+ * stage: low 4 bits 0 = all, 1..3 = rows, sort, reduce (per-kernel timing); bit 4 = run the TRACED
+ * build of the rows kernel (same results; per-wave timeline for gags_debug_rows_trace).
+ * Returns 1 when D is not eligible. */
 int64_t gags_bwd_staged_scratch_bytes(int64_t rows, int n, int d);
 int gags_raster_bwd_colors_staged(int d, int n, int width, int height, const int32_t *isect_offsets,
                                   int64_t n_isects, const float *v_render_colors,
@@ -150,6 +152,11 @@ int gags_raster_bwd_colors_staged(int d, int n, int width, int height, const int
 int gags_raster_stats(int width, int height, const float *means2d, const float *conics,
                       const float *opacities, const int32_t *isect_offsets, const int32_t *flatten_ids,
                       int64_t n_isects, int64_t *counts, void *stream);
+
+/* Diagnostics: copy the timeline left by the traced rows kernel (stage bit 4) to the host: 8 int64 per
+ * workgroup {t_start, t_end, xcc<<32|hw_id, slots<<32|duration in 10 ns, load wait, MFMA burst, stores,
+ * setup} in shader-counter ticks.  n_workgroups <= 262144.  tools/rows_trace.py. */
+int gags_debug_rows_trace(long long *dst_host, int n_workgroups);
 
 /* K2: projection backward: chain rule of gags_project_fwd for Gaussians with radii>0.
  * Inputs v_means2d[N,2], v_depths[N] (may be NULL), v_conics[N,3];

@@ -1,5 +1,11 @@
 #!/usr/bin/env python
-"""Summarise rocprofv3 --pmc passes: per kernel (short name) mean counter value per dispatch."""
+"""Summarise rocprofv3 --pmc passes: per kernel (short name) mean counter value per dispatch.
+
+With a third argument, also writes the per-launch HBM traffic of every kernel as JSON (bench.py reads it for
+`roofline.traffic`): fetch = 2 * FETCH_SIZE KiB (gfx950: FETCH_SIZE tallies 128-B requests at 64 B,
+MI355X_MICROARCH.md "HBM"), write = WRITE_SIZE KiB (checked here against a known byte count: the rows kernel
+stores exactly rows * D * 4 bytes and WRITE_SIZE reports that number)."""
+import json
 import csv
 import glob
 import os
@@ -30,6 +36,14 @@ def main():
         for (k, _), ctrs in per_dispatch.items():
             for c, v in ctrs.items():
                 acc[k][c].append(v)
+    if len(sys.argv) > 3:
+        traffic = {}
+        for k in acc:
+            if "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
+                f = sum(acc[k]["FETCH_SIZE"]) / len(acc[k]["FETCH_SIZE"]) * 1024.0 * 2.0
+                w = sum(acc[k]["WRITE_SIZE"]) / len(acc[k]["WRITE_SIZE"]) * 1024.0
+                traffic[k] = {"fetch_bytes": f, "write_bytes": w, "hbm_bytes": f + w}
+        json.dump(traffic, open(sys.argv[3], "w"), indent=1, sort_keys=True)
     for k in sorted(acc):
         print(k)
         for c in sorted(acc[k]):

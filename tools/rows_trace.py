@@ -22,13 +22,12 @@ cam = syn.make_camera(w, h, device=dev)
 G = syn.make_cotangent(d, h, w, seed=1, device=dev)
 for it in range(3):
     pc._semantic_feature.grad = None
-    pkg = render(cam, pc, None, torch.zeros(3, device=dev), feature_mode=True, raster_flags=16)
+    pkg = render(cam, pc, None, torch.zeros(3, device=dev), feature_mode=True, raster_flags=_lib.GAGS_BWD_TRACE)
     (pkg["render"] * G).sum().backward()
 torch.cuda.synchronize()
 nwg = ((w + 15) // 16) * ((h + 15) // 16) * 4 * (d // 128)
 buf = np.zeros((nwg, 8), np.int64)
 lib = _lib.load()
-lib.gags_debug_rows_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert lib.gags_debug_rows_trace(buf.ctypes.data, nwg) == 0
 b = buf[buf[:, 1] > 0]
 t0, t2 = b[:, 0], b[:, 1]
