@@ -201,14 +201,33 @@ def main():
     profiler.enable(True)
     barrier()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        marks[i].record()
         step()
+    marks[args.steps].record()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
     stages = profiler.summary()
     profiler.enable(False)
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+
+    # R9 (outside the metric, which is fwd+bwd): the optimizer step on the gradient the last step left
+    adam = None
+    if rank == 0 and pc._semantic_feature.grad is not None:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        pc.optimizer.step()
+        for i in range(5):
+            ev[i].record()
+            pc.optimizer.step()
+        ev[5].record()
+        torch.cuda.synchronize()
+        ms = ev[0].elapsed_time(ev[5]) / 5
+        nbytes = 28.0 * pc._semantic_feature.numel()  # p, g, m, v read; p, m, v written
+        adam = {"kernel": "adam_step_kernel", "avg_launch_ms": ms, "bound": "hbm", "achieved": nbytes / ms / 1e6,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / ms / 1e6 / HBM_PEAK_GBS}
 
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
@@ -263,6 +282,9 @@ def main():
             "roofline": roof,
             "kernels": kernels,
             "stages_ms": {k: round(v[0], 4) for k, v in sorted(stages.items())},
+            "step_ms": {"median": per_step[len(per_step) // 2], "p10": per_step[int(0.1 * (len(per_step) - 1))],
+                        "p90": per_step[int(round(0.9 * (len(per_step) - 1)))]},
+            "optimizer_step": adam,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pc, cam, d, width, height, args.cpu_seconds)

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libgags_hip.so")
 
-_vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+_vp, _i32, _i64, _f32, _f64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 
 # name -> (restype, argtypes); must list every symbol include/gags_raster.h declares
 SIGNATURES = {
@@ -50,6 +50,7 @@ SIGNATURES = {
     "gags_sh_fwd": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_sh_bwd": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_ed_normalize": (_i32, [_i64, _i32, _vp, _vp, _vp]),
+    "gags_adam_step": (_i32, [_i64, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _f64, _i32, _vp]),
 }
 
 GAGS_BWD_COLORS_ONLY = 1

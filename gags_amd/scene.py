@@ -134,7 +134,11 @@ class GaussianModel:
                 torch.zeros((n, semantic_dim), device=self._xyz.device).contiguous().requires_grad_(True))
         for p in (self._xyz, self._features_dc, self._features_rest, self._opacity, self._scaling, self._rotation):
             p.requires_grad_(False)
-        self.optimizer = torch.optim.Adam(
-            [{"params": [self._semantic_feature], "lr": semantic_feature_lr, "name": "semantic_feature"}],
-            lr=0.0, eps=1e-15)
+        # same constructor call as the reference; on the GPU the step is the single-pass HIP kernel
+        groups = [{"params": [self._semantic_feature], "lr": semantic_feature_lr, "name": "semantic_feature"}]
+        if self._semantic_feature.is_cuda:
+            from .optim import FeatureAdam
+            self.optimizer = FeatureAdam(groups, lr=0.0, eps=1e-15)
+        else:  # host-side bookkeeping only (CPU unit tests): the stock optimizer the reference uses
+            self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
         return self.optimizer

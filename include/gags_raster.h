@@ -183,6 +183,12 @@ int gags_sh_bwd(int n, int kc, int degree, const float *means, const float *camp
 int gags_ed_normalize(int64_t n_pix, int d, float *render_colors, const float *render_alphas,
                       void *stream);
 
+/* R9: one Adam step of the feature parameter, in place, torch.optim.Adam semantics without weight decay
+ * or amsgrad (the reference's optimizer: scene/gaussian_model.py:192-208, eps = 1e-15; stepped at
+ * train.py:221-223).  `step` is the 1-based step count; all four arrays have `numel` floats, 16-B aligned. */
+int gags_adam_step(int64_t numel, float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                   double lr, double beta1, double beta2, double eps, int step, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -686,3 +686,30 @@ void orc_raster_bwd_colors_fwdorder(int D, int width, int height, int tile_w, in
         free(lc);
     }
 }
+
+/* ------------------------------------------------------------------------------------
+ * R9  Adam step of the feature parameter, as the reference configures it:
+ * /root/reference/scene/gaussian_model.py:192-208 (`torch.optim.Adam(l, lr=0.0, eps=1e-15)`, one
+ * group: `_semantic_feature`, lr = semantic_feature_lr), stepped at /root/reference/train.py:221-223.
+ * torch.optim.Adam, single-tensor path, no weight decay, no amsgrad:
+ *     m <- m + (1-b1)(g - m);  v <- v*b2 + (1-b2) g g
+ *     p <- p - (lr / (1-b1^t)) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
+ * The scalars are formed in double (python floats in torch) and applied in fp32.
+ * ---------------------------------------------------------------------------------- */
+void orc_adam_step(int64_t n, float *p, const float *g, float *m, float *v, double lr, double beta1,
+                   double beta2, double eps, int step)
+{
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    const float w1 = (float)(1.0 - beta1), b2 = (float)beta2, w2 = (float)(1.0 - beta2);
+    const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2), epsf = (float)eps;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        const float gi = g[i];
+        const float mi = m[i] + w1 * (gi - m[i]);
+        const float vi = v[i] * b2 + (w2 * gi) * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + epsf;
+        p[i] = p[i] - step_size * (mi / denom);
+        m[i] = mi;
+        v[i] = vi;
+    }
+}

@@ -226,3 +226,12 @@ def rasterization(means, quats, scales, opacities, colors, viewmat, K, backgroun
                 colors=cols, backgrounds=bg, last_ids=last, width=width, height=height, tile_size=TILE,
                 n_cameras=1, **b, **stats)
     return out, alphas, info
+
+
+def adam_step(p, g, m, v, lr, beta1=0.9, beta2=0.999, eps=1e-15, step=1):
+    """In-place Adam step on float32 numpy arrays (R9: scene/gaussian_model.py:208, train.py:221-223)."""
+    for a in (p, g, m, v):
+        assert a.dtype == np.float32 and a.flags.c_contiguous
+    lib().orc_adam_step(ctypes.c_int64(p.size), _p(p), _p(g), _p(m), _p(v), ctypes.c_double(lr),
+                        ctypes.c_double(beta1), ctypes.c_double(beta2), ctypes.c_double(eps), ctypes.c_int(step))
+    return p, m, v

@@ -130,3 +130,19 @@ def test_render_hands_the_rasterizer_what_the_reference_does(monkeypatch, name):
     np.testing.assert_array_equal(res["visibility_filter"].numpy(), G[f"call_{name}_visibility"])
     np.testing.assert_array_equal(res["radii"].numpy(), G[f"call_{name}_radii"])
     assert tuple(res["viewspace_points"].shape) == tuple(G[f"call_{name}_vsp_shape"])
+
+
+def test_oracle_adam_matches_the_reference_optimizer(oracle):
+    """R9: the C restatement of Adam reproduces three steps of torch.optim.Adam configured exactly as
+    scene/gaussian_model.py:192-208 does (fixture: tests/golden/make_golden_adam.py)."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "adam_vectors.npz"))
+    p = z["p0"].copy()
+    m = np.zeros_like(p)
+    v = np.zeros_like(p)
+    for t in range(1, 4):
+        oracle.adam_step(p, np.ascontiguousarray(z[f"g{t}"]), m, v, float(z["lr"]), eps=1e-15, step=t)
+        # fp32 tolerance: one rounding of the operands' magnitude (torch's lerp / addcmul may fuse or reorder
+        # one operation); |g| ~ 1, so 2e-8 absolute where the result cancels
+        np.testing.assert_allclose(m, z[f"m{t}"], rtol=2e-6, atol=2e-8)
+        np.testing.assert_allclose(v, z[f"v{t}"], rtol=2e-6, atol=2e-8)
+        np.testing.assert_allclose(p, z[f"p{t}"], rtol=2.5e-7, atol=1e-9)  # one ulp of p

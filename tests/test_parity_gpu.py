@@ -228,3 +228,52 @@ def test_render_boundary_matches_reference_contract(oracle):
     with torch.no_grad():
         pkg3 = render(cam, pc, None, bg, feature_mode=False, render_mode="RGB+ED")
     assert pkg3["render"].shape == (4, h, w)
+
+
+@pytest.mark.gpu
+def test_adam_step_matches_oracle_and_fixture(oracle):
+    """R9 (scene/gaussian_model.py:192-208, train.py:221-223): the single-pass HIP Adam follows the oracle's
+    operation order exactly; three steps from the committed torch.optim.Adam fixture, numel % 4 != 0."""
+    import os
+    import torch
+    from gags_amd.optim import FeatureAdam
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "adam_vectors.npz"))
+    dev = torch.device("cuda", 0)
+    p = torch.nn.Parameter(torch.from_numpy(z["p0"].copy()).to(dev))
+    opt = FeatureAdam([{"params": [p], "lr": float(z["lr"]), "name": "semantic_feature"}], lr=0.0, eps=1e-15)
+    po, mo, vo = z["p0"].copy(), np.zeros_like(z["p0"]), np.zeros_like(z["p0"])
+    for t in range(1, 4):
+        g = np.ascontiguousarray(z[f"g{t}"])
+        p.grad = torch.from_numpy(g).to(dev)
+        opt.step()
+        oracle.adam_step(po, g, mo, vo, float(z["lr"]), eps=1e-15, step=t)
+        st = opt.state[p]
+        np.testing.assert_array_equal(st["exp_avg"].cpu().numpy(), mo)      # same fp32 operations, same order
+        np.testing.assert_array_equal(st["exp_avg_sq"].cpu().numpy(), vo)
+        np.testing.assert_array_equal(p.detach().cpu().numpy(), po)
+        np.testing.assert_allclose(p.detach().cpu().numpy(), z[f"p{t}"], rtol=2.5e-7, atol=1e-9)  # vs torch itself: one ulp
+    assert int(st["step"].item()) == 3
+
+
+@pytest.mark.gpu
+def test_training_setup_uses_the_hip_optimizer_and_matches_torch_adam():
+    """GaussianModel.training_setup on the GPU: same constructor arguments as the reference, the step equals the
+    stock torch.optim.Adam on the same device to fp32 rounding, at a size that exercises the grid-stride loop."""
+    import torch
+    from gags_amd import synthetic as syn
+    from gags_amd.optim import FeatureAdam
+    dev = torch.device("cuda", 0)
+    pc = syn.make_model(20000, 64, 64, 48, seed=3, device=dev, gen_device=dev)
+    opt = pc.training_setup()
+    assert isinstance(opt, FeatureAdam) and opt.param_groups[0]["eps"] == 1e-15 and opt.param_groups[0]["name"] == "semantic_feature"
+    ref = torch.nn.Parameter(pc._semantic_feature.detach().clone())
+    ropt = torch.optim.Adam([{"params": [ref], "lr": 1e-3}], lr=0.0, eps=1e-15)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    for _ in range(3):
+        g = torch.randn(ref.shape, device=dev, generator=gen)
+        pc._semantic_feature.grad = g.clone(); ref.grad = g.clone()
+        opt.step(); ropt.step()
+    torch.testing.assert_close(pc._semantic_feature.detach(), ref.detach(), rtol=2.5e-7, atol=1e-9)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        q = torch.nn.Parameter(torch.zeros(4, 4)); q.grad = torch.ones(4, 4)
+        FeatureAdam([q], lr=1e-3).step()
