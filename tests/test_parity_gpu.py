@@ -277,3 +277,63 @@ def test_training_setup_uses_the_hip_optimizer_and_matches_torch_adam():
     with pytest.raises(RuntimeError, match="no CPU path"):
         q = torch.nn.Parameter(torch.zeros(4, 4)); q.grad = torch.ones(4, 4)
         FeatureAdam([q], lr=1e-3).step()
+
+
+def test_full_size_properties_c3():
+    """BASELINE's full size (C3: 1.5 M Gaussians, 1080p, D = 512), where the oracle would take minutes per view:
+    size-independent properties of the operator instead.  The render is linear in the features, the colours-only
+    backward is its transpose, and both are bit-reproducible."""
+    from gags_amd import _lib, synthetic as syn
+    from gags_amd.gaussian_renderer import render
+    cfg = syn.CONFIGS["C3"]
+    n, d, w, h = cfg["n"], cfg["d"], cfg["width"], cfg["height"]
+    dev = torch.device("cuda", 0)
+    pc = syn.make_model(n, d, w, h, seed=0, device=dev, gen_device=dev)
+    pc.training_setup()
+    cam = syn.make_camera(w, h, device=dev)
+    bg = torch.zeros(3, device=dev)
+    G = syn.make_cotangent(d, h, w, seed=1, device=dev)  # [D,H,W] view of [H,W,D] memory
+
+    def fwd(flags=0):
+        pkg = render(cam, pc, None, bg, feature_mode=True, raster_flags=flags)
+        return pkg
+
+    def grad_of(pkg, cot):
+        pc._semantic_feature.grad = None
+        (pkg["render"] * cot).sum().backward()
+        return pc._semantic_feature.grad
+
+    pkg = fwd()
+    out = pkg["render"].detach()
+    radii = pkg["radii"]
+    assert out.shape == (d, h, w) and torch.isfinite(out).all()
+    # (1) the matrix-core split forward and the VALU kernel are the same fmaf chain: identical bits at full size
+    pkv = fwd(_lib.GAGS_FWD_NO_MFMA)
+    assert torch.equal(out, pkv["render"].detach())
+    assert torch.equal(pkg["alphas"], pkv["alphas"]) and torch.equal(pkg["info"]["last_ids"], pkv["info"]["last_ids"])
+    del pkv
+    # (2) determinism and (3) homogeneity (scaling by 2 is exact in fp32)
+    g1 = grad_of(pkg, G).clone()
+    g1b = grad_of(fwd(), G).clone()
+    assert torch.equal(g1, g1b)  # no atomics on the default path
+    del g1b
+    with torch.no_grad():
+        pc._semantic_feature.mul_(2.0)
+    pk2 = fwd()
+    assert torch.equal(pk2["render"].detach(), 2.0 * out)
+    assert torch.equal(pk2["alphas"], pkg["alphas"])  # geometry only
+    g2 = grad_of(pk2, 2.0 * G)
+    assert torch.equal(g2, 2.0 * g1)
+    del pk2, g2
+    with torch.no_grad():
+        pc._semantic_feature.mul_(0.5)
+    # (4) transpose identity  <R f, G> = <f, R^T G>  in float64
+    lhs = torch.dot(out.permute(1, 2, 0).reshape(-1).double(), G.permute(1, 2, 0).reshape(-1).double())
+    rhs = torch.dot(pc._semantic_feature.detach().reshape(-1).double(), g1.reshape(-1).double())
+    assert abs(lhs.item() - rhs.item()) <= 1e-5 * max(abs(lhs.item()), out.double().norm().item() * G.double().norm().item() * 1e-3)
+    # (5) culled Gaussians receive exactly zero, and the gradient was written in full (no stale memory)
+    assert torch.all(g1[radii <= 0] == 0)
+    assert torch.isfinite(g1).all() and g1.abs().max() > 0
+    # (6) the float-atomic fallback computes the same sums (different order)
+    ga = grad_of(fwd(_lib.GAGS_BWD_ATOMIC), G)
+    assert ((ga - g1).double().norm() / g1.double().norm()).item() <= 1e-5
