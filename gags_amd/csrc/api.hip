@@ -55,7 +55,7 @@ inline FwdScratch fwd_layout(int64_t n_isects, int width, int height)
     L.total = o;
     return L;
 }
-inline bool mfma_width(int d) { return d >= 32 && d % 32 == 0; }
+inline bool fused_width(int d) { return d >= 32 && d % 32 == 0; }  // single-kernel forward / atomic backward
 }  // namespace
 
 extern "C" int gags_pack_isects(int n, int64_t n_isects, const int32_t *flatten_ids, const float *means2d,
@@ -85,8 +85,9 @@ extern "C" int gags_raster_fwd(int d, int n, int width, int height, const float 
     if (!isect_offsets || !render_colors || !render_alphas || !last_ids) return GAGS_EINVAL;
     if (n_isects > 0 && (!means2d || !conics || !opacities || !colors || !flatten_ids)) return GAGS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (!(flags & GAGS_FWD_NO_MFMA) && mfma_width(d) && (packed || n_isects == 0) && n > 0) {
-        if (scratch && blk_rows) {  // split forward: weights once, then the feature stream
+    const bool split = scratch && blk_rows && gags_mfma_width(d);
+    if (!(flags & GAGS_FWD_NO_MFMA) && (split || fused_width(d)) && (packed || n_isects == 0) && n > 0) {
+        if (split) {  // split forward: weights once, then the feature stream
             const FwdScratch L = fwd_layout(n_isects, width, height);
             if (scratch_bytes < L.total) return GAGS_ESCRATCH;
             char *sb = (char *)scratch;

@@ -79,6 +79,11 @@ __device__ __forceinline__ int gags_tile_of_order(int o, int tile_w, int tile_h)
     return (y0 + (r - x * h)) * tile_w + x;
 }
 
+// Feature widths served by the split matrix-core path (weights pass + feature pass, staged backward): multiples
+// of 32, and multiples of 4 from 16 up (32-channel slices, the last one ragged) -- 16 is the width the reference
+// actually rasterizes (train.py:68).  Everything else (RGB, RGB+ED, odd widths) runs the VALU kernels.
+__host__ __device__ __forceinline__ bool gags_mfma_width(int d) { return d >= 16 && (d % 32 == 0 || d % 4 == 0); }
+
 // Slot space of the matrix-core rasterizer (raster_weights.hip): every (tile, 8x8 block) owns a fixed
 // region of K-step slots sized by the tile's list length, so no counting pass is needed.
 //   base(tile, blk) = 4*(start + tile) + blk * even(L),  capacity even(L),  L = end - start,  blk in 0..3

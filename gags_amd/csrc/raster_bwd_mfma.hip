@@ -65,8 +65,9 @@ __device__ __forceinline__ void tile_mfma(f32x16 (&acc)[NBB], const float (&A)[1
 // raster_weights wrote.  The cotangent slab (64 px x 128 ch) sits in 128 VGPRs as B operands.
 __device__ long long g_rows_trace[8 * 262144];  // TRACE builds only: per-wave timeline (tools/rows_trace.py)
 
-template <bool TRACE>
-__global__ __launch_bounds__(64, 2) void raster_bwd_rows(
+// NBR = channel tiles of 32 per wave: 4 (D % 128 == 0; two waves per SIMD), 2 (D % 64 == 0) or 1 (D % 32 == 0).
+template <int NBR, bool TRACE>
+__global__ __launch_bounds__(64, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void raster_bwd_rows(
     int d, int width, int height, int tile_w, int n_tiles, int n_slices, const float *__restrict__ v_render_colors,
     const int32_t *__restrict__ offsets, int n_isects, const int32_t *__restrict__ blk_rows,
     const int32_t *__restrict__ row_end, const float *__restrict__ wt, const int32_t *__restrict__ gid_s,
@@ -87,20 +88,30 @@ __global__ __launch_bounds__(64, 2) void raster_bwd_rows(
     const int start = offsets[tile];
     const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
     const int sb = gags_slot_base(start, end, tile, blk);
-    const int ch0 = slice * CSB;
+    const int ch0 = slice * (32 * NBR);
     BlockGeom64 g;
     g.init(tile, blk, tile_w, width, height, lane);
     const int p = g.p, k = g.k;
 
-    // V[t][j] = v_out[pixel t of half k][ch0 + 4p + j]  ("strided-4" channel tiles: float4 loads / stores)
-    float V[32][NBB];
+    // V[t][j] = v_out[pixel t of half k][ch0 + NBR*p + j]  ("strided-NBR" channel tiles: one vector load / store)
+    float V[32][NBR];
 #pragma unroll
     for (int t = 0; t < 32; ++t) {
         const int qj = g.bx0 + (t & 7), qi = g.by0 + 4 * k + (t >> 3);
         const bool ok = (qi < height) && (qj < width);
-        const float4 v = *reinterpret_cast<const float4 *>(
-            v_render_colors + ((size_t)min(qi, height - 1) * width + min(qj, width - 1)) * d + ch0 + 4 * p);
-        V[t][0] = ok ? v.x : 0.f; V[t][1] = ok ? v.y : 0.f; V[t][2] = ok ? v.z : 0.f; V[t][3] = ok ? v.w : 0.f;
+        // NBR == 1 also serves a ragged last slice (D % 32 != 0): lanes past the row are clamped here, masked below
+        const float *src = v_render_colors + ((size_t)min(qi, height - 1) * width + min(qj, width - 1)) * d +
+                           (NBR == 1 ? min(ch0 + p, d - 1) : ch0 + NBR * p);
+        if constexpr (NBR == 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(src);
+            V[t][0] = ok ? v.x : 0.f; V[t][1] = ok ? v.y : 0.f; V[t][2] = ok ? v.z : 0.f; V[t][3] = ok ? v.w : 0.f;
+        } else if constexpr (NBR == 2) {
+            const float2 v = *reinterpret_cast<const float2 *>(src);
+            V[t][0] = ok ? v.x : 0.f; V[t][1] = ok ? v.y : 0.f;
+        } else {
+            const float v = src[0];
+            V[t][0] = ok ? v : 0.f;
+        }
     }
 
     const int nblocks = (cnt + 31) >> 5;
@@ -131,23 +142,26 @@ __global__ __launch_bounds__(64, 2) void raster_bwd_rows(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (TRACE) { const long long now = __builtin_readcyclecounter(); phA += now - tph; tph = now; }
         __builtin_amdgcn_sched_barrier(0);
-        f32x16 acc[NBB];
+        f32x16 acc[NBR];
 #pragma unroll
-        for (int j = 0; j < NBB; ++j)
+        for (int j = 0; j < NBR; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 #pragma unroll
         for (int t = 0; t < 32; ++t)
 #pragma unroll
-            for (int j = 0; j < NBB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[t], V[t][j], acc[j], 0, 0, 0);
+            for (int j = 0; j < NBR; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[t], V[t][j], acc[j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (TRACE) { const long long now = __builtin_readcyclecounter(); phM += now - tph; tph = now; }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int slot = (r & 3) + 8 * (r >> 2) + 4 * k;
-            if (slot < count)  // 32 lanes x 16 B = the row's 512 contiguous bytes of this slice
-                *reinterpret_cast<float4 *>(prow + (size_t)(base + 32 * m + slot) * d + ch0 + 4 * p) =
-                    make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+            if (slot < count) {  // 32 lanes x 4*NBR B = the row's contiguous bytes of this slice
+                float *dst = prow + (size_t)(base + 32 * m + slot) * d + ch0 + NBR * p;
+                if constexpr (NBR == 4) *reinterpret_cast<float4 *>(dst) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+                else if constexpr (NBR == 2) *reinterpret_cast<float2 *>(dst) = make_float2(acc[0][r], acc[1][r]);
+                else if (ch0 + p < d) dst[0] = acc[0][r];
+            }
         }
         if (TRACE) {
             __builtin_amdgcn_sched_barrier(0);
@@ -340,10 +354,12 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
     // stage: 0 = everything; 1 = rows, 2 = sort + segment offsets, 3 = reduce (per-kernel timing)
     GAGS_CLEAR_ERR();
     const int stage = stage_flags & 15;
-    if (d < CSB || d % CSB != 0 || d > 1024) return 1;
+    if (!gags_mfma_width(d) || d > 1024) return 1;
     const bool sA = stage == 0 || stage == 1, sS = stage == 0 || stage == 2, sR = stage == 0 || stage == 3;
     const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
-    const int n_tiles = tile_w * tile_h, n_slices = d / CSB;
+    const int n_tiles = tile_w * tile_h;
+    const int nbr = d % 128 == 0 ? 4 : (d % 64 == 0 ? 2 : 1);  // channel tiles (of 32) per wave
+    const int n_slices = (d + 32 * nbr - 1) / (32 * nbr);  // nbr == 1: ragged last slice
     const StagedLayout L = staged_layout(rows > 0 ? rows : 1, n_gauss, d);
     if (scratch_bytes < L.total) return GAGS_ESCRATCH;
     char *sb = (char *)scratch;
@@ -353,12 +369,18 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
     if (rows > 0) {
         if (sA) {
             const dim3 grid(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices);
-            if (stage_flags & 16)  // diagnostics: per-wave timeline into g_rows_trace (tools/rows_trace.py)
-                hipLaunchKernelGGL(raster_bwd_rows<true>, grid, dim3(64), 0, st, d, width, height, tile_w, n_tiles, n_slices,
-                                   v_out, offsets, n_isects, blk_rows, row_end, wt, gid_s, prow, key, idx);
-            else
-                hipLaunchKernelGGL(raster_bwd_rows<false>, grid, dim3(64), 0, st, d, width, height, tile_w, n_tiles, n_slices,
-                                   v_out, offsets, n_isects, blk_rows, row_end, wt, gid_s, prow, key, idx);
+#define GAGS_ROWS_LAUNCH(NBR, TRACE)                                                                                    \
+    hipLaunchKernelGGL((raster_bwd_rows<NBR, TRACE>), grid, dim3(64), 0, st, d, width, height, tile_w, n_tiles, n_slices, \
+                       v_out, offsets, n_isects, blk_rows, row_end, wt, gid_s, prow, key, idx)
+            if (nbr == 4) {
+                if (stage_flags & 16) GAGS_ROWS_LAUNCH(4, true);  // diagnostics: per-wave timeline (tools/rows_trace.py)
+                else GAGS_ROWS_LAUNCH(4, false);
+            } else if (nbr == 2) {
+                GAGS_ROWS_LAUNCH(2, false);
+            } else {
+                GAGS_ROWS_LAUNCH(1, false);
+            }
+#undef GAGS_ROWS_LAUNCH
         }
         if (sS) {
             int nbits = 1;

@@ -33,7 +33,9 @@ __device__ __forceinline__ void load_rows(const float *__restrict__ colors, int 
                                           float4 (&bq)[FwdCfg<NB>::NG])
 {
     constexpr int VEC = FwdCfg<NB>::VEC, NG = FwdCfg<NB>::NG;
-    const float *row = colors + (size_t)gid * d + ch0 + VEC * p;
+    // VEC == 1 also serves a ragged last slice (D % 32 != 0): lanes past the row read its last channel and
+    // are masked at the store (an output column depends on its own B column only)
+    const float *row = colors + (size_t)gid * d + (VEC == 1 ? min(ch0 + p, d - 1) : ch0 + VEC * p);
 #pragma unroll
     for (int gq = 0; gq < NG; ++gq) {
         if constexpr (VEC == 4) bq[gq] = *reinterpret_cast<const float4 *>(row + gq * 128);
@@ -72,7 +74,7 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[NB], const BlockGeo
 #pragma unroll
         for (int gq = 0; gq < NG; ++gq)
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) bgv[gq * VEC + i] = backgrounds[ch0 + gq * 32 * VEC + VEC * g.p + i];
+            for (int i = 0; i < VEC; ++i) bgv[gq * VEC + i] = backgrounds[min(ch0 + gq * 32 * VEC + VEC * g.p + i, d - 1)];
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -90,7 +92,7 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[NB], const BlockGeo
             }
             if constexpr (VEC == 4) *reinterpret_cast<float4 *>(o + gq * 128) = make_float4(v[0], v[1], v[2], v[3]);
             else if constexpr (VEC == 2) *reinterpret_cast<float2 *>(o) = make_float2(v[0], v[1]);
-            else o[0] = v[0];
+            else if (ch0 + g.p < d) o[0] = v[0];
         }
     }
 }
@@ -275,7 +277,7 @@ int launch_feat(int d, int width, int height, int n_gauss, const float *colors, 
                 const float *Tbuf, float *out, hipStream_t st)
 {
     const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
-    const int n_tiles = tile_w * tile_h, n_slices = d / (32 * NB);
+    const int n_tiles = tile_w * tile_h, n_slices = (d + 32 * NB - 1) / (32 * NB);  // NB == 1: ragged last slice
     hipLaunchKernelGGL(raster_fwd_feat<NB>, dim3(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices), dim3(64), 0, st, d, width, height, tile_w,
                        n_tiles, n_slices, n_gauss, colors, backgrounds, offsets, n_isects, blk_rows, wt, gid_s, Tbuf,
                        out);

@@ -153,6 +153,12 @@ def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height, conics=
     return ids_s[:n_isects], flat_s[:n_isects], offsets, n_isects, packed
 
 
+def _mfma_width(d):
+    """Feature widths served by the split matrix-core path (gags_mfma_width in csrc/common.h): multiples of 32, and
+    multiples of 4 from 16 up -- 16 is what the reference rasterizes (train.py:68)."""
+    return d >= 16 and d % 4 == 0
+
+
 class _Rasterize(torch.autograd.Function):
     """K9 forward / K10 backward over pre-binned intersections.
 
@@ -184,7 +190,7 @@ class _Rasterize(torch.autograd.Function):
                                       ptr(backgrounds), ptr(offsets), ptr(flatten_ids), n_isects, ptr(packed),
                                       ptr(out), ptr(alphas), ptr(last_ids), ptr(scratch), nbytes, ptr(blk_rows),
                                       flags & 3, _stream()), "gags_raster_fwd")
-        staged = (split and d % 128 == 0 and d <= 1024 and ctx.needs_input_grad[2]
+        staged = (split and _mfma_width(d) and d <= 1024 and ctx.needs_input_grad[2]
                   and not (flags & _lib.GAGS_BWD_ATOMIC))
         ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, packed, alphas,
                               last_ids, scratch if staged else None, blk_rows if staged else None)
@@ -312,7 +318,7 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
         bg = None if bg is None else torch.zeros(1, device=bg.device)
 
     with torch.no_grad(), profiler.stage("binning"):
-        wide = cols.shape[-1] >= 32 and cols.shape[-1] % 32 == 0  # matrix-core path wants packed records
+        wide = _mfma_width(cols.shape[-1])  # matrix-core path wants packed records
         isect_ids, flatten_ids, isect_offsets, n_isects, packed = tile_binning(
             means2d, radii, depths, tiles, width, height, conics if wide else None, _c(opacities) if wide else None)
 

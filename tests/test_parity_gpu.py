@@ -71,6 +71,11 @@ def _check_indices(info, oinfo):
     (3000, 176, 130, 256, 8, 6, 5.0, 1.0),     # MFMA path, NB=8, one slice
     (2500, 130, 100, 512, 9, 1, 5.0, None),    # MFMA path, NB=8, two slices (C3 width)
     (6000, 96, 64, 128, 10, None, 16.0, 0.2),  # large splats: long per-tile lists, early termination
+    (3000, 150, 110, 96, 11, 4, 5.0, 0.1),     # staged backward with 32-channel slices (D % 64 != 0)
+    (3000, 150, 110, 160, 12, 7, 5.0, None),   # 32-channel slices, five of them
+    (3000, 150, 110, 192, 13, None, 5.0, 0.0), # 64-channel slices
+    (3000, 150, 110, 48, 14, 2, 5.0, 0.4),     # ragged last slice (D % 32 = 16) on the matrix-core path
+    (2000, 97, 61, 20, 15, 5, 6.0, 0.3),       # one ragged slice, ragged image
 ])
 def test_forward_and_colour_grad(oracle, n, w, h, d, seed, view, mult, bgv):
     s = scene_arrays(n, d, w, h, seed=seed, view=view, scale_mult=mult)
