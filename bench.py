@@ -58,7 +58,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
     ap.add_argument("--no-allreduce", action="store_true", help="(debug) skip the gradient reduction at N>1")
+    ap.add_argument("--grad-reduce", default="rs_ag", choices=["rs_ag", "allreduce"],
+                    help="by-view step: bucketed reduce-scatter + all-gather (default) or plain all-reduce")
     ap.add_argument("--raster-flags", type=int, default=0)
+    ap.add_argument("--parallel", default="auto", choices=["auto", "view", "channel"],
+                    help="N>1: one view per GPU + gradient exchange (view), every GPU renders all N views for its "
+                         "channel shard with no exchange (channel), or whichever two probe steps show faster (auto)")
     return ap.parse_args()
 
 
@@ -143,11 +148,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    local_rank %= torch.cuda.device_count()  # (debugging on fewer GPUs than ranks; the driver runs one rank per GPU)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("GAGS_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; gloo only for debugging
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from gags_amd import _lib, profiler, synthetic as syn
     from gags_amd.gaussian_renderer import render
@@ -161,25 +171,67 @@ def main():
         cfg["d"] = args.d
     n, d, width, height = cfg["n"], cfg["d"], cfg["width"], cfg["height"]
 
-    # replicated Gaussians (same seed on every rank), one yawed view per rank (C4's cameras)
-    pc = syn.make_model(n, d, width, height, seed=0, device=dev, gen_device=dev)
-    pc.training_setup()
-    cam = syn.make_camera(width, height, view=(rank % 8) if world > 1 else None, device=dev)
-    bg = torch.zeros(3, device=dev)
-    G = syn.make_cotangent(d, height, width, seed=1, device=dev)  # [D,H,W] view of [H,W,D] memory
-
-    def step():
-        pc._semantic_feature.grad = None
-        pkg = render(cam, pc, None, bg, feature_mode=True, raster_flags=args.raster_flags)
-        loss = _CotangentLoss.apply(pkg["render"].permute(1, 2, 0), G.permute(1, 2, 0))
-        loss.backward()
-        if world > 1 and not args.no_allreduce:
-            reduce_feature_grad(pc._semantic_feature.grad)
-        return pkg
+    from gags_amd.dist import channel_shard
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
+
+    def build(mode):
+        """(step function, model, camera of the last view, local feature width) of one decomposition (gags_amd/dist.py).
+        view   : Gaussians + features replicated (same seed on every rank), one yawed view per rank (C4's cameras),
+                 reduce-scatter + all-gather of the feature gradient at step end.
+        channel: every rank renders all `world` views for its channel shard; no exchange."""
+        if mode == "channel":
+            c0, c1 = channel_shard(d)
+            dl = c1 - c0
+            views = list(range(world))
+        else:
+            dl = d
+            views = [rank % 8] if world > 1 else [None]
+        pc_ = syn.make_model(n, dl, width, height, seed=0, device=dev, gen_device=dev)
+        pc_.training_setup()
+        cams = [syn.make_camera(width, height, view=(v % 8) if v is not None else None, device=dev) for v in views]
+        G_ = syn.make_cotangent(dl, height, width, seed=1, device=dev)  # [D,H,W] view of [H,W,D] memory
+
+        def step_():
+            pc_._semantic_feature.grad = None
+            for cam_ in cams:
+                pkg_ = render(cam_, pc_, None, bg, feature_mode=True, raster_flags=args.raster_flags)
+                loss = _CotangentLoss.apply(pkg_["render"].permute(1, 2, 0), G_.permute(1, 2, 0))
+                loss.backward()
+            if mode == "view" and world > 1 and not args.no_allreduce:
+                reduce_feature_grad(pc_._semantic_feature.grad, mode=args.grad_reduce)
+            return pkg_
+        return step_, pc_, cams[-1], dl
+
+    bg = torch.zeros(3, device=dev)
+    mode, probe = "view", None
+    if world > 1 and args.parallel != "view":
+        lo, hi = channel_shard(d)
+        widths = torch.tensor([hi - lo], device=dev)
+        torch.distributed.all_reduce(widths, op=torch.distributed.ReduceOp.MIN)
+        channel_ok = int(widths.item()) >= 16  # every rank gets a matrix-core-wide shard
+        if args.parallel == "channel":
+            if not channel_ok:
+                raise SystemExit(f"--parallel channel needs D >= 16 * {world}")
+            mode = "channel"
+        elif channel_ok:  # auto: two probe steps of each, same decision on every rank (MAX over ranks)
+            probe = {}
+            for m in ("view", "channel"):
+                fn, pc_, _, _ = build(m)
+                fn()
+                torch.cuda.synchronize(); barrier()
+                t0 = time.perf_counter()
+                fn(); fn()
+                torch.cuda.synchronize(); barrier()
+                tt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+                torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+                probe[m] = 1e3 * float(tt.item()) / 2
+                del fn, pc_
+                torch.cuda.empty_cache()
+            mode = min(probe, key=probe.get)
+    step, pc, cam, d_local = build(mode)
 
     for _ in range(args.warmup):
         pkg = step()
@@ -245,11 +297,12 @@ def main():
         #                 (HBM bound; the kernel actually reads one row per touched (tile, Gaussian))
         #   raster_bwd  : 14*Q_eval + 2*D*Q_blend flops              (single-kernel atomic backward, if used)
         rows = profiler.notes().get("bwd_rows", 0)
+        dl = d_local  # feature width of one launch on this rank (D, or the rank's channel shard)
         work = {
-            "raster_fwd": ("mfma", 14.0 * q_eval + 2.0 * d * q_blend),
-            "bwd_rows": ("mfma", 2.0 * d * q_blend),
-            "bwd_reduce": ("hbm", 4.0 * d * (n_visible + n)),
-            "raster_bwd": ("mfma", 14.0 * q_eval + 2.0 * d * q_blend),
+            "raster_fwd": ("mfma", 14.0 * q_eval + 2.0 * dl * q_blend),
+            "bwd_rows": ("mfma", 2.0 * dl * q_blend),
+            "bwd_reduce": ("hbm", 4.0 * dl * (n_visible + n)),
+            "raster_bwd": ("mfma", 14.0 * q_eval + 2.0 * dl * q_blend),
         }
         kernels = {}
         for name, (bound, amount) in work.items():
@@ -263,7 +316,7 @@ def main():
                                  "frac": ach / peak}
         # HBM traffic per launch from the committed rocprofv3 PMC passes of this very command
         # (tools/pmc_passes.sh -> profiles/*_pmc_traffic.json: 2*FETCH_SIZE + WRITE_SIZE, separate passes)
-        traffic, traffic_src = pmc_traffic(args)
+        traffic, traffic_src = pmc_traffic(args) if world == 1 else ({}, None)
         for name, members in STAGE_KERNELS.items():
             if name in kernels:
                 tb = [traffic[m]["hbm_bytes"] for m in members if m in traffic]
@@ -275,10 +328,16 @@ def main():
             "value": value, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {n} Gaussians, {width}x{height}, D={d}, 1 view/GPU/step",
+            "config": {"workload": f"{args.config}: {n} Gaussians, {width}x{height}, D={d}, {world} view(s)/step"
+                                   + (f", every GPU renders all {world} views for its {d_local} channels"
+                                      if mode == "channel" else ", 1 view/GPU/step"),
                        "n_gaussians": n, "width": width, "height": height, "feature_dim": d,
                        "visible": n_visible, "n_isects": n_isects, "pairs_evaluated": q_eval,
-                       "pairs_blended": q_blend, "bwd_rows": rows, "parallelism": f"view-dp{world}"},
+                       "pairs_blended": q_blend, "bwd_rows": rows,
+                       "parallelism": (f"channel-shard{world} (no data-path collective)" if mode == "channel"
+                                       else f"view-dp{world}" + (" + RCCL reduce-scatter/all-gather of the feature gradient"
+                                                                if world > 1 else "")),
+                       "parallel_probe_ms_per_step": probe},
             "roofline": roof,
             "kernels": kernels,
             "stages_ms": {k: round(v[0], 4) for k, v in sorted(stages.items())},

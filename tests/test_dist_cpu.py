@@ -55,3 +55,63 @@ def test_single_process_is_noop():
     g = torch.arange(12.0).reshape(3, 4)
     assert reduce_feature_grad(g.clone()).equal(g)
     assert shard_views(5, rank=0, world_size=1) == [0, 1, 2, 3, 4]
+
+
+def test_channel_shards_partition_the_feature_width():
+    from gags_amd.dist import channel_shard
+    for d, ws in ((512, 8), (512, 2), (512, 3), (16, 8), (48, 2), (100, 4), (33, 2)):
+        got = [channel_shard(d, rank=r, world_size=ws) for r in range(ws)]
+        assert got[0][0] == 0 and got[-1][1] == d
+        for (a0, a1), (b0, b1) in zip(got, got[1:]):
+            assert a1 == b0 and a0 <= a1
+        for c0, c1 in got[:-1]:
+            assert (c1 - c0) % 16 == 0
+    assert channel_shard(512, rank=3, world_size=8) == (192, 256)
+
+
+def _channel_worker(rank, world, port, q):
+    """by-channel step on a linear stand-in renderer (render = features^T pooled over a fixed weight map):
+    the shards' gradients, concatenated, equal the full-width single-process gradient -- with no collective."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gags_amd.dist import channel_shard, distributed_step
+    n, d, h, w, views = 50, 64, 6, 5, 3
+    gen = torch.Generator().manual_seed(0)
+    feats = torch.randn(n, d, generator=gen)
+    W = [torch.rand(h * w, n, generator=gen) for _ in range(views)]   # per-view blending weights (the "geometry")
+    G = [torch.randn(d, h, w, generator=gen) for _ in range(views)]
+
+    class PC:
+        pass
+
+    def render_fn(cam, pc, pipe, bg, feature_mode=True):
+        return {"render": (W[cam] @ pc._semantic_feature).t().reshape(-1, h, w)}
+
+    c0, c1 = channel_shard(d)
+    pc = PC()
+    pc._semantic_feature = torch.nn.Parameter(feats[:, c0:c1].clone())
+    distributed_step(render_fn, list(range(views)), pc, None, [g[c0:c1] for g in G], mode="channel")
+    full = PC()
+    full._semantic_feature = torch.nn.Parameter(feats.clone())
+    for v in range(views):
+        (render_fn(v, full, None, None)["render"] * G[v]).sum().backward()
+    ok = torch.allclose(pc._semantic_feature.grad, full._semantic_feature.grad[:, c0:c1], rtol=1e-5, atol=1e-5)
+    q.put((rank, bool(ok), (c0, c1)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_channel_sharded_step_two_ranks():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_channel_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    assert res[0][2] == (0, 32) and res[1][2] == (32, 64)
