@@ -60,9 +60,9 @@ __device__ __forceinline__ void tile_mfma(f32x16 (&acc)[NBB], const float (&A)[1
 }
 
 // ---- staged: rows ------------------------------------------------------------------------------------
-// One wave per (tile, 8x8 block, 128-channel slice).  K = the block's 64 pixels: K-step t pairs pixel t of
-// the upper 8x4 half (k = 0) with pixel t of the lower half (k = 1), exactly the [upper | lower] row layout
-// raster_weights wrote.  The cotangent slab (64 px x 128 ch) sits in 128 VGPRs as B operands.
+// One wave per (tile, 8x8 block, channel slice).  K = the block's 64 pixels in the order of the weight rows
+// raster_weights wrote (32 (upper, lower) pairs): K-step t pairs element t of the row's first half (k = 0)
+// with element t of its second half (k = 1).  The cotangent slab (64 px x 128 ch) sits in 128 VGPRs as B operands.
 __device__ long long g_rows_trace[8 * 262144];  // TRACE builds only: per-wave timeline (tools/rows_trace.py)
 
 // NBR = channel tiles of 32 per wave: 4 (D % 128 == 0; two waves per SIMD), 2 (D % 64 == 0) or 1 (D % 32 == 0).
@@ -97,7 +97,9 @@ __global__ __launch_bounds__(64, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void raste
     float V[32][NBR];
 #pragma unroll
     for (int t = 0; t < 32; ++t) {
-        const int qj = g.bx0 + (t & 7), qi = g.by0 + 4 * k + (t >> 3);
+        // K-step t of half-wave k = pixel 16k + t/2 of the 8x4 half t%2: the order of the weight rows
+        const int px = 16 * k + (t >> 1);
+        const int qj = g.bx0 + (px & 7), qi = g.by0 + 4 * (t & 1) + (px >> 3);
         const bool ok = (qi < height) && (qj < width);
         // NBR == 1 also serves a ragged last slice (D % 32 != 0): lanes past the row are clamped here, masked below
         const float *src = v_render_colors + ((size_t)min(qi, height - 1) * width + min(qj, width - 1)) * d +

@@ -3,9 +3,8 @@
 // to the sequential definition (and to each other and to the VALU kernels).
 //
 //  raster_fwd_feat<NB>   default; needs the scratch written by raster_weights.hip.
-//      One wave per (tile, 8x8 block, slice of 32*NB <= 128 channels): a pure stream.  Per K-step two
-//      dwords of weights per lane (the two 32x2 A operands of the block's upper / lower half, read
-//      column-wise from wt), two feature rows as one float4 per lane (the B operands, straight from
+//      One wave per (tile, 8x8 block, slice of 32*NB <= 128 channels): a pure stream.  Per K-step one
+//      8-byte pair of weights per lane (the two 32x2 A operands of the block's upper / lower half), two feature rows as one float4 per lane (the B operands, straight from
 //      global/L2 into VGPRs, four steps ahead) and 2*NB MFMAs.  No alpha work, no LDS, no barrier.
 //  raster_fwd_fused<NB>  fallback when the caller provides no scratch: same decomposition, but every
 //      wave also runs the HitStream / alpha / transmittance pipeline itself (repeated per slice).
@@ -132,39 +131,49 @@ __global__ __launch_bounds__(64, 2) void raster_fwd_feat(
     if (steps > 0) {
         // this lane's slot of step s, clamped to the block's last pair (surplus steps carry weight 0)
         auto slot_of = [&](int s) { return sb + 2 * min(s, steps - 1) + k; };
-        // raw id of the slot; clamped only when it is USED (a lone hit's partner slot carries N): touching the
-        // loaded value earlier would make the compiler wait for the load right after issuing it
-        auto gid_of = [&](int s) { return gid_s[slot_of(s)]; };
         const int gmax = n_gauss - 1;
         // PD-deep software pipeline: the feature rows of step s+PD are requested while step s runs its
         // MFMAs (rows mostly come from L2 / Infinity Cache: ~1-2 us), the ids another PD steps earlier.
+        // The ids of a whole group of PD steps travel in ONE vector load (lane l < 2*PD holds slot 2s + l) and
+        // are picked out with v_readlane when used; ids are clamped only then (a lone hit's partner slot
+        // carries N) -- touching a loaded value earlier would make the compiler wait for it right after issue.
+        // Vector-memory instructions per K-step: 1 (rows) + 1 (weight pair) + 1/PD (ids); they are not free
+        // next to the MFMAs (hardware findings).
         constexpr int PD = 4;
         float aA[PD], aB[PD];
         float4 b[PD][NG];
-        int gq[PD];
-        // prologue: issue the loads in exactly the order of the steady state (rows, id, weights per step) so
-        // that the compiler's counted vmcnt waits agree on both edges into the loop
-        int g0[PD];
+        auto ids_of = [&](int s) {  // ids of steps s .. s+PD-1, clamped to the block's last pair
+            return gid_s[sb + min(2 * s + (lane & (2 * PD - 1)), 2 * steps - 2 + (lane & 1))];
+        };
+        auto pick = [&](int gv, int i) {  // id of this lane's slot (k) of step i of the group
+            const int g0 = __builtin_amdgcn_readlane(gv, 2 * i), g1 = __builtin_amdgcn_readlane(gv, 2 * i + 1);
+            return min(k ? g1 : g0, gmax);
+        };
+        // prologue: issue the loads in exactly the order of the steady state so that the compiler's counted
+        // vmcnt waits agree on both edges into the loop
+        int gv = 0;
+        {
+            const int g0v = ids_of(0);
 #pragma unroll
-        for (int i = 0; i < PD; ++i) g0[i] = gid_of(i);
-#pragma unroll
-        for (int i = 0; i < PD; ++i) {
-            load_rows<NB>(colors, min(g0[i], gmax), d, ch0, p, b[i]);
-            gq[i] = gid_of(PD + i);
-            const float *w = wt + (size_t)slot_of(i) * 64 + p;
-            aA[i] = w[0]; aB[i] = w[32];
-            __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < PD; ++i) {
+                load_rows<NB>(colors, pick(g0v, i), d, ch0, p, b[i]);
+                if (i == 0) gv = ids_of(PD);
+                const float2 w = *reinterpret_cast<const float2 *>(wt + (size_t)slot_of(i) * 64 + 2 * p);
+                aA[i] = w.x; aB[i] = w.y;
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         for (int s = 0; s < steps; s += PD) {
+            const int gv_use = gv;
 #pragma unroll
             for (int i = 0; i < PD; ++i) {
                 const bool live = s + i < steps;
                 mfma_step<NB>(accA, live ? aA[i] : 0.f, b[i]);
                 mfma_step<NB>(accB, live ? aB[i] : 0.f, b[i]);
-                load_rows<NB>(colors, min(gq[i], gmax), d, ch0, p, b[i]);
-                gq[i] = gid_of(s + 2 * PD + i);
-                const float *w = wt + (size_t)slot_of(s + PD + i) * 64 + p;
-                aA[i] = w[0]; aB[i] = w[32];
+                load_rows<NB>(colors, pick(gv_use, i), d, ch0, p, b[i]);
+                if (i == 0) gv = ids_of(s + 2 * PD);
+                const float2 w = *reinterpret_cast<const float2 *>(wt + (size_t)slot_of(s + PD + i) * 64 + 2 * p);
+                aA[i] = w.x; aB[i] = w.y;
                 // the machine scheduler would otherwise sink these loads to just before their use PD steps
                 // later (it minimises register pressure), collapsing the pipeline to depth 1
                 __builtin_amdgcn_sched_barrier(0);

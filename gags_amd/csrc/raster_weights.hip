@@ -4,10 +4,11 @@
 // scalar work of the view exactly once -- alpha, skip rule, transmittance chain, stop rule --
 // independent of the feature width, at high occupancy (no accumulators: ~45 VGPRs), and leaves
 // behind what the feature-width-proportional passes need as pure streams:
-//   wt[slot][64]   : alpha*T of the block's 64 pixels for every K-step slot that blended anything
-//                    ([upper 8x4 half | lower 8x4 half]): row-wise it is the MFMA A operand of the
-//                    BACKWARD (K-step t pairs pixel t of the upper half with pixel t of the lower half),
-//                    column-wise the two A operands of the forward;
+//   wt[slot][64]   : alpha*T of the block's 64 pixels for every K-step slot that blended anything, as 32
+//                    (upper half, lower half) pairs: element 2p + h = pixel p of the 8x4 half h.  The forward
+//                    reads one pair per lane and K-step (ONE 8-byte load: its two A operands); the backward
+//                    reads rows, 32 consecutive floats per lane (its A operands: K-step t of half-wave k is
+//                    pixel 16k + t/2 of half t%2);
 //   gid[slot]      : Gaussian id of the slot (N for the unused partner of a lone last hit);
 //   blk_rows[blk]  : number of slots of the block (even);
 //   Tbuf / render_alphas / last_ids : per-pixel results of the chain.
@@ -109,9 +110,8 @@ __global__ __launch_bounds__(64, 4) void raster_weights_kernel(
             sA.cur = blA ? sidx_c : sA.cur;
             sB.cur = blB ? sidx_c : sB.cur;
             if (__any(wA != 0.f || wB != 0.f)) {  // steps nobody blends leave no slot
-                float *dst = wt + (size_t)(row + k) * 64 + p;  // row = [upper 32 px | lower 32 px]
-                dst[0] = wA;
-                dst[32] = wB;
+                // row = 32 (upper, lower) pairs: element 2p + h = pixel p of half h
+                *reinterpret_cast<float2 *>(wt + (size_t)(row + k) * 64 + 2 * p) = make_float2(wA, wB);
                 if (p == 0) gid_s[row + k] = gid_c;
                 row += 2;
             }
