@@ -2,8 +2,8 @@
 mirror of gsplat.rasterization).  Index tensors (radii, tiles_per_gauss, isect_ids,
 flatten_ids, isect_offsets, last_ids) must be BIT-EXACT; forward renders are bit-exact too on
 the fp32 paths (same op order, explicit exp polynomial, fmaf accumulation in sorted order);
-gradients are accumulated with float atomics, so they are compared with rel-L2 <= 2e-5
-against the oracle's double-accumulated sums."""
+gradients are summed in a different (fixed, or for the atomic kernels arbitrary) order than the
+oracle's double-accumulated sums, so they are compared with rel-L2 <= 2e-5."""
 import numpy as np
 import pytest
 import torch
@@ -68,8 +68,8 @@ def _check_indices(info, oinfo):
     (4000, 160, 120, 64, 5, None, 4.0, 0.5),   # MFMA path, NB=2
     (2000, 97, 61, 32, 6, 3, 6.0, 0.3),        # MFMA path, NB=1, ragged image
     (5000, 200, 152, 128, 7, None, 4.0, 0.0),  # MFMA path, NB=4 (C2 width)
-    (3000, 176, 130, 256, 8, 6, 5.0, 1.0),     # MFMA path, NB=8, one slice
-    (2500, 130, 100, 512, 9, 1, 5.0, None),    # MFMA path, NB=8, two slices (C3 width)
+    (3000, 176, 130, 256, 8, 6, 5.0, 1.0),     # MFMA path, two 128-channel slices
+    (2500, 130, 100, 512, 9, 1, 5.0, None),    # MFMA path, four 128-channel slices (C3 width)
     (6000, 96, 64, 128, 10, None, 16.0, 0.2),  # large splats: long per-tile lists, early termination
     (3000, 150, 110, 96, 11, 4, 5.0, 0.1),     # staged backward with 32-channel slices (D % 64 != 0)
     (3000, 150, 110, 160, 12, 7, 5.0, None),   # 32-channel slices, five of them
