@@ -30,7 +30,7 @@ struct HRec {
     int gid, sidx;  // Gaussian id, sorted intersection index
 };
 
-constexpr int RING = 256;      // per-wave ring of compacted hits (8 KB)
+constexpr int RING = 128;      // per-wave ring of compacted hits (4 KB; at most 5 + 64 are ever queued)
 constexpr int WT_STRIDE = 36;  // dwords per slot row of an LDS weight tile (conflict-free b32 write / b128 read)
 
 __device__ __forceinline__ GRec make_grec(const float *__restrict__ means2d, const float *__restrict__ conics,

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void gather_grec_kernel(int n_isects, const in
     dst[0] = u; dst[1] = v;
 }
 
-__global__ __launch_bounds__(64, 4) void raster_weights_kernel(
+__global__ __launch_bounds__(64, 8) void raster_weights_kernel(
     int width, int height, int tile_w, int n_tiles, int n_gauss, const GRec *__restrict__ packed,
     const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids, int n_isects,
     float *__restrict__ wt, int32_t *__restrict__ gid_s, int32_t *__restrict__ blk_rows, float *__restrict__ Tbuf,
