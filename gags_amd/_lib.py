@@ -30,9 +30,11 @@ SIGNATURES = {
     "gags_scan_scratch_bytes": (_i64, [_i32]),
     "gags_cumsum_i32": (_i32, [_i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     "gags_read_i32": (_i32, [_vp, _vp, _vp]),
-    "gags_tile_emit": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "gags_depth_order_scratch_bytes": (_i64, [_i32]),
+    "gags_depth_order": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "gags_tile_emit": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "gags_sort_scratch_bytes": (_i64, [_i64]),
-    "gags_sort_pairs": (_i32, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "gags_sort_pairs": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "gags_tile_offsets": (_i32, [_i64, _vp, _i32, _vp, _vp]),
     "gags_pack_isects": (_i32, [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_raster_fwd_scratch_bytes": (_i64, [_i64, _i32, _i32]),

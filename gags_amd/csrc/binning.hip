@@ -8,18 +8,20 @@ namespace {
 __global__ __launch_bounds__(256) void tile_emit_kernel(int n, const float *__restrict__ means2d,
                                                         const int32_t *__restrict__ radii,
                                                         const float *__restrict__ depths,
-                                                        const int32_t *__restrict__ cum, int tile_w, int tile_h,
+                                                        const int32_t *__restrict__ cum,
+                                                        const int32_t *__restrict__ order, int tile_w, int tile_h,
                                                         int64_t *__restrict__ isect_ids,
                                                         int32_t *__restrict__ flatten_ids)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    const int j = blockIdx.x * 256 + threadIdx.x;  // position in the emission order
+    if (j >= n) return;
+    const int i = order ? order[j] : j;            // Gaussian
     const int rad = radii[i];
     if (rad <= 0) return;
     const float2 m = reinterpret_cast<const float2 *>(means2d)[i];
     int x0, x1, y0, y1;
     gags_tile_aabb(m.x, m.y, rad, tile_w, tile_h, x0, x1, y0, y1);
-    int cur = (i == 0) ? 0 : cum[i - 1];
+    int cur = (j == 0) ? 0 : cum[j - 1];
     const int64_t dbits = (int64_t)(uint32_t)__float_as_int(depths[i]);
     for (int ty = y0; ty < y1; ++ty)
         for (int tx = x0; tx < x1; ++tx) {
@@ -118,7 +120,7 @@ extern "C" int gags_read_i32(const int32_t *src, int32_t *dst_host, void *stream
 }
 
 extern "C" int gags_tile_emit(int n, const float *means2d, const int32_t *radii, const float *depths,
-                              const int32_t *cum, int tile_w, int tile_h, int64_t *isect_ids,
+                              const int32_t *cum, const int32_t *order, int tile_w, int tile_h, int64_t *isect_ids,
                               int32_t *flatten_ids, void *stream)
 {
     GAGS_CLEAR_ERR();
@@ -126,7 +128,7 @@ extern "C" int gags_tile_emit(int n, const float *means2d, const int32_t *radii,
     if (n == 0) return GAGS_OK;
     if (!means2d || !radii || !depths || !cum || !isect_ids || !flatten_ids) return GAGS_EINVAL;
     hipLaunchKernelGGL(tile_emit_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, means2d,
-                       radii, depths, cum, tile_w, tile_h, isect_ids, flatten_ids);
+                       radii, depths, cum, order, tile_w, tile_h, isect_ids, flatten_ids);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }

@@ -119,14 +119,15 @@ int64_t sort_scratch_bytes_t(int64_t n_in)
     return keys + vals + hist + gags_scan::scratch_bytes(nblocks * RS_RADIX);
 }
 
-// stable LSD sort of (key, value) pairs on key bits [0, nbits); ping-pongs through `scratch` so that the
-// last pass lands in keys_out / vals_out.
+// stable LSD sort of (key, value) pairs on key bits [first_bit, first_bit + nbits); ping-pongs through
+// `scratch` so that the last pass lands in keys_out / vals_out.
 template <typename K>
-int sort_pairs_t(int64_t n, int nbits, const K *keys_in, const int32_t *vals_in, K *keys_out, int32_t *vals_out,
-                 void *scratch, int64_t scratch_bytes, hipStream_t st)
+int sort_pairs_t(int64_t n, int first_bit, int nbits, const K *keys_in, const int32_t *vals_in, K *keys_out,
+                 int32_t *vals_out, void *scratch, int64_t scratch_bytes, hipStream_t st)
 {
     if (n == 0) return GAGS_OK;
-    if (n < 0 || n >= (1ll << 31) || nbits <= 0 || nbits > (int)(8 * sizeof(K))) return GAGS_EINVAL;
+    if (n < 0 || n >= (1ll << 31) || nbits <= 0 || first_bit < 0 || first_bit + nbits > (int)(8 * sizeof(K)))
+        return GAGS_EINVAL;
     if (!keys_in || !vals_in || !keys_out || !vals_out || !scratch) return GAGS_EINVAL;
     if (scratch_bytes < sort_scratch_bytes_t<K>(n)) return GAGS_ESCRATCH;
     const int nblocks = (int)((n + RS_TILE - 1) / RS_TILE);
@@ -143,9 +144,9 @@ int sort_pairs_t(int64_t n, int nbits, const K *keys_in, const int32_t *vals_in,
         const bool to_out = ((passes - 1 - p) % 2) == 0;
         K *dst_k = to_out ? keys_out : ktmp;
         int32_t *dst_v = to_out ? vals_out : vtmp;
-        hipLaunchKernelGGL(rs_histogram<K>, dim3(nblocks), dim3(RS_THREADS), 0, st, n, p * 8, src_k, hist, nblocks);
+        hipLaunchKernelGGL(rs_histogram<K>, dim3(nblocks), dim3(RS_THREADS), 0, st, n, first_bit + p * 8, src_k, hist, nblocks);
         gags_scan::launch<true>(RS_RADIX * nblocks, (const int32_t *)hist, (int32_t *)hist, nullptr, scan_tmp, st);
-        hipLaunchKernelGGL(rs_scatter<K>, dim3(nblocks), dim3(RS_THREADS), 0, st, n, p * 8, src_k, src_v, dst_k, dst_v,
+        hipLaunchKernelGGL(rs_scatter<K>, dim3(nblocks), dim3(RS_THREADS), 0, st, n, first_bit + p * 8, src_k, src_v, dst_k, dst_v,
                            hist, nblocks);
         src_k = dst_k;
         src_v = dst_v;
@@ -162,17 +163,67 @@ int gags_sort_pairs_u32(int64_t n, int nbits, const uint32_t *keys_in, const int
                         int32_t *vals_out, void *scratch, int64_t scratch_bytes, hipStream_t st)
 {
     GAGS_CLEAR_ERR();
-    return sort_pairs_t<uint32_t>(n, nbits, keys_in, vals_in, keys_out, vals_out, scratch, scratch_bytes, st);
+    return sort_pairs_t<uint32_t>(n, 0, nbits, keys_in, vals_in, keys_out, vals_out, scratch, scratch_bytes, st);
 }
 
 extern "C" int64_t gags_sort_scratch_bytes(int64_t n_isects) { return sort_scratch_bytes_t<uint64_t>(n_isects); }
 
-extern "C" int gags_sort_pairs(int64_t n, int tile_bits, const int64_t *keys_in, const int32_t *vals_in,
-                               int64_t *keys_out, int32_t *vals_out, void *scratch, int64_t scratch_bytes,
-                               void *stream)
+extern "C" int gags_sort_pairs(int64_t n, int tile_bits, int depth_sorted, const int64_t *keys_in,
+                               const int32_t *vals_in, int64_t *keys_out, int32_t *vals_out, void *scratch,
+                               int64_t scratch_bytes, void *stream)
 {
     GAGS_CLEAR_ERR();
     if (n < 0 || tile_bits < 0 || tile_bits > 31) return GAGS_EINVAL;
-    return sort_pairs_t<uint64_t>(n, 32 + tile_bits, (const uint64_t *)keys_in, vals_in, (uint64_t *)keys_out, vals_out,
+    // input already in depth order (gags_depth_order + ordered gags_tile_emit): the stable sort only has to
+    // group by tile, 2 passes instead of 6 at 1080p
+    const int first = depth_sorted ? 32 : 0, nbits = depth_sorted ? (tile_bits > 0 ? tile_bits : 1) : 32 + tile_bits;
+    return sort_pairs_t<uint64_t>(n, first, nbits, (const uint64_t *)keys_in, vals_in, (uint64_t *)keys_out, vals_out,
                                   scratch, scratch_bytes, (hipStream_t)stream);
+}
+
+namespace {
+__global__ __launch_bounds__(256) void iota_kernel(int n, int32_t *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = i;
+}
+__global__ __launch_bounds__(256) void gather_i32_kernel(int n, const int32_t *__restrict__ idx,
+                                                         const int32_t *__restrict__ src, int32_t *__restrict__ dst)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+inline int64_t al256s(int64_t x) { return (x + 255) / 256 * 256; }
+}  // namespace
+
+// K7a: depth order of the Gaussians (stable argsort of the depth bits: depths of visible Gaussians are
+// positive, so their float bits order like the values; culled ones land anywhere and emit nothing) and the
+// tile counts in that order.  N elements instead of n_isects: the per-intersection sort then only groups by tile.
+extern "C" int64_t gags_depth_order_scratch_bytes(int n)
+{
+    const int64_t m = n > 0 ? n : 1;
+    return 2 * al256s(m * 4) + sort_scratch_bytes_t<uint32_t>(m);
+}
+
+extern "C" int gags_depth_order(int n, const float *depths, const int32_t *tiles_per_gauss, int32_t *order,
+                                int32_t *tiles_ordered, void *scratch, int64_t scratch_bytes, void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (n < 0) return GAGS_EINVAL;
+    if (n == 0) return GAGS_OK;
+    if (!depths || !tiles_per_gauss || !order || !tiles_ordered || !scratch) return GAGS_EINVAL;
+    if (scratch_bytes < gags_depth_order_scratch_bytes(n)) return GAGS_ESCRATCH;
+    hipStream_t st = (hipStream_t)stream;
+    char *sb = (char *)scratch;
+    int32_t *iota = (int32_t *)sb;
+    uint32_t *keys_sorted = (uint32_t *)(sb + al256s((int64_t)n * 4));
+    void *sort_scratch = sb + 2 * al256s((int64_t)n * 4);
+    hipLaunchKernelGGL(iota_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, iota);
+    const int rc = sort_pairs_t<uint32_t>(n, 0, 32, reinterpret_cast<const uint32_t *>(depths), iota, keys_sorted, order,
+                                          sort_scratch, sort_scratch_bytes_t<uint32_t>(n), st);
+    if (rc != GAGS_OK) return rc;
+    hipLaunchKernelGGL(gather_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, order, tiles_per_gauss,
+                       tiles_ordered);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
 }

@@ -125,9 +125,17 @@ def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height, conics=
     tile_bits = max(1, (n_tiles - 1).bit_length())
     cum = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     total = torch.empty(1, dtype=torch.int32, device=dev)
+    # Gaussians in depth order first (N keys), intersections emitted in that order: the per-intersection sort
+    # (n_isects ~ 5 N keys) then only groups by tile -- 2 radix passes instead of 6, same sorted result
+    order = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    tiles_ord = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    dsb = lib.gags_depth_order_scratch_bytes(n)
+    dscratch = torch.empty(dsb, dtype=torch.uint8, device=dev)
+    check(lib.gags_depth_order(n, ptr(depths), ptr(tiles_per_gauss), ptr(order), ptr(tiles_ord), ptr(dscratch), dsb, st),
+          "gags_depth_order")
     sb = lib.gags_scan_scratch_bytes(n)
     scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
-    check(lib.gags_cumsum_i32(n, ptr(tiles_per_gauss), ptr(cum), ptr(total), ptr(scratch), sb, st), "gags_cumsum_i32")
+    check(lib.gags_cumsum_i32(n, ptr(tiles_ord), ptr(cum), ptr(total), ptr(scratch), sb, st), "gags_cumsum_i32")
     host = ctypes.c_int32(0)
     check(lib.gags_read_i32(ptr(total), ctypes.byref(host), st), "gags_read_i32")
     n_isects = int(host.value)
@@ -137,11 +145,11 @@ def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height, conics=
     ids_s = torch.empty_like(ids)
     flat_s = torch.empty_like(flat)
     if n_isects > 0:
-        check(lib.gags_tile_emit(n, ptr(means2d), ptr(radii), ptr(depths), ptr(cum), tile_w, tile_h, ptr(ids),
-                                 ptr(flat), st), "gags_tile_emit")
+        check(lib.gags_tile_emit(n, ptr(means2d), ptr(radii), ptr(depths), ptr(cum), ptr(order), tile_w, tile_h,
+                                 ptr(ids), ptr(flat), st), "gags_tile_emit")
         ssb = lib.gags_sort_scratch_bytes(n_isects)
         sscratch = torch.empty(ssb, dtype=torch.uint8, device=dev)
-        check(lib.gags_sort_pairs(n_isects, tile_bits, ptr(ids), ptr(flat), ptr(ids_s), ptr(flat_s), ptr(sscratch),
+        check(lib.gags_sort_pairs(n_isects, tile_bits, 1, ptr(ids), ptr(flat), ptr(ids_s), ptr(flat_s), ptr(sscratch),
                                   ssb, st), "gags_sort_pairs")
     check(lib.gags_tile_offsets(n_isects, ptr(ids_s), n_tiles, ptr(offsets), st), "gags_tile_offsets")
     packed = None

@@ -70,16 +70,26 @@ int gags_cumsum_i32(int n, const int32_t *in, int32_t *cum, int32_t *total,
 /* the single device->host readback of the path (n_isects); synchronizes `stream`. */
 int gags_read_i32(const int32_t *src, int32_t *dst_host, void *stream);
 
-/* K6: emit (key, value) per (Gaussian, tile) intersection in Gaussian-major order.
- * isect_ids[n_isects] int64, flatten_ids[n_isects] int32. */
+/* K7a (optional, faster binning): order[N] = stable argsort of the Gaussians by depth bits, and
+ * tiles_ordered[i] = tiles_per_gauss[order[i]] (prefix-sum THAT, emit in that order, and K7 only has to
+ * group by tile).  scratch: gags_depth_order_scratch_bytes(n) bytes. */
+int64_t gags_depth_order_scratch_bytes(int n);
+int gags_depth_order(int n, const float *depths, const int32_t *tiles_per_gauss, int32_t *order,
+                     int32_t *tiles_ordered, void *scratch, int64_t scratch_bytes, void *stream);
+
+/* K6: emit (key, value) per (Gaussian, tile) intersection, Gaussian after Gaussian in the order given
+ * (order == NULL: by index); cum = inclusive prefix sum of the tile counts IN THAT ORDER.
+ * isect_ids[n_isects] int64 = tile << 32 | depth bits, flatten_ids[n_isects] int32 = Gaussian. */
 int gags_tile_emit(int n, const float *means2d, const int32_t *radii, const float *depths,
-                   const int32_t *cum, int tile_w, int tile_h,
+                   const int32_t *cum, const int32_t *order, int tile_w, int tile_h,
                    int64_t *isect_ids, int32_t *flatten_ids, void *stream);
 
-/* K7: stable radix sort of the pairs on key bits [0, 32 + tile_bits).
+/* K7: stable radix sort of the pairs on key bits [0, 32 + tile_bits); with depth_sorted != 0 the input
+ * is already in depth order (K7a + ordered K6) and only bits [32, 32 + tile_bits) are sorted -- same
+ * result (ties: depth, then Gaussian index), 2 passes instead of 6 at 1080p.
  * scratch: gags_sort_scratch_bytes(n_isects) bytes. */
 int64_t gags_sort_scratch_bytes(int64_t n_isects);
-int gags_sort_pairs(int64_t n_isects, int tile_bits,
+int gags_sort_pairs(int64_t n_isects, int tile_bits, int depth_sorted,
                     const int64_t *keys_in, const int32_t *vals_in,
                     int64_t *keys_out, int32_t *vals_out,
                     void *scratch, int64_t scratch_bytes, void *stream);

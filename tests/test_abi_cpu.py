@@ -50,7 +50,9 @@ def test_argument_validation_returns_codes_without_launching(lib):
     assert lib.gags_project_fwd(8, *([None] * 5), 16, 16, 0.3, 0.01, 1e10, 0.0, *([None] * 5), None) == -1
     assert lib.gags_raster_fwd(0, 4, 16, 16, *([None] * 7), 0, None, None, None, None, None, 0, None, 0, None) == -1
     assert lib.gags_raster_fwd_scratch_bytes(1000, 64, 48) >= 4 * 1000 * 260
-    assert lib.gags_sort_pairs(4, 40, None, None, None, None, None, 0, None) == -1
+    assert lib.gags_sort_pairs(4, 40, 0, None, None, None, None, None, 0, None) == -1
+    assert lib.gags_depth_order(-1, None, None, None, None, None, 0, None) == -1
+    assert lib.gags_depth_order_scratch_bytes(1000) > 2 * 1000 * 4
     assert lib.gags_sort_scratch_bytes(1000) > 1000 * 12
     assert lib.gags_scan_scratch_bytes(100000) >= 4
     assert lib.gags_cumsum_i32(-5, None, None, None, None, 0, None) == -1
