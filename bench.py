@@ -38,8 +38,16 @@ class _CotangentLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, G):
+        from gags_amd import _lib
         ctx.save_for_backward(G)
-        return torch.dot(x.reshape(-1), G.reshape(-1))
+        x, G = x.contiguous(), G.contiguous()  # both already are: [H,W,D] memory
+        lib = _lib.load()
+        out = torch.empty(1, device=x.device)
+        nb = lib.gags_dot_scratch_bytes()
+        scratch = torch.empty(nb, dtype=torch.uint8, device=x.device)
+        _lib.check(lib.gags_dot_f32(x.numel(), _lib.ptr(x), _lib.ptr(G), _lib.ptr(out), _lib.ptr(scratch), nb,
+                                    torch.cuda.current_stream().cuda_stream), "gags_dot_f32")
+        return out[0]
 
     @staticmethod
     def backward(ctx, g):

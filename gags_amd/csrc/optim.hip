@@ -66,3 +66,58 @@ extern "C" int gags_adam_step(int64_t numel, float *param, const float *grad, fl
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }
+
+// ---- harness helper: loss = <render, G>, the terminal loss of the synthetic step -------------
+// Two 4.25 GB streams at C3: one read each, fp32 partial sums per thread, double across threads / blocks; fixed
+// grid and order => reproducible.  (rocBLAS sdot runs the same reduction at ~4.8 TB/s; this one is bandwidth-bound.)
+namespace {
+
+constexpr int DOT_BLOCKS = 256 * 8;
+
+__global__ __launch_bounds__(256) void dot_partial_kernel(int64_t n, const float *__restrict__ x,
+                                                          const float *__restrict__ y, double *__restrict__ partial)
+{
+    __shared__ double sm[4];
+    const int64_t n4 = n >> 2, stride = (int64_t)DOT_BLOCKS * 256;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 u = reinterpret_cast<const float4 *>(x)[i], v = reinterpret_cast<const float4 *>(y)[i];
+        a0 = fmaf(u.x, v.x, a0); a1 = fmaf(u.y, v.y, a1); a2 = fmaf(u.z, v.z, a2); a3 = fmaf(u.w, v.w, a3);
+    }
+    const int64_t tail = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (tail < n) a0 = fmaf(x[tail], y[tail], a0);
+    double s = ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+__global__ __launch_bounds__(256) void dot_final_kernel(const double *__restrict__ partial, float *__restrict__ out)
+{
+    __shared__ double sm[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < DOT_BLOCKS; i += 256) s += partial[i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (float)((sm[0] + sm[1]) + (sm[2] + sm[3]));
+}
+
+}  // namespace
+
+extern "C" int64_t gags_dot_scratch_bytes(void) { return (int64_t)DOT_BLOCKS * sizeof(double); }
+
+extern "C" int gags_dot_f32(int64_t numel, const float *x, const float *y, float *out, void *scratch,
+                            int64_t scratch_bytes, void *stream)
+{
+    if (numel < 0 || !out || !scratch || scratch_bytes < gags_dot_scratch_bytes()) return GAGS_EINVAL;
+    if (numel > 0 && (!x || !y)) return GAGS_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return GAGS_EINVAL;
+    GAGS_CLEAR_ERR();
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(dot_partial_kernel, dim3(DOT_BLOCKS), dim3(256), 0, st, numel, x, y, (double *)scratch);
+    hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(256), 0, st, (const double *)scratch, out);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}

@@ -199,6 +199,13 @@ int gags_ed_normalize(int64_t n_pix, int d, float *render_colors, const float *r
 int gags_adam_step(int64_t numel, float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                    double lr, double beta1, double beta2, double eps, int step, void *stream);
 
+/* Harness helper (the build's own synthetic step): out[0] = <x, y> over `numel` floats,
+ * the terminal loss `(render * G).sum()` of bench.py; reproducible (fixed grid and order).
+ * scratch: gags_dot_scratch_bytes() bytes; x, y 16-B aligned. */
+int64_t gags_dot_scratch_bytes(void);
+int gags_dot_f32(int64_t numel, const float *x, const float *y, float *out, void *scratch,
+                 int64_t scratch_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

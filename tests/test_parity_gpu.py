@@ -342,3 +342,24 @@ def test_full_size_properties_c3():
     # (6) the float-atomic fallback computes the same sums (different order)
     ga = grad_of(fwd(_lib.GAGS_BWD_ATOMIC), G)
     assert ((ga - g1).double().norm() / g1.double().norm()).item() <= 1e-5
+
+
+def test_harness_dot_matches_float64():
+    """Row H: the harness loss <render, G> (gags_dot_f32) against a float64 dot; ragged length, reproducible."""
+    from gags_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(11)
+    n = 3 * 1000 * 1000 + 3
+    x = torch.randn(n + 4, device=dev, generator=gen)[:n]  # 16-B aligned start, n % 4 != 0
+    y = torch.randn(n + 4, device=dev, generator=gen)[:n]
+    nb = lib.gags_dot_scratch_bytes()
+    scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+    outs = []
+    for _ in range(2):
+        out = torch.empty(1, device=dev)
+        _lib.check(lib.gags_dot_f32(n, _lib.ptr(x), _lib.ptr(y), _lib.ptr(out), _lib.ptr(scratch), nb, None), "dot")
+        outs.append(out.item())
+    ref = torch.dot(x.double(), y.double()).item()
+    assert outs[0] == outs[1]
+    assert abs(outs[0] - ref) <= 1e-5 * (x.double().norm() * y.double().norm()).item()
