@@ -353,6 +353,14 @@ def main():
                         "p90": per_step[int(round(0.9 * (len(per_step) - 1)))]},
             "optimizer_step": adam,
         }
+        # whole-step view of the metric's "HBM-roofline %": compulsory traffic of one view, every tensor once
+        # (SURVEY.md 8d):  72 N + 36 I + 2 V D s_f + 2 P (D s_o + 8) + 4 V D   bytes, s_f = s_o = 4
+        pix = width * height
+        b_view = 72.0 * n + 36.0 * n_isects + 2.0 * n_visible * dl * 4 + 2.0 * pix * (dl * 4 + 8) + 4.0 * n_visible * dl
+        views_per_gpu_step = world if mode == "channel" else 1
+        gbs = b_view * views_per_gpu_step / (ms_per_step * 1e-3) / 1e9
+        line["hbm_roofline_step"] = {"algorithmic_bytes_per_view": b_view, "achieved": gbs, "peak": HBM_PEAK_GBS,
+                                     "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pc, cam, d, width, height, args.cpu_seconds)
         print(json.dumps(line), flush=True)
