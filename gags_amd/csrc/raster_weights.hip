@@ -9,7 +9,7 @@
 //                    reads one pair per lane and K-step (ONE 8-byte load: its two A operands); the backward
 //                    reads rows, 32 consecutive floats per lane (its A operands: K-step t of half-wave k is
 //                    pixel 16k + t/2 of half t%2);
-//   gid[slot]      : Gaussian id of the slot (N for the unused partner of a lone last hit);
+//   gid[slot]      : Gaussian id of the slot (N for the zero slot that pads an odd count);
 //   blk_rows[blk]  : number of slots of the block (even);
 //   Tbuf / render_alphas / last_ids : per-pixel results of the chain.
 // Slots of a block live in a fixed, sparse region of the slot space (no counting pre-pass):
@@ -109,15 +109,27 @@ __global__ __launch_bounds__(64, 8) void raster_weights_kernel(
             const float wB = step_pair(sB, __uint_as_float(swB[0]), __uint_as_float(swB[1]), k, blB);
             sA.cur = blA ? sidx_c : sA.cur;
             sB.cur = blB ? sidx_c : sB.cur;
-            if (__any(wA != 0.f || wB != 0.f)) {  // steps nobody blends leave no slot
+            // a hit that blends into none of the block's pixels leaves no slot (its partner in the step may):
+            // zero rows would be multiplied, stored, sorted and summed like any other -- they were 20 % of all rows
+            const unsigned long long nzm = __ballot(wA != 0.f || wB != 0.f);
+            const bool nz0 = (nzm & 0xffffffffull) != 0, nz1 = (nzm >> 32) != 0;  // slot k = half-wave k
+            if (k ? nz1 : nz0) {
+                const int pos = row + ((k && nz0) ? 1 : 0);
                 // row = 32 (upper, lower) pairs: element 2p + h = pixel p of half h
-                *reinterpret_cast<float2 *>(wt + (size_t)(row + k) * 64 + 2 * p) = make_float2(wA, wB);
-                if (p == 0) gid_s[row + k] = gid_c;
-                row += 2;
+                *reinterpret_cast<float2 *>(wt + (size_t)pos * 64 + 2 * p) = make_float2(wA, wB);
+                if (p == 0) gid_s[pos] = gid_c;
             }
+            row += (int)nz0 + (int)nz1;
             return more && !__all(sA.done && sB.done);
         };
         while (kstep()) {}
+    }
+    if ((row - sb) & 1) {  // consumers take slots in pairs: pad with one zero slot that belongs to no Gaussian
+        if (k == 0) {
+            *reinterpret_cast<float2 *>(wt + (size_t)row * 64 + 2 * p) = make_float2(0.f, 0.f);
+            if (p == 0) gid_s[row] = n_gauss;
+        }
+        row += 1;
     }
     if (lane == 0) blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk] = row - sb;
     {
