@@ -44,3 +44,23 @@ I = ids.numel()
 slots = int(cap["blk_rows"].sum())
 print("tile-list entries %d; (entry, block) pairs %d; pass the extent test %d (%.1f %%); become slots %d (%.1f %% of the hits)" % (
     I, 4 * I, total_hits, 100.0 * total_hits / (4 * I), slots, 100.0 * slots / total_hits))
+
+# of the hits that pass the box test: how many reach alpha >= 1/255 on at least one pixel centre of the block
+# (what an exact geometric test could keep at most); the rest of the non-blending hits is occlusion (T <= 1e-4)
+a, b, c, o = pk[:, 2], pk[:, 3], pk[:, 4], pk[:, 5]
+geo = 0
+pxs = torch.arange(8, device=dev).float() + 0.5
+for blk in range(4):
+    bx0 = tx + (blk & 1) * 8; by0 = ty + (blk >> 1) * 8
+    hit = (x + ex >= bx0 + 0.5) & (x - ex <= bx0 + 7.5) & (y + ey >= by0 + 0.5) & (y - ey <= by0 + 7.5)
+    idx = hit.nonzero().squeeze(1)
+    for ch in torch.split(idx, 1 << 20):
+        dx = x[ch, None] - (bx0[ch, None] + pxs[None, :])          # [m, 8]
+        dy = y[ch, None] - (by0[ch, None] + pxs[None, :])          # [m, 8]
+        sig = 0.5 * (a[ch, None, None] * dx[:, None, :] ** 2 + c[ch, None, None] * dy[:, :, None] ** 2) \
+            + b[ch, None, None] * dx[:, None, :] * dy[:, :, None]  # [m, 8(y), 8(x)]
+        al = torch.clamp(o[ch, None, None] * torch.exp(-sig), max=0.999)
+        ok = ((sig >= 0) & (al >= 1.0 / 255.0)).flatten(1).any(1)
+        geo += int(ok.sum())
+print("hits with alpha >= 1/255 on some pixel of the block: %d (%.1f %% of the box hits); slots %d => occluded %.1f %%" % (
+    geo, 100.0 * geo / total_hits, slots, 100.0 * (geo - slots) / max(geo, 1)))
