@@ -6,6 +6,8 @@
 //   mode 4: 128 MFMAs, then 224 independent VALU ops, then the 16 stores   (VALU block after the MFMAs)
 //   mode 6: like 2, but the accumulators are zeroed per tile and the stores write the accumulators (true dependency)
 //   mode 7: like 6 plus 8 x global_load_dwordx4 of A operands per tile (consumed by the next tile's MFMAs)
+//   mode 8: like 7 with the accumulators in AccVGPRs (inline-asm MFMA, "a" constraint)
+//   mode 9: like 8 with the accumulators in arch VGPRs
 //   mode 5: 128 MFMAs with 2 VALU ops in the shadow of each, then the 16 stores
 // 2048 waves (2 per SIMD, 256 VGPRs each) or 1024 waves; `stream` = 1: every tile stores to fresh memory (HBM),
 // 0: the wave re-writes its own 16 KB (L2).
@@ -42,6 +44,32 @@ __global__ __launch_bounds__(64, 2) void k(int tiles, int stream, float *buf, si
             for (int t = 0; t < 32; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(Areg[t >> 2][t & 3], bj[j], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) Areg[i] = An[i];
+        }
+        if (MODE == 9) {  // as 8, accumulators in arch VGPRs: separates "AccVGPR" from "asm-pinned order"
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(dst + 4096);
+            f32x4 An[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) An[i] = src[i * 64];
+#pragma unroll
+            for (int t = 0; t < 32; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[j]) : "v"(Areg[t >> 2][t & 3]), "v"(bj[j]));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) Areg[i] = An[i];
+        }
+        if (MODE == 8) {
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(dst + 4096);
+            f32x4 An[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) An[i] = src[i * 64];
+#pragma unroll
+            for (int t = 0; t < 32; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[j]) : "v"(Areg[t >> 2][t & 3]), "v"(bj[j]));
 #pragma unroll
             for (int i = 0; i < 8; ++i) Areg[i] = An[i];
         }
@@ -135,6 +163,8 @@ int main()
             run<5>(waves, tiles, stream, buf, wave_stride, sink);
             run<6>(waves, tiles, stream, buf, wave_stride, sink);
             run<7>(waves, tiles, stream, buf, wave_stride, sink);
+            run<8>(waves, tiles, stream, buf, wave_stride, sink);
+            run<9>(waves, tiles, stream, buf, wave_stride, sink);
         }
     return 0;
 }
