@@ -127,6 +127,64 @@ __global__ __launch_bounds__(64, 2) void k(int tiles, int stream, float *buf, si
     if (s == 12345.f) sink[0] = s;
 }
 
+// Big tiles, ONE wave per SIMD: 256 MFMAs (8 accumulator tiles = 256 channels) per 32-slot tile, the next tile's
+// 8 KB of A operands requested before the burst and waited for after it, then 32 row stores (true dependency).
+__global__ __launch_bounds__(64, 1) void kbig(int tiles, float *buf, size_t wave_stride, float *sink)
+{
+    asm volatile("v_mov_b32 v255, 0" ::: "v255");
+    const float a = threadIdx.x * 1e-3f, b = threadIdx.x * 2e-3f;
+    float bj[8];
+    for (int j = 0; j < 8; ++j) bj[j] = b + j;
+    f32x4 Areg[8];
+    for (int i = 0; i < 8; ++i) Areg[i] = f32x4{a, b, a, b};
+    float *base = buf + (size_t)blockIdx.x * wave_stride + threadIdx.x * 4;
+    float s = 0.f;
+    for (int m = 0; m < tiles; ++m) {
+        float *dst = base + (size_t)m * 8192;  // 32 KB of rows per tile
+        f32x16 acc[8];
+        for (int j = 0; j < 8; ++j)
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(dst + 8192);
+        f32x4 An[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) An[i] = src[i * 64];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 32; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[j]) : "v"(Areg[t >> 2][t & 3]), "v"(bj[j]));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) Areg[i] = An[i];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            f32x4 o0 = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]}, o1 = {acc[4][r], acc[5][r], acc[6][r], acc[7][r]};
+            asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst + r * 512), "v"(o0) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst + r * 512 + 256), "v"(o1) : "memory");
+        }
+    }
+    if (s == 12345.f) sink[0] = s;
+}
+
+static void run_big(int tiles, float *buf, float *sink)
+{
+    const int waves = 1024;
+    const size_t wave_stride = (size_t)(tiles + 1) * 8192;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(kbig, dim3(waves), dim3(64), 0, 0, 2, buf, wave_stride, sink);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL(kbig, dim3(waves), dim3(64), 0, 0, tiles, buf, wave_stride, sink);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    const double flop = (double)waves * tiles * 256 * 4096.0, bytes = (double)waves * tiles * 32768.0;
+    printf("big tiles, 1 wave/SIMD: %.3f ms  %.1f TFLOP/s  %.2f TB/s stored\n", ms, flop / ms * 1e-9, bytes / ms * 1e-9);
+}
+
 template <int MODE>
 static void run(int waves, int tiles, int stream, float *buf, size_t wave_stride, float *sink)
 {
@@ -151,7 +209,7 @@ int main()
     const int tiles = 256;
     const size_t wave_stride = (size_t)tiles * 4096;  // floats: 16 KB per tile
     float *buf, *sink;
-    (void)hipMalloc(&buf, 2049 * wave_stride * 4);  // 8 GB
+    (void)hipMalloc(&buf, 2112 * wave_stride * 4);  // + slack: every mode reads one tile past its last  // 8 GB
     (void)hipMalloc(&sink, 4);
     for (int stream = 1; stream < 2; ++stream)
         for (int waves : {2048}) {
@@ -166,5 +224,6 @@ int main()
             run<8>(waves, tiles, stream, buf, wave_stride, sink);
             run<9>(waves, tiles, stream, buf, wave_stride, sink);
         }
+    run_big(256, buf, sink);
     return 0;
 }
