@@ -1,5 +1,6 @@
 // C-ABI entry points of the raster stages: argument validation + dispatch onto the VALU kernels
-// (narrow / odd D, full geometry gradients) and the matrix-core kernels (D % 32 == 0).
+// (narrow / odd D, full geometry gradients) and the matrix-core kernels (D >= 16, D % 4 == 0;
+// the single-kernel fallbacks: D % 32 == 0).
 #include "common.h"
 
 // raster_valu.hip

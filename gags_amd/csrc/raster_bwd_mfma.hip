@@ -8,8 +8,8 @@
 // What happens to those rows is the whole story on this part: float atomics are executed at the memory
 // side on a multi-XCD MI355X (TCC_EA0_ATOMIC == TCC_ATOMIC, ~1.2 TB/s measured) while plain stores of the
 // same rows are almost free.  So the default ("staged") path has NO atomics and is bit-reproducible:
-//   rows    one wave per (tile, block, 128-channel slice): weight tile from the forward's scratch (wt),
-//           64 MFMAs, 32 rows stored at fixed addresses (prefix sum of the forward's slot counts);
+//   rows    one wave per (tile, 8x8 block, slice of 128 / 64 / 32 channels): weight tile from the forward's
+//           scratch (wt), 32 MFMAs per 32 channels, 32 rows stored at fixed addresses (prefix sum of the forward's slot counts);
 //   sort    (Gaussian id, row) pairs, radix sort on 32-bit keys; per-Gaussian offsets;
 //   reduce  v_colors[g] = sum of its rows, written once (no zero-fill of v_colors needed).
 // The single-kernel atomic variant (recomputes alpha itself; needs neither scratch nor the forward's
@@ -65,7 +65,8 @@ __device__ __forceinline__ void tile_mfma(f32x16 (&acc)[NBB], const float (&A)[1
 // with element t of its second half (k = 1).  The cotangent slab (64 px x 128 ch) sits in 128 VGPRs as B operands.
 __device__ long long g_rows_trace[8 * 262144];  // TRACE builds only: per-wave timeline (tools/rows_trace.py)
 
-// NBR = channel tiles of 32 per wave: 4 (D % 128 == 0; two waves per SIMD), 2 (D % 64 == 0) or 1 (D % 32 == 0).
+// NBR = channel tiles of 32 per wave: 4 (D % 128 == 0; two waves per SIMD), 2 (D % 64 == 0) or 1 (any other
+// D % 4 == 0: the last slice may be ragged).
 template <int NBR, bool TRACE>
 __global__ __launch_bounds__(64, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void raster_bwd_rows(
     int d, int width, int height, int tile_w, int n_tiles, int n_slices, const float *__restrict__ v_render_colors,

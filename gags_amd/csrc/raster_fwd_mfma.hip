@@ -1,4 +1,4 @@
-// K9 on the matrix cores (D % 32 == 0), exact fp32: v_mfma_f32_32x32x2_f32 is bit-for-bit a
+// K9 on the matrix cores (split path: D >= 16, D % 4 == 0; fused kernel: D % 32 == 0), exact fp32: v_mfma_f32_32x32x2_f32 is bit-for-bit a
 // k-ordered fmaf chain and zero weights are exact no-ops, so both kernels below are bit-identical
 // to the sequential definition (and to each other and to the VALU kernels).
 //

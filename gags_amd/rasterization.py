@@ -170,7 +170,7 @@ def _mfma_width(d):
 class _Rasterize(torch.autograd.Function):
     """K9 forward / K10 backward over pre-binned intersections.
 
-    Matrix-core widths (D % 32 == 0) run the split forward: one weights pass (alpha, transmittance,
+    Matrix-core widths (D >= 16, D % 4 == 0) run the split forward: one weights pass (alpha, transmittance,
     stop rule: once per view) that leaves weight tiles in a scratch buffer, then the feature stream.
     The same scratch feeds the staged, atomic-free colours-only backward."""
 

@@ -114,7 +114,7 @@ int gags_pack_isects(int n, int64_t n_isects, const int32_t *flatten_ids, const 
  * colors[N,D] / backgrounds[D] (gaussian_renderer/__init__.py:61,64).
  * backgrounds may be NULL.  Outputs render_colors[H,W,D], render_alphas[H,W],
  * last_ids[H,W] (sorted index of the last blended Gaussian per pixel).
- * Kernel choice: D % 32 == 0 with `packed` given runs on the matrix cores -- as the split
+ * Kernel choice: with `packed` given, D >= 16 and D % 4 == 0 runs on the matrix cores as the split
  * weights + feature passes when `scratch` (gags_raster_fwd_scratch_bytes) and `blk_rows`
  * ([tile_h*tile_w*4] int32, written: slots per 8x8 pixel block) are provided, else as one fused kernel; anything else runs the
  * VALU kernels.  The scratch and blk_rows of a split forward are what
@@ -141,8 +141,8 @@ int gags_raster_bwd(int d, int width, int height, const float *means2d, const fl
                     float *v_colors, float *v_opacities, float *v_means2d, float *v_conics,
                     int flags, void *stream);
 
-/* K10, staged flavour: colours-only backward WITHOUT atomics (deterministic), D % 128 == 0,
- * D <= 1024.  Consumes the scratch + blk_rows of a split gags_raster_fwd, the inclusive prefix
+/* K10, staged flavour: colours-only backward WITHOUT atomics (deterministic), 16 <= D <= 1024,
+ * D % 4 == 0.  Consumes the scratch + blk_rows of a split gags_raster_fwd, the inclusive prefix
  * sum row_end of blk_rows (gags_cumsum_i32) and its total `rows` (gags_read_i32).  Partial sums
  * are stored as rows, sorted by Gaussian and reduced; v_colors[N,D] is written in full (no
  * zero-fill needed).  scratch: gags_bwd_staged_scratch_bytes(rows, n, d) bytes.
