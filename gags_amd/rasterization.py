@@ -32,10 +32,18 @@ def _stream():
 
 
 def _need_cuda(*ts):
+    cur = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError("gags_amd.rasterization: all tensors must live on the GPU "
                                "(there is no CPU path; see oracle/ for the test-only CPU restatement)")
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:  # kernels are launched on the current device's stream
+            raise RuntimeError(f"gags_amd.rasterization: tensor on cuda:{t.device.index} but the current device is "
+                               f"cuda:{cur}; one process per GPU, torch.cuda.set_device(local_rank) first")
 
 
 def _c(t):
