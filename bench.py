@@ -185,11 +185,12 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
-    def build(mode):
+    def build(mode, grad_reduce=None):
         """(step function, model, camera of the last view, local feature width) of one decomposition (gags_amd/dist.py).
         view   : Gaussians + features replicated (same seed on every rank), one yawed view per rank (C4's cameras),
-                 reduce-scatter + all-gather of the feature gradient at step end.
+                 reduce-scatter + all-gather (or all-reduce) of the feature gradient at step end.
         channel: every rank renders all `world` views for its channel shard; no exchange."""
+        grad_reduce = grad_reduce or args.grad_reduce
         if mode == "channel":
             c0, c1 = channel_shard(d)
             dl = c1 - c0
@@ -209,7 +210,7 @@ def main():
                 loss = _CotangentLoss.apply(pkg_["render"].permute(1, 2, 0), G_.permute(1, 2, 0))
                 loss.backward()
             if mode == "view" and world > 1 and not args.no_allreduce:
-                reduce_feature_grad(pc_._semantic_feature.grad, mode=args.grad_reduce)
+                reduce_feature_grad(pc_._semantic_feature.grad, mode=grad_reduce)
             return pkg_
         return step_, pc_, cams[-1], dl
 
@@ -224,10 +225,11 @@ def main():
             if not channel_ok:
                 raise SystemExit(f"--parallel channel needs D >= 16 * {world}")
             mode = "channel"
-        elif channel_ok:  # auto: two probe steps of each, same decision on every rank (MAX over ranks)
+        elif channel_ok:  # auto: two probe steps of each candidate, same decision on every rank (MAX over ranks)
             probe = {}
-            for m in ("view", "channel"):
-                fn, pc_, _, _ = build(m)
+            cands = {"view": ("view", "rs_ag"), "view/allreduce": ("view", "allreduce"), "channel": ("channel", None)}
+            for name, (m, gr) in cands.items():
+                fn, pc_, _, _ = build(m, gr)
                 fn()
                 torch.cuda.synchronize(); barrier()
                 t0 = time.perf_counter()
@@ -235,10 +237,13 @@ def main():
                 torch.cuda.synchronize(); barrier()
                 tt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
                 torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-                probe[m] = 1e3 * float(tt.item()) / 2
+                probe[name] = 1e3 * float(tt.item()) / 2
                 del fn, pc_
                 torch.cuda.empty_cache()
-            mode = min(probe, key=probe.get)
+            best = min(probe, key=probe.get)
+            mode, chosen_reduce = cands[best]
+            if chosen_reduce:
+                args.grad_reduce = chosen_reduce
     step, pc, cam, d_local = build(mode)
 
     for _ in range(args.warmup):
@@ -343,8 +348,9 @@ def main():
                        "visible": n_visible, "n_isects": n_isects, "pairs_evaluated": q_eval,
                        "pairs_blended": q_blend, "bwd_rows": rows,
                        "parallelism": (f"channel-shard{world} (no data-path collective)" if mode == "channel"
-                                       else f"view-dp{world}" + (" + RCCL reduce-scatter/all-gather of the feature gradient"
-                                                                if world > 1 else "")),
+                                       else f"view-dp{world}" + ((" + RCCL all-reduce of the feature gradient" if args.grad_reduce == "allreduce"
+                                                                  else " + RCCL reduce-scatter/all-gather of the feature gradient")
+                                                                 if world > 1 else "")),
                        "parallel_probe_ms_per_step": probe},
             "roofline": roof,
             "kernels": kernels,
