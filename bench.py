@@ -230,12 +230,17 @@ def main():
             cands = {"view": ("view", "rs_ag"), "view/allreduce": ("view", "allreduce"), "channel": ("channel", None)}
             for name, (m, gr) in cands.items():
                 fn, pc_, _, _ = build(m, gr)
-                fn()
-                torch.cuda.synchronize(); barrier()
-                t0 = time.perf_counter()
-                fn(); fn()
-                torch.cuda.synchronize(); barrier()
-                tt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+                try:  # a collective flavour the backend refuses costs its candidate, not the run
+                    fn()
+                    torch.cuda.synchronize(); barrier()
+                    t0 = time.perf_counter()
+                    fn(); fn()
+                    torch.cuda.synchronize(); barrier()
+                    elapsed = time.perf_counter() - t0
+                except RuntimeError as e:
+                    print(f"[bench] rank {rank}: probe of '{name}' failed: {e}", file=sys.stderr, flush=True)
+                    elapsed = float("inf")
+                tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
                 torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
                 probe[name] = 1e3 * float(tt.item()) / 2
                 del fn, pc_
