@@ -191,13 +191,14 @@ def main():
                  reduce-scatter + all-gather (or all-reduce) of the feature gradient at step end.
         channel: every rank renders all `world` views for its channel shard; no exchange."""
         grad_reduce = grad_reduce or args.grad_reduce
+        first = max(0, (8 - world) // 2)  # the `world` middle cameras of C4's eight (yaw (v - 3.5) * 5 degrees)
         if mode == "channel":
             c0, c1 = channel_shard(d)
             dl = c1 - c0
-            views = list(range(world))
+            views = [first + v for v in range(world)]
         else:
             dl = d
-            views = [rank % 8] if world > 1 else [None]
+            views = [first + rank] if world > 1 else [None]
         pc_ = syn.make_model(n, dl, width, height, seed=0, device=dev, gen_device=dev)
         pc_.training_setup()
         cams = [syn.make_camera(width, height, view=(v % 8) if v is not None else None, device=dev) for v in views]
@@ -242,10 +243,10 @@ def main():
                     elapsed = float("inf")
                 tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
                 torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-                probe[name] = 1e3 * float(tt.item()) / 2
+                probe[name] = 1e3 * float(tt.item()) / 2 if tt.item() != float("inf") else None
                 del fn, pc_
                 torch.cuda.empty_cache()
-            best = min(probe, key=probe.get)
+            best = min((k_ for k_ in probe if probe[k_] is not None), key=probe.get, default="channel")
             mode, chosen_reduce = cands[best]
             if chosen_reduce:
                 args.grad_reduce = chosen_reduce
