@@ -60,7 +60,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C5"])
+    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C5", "C3H"])
+    ap.add_argument("--no-heavy", action="store_true",
+                    help="skip the second measurement (C3 geometry at SURVEY 8d's literal splat scale, 'C3H')")
     ap.add_argument("--n", type=int, default=None)
     ap.add_argument("--d", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -69,9 +71,10 @@ def parse():
     ap.add_argument("--grad-reduce", default="rs_ag", choices=["rs_ag", "allreduce"],
                     help="by-view step: bucketed reduce-scatter + all-gather (default) or plain all-reduce")
     ap.add_argument("--raster-flags", type=int, default=0)
-    ap.add_argument("--parallel", default="auto", choices=["auto", "view", "channel"],
-                    help="N>1: one view per GPU + gradient exchange (view), every GPU renders all N views for its "
-                         "channel shard with no exchange (channel), or whichever two probe steps show faster (auto)")
+    ap.add_argument("--parallel", default="view", choices=["auto", "view", "channel"],
+                    help="N>1: one view per GPU + gradient exchange (view: north_star's decomposition, the default), "
+                         "every GPU renders all N views for its channel shard with no exchange (channel), or whichever "
+                         "two probe steps show faster (auto)")
     return ap.parse_args()
 
 
@@ -123,11 +126,32 @@ def cpu_baseline(pc, cam, d, width, height, target_s):
         n_s = len(range(0, n_tiles, step))
     t_view = t_bin + t_s * (n_tiles / n_s)
     return {
-        "value": 1.0 / t_view, "unit": "views/s", "cores": orc.max_threads(), "kind": "port",
+        "value": 1.0 / t_view, "unit": "views/s", "cores": orc.max_threads(), "host": host_cpu(), "kind": "port",
         "sample": (f"oracle/gags_oracle.c (OpenMP, fp32): projection+binning of the full view ({t_bin:.2f} s) + raster "
                    f"fwd + colours-only bwd on every {step}-th tile ({n_s} of {n_tiles} tiles, {t_s:.2f} s), "
                    f"raster time scaled by {n_tiles / n_s:.1f}x"),
     }
+
+
+def host_cpu():
+    """Sockets x cores x threads and the model name of the host (cpu_baseline.cores = OpenMP threads used)."""
+    try:
+        phys, cores, model, logical = set(), set(), "", 0
+        pid = cid = None
+        for ln in open("/proc/cpuinfo"):
+            k, _, v = ln.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "processor":
+                logical += 1
+            elif k == "model name":
+                model = v
+            elif k == "physical id":
+                pid = v; phys.add(v)
+            elif k == "core id":
+                cid = v; cores.add((pid, cid))
+        return {"model": model, "sockets": len(phys) or 1, "physical_cores": len(cores) or logical, "hw_threads": logical}
+    except OSError:
+        return None
 
 
 # kernels behind each bracketed stage, by their short rocprofv3 names (tools/pmc_summary.py)
@@ -178,6 +202,7 @@ def main():
     if args.d:
         cfg["d"] = args.d
     n, d, width, height = cfg["n"], cfg["d"], cfg["width"], cfg["height"]
+    scale0 = cfg.get("scale0", syn.SCALE0)
 
     from gags_amd.dist import channel_shard
 
@@ -185,7 +210,7 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
-    def build(mode, grad_reduce=None):
+    def build(mode, grad_reduce=None, scale0=scale0):
         """(step function, model, camera of the last view, local feature width) of one decomposition (gags_amd/dist.py).
         view   : Gaussians + features replicated (same seed on every rank), one yawed view per rank (C4's cameras),
                  reduce-scatter + all-gather (or all-reduce) of the feature gradient at step end.
@@ -199,7 +224,7 @@ def main():
         else:
             dl = d
             views = [first + rank] if world > 1 else [None]
-        pc_ = syn.make_model(n, dl, width, height, seed=0, device=dev, gen_device=dev)
+        pc_ = syn.make_model(n, dl, width, height, seed=0, device=dev, gen_device=dev, scale0=scale0)
         pc_.training_setup()
         cams = [syn.make_camera(width, height, view=(v % 8) if v is not None else None, device=dev) for v in views]
         G_ = syn.make_cotangent(dl, height, width, seed=1, device=dev)  # [D,H,W] view of [H,W,D] memory
@@ -351,6 +376,10 @@ def main():
                                    + (f", every GPU renders all {world} views for its {d_local} channels"
                                       if mode == "channel" else ", 1 view/GPU/step"),
                        "n_gaussians": n, "width": width, "height": height, "feature_dim": d,
+                       "splat_scale0": scale0, "splat_scale_note": ("SURVEY 8d literal 0.004 z_mean" if scale0 == syn.SCALE0_SURVEY
+                                                                     else "0.0009 z_mean: meets SURVEY 8d's stated median radius / I~5N; "
+                                                                          "the literal 0.004 constant is reported as heavy_workload"),
+                       "isects_per_visible": n_isects / max(n_visible, 1),
                        "visible": n_visible, "n_isects": n_isects, "pairs_evaluated": q_eval,
                        "pairs_blended": q_blend, "bwd_rows": rows,
                        "parallelism": (f"channel-shard{world} (no data-path collective)" if mode == "channel"
@@ -375,6 +404,27 @@ def main():
                                      "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pc, cam, d, width, height, args.cpu_seconds)
+        if world == 1 and args.config == "C3" and not (args.no_heavy or args.n or args.d):
+            # second reading of SURVEY 8d (gags_amd/synthetic.py): same N / resolution / D, ~4.4x larger splats
+            del step, pc
+            torch.cuda.empty_cache()
+            hstep, hpc, _, _ = build("view", scale0=syn.SCALE0_SURVEY)
+            for _ in range(2):
+                hp = hstep()
+            torch.cuda.synchronize()
+            hi = hp["info"]["n_isects"]
+            hv = int((hp["radii"] > 0).sum().item())
+            del hp
+            hsteps = max(3, min(args.steps, 10))
+            t0 = time.perf_counter()
+            for _ in range(hsteps):
+                hstep()
+            torch.cuda.synchronize()
+            hdt = time.perf_counter() - t0
+            line["heavy_workload"] = {
+                "workload": f"C3H: {n} Gaussians, {width}x{height}, D={d}, splat scale 0.004 z_mean (SURVEY 8d literal)",
+                "value": hsteps / hdt, "unit": "views/s", "ms_per_step": 1e3 * hdt / hsteps, "steps": hsteps,
+                "n_isects": hi, "visible": hv, "isects_per_visible": hi / max(hv, 1)}
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

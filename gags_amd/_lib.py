@@ -16,7 +16,8 @@ import torch  # noqa: F401  (load order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libgags_hip.so")
+# GAGS_HIP_LIBRARY: diagnostics only (tools/rows_trace.py loads the `make trace` build); the default is the product .so
+LIB_PATH = os.environ.get("GAGS_HIP_LIBRARY") or os.path.join(CSRC, "libgags_hip.so")
 
 _vp, _i32, _i64, _f32, _f64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 

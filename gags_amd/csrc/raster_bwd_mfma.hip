@@ -63,7 +63,14 @@ __device__ __forceinline__ void tile_mfma(f32x16 (&acc)[NBB], const float (&A)[1
 // One wave per (tile, 8x8 block, channel slice).  K = the block's 64 pixels in the order of the weight rows
 // raster_weights wrote (32 (upper, lower) pairs): K-step t pairs element t of the row's first half (k = 0)
 // with element t of its second half (k = 1).  The cotangent slab (64 px x 128 ch) sits in 128 VGPRs as B operands.
-__device__ long long g_rows_trace[8 * 262144];  // TRACE builds only: per-wave timeline (tools/rows_trace.py)
+// The per-wave timeline buffer exists only in the diagnostics build (`make trace` -> libgags_hip_trace.so,
+// tools/rows_trace.py); the product library has no global mutable state (include/gags_raster.h).
+#ifdef GAGS_TRACE_BUILD
+__device__ long long g_rows_trace[8 * 262144];
+#define GAGS_TRACE_STORE(i, v) (g_rows_trace[8 * (size_t)blockIdx.x + (i)] = (v))
+#else
+#define GAGS_TRACE_STORE(i, v) ((void)(v))
+#endif
 
 // NBR = channel tiles of 32 per wave: 4 (D % 128 == 0; two waves per SIMD), 2 (D % 64 == 0) or 1 (any other
 // D % 4 == 0: the last slice may be ragged).
@@ -173,12 +180,11 @@ __global__ __launch_bounds__(64, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void raste
     }
     if (TRACE && lane == 0 && blockIdx.x < 262144) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        long long *tr = g_rows_trace + 8 * (size_t)blockIdx.x;
-        tr[0] = tr0; tr[1] = __builtin_readcyclecounter();
-        tr[2] = ((long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32) |  // XCC_ID, HW_ID
-                (unsigned)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
-        tr[3] = ((long long)cnt << 32) | (unsigned)(wall_clock64() - trr);  // wave duration, 100 MHz ticks
-        tr[4] = phA; tr[5] = phM; tr[6] = phS; tr[7] = tr0 - tr_entry;
+        GAGS_TRACE_STORE(0, tr0); GAGS_TRACE_STORE(1, (long long)__builtin_readcyclecounter());
+        GAGS_TRACE_STORE(2, ((long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32) |  // XCC_ID, HW_ID
+                                (unsigned)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)));
+        GAGS_TRACE_STORE(3, ((long long)cnt << 32) | (unsigned)(wall_clock64() - trr));  // wave duration, 100 MHz ticks
+        GAGS_TRACE_STORE(4, phA); GAGS_TRACE_STORE(5, phM); GAGS_TRACE_STORE(6, phS); GAGS_TRACE_STORE(7, tr0 - tr_entry);
     }
 }
 
@@ -376,8 +382,11 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
     hipLaunchKernelGGL((raster_bwd_rows<NBR, TRACE>), grid, dim3(64), 0, st, d, width, height, tile_w, n_tiles, n_slices, \
                        v_out, offsets, n_isects, blk_rows, row_end, wt, gid_s, prow, key, idx)
             if (nbr == 4) {
+#ifdef GAGS_TRACE_BUILD
                 if (stage_flags & 16) GAGS_ROWS_LAUNCH(4, true);  // diagnostics: per-wave timeline (tools/rows_trace.py)
-                else GAGS_ROWS_LAUNCH(4, false);
+                else
+#endif
+                    GAGS_ROWS_LAUNCH(4, false);
             } else if (nbr == 2) {
                 GAGS_ROWS_LAUNCH(2, false);
             } else {
@@ -424,8 +433,13 @@ int gags_raster_bwd_atomic_launch(int d, int width, int height, const void *pack
 // diagnostics: copy the traced rows kernel's per-wave records (8 int64 per workgroup) to the host
 extern "C" int gags_debug_rows_trace(long long *dst, int n_workgroups)
 {
+#ifdef GAGS_TRACE_BUILD
     if (n_workgroups < 0 || n_workgroups > 262144) return GAGS_EINVAL;
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_rows_trace), sizeof(long long) * 8 * (size_t)n_workgroups) == hipSuccess
                ? GAGS_OK
                : GAGS_ELAUNCH;
+#else
+    (void)dst; (void)n_workgroups;
+    return GAGS_ENODEV;  // the product library carries no trace buffer: build `make trace`
+#endif
 }

@@ -62,16 +62,25 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_spine(int nb, int32_t *__re
                                                            int32_t *__restrict__ total_out)
 {
     __shared__ int smem[4];
+    __shared__ double wide[SCAN_THREADS];
     int carry = 0;
+    double dsum = 0.0;  // the same total in a type that cannot wrap: an int32 overflow is reported, not returned
     for (int base = 0; base < nb; base += SCAN_THREADS) {
         const int i = base + threadIdx.x;
         const int v = (i < nb) ? block_sums[i] : 0;
+        dsum += (double)v;
         int total;
         const int incl = block_incl_scan(v, total, smem);
         if (i < nb) block_sums[i] = carry + incl - v;
         carry += total;
     }
-    if (threadIdx.x == 0 && total_out) total_out[0] = carry;
+    wide[threadIdx.x] = dsum;
+    __syncthreads();
+    if (threadIdx.x == 0 && total_out) {
+        double t = 0.0;
+        for (int k = 0; k < SCAN_THREADS; ++k) t += wide[k];
+        total_out[0] = (t > 2147483647.0) ? -1 : carry;  // -1: the caller must refuse (rasterization.py)
+    }
 }
 
 template <bool EXCLUSIVE>

@@ -25,6 +25,8 @@ from . import _lib, profiler
 from ._lib import check, ptr
 
 TILE = 16
+MAX_ISECTS = 1 << 27  # limit of the C ABI (int32 slot indices: 4 slots per intersection)
+SCRATCH_CHECK_BYTES = 8 << 30  # above this the split forward first checks that its scratch fits in free memory
 
 
 def _stream():
@@ -147,6 +149,9 @@ def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height, conics=
     host = ctypes.c_int32(0)
     check(lib.gags_read_i32(ptr(total), ctypes.byref(host), st), "gags_read_i32")
     n_isects = int(host.value)
+    if n_isects < 0 or n_isects >= MAX_ISECTS:  # the int32 prefix sum wrapped, or the slot space would
+        raise RuntimeError(f"gags_amd.rasterization: {n_isects if n_isects >= 0 else '> 2^31'} tile intersections in one "
+                           f"view; the kernels index at most 2^27 = {MAX_ISECTS} (INTEGRATION.md, memory model)")
     offsets = torch.empty(tile_h, tile_w, dtype=torch.int32, device=dev)
     ids = torch.empty(max(n_isects, 1), dtype=torch.int64, device=dev)
     flat = torch.empty(max(n_isects, 1), dtype=torch.int32, device=dev)
@@ -194,11 +199,14 @@ class _Rasterize(torch.autograd.Function):
         out = torch.empty(height, width, d, device=dev)
         alphas = torch.empty(height, width, device=dev)
         last_ids = torch.empty(height, width, dtype=torch.int32, device=dev)
-        split = packed is not None and not (flags & (_lib.GAGS_FWD_NO_MFMA | _lib.GAGS_FWD_FUSED))
+        split = n > 0 and packed is not None and not (flags & (_lib.GAGS_FWD_NO_MFMA | _lib.GAGS_FWD_FUSED))
         scratch = blk_rows = None
         nbytes = 0
         if split:
             nbytes = lib.gags_raster_fwd_scratch_bytes(n_isects, width, height)
+            if nbytes > SCRATCH_CHECK_BYTES and nbytes > 0.8 * torch.cuda.mem_get_info(dev)[0]:
+                split, nbytes = False, 0  # slot space (1 KB per intersection) does not fit: scratch-free kernels
+        if split:
             scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             blk_rows = torch.empty(offsets.numel() * 4, dtype=torch.int32, device=dev)  # per 8x8 pixel block
         with profiler.stage("raster_fwd"):
@@ -318,6 +326,12 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
     if sh_degree is not None:
         if colors.dim() != 3 or colors.shape[2] != 3:
             raise ValueError("SH colours must be [N,K,3]")
+        if means.requires_grad:
+            # gsplat propagates d colour / d view direction into means; this build treats directions as constants
+            # (the reference only reaches the SH branch with frozen geometry or under no_grad): refuse, do not
+            # return a silently incomplete gradient
+            raise NotImplementedError("sh_degree with means.requires_grad: the view-direction gradient of the SH "
+                                      "colours is not implemented; detach means or pass explicit colours")
         campos = torch.inverse(viewmat.double())[:3, 3].float()
         cols = _SH.apply(colors, means, campos, radii, int(sh_degree))
     else:

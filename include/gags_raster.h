@@ -62,7 +62,8 @@ int gags_project_fwd(int n, const float *means, const float *quats, const float 
                      int32_t *tiles_per_gauss, void *stream);
 
 /* K5: inclusive prefix sum of tiles_per_gauss -> cum[N]; the grand total (n_isects) is
- * also written to total[0].  scratch: gags_scan_scratch_bytes(n) bytes. */
+ * also written to total[0], or -1 when it does not fit an int32 (the caller must refuse the view).
+ * scratch: gags_scan_scratch_bytes(n) bytes. */
 int64_t gags_scan_scratch_bytes(int n);
 int gags_cumsum_i32(int n, const int32_t *in, int32_t *cum, int32_t *total,
                     void *scratch, int64_t scratch_bytes, void *stream);
@@ -147,7 +148,8 @@ int gags_raster_bwd(int d, int width, int height, const float *means2d, const fl
  * are stored as rows, sorted by Gaussian and reduced; v_colors[N,D] is written in full (no
  * zero-fill needed).  scratch: gags_bwd_staged_scratch_bytes(rows, n, d) bytes.
  * stage: low 4 bits 0 = all, 1..3 = rows, sort, reduce (per-kernel timing); bit 4 = run the TRACED
- * build of the rows kernel (same results; per-wave timeline for gags_debug_rows_trace).
+ * rows kernel (same results; per-wave timeline for gags_debug_rows_trace) -- only in the diagnostics
+ * build `make -C gags_amd/csrc trace`; the product library ignores the bit.
  * Returns 1 when D is not eligible. */
 int64_t gags_bwd_staged_scratch_bytes(int64_t rows, int n, int d);
 int gags_raster_bwd_colors_staged(int d, int n, int width, int height, const int32_t *isect_offsets,
@@ -165,7 +167,8 @@ int gags_raster_stats(int width, int height, const float *means2d, const float *
 
 /* Diagnostics: copy the timeline left by the traced rows kernel (stage bit 4) to the host: 8 int64 per
  * workgroup {t_start, t_end, xcc<<32|hw_id, slots<<32|duration in 10 ns, load wait, MFMA burst, stores,
- * setup} in shader-counter ticks.  n_workgroups <= 262144.  tools/rows_trace.py. */
+ * setup} in shader-counter ticks.  n_workgroups <= 262144.  tools/rows_trace.py.  The buffer exists only in
+ * the diagnostics build (libgags_hip_trace.so); the product library returns GAGS_ENODEV. */
 int gags_debug_rows_trace(long long *dst_host, int n_workgroups);
 
 /* K2: projection backward: chain rule of gags_project_fwd for Gaussians with radii>0.

@@ -137,7 +137,12 @@ def test_backward_flavours_agree_and_staged_is_deterministic(oracle):
     assert np.all(g["block"][culled] == 0)  # v_colors written in full
 
 
-@pytest.mark.parametrize("n,w,h,d,seed,view", [(2500, 128, 96, 16, 7, 3), (2000, 100, 70, 3, 8, None)])
+@pytest.mark.parametrize("n,w,h,d,seed,view", [
+    (2500, 128, 96, 16, 7, 3), (2000, 100, 70, 3, 8, None),
+    (2000, 112, 80, 48, 9, 5),    # two channel chunks, the second one ragged: per-chunk bg dot, v_alpha on chunk 0 only
+    (2000, 112, 80, 64, 10, None),
+    (1500, 96, 64, 128, 11, 2),   # C2 width with every geometry gradient
+])
 def test_full_backward(oracle, n, w, h, d, seed, view):
     s = scene_arrays(n, d, w, h, seed=seed, view=view, scale_mult=5.0)
     bg = np.full(d, 0.25, np.float32)
@@ -178,6 +183,60 @@ def test_render_modes_and_sh(oracle):
     out, alpha, info, _ = _run_gpu(s, w, h, s["sh"], bg, sh_degree=3)
     np.testing.assert_array_equal(alpha, o_alpha)
     assert rel_l2(out, o_out) <= 1e-6
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2])
+def test_sh_low_degrees(oracle, deg):
+    """active_sh_degree < 3 (the reference raises it every 1000 iterations: train.py oneupSHdegree): the first
+    (deg+1)^2 coefficients are used, the rest ignored."""
+    n, w, h = 2000, 128, 96
+    s = scene_arrays(n, 3, w, h, seed=20 + deg, view=deg, scale_mult=4.0)
+    bg = np.array([0.0, 0.5, 1.0], np.float32)
+    o_out, o_alpha, _ = oracle.rasterization(s["means"], s["quats"], s["scales"], s["opacities"], s["sh"], s["viewmat"],
+                                             s["K"], bg, w, h, sh_degree=deg)
+    out, alpha, _, _ = _run_gpu(s, w, h, s["sh"], bg, sh_degree=deg)
+    np.testing.assert_array_equal(alpha, o_alpha)
+    assert rel_l2(out, o_out) <= 1e-6
+
+
+def test_sh_with_trainable_means_is_refused():
+    from gags_amd.rasterization import rasterization
+    s = scene_arrays(64, 3, 32, 32, seed=1)
+    means = to_dev(s["means"]).requires_grad_(True)
+    with pytest.raises(NotImplementedError, match="view-direction"):
+        rasterization(means, to_dev(s["quats"]), to_dev(s["scales"]), to_dev(s["opacities"]), to_dev(s["sh"]),
+                      to_dev(s["viewmat"])[None], to_dev(s["K"])[None], 32, 32, sh_degree=3)
+
+
+def test_expected_depth_with_gradient(oracle):
+    """RGB+ED when the output requires grad (the normalisation then runs through autograd, not in place)."""
+    n, w, h = 1500, 96, 64
+    s = scene_arrays(n, 3, w, h, seed=17, view=3, scale_mult=5.0)
+    bg = np.array([0.1, 0.2, 0.3], np.float32)
+    o_out, _, _ = oracle.rasterization(s["means"], s["quats"], s["scales"], s["opacities"], s["colors"], s["viewmat"],
+                                       s["K"], bg, w, h, render_mode="RGB+ED")
+    v_out = np.zeros((h, w, 4), np.float32)
+    v_out[..., :3] = np.random.default_rng(2).standard_normal((h, w, 3))
+    out, _, _, grads = _run_gpu(s, w, h, s["colors"], bg, render_mode="RGB+ED", v_out=v_out)
+    np.testing.assert_array_equal(out[..., :3], o_out[..., :3])
+    np.testing.assert_allclose(out[..., 3], o_out[..., 3], rtol=1e-6, atol=0)
+    assert np.isfinite(grads["colors"]).all() and np.abs(grads["colors"]).max() > 0
+
+
+def test_no_gaussians_at_all():
+    """N == 0 with colours requiring grad: background render, empty gradient, no scratch sized from garbage."""
+    from gags_amd.rasterization import rasterization
+    dev = torch.device("cuda", 0)
+    d, w, h = 32, 48, 32
+    cols = torch.zeros(0, d, device=dev, requires_grad=True)
+    bg = torch.full((1, d), 0.25, device=dev)
+    out, alphas, info = rasterization(torch.zeros(0, 3, device=dev), torch.zeros(0, 4, device=dev),
+                                      torch.zeros(0, 3, device=dev), torch.zeros(0, device=dev), cols,
+                                      torch.eye(4, device=dev)[None], torch.eye(3, device=dev)[None], w, h, backgrounds=bg)
+    assert info["n_isects"] == 0
+    assert torch.equal(out[0], bg.expand(h, w, d)) and float(alphas.abs().max()) == 0.0
+    out.sum().backward()
+    assert cols.grad.shape == (0, d)
 
 
 def test_empty_and_culled(oracle):

@@ -7,7 +7,10 @@ import ctypes
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+# the trace buffer lives only in the diagnostics build (make -C gags_amd/csrc trace)
+os.environ.setdefault("GAGS_HIP_LIBRARY", os.path.join(ROOT, "gags_amd", "csrc", "libgags_hip_trace.so"))
 import numpy as np
 import torch
 from gags_amd import _lib, synthetic as syn
