@@ -79,7 +79,7 @@ def _full_size_case(oracle, n, w, h, d, seed, backward=True, scale0=None, bgv=0.
     np.testing.assert_array_equal(info["conics"][0].detach().cpu().numpy(), oi["conics"])
     np.testing.assert_array_equal(info["depths"][0].detach().cpu().numpy(), oi["depths"])
     np.testing.assert_array_equal(info["last_ids"].cpu().numpy(), oi["last_ids"])
-    np.testing.assert_array_equal(alphas[0, ..., 0].cpu().numpy(), o_alpha)
+    np.testing.assert_array_equal(alphas[0, ..., 0].detach().cpu().numpy(), o_alpha)
     assert _big_equal(out[0].detach(), o_out), "forward render differs from the oracle"  # bit-exact forward
     stats = dict(n_isects=oi["n_isects"], visible=int((oi["radii"] > 0).sum()), n_blend=oi["n_blend"])
     if not backward:

@@ -234,7 +234,7 @@ def test_no_gaussians_at_all():
                                       torch.zeros(0, 3, device=dev), torch.zeros(0, device=dev), cols,
                                       torch.eye(4, device=dev)[None], torch.eye(3, device=dev)[None], w, h, backgrounds=bg)
     assert info["n_isects"] == 0
-    assert torch.equal(out[0], bg.expand(h, w, d)) and float(alphas.abs().max()) == 0.0
+    assert torch.equal(out[0], bg.expand(h, w, d)) and float(alphas.detach().abs().max()) == 0.0
     out.sum().backward()
     assert cols.grad.shape == (0, d)
 
