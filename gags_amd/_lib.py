@@ -16,8 +16,7 @@ import torch  # noqa: F401  (load order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-# GAGS_HIP_LIBRARY: diagnostics only (tools/rows_trace.py loads the `make trace` build); the default is the product .so
-LIB_PATH = os.environ.get("GAGS_HIP_LIBRARY") or os.path.join(CSRC, "libgags_hip.so")
+LIB_PATH = os.path.join(CSRC, "libgags_hip.so")
 
 _vp, _i32, _i64, _f32, _f64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 
@@ -43,11 +42,13 @@ SIGNATURES = {
                                _vp, _i64, _vp, _i32, _vp]),
     "gags_raster_bwd": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp, _vp, _i32, _vp]),
+    "gags_bwd_rowmap_scratch_bytes": (_i64, [_i64]),
+    "gags_bwd_rowmap_elems": (_i64, [_i64, _i32, _i32]),
+    "gags_bwd_rowmap": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
     "gags_bwd_staged_scratch_bytes": (_i64, [_i64, _i32, _i32]),
     "gags_raster_bwd_colors_staged": (_i32, [_i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
                                              _i64, _vp, _i32, _vp]),
     "gags_raster_stats": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
-    "gags_debug_rows_trace": (_i32, [_vp, _i32]),
     "gags_project_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _vp, _vp]),
     "gags_sh_fwd": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -62,7 +63,6 @@ GAGS_BWD_COLORS_ONLY = 1
 GAGS_FWD_NO_MFMA = 2
 GAGS_BWD_ATOMIC = 4  # python-side: use the atomic colours-only backward instead of the staged one
 GAGS_FWD_FUSED = 8  # python-side: single-kernel matrix-core forward (no scratch) instead of weights + features
-GAGS_BWD_TRACE = 16  # staged backward: traced build of the rows kernel (tools/rows_trace.py)
 
 _lib = None
 

@@ -2,6 +2,7 @@
 // (narrow / odd D, full geometry gradients) and the matrix-core kernels (D >= 16, D % 4 == 0;
 // the single-kernel fallbacks: D % 32 == 0).
 #include "common.h"
+#include "scan.h"
 
 // raster_valu.hip
 int gags_raster_fwd_valu(int d, int width, int height, const float *means2d, const float *conics,
@@ -17,8 +18,9 @@ int gags_raster_bwd_valu(int d, int width, int height, const float *means2d, con
 int gags_pack_isects_launch(int n, int n_isects, const int32_t *flat, const float *means2d, const float *conics,
                             const float *opacities, const int32_t *radii, void *grec, void *packed, hipStream_t st);
 int gags_raster_weights_launch(int width, int height, int n_gauss, const void *packed, const int32_t *offsets,
-                               const int32_t *flat, int n_isects, float *wt, int32_t *gid_s, int32_t *blk_rows,
-                               float *Tbuf, float *alphas, int32_t *last_ids, hipStream_t st);
+                               const int32_t *flat, int n_isects, float *wt, int32_t *gid_s, int32_t *sidx_s,
+                               int32_t *hit, int32_t *blk_rows, float *Tbuf, float *alphas, int32_t *last_ids,
+                               hipStream_t st);
 // raster_fwd_mfma.hip
 int gags_raster_fwd_feat_launch(int d, int width, int height, int n_gauss, const float *colors,
                                 const float *backgrounds, const int32_t *offsets, int n_isects,
@@ -30,9 +32,11 @@ int gags_raster_fwd_fused_launch(int d, int width, int height, const void *packe
 // raster_bwd_mfma.hip
 int64_t gags_bwd_staged_scratch_bytes_impl(int64_t rows, int n_gauss, int d);
 int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, const int32_t *offsets, int n_isects,
-                                  const float *v_out, const int32_t *blk_rows, const int32_t *row_end, int64_t rows,
-                                  const float *wt, const int32_t *gid_s, void *scratch, int64_t scratch_bytes,
-                                  float *v_colors, int stage, hipStream_t st);
+                                  const float *v_out, const int32_t *blk_rows, const int32_t *trow, int64_t rows,
+                                  const float *wt, const int32_t *gid_s, const int32_t *trow_s, void *scratch,
+                                  int64_t scratch_bytes, float *v_colors, int stage, hipStream_t st);
+int gags_bwd_slot_rows_launch(int width, int height, int n_isects, const int32_t *offsets, const int32_t *blk_rows,
+                              const int32_t *sidx_s, const int32_t *trow, int32_t *trow_s, hipStream_t st);
 int gags_raster_bwd_atomic_launch(int d, int width, int height, const void *packed, const int32_t *offsets,
                                   const int32_t *flat, int n_isects, const float *v_out, float *v_colors,
                                   hipStream_t st);
@@ -40,7 +44,7 @@ int gags_raster_bwd_atomic_launch(int d, int width, int height, const void *pack
 namespace {
 inline int64_t al256(int64_t x) { return (x + 255) / 256 * 256; }
 struct FwdScratch {
-    int64_t wt, gid, tbuf, total;
+    int64_t wt, gid, sidx, hit, tbuf, total;
 };
 // slot space: GAGS_BLOCKS_PER_TILE * (n_isects + n_tiles) slots of 64 weights (+ slack so that the backward may
 // read a whole 32-slot tile)
@@ -52,6 +56,8 @@ inline FwdScratch fwd_layout(int64_t n_isects, int width, int height)
     int64_t o = 0;
     L.wt = o; o += al256(slots * 256);
     L.gid = o; o += al256(slots * 4);
+    L.sidx = o; o += al256(slots * 4);
+    L.hit = o; o += al256((n_isects + 1) * 4);
     L.tbuf = o; o += al256((int64_t)width * height * 4);
     L.total = o;
     return L;
@@ -96,7 +102,8 @@ extern "C" int gags_raster_fwd(int d, int n, int width, int height, const float 
             int32_t *gid_s = (int32_t *)(sb + L.gid);
             float *tbuf = (float *)(sb + L.tbuf);
             int rc = gags_raster_weights_launch(width, height, n, packed, isect_offsets, flatten_ids, (int)n_isects, wt,
-                                                gid_s, blk_rows, tbuf, render_alphas, last_ids, st);
+                                                gid_s, (int32_t *)(sb + L.sidx), (int32_t *)(sb + L.hit), blk_rows, tbuf,
+                                                render_alphas, last_ids, st);
             if (rc != GAGS_OK) return rc;
             return gags_raster_fwd_feat_launch(d, width, height, n, colors, backgrounds, isect_offsets, (int)n_isects,
                                                blk_rows, wt, gid_s, tbuf, render_colors, st);
@@ -139,9 +146,55 @@ extern "C" int64_t gags_bwd_staged_scratch_bytes(int64_t rows, int n, int d)
     return gags_bwd_staged_scratch_bytes_impl(rows, n, d);
 }
 
+namespace {
+// rowmap = trow[n_isects + 1] (exclusive prefix sum of the forward's hit flags) followed, 256-B aligned, by
+// trow_s[slots] (tile row of every K-step slot of the forward's slot space)
+inline int64_t rowmap_slot_off(int64_t n_isects) { return al256((n_isects + 1) * 4) / 4; }
+inline int64_t slot_count(int64_t n_isects, int width, int height)
+{
+    const int64_t tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
+    return GAGS_BLOCKS_PER_TILE * (n_isects + tile_w * tile_h) + 64;
+}
+}  // namespace
+
+extern "C" int64_t gags_bwd_rowmap_elems(int64_t n_isects, int width, int height)
+{
+    if (n_isects < 0 || width <= 0 || height <= 0) return 0;
+    return rowmap_slot_off(n_isects) + slot_count(n_isects, width, height);
+}
+
+extern "C" int64_t gags_bwd_rowmap_scratch_bytes(int64_t n_isects)
+{
+    return n_isects < 0 ? 0 : gags_scan::scratch_bytes(n_isects > 0 ? n_isects : 1);
+}
+
+extern "C" int gags_bwd_rowmap(int64_t n_isects, int width, int height, const int32_t *isect_offsets,
+                               const int32_t *blk_rows, const void *fwd_scratch, int64_t fwd_scratch_bytes,
+                               int32_t *rowmap, int64_t rowmap_elems, int32_t *total, void *scratch,
+                               int64_t scratch_bytes, void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (n_isects < 0 || n_isects >= (1ll << 27) || width <= 0 || height <= 0 || !fwd_scratch || !rowmap || !total ||
+        !isect_offsets || !blk_rows)
+        return GAGS_EINVAL;
+    if (rowmap_elems < gags_bwd_rowmap_elems(n_isects, width, height)) return GAGS_ESCRATCH;
+    const FwdScratch L = fwd_layout(n_isects, width, height);
+    if (fwd_scratch_bytes < L.total) return GAGS_ESCRATCH;
+    hipStream_t st = (hipStream_t)stream;
+    int32_t *trow = rowmap;
+    if (hipMemsetAsync(trow, 0, sizeof(int32_t), st) != hipSuccess) return GAGS_ELAUNCH;
+    if (n_isects == 0) return hipMemsetAsync(total, 0, sizeof(int32_t), st) == hipSuccess ? GAGS_OK : GAGS_ELAUNCH;
+    if (!scratch || scratch_bytes < gags_scan::scratch_bytes(n_isects)) return GAGS_ESCRATCH;
+    const char *fs = (const char *)fwd_scratch;
+    gags_scan::launch<false>((int)n_isects, (const int32_t *)(fs + L.hit), trow + 1, total, (int32_t *)scratch, st);
+    GAGS_CHECK_LAUNCH();
+    return gags_bwd_slot_rows_launch(width, height, (int)n_isects, isect_offsets, blk_rows,
+                                     (const int32_t *)(fs + L.sidx), trow, rowmap + rowmap_slot_off(n_isects), st);
+}
+
 extern "C" int gags_raster_bwd_colors_staged(int d, int n, int width, int height, const int32_t *isect_offsets,
                                              int64_t n_isects, const float *v_render_colors, const int32_t *blk_rows,
-                                             const int32_t *row_end, int64_t rows, const void *fwd_scratch,
+                                             const int32_t *rowmap, int64_t rows, const void *fwd_scratch,
                                              int64_t fwd_scratch_bytes, void *scratch, int64_t scratch_bytes,
                                              float *v_colors, int stage, void *stream)
 {
@@ -149,12 +202,13 @@ extern "C" int gags_raster_bwd_colors_staged(int d, int n, int width, int height
         rows >= (1ll << 31) || stage < 0 || (stage & 15) > 3)
         return GAGS_EINVAL;
     if (n == 0) return GAGS_OK;
-    if (!isect_offsets || !blk_rows || !row_end || !fwd_scratch || !scratch || !v_colors || !v_render_colors)
+    if (!isect_offsets || !blk_rows || !rowmap || !fwd_scratch || !scratch || !v_colors || !v_render_colors)
         return GAGS_EINVAL;
     const FwdScratch L = fwd_layout(n_isects, width, height);
     if (fwd_scratch_bytes < L.total) return GAGS_ESCRATCH;
     const char *fs = (const char *)fwd_scratch;
     return gags_raster_bwd_staged_launch(d, width, height, n, isect_offsets, (int)n_isects, v_render_colors, blk_rows,
-                                         row_end, rows, (const float *)(fs + L.wt), (const int32_t *)(fs + L.gid),
-                                         scratch, scratch_bytes, v_colors, stage, (hipStream_t)stream);
+                                         rowmap, rows, (const float *)(fs + L.wt), (const int32_t *)(fs + L.gid),
+                                         rowmap + rowmap_slot_off(n_isects), scratch, scratch_bytes, v_colors, stage,
+                                         (hipStream_t)stream);
 }

@@ -60,131 +60,207 @@ __device__ __forceinline__ void tile_mfma(f32x16 (&acc)[NBB], const float (&A)[1
 }
 
 // ---- staged: rows ------------------------------------------------------------------------------------
-// One wave per (tile, 8x8 block, channel slice).  K = the block's 64 pixels in the order of the weight rows
-// raster_weights wrote (32 (upper, lower) pairs): K-step t pairs element t of the row's first half (k = 0)
-// with element t of its second half (k = 1).  The cotangent slab (64 px x 128 ch) sits in 128 VGPRs as B operands.
-// The per-wave timeline buffer exists only in the diagnostics build (`make trace` -> libgags_hip_trace.so,
-// tools/rows_trace.py); the product library has no global mutable state (include/gags_raster.h).
-#ifdef GAGS_TRACE_BUILD
-__device__ long long g_rows_trace[8 * 262144];
-#define GAGS_TRACE_STORE(i, v) (g_rows_trace[8 * (size_t)blockIdx.x + (i)] = (v))
-#else
-#define GAGS_TRACE_STORE(i, v) ((void)(v))
-#endif
+// One workgroup per (tile, channel slice); wave b of its four owns the tile's 8x8 pixel block b.  K = the block's 64
+// pixels in the order of the weight rows raster_weights wrote (32 (upper, lower) pairs): K-step t pairs element t of
+// the row's first half (k = 0) with element t of its second half (k = 1).  The wave's cotangent slab (64 px x 32*NBR
+// channels) sits in 32*NBR VGPRs as B operands for the whole tile.
+//
+// A Gaussian that blends into several blocks of the tile leaves ONE gradient row for the tile, not one per block:
+// the tile's rows -- numbered by trow[] = exclusive prefix sum of the forward's hit[] flags, i.e. in sorted order --
+// are produced in chunks.  A chunk [r0, r1) ends where a block would need a 33rd slot (its run of slots inside the
+// chunk is one 32-row MFMA tile) or after CMAX rows.  Per chunk every wave multiplies its run (the 128-MFMA burst
+// of one weight tile), parks the partial rows in LDS, and after a barrier the workgroup adds the up to four partial
+// rows of every tile row in a fixed order (block 0..3: bit-reproducible) and stores the merged row once, 128 B
+// per lane-quad.  Compared with one row per (block, Gaussian) this halves the rows written, sorted and reduced
+// (C3: 4.44 M -> ~2 M rows of 2 KB) for ~10 % more MFMA issue (runs are on average 27 of 32 slots long).
+constexpr int CMAX = 64;  // merged rows per chunk (bounds pos[] and the merge loop)
 
-// NBR = channel tiles of 32 per wave: 4 (D % 128 == 0; two waves per SIMD), 2 (D % 64 == 0) or 1 (any other
-// D % 4 == 0: the last slice may be ragged).
-template <int NBR, bool TRACE>
-__global__ __launch_bounds__(64, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void raster_bwd_rows(
+template <int NBR>
+__global__ __launch_bounds__(256, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void raster_bwd_rows(
     int d, int width, int height, int tile_w, int n_tiles, int n_slices, const float *__restrict__ v_render_colors,
     const int32_t *__restrict__ offsets, int n_isects, const int32_t *__restrict__ blk_rows,
-    const int32_t *__restrict__ row_end, const float *__restrict__ wt, const int32_t *__restrict__ gid_s,
-    float *__restrict__ prow, uint32_t *__restrict__ row_key, int32_t *__restrict__ row_idx)
+    const int32_t *__restrict__ trow, const float *__restrict__ wt, const int32_t *__restrict__ gid_s,
+    const int32_t *__restrict__ trow_s, float *__restrict__ prow, uint32_t *__restrict__ row_key,
+    int32_t *__restrict__ row_idx)
 {
-    long long tr_entry = 0;
-    if (TRACE) tr_entry = __builtin_readcyclecounter();
-    const int lane = threadIdx.x;
-    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * GAGS_BLOCKS_PER_TILE * n_slices);
-    const int slice = logical % n_slices, rest = logical / n_slices;
-    const int blk = rest & 3;
-    const int tile = gags_tile_of_order(rest >> 2, tile_w, n_tiles / tile_w);
-    const int cnt = blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk];
-    long long tr0 = 0, trr = 0, phA = 0, phM = 0, phS = 0, tph = 0;
-    if (TRACE) { tr0 = __builtin_readcyclecounter(); trr = wall_clock64(); }
-    if (cnt == 0) return;
-    const int base = row_end[tile * GAGS_BLOCKS_PER_TILE + blk] - cnt;  // first compact row of the block
+    constexpr int CW = 32 * NBR;  // channels per slice
+    constexpr int C4 = CW / 4;    // float4 columns per row of the slice
+    __shared__ __attribute__((aligned(16))) float stage[4][32][CW];  // partial rows of the chunk, per block
+    __shared__ uint8_t pos[2][4][CMAX];  // pos[parity][b][row - r0] = slot of block b's run holding that tile row, 0xff: none
+    __shared__ int cand[2][4];
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * n_slices);
+    const int slice = logical % n_slices;
+    const int tile = gags_tile_of_order(logical / n_slices, tile_w, n_tiles / tile_w);
     const int start = offsets[tile];
     const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+    const int R0 = trow[start], R1 = trow[end];
+    if (R1 == R0) return;  // nothing blended in this tile (uniform over the workgroup)
+    const int blk = wave;
+    const int cnt = blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk];
     const int sb = gags_slot_base(start, end, tile, blk);
-    const int ch0 = slice * (32 * NBR);
+    const int ch0 = slice * CW;
     BlockGeom64 g;
     g.init(tile, blk, tile_w, width, height, lane);
     const int p = g.p, k = g.k;
 
     // V[t][j] = v_out[pixel t of half k][ch0 + NBR*p + j]  ("strided-NBR" channel tiles: one vector load / store)
     float V[32][NBR];
+    if (cnt > 0) {
 #pragma unroll
-    for (int t = 0; t < 32; ++t) {
-        // K-step t of half-wave k = pixel 16k + t/2 of the 8x4 half t%2: the order of the weight rows
-        const int px = 16 * k + (t >> 1);
-        const int qj = g.bx0 + (px & 7), qi = g.by0 + 4 * (t & 1) + (px >> 3);
-        const bool ok = (qi < height) && (qj < width);
-        // NBR == 1 also serves a ragged last slice (D % 32 != 0): lanes past the row are clamped here, masked below
-        const float *src = v_render_colors + ((size_t)min(qi, height - 1) * width + min(qj, width - 1)) * d +
-                           (NBR == 1 ? min(ch0 + p, d - 1) : ch0 + NBR * p);
-        if constexpr (NBR == 4) {
-            const float4 v = *reinterpret_cast<const float4 *>(src);
-            V[t][0] = ok ? v.x : 0.f; V[t][1] = ok ? v.y : 0.f; V[t][2] = ok ? v.z : 0.f; V[t][3] = ok ? v.w : 0.f;
-        } else if constexpr (NBR == 2) {
-            const float2 v = *reinterpret_cast<const float2 *>(src);
-            V[t][0] = ok ? v.x : 0.f; V[t][1] = ok ? v.y : 0.f;
-        } else {
-            const float v = src[0];
-            V[t][0] = ok ? v : 0.f;
-        }
-    }
-
-    const int nblocks = (cnt + 31) >> 5;
-    for (int m = 0; m < nblocks; ++m) {
-        // weight tile m: slots sb+32m .. +31; lane (i = p, k) owns the 32 floats of half k of row i
-        float A[32];
-        __builtin_amdgcn_sched_barrier(0);
-        if (TRACE) tph = __builtin_readcyclecounter();
-        {
-            const float4 *src = reinterpret_cast<const float4 *>(wt + (size_t)(sb + 32 * m + p) * 64 + k * 32);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const float4 v = src[t];
-                A[4 * t] = v.x; A[4 * t + 1] = v.y; A[4 * t + 2] = v.z; A[4 * t + 3] = v.w;
+        for (int t = 0; t < 32; ++t) {
+            // K-step t of half-wave k = pixel 16k + t/2 of the 8x4 half t%2: the order of the weight rows
+            const int px = 16 * k + (t >> 1);
+            const int qj = g.bx0 + (px & 7), qi = g.by0 + 4 * (t & 1) + (px >> 3);
+            const bool ok = (qi < height) && (qj < width);
+            // NBR == 1 also serves a ragged last slice (D % 32 != 0): lanes past the row are clamped here, masked below
+            const float *src = v_render_colors + ((size_t)min(qi, height - 1) * width + min(qj, width - 1)) * d +
+                               (NBR == 1 ? min(ch0 + p, d - 1) : ch0 + NBR * p);
+            if constexpr (NBR == 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(src);
+                V[t][0] = ok ? v.x : 0.f; V[t][1] = ok ? v.y : 0.f; V[t][2] = ok ? v.z : 0.f; V[t][3] = ok ? v.w : 0.f;
+            } else if constexpr (NBR == 2) {
+                const float2 v = *reinterpret_cast<const float2 *>(src);
+                V[t][0] = ok ? v.x : 0.f; V[t][1] = ok ? v.y : 0.f;
+            } else {
+                const float v = src[0];
+                V[t][0] = ok ? v : 0.f;
             }
         }
-        const int count = min(32, cnt - 32 * m);
-        if (slice == 0 && k == 0 && p < count) {  // row -> Gaussian map for the sort
-            row_key[base + 32 * m + p] = (uint32_t)gid_s[sb + 32 * m + p];
-            row_idx[base + 32 * m + p] = base + 32 * m + p;
-        }
-        // The 128 MFMAs of a tile are issued as ONE uninterrupted burst: everything they read is waited for
-        // up front (the compiler would start after the first four loads and stall again in mid-burst), and
-        // nothing else is scheduled into the burst.  The two waves of a SIMD then settle into opposite
-        // phases -- one multiplies while the other loads / stores -- instead of stalling and resuming in
-        // lock step with the matrix pipe idle in between: 5.8 -> 4.5 ms on C3, identical instructions otherwise.
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (TRACE) { const long long now = __builtin_readcyclecounter(); phA += now - tph; tph = now; }
-        __builtin_amdgcn_sched_barrier(0);
-        f32x16 acc[NBR];
-#pragma unroll
-        for (int j = 0; j < NBR; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    } else {
 #pragma unroll
         for (int t = 0; t < 32; ++t)
 #pragma unroll
-            for (int j = 0; j < NBR; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[t], V[t][j], acc[j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (TRACE) { const long long now = __builtin_readcyclecounter(); phM += now - tph; tph = now; }
+            for (int j = 0; j < NBR; ++j) V[t][j] = 0.f;
+    }
+
+    int pb = 0;  // slots of this block already consumed
+    int r0 = R0;
+    // tile rows (and Gaussians) of this block's next 33 slots: sorted, hence increasing; 0x7fffffff past the end and
+    // for the pad slot of an odd count.  Always fetched one chunk ahead.
+    int tr = 0x7fffffff, gid = 0;
+    if (lane <= 32 && lane < cnt) {
+        tr = trow_s[sb + lane];
+        gid = gid_s[sb + lane];
+    }
+    // weight tile: slots sb+pb .. +31; lane (i = p, k) owns the 32 floats of half k of row i.  Rows past the run (the
+    // next chunk's slots, or memory past the block) only produce accumulator rows nobody stores.  Also requested one
+    // chunk ahead: right after the previous burst has consumed the registers.
+    float A[32];
+    auto load_A = [&](int first) {
+        const float4 *src = reinterpret_cast<const float4 *>(wt + (size_t)(sb + first + p) * 64 + k * 32);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int slot = (r & 3) + 8 * (r >> 2) + 4 * k;
-            if (slot < count) {  // 32 lanes x 4*NBR B = the row's contiguous bytes of this slice
-                float *dst = prow + (size_t)(base + 32 * m + slot) * d + ch0 + NBR * p;
-                if constexpr (NBR == 4) *reinterpret_cast<float4 *>(dst) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
-                else if constexpr (NBR == 2) *reinterpret_cast<float2 *>(dst) = make_float2(acc[0][r], acc[1][r]);
-                else if (ch0 + p < d) dst[0] = acc[0][r];
+        for (int t = 0; t < 8; ++t) {
+            const float4 v = src[t];
+            A[4 * t] = v.x; A[4 * t + 1] = v.y; A[4 * t + 2] = v.z; A[4 * t + 3] = v.w;
+        }
+    };
+    if (cnt > 0) load_A(0);
+    for (int it = 0; r0 < R1; ++it) {
+        const int par = it & 1;
+        if (threadIdx.x < CMAX) reinterpret_cast<uint32_t *>(&pos[par][0][0])[threadIdx.x] = 0xffffffffu;
+        const int tr32 = __builtin_amdgcn_readlane(tr, 32);
+        if (lane == 0) cand[par][wave] = tr32;
+        __syncthreads();
+        const int r1 = min(min(min(cand[par][0], cand[par][1]), min(cand[par][2], cand[par][3])), min(r0 + CMAX, R1));
+        const bool mine = lane < 32 && tr < r1;
+        const int run = __popcll(__ballot(mine));  // this block's slots pb .. pb+run-1 fall into [r0, r1)
+        const int tr_c = tr, gid_c = gid;
+        const int pbn = pb + run;
+        if (run > 0) {
+            if (mine) pos[par][wave][tr_c - r0] = (uint8_t)lane;
+            // The 32*NBR MFMAs of a weight tile are issued as ONE uninterrupted burst: everything they read is waited
+            // for up front and nothing else is scheduled into the burst, so that the waves sharing a SIMD alternate
+            // (one multiplies while the other loads / merges) instead of stalling and resuming in lock step.
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 acc[NBR];
+#pragma unroll
+            for (int j = 0; j < NBR; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 32; ++t)
+#pragma unroll
+                for (int j = 0; j < NBR; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[t], V[t][j], acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (mine && slice == 0) {  // row -> Gaussian map for the sort (every block of the row stores the same pair)
+                row_key[tr_c] = (uint32_t)gid_c;
+                row_idx[tr_c] = tr_c;
+            }
+            // next chunk's operands: in flight while this chunk is parked and merged
+            tr = 0x7fffffff;
+            if (lane <= 32 && pbn + lane < cnt) {
+                tr = trow_s[sb + pbn + lane];
+                gid = gid_s[sb + pbn + lane];
+            }
+            if (pbn < cnt) load_A(pbn);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int slot = (r & 3) + 8 * (r >> 2) + 4 * k;
+                if (slot < run) {
+                    float *dst = &stage[wave][slot][NBR * p];
+                    if constexpr (NBR == 4) *reinterpret_cast<float4 *>(dst) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+                    else if constexpr (NBR == 2) *reinterpret_cast<float2 *>(dst) = make_float2(acc[0][r], acc[1][r]);
+                    else dst[0] = acc[0][r];
+                }
             }
         }
-        if (TRACE) {
-            __builtin_amdgcn_sched_barrier(0);
-            phS += __builtin_readcyclecounter() - tph;
+        __syncthreads();
+        // merged rows of the chunk: sum over the blocks that hold the row, in block order; one float4 per thread and item
+        const int items = (r1 - r0) * C4;
+        // branch-free, fully unrolled (at most CMAX * C4 / 256 trips): see raster_bwd_rows_pair
+        int gt = threadIdx.x;
+        asm volatile("" : "+v"(gt));
+#pragma unroll
+        for (int trip = 0; trip < CMAX * C4 / 256; ++trip) {
+            const int item = gt + 256 * trip;
+            if (item < items) {
+                const int row = item / C4, c4 = item - row * C4;
+                float4 v[4];
+                bool has[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int q = pos[par][b][row];
+                    has[b] = q != 0xff;
+                    v[b] = *reinterpret_cast<const float4 *>(&stage[b][has[b] ? q : 0][4 * c4]);
+                }
+                float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    sum.x += has[b] ? v[b].x : 0.f; sum.y += has[b] ? v[b].y : 0.f;
+                    sum.z += has[b] ? v[b].z : 0.f; sum.w += has[b] ? v[b].w : 0.f;
+                }
+                if (ch0 + 4 * c4 < d)  // ragged last slice (D % 32 != 0; D % 4 == 0)
+                    *reinterpret_cast<float4 *>(prow + (size_t)(r0 + row) * d + ch0 + 4 * c4) = sum;
+            }
+            if (trip & 1) __builtin_amdgcn_sched_barrier(0);
         }
+        pb = pbn;
+        r0 = r1;
+        // no third barrier: the next chunk's stores into stage[] / pos[par ^ 1] / cand[par ^ 1] come after ITS first
+        // barrier, which every thread reaches only after finishing the loop above
     }
-    if (TRACE && lane == 0 && blockIdx.x < 262144) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        GAGS_TRACE_STORE(0, tr0); GAGS_TRACE_STORE(1, (long long)__builtin_readcyclecounter());
-        GAGS_TRACE_STORE(2, ((long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32) |  // XCC_ID, HW_ID
-                                (unsigned)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)));
-        GAGS_TRACE_STORE(3, ((long long)cnt << 32) | (unsigned)(wall_clock64() - trr));  // wave duration, 100 MHz ticks
-        GAGS_TRACE_STORE(4, phA); GAGS_TRACE_STORE(5, phM); GAGS_TRACE_STORE(6, phS); GAGS_TRACE_STORE(7, tr0 - tr_entry);
+}
+
+// trow_s[slot] = tile row of the slot's intersection (0x7fffffff for the pad slot of an odd count): one coalesced
+// stream per block for the rows kernel instead of a dependent sidx -> trow gather.  One wave per (tile, block).
+__global__ __launch_bounds__(64) void slot_rows_kernel(int n_tiles, int n_isects, const int32_t *__restrict__ offsets,
+                                                       const int32_t *__restrict__ blk_rows,
+                                                       const int32_t *__restrict__ sidx_s,
+                                                       const int32_t *__restrict__ trow, int32_t *__restrict__ trow_s)
+{
+    const int tile = blockIdx.x >> 2, blk = blockIdx.x & 3;
+    const int cnt = blk_rows[blockIdx.x];
+    const int start = offsets[tile];
+    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+    const int sb = gags_slot_base(start, end, tile, blk);
+    for (int j = threadIdx.x; j < cnt; j += 64) {
+        const int sx = sidx_s[sb + j];
+        trow_s[sb + j] = sx >= 0 ? trow[sx] : 0x7fffffff;
     }
 }
 
@@ -354,11 +430,22 @@ int64_t gags_bwd_staged_scratch_bytes_impl(int64_t rows, int n_gauss, int d)
     return staged_layout(rows > 0 ? rows : 1, n_gauss, d).total;
 }
 
+int gags_bwd_slot_rows_launch(int width, int height, int n_isects, const int32_t *offsets, const int32_t *blk_rows,
+                              const int32_t *sidx_s, const int32_t *trow, int32_t *trow_s, hipStream_t st)
+{
+    GAGS_CLEAR_ERR();
+    const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
+    hipLaunchKernelGGL(slot_rows_kernel, dim3(tile_w * tile_h * GAGS_BLOCKS_PER_TILE), dim3(64), 0, st, tile_w * tile_h,
+                       n_isects, offsets, blk_rows, sidx_s, trow, trow_s);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
 // 1 = width not eligible
 int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, const int32_t *offsets, int n_isects,
-                                  const float *v_out, const int32_t *blk_rows, const int32_t *row_end, int64_t rows,
-                                  const float *wt, const int32_t *gid_s, void *scratch, int64_t scratch_bytes,
-                                  float *v_colors, int stage_flags, hipStream_t st)
+                                  const float *v_out, const int32_t *blk_rows, const int32_t *trow, int64_t rows,
+                                  const float *wt, const int32_t *gid_s, const int32_t *trow_s, void *scratch,
+                                  int64_t scratch_bytes, float *v_colors, int stage_flags, hipStream_t st)
 {
     // stage: 0 = everything; 1 = rows, 2 = sort + segment offsets, 3 = reduce (per-kernel timing)
     GAGS_CLEAR_ERR();
@@ -377,21 +464,13 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
     float *prow = (float *)(sb + L.prow);
     if (rows > 0) {
         if (sA) {
-            const dim3 grid(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices);
-#define GAGS_ROWS_LAUNCH(NBR, TRACE)                                                                                    \
-    hipLaunchKernelGGL((raster_bwd_rows<NBR, TRACE>), grid, dim3(64), 0, st, d, width, height, tile_w, n_tiles, n_slices, \
-                       v_out, offsets, n_isects, blk_rows, row_end, wt, gid_s, prow, key, idx)
-            if (nbr == 4) {
-#ifdef GAGS_TRACE_BUILD
-                if (stage_flags & 16) GAGS_ROWS_LAUNCH(4, true);  // diagnostics: per-wave timeline (tools/rows_trace.py)
-                else
-#endif
-                    GAGS_ROWS_LAUNCH(4, false);
-            } else if (nbr == 2) {
-                GAGS_ROWS_LAUNCH(2, false);
-            } else {
-                GAGS_ROWS_LAUNCH(1, false);
-            }
+            const dim3 grid(n_tiles * n_slices);
+#define GAGS_ROWS_LAUNCH(NBR)                                                                                       \
+    hipLaunchKernelGGL((raster_bwd_rows<NBR>), grid, dim3(256), 0, st, d, width, height, tile_w, n_tiles, n_slices, \
+                       v_out, offsets, n_isects, blk_rows, trow, wt, gid_s, trow_s, prow, key, idx)
+            if (nbr == 4) GAGS_ROWS_LAUNCH(4);
+            else if (nbr == 2) GAGS_ROWS_LAUNCH(2);
+            else GAGS_ROWS_LAUNCH(1);
 #undef GAGS_ROWS_LAUNCH
         }
         if (sS) {
@@ -428,18 +507,4 @@ int gags_raster_bwd_atomic_launch(int d, int width, int height, const void *pack
                        v_colors);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
-}
-
-// diagnostics: copy the traced rows kernel's per-wave records (8 int64 per workgroup) to the host
-extern "C" int gags_debug_rows_trace(long long *dst, int n_workgroups)
-{
-#ifdef GAGS_TRACE_BUILD
-    if (n_workgroups < 0 || n_workgroups > 262144) return GAGS_EINVAL;
-    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_rows_trace), sizeof(long long) * 8 * (size_t)n_workgroups) == hipSuccess
-               ? GAGS_OK
-               : GAGS_ELAUNCH;
-#else
-    (void)dst; (void)n_workgroups;
-    return GAGS_ENODEV;  // the product library carries no trace buffer: build `make trace`
-#endif
 }

@@ -10,6 +10,9 @@
 //                    reads rows, 32 consecutive floats per lane (its A operands: K-step t of half-wave k is
 //                    pixel 16k + t/2 of half t%2);
 //   gid[slot]      : Gaussian id of the slot (N for the zero slot that pads an odd count);
+//   sidx[slot]     : sorted intersection index of the slot (-1 for the pad slot), and hit[sidx] = 1: the backward
+//                    numbers the (tile, Gaussian) pairs that blended anything by a prefix sum over `hit` and merges
+//                    the four blocks' partial gradient rows of such a pair into ONE row (raster_bwd_mfma.hip);
 //   blk_rows[blk]  : number of slots of the block (even);
 //   Tbuf / render_alphas / last_ids : per-pixel results of the chain.
 // Slots of a block live in a fixed, sparse region of the slot space (no counting pre-pass):
@@ -60,8 +63,9 @@ __global__ __launch_bounds__(256) void gather_grec_kernel(int n_isects, const in
 __global__ __launch_bounds__(64, 8) void raster_weights_kernel(
     int width, int height, int tile_w, int n_tiles, int n_gauss, const GRec *__restrict__ packed,
     const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids, int n_isects,
-    float *__restrict__ wt, int32_t *__restrict__ gid_s, int32_t *__restrict__ blk_rows, float *__restrict__ Tbuf,
-    float *__restrict__ render_alphas, int32_t *__restrict__ last_ids)
+    float *__restrict__ wt, int32_t *__restrict__ gid_s, int32_t *__restrict__ sidx_s, int32_t *__restrict__ hit,
+    int32_t *__restrict__ blk_rows, float *__restrict__ Tbuf, float *__restrict__ render_alphas,
+    int32_t *__restrict__ last_ids)
 {
     __shared__ __attribute__((aligned(16))) HRec ring[RING];
 
@@ -117,7 +121,11 @@ __global__ __launch_bounds__(64, 8) void raster_weights_kernel(
                 const int pos = row + ((k && nz0) ? 1 : 0);
                 // row = 32 (upper, lower) pairs: element 2p + h = pixel p of half h
                 *reinterpret_cast<float2 *>(wt + (size_t)pos * 64 + 2 * p) = make_float2(wA, wB);
-                if (p == 0) gid_s[pos] = gid_c;
+                if (p == 0) {
+                    gid_s[pos] = gid_c;
+                    sidx_s[pos] = sidx_c;
+                    hit[sidx_c] = 1;  // up to four blocks store the same 1
+                }
             }
             row += (int)nz0 + (int)nz1;
             return more && !__all(sA.done && sB.done);
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(64, 8) void raster_weights_kernel(
     if ((row - sb) & 1) {  // consumers take slots in pairs: pad with one zero slot that belongs to no Gaussian
         if (k == 0) {
             *reinterpret_cast<float2 *>(wt + (size_t)row * 64 + 2 * p) = make_float2(0.f, 0.f);
-            if (p == 0) gid_s[row] = n_gauss;
+            if (p == 0) { gid_s[row] = n_gauss; sidx_s[row] = -1; }
         }
         row += 1;
     }
@@ -169,15 +177,18 @@ int gags_pack_isects_launch(int n, int n_isects, const int32_t *flat, const floa
 }
 
 int gags_raster_weights_launch(int width, int height, int n_gauss, const void *packed, const int32_t *offsets,
-                               const int32_t *flat, int n_isects, float *wt, int32_t *gid_s, int32_t *blk_rows,
-                               float *Tbuf, float *alphas, int32_t *last_ids, hipStream_t st)
+                               const int32_t *flat, int n_isects, float *wt, int32_t *gid_s, int32_t *sidx_s,
+                               int32_t *hit, int32_t *blk_rows, float *Tbuf, float *alphas, int32_t *last_ids,
+                               hipStream_t st)
 {
     GAGS_CLEAR_ERR();
     const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
     const int n_tiles = tile_w * tile_h;
+    // hit[i] = 1 for every intersection that blends into at least one pixel of its tile (+1 entry: an empty view)
+    if (hipMemsetAsync(hit, 0, sizeof(int32_t) * ((size_t)n_isects + 1), st) != hipSuccess) return GAGS_ELAUNCH;
     hipLaunchKernelGGL(raster_weights_kernel, dim3(n_tiles * GAGS_BLOCKS_PER_TILE), dim3(64), 0, st, width, height, tile_w, n_tiles,
-                       n_gauss, reinterpret_cast<const GRec *>(packed), offsets, flat, n_isects, wt, gid_s, blk_rows,
-                       Tbuf, alphas, last_ids);
+                       n_gauss, reinterpret_cast<const GRec *>(packed), offsets, flat, n_isects, wt, gid_s, sidx_s, hit,
+                       blk_rows, Tbuf, alphas, last_ids);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }

@@ -238,8 +238,7 @@ class _Rasterize(torch.autograd.Function):
         if backgrounds is not None and ctx.needs_input_grad[4]:
             v_bg = ((1.0 - alphas)[..., None] * v_out).sum(dim=(0, 1))
         if not need_geom and blk_rows is not None:
-            v_colors = _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height,
-                                        flags & _lib.GAGS_BWD_TRACE)
+            v_colors = _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height)
             return None, None, v_colors, None, v_bg, None, None, None, None, None, None
         v_colors = torch.zeros(n, d, device=dev)
         if need_geom:
@@ -258,18 +257,20 @@ class _Rasterize(torch.autograd.Function):
         return v_m2d, v_con, v_colors, v_opac, v_bg, None, None, None, None, None, None
 
 
-def _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height, xflag=0):
-    """Colours-only backward without atomics: slot counts of the forward -> prefix sum -> one 4-byte
-    readback (total rows) -> stored partial rows -> sort by Gaussian -> segmented sum."""
+def _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height):
+    """Colours-only backward without atomics: hit flags of the forward -> prefix sum (one row per (tile, Gaussian)
+    pair that blended anything) -> one 4-byte readback (total rows) -> merged partial rows -> sort by Gaussian ->
+    segmented sum."""
     dev = v_out.device
     st = _stream()
-    nb = blk_rows.numel()
-    row_end = torch.empty(nb, dtype=torch.int32, device=dev)
+    ne = lib.gags_bwd_rowmap_elems(n_isects, width, height)
+    trow = torch.empty(ne, dtype=torch.int32, device=dev)
     total = torch.empty(1, dtype=torch.int32, device=dev)
-    sb = lib.gags_scan_scratch_bytes(nb)
-    stmp = torch.empty(sb, dtype=torch.uint8, device=dev)
+    sb = lib.gags_bwd_rowmap_scratch_bytes(n_isects)
+    stmp = torch.empty(max(sb, 4), dtype=torch.uint8, device=dev)
     with profiler.stage("bwd_rowcount"):
-        check(lib.gags_cumsum_i32(nb, ptr(blk_rows), ptr(row_end), ptr(total), ptr(stmp), sb, st), "gags_cumsum_i32")
+        check(lib.gags_bwd_rowmap(n_isects, width, height, ptr(offsets), ptr(blk_rows), ptr(fwd_scratch),
+                                  fwd_scratch.numel(), ptr(trow), ne, ptr(total), ptr(stmp), sb, st), "gags_bwd_rowmap")
         host = ctypes.c_int32(0)
         check(lib.gags_read_i32(ptr(total), ctypes.byref(host), st), "gags_read_i32")
     rows = int(host.value)
@@ -279,8 +280,8 @@ def _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d,
 
     def run(stage):
         check(lib.gags_raster_bwd_colors_staged(d, n, width, height, ptr(offsets), n_isects, ptr(v_out), ptr(blk_rows),
-                                                ptr(row_end), rows, ptr(fwd_scratch), fwd_scratch.numel(),
-                                                ptr(scratch), nbytes, ptr(v_colors), stage | xflag, st),
+                                                ptr(trow), rows, ptr(fwd_scratch), fwd_scratch.numel(),
+                                                ptr(scratch), nbytes, ptr(v_colors), stage, st),
               "gags_raster_bwd_colors_staged")
 
     if profiler.ENABLED:  # one event pair per kernel (group), for the roofline line of bench.py

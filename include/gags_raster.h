@@ -143,18 +143,27 @@ int gags_raster_bwd(int d, int width, int height, const float *means2d, const fl
                     int flags, void *stream);
 
 /* K10, staged flavour: colours-only backward WITHOUT atomics (deterministic), 16 <= D <= 1024,
- * D % 4 == 0.  Consumes the scratch + blk_rows of a split gags_raster_fwd, the inclusive prefix
- * sum row_end of blk_rows (gags_cumsum_i32) and its total `rows` (gags_read_i32).  Partial sums
- * are stored as rows, sorted by Gaussian and reduced; v_colors[N,D] is written in full (no
- * zero-fill needed).  scratch: gags_bwd_staged_scratch_bytes(rows, n, d) bytes.
- * stage: low 4 bits 0 = all, 1..3 = rows, sort, reduce (per-kernel timing); bit 4 = run the TRACED
- * rows kernel (same results; per-wave timeline for gags_debug_rows_trace) -- only in the diagnostics
- * build `make -C gags_amd/csrc trace`; the product library ignores the bit.
- * Returns 1 when D is not eligible. */
+ * D % 4 == 0.  Consumes the scratch + blk_rows of a split gags_raster_fwd.
+ *
+ * gags_bwd_rowmap: numbers the (tile, Gaussian) pairs that blended into at least one pixel -- one partial
+ * gradient row each -- in sorted order: rowmap[0 .. n_isects] = exclusive prefix sum of the hit flags the
+ * forward left in its scratch, followed by the row number of every K-step slot of the forward; total[0] = the
+ * row count `rows` (read it with gags_read_i32).  rowmap: gags_bwd_rowmap_elems(...) int32;
+ * scratch: gags_bwd_rowmap_scratch_bytes(n_isects) bytes.
+ *
+ * gags_raster_bwd_colors_staged: per tile the four pixel blocks' partial rows are merged on chip and stored
+ * once per (tile, Gaussian), the rows are sorted by Gaussian and reduced; v_colors[N,D] is written in full
+ * (no zero-fill needed).  scratch: gags_bwd_staged_scratch_bytes(rows, n, d) bytes.
+ * stage: 0 = all, 1..3 = rows, sort, reduce (per-kernel timing).  Returns 1 when D is not eligible. */
+int64_t gags_bwd_rowmap_elems(int64_t n_isects, int width, int height);
+int64_t gags_bwd_rowmap_scratch_bytes(int64_t n_isects);
+int gags_bwd_rowmap(int64_t n_isects, int width, int height, const int32_t *isect_offsets, const int32_t *blk_rows,
+                    const void *fwd_scratch, int64_t fwd_scratch_bytes, int32_t *rowmap, int64_t rowmap_elems,
+                    int32_t *total, void *scratch, int64_t scratch_bytes, void *stream);
 int64_t gags_bwd_staged_scratch_bytes(int64_t rows, int n, int d);
 int gags_raster_bwd_colors_staged(int d, int n, int width, int height, const int32_t *isect_offsets,
                                   int64_t n_isects, const float *v_render_colors,
-                                  const int32_t *blk_rows, const int32_t *row_end, int64_t rows,
+                                  const int32_t *blk_rows, const int32_t *rowmap, int64_t rows,
                                   const void *fwd_scratch, int64_t fwd_scratch_bytes,
                                   void *scratch, int64_t scratch_bytes, float *v_colors, int stage,
                                   void *stream);
@@ -164,12 +173,6 @@ int gags_raster_bwd_colors_staged(int d, int n, int width, int height, const int
 int gags_raster_stats(int width, int height, const float *means2d, const float *conics,
                       const float *opacities, const int32_t *isect_offsets, const int32_t *flatten_ids,
                       int64_t n_isects, int64_t *counts, void *stream);
-
-/* Diagnostics: copy the timeline left by the traced rows kernel (stage bit 4) to the host: 8 int64 per
- * workgroup {t_start, t_end, xcc<<32|hw_id, slots<<32|duration in 10 ns, load wait, MFMA burst, stores,
- * setup} in shader-counter ticks.  n_workgroups <= 262144.  tools/rows_trace.py.  The buffer exists only in
- * the diagnostics build (libgags_hip_trace.so); the product library returns GAGS_ENODEV. */
-int gags_debug_rows_trace(long long *dst_host, int n_workgroups);
 
 /* K2: projection backward: chain rule of gags_project_fwd for Gaussians with radii>0.
  * Inputs v_means2d[N,2], v_depths[N] (may be NULL), v_conics[N,3];
