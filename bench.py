@@ -63,13 +63,17 @@ def parse():
     ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C5", "C3H"])
     ap.add_argument("--no-heavy", action="store_true",
                     help="skip the second measurement (C3 geometry at SURVEY 8d's literal splat scale, 'C3H')")
-    ap.add_argument("--n", type=int, default=None)
-    ap.add_argument("--d", type=int, default=None)
+    ap.add_argument("--n", "--n-gaussians", dest="n", type=int, default=None)
+    ap.add_argument("--d", "--feature-dim", dest="d", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
     ap.add_argument("--no-allreduce", action="store_true", help="(debug) skip the gradient reduction at N>1")
     ap.add_argument("--grad-reduce", default="rs_ag", choices=["rs_ag", "allreduce"],
                     help="by-view step: bucketed reduce-scatter + all-gather (default) or plain all-reduce")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="by-view step: exchange the whole gradient after the backward instead of range by range during it")
+    ap.add_argument("--wire", default="fp32", choices=["fp32", "bf16"],
+                    help="by-view step: dtype of the gradient on the wire (bf16: opt-in, ~1e-2 relative error, halves the bytes)")
     ap.add_argument("--raster-flags", type=int, default=0)
     ap.add_argument("--parallel", default="view", choices=["auto", "view", "channel"],
                     help="N>1: one view per GPU + gradient exchange (view: north_star's decomposition, the default), "
@@ -193,8 +197,9 @@ def main():
 
     from gags_amd import _lib, profiler, synthetic as syn
     from gags_amd.gaussian_renderer import render
-    from gags_amd.dist import reduce_feature_grad
+    from gags_amd.dist import OverlappedGradReducer, reduce_feature_grad
     _lib.load()
+    exposed = []  # per step: ms the compute stream waited for the gradient exchange after the backward (by-view, N>1)
 
     cfg = dict(syn.CONFIGS[args.config])
     if args.n:
@@ -229,14 +234,29 @@ def main():
         cams = [syn.make_camera(width, height, view=(v % 8) if v is not None else None, device=dev) for v in views]
         G_ = syn.make_cotangent(dl, height, width, seed=1, device=dev)  # [D,H,W] view of [H,W,D] memory
 
+        exchange = mode == "view" and world > 1 and not args.no_allreduce
+        overlap = exchange and not args.no_overlap
+        red = OverlappedGradReducer(mode=grad_reduce, wire=args.wire) if overlap else None
+
         def step_():
             pc_._semantic_feature.grad = None
             for cam_ in cams:
                 pkg_ = render(cam_, pc_, None, bg, feature_mode=True, raster_flags=args.raster_flags)
                 loss = _CotangentLoss.apply(pkg_["render"].permute(1, 2, 0), G_.permute(1, 2, 0))
-                loss.backward()
-            if mode == "view" and world > 1 and not args.no_allreduce:
-                reduce_feature_grad(pc_._semantic_feature.grad, mode=grad_reduce)
+                if red is not None:
+                    with red:  # the feature gradient is exchanged range by range while later ranges are computed
+                        loss.backward()
+                    red.finish(pc_._semantic_feature.grad)
+                    exposed[:] = [red]
+                else:
+                    loss.backward()
+            if exchange and red is None:
+                if args.wire == "bf16":
+                    g16 = pc_._semantic_feature.grad.to(torch.bfloat16)
+                    reduce_feature_grad(g16, mode=grad_reduce)
+                    pc_._semantic_feature.grad.copy_(g16)
+                else:
+                    reduce_feature_grad(pc_._semantic_feature.grad, mode=grad_reduce)
             return pkg_
         return step_, pc_, cams[-1], dl
 
@@ -325,6 +345,7 @@ def main():
         adam = {"kernel": "adam_step_kernel", "avg_launch_ms": ms, "bound": "hbm", "achieved": nbytes / ms / 1e6,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / ms / 1e6 / HBM_PEAK_GBS}
 
+    exposed_ms = exposed[-1].exposed_ms() if exposed else None
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -386,7 +407,10 @@ def main():
                                        else f"view-dp{world}" + ((" + RCCL all-reduce of the feature gradient" if args.grad_reduce == "allreduce"
                                                                   else " + RCCL reduce-scatter/all-gather of the feature gradient")
                                                                  if world > 1 else "")),
-                       "parallel_probe_ms_per_step": probe},
+                       "parallel_probe_ms_per_step": probe,
+                       "grad_exchange": (None if world == 1 or mode != "view" else
+                                         {"overlapped_with_backward": not args.no_overlap, "wire": args.wire,
+                                          "collective": args.grad_reduce, "exposed_ms_last_step": exposed_ms})},
             "roofline": roof,
             "kernels": kernels,
             "stages_ms": {k: round(v[0], 4) for k, v in sorted(stages.items())},

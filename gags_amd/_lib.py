@@ -48,6 +48,8 @@ SIGNATURES = {
     "gags_bwd_staged_scratch_bytes": (_i64, [_i64, _i32, _i32]),
     "gags_raster_bwd_colors_staged": (_i32, [_i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
                                              _i64, _vp, _i32, _vp]),
+    "gags_raster_bwd_colors_staged_range": (_i32, [_i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
+                                                   _i64, _vp, _i32, _i32, _i32, _vp]),
     "gags_raster_stats": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "gags_project_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _vp, _vp]),

@@ -77,13 +77,13 @@ constexpr int CMAX = 64;  // merged rows per chunk (bounds pos[] and the merge l
 
 template <int NBR>
 __global__ __launch_bounds__(256, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void raster_bwd_rows(
-    int d, int width, int height, int tile_w, int n_tiles, int n_slices, const float *__restrict__ v_render_colors,
-    const int32_t *__restrict__ offsets, int n_isects, const int32_t *__restrict__ blk_rows,
-    const int32_t *__restrict__ trow, const float *__restrict__ wt, const int32_t *__restrict__ gid_s,
-    const int32_t *__restrict__ trow_s, float *__restrict__ prow, uint32_t *__restrict__ row_key,
-    int32_t *__restrict__ row_idx)
+    int d, int width, int height, int tile_w, int n_tiles, int slice0, int n_slices,
+    const float *__restrict__ v_render_colors, const int32_t *__restrict__ offsets, int n_isects,
+    const int32_t *__restrict__ blk_rows, const int32_t *__restrict__ trow, const float *__restrict__ wt,
+    const int32_t *__restrict__ gid_s, const int32_t *__restrict__ trow_s, float *__restrict__ prow,
+    uint32_t *__restrict__ row_key, int32_t *__restrict__ row_idx)
 {
-    constexpr int CW = 32 * NBR;  // channels per slice
+    constexpr int CW = 32 * NBR;  // channels per slice; this launch covers slices slice0 .. slice0 + n_slices - 1
     constexpr int C4 = CW / 4;    // float4 columns per row of the slice
     __shared__ __attribute__((aligned(16))) float stage[4][32][CW];  // partial rows of the chunk, per block
     __shared__ uint8_t pos[2][4][CMAX];  // pos[parity][b][row - r0] = slot of block b's run holding that tile row, 0xff: none
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void rast
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int logical = gags_xcd_remap(blockIdx.x, n_tiles * n_slices);
-    const int slice = logical % n_slices;
+    const int slice = slice0 + logical % n_slices;
     const int tile = gags_tile_of_order(logical / n_slices, tile_w, n_tiles / tile_w);
     const int start = offsets[tile];
     const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
@@ -288,15 +288,16 @@ __global__ void seg_fill_kernel(int n_keys, int32_t *__restrict__ seg)
 }
 
 // v_colors[g, :] = sum over the Gaussian's rows, in sorted (= deterministic) order; float4 per lane
-__global__ __launch_bounds__(256) void reduce_rows_kernel(int n_gauss, int d, const int32_t *__restrict__ seg,
+__global__ __launch_bounds__(256) void reduce_rows_kernel(int n_gauss, int d, int ch_begin, int ch_count,
+                                                          const int32_t *__restrict__ seg,
                                                           const int32_t *__restrict__ sorted_rows,
                                                           const float *__restrict__ prow, float *__restrict__ v_colors)
 {
-    const int lpg = d >> 2;  // lanes per Gaussian
+    const int lpg = ch_count >> 2;  // lanes per Gaussian (channels ch_begin .. ch_begin + ch_count - 1 of its row)
     const int gpb = 256 / lpg;
     const int gl = threadIdx.x / lpg;
     const int g = blockIdx.x * gpb + gl;
-    const int cl = (threadIdx.x % lpg) * 4;
+    const int cl = ch_begin + (threadIdx.x % lpg) * 4;
     if (gl >= gpb || g >= n_gauss) return;
     const int b = seg[g], e = seg[g + 1];
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -445,7 +446,8 @@ int gags_bwd_slot_rows_launch(int width, int height, int n_isects, const int32_t
 int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, const int32_t *offsets, int n_isects,
                                   const float *v_out, const int32_t *blk_rows, const int32_t *trow, int64_t rows,
                                   const float *wt, const int32_t *gid_s, const int32_t *trow_s, void *scratch,
-                                  int64_t scratch_bytes, float *v_colors, int stage_flags, hipStream_t st)
+                                  int64_t scratch_bytes, float *v_colors, int stage_flags, int ch_begin, int ch_count,
+                                  hipStream_t st)
 {
     // stage: 0 = everything; 1 = rows, 2 = sort + segment offsets, 3 = reduce (per-kernel timing)
     GAGS_CLEAR_ERR();
@@ -455,7 +457,13 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
     const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
     const int n_tiles = tile_w * tile_h;
     const int nbr = d % 128 == 0 ? 4 : (d % 64 == 0 ? 2 : 1);  // channel tiles (of 32) per wave
-    const int n_slices = (d + 32 * nbr - 1) / (32 * nbr);  // nbr == 1: ragged last slice
+    // channel range of this call: whole slices (a by-view step exchanges the gradient slice by slice while the next
+    // slice is computed, gags_amd/dist.py); the default is everything
+    if (ch_count <= 0 || ch_begin < 0 || ch_begin + ch_count > d || ch_begin % (32 * nbr) != 0 ||
+        (ch_count % (32 * nbr) != 0 && ch_begin + ch_count != d))
+        return GAGS_EINVAL;
+    const int slice0 = ch_begin / (32 * nbr);
+    const int n_slices = (ch_count + 32 * nbr - 1) / (32 * nbr);  // nbr == 1: ragged last slice
     const StagedLayout L = staged_layout(rows > 0 ? rows : 1, n_gauss, d);
     if (scratch_bytes < L.total) return GAGS_ESCRATCH;
     char *sb = (char *)scratch;
@@ -466,8 +474,8 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
         if (sA) {
             const dim3 grid(n_tiles * n_slices);
 #define GAGS_ROWS_LAUNCH(NBR)                                                                                       \
-    hipLaunchKernelGGL((raster_bwd_rows<NBR>), grid, dim3(256), 0, st, d, width, height, tile_w, n_tiles, n_slices, \
-                       v_out, offsets, n_isects, blk_rows, trow, wt, gid_s, trow_s, prow, key, idx)
+    hipLaunchKernelGGL((raster_bwd_rows<NBR>), grid, dim3(256), 0, st, d, width, height, tile_w, n_tiles, slice0,  \
+                       n_slices, v_out, offsets, n_isects, blk_rows, trow, wt, gid_s, trow_s, prow, key, idx)
             if (nbr == 4) GAGS_ROWS_LAUNCH(4);
             else if (nbr == 2) GAGS_ROWS_LAUNCH(2);
             else GAGS_ROWS_LAUNCH(1);
@@ -485,9 +493,9 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
         hipLaunchKernelGGL(seg_fill_kernel, dim3((n_gauss + 1 + 255) / 256), dim3(256), 0, st, n_gauss, seg);
     }
     if (sR) {
-        const int gpb = 256 / (d >> 2);
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3((n_gauss + gpb - 1) / gpb), dim3(256), 0, st, n_gauss, d, seg,
-                           idx_s, prow, v_colors);
+        const int gpb = 256 / (ch_count >> 2);
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((n_gauss + gpb - 1) / gpb), dim3(256), 0, st, n_gauss, d, ch_begin,
+                           ch_count, seg, idx_s, prow, v_colors);
     }
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;

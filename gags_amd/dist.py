@@ -45,6 +45,22 @@ def channel_shard(d, rank=None, world_size=None, multiple=16):
     return min(lo, d), min(hi, d)
 
 
+_AG_IN_PLACE = True
+
+
+def _all_gather_in_place(out, shard):
+    """all-gather whose input is the rank's own slot of the output (NCCL's in-place form: no staging copy).  A backend
+    that refuses aliased buffers costs one clone per bucket from then on."""
+    global _AG_IN_PLACE
+    if _AG_IN_PLACE:
+        try:
+            dist.all_gather_into_tensor(out, shard)
+            return
+        except (RuntimeError, ValueError):
+            _AG_IN_PLACE = False
+    dist.all_gather_into_tensor(out, shard.clone())
+
+
 def reduce_feature_grad(grad, mode="rs_ag", average=False, bucket_bytes=BUCKET_BYTES):
     """In-place sum (or mean) over ranks of a [N,D] gradient.  No-op at world size 1."""
     ws = world()
@@ -66,7 +82,7 @@ def reduce_feature_grad(grad, mode="rs_ag", average=False, bucket_bytes=BUCKET_B
             b = flat[o:o + per]
             shard = b.view(ws, per // ws)[dist.get_rank()]
             dist.reduce_scatter_tensor(shard, b)
-            dist.all_gather_into_tensor(b, shard.clone())
+            _all_gather_in_place(b, shard)
         if main < numel:
             dist.all_reduce(flat[main:])
     else:
@@ -74,6 +90,93 @@ def reduce_feature_grad(grad, mode="rs_ag", average=False, bucket_bytes=BUCKET_B
     if average:
         flat.div_(ws)
     return grad
+
+
+class OverlappedGradReducer:
+    """By-view step with the gradient exchange overlapped with the backward (SURVEY 8e "overlapped with the tail of
+    bwd").  Used as a context manager around `loss.backward()`: the staged backward then produces the feature
+    gradient one 128-channel range at a time (gags_amd.rasterization.GRAD_RANGE_HOOK) and every finished range is
+    packed, summed over the ranks and unpacked on a second stream while the next range is still being computed:
+
+        red = OverlappedGradReducer(mode="rs_ag")
+        with red:
+            loss.backward()
+        red.finish(pc._semantic_feature.grad)     # compute stream waits for the exchange; exact fp32 sum
+
+    wire="bf16" (opt-in) halves the bytes on xGMI: the range is rounded to bfloat16, summed in bfloat16 by the
+    collective and widened again; the result differs from the fp32 sum by ~1e-2 relative (tests/test_dist_cpu.py
+    states and checks the bound), so it is never the default.
+    If autograd did not adopt the tensor the hook saw (another consumer of the gradient forced a copy), finish() falls
+    back to the plain reduction of the final gradient: always correct, overlap lost.
+    `exposed_ms()` = time the compute stream had to wait for the exchange after the backward had finished."""
+
+    def __init__(self, mode="rs_ag", wire=None, bucket_bytes=BUCKET_BYTES):
+        self.mode, self.wire, self.bucket_bytes = mode, wire, bucket_bytes
+        self.comm = torch.cuda.Stream() if torch.cuda.is_available() else None
+        self._reset()
+
+    def _reset(self):
+        self._ptr, self._covered, self._ev = None, 0, None
+
+    def __enter__(self):
+        from . import rasterization
+        self._reset()
+        self._prev = rasterization.GRAD_RANGE_HOOK
+        rasterization.GRAD_RANGE_HOOK = self.on_range
+        return self
+
+    def __exit__(self, *exc):
+        from . import rasterization
+        rasterization.GRAD_RANGE_HOOK = self._prev
+        return False
+
+    def _exchange(self, grad, c0, c1):
+        part = grad[:, c0:c1]
+        buf = part.contiguous()  # pack (a copy unless the range is the whole row)
+        if self.wire == "bf16":
+            w = buf.to(torch.bfloat16)
+            reduce_feature_grad(w, mode=self.mode, bucket_bytes=self.bucket_bytes)
+            buf.copy_(w)
+        elif self.wire in (None, "fp32"):
+            reduce_feature_grad(buf, mode=self.mode, bucket_bytes=self.bucket_bytes)
+        else:
+            raise ValueError(self.wire)
+        if buf.data_ptr() != part.data_ptr():
+            part.copy_(buf)  # unpack
+
+    def on_range(self, grad, c0, c1):
+        if world() > 1:
+            if grad.is_cuda and self.comm is not None:
+                ev = torch.cuda.Event()
+                ev.record()  # the range's kernels, on the compute stream
+                with torch.cuda.stream(self.comm):
+                    self.comm.wait_event(ev)
+                    self._exchange(grad, c0, c1)
+                grad.record_stream(self.comm)
+            else:
+                self._exchange(grad, c0, c1)
+        self._ptr = grad.data_ptr()
+        self._covered += c1 - c0
+
+    def finish(self, param_grad):
+        """Make the reduced gradient visible to the compute stream; returns True if the overlapped exchange was used."""
+        cuda = param_grad.is_cuda and self.comm is not None
+        if cuda:
+            self._bwd_done = torch.cuda.Event(enable_timing=True)
+            self._bwd_done.record()
+            torch.cuda.current_stream().wait_stream(self.comm)
+            self._all_done = torch.cuda.Event(enable_timing=True)
+            self._all_done.record()
+        used = self._ptr == param_grad.data_ptr() and self._covered == param_grad.shape[1]
+        if not used and world() > 1:
+            reduce_feature_grad(param_grad, mode=self.mode, bucket_bytes=self.bucket_bytes)
+        return used
+
+    def exposed_ms(self):
+        if getattr(self, "_all_done", None) is None:
+            return 0.0
+        self._all_done.synchronize()
+        return float(self._bwd_done.elapsed_time(self._all_done))
 
 
 def distributed_step(render_fn, cams, pc, bg, cotangents, mode="rs_ag"):

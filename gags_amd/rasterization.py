@@ -25,6 +25,13 @@ from . import _lib, profiler
 from ._lib import check, ptr
 
 TILE = 16
+# Multi-GPU by-view step (gags_amd/dist.py: OverlappedGradReducer): when set, the staged colours-only backward
+# produces the feature gradient one channel range at a time and calls
+#     GRAD_RANGE_HOOK(v_colors_alias [N,D], ch_begin, ch_end)
+# right after the kernels of each range were enqueued, so that the exchange of one range overlaps the computation
+# of the next.  The alias shares storage with the tensor handed to autograd.
+GRAD_RANGE_HOOK = None
+GRAD_RANGE_CHANNELS = 128
 MAX_ISECTS = 1 << 27  # limit of the C ABI (int32 slot indices: 4 slots per intersection)
 SCRATCH_CHECK_BYTES = 8 << 30  # above this the split forward first checks that its scratch fits in free memory
 
@@ -284,12 +291,25 @@ def _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d,
                                                 ptr(scratch), nbytes, ptr(v_colors), stage, st),
               "gags_raster_bwd_colors_staged")
 
-    if profiler.ENABLED:  # one event pair per kernel (group), for the roofline line of bench.py
+    hook = GRAD_RANGE_HOOK
+    if hook is not None and d % GRAD_RANGE_CHANNELS == 0 and d > GRAD_RANGE_CHANNELS:
+        alias = v_colors.detach()  # own TensorImpl, same storage: autograd may still adopt v_colors without a copy
+        for c0 in range(0, d, GRAD_RANGE_CHANNELS):
+            for stage in ((1, 2, 3) if c0 == 0 else (1, 3)):
+                with profiler.stage(("bwd_rows", "bwd_sort", "bwd_reduce")[stage - 1]):
+                    check(lib.gags_raster_bwd_colors_staged_range(
+                        d, n, width, height, ptr(offsets), n_isects, ptr(v_out), ptr(blk_rows), ptr(trow), rows,
+                        ptr(fwd_scratch), fwd_scratch.numel(), ptr(scratch), nbytes, ptr(v_colors), stage, c0,
+                        GRAD_RANGE_CHANNELS, st), "gags_raster_bwd_colors_staged_range")
+            hook(alias, c0, c0 + GRAD_RANGE_CHANNELS)
+    elif profiler.ENABLED:  # one event pair per kernel (group), for the roofline line of bench.py
         for stage, name in enumerate(("bwd_rows", "bwd_sort", "bwd_reduce"), start=1):
             with profiler.stage(name):
                 run(stage)
     else:
         run(0)
+        if hook is not None:
+            hook(v_colors.detach(), 0, d)
     profiler.note("bwd_rows", rows)
     return v_colors
 

@@ -167,6 +167,17 @@ int gags_raster_bwd_colors_staged(int d, int n, int width, int height, const int
                                   const void *fwd_scratch, int64_t fwd_scratch_bytes,
                                   void *scratch, int64_t scratch_bytes, float *v_colors, int stage,
                                   void *stream);
+/* The same for channels [ch_begin, ch_begin + ch_count) only (whole 128- / 64- / 32-channel slices, as D % 128 / 64
+ * allows; the last range may end at D): v_colors[:, ch_begin : ch_begin + ch_count] is written.  A multi-GPU by-view
+ * step calls it range after range -- stage 1, 2, 3 for the range that starts at 0 (it writes the row -> Gaussian
+ * keys the sort needs), stage 1 and 3 for the others -- and exchanges each range while the next is computed
+ * (gags_amd/dist.py).  Same scratch for every range of a view. */
+int gags_raster_bwd_colors_staged_range(int d, int n, int width, int height, const int32_t *isect_offsets,
+                                        int64_t n_isects, const float *v_render_colors,
+                                        const int32_t *blk_rows, const int32_t *rowmap, int64_t rows,
+                                        const void *fwd_scratch, int64_t fwd_scratch_bytes,
+                                        void *scratch, int64_t scratch_bytes, float *v_colors, int stage,
+                                        int ch_begin, int ch_count, void *stream);
 
 /* Diagnostics (roofline model): counts[0] += (pixel,Gaussian) pairs evaluated
  * before each pixel's stop, counts[1] += pairs blended.  counts[2] int64, zeroed by caller. */

@@ -89,3 +89,57 @@ def test_channel_sharded_step_is_bit_identical_and_exchange_free(tmp_path):
     g0, g1 = _run("channel", tmp_path)
     assert g0.shape == (N, D // 2) and g1.shape == (N, D // 2)
     np.testing.assert_array_equal(np.concatenate([g0, g1], axis=1), ref)
+
+
+def _nccl_worker(rank, world, port, q):
+    """The default exchange of the by-view step on DEVICE tensors over RCCL: bucketed reduce-scatter + in-place
+    all-gather (gags_amd/dist.py:reduce_feature_grad, mode rs_ag), one GPU per rank."""
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from gags_amd.dist import OverlappedGradReducer, reduce_feature_grad
+    n, d = 10007, 512
+    grads = [torch.randn(n, d, generator=torch.Generator().manual_seed(3 + r)) for r in range(world)]
+    expect = sum(grads).to(dev)
+    g = grads[rank].to(dev)
+    reduce_feature_grad(g, mode="rs_ag", bucket_bytes=1 << 20)
+    ok1 = torch.allclose(g, expect, rtol=1e-6, atol=1e-6)
+    g2 = grads[rank].to(dev)
+    red = OverlappedGradReducer(mode="rs_ag")
+    with red:
+        from gags_amd import rasterization
+        for c0 in range(0, d, 128):
+            rasterization.GRAD_RANGE_HOOK(g2.detach(), c0, c0 + 128)
+    used = red.finish(g2)
+    torch.cuda.synchronize()
+    ok2 = used and torch.allclose(g2, expect, rtol=1e-6, atol=1e-6)
+    q.put((rank, bool(ok1), bool(ok2)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rs_ag_on_device_tensors_over_rccl():
+    """Needs two GPUs (skipped on the one-GPU test box; the driver's multi-GPU runs exercise the same code through
+    bench.py --gpus N)."""
+    import torch
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(a and b for _, a, b in res)

@@ -137,6 +137,26 @@ def test_backward_flavours_agree_and_staged_is_deterministic(oracle):
     assert np.all(g["block"][culled] == 0)  # v_colors written in full
 
 
+def test_backward_by_channel_ranges_is_bit_identical(oracle):
+    """The by-view multi-GPU step asks the staged backward for the gradient one 128-channel range at a time
+    (rasterization.GRAD_RANGE_HOOK, gags_amd/dist.py): same kernels on a sub-range, so the same bits as the one-shot
+    backward, and the hook sees the ranges in order on an alias of the tensor autograd receives."""
+    from gags_amd import rasterization as R
+    n, w, h, d = 5000, 192, 144, 384
+    s = scene_arrays(n, d, w, h, seed=41, view=3, scale_mult=5.0)
+    v_out = np.random.default_rng(9).standard_normal((h, w, d)).astype(np.float32)
+    _, _, _, g_full = _run_gpu(s, w, h, s["colors"], None, v_out=v_out)
+    seen = []
+    R.GRAD_RANGE_HOOK = lambda grad, c0, c1: seen.append((grad.data_ptr(), c0, c1))
+    try:
+        _, _, _, g_rng = _run_gpu(s, w, h, s["colors"], None, v_out=v_out)
+    finally:
+        R.GRAD_RANGE_HOOK = None
+    assert [(c0, c1) for _, c0, c1 in seen] == [(0, 128), (128, 256), (256, 384)]
+    assert len({p for p, _, _ in seen}) == 1
+    np.testing.assert_array_equal(g_rng["colors"], g_full["colors"])
+
+
 @pytest.mark.parametrize("n,w,h,d,seed,view", [
     (2500, 128, 96, 16, 7, 3), (2000, 100, 70, 3, 8, None),
     (2000, 112, 80, 48, 9, 5),    # two channel chunks, the second one ragged: per-chunk bg dot, v_alpha on chunk 0 only
