@@ -59,6 +59,18 @@ SIGNATURES = {
     "gags_adam_step": (_i32, [_i64, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _f64, _i32, _vp]),
     "gags_dot_scratch_bytes": (_i64, []),
     "gags_dot_f32": (_i32, [_i64, _vp, _vp, _vp, _vp, _i64, _vp]),
+    # include/gags_next.h
+    "gags_trained_seg": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp]),
+    "gags_entropy_fwd": (_i32, [_i64, _vp, _vp, _vp]),
+    "gags_entropy_bwd": (_i32, [_i64, _vp, _f32, _vp, _vp]),
+    "gags_segment_stats": (_i32, [_i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "gags_region_var_bwd": (_i32, [_i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "gags_gather_seg_coef": (_i32, [_i64, _vp, _i32, _vp, _vp, _vp]),
+    "gags_sam_clip_feature": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gags_sam_clip_feature_bwd_scale": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "gags_distill_l1_map_fwd": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gags_distill_l1_map_bwd": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gags_relevancy": (_i32, [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
 }
 
 GAGS_BWD_COLORS_ONLY = 1

@@ -1,0 +1,457 @@
+// N2 / N4: the image-space kernels either side of the rasterizer in the reference's training and query
+// loops -- ground-truth feature assembly, masked L1 map, segment-wise losses, LERF relevancy.  All HBM-bound byte /
+// gather work over [C, H, W] maps: coalesced along pixels, small tables (segment embeddings, segment statistics) left
+// to L2; nothing is reshaped into a GEMM.  Numerics follow the reference's torch ops (fp32; sums that torch does as
+// one big reduction are accumulated in double here).
+#include "common.h"
+#include "gags_next.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// get_trained_seg (utils/loss_utils.py:138-154)
+__global__ __launch_bounds__(256) void trained_seg_kernel(int h, int w, const float *__restrict__ seg_map,
+                                                          const float *__restrict__ scale_map, float *__restrict__ out)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= h * w) return;
+    const int y = p / w, x = p - y * w;
+    float best = 0.f;
+    int arg = 0;
+    for (int ch = 0; ch < 3; ++ch) {
+        float s = 0.f;  // conv2d with a 5x5 kernel of 1/25, zero padding 2
+        for (int dy = -2; dy <= 2; ++dy)
+            for (int dx = -2; dx <= 2; ++dx) {
+                const int yy = y + dy, xx = x + dx;
+                if (yy >= 0 && yy < h && xx >= 0 && xx < w) s = fmaf(scale_map[((size_t)ch * h + yy) * w + xx], 0.04f, s);
+            }
+        if (ch == 0 || s > best) { best = s; arg = ch; }  // first maximum wins, as torch.argmax
+    }
+    out[p] = seg_map[((size_t)(1 + arg) * h + y) * w + x];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// scale_regulation_loss (utils/loss_utils.py:59-66)
+__global__ __launch_bounds__(256) void entropy_fwd_kernel(int64_t n, const float *__restrict__ s, double *__restrict__ acc)
+{
+    __shared__ double sm[4];
+    double a = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = s[i];
+        a += (double)(-v * logf(v + 1e-6f));
+    }
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, (sm[0] + sm[1]) + (sm[2] + sm[3]));
+}
+
+__global__ __launch_bounds__(256) void entropy_bwd_kernel(int64_t n, const float *__restrict__ s, float v, float *__restrict__ vs)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = s[i];
+    vs[i] = -(logf(x + 1e-6f) + x / (x + 1e-6f)) * v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// per-segment moments.  One wave = 64 consecutive pixels; neighbouring pixels mostly share a segment, so when the
+// whole wave agrees it reduces first and issues ONE double atomic per moment, otherwise every lane adds its own.
+__global__ __launch_bounds__(256) void segment_stats_kernel(int64_t n_pix, int c, const float *__restrict__ x,
+                                                            const float *__restrict__ seg, int n_seg,
+                                                            double *__restrict__ s1, double *__restrict__ s2,
+                                                            int32_t *__restrict__ cnt)
+{
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int id = -1;
+    if (p < n_pix) {
+        const float f = seg[p];
+        id = (f >= 0.f && f < (float)n_seg) ? (int)f : -1;
+    }
+    const int first = __builtin_amdgcn_readfirstlane(id);
+    const bool uniform = __all(id == first);
+    if (uniform) {
+        if (first < 0) return;
+        if (lane == 0) atomicAdd(&cnt[first], 64);
+        for (int ch = 0; ch < c; ++ch) {
+            const float v = x[(size_t)ch * n_pix + p];
+            double a = v, b = (double)v * (double)v;
+            for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
+            if (lane == 0) { atomicAdd(&s1[(size_t)first * c + ch], a); atomicAdd(&s2[(size_t)first * c + ch], b); }
+        }
+    } else if (id >= 0) {
+        atomicAdd(&cnt[id], 1);
+        for (int ch = 0; ch < c; ++ch) {
+            const float v = x[(size_t)ch * n_pix + p];
+            atomicAdd(&s1[(size_t)id * c + ch], (double)v);
+            atomicAdd(&s2[(size_t)id * c + ch], (double)v * (double)v);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void region_var_bwd_kernel(int64_t n_pix, int c, const float *__restrict__ x,
+                                                             const float *__restrict__ seg, int n_seg,
+                                                             const float *__restrict__ mean, const float *__restrict__ coef,
+                                                             float *__restrict__ vx)
+{
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_pix) return;
+    const float f = seg[p];
+    const int id = (f >= 0.f && f < (float)n_seg) ? (int)f : -1;
+    const float k = id >= 0 ? coef[id] : 0.f;
+    for (int ch = 0; ch < c; ++ch) {
+        const size_t o = (size_t)ch * n_pix + p;
+        vx[o] = id >= 0 ? k * (x[o] - mean[(size_t)id * c + ch]) : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_seg_coef_kernel(int64_t n_pix, const float *__restrict__ seg, int n_seg,
+                                                              const float *__restrict__ coef, float *__restrict__ out)
+{
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_pix) return;
+    const float f = seg[p];
+    out[p] = (f >= 0.f && f < (float)n_seg) ? coef[(int)f] : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// read_sam_clip_feature and the fused distillation L1 (scene/dataset_readers.py:54-121, train.py:165-166).
+//
+// A workgroup owns 64 consecutive pixels of the [H, W] map and walks the channels in blocks of 64.  Phase A (thread =
+// pixel x 16-channel quarter): the level features F_l[c] = bilinear blend of the embedding rows of the pixel's (up to
+// four) source pixels, rows read 64 contiguous bytes per thread; they go to LDS.  Phase B (thread = channel x pixel,
+// pixels fastest): everything that touches the channel-major maps, coalesced along pixels.
+constexpr int TP = 64;       // pixels per workgroup
+constexpr int CB = 64;       // channels per block
+constexpr int LDP = CB + 1;  // LDS row pitch (floats): conflict-free in both phases
+
+struct Taps {
+    int id[3][4];   // embedding row of (level, tap)
+    float wgt[4];   // bilinear weights of the four taps (same for every level)
+    float mask;     // 1 if all three levels have a segment at the nearest source pixel
+};
+
+__device__ __forceinline__ Taps make_taps(int p, int H, int W, int h, int w, int n_emb, const float *__restrict__ seg_map)
+{
+    Taps t;
+    const int y = p / W, x = p - y * W;
+    // torch upsample_bilinear2d, align_corners=True: src = dst * (in - 1) / (out - 1)
+    const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const float fy = sy * (float)y, fx = sx * (float)x;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    t.wgt[0] = (1.f - ly) * (1.f - lx); t.wgt[1] = (1.f - ly) * lx; t.wgt[2] = ly * (1.f - lx); t.wgt[3] = ly * lx;
+    const int sp[4] = {y0 * w + x0, y0 * w + x1, y1 * w + x0, y1 * w + x1};
+    // nearest resize of the validity mask: src = floor(dst * in / out)
+    const int ny = min((int)floorf((float)y * ((float)h / (float)H)), h - 1);
+    const int nx = min((int)floorf((float)x * ((float)w / (float)W)), w - 1);
+    bool ok = true;
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        const float *lev = seg_map + (size_t)(l + 1) * h * w;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int id = (int)lev[sp[k]];
+            t.id[l][k] = id < 0 ? id + n_emb : id;  // img_embed[-1] is the LAST row in the reference (Python indexing)
+        }
+        ok = ok && lev[ny * w + nx] != -1.0f;
+    }
+    t.mask = ok ? 1.f : 0.f;
+    return t;
+}
+
+// F_l[ch] for 16 channels starting at c0 of one pixel, as torch computes it:
+// h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11); the products by the lambdas are folded into wgt[] here
+__device__ __forceinline__ void level_feature16(const Taps &t, int l, const float *__restrict__ img_embed, int c, int c0,
+                                                float (&f)[16])
+{
+#pragma unroll
+    for (int j = 0; j < 16; ++j) f[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (t.wgt[k] == 0.f) continue;  // identity resize: a single tap
+        const float4 *row = reinterpret_cast<const float4 *>(img_embed + (size_t)t.id[l][k] * c + c0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = row[q];
+            f[4 * q] = fmaf(t.wgt[k], v.x, f[4 * q]); f[4 * q + 1] = fmaf(t.wgt[k], v.y, f[4 * q + 1]);
+            f[4 * q + 2] = fmaf(t.wgt[k], v.z, f[4 * q + 2]); f[4 * q + 3] = fmaf(t.wgt[k], v.w, f[4 * q + 3]);
+        }
+    }
+}
+
+// MODE 0: feature_map + mask; 1: v_scale from v_feature; 2: fused L1 map forward; 3: fused L1 map backward
+template <int MODE>
+__global__ __launch_bounds__(256) void sam_feature_kernel(int c, int H, int W, int h, int w, int n_emb,
+                                                          const float *__restrict__ pred /* 2,3: pred; 1: v_feature */,
+                                                          const float *__restrict__ img_embed,
+                                                          const float *__restrict__ seg_map,
+                                                          const float *__restrict__ scale_map,
+                                                          const float *__restrict__ v_map, float *__restrict__ out0,
+                                                          float *__restrict__ out1)
+{
+    __shared__ float F[3][TP][LDP];
+    __shared__ float red[4][TP][4];
+    const int HW = H * W;
+    const int p0 = blockIdx.x * TP;
+    // phase-A identity: pixel pa, channel quarter qa
+    const int pa = threadIdx.x >> 2, qa = threadIdx.x & 3;
+    const int pA = min(p0 + pa, HW - 1);
+    const Taps tp = make_taps(pA, H, W, h, w, n_emb, seg_map);
+    // phase-B identity: pixel pb (fastest), channel residue rb
+    const int pb = threadIdx.x & 63, rb = threadIdx.x >> 6;
+    const int pB = p0 + pb;
+    const bool inB = pB < HW;
+    const int pBc = min(pB, HW - 1);
+    float sc[3] = {0.f, 0.f, 0.f};
+    if (MODE != 1) {
+#pragma unroll
+        for (int l = 0; l < 3; ++l) sc[l] = scale_map[(size_t)l * HW + pBc];
+    }
+    // the mask of pixel pb: computed by the phase-A threads of that pixel; hand it over through LDS
+    if (qa == 0) red[0][pa][0] = tp.mask;
+    __syncthreads();
+    const float maskB = red[0][pb][0];
+    __syncthreads();
+    const float vB = (MODE == 3) ? v_map[pBc] * (1.0f / (float)c) : 0.f;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;  // MODE 2: |diff| sum in acc0; MODE 1 / 3: v_scale partials
+
+    for (int cb = 0; cb < c; cb += CB) {
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            float f[16];
+            const int c0 = cb + qa * 16;
+            if (c0 < c) level_feature16(tp, l, img_embed, c, c0, f);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) F[l][pa][qa * 16 + j] = (c0 < c) ? f[j] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int k = 0; k < CB / 4; ++k) {
+            const int cl = rb + 4 * k, ch = cb + cl;
+            if (ch >= c) break;
+            const float f0 = F[0][pb][cl], f1 = F[1][pb][cl], f2 = F[2][pb][cl];
+            const size_t o = (size_t)ch * HW + pBc;
+            if (MODE == 0) {
+                // feature_map_s * scale_map[0] + feature_map_m * scale_map[1] + feature_map_l * scale_map[2]
+                if (inB) out0[o] = (f0 * sc[0] + f1 * sc[1]) + f2 * sc[2];
+            } else if (MODE == 1) {
+                const float v = inB ? pred[o] : 0.f;
+                acc0 = fmaf(v, f0, acc0); acc1 = fmaf(v, f1, acc1); acc2 = fmaf(v, f2, acc2);
+            } else {
+                const float gt = (f0 * sc[0] + f1 * sc[1]) + f2 * sc[2];
+                const float diff = pred[o] * maskB - gt * maskB;
+                if (MODE == 2) {
+                    acc0 += fabsf(diff);
+                } else {
+                    const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+                    const float g = sgn * vB * maskB;  // d |pred*m - gt*m| / d pred, times v / c
+                    if (inB) out0[o] = g;
+                    acc0 = fmaf(-g, f0, acc0); acc1 = fmaf(-g, f1, acc1); acc2 = fmaf(-g, f2, acc2);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (MODE == 0) {
+        if (rb == 0 && inB) out1[pB] = maskB;
+        return;
+    }
+    red[rb][pb][0] = acc0; red[rb][pb][1] = acc1; red[rb][pb][2] = acc2;
+    __syncthreads();
+    if (rb == 0 && inB) {
+        if (MODE == 2) {
+            out0[pB] = ((red[0][pb][0] + red[1][pb][0]) + (red[2][pb][0] + red[3][pb][0])) / (float)c;
+            out1[pB] = maskB;
+        } else {
+            float *vs = out1;
+#pragma unroll
+            for (int l = 0; l < 3; ++l)
+                vs[(size_t)l * HW + pB] = (red[0][pb][l] + red[1][pb][l]) + (red[2][pb][l] + red[3][pb][l]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LERF relevancy (eval/openclip_encoder.py:42-56): one wave per pixel embedding, phrases in LDS.
+constexpr int REL_MAX_PHRASES = 32;
+
+__global__ __launch_bounds__(256) void relevancy_kernel(int64_t n_pix, int c, int n_pos, int n_neg,
+                                                        const float *__restrict__ embed, const float *__restrict__ pos,
+                                                        const float *__restrict__ neg, float *__restrict__ probs)
+{
+    extern __shared__ float ph[];  // [n_pos + n_neg][c]
+    const int np = n_pos + n_neg;
+    for (int i = threadIdx.x; i < np * c; i += 256) ph[i] = i < n_pos * c ? pos[i] : neg[i - n_pos * c];
+    __syncthreads();
+    __shared__ float sims[4][REL_MAX_PHRASES];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t p = (int64_t)blockIdx.x * 4 + wv;
+    if (p >= n_pix) return;
+    float e[16];  // this lane's share of the embedding (c <= 1024)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) e[q] = (lane + 64 * q < c) ? embed[(size_t)p * c + lane + 64 * q] : 0.f;
+    for (int j = 0; j < np; ++j) {
+        float d = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (lane + 64 * q < c) d = fmaf(e[q], ph[j * c + lane + 64 * q], d);
+        for (int off = 32; off > 0; off >>= 1) d += __shfl_down(d, off, 64);
+        if (lane == 0) sims[wv][j] = d;
+    }
+    if (lane != 0) return;
+    for (int j = 0; j < n_pos; ++j) {
+        float best0 = 0.f, best1 = 0.f;
+        for (int k = 0; k < n_neg; ++k) {
+            const float a = 10.f * sims[wv][j], b = 10.f * sims[wv][n_pos + k];
+            const float m = fmaxf(a, b);
+            const float ea = expf(a - m), eb = expf(b - m);
+            const float p0 = ea / (ea + eb), p1 = eb / (ea + eb);
+            if (k == 0 || p0 < best0) { best0 = p0; best1 = p1; }  // argmin keeps the first minimum
+        }
+        probs[((size_t)j * n_pix + p) * 2] = best0;
+        probs[((size_t)j * n_pix + p) * 2 + 1] = best1;
+    }
+}
+
+inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+extern "C" int gags_trained_seg(int h, int w, const float *seg_map, const float *scale_map, float *out, void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (h <= 0 || w <= 0 || !seg_map || !scale_map || !out) return GAGS_EINVAL;
+    hipLaunchKernelGGL(trained_seg_kernel, dim3(nblk((int64_t)h * w)), dim3(256), 0, (hipStream_t)stream, h, w, seg_map,
+                       scale_map, out);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+extern "C" int gags_entropy_fwd(int64_t n, const float *s, double *acc, void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (n < 0 || !acc || (n > 0 && !s)) return GAGS_EINVAL;
+    if (n == 0) return GAGS_OK;
+    const unsigned grid = (unsigned)(nblk(n) < 2048u ? nblk(n) : 2048u);
+    hipLaunchKernelGGL(entropy_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, s, acc);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+extern "C" int gags_entropy_bwd(int64_t n, const float *s, float v_over_n, float *v_s, void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (n < 0 || (n > 0 && (!s || !v_s))) return GAGS_EINVAL;
+    if (n == 0) return GAGS_OK;
+    hipLaunchKernelGGL(entropy_bwd_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, n, s, v_over_n, v_s);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+extern "C" int gags_segment_stats(int64_t n_pix, int c, const float *x, const float *seg, int n_seg, double *s1, double *s2,
+                                  int32_t *cnt, void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (n_pix < 0 || c <= 0 || n_seg <= 0 || !s1 || !s2 || !cnt || (n_pix > 0 && (!x || !seg))) return GAGS_EINVAL;
+    if (n_pix == 0) return GAGS_OK;
+    hipLaunchKernelGGL(segment_stats_kernel, dim3(nblk(n_pix)), dim3(256), 0, (hipStream_t)stream, n_pix, c, x, seg, n_seg,
+                       s1, s2, cnt);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+extern "C" int gags_region_var_bwd(int64_t n_pix, int c, const float *x, const float *seg, int n_seg, const float *mean,
+                                   const float *coef, float *v_x, void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (n_pix < 0 || c <= 0 || n_seg <= 0 || (n_pix > 0 && (!x || !seg || !mean || !coef || !v_x))) return GAGS_EINVAL;
+    if (n_pix == 0) return GAGS_OK;
+    hipLaunchKernelGGL(region_var_bwd_kernel, dim3(nblk(n_pix)), dim3(256), 0, (hipStream_t)stream, n_pix, c, x, seg, n_seg,
+                       mean, coef, v_x);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+extern "C" int gags_gather_seg_coef(int64_t n_pix, const float *seg, int n_seg, const float *coef, float *out, void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (n_pix < 0 || n_seg <= 0 || (n_pix > 0 && (!seg || !coef || !out))) return GAGS_EINVAL;
+    if (n_pix == 0) return GAGS_OK;
+    hipLaunchKernelGGL(gather_seg_coef_kernel, dim3(nblk(n_pix)), dim3(256), 0, (hipStream_t)stream, n_pix, seg, n_seg, coef,
+                       out);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+namespace {
+inline bool sam_args_ok(int c, int H, int W, int h, int w, int n_emb)
+{
+    return c > 0 && c % 16 == 0 && H > 0 && W > 0 && h > 0 && w > 0 && n_emb > 0;
+}
+}  // namespace
+
+extern "C" int gags_sam_clip_feature(int c, int H, int W, int h, int w, int n_emb, const float *img_embed,
+                                     const float *seg_map, const float *scale_map, float *feature_map, float *mask,
+                                     void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (!sam_args_ok(c, H, W, h, w, n_emb) || !img_embed || !seg_map || !scale_map || !feature_map || !mask) return GAGS_EINVAL;
+    hipLaunchKernelGGL(sam_feature_kernel<0>, dim3((H * W + TP - 1) / TP), dim3(256), 0, (hipStream_t)stream, c, H, W, h, w,
+                       n_emb, (const float *)nullptr, img_embed, seg_map, scale_map, (const float *)nullptr, feature_map, mask);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+extern "C" int gags_sam_clip_feature_bwd_scale(int c, int H, int W, int h, int w, int n_emb, const float *img_embed,
+                                               const float *seg_map, const float *v_feature, float *v_scale, void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (!sam_args_ok(c, H, W, h, w, n_emb) || !img_embed || !seg_map || !v_feature || !v_scale) return GAGS_EINVAL;
+    hipLaunchKernelGGL(sam_feature_kernel<1>, dim3((H * W + TP - 1) / TP), dim3(256), 0, (hipStream_t)stream, c, H, W, h, w,
+                       n_emb, v_feature, img_embed, seg_map, (const float *)nullptr, (const float *)nullptr,
+                       (float *)nullptr, v_scale);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+extern "C" int gags_distill_l1_map_fwd(int c, int H, int W, int h, int w, int n_emb, const float *pred, const float *img_embed,
+                                       const float *seg_map, const float *scale_map, float *l1_map, float *mask, void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (!sam_args_ok(c, H, W, h, w, n_emb) || !pred || !img_embed || !seg_map || !scale_map || !l1_map || !mask)
+        return GAGS_EINVAL;
+    hipLaunchKernelGGL(sam_feature_kernel<2>, dim3((H * W + TP - 1) / TP), dim3(256), 0, (hipStream_t)stream, c, H, W, h, w,
+                       n_emb, pred, img_embed, seg_map, scale_map, (const float *)nullptr, l1_map, mask);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+extern "C" int gags_distill_l1_map_bwd(int c, int H, int W, int h, int w, int n_emb, const float *pred, const float *img_embed,
+                                       const float *seg_map, const float *scale_map, const float *v_map, float *v_pred,
+                                       float *v_scale, void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (!sam_args_ok(c, H, W, h, w, n_emb) || !pred || !img_embed || !seg_map || !scale_map || !v_map || !v_pred || !v_scale)
+        return GAGS_EINVAL;
+    hipLaunchKernelGGL(sam_feature_kernel<3>, dim3((H * W + TP - 1) / TP), dim3(256), 0, (hipStream_t)stream, c, H, W, h, w,
+                       n_emb, pred, img_embed, seg_map, scale_map, v_map, v_pred, v_scale);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+extern "C" int gags_relevancy(int64_t n_pix, int c, int n_pos, int n_neg, const float *embed, const float *pos,
+                              const float *neg, float *probs, void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (n_pix < 0 || c <= 0 || n_pos <= 0 || n_neg <= 0 || n_pos + n_neg > REL_MAX_PHRASES || c > 1024 ||
+        (size_t)(n_pos + n_neg) * c * 4 > 60000 || !pos || !neg || (n_pix > 0 && (!embed || !probs)))
+        return GAGS_EINVAL;
+    if (n_pix == 0) return GAGS_OK;
+    hipLaunchKernelGGL(relevancy_kernel, dim3((unsigned)((n_pix + 3) / 4)), dim3(256), (size_t)(n_pos + n_neg) * c * 4,
+                       (hipStream_t)stream, n_pix, c, n_pos, n_neg, embed, pos, neg, probs);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}

@@ -1,0 +1,220 @@
+"""The image-space losses and ground-truth assembly of the distillation step, same function
+names, arguments and results as the reference's, on HIP kernels (include/gags_next.h, csrc/losses.hip):
+
+    utils/loss_utils.py:20-24     l1_loss, l1_loss_map
+    utils/loss_utils.py:32-57     Scale_balance_loss(loss_map, seg_map, mask, mix_seg=True)
+    utils/loss_utils.py:59-66     scale_regulation_loss(scale_map)
+    utils/loss_utils.py:103-136   scale_region_regulation_loss(scale_map, seg_map, mix_seg=True)
+    utils/loss_utils.py:138-154   get_trained_seg(seg_map, scale_map)
+    scene/dataset_readers.py:54-121  read_sam_clip_feature(img_embed, seg_map, scale_map)   (default mode)
+and the fusion the reference's train.py:165-166 spells as three full-size elementwise passes plus a [512,H,W]
+ground-truth tensor:
+    distill_l1_map(pred, img_embed, seg_map, scale_map) == l1_loss_map(pred * mask, gt * mask), mask
+
+The reference walks the segment ids in a Python loop (one boolean-mask pass over the image per id); here one pass
+over the pixels accumulates every segment's moments (gags_segment_stats) and the tiny per-segment arithmetic is done
+on [n_seg]-sized tensors.  Only the variants train.py reaches are implemented (mix_seg=True; default gather mode);
+anything else raises.  GPU tensors only: there is no CPU path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr
+
+
+def _st():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f(t):
+    if not t.is_cuda:
+        raise RuntimeError("gags_amd.losses: tensors must live on the GPU (there is no CPU path)")
+    return t if (t.is_contiguous() and t.dtype == torch.float32) else t.contiguous().float()
+
+
+def _n_seg(seg_map):
+    # ids are small non-negative integers stored as floats; one readback sizes the statistics tables
+    return max(int(seg_map.max().item()) + 1, 1)
+
+
+def l1_loss(network_output, gt):
+    return torch.abs(network_output - gt).mean()
+
+
+def l1_loss_map(network_output, gt):
+    return torch.abs(network_output - gt).mean(dim=0)
+
+
+class _Entropy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scale_map):
+        s = _f(scale_map)
+        acc = torch.zeros(1, dtype=torch.float64, device=s.device)
+        check(_lib.load().gags_entropy_fwd(s.numel(), ptr(s), ptr(acc), _st()), "gags_entropy_fwd")
+        ctx.save_for_backward(s)
+        return (acc[0] / s.numel()).float()
+
+    @staticmethod
+    def backward(ctx, v):
+        (s,) = ctx.saved_tensors
+        vs = torch.empty_like(s)
+        check(_lib.load().gags_entropy_bwd(s.numel(), ptr(s), float(v.item()) / s.numel(), ptr(vs), _st()), "gags_entropy_bwd")
+        return vs
+
+
+def scale_regulation_loss(scale_map):
+    """mean(-s * log(s + 1e-6)) over the [3,H,W] scale map (utils/loss_utils.py:59-66)."""
+    return _Entropy.apply(scale_map)
+
+
+def _segment_stats(x, seg_map, n_seg):
+    c, n_pix = x.shape[0], seg_map.numel()
+    s1 = torch.zeros(n_seg, c, dtype=torch.float64, device=x.device)
+    s2 = torch.zeros_like(s1)
+    cnt = torch.zeros(n_seg, dtype=torch.int32, device=x.device)
+    check(_lib.load().gags_segment_stats(n_pix, c, ptr(x), ptr(seg_map), n_seg, ptr(s1), ptr(s2), ptr(cnt), _st()),
+          "gags_segment_stats")
+    return s1, s2, cnt
+
+
+class _ScaleBalance(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, loss_map, seg_map):
+        lm, seg = _f(loss_map), _f(seg_map)
+        n_seg = _n_seg(seg)
+        s1, _, cnt = _segment_stats(lm.reshape(1, -1), seg.reshape(-1), n_seg)
+        present = cnt > 0
+        k = present.sum().clamp(min=1)
+        means = torch.where(present, s1[:, 0] / cnt.clamp(min=1), torch.zeros_like(s1[:, 0]))
+        ctx.save_for_backward(seg, (present.double() / (cnt.clamp(min=1).double() * k)).float())
+        ctx.n_seg = n_seg
+        return (means.sum() / k).float()
+
+    @staticmethod
+    def backward(ctx, v):
+        seg, coef = ctx.saved_tensors
+        out = torch.empty_like(seg)
+        check(_lib.load().gags_gather_seg_coef(seg.numel(), ptr(seg), ctx.n_seg, ptr((coef * v).contiguous()), ptr(out), _st()),
+              "gags_gather_seg_coef")
+        return out, None
+
+
+def Scale_balance_loss(loss_map, seg_map, mask, scale_select_idx=1, mix_seg=False):
+    """Mean over the segments present in seg_map [H,W] of the segment's mean of loss_map [H,W]
+    (utils/loss_utils.py:32-57 with mix_seg=True, the only form train.py:167 uses; `mask` is unused there too)."""
+    if not mix_seg:
+        raise NotImplementedError("Scale_balance_loss: only mix_seg=True (train.py:167) is implemented")
+    return _ScaleBalance.apply(loss_map, seg_map)
+
+
+class _RegionVar(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, seg_map):
+        x, seg = _f(x), _f(seg_map)
+        c, hh, ww = x.shape
+        n_seg = _n_seg(seg)
+        s1, s2, cnt = _segment_stats(x.reshape(c, -1), seg.reshape(-1), n_seg)
+        n = cnt.double()
+        ok = cnt >= 2  # segments of 0 or 1 pixels are skipped (loss_utils.py:124-125)
+        nn = torch.where(ok, n, torch.full_like(n, 2.0))
+        mean = s1 / nn[:, None]
+        var = (s2 - nn[:, None] * mean * mean) / (nn[:, None] - 1.0)  # unbiased, as torch.var
+        per_seg = torch.where(ok, nn * var.mean(dim=1), torch.zeros_like(nn))
+        loss = per_seg.sum() / (hh * ww)
+        coef = torch.where(ok, 2.0 * nn / ((nn - 1.0) * c * hh * ww), torch.zeros_like(nn))
+        ctx.save_for_backward(x, seg, mean.float().contiguous(), coef.float())
+        ctx.n_seg = n_seg
+        return loss.float()
+
+    @staticmethod
+    def backward(ctx, v):
+        x, seg, mean, coef = ctx.saved_tensors
+        vx = torch.empty_like(x)
+        check(_lib.load().gags_region_var_bwd(seg.numel(), x.shape[0], ptr(x), ptr(seg), ctx.n_seg, ptr(mean),
+                                              ptr((coef * v).contiguous()), ptr(vx), _st()), "gags_region_var_bwd")
+        return vx, None
+
+
+def scale_region_regulation_loss(scale_map, seg_map, scale_bal_idx=1, mix_seg=False):
+    """sum over segments of n_seg * mean_c(var_c) / (H*W) of the map [C,H,W] under seg_map [H,W]
+    (utils/loss_utils.py:103-136 with mix_seg=True; train.py:153 feeds it the rasterized feature map)."""
+    if not mix_seg:
+        raise NotImplementedError("scale_region_regulation_loss: only mix_seg=True (train.py:153) is implemented")
+    return _RegionVar.apply(scale_map, seg_map)
+
+
+def get_trained_seg(seg_map, scale_map):
+    """seg_map [4,H,W], scale_map [3,H,W] -> [H,W]: the segment id of the level the 5x5-smoothed scale map prefers."""
+    seg, sc = _f(seg_map), _f(scale_map.detach())
+    _, h, w = seg.shape
+    out = torch.empty(h, w, device=seg.device)
+    check(_lib.load().gags_trained_seg(h, w, ptr(seg), ptr(sc), ptr(out), _st()), "gags_trained_seg")
+    return out
+
+
+class _SamFeature(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img_embed, seg_map, scale_map):
+        e, seg, sc = _f(img_embed), _f(seg_map), _f(scale_map)
+        c, (_, h, w), (_, H, W) = e.shape[1], seg.shape, sc.shape
+        feat = torch.empty(c, H, W, device=e.device)
+        mask = torch.empty(H, W, device=e.device)
+        check(_lib.load().gags_sam_clip_feature(c, H, W, h, w, e.shape[0], ptr(e), ptr(seg), ptr(sc), ptr(feat), ptr(mask),
+                                                _st()), "gags_sam_clip_feature")
+        ctx.save_for_backward(e, seg)
+        ctx.dims = (c, H, W, h, w)
+        ctx.mark_non_differentiable(mask)
+        return feat, mask
+
+    @staticmethod
+    def backward(ctx, v_feat, _v_mask):
+        e, seg = ctx.saved_tensors
+        c, H, W, h, w = ctx.dims
+        vs = torch.empty(3, H, W, device=e.device)
+        check(_lib.load().gags_sam_clip_feature_bwd_scale(c, H, W, h, w, e.shape[0], ptr(e), ptr(seg), ptr(_f(v_feat)), ptr(vs),
+                                                          _st()), "gags_sam_clip_feature_bwd_scale")
+        return None, None, vs
+
+
+def read_sam_clip_feature(img_embed, seg_map, scale_map, max_mode=False, median_mode=False, show_scale_map=False):
+    """(feature_map [C,H,W], mask [1,H,W] bool) as scene/dataset_readers.py:54-121 in its default mode."""
+    if max_mode or median_mode or show_scale_map:
+        raise NotImplementedError("read_sam_clip_feature: only the default mode (train.py:162,165) is implemented")
+    feat, mask = _SamFeature.apply(img_embed, seg_map, scale_map)
+    return feat, (mask != 0)[None]
+
+
+class _DistillL1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, img_embed, seg_map, scale_map):
+        p, e, seg, sc = _f(pred), _f(img_embed), _f(seg_map), _f(scale_map)
+        c, (_, h, w), (_, H, W) = e.shape[1], seg.shape, sc.shape
+        if p.shape != (c, H, W):
+            raise ValueError(f"pred {tuple(p.shape)} vs embeddings of width {c} and a {H}x{W} scale map")
+        l1 = torch.empty(H, W, device=p.device)
+        mask = torch.empty(H, W, device=p.device)
+        check(_lib.load().gags_distill_l1_map_fwd(c, H, W, h, w, e.shape[0], ptr(p), ptr(e), ptr(seg), ptr(sc), ptr(l1),
+                                                  ptr(mask), _st()), "gags_distill_l1_map_fwd")
+        ctx.save_for_backward(p, e, seg, sc)
+        ctx.dims = (c, H, W, h, w)
+        ctx.mark_non_differentiable(mask)
+        return l1, mask
+
+    @staticmethod
+    def backward(ctx, v_map, _v_mask):
+        p, e, seg, sc = ctx.saved_tensors
+        c, H, W, h, w = ctx.dims
+        vp = torch.empty_like(p)
+        vs = torch.empty(3, H, W, device=p.device)
+        check(_lib.load().gags_distill_l1_map_bwd(c, H, W, h, w, e.shape[0], ptr(p), ptr(e), ptr(seg), ptr(sc), ptr(_f(v_map)),
+                                                  ptr(vp), ptr(vs), _st()), "gags_distill_l1_map_bwd")
+        return vp, None, None, vs
+
+
+def distill_l1_map(pred, img_embed, seg_map, scale_map):
+    """train.py:165-166 in one pass: (l1_loss_map(pred * mask, gt * mask) [H,W], mask [1,H,W] bool) with
+    gt, mask = read_sam_clip_feature(img_embed, seg_map, scale_map); gradients reach `pred` and `scale_map`."""
+    l1, mask = _DistillL1.apply(pred, img_embed, seg_map, scale_map)
+    return l1, (mask != 0)[None]

@@ -1,0 +1,73 @@
+/*
+ * gags_next.h -- C ABI of the kernels either side of the rasterizer, same
+ * library (libgags_hip.so) and conventions as gags_raster.h: extern "C", device pointers, caller-owned memory,
+ * `stream` = hipStream_t as void*, return GAGS_OK or a negative GAGS_E* code.  fp32 unless noted.
+ *
+ * Feature / scale maps are CHANNEL-MAJOR [C, H, W] as everywhere in the reference after
+ * gaussian_renderer/__init__.py:73 (`permute(2, 0, 1)`); a segmentation map holds segment ids as floats, -1 = none
+ * (scene/cameras.py seg_map, preprocess.py:332-336).
+ */
+#ifndef GAGS_NEXT_H
+#define GAGS_NEXT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- N2: losses and ground-truth assembly of train.py:149-172 -------------------------------------------------- */
+
+/* utils/loss_utils.py:138-154 get_trained_seg: 5x5 mean filter (zero padded) of scale_map[3,h,w], arg-max level,
+ * out[h,w] = seg_map[1 + level] (seg_map[4,h,w]).  No gradient (arg-max). */
+int gags_trained_seg(int h, int w, const float *seg_map, const float *scale_map, float *out, void *stream);
+
+/* utils/loss_utils.py:59-66 scale_regulation_loss: acc[0] += sum(-s * log(s + 1e-6)) over n values (acc: one
+ * double, zeroed by the caller; loss = acc / n).  Backward: v_s[i] = -(log(s + eps) + s / (s + eps)) * v_over_n. */
+int gags_entropy_fwd(int64_t n, const float *s, double *acc, void *stream);
+int gags_entropy_bwd(int64_t n, const float *s, float v_over_n, float *v_s, void *stream);
+
+/* Per-segment first and second moments of a channel-major map x[c, n_pix] under the segment map seg[n_pix]
+ * (ids in [0, n_seg), anything negative = no segment): s1[n_seg, c], s2[n_seg, c] (double) and cnt[n_seg], all
+ * zeroed by the caller.  This is the one pass over the pixels behind both segment losses, which the reference
+ * computes with a Python loop over the segment ids (utils/loss_utils.py:47-54 Scale_balance_loss with c = 1,
+ * :117-133 scale_region_regulation_loss with c = the feature width). */
+int gags_segment_stats(int64_t n_pix, int c, const float *x, const float *seg, int n_seg, double *s1, double *s2,
+                       int32_t *cnt, void *stream);
+/* Backward of the region-variance loss: v_x[c, p] = coef[seg(p)] * (x[c, p] - mean[seg(p), c]), 0 outside segments. */
+int gags_region_var_bwd(int64_t n_pix, int c, const float *x, const float *seg, int n_seg, const float *mean,
+                        const float *coef, float *v_x, void *stream);
+/* Backward of the segment-balanced mean: out[p] = coef[seg(p)], 0 outside segments. */
+int gags_gather_seg_coef(int64_t n_pix, const float *seg, int n_seg, const float *coef, float *out, void *stream);
+
+/* scene/dataset_readers.py:54-121 read_sam_clip_feature (default mode): for the three granularity levels l = 1..3 of
+ * seg_map[4, h, w] gather img_embed[n_emb, c] rows (id -1 reads the LAST row, as Python indexing does), resize
+ * bilinearly (align_corners) to the scale map's [H, W] and blend with scale_map[3, H, W]:
+ *     feature_map[c, H, W] = sum_l F_l * scale_map[l],   mask[H, W] = all three ids != -1 (nearest resize), 0/1.
+ * _bwd_scale: v_scale[l, H, W] = sum_c v_feature[c] * F_l[c]  (scale_map comes from the trainable scale decoder). */
+int gags_sam_clip_feature(int c, int H, int W, int h, int w, int n_emb, const float *img_embed, const float *seg_map,
+                          const float *scale_map, float *feature_map, float *mask, void *stream);
+int gags_sam_clip_feature_bwd_scale(int c, int H, int W, int h, int w, int n_emb, const float *img_embed,
+                                    const float *seg_map, const float *v_feature, float *v_scale, void *stream);
+
+/* train.py:165-166 fused: l1_map[H, W] = mean_c |pred * mask - gt * mask| with gt, mask = read_sam_clip_feature(...)
+ * WITHOUT materialising the [c, H, W] ground truth (4.25 GB at 1080p x 512) or the two masked copies.
+ * Backward for a cotangent v_map[H, W]: v_pred[c, H, W] and v_scale[3, H, W]. */
+int gags_distill_l1_map_fwd(int c, int H, int W, int h, int w, int n_emb, const float *pred, const float *img_embed,
+                            const float *seg_map, const float *scale_map, float *l1_map, float *mask, void *stream);
+int gags_distill_l1_map_bwd(int c, int H, int W, int h, int w, int n_emb, const float *pred, const float *img_embed,
+                            const float *seg_map, const float *scale_map, const float *v_map, float *v_pred,
+                            float *v_scale, void *stream);
+
+/* ---- N4: query-time relevancy (eval/openclip_encoder.py:42-56, 96-111) ---------------------------------------- */
+
+/* For every pixel embedding embed[n_pix, c] and every positive phrase j: the LERF relevancy pair
+ * probs[j, n_pix, 2] = softmax(10 * (sim_pos_j, sim_neg_k*)) with k* the negative phrase that minimises the positive
+ * probability.  pos[n_pos, c], neg[n_neg, c] are unit text embeddings.  One read of the embeddings for all phrases. */
+int gags_relevancy(int64_t n_pix, int c, int n_pos, int n_neg, const float *embed, const float *pos, const float *neg,
+                   float *probs, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAGS_NEXT_H */
