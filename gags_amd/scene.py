@@ -11,7 +11,8 @@ Only what `render(...)` reads is mirrored:
   `FoVx, FoVy, image_width, image_height` (mutable: render.py:115-116) and
   `world_view_transform` = W2C^T, built as utils/graphics_utils.py:38-49 does.
 
-PLY / checkpoint I/O, densification, COLMAP loading are out of scope.
+PLY / checkpoint I/O (`save_ply`, `load_ply`, `capture`, `restore`: SURVEY.md 8f N3) go through
+gags_amd/io_formats.py; densification and COLMAP loading are out of scope.
 """
 import math
 
@@ -125,6 +126,48 @@ class GaussianModel:
             m._semantic_feature = nn.Parameter(semantic_feature.contiguous().float(), requires_grad=True)
         m.active_sh_degree = sh_degree if active_sh_degree is None else active_sh_degree
         return m
+
+    # -- on-disk formats: scene/gaussian_model.py:63-113,240-318 (gags_amd/io_formats.py) ----------------------
+    def save_ply(self, path):
+        from . import io_formats
+        io_formats.write_ply(path, self._xyz, self._features_dc, self._features_rest, self._opacity, self._scaling,
+                             self._rotation, self._semantic_feature)
+
+    def load_ply(self, path, device="cuda"):
+        from . import io_formats
+        t = {k: (None if v is None else torch.from_numpy(np.array(v)).to(device)) for k, v in
+             io_formats.read_ply(path, self.max_sh_degree).items()}
+        new = GaussianModel.from_tensors(t["xyz"], t["scaling"], t["rotation"], t["opacity"], t["features_dc"],
+                                         t["features_rest"], t["semantic_feature"], sh_degree=self.max_sh_degree)
+        self.__dict__.update(new.__dict__)
+        self.active_sh_degree = self.max_sh_degree
+        return self
+
+    def capture(self):
+        """The reference's 13-tuple (scene/gaussian_model.py:63-78); the densification statistics it carries are
+        empty here (densification is dead code in the feature flow)."""
+        dev = self._xyz.device
+        n = self._xyz.shape[0]
+        return (self.active_sh_degree, self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation,
+                self._opacity, getattr(self, "max_radii2D", torch.zeros(n, device=dev)),
+                getattr(self, "xyz_gradient_accum", torch.zeros(n, 1, device=dev)),
+                getattr(self, "denom", torch.zeros(n, 1, device=dev)),
+                self.optimizer.state_dict() if self.optimizer is not None else {},
+                getattr(self, "spatial_lr_scale", 1.0), self._semantic_feature)
+
+    def restore(self, model_args, semantic_feature_lr=0.001, semantic_dim=16):
+        """12-tuple (RGB field: features start from zeros, train.py:82-94) or 13-tuple (feature field: features and
+        optimizer state are taken over), as scene/gaussian_model.py:80-113."""
+        if len(model_args) not in (12, 13):
+            raise ValueError("checkpoint tuple must have 12 or 13 entries")
+        (self.active_sh_degree, self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation,
+         self._opacity, self.max_radii2D, xyz_gradient_accum, denom, opt_dict, self.spatial_lr_scale) = model_args[:12]
+        self._semantic_feature = model_args[12] if len(model_args) == 13 else None
+        self.training_setup(semantic_feature_lr, semantic_dim)
+        if len(model_args) == 13 and opt_dict:
+            self.optimizer.load_state_dict(opt_dict)
+        self.xyz_gradient_accum, self.denom = xyz_gradient_accum, denom
+        return self
 
     def training_setup(self, semantic_feature_lr=0.001, semantic_dim=16):
         """Feature-only optimisation, as scene/gaussian_model.py:183-208."""
