@@ -59,6 +59,27 @@ int gags_distill_l1_map_bwd(int c, int H, int W, int h, int w, int n_emb, const 
                             const float *seg_map, const float *scale_map, const float *v_map, float *v_pred,
                             float *v_scale, void *stream);
 
+/* ---- N1: the per-pixel decoders (models/networks.py:109-248: stacks of 1x1 convolutions) ---------------------- */
+
+/* fp32 pixel-major x[n_pix, c] (the rasterizer's own [H, W, D] output) -> bf16 y[n_pix, c_pad], zero-padded
+ * (c_pad % 32 == 0). */
+int gags_decoder_pack_input(int64_t n_pix, int c, int c_pad, const float *x, void *y_bf16, void *stream);
+
+/* One 1x1-convolution layer as a GEMM on the 16-bit matrix cores (bf16 operands, fp32 accumulate):
+ *     y[p, n] = act( sum_k (a1[p, k] + a2[p, k]) * w[n, k] + bias[n] ) * (mask_src[p, n] > 0) + residual[p, n]
+ * a1, a2 (optional: the residual sums x1 + x2 / x3 + x4 of CNN_decoder.forward), w, mask_src (optional), residual
+ * (optional), y_bf16: bf16; bias (optional), y_f32 (optional second output): fp32.  k_in % 32 == 0, n_out % 4 == 0.
+ * The backward's input-gradient GEMM is the same call with w = W^T, mask_src = the layer below's output (its ReLU
+ * mask) and residual = the gradient arriving over a skip connection. */
+int gags_decoder_layer(int64_t n_pix, int n_out, int k_in, const void *a1, const void *a2, const void *w,
+                       const float *bias, int relu, const void *mask_src, const void *residual, void *y_bf16,
+                       float *y_f32, void *stream);
+
+/* Output head: pixel-major fp32 logits x[n_pix, ld] (first c columns) -> CHANNEL-major out[c, n_pix] (the
+ * reference's [C, H, W]); mode 0 = F.normalize(dim=0) (CNN_decoder, :192), mode 1 = softmax over channels
+ * (CNN_scale_decoder, :242). */
+int gags_decoder_head(int64_t n_pix, int c, int ld, int mode, const float *x, float *out, void *stream);
+
 /* ---- N4: query-time relevancy (eval/openclip_encoder.py:42-56, 96-111) ---------------------------------------- */
 
 /* For every pixel embedding embed[n_pix, c] and every positive phrase j: the LERF relevancy pair
