@@ -6,7 +6,7 @@
 // Layout: activations are PIXEL-major [P, C] bf16 -- what the rasterizer writes is [H, W, D] already, so the
 // 16-channel render feeds layer 0 without the reference's permute -- weights [C_out, C_in] bf16 (C_in contiguous:
 // both MFMA operands are then 16-byte rows).  One kernel serves every layer:
-//     Y[p, n] = act( sum_k (A1[p, k] (+ A2[p, k])) * W[n, k] + bias[n] ) (* mask) (+ E[p, n])
+//     Y[p, n] = ( act( sum_k (A1[p, k] (+ A2[p, k])) * W[n, k] + bias[n] ) (+ E[p, n]) ) (* mask)
 // with the second source for the residual sums (x1 + x2, x3 + x4 of CNN_decoder.forward) and, in the backward, the
 // ReLU mask of the layer below and the residual's gradient in the epilogue.
 #include "common.h"
@@ -26,20 +26,28 @@ __device__ __forceinline__ unsigned short f2bf(float f)
 }
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 
-constexpr int TM = 128, TN = 128, TK = 32;  // workgroup tile: 128 pixels x 128 outputs, K step 32
-constexpr int LDK = TK + 8;                  // LDS row pitch in bf16 (80 B: 16-byte aligned, spreads the banks)
+constexpr int TM = 128, TN = 128, TK = 64;  // workgroup tile: 128 pixels x 128 outputs, K step 64
+constexpr int LDK = TK + 8;                  // LDS row pitch in bf16 (144 B: 16-byte aligned, spreads the banks)
 
 struct GemmArgs {
     const unsigned short *A1, *A2;  // [P, K] bf16, A2 optional (summed with A1 in fp32, rounded once)
     const unsigned short *W;        // [N, K] bf16
     const float *bias;              // [N] or null
     const unsigned short *mask_src; // [P, N] bf16 or null: output multiplied by (mask_src > 0)
-    const unsigned short *E;        // [P, N] bf16 or null: added after the mask
+    const unsigned short *E;        // [P, N] bf16 or null: added before the mask
     unsigned short *Y;              // [P, N] bf16 or null
+    unsigned short *Ypre;           // [P, N] bf16 or null: the value before the mask (a skip connection's gradient)
     float *Yf;                      // [P, N] fp32 or null
     int64_t P;
     int N, K, relu;
 };
+
+__device__ __forceinline__ unsigned add_bf16x2(unsigned x, unsigned y)
+{
+    const float lo = bf2f((unsigned short)(x & 0xffff)) + bf2f((unsigned short)(y & 0xffff));
+    const float hi = bf2f((unsigned short)(x >> 16)) + bf2f((unsigned short)(y >> 16));
+    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
 
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a)
 {
@@ -56,32 +64,34 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a)
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // staging identity: row tid / 2, 16 consecutive k at 16 * (tid % 2)
-    const int sr = tid >> 1, sh = (tid & 1) * 16;
-    const int64_t arow = min(p0 + sr, a.P - 1);
-    const int brow = min(n0 + sr, a.N - 1);
-    for (int k0 = 0; k0 < a.K; k0 += TK) {
-        {
-            const uint4 *src = reinterpret_cast<const uint4 *>(a.A1 + arow * a.K + k0 + sh);
-            uint4 u0 = src[0], u1 = src[1];
-            if (a.A2) {  // residual sum of two activations: add in fp32, round once
-                const uint4 *s2 = reinterpret_cast<const uint4 *>(a.A2 + arow * a.K + k0 + sh);
-                const uint4 v0 = s2[0], v1 = s2[1];
-                auto add2 = [](unsigned x, unsigned y) {
-                    const float lo = bf2f((unsigned short)(x & 0xffff)) + bf2f((unsigned short)(y & 0xffff));
-                    const float hi = bf2f((unsigned short)(x >> 16)) + bf2f((unsigned short)(y >> 16));
-                    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
-                };
-                u0 = make_uint4(add2(u0.x, v0.x), add2(u0.y, v0.y), add2(u0.z, v0.z), add2(u0.w, v0.w));
-                u1 = make_uint4(add2(u1.x, v1.x), add2(u1.y, v1.y), add2(u1.z, v1.z), add2(u1.w, v1.w));
+    // staging identity: 16-byte piece tid % 8 of rows tid / 8 + 32 q (eight consecutive lanes read one row's 128
+    // contiguous bytes: fully coalesced); the next K step's operands are requested into registers before the current
+    // one is multiplied (the K loop is only 4-8 steps long: no deeper pipeline)
+    const int sr = tid >> 3, sh = (tid & 7) * 8;
+    uint4 ra[4], rb[4];
+    auto fetch = [&](int k0) {
+        const bool ok = k0 + sh < a.K;  // K is a multiple of 32, the step is 64
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t arow = min(p0 + sr + 32 * q, a.P - 1);
+            const int brow = min(n0 + sr + 32 * q, a.N - 1);
+            ra[q] = ok ? *reinterpret_cast<const uint4 *>(a.A1 + arow * a.K + k0 + sh) : make_uint4(0, 0, 0, 0);
+            rb[q] = ok ? *reinterpret_cast<const uint4 *>(a.W + (size_t)brow * a.K + k0 + sh) : make_uint4(0, 0, 0, 0);
+            if (a.A2 && ok) {  // residual sum of two activations: add in fp32, round once
+                const uint4 v = *reinterpret_cast<const uint4 *>(a.A2 + arow * a.K + k0 + sh);
+                ra[q] = make_uint4(add_bf16x2(ra[q].x, v.x), add_bf16x2(ra[q].y, v.y), add_bf16x2(ra[q].z, v.z), add_bf16x2(ra[q].w, v.w));
             }
-            *reinterpret_cast<uint4 *>(&As[sr][sh]) = u0;
-            *reinterpret_cast<uint4 *>(&As[sr][sh + 8]) = u1;
-            const uint4 *wsrc = reinterpret_cast<const uint4 *>(a.W + (size_t)brow * a.K + k0 + sh);
-            *reinterpret_cast<uint4 *>(&Bs[sr][sh]) = wsrc[0];
-            *reinterpret_cast<uint4 *>(&Bs[sr][sh + 8]) = wsrc[1];
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < a.K; k0 += TK) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<uint4 *>(&As[sr + 32 * q][sh]) = ra[q];
+            *reinterpret_cast<uint4 *>(&Bs[sr + 32 * q][sh]) = rb[q];
         }
         __syncthreads();
+        if (k0 + TK < a.K) fetch(k0 + TK);
 #pragma unroll
         for (int ks = 0; ks < TK; ks += 16) {
             bf16x8 af[2], bf[2];
@@ -119,17 +129,20 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a)
                     v[q] = t;
                 }
                 const size_t o = (size_t)p * a.N + n;
+                if (a.E) {
+                    const uint2 e = *reinterpret_cast<const uint2 *>(a.E + o);
+                    v[0] += bf2f((unsigned short)(e.x & 0xffff)); v[1] += bf2f((unsigned short)(e.x >> 16));
+                    v[2] += bf2f((unsigned short)(e.y & 0xffff)); v[3] += bf2f((unsigned short)(e.y >> 16));
+                }
+                if (a.Ypre)
+                    *reinterpret_cast<uint2 *>(a.Ypre + o) = make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16),
+                                                                        (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
                 if (a.mask_src) {
                     const uint2 m = *reinterpret_cast<const uint2 *>(a.mask_src + o);
                     v[0] = bf2f((unsigned short)(m.x & 0xffff)) > 0.f ? v[0] : 0.f;
                     v[1] = bf2f((unsigned short)(m.x >> 16)) > 0.f ? v[1] : 0.f;
                     v[2] = bf2f((unsigned short)(m.y & 0xffff)) > 0.f ? v[2] : 0.f;
                     v[3] = bf2f((unsigned short)(m.y >> 16)) > 0.f ? v[3] : 0.f;
-                }
-                if (a.E) {
-                    const uint2 e = *reinterpret_cast<const uint2 *>(a.E + o);
-                    v[0] += bf2f((unsigned short)(e.x & 0xffff)); v[1] += bf2f((unsigned short)(e.x >> 16));
-                    v[2] += bf2f((unsigned short)(e.y & 0xffff)); v[3] += bf2f((unsigned short)(e.y >> 16));
                 }
                 if (a.Y)
                     *reinterpret_cast<uint2 *>(a.Y + o) = make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16),
@@ -203,6 +216,199 @@ __global__ __launch_bounds__(256) void head_kernel(int64_t P, int C, int ld, int
     }
 }
 
+// Weight gradient of one layer: dW[n, k] += sum_p dz[p, n] * (a1[p, k] + a2[p, k]),  db[n] += sum_p dz[p, n].
+// The contraction runs over PIXELS, the slow index of both operands, so the 32-pixel tiles are transposed on their
+// way into LDS (8-byte stores of four pixels of one column) and both MFMA fragments become 16-byte rows again.
+// Workgroup = (128 n) x (128 k) x (a chunk of pixels); chunks are combined with float atomics.
+constexpr int WP = 32;          // pixels per step (8 groups of 4 x 32 groups of 4 columns = 256 threads)
+constexpr int LDP2 = WP + 8;    // LDS row pitch (bf16)
+constexpr int WCHUNK = 16384;   // pixels per workgroup
+
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(int64_t P, int N, int K, const unsigned short *__restrict__ dz,
+                                                         const unsigned short *__restrict__ a1,
+                                                         const unsigned short *__restrict__ a2, float *__restrict__ dW,
+                                                         float *__restrict__ db)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short At[128][LDP2];  // [n][p]
+    __shared__ __attribute__((aligned(16))) unsigned short Bt[128][LDP2];  // [k][p]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wy = wave >> 1, wx = wave & 1;
+    const int n0 = blockIdx.y * 128, k0 = blockIdx.z * 128;
+    const int64_t pa = (int64_t)blockIdx.x * WCHUNK, pb = min(pa + WCHUNK, P);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // staging: thread = 4 consecutive pixels x 4 consecutive columns; a column's four pixels go to LDS as one 8-byte
+    // store (the transposition), 8 stores per thread and step instead of 32 two-byte ones
+    const int sp = (tid >> 5) * 4, sc = (tid & 31) * 4;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = db != nullptr && blockIdx.z == 0;
+    for (int64_t p0 = pa; p0 < pb; p0 += WP) {
+        uint2 zr[4], xr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t p = p0 + sp + r;
+            zr[r] = xr[r] = make_uint2(0, 0);
+            if (p < pb) {
+                if (n0 + sc < N) zr[r] = *reinterpret_cast<const uint2 *>(dz + p * N + n0 + sc);
+                if (k0 + sc < K) {
+                    xr[r] = *reinterpret_cast<const uint2 *>(a1 + p * K + k0 + sc);
+                    if (a2) {
+                        const uint2 y = *reinterpret_cast<const uint2 *>(a2 + p * K + k0 + sc);
+                        xr[r] = make_uint2(add_bf16x2(xr[r].x, y.x), add_bf16x2(xr[r].y, y.y));
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {  // column c of the thread's 4: its four pixels, packed
+            auto col = [&](const uint2 (&v)[4]) {
+                unsigned short e[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned wv = (c < 2) ? v[r].x : v[r].y;
+                    e[r] = (unsigned short)((c & 1) ? (wv >> 16) : (wv & 0xffff));
+                }
+                return make_uint2((unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16));
+            };
+            const uint2 zc = col(zr), xc = col(xr);
+            *reinterpret_cast<uint2 *>(&At[sc + c][sp]) = zc;
+            *reinterpret_cast<uint2 *>(&Bt[sc + c][sp]) = xc;
+            if (do_bias)
+                bsum[c] += (bf2f((unsigned short)(zc.x & 0xffff)) + bf2f((unsigned short)(zc.x >> 16))) +
+                           (bf2f((unsigned short)(zc.y & 0xffff)) + bf2f((unsigned short)(zc.y >> 16)));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < WP; ks += 16) {
+            bf16x8 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                af[i] = *reinterpret_cast<const bf16x8 *>(&At[wy * 64 + i * 32 + (lane & 31)][ks + 8 * (lane >> 5)]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                bf[j] = *reinterpret_cast<const bf16x8 *>(&Bt[wx * 64 + j * 32 + (lane & 31)][ks + 8 * (lane >> 5)]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // accumulator: column = lane & 31 -> k, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -> n
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = k0 + wx * 64 + j * 32 + (lane & 31);
+            if (k >= K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wy * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (n < N) __hip_atomic_fetch_add(dW + (size_t)n * K + k, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    if (do_bias) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (n0 + sc + c < N) __hip_atomic_fetch_add(db + n0 + sc + c, bsum[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// backward of the output heads: channel-major cotangent G[C, P] and the saved pixel-major logits x[P, ld] ->
+// pixel-major bf16 dz[P, ld] (columns >= C zero).
+//   mode 0 (y = x / max(||x||, eps)):  dz = (g - y <y, g>) / max(||x||, eps)
+//   mode 1 (y = softmax(x)):           dz = y * (g - <y, g>)
+__global__ __launch_bounds__(256) void head_bwd_kernel(int64_t P, int C, int ld, int mode, const float *__restrict__ x,
+                                                       const float *__restrict__ G, unsigned short *__restrict__ dz)
+{
+    __shared__ float tile[64][65];
+    __shared__ float stat[64][3];
+    const int64_t p0 = (int64_t)blockIdx.x * 64;
+    const int tid = threadIdx.x;
+    // pass 1a: norm / (max, Z) per pixel from the logits
+    {
+        const int px = tid >> 2, q = tid & 3;
+        const int64_t p = min(p0 + px, P - 1);
+        float s = 0.f, m = -3.0e38f;
+        for (int c = q; c < C; c += 4) {
+            const float v = x[p * ld + c];
+            s = fmaf(v, v, s);
+            m = fmaxf(m, v);
+        }
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+        m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2));
+        float z = 0.f;
+        if (mode == 1) {
+            for (int c = q; c < C; c += 4) z += expf(x[p * ld + c] - m);
+            z += __shfl_xor(z, 1); z += __shfl_xor(z, 2);
+        }
+        if (q == 0) { stat[px][0] = mode == 0 ? fmaxf(sqrtf(s), 1e-12f) : m; stat[px][1] = z; stat[px][2] = 0.f; }
+    }
+    __syncthreads();
+    // pass 1b: <y, g> per pixel (G is channel-major: transpose block-wise through LDS)
+    float part = 0.f;  // thread = pixel tid & 63, channels (tid >> 6) + 4 j of each block
+    for (int cb = 0; cb < C; cb += 64) {
+        for (int e = tid; e < 64 * 64; e += 256) {
+            const int c = e >> 6, px = e & 63;
+            tile[px][c] = (cb + c < C && p0 + px < P) ? G[(size_t)(cb + c) * P + p0 + px] : 0.f;
+        }
+        __syncthreads();
+        {
+            const int px = tid & 63;
+            const int64_t p = min(p0 + px, P - 1);
+            for (int c = tid >> 6; c < 64 && cb + c < C; c += 4) {
+                const float v = x[p * ld + cb + c];
+                const float y = mode == 0 ? v / stat[px][0] : expf(v - stat[px][0]) / stat[px][1];
+                part = fmaf(y, tile[px][c], part);
+            }
+        }
+        __syncthreads();
+    }
+    atomicAdd(&stat[tid & 63][2], part);
+    __syncthreads();
+    // pass 2: dz, pixel-major bf16
+    for (int cb = 0; cb < ld; cb += 64) {
+        for (int e = tid; e < 64 * 64; e += 256) {
+            const int c = e >> 6, px = e & 63;
+            tile[px][c] = (cb + c < C && p0 + px < P) ? G[(size_t)(cb + c) * P + p0 + px] : 0.f;
+        }
+        __syncthreads();
+        for (int e = tid; e < 64 * 64; e += 256) {
+            const int px = e >> 6, c = e & 63;
+            if (p0 + px >= P || cb + c >= ld) continue;
+            float d = 0.f;
+            if (cb + c < C) {
+                const float v = x[(p0 + px) * ld + cb + c], g = tile[px][c], dot = stat[px][2];
+                if (mode == 0) {
+                    const float nrm = stat[px][0];
+                    d = (g - (v / nrm) * dot) / nrm;
+                } else {
+                    const float y = expf(v - stat[px][0]) / stat[px][1];
+                    d = y * (g - dot);
+                }
+            }
+            dz[(p0 + px) * ld + cb + c] = f2bf(d);
+        }
+        __syncthreads();
+    }
+}
+
+// bf16 [P, ld] -> fp32 [P, C] (first C columns): the input gradient in the rasterizer's [H, W, D] layout
+__global__ __launch_bounds__(256) void unpack_f32_kernel(int64_t P, int C, int ld, const unsigned short *__restrict__ x,
+                                                         float *__restrict__ y)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P * C) return;
+    const int64_t p = i / C;
+    y[i] = bf2f(x[p * ld + (i - p * C)]);
+}
+
 }  // namespace
 
 extern "C" int gags_decoder_pack_input(int64_t n_pix, int c, int c_pad, const float *x, void *y_bf16, void *stream)
@@ -218,16 +424,17 @@ extern "C" int gags_decoder_pack_input(int64_t n_pix, int c, int c_pad, const fl
 
 extern "C" int gags_decoder_layer(int64_t n_pix, int n_out, int k_in, const void *a1, const void *a2, const void *w,
                                   const float *bias, int relu, const void *mask_src, const void *residual, void *y_bf16,
-                                  float *y_f32, void *stream)
+                                  void *y_premask_bf16, float *y_f32, void *stream)
 {
     GAGS_CLEAR_ERR();
-    if (n_pix < 0 || n_out <= 0 || k_in <= 0 || k_in % 32 != 0 || n_out % 4 != 0 || !a1 || !w || (!y_bf16 && !y_f32))
+    if (n_pix < 0 || n_out <= 0 || k_in <= 0 || k_in % 32 != 0 || n_out % 4 != 0 || !a1 || !w ||
+        (!y_bf16 && !y_f32 && !y_premask_bf16))
         return GAGS_EINVAL;
     if (n_pix == 0) return GAGS_OK;
     GemmArgs g;
     g.A1 = (const unsigned short *)a1; g.A2 = (const unsigned short *)a2; g.W = (const unsigned short *)w; g.bias = bias;
     g.mask_src = (const unsigned short *)mask_src; g.E = (const unsigned short *)residual;
-    g.Y = (unsigned short *)y_bf16; g.Yf = y_f32; g.P = n_pix; g.N = n_out; g.K = k_in; g.relu = relu;
+    g.Y = (unsigned short *)y_bf16; g.Ypre = (unsigned short *)y_premask_bf16; g.Yf = y_f32; g.P = n_pix; g.N = n_out; g.K = k_in; g.relu = relu;
     hipLaunchKernelGGL(gemm_bf16_kernel, dim3((unsigned)((n_pix + TM - 1) / TM), (unsigned)((n_out + TN - 1) / TN)), dim3(256), 0,
                        (hipStream_t)stream, g);
     GAGS_CHECK_LAUNCH();
@@ -240,6 +447,43 @@ extern "C" int gags_decoder_head(int64_t n_pix, int c, int ld, int mode, const f
     if (n_pix < 0 || c <= 0 || ld < c || (mode != 0 && mode != 1) || (n_pix > 0 && (!x || !out))) return GAGS_EINVAL;
     if (n_pix == 0) return GAGS_OK;
     hipLaunchKernelGGL(head_kernel, dim3((unsigned)((n_pix + 63) / 64)), dim3(256), 0, (hipStream_t)stream, n_pix, c, ld, mode, x, out);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+extern "C" int gags_decoder_wgrad(int64_t n_pix, int n_out, int k_in, const void *dz, const void *a1, const void *a2,
+                                  float *d_w, float *d_b, void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (n_pix < 0 || n_out <= 0 || k_in <= 0 || n_out % 16 != 0 || k_in % 16 != 0 || !dz || !a1 || !d_w) return GAGS_EINVAL;
+    if (n_pix == 0) return GAGS_OK;
+    hipLaunchKernelGGL(wgrad_bf16_kernel, dim3((unsigned)((n_pix + WCHUNK - 1) / WCHUNK), (unsigned)((n_out + 127) / 128),
+                                               (unsigned)((k_in + 127) / 128)),
+                       dim3(256), 0, (hipStream_t)stream, n_pix, n_out, k_in, (const unsigned short *)dz,
+                       (const unsigned short *)a1, (const unsigned short *)a2, d_w, d_b);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+extern "C" int gags_decoder_head_bwd(int64_t n_pix, int c, int ld, int mode, const float *x, const float *g, void *dz_bf16,
+                                     void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (n_pix < 0 || c <= 0 || ld < c || (mode != 0 && mode != 1) || (n_pix > 0 && (!x || !g || !dz_bf16))) return GAGS_EINVAL;
+    if (n_pix == 0) return GAGS_OK;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((n_pix + 63) / 64)), dim3(256), 0, (hipStream_t)stream, n_pix, c, ld, mode,
+                       x, g, (unsigned short *)dz_bf16);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+extern "C" int gags_decoder_unpack_grad(int64_t n_pix, int c, int ld, const void *x_bf16, float *y, void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (n_pix < 0 || c <= 0 || ld < c || (n_pix > 0 && (!x_bf16 || !y))) return GAGS_EINVAL;
+    if (n_pix == 0) return GAGS_OK;
+    hipLaunchKernelGGL(unpack_f32_kernel, dim3((unsigned)((n_pix * c + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_pix, c,
+                       ld, (const unsigned short *)x_bf16, y);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }

@@ -9,8 +9,11 @@ GEMM kernels (include/gags_next.h N1, csrc/decoder.hip) instead of cuDNN 1x1 con
 Input: [C,H,W]; when it is the rasterizer's output (a permuted view of [H,W,C] memory, gaussian_renderer.py) the
 pixel-major layout the kernels want is already there and nothing is transposed.  Output: [C_out,H,W] fp32, contiguous.
 
-Precision: bf16 operands, fp32 accumulation, activations kept in bf16 between layers.  The reference's cuDNN path uses
-TF32 by PyTorch default; against its fp32 CPU results the outputs agree to ~5e-3 relative (tests/test_decoders_gpu.py).
+Precision: bf16 operands, fp32 accumulation, activations and their gradients kept in bf16 between layers.  The
+reference's cuDNN path uses TF32 by PyTorch default; against its fp32 CPU results the outputs agree to ~5e-3 and the
+gradients to ~2e-2 relative (tests/test_decoders_gpu.py).  Backward: input-gradient GEMMs are the forward kernel with
+W^T (ReLU mask and skip-connection gradient fused into the epilogue), weight gradients contract over the pixels
+(gags_decoder_wgrad); the input gradient comes back in the rasterizer's [H,W,C] layout.
 """
 import ctypes
 
@@ -38,9 +41,140 @@ def _pixel_major(x):
     return xp.reshape(h * w, c), h, w
 
 
+def _layer(n_pix, w, b, a1, a2=None, relu=True, f32=False, mask_src=None, residual=None, premask=False):
+    """One GEMM layer (gags_decoder_layer).  Returns y (bf16, or fp32 with f32=True) and, with premask=True, also the
+    bf16 value before the mask."""
+    n, k = w.shape
+    dev = w.device
+    y = None if f32 else torch.empty(n_pix, n, dtype=torch.bfloat16, device=dev)
+    yf = torch.empty(n_pix, n, device=dev) if f32 else None
+    ypre = torch.empty(n_pix, n, dtype=torch.bfloat16, device=dev) if premask else None
+    check(_lib.load().gags_decoder_layer(n_pix, n, k, ptr(a1), ptr(a2), ptr(w), ptr(b), int(relu), ptr(mask_src),
+                                         ptr(residual), ptr(y), ptr(ypre), ptr(yf), _st()), "gags_decoder_layer")
+    out = yf if f32 else y
+    return (out, ypre) if premask else out
+
+
+def _wgrad(n_pix, dz, a1, a2, n, k):
+    dw = torch.zeros(n, k, device=dz.device)
+    db = torch.zeros(n, device=dz.device)
+    check(_lib.load().gags_decoder_wgrad(n_pix, n, k, ptr(dz), ptr(a1), ptr(a2), ptr(dw), ptr(db), _st()), "gags_decoder_wgrad")
+    return dw, db
+
+
+def _pack_weights(weights, biases):
+    """bf16 [N_pad, K_pad] weights + their transposes (for the input-gradient GEMMs) and fp32 [N_pad] biases; every
+    dimension zero-padded to a multiple of 32."""
+    out = []
+    for wt, bs in zip(weights, biases):
+        co, ci = wt.shape[:2]
+        w = torch.zeros(_pad32(co), _pad32(ci), device=wt.device, dtype=torch.bfloat16)
+        w[:co, :ci] = wt.detach()[:, :, 0, 0].to(torch.bfloat16)
+        b = torch.zeros(_pad32(co), device=wt.device)
+        b[:co] = bs.detach()
+        out.append((w, b))
+    return out
+
+
+class _DecoderFn(torch.autograd.Function):
+    """Forward and backward of a decoder as GEMM launches.  `kind` = "decoder" (CNN_decoder: two residual sums,
+    normalize head) or "scale" (CNN_scale_decoder: plain chain, softmax head).  params = w0, b0, w1, b1, ..."""
+
+    @staticmethod
+    def forward(ctx, x, kind, c_out, *params):
+        weights, biases = params[0::2], params[1::2]
+        wb = _pack_weights(weights, biases)
+        xp, h, w = _pixel_major(x)
+        p = h * w
+        a0 = torch.empty(p, wb[0][0].shape[1], dtype=torch.bfloat16, device=x.device)
+        check(_lib.load().gags_decoder_pack_input(p, xp.shape[1], a0.shape[1], ptr(xp), ptr(a0), _st()), "gags_decoder_pack_input")
+        acts = [a0]
+        if kind == "decoder":
+            x1 = _layer(p, *wb[0], a0)
+            t1 = _layer(p, *wb[1], x1)
+            x2 = _layer(p, *wb[2], t1)
+            x3 = _layer(p, *wb[3], x1, x2)   # conv(x1 + x2)
+            t4 = _layer(p, *wb[4], x3)
+            x4 = _layer(p, *wb[5], t4)
+            t6 = _layer(p, *wb[6], x3, x4)   # conv(x3 + x4)
+            t7 = _layer(p, *wb[7], t6)
+            logits = _layer(p, *wb[8], t7, relu=False, f32=True)
+            acts += [x1, t1, x2, x3, t4, x4, t6, t7]
+        else:
+            a = a0
+            for i, (wt, b) in enumerate(wb):
+                last = i + 1 == len(wb)
+                a = _layer(p, wt, b, a, relu=not last, f32=last)
+                if not last:
+                    acts.append(a)
+            logits = a
+        out = torch.empty(c_out, h, w, device=x.device)
+        check(_lib.load().gags_decoder_head(p, c_out, logits.shape[1], 0 if kind == "decoder" else 1, ptr(logits), ptr(out), _st()),
+              "gags_decoder_head")
+        ctx.kind, ctx.c_out, ctx.hw, ctx.c_in = kind, c_out, (h, w), xp.shape[1]
+        ctx.wb = wb
+        ctx.shapes = [tuple(t.shape) for t in weights]
+        ctx.save_for_backward(logits, *acts)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, *acts = ctx.saved_tensors
+        wb, (h, w), kind = ctx.wb, ctx.hw, ctx.kind
+        p = h * w
+        lib = _lib.load()
+        g = g if (g.is_contiguous() and g.dtype == torch.float32) else g.contiguous().float()
+        dz = torch.empty(p, logits.shape[1], dtype=torch.bfloat16, device=g.device)
+        check(lib.gags_decoder_head_bwd(p, ctx.c_out, logits.shape[1], 0 if kind == "decoder" else 1, ptr(logits), ptr(g), ptr(dz),
+                                        _st()), "gags_decoder_head_bwd")
+        wt = [wgt.t().contiguous() for wgt, _ in wb]  # [K_pad, N_pad]: the input-gradient GEMM contracts over N
+        dws = [None] * len(wb)
+
+        def wg(i, dz_i, a1, a2=None):
+            dws[i] = _wgrad(p, dz_i, a1, a2, *wb[i][0].shape)
+
+        def dx(i, dz_i, mask_src=None, residual=None, premask=False):
+            return _layer(p, wt[i], None, dz_i, relu=False, mask_src=mask_src, residual=residual, premask=premask)
+
+        if kind == "decoder":
+            a0, x1, t1, x2, x3, t4, x4, t6, t7 = acts
+            wg(8, dz, t7)
+            dz7 = dx(8, dz, mask_src=t7)
+            wg(7, dz7, t6)
+            dz6 = dx(7, dz7, mask_src=t6)
+            wg(6, dz6, x3, x4)
+            dz5, g36 = dx(6, dz6, mask_src=x4, premask=True)     # d(x3 + x4): masked for x4's ReLU, raw for the skip to x3
+            wg(5, dz5, t4)
+            dz4 = dx(5, dz5, mask_src=t4)
+            wg(4, dz4, x3)
+            dz3 = dx(4, dz4, mask_src=x3, residual=g36)           # both paths into x3, then its ReLU
+            wg(3, dz3, x1, x2)
+            dz2, g13 = dx(3, dz3, mask_src=x2, premask=True)
+            wg(2, dz2, t1)
+            dz1 = dx(2, dz2, mask_src=t1)
+            wg(1, dz1, x1)
+            dz0 = dx(1, dz1, mask_src=x1, residual=g13)
+            wg(0, dz0, a0)
+            gin = dx(0, dz0)
+        else:
+            cur = dz
+            for i in range(len(wb) - 1, -1, -1):
+                wg(i, cur, acts[i])
+                cur = dx(i, cur, mask_src=acts[i] if i > 0 else None)
+            gin = cur
+        gx = torch.empty(h, w, ctx.c_in, device=g.device)
+        check(lib.gags_decoder_unpack_grad(p, ctx.c_in, gin.shape[1], ptr(gin), ptr(gx), _st()), "gags_decoder_unpack_grad")
+        grads = []
+        for (dw, db), shp in zip(dws, ctx.shapes):
+            co, ci = shp[:2]
+            grads += [dw[:co, :ci].reshape(shp).contiguous(), db[:co].contiguous()]
+        return (gx.permute(2, 0, 1), None, None, *grads)
+
+
 class _Stack(nn.Module):
     """A stack of 1x1 convolutions held as nn.Conv2d (+ nn.ReLU entries: the reference's ModuleList indices, so the
-    parameter names match) whose forward is run by the GEMM kernels."""
+    parameter names match) whose forward and backward are run by the GEMM kernels."""
+    kind = "scale"
 
     def __init__(self, dims_in, dims_out):
         super().__init__()
@@ -54,67 +188,19 @@ class _Stack(nn.Module):
     def convs(self):
         return [m for m in self.decoder if isinstance(m, nn.Conv2d)]
 
-    def _packed(self):
-        """bf16 [N_pad, K_pad] weights (zero padded so that every K is a multiple of 32 and every N but the last one
-        too) and fp32 [N_pad] biases of every layer."""
-        out = []
-        convs = self.convs()
-        for i, m in enumerate(convs):
-            co, ci = m.weight.shape[:2]
-            kp = _pad32(ci)
-            np_ = _pad32(co) if i + 1 < len(convs) else (co + 3) // 4 * 4
-            w = torch.zeros(np_, kp, device=m.weight.device, dtype=torch.bfloat16)
-            w[:co, :ci] = m.weight.detach()[:, :, 0, 0].to(torch.bfloat16)
-            b = torch.zeros(np_, device=m.weight.device)
-            b[:co] = m.bias.detach()
-            out.append((w, b))
-        return out
-
-    @staticmethod
-    def _layer(n_pix, w, b, a1, a2=None, relu=True, f32=False):
-        n, k = w.shape
-        dev = w.device
-        y = None if f32 else torch.empty(n_pix, n, dtype=torch.bfloat16, device=dev)
-        yf = torch.empty(n_pix, n, device=dev) if f32 else None
-        check(_lib.load().gags_decoder_layer(n_pix, n, k, ptr(a1), ptr(a2), ptr(w), ptr(b), int(relu), None, None, ptr(y),
-                                             ptr(yf), _st()), "gags_decoder_layer")
-        return yf if f32 else y
-
-    def _input(self, x, k_pad):
+    def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("gags_amd.decoders: tensors must live on the GPU (there is no CPU path)")
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("gags_amd.decoders: forward only so far (run under torch.no_grad(); the reference "
-                                      "uses the decoders without grad in render.py / evaluate_iou_loc.py)")
-        xp, h, w = _pixel_major(x)
-        a = torch.empty(h * w, k_pad, dtype=torch.bfloat16, device=x.device)
-        check(_lib.load().gags_decoder_pack_input(h * w, xp.shape[1], k_pad, ptr(xp), ptr(a), _st()), "gags_decoder_pack_input")
-        return a, h, w
-
-    @staticmethod
-    def _head(logits, c, mode, h, w):
-        out = torch.empty(c, h, w, device=logits.device)
-        check(_lib.load().gags_decoder_head(h * w, c, logits.shape[1], mode, ptr(logits), ptr(out), _st()), "gags_decoder_head")
-        return out
+        params = [t for m in self.convs() for t in (m.weight, m.bias)]
+        return _DecoderFn.apply(x, self.kind, self.output_dim, *params)
 
 
 class CNN_decoder(_Stack):
+    kind = "decoder"
+
     def __init__(self, input_dim, output_dim):
         super().__init__([input_dim] + [256] * 8, [256] * 8 + [output_dim])
         self.output_dim = output_dim
-
-    def forward(self, x):
-        wb = self._packed()
-        a, h, w = self._input(x, wb[0][0].shape[1])
-        p = h * w
-        x1 = self._layer(p, *wb[0], a)
-        x2 = self._layer(p, *wb[2], self._layer(p, *wb[1], x1))
-        x3 = self._layer(p, *wb[3], x1, x2)                      # conv(x1 + x2)
-        x4 = self._layer(p, *wb[5], self._layer(p, *wb[4], x3))
-        x5 = self._layer(p, *wb[6], x3, x4)                      # conv(x3 + x4)
-        x5 = self._layer(p, *wb[7], x5)
-        logits = self._layer(p, *wb[8], x5, relu=False, f32=True)
-        return self._head(logits, self.output_dim, 0, h, w)       # F.normalize(dim=0)
 
 
 class CNN_scale_decoder(_Stack):
@@ -122,12 +208,3 @@ class CNN_scale_decoder(_Stack):
         dims = [64, 128, 64, 32, 16, output_dim]
         super().__init__([input_dim] + dims[:-1], dims)
         self.output_dim = output_dim
-
-    def forward(self, x):
-        wb = self._packed()
-        a, h, w = self._input(x, wb[0][0].shape[1])
-        p = h * w
-        for i, (wt, b) in enumerate(wb):
-            last = i + 1 == len(wb)
-            a = self._layer(p, wt, b, a, relu=not last, f32=last)
-        return self._head(a, self.output_dim, 1, h, w)            # softmax(dim=0)

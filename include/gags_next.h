@@ -73,7 +73,23 @@ int gags_decoder_pack_input(int64_t n_pix, int c, int c_pad, const float *x, voi
  * mask) and residual = the gradient arriving over a skip connection. */
 int gags_decoder_layer(int64_t n_pix, int n_out, int k_in, const void *a1, const void *a2, const void *w,
                        const float *bias, int relu, const void *mask_src, const void *residual, void *y_bf16,
-                       float *y_f32, void *stream);
+                       void *y_premask_bf16, float *y_f32, void *stream);
+/* (y_premask_bf16, optional: the value before the mask -- the gradient that also travels over a skip connection.) */
+
+/* Weight and bias gradient of one layer: d_w[n_out, k_in] += sum_p dz[p, n] * (a1[p, k] + a2[p, k]),
+ * d_b[n_out] += sum_p dz[p, n] (d_b optional); both fp32, zeroed by the caller, accumulated with float atomics over
+ * pixel chunks.  dz, a1, a2 (optional): bf16 pixel-major.  n_out % 16 == 0, k_in % 16 == 0. */
+int gags_decoder_wgrad(int64_t n_pix, int n_out, int k_in, const void *dz, const void *a1, const void *a2, float *d_w,
+                       float *d_b, void *stream);
+
+/* Backward of gags_decoder_head: channel-major cotangent g[c, n_pix] + the saved logits x[n_pix, ld] ->
+ * pixel-major bf16 dz[n_pix, ld]. */
+int gags_decoder_head_bwd(int64_t n_pix, int c, int ld, int mode, const float *x, const float *g, void *dz_bf16,
+                          void *stream);
+
+/* bf16 x[n_pix, ld] -> fp32 y[n_pix, c] (first c columns): the decoder's input gradient in the rasterizer's own
+ * [H, W, D] layout. */
+int gags_decoder_unpack_grad(int64_t n_pix, int c, int ld, const void *x_bf16, float *y, void *stream);
 
 /* Output head: pixel-major fp32 logits x[n_pix, ld] (first c columns) -> CHANNEL-major out[c, n_pix] (the
  * reference's [C, H, W]); mode 0 = F.normalize(dim=0) (CNN_decoder, :192), mode 1 = softmax over channels

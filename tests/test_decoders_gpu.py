@@ -16,6 +16,7 @@ sys.path.insert(0, os.path.join(HERE, "golden"))
 
 # bf16 operands (8-bit mantissa) through 9 / 6 layers against the fp32 reference
 FWD_TOL = 6e-3
+BWD_TOL = 3e-2   # gradients: bf16 activations AND bf16 gradients through every layer
 
 
 def _load(model, weights):
@@ -81,3 +82,84 @@ def test_decoder_at_render_resolution_against_fp32_torch():
         ref = torch.nn.functional.normalize(conv(16, x5), dim=0)
     got = y[:, 500:532, 900:1028]
     assert ((got - ref).double().norm() / ref.double().norm()).item() <= FWD_TOL
+
+
+def _cos(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
+
+
+def test_decoder_backward_against_reference_gradients():
+    """Input gradient (the rasterizer's cotangent in the real flow, train.py:159,174) and every weight / bias gradient
+    against autograd through the reference modules in fp32.  A low-precision forward flips the ReLU of the few units
+    whose pre-activation is within rounding of zero (a fraction f ~ 0.5 % per layer with 8-bit mantissas; TF32, what
+    the reference itself runs, flips ~0.1 %), and a flipped unit changes its gradient contribution entirely: rel-L2
+    ~ sqrt(f) per layer whatever the precision of the backward.  Hence direction (cosine) + a loose norm bound here,
+    and the exact check of the backward kernels in the next test."""
+    from gags_amd.decoders import CNN_decoder, CNN_scale_decoder
+    from make_golden_next import decoder_weights
+    wd, ws = decoder_weights(0)
+    for model, weights, pre in ((CNN_decoder(16, 512), wd, "dec"), (CNN_scale_decoder(16, 3), ws, "sdec")):
+        m = _load(model, weights)
+        x = torch.from_numpy(Z[f"{pre}_x"]).cuda().requires_grad_(True)
+        y = m(x)
+        (y * torch.from_numpy(Z[f"{pre}_G"]).cuda()).sum().backward()
+        assert _cos(x.grad.cpu().numpy(), Z[f"{pre}_vx"]) >= 0.985 and rel_l2(x.grad.cpu().numpy(), Z[f"{pre}_vx"]) <= 0.2, pre
+        for i, cv in enumerate(m.convs()):
+            gw, gb = cv.weight.grad[:, :, 0, 0].cpu().numpy(), cv.bias.grad.cpu().numpy()
+            ref = Z[f"{pre}_vw{i}"]
+            assert _cos(gw[:ref.shape[0]], ref) >= 0.985 and rel_l2(gw[:ref.shape[0]], ref) <= 0.2, (pre, i)
+            assert _cos(gb, Z[f"{pre}_vb{i}"]) >= 0.98, (pre, i)
+    # the last layer sits above every ReLU: its gradients only carry the rounding of the operands
+    last = m.convs()[-1]
+    assert rel_l2(last.weight.grad[:, :, 0, 0].cpu().numpy(), Z["sdec_vw5"]) <= 1.5e-2
+
+
+def test_decoder_backward_kernels_against_fp32_on_the_same_masks():
+    """The backward kernels proper: fp32 torch autograd through the SAME network with the weights rounded to bf16 and
+    the ReLU decisions of the kernels' own forward (a straight-through mask), at 256 x 320 pixels.  What is left is
+    the bf16 rounding of the activations and of the gradients between layers: <= 1.5e-2 rel-L2."""
+    from gags_amd import decoders as D
+    from make_golden_next import decoder_weights
+    wd, _ = decoder_weights(0)
+    dec = _load(D.CNN_decoder(16, 512), wd)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    H, W = 256, 320
+    x = torch.randn(H, W, 16, device="cuda", generator=g).permute(2, 0, 1).requires_grad_(True)
+    G = torch.randn(512, H, W, device="cuda", generator=g)
+    y = dec(x)
+    (y * G).sum().backward()
+    got = {"x": x.grad.clone(), **{f"w{i}": c.weight.grad[:, :, 0, 0].clone() for i, c in enumerate(dec.convs())},
+           **{f"b{i}": c.bias.grad.clone() for i, c in enumerate(dec.convs())}}
+    # fp32 statement with the kernels' masks
+    wb = D._pack_weights([c.weight for c in dec.convs()], [c.bias for c in dec.convs()])
+    p = H * W
+    xp = x.detach().permute(1, 2, 0).reshape(p, 16)
+    a0 = torch.zeros(p, 32, device="cuda"); a0[:, :16] = xp.to(torch.bfloat16).float()
+    Wf = [w.float().requires_grad_(True) for w, _ in wb]
+    Bf = [b.clone().requires_grad_(True) for _, b in wb]
+    a0.requires_grad_(True)
+
+    # the kernels' own chain of activations: its ReLU decisions are the masks of the fp32 statement
+    with torch.no_grad():
+        k0 = a0.detach().to(torch.bfloat16)
+        k1 = D._layer(p, *wb[0], k0); kt1 = D._layer(p, *wb[1], k1); k2 = D._layer(p, *wb[2], kt1)
+        k3 = D._layer(p, *wb[3], k1, k2); kt4 = D._layer(p, *wb[4], k3); k4 = D._layer(p, *wb[5], kt4)
+        kt6 = D._layer(p, *wb[6], k3, k4); kt7 = D._layer(p, *wb[7], kt6)
+
+    def lay(i, kern, a, a2=None):
+        inp = a if a2 is None else a + a2
+        return (inp @ Wf[i].t() + Bf[i]) * (kern.float() > 0)
+
+    x1 = lay(0, k1, a0); t1 = lay(1, kt1, x1); x2 = lay(2, k2, t1); x3 = lay(3, k3, x1, x2); t4 = lay(4, kt4, x3)
+    x4 = lay(5, k4, t4); t6 = lay(6, kt6, x3, x4); t7 = lay(7, kt7, t6)
+    logits = t7 @ Wf[8].t() + Bf[8]
+    ref_y = torch.nn.functional.normalize(logits, dim=1)
+    (ref_y * G.reshape(512, p).t()).sum().backward()
+    assert ((y.reshape(512, p).t() - ref_y).double().norm() / ref_y.double().norm()).item() <= 1.5e-2
+    errs = {"x": ((got["x"].permute(1, 2, 0).reshape(p, 16) - a0.grad[:, :16]).double().norm() / a0.grad[:, :16].double().norm()).item()}
+    for i, c in enumerate(dec.convs()):
+        co, ci = c.weight.shape[:2]
+        errs[f"w{i}"] = ((got[f"w{i}"] - Wf[i].grad[:co, :ci]).double().norm() / Wf[i].grad[:co, :ci].double().norm()).item()
+        errs[f"b{i}"] = ((got[f"b{i}"] - Bf[i].grad[:co]).double().norm() / Bf[i].grad[:co].double().norm()).item()
+    assert max(errs.values()) <= 1.5e-2, errs

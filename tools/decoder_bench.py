@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""Timing of the SURVEY 8f rows around the rasterizer at the reference's real width (D = 16, train.py:68):
+render(16-d) -> CNN_scale_decoder / CNN_decoder -> distillation losses -> backward through decoder and rasterizer,
+i.e. one iteration of train.py:142-174 on synthetic inputs (1.5 M Gaussians, 1080p).  Prints one JSON line."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from gags_amd import losses as L, synthetic as syn
+from gags_amd.decoders import CNN_decoder, CNN_scale_decoder
+from gags_amd.gaussian_renderer import render
+
+dev = torch.device("cuda", 0)
+cfg = syn.CONFIGS["C3"]
+n, w, h, d = cfg["n"], cfg["width"], cfg["height"], 16
+pc = syn.make_model(n, d, w, h, seed=0, device=dev, gen_device=dev)
+pc.training_setup()
+cam = syn.make_camera(w, h, device=dev)
+bg = torch.zeros(3, device=dev)
+dec, sdec = CNN_decoder(16, 512).to(dev), CNN_scale_decoder(16, 3).to(dev)
+g = torch.Generator(device=dev).manual_seed(0)
+n_emb = 300
+img_embed = torch.nn.functional.normalize(torch.randn(n_emb, 512, device=dev, generator=g), dim=-1)
+seg = torch.randint(-1, n_emb, (4, h // 8, w // 8), device=dev, generator=g).float().repeat_interleave(8, 1).repeat_interleave(8, 2)
+seg = seg[:, :h, :w].contiguous()
+
+
+def ev():
+    e = torch.cuda.Event(enable_timing=True); e.record(); return e
+
+
+def iteration(times=None):
+    marks = [ev()]
+    pkg = render(cam, pc, None, bg, feature_mode=True)
+    fmap = pkg["render"]; marks.append(ev())
+    scale_map = sdec(fmap.detach()); marks.append(ev())
+    seg_tr = L.get_trained_seg(seg, scale_map)
+    reg = L.scale_region_regulation_loss(fmap, seg_tr, mix_seg=True)
+    ce = L.scale_regulation_loss(scale_map); marks.append(ev())
+    f512 = dec(fmap); marks.append(ev())
+    l1m, mask = L.distill_l1_map(f512, img_embed, seg, scale_map)
+    l1 = L.Scale_balance_loss(l1m, seg_tr, mask.squeeze(0), mix_seg=True)
+    loss = 1.0 * l1 + 0.002 * ce + 0.1 * reg; marks.append(ev())
+    for m in (dec, sdec):
+        m.zero_grad(set_to_none=True)
+    pc._semantic_feature.grad = None
+    loss.backward(); marks.append(ev())
+    if times is not None:
+        torch.cuda.synchronize()
+        for k, (a, b) in zip(("render16", "scale_decoder", "seg_losses", "decoder_fwd", "distill_loss", "backward"), zip(marks, marks[1:])):
+            times.setdefault(k, []).append(a.elapsed_time(b))
+    return loss
+
+
+for _ in range(2):
+    iteration()
+torch.cuda.synchronize()
+times = {}
+t0 = time.perf_counter()
+K = 5
+for _ in range(K):
+    iteration(times)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / K
+print(json.dumps({"workload": "train.py:142-174 iteration, 1.5M Gaussians, 1920x1080, D=16 -> CNN decoders (bf16 MFMA) -> losses",
+                  "ms_per_iteration": 1e3 * dt, "iterations_per_s": 1 / dt,
+                  "stages_ms": {k: sum(v) / len(v) for k, v in times.items()}}))
