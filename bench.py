@@ -161,7 +161,7 @@ def host_cpu():
 # kernels behind each bracketed stage, by their short rocprofv3 names (tools/pmc_summary.py)
 STAGE_KERNELS = {
     "raster_fwd": ("raster_weights_kernel", "raster_fwd_feat<4>"),
-    "bwd_rows": ("raster_bwd_rows<4, false>",),
+    "bwd_rows": ("raster_bwd_rows<4>",),
     "bwd_reduce": ("reduce_rows_kernel",),
 }
 

@@ -82,6 +82,7 @@ SIGNATURES = {
 GAGS_BWD_COLORS_ONLY = 1
 GAGS_FWD_NO_MFMA = 2
 GAGS_BWD_ATOMIC = 4  # python-side: use the atomic colours-only backward instead of the staged one
+GAGS_FEAT_F16 = 32  # forward: colors is an fp16 table (include/gags_raster.h)
 GAGS_FWD_FUSED = 8  # python-side: single-kernel matrix-core forward (no scratch) instead of weights + features
 
 _lib = None

@@ -22,7 +22,7 @@ int gags_raster_weights_launch(int width, int height, int n_gauss, const void *p
                                int32_t *hit, int32_t *blk_rows, float *Tbuf, float *alphas, int32_t *last_ids,
                                hipStream_t st);
 // raster_fwd_mfma.hip
-int gags_raster_fwd_feat_launch(int d, int width, int height, int n_gauss, const float *colors,
+int gags_raster_fwd_feat_launch(int d, int width, int height, int n_gauss, const float *colors, int colors_f16,
                                 const float *backgrounds, const int32_t *offsets, int n_isects,
                                 const int32_t *blk_rows, const float *wt, const int32_t *gid_s, const float *Tbuf,
                                 float *out, hipStream_t st);
@@ -94,6 +94,8 @@ extern "C" int gags_raster_fwd(int d, int n, int width, int height, const float 
     if (n_isects > 0 && (!means2d || !conics || !opacities || !colors || !flatten_ids)) return GAGS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const bool split = scratch && blk_rows && gags_mfma_width(d);
+    if ((flags & GAGS_FEAT_F16) && (!split || (flags & GAGS_FWD_NO_MFMA) || !packed || n <= 0))
+        return GAGS_EINVAL;  // an fp16 feature table is only read by the feature pass of the split forward
     if (!(flags & GAGS_FWD_NO_MFMA) && (split || fused_width(d)) && (packed || n_isects == 0) && n > 0) {
         if (split) {  // split forward: weights once, then the feature stream
             const FwdScratch L = fwd_layout(n_isects, width, height);
@@ -106,7 +108,7 @@ extern "C" int gags_raster_fwd(int d, int n, int width, int height, const float 
                                                 gid_s, (int32_t *)(sb + L.sidx), (int32_t *)(sb + L.hit), blk_rows, tbuf,
                                                 render_alphas, last_ids, st);
             if (rc != GAGS_OK) return rc;
-            return gags_raster_fwd_feat_launch(d, width, height, n, colors, backgrounds, isect_offsets, (int)n_isects,
+            return gags_raster_fwd_feat_launch(d, width, height, n, colors, (flags & GAGS_FEAT_F16) ? 1 : 0, backgrounds, isect_offsets, (int)n_isects,
                                                blk_rows, wt, gid_s, tbuf, render_colors, st);
         }
         return gags_raster_fwd_fused_launch(d, width, height, packed, colors, backgrounds, isect_offsets, flatten_ids,

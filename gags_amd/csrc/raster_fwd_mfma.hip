@@ -12,6 +12,7 @@
 // Accumulator tile i of a group of 4 holds channels {4n+i}: one float4 load feeds 4 tiles and the
 // epilogue stores 16 B per lane.  All D channels of a slice are composited in ONE walk of the list
 // (gsplat re-walks it ceil(D/32) times).
+#include <hip/hip_fp16.h>
 #include "raster_mfma_common.h"
 
 using namespace gags_mfma;
@@ -26,20 +27,40 @@ struct FwdCfg {
     static_assert(NB == 1 || NB == 2 || NB % 4 == 0, "NB in {1,2,4,8,16}");
 };
 
-// two feature rows (slot k's row for this half-wave) as B operands
-template <int NB>
+// two feature rows (slot k's row for this half-wave) as B operands.  HALF: the feature table is stored as fp16
+// (BASELINE.json configs[4]: half the gather traffic; the values are widened exactly and everything downstream is the
+// same fp32 arithmetic, so the render is bit-identical to the fp32 path on the fp16-rounded table)
+template <int NB, bool HALF = false>
 __device__ __forceinline__ void load_rows(const float *__restrict__ colors, int gid, int d, int ch0, int p,
                                           float4 (&bq)[FwdCfg<NB>::NG])
 {
     constexpr int VEC = FwdCfg<NB>::VEC, NG = FwdCfg<NB>::NG;
     // VEC == 1 also serves a ragged last slice (D % 32 != 0): lanes past the row read its last channel and
     // are masked at the store (an output column depends on its own B column only)
-    const float *row = colors + (size_t)gid * d + (VEC == 1 ? min(ch0 + p, d - 1) : ch0 + VEC * p);
+    const size_t off = (size_t)gid * d + (VEC == 1 ? min(ch0 + p, d - 1) : ch0 + VEC * p);
+    if constexpr (HALF) {
+        const __half *row = reinterpret_cast<const __half *>(colors) + off;
 #pragma unroll
-    for (int gq = 0; gq < NG; ++gq) {
-        if constexpr (VEC == 4) bq[gq] = *reinterpret_cast<const float4 *>(row + gq * 128);
-        else if constexpr (VEC == 2) { const float2 t = *reinterpret_cast<const float2 *>(row); bq[gq] = make_float4(t.x, t.y, 0.f, 0.f); }
-        else bq[gq] = make_float4(row[0], 0.f, 0.f, 0.f);
+        for (int gq = 0; gq < NG; ++gq) {
+            if constexpr (VEC == 4) {
+                const uint2 u = *reinterpret_cast<const uint2 *>(row + gq * 128);
+                const __half2 a = *reinterpret_cast<const __half2 *>(&u.x), b = *reinterpret_cast<const __half2 *>(&u.y);
+                bq[gq] = make_float4(__low2float(a), __high2float(a), __low2float(b), __high2float(b));
+            } else if constexpr (VEC == 2) {
+                const __half2 a = *reinterpret_cast<const __half2 *>(row);
+                bq[gq] = make_float4(__low2float(a), __high2float(a), 0.f, 0.f);
+            } else {
+                bq[gq] = make_float4(__half2float(row[0]), 0.f, 0.f, 0.f);
+            }
+        }
+    } else {
+        const float *row = colors + off;
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) {
+            if constexpr (VEC == 4) bq[gq] = *reinterpret_cast<const float4 *>(row + gq * 128);
+            else if constexpr (VEC == 2) { const float2 t = *reinterpret_cast<const float2 *>(row); bq[gq] = make_float4(t.x, t.y, 0.f, 0.f); }
+            else bq[gq] = make_float4(row[0], 0.f, 0.f, 0.f);
+        }
     }
 }
 
@@ -98,7 +119,7 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[NB], const BlockGeo
 
 // Feature pass over 8x8 pixel blocks: each lane owns two pixels (upper / lower half of the block), i.e. the
 // wave holds TWO 32-row accumulator sets of NB channel tiles each (NB = 4: 128 channels, 128 VGPRs).
-template <int NB>
+template <int NB, bool HALF>
 __global__ __launch_bounds__(64, 2) void raster_fwd_feat(
     int d, int width, int height, int tile_w, int n_tiles, int n_slices, int n_gauss,
     const float *__restrict__ colors, const float *__restrict__ backgrounds, const int32_t *__restrict__ offsets,
@@ -156,7 +177,7 @@ __global__ __launch_bounds__(64, 2) void raster_fwd_feat(
             const int g0v = ids_of(0);
 #pragma unroll
             for (int i = 0; i < PD; ++i) {
-                load_rows<NB>(colors, pick(g0v, i), d, ch0, p, b[i]);
+                load_rows<NB, HALF>(colors, pick(g0v, i), d, ch0, p, b[i]);
                 if (i == 0) gv = ids_of(PD);
                 const float2 w = *reinterpret_cast<const float2 *>(wt + (size_t)slot_of(i) * 64 + 2 * p);
                 aA[i] = w.x; aB[i] = w.y;
@@ -170,7 +191,7 @@ __global__ __launch_bounds__(64, 2) void raster_fwd_feat(
                 const bool live = s + i < steps;
                 mfma_step<NB>(accA, live ? aA[i] : 0.f, b[i]);
                 mfma_step<NB>(accB, live ? aB[i] : 0.f, b[i]);
-                load_rows<NB>(colors, pick(gv_use, i), d, ch0, p, b[i]);
+                load_rows<NB, HALF>(colors, pick(gv_use, i), d, ch0, p, b[i]);
                 if (i == 0) gv = ids_of(s + 2 * PD);
                 const float2 w = *reinterpret_cast<const float2 *>(wt + (size_t)slot_of(s + PD + i) * 64 + 2 * p);
                 aA[i] = w.x; aB[i] = w.y;
@@ -280,14 +301,14 @@ __global__ __launch_bounds__(64, (NB >= 16 ? 1 : 2)) void raster_fwd_fused(
     epilogue<NB>(acc, g, width, height, d, ch0, backgrounds, render_colors, Tq);
 }
 
-template <int NB>
+template <int NB, bool HALF>
 int launch_feat(int d, int width, int height, int n_gauss, const float *colors, const float *backgrounds,
                 const int32_t *offsets, int n_isects, const int32_t *blk_rows, const float *wt, const int32_t *gid_s,
                 const float *Tbuf, float *out, hipStream_t st)
 {
     const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
     const int n_tiles = tile_w * tile_h, n_slices = (d + 32 * NB - 1) / (32 * NB);  // NB == 1: ragged last slice
-    hipLaunchKernelGGL(raster_fwd_feat<NB>, dim3(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices), dim3(64), 0, st, d, width, height, tile_w,
+    hipLaunchKernelGGL((raster_fwd_feat<NB, HALF>), dim3(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices), dim3(64), 0, st, d, width, height, tile_w,
                        n_tiles, n_slices, n_gauss, colors, backgrounds, offsets, n_isects, blk_rows, wt, gid_s, Tbuf,
                        out);
     GAGS_CHECK_LAUNCH();
@@ -310,16 +331,21 @@ int launch_fused(int d, int width, int height, const GRec *packed, const float *
 }  // namespace
 
 // feature pass of the split forward (after gags_raster_weights_launch)
-int gags_raster_fwd_feat_launch(int d, int width, int height, int n_gauss, const float *colors,
+int gags_raster_fwd_feat_launch(int d, int width, int height, int n_gauss, const float *colors, int colors_f16,
                                 const float *backgrounds, const int32_t *offsets, int n_isects,
                                 const int32_t *blk_rows, const float *wt, const int32_t *gid_s, const float *Tbuf,
                                 float *out, hipStream_t st)
 {
     GAGS_CLEAR_ERR();
 #define ARGS d, width, height, n_gauss, colors, backgrounds, offsets, n_isects, blk_rows, wt, gid_s, Tbuf, out, st
-    if (d % 128 == 0) return launch_feat<4>(ARGS);
-    if (d % 64 == 0) return launch_feat<2>(ARGS);
-    return launch_feat<1>(ARGS);
+    if (colors_f16) {
+        if (d % 128 == 0) return launch_feat<4, true>(ARGS);
+        if (d % 64 == 0) return launch_feat<2, true>(ARGS);
+        return launch_feat<1, true>(ARGS);
+    }
+    if (d % 128 == 0) return launch_feat<4, false>(ARGS);
+    if (d % 64 == 0) return launch_feat<2, false>(ARGS);
+    return launch_feat<1, false>(ARGS);
 #undef ARGS
 }
 

@@ -198,7 +198,12 @@ class _Rasterize(torch.autograd.Function):
     def forward(ctx, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, packed, width, height,
                 flags):
         lib = _lib.load()
-        means2d, conics, colors, opacities = _c(means2d), _c(conics), _c(colors), _c(opacities)
+        means2d, conics, opacities = _c(means2d), _c(conics), _c(opacities)
+        # an fp16 feature table (BASELINE.json configs[4]) is read as it is by the matrix-core feature pass: widened
+        # exactly, same fp32 arithmetic; every other kernel gets fp32
+        half = (colors.dtype == torch.float16 and packed is not None and colors.shape[0] > 0
+                and not (flags & (_lib.GAGS_FWD_NO_MFMA | _lib.GAGS_FWD_FUSED)))
+        colors = (colors if colors.is_contiguous() else colors.contiguous()) if half else _c(colors)
         backgrounds = None if backgrounds is None else _c(backgrounds)
         n, d = colors.shape
         dev = colors.device
@@ -220,12 +225,13 @@ class _Rasterize(torch.autograd.Function):
             check(lib.gags_raster_fwd(d, n, width, height, ptr(means2d), ptr(conics), ptr(opacities), ptr(colors),
                                       ptr(backgrounds), ptr(offsets), ptr(flatten_ids), n_isects, ptr(packed),
                                       ptr(out), ptr(alphas), ptr(last_ids), ptr(scratch), nbytes, ptr(blk_rows),
-                                      flags & 3, _stream()), "gags_raster_fwd")
+                                      (flags & 3) | (_lib.GAGS_FEAT_F16 if half else 0), _stream()), "gags_raster_fwd")
         staged = (split and _mfma_width(d) and d <= 1024 and ctx.needs_input_grad[2]
                   and not (flags & _lib.GAGS_BWD_ATOMIC))
         ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, packed, alphas,
                               last_ids, scratch if staged else None, blk_rows if staged else None)
         ctx.cfg = (width, height, flags)
+        ctx.half = half
         ctx.mark_non_differentiable(last_ids)
         return out, alphas, last_ids
 
@@ -246,7 +252,11 @@ class _Rasterize(torch.autograd.Function):
             v_bg = ((1.0 - alphas)[..., None] * v_out).sum(dim=(0, 1))
         if not need_geom and blk_rows is not None:
             v_colors = _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height)
+            if ctx.half:
+                v_colors = v_colors.half()  # autograd wants the table's dtype; an fp32 master sits behind a .half() cast
             return None, None, v_colors, None, v_bg, None, None, None, None, None, None
+        if ctx.half:
+            raise NotImplementedError("fp16 feature table: only the colours-only (feature distillation) backward is implemented")
         v_colors = torch.zeros(n, d, device=dev)
         if need_geom:
             v_opac = torch.zeros(n, device=dev)
@@ -369,12 +379,24 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
         bg = None if bg is None else torch.zeros(1, device=bg.device)
 
     with torch.no_grad(), profiler.stage("binning"):
-        wide = _mfma_width(cols.shape[-1])  # matrix-core path wants packed records
+        dcols = cols.shape[-1]
+        wide = _mfma_width(dcols) or (dcols > 32 and dcols % 4 != 0)  # matrix-core path wants packed records
         isect_ids, flatten_ids, isect_offsets, n_isects, packed = tile_binning(
             means2d, radii, depths, tiles, width, height, conics if wide else None, _c(opacities) if wide else None)
 
-    out, alphas, last_ids = _Rasterize.apply(means2d, conics, cols, opacities, bg, isect_offsets, flatten_ids,
-                                             packed, width, height, int(raster_flags))
+    dfull = cols.shape[-1]
+    if dfull > 32 and dfull % 4 != 0:
+        # e.g. 513 = 512 CLIP channels + 1 (BASELINE.json configs[4] "512-d feat + granularity"): the multiple-of-4 part
+        # runs on the matrix cores, the 1-3 remaining channels on the VALU kernels; same lists, same alpha / T (A12)
+        dm = dfull - dfull % 4
+        o1, alphas, last_ids = _Rasterize.apply(means2d, conics, cols[:, :dm], opacities, None if bg is None else bg[:dm],
+                                                isect_offsets, flatten_ids, packed, width, height, int(raster_flags))
+        o2, _, _ = _Rasterize.apply(means2d, conics, cols[:, dm:].float(), opacities, None if bg is None else bg[dm:],
+                                    isect_offsets, flatten_ids, None, width, height, int(raster_flags))
+        out = torch.cat([o1, o2], dim=-1)
+    else:
+        out, alphas, last_ids = _Rasterize.apply(means2d, conics, cols, opacities, bg, isect_offsets, flatten_ids,
+                                                 packed, width, height, int(raster_flags))
     if render_mode in ("ED", "RGB+ED"):
         if out.requires_grad:
             out = torch.cat([out[..., :-1], out[..., -1:] / alphas[..., None].clamp(min=1e-10)], dim=-1)

@@ -42,6 +42,8 @@ extern "C" {
 /* raster flags */
 #define GAGS_BWD_COLORS_ONLY 1 /* backward: only v_colors (all the GAD flow consumes) */
 #define GAGS_FWD_NO_MFMA 2     /* force the VALU kernels even when D allows the MFMA path */
+#define GAGS_FEAT_F16 32       /* forward: `colors` points to an fp16 [N,D] table (BASELINE.json configs[4]: fp16 feature
+                                  storage); widened exactly, same fp32 arithmetic.  Split matrix-core forward only. */
 
 int gags_abi_version(void);
 const char *gags_strerror(int code);

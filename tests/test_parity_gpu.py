@@ -137,6 +137,61 @@ def test_backward_flavours_agree_and_staged_is_deterministic(oracle):
     assert np.all(g["block"][culled] == 0)  # v_colors written in full
 
 
+def test_fp16_feature_table_is_exact_on_the_rounded_table(oracle):
+    """BASELINE.json configs[4]: fp16 feature storage.  The feature pass widens the halves exactly and runs the same
+    fp32 arithmetic, so against the oracle on the fp16-ROUNDED table the render is bit-identical (tolerance 0) and the
+    gradient (returned in the table's dtype) agrees to fp16 rounding."""
+    n, w, h, d = 4000, 192, 144, 256
+    s = scene_arrays(n, d, w, h, seed=51, view=2, scale_mult=5.0)
+    table = torch.from_numpy(s["colors"]).half()
+    rounded = table.float().numpy()
+    bg = np.full(d, 0.2, np.float32)
+    v_out = np.random.default_rng(4).standard_normal((h, w, d)).astype(np.float32)
+    o_out, o_alpha, oinfo = oracle.rasterization(s["means"], s["quats"], s["scales"], s["opacities"], rounded, s["viewmat"],
+                                                 s["K"], bg, w, h)
+    from gags_amd.rasterization import rasterization
+    cols = table.cuda().requires_grad_(True)
+    out, alphas, info = rasterization(to_dev(s["means"]), to_dev(s["quats"]), to_dev(s["scales"]), to_dev(s["opacities"]), cols,
+                                      to_dev(s["viewmat"])[None], to_dev(s["K"])[None], w, h, backgrounds=to_dev(bg)[None])
+    assert out.dtype == torch.float32
+    np.testing.assert_array_equal(out[0].detach().cpu().numpy(), o_out)
+    (out[0] * to_dev(v_out)).sum().backward()
+    assert cols.grad.dtype == torch.float16
+    o_vf = oracle.raster_bwd_colors_fwdorder(oinfo["means2d"], oinfo["conics"], s["opacities"], d, w, h, oinfo["isect_offsets"],
+                                             oinfo["flatten_ids"], v_out, n)
+    assert rel_l2(cols.grad.float().cpu().numpy(), o_vf) <= 5e-4  # fp16 rounding of the returned gradient
+    # an fp32 master behind a .half() cast receives the fp32-accumulated gradient through autograd's cast
+    master = torch.from_numpy(s["colors"]).cuda().requires_grad_(True)
+    out2, _, _ = rasterization(to_dev(s["means"]), to_dev(s["quats"]), to_dev(s["scales"]), to_dev(s["opacities"]), master.half(),
+                               to_dev(s["viewmat"])[None], to_dev(s["K"])[None], w, h, backgrounds=to_dev(bg)[None])
+    assert torch.equal(out2, out)
+    (out2[0] * to_dev(v_out)).sum().backward()
+    assert master.grad.dtype == torch.float32 and rel_l2(master.grad.cpu().numpy(), o_vf) <= 5e-4
+
+
+@pytest.mark.parametrize("d", [37, 513])
+def test_width_with_extra_channels(oracle, d):
+    """D = 4k + r (513 = 512 CLIP channels + 1, configs[4]): matrix cores for the multiple-of-4 part, VALU kernels for
+    the rest, one binning; bit-exact forward, gradients for every column."""
+    n, w, h = 2500, 144, 112
+    s = scene_arrays(n, d, w, h, seed=52, view=6, scale_mult=5.0)
+    bg = np.linspace(0.0, 1.0, d).astype(np.float32)
+    v_out = np.random.default_rng(5).standard_normal((h, w, d)).astype(np.float32)
+    o_out, o_alpha, oinfo = oracle.rasterization(s["means"], s["quats"], s["scales"], s["opacities"], s["colors"], s["viewmat"],
+                                                 s["K"], bg, w, h)
+    out, alpha, info, grads = _run_gpu(s, w, h, s["colors"], bg, v_out=v_out)
+    _check_indices(info, oinfo)
+    np.testing.assert_array_equal(out, o_out)
+    o_vf = oracle.raster_bwd_colors_fwdorder(oinfo["means2d"], oinfo["conics"], s["opacities"], d, w, h, oinfo["isect_offsets"],
+                                             oinfo["flatten_ids"], v_out, n)
+    o_vc, _, _, _ = oracle.raster_bwd(oinfo["means2d"], oinfo["conics"], s["opacities"], s["colors"], bg, w, h,
+                                      oinfo["isect_offsets"], oinfo["flatten_ids"], o_alpha, oinfo["last_ids"], v_out, None,
+                                      colors_only=True)
+    dm = d - d % 4
+    assert rel_l2(grads["colors"][:, :dm], o_vf[:, :dm]) <= GRAD_TOL       # matrix-core part: forward-order sums
+    assert rel_l2(grads["colors"][:, dm:], o_vc[:, dm:]) <= 1e-4           # VALU part: gsplat-order sums, float atomics
+
+
 def test_backward_by_channel_ranges_is_bit_identical(oracle):
     """The by-view multi-GPU step asks the staged backward for the gradient one 128-channel range at a time
     (rasterization.GRAD_RANGE_HOOK, gags_amd/dist.py): same kernels on a sub-range, so the same bits as the one-shot

@@ -20,5 +20,5 @@ FETCH_SIZE TCC_ATOMIC
 WRITE_SIZE TCC_HIT TCC_MISS
 TCC_EA0_RDREQ TCC_EA0_WRREQ TCC_EA0_ATOMIC TCC_REQ
 LIST
-python "$R/tools/pmc_summary.py" "$OUT" "raster_|rs_|project|tile_|scan_|reduce_rows|gather_grec|make_grec|seg_" "$OUT/traffic.json" > "$OUT/summary.txt" 2>&1
+python "$R/tools/pmc_summary.py" "$OUT" "raster_|rs_|project|tile_|scan_|reduce_rows|gather_grec|make_grec|seg_|slot_rows|dot_" "$OUT/traffic.json" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box call that refreshes everything under profiles/ for a round:
-#   kernel-trace stats, PMC passes, the bench line (with the CPU baseline), the rows-kernel timeline and the
+#   kernel-trace stats, PMC passes, the bench line (with the CPU baseline), the chunk statistics of the rows kernel, the D=16 iteration and the
 #   micro-benchmarks.  Usage (from the repo root, on the GPU box): tools/profile_round.sh r01
 set -u
 TAG=${1:-r01}
@@ -10,14 +10,15 @@ mkdir -p "$O"
 export TMPDIR=/tmp
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats -d "$O/stats" -o c3 --output-format csv -- \
-    python "$R/bench.py" --no-cpu-baseline --steps 5 --warmup 2 > "$O/stats.log" 2>&1
+    python "$R/bench.py" --no-cpu-baseline --no-heavy --steps 5 --warmup 2 > "$O/stats.log" 2>&1
 S=$(find "$O/stats" -name '*kernel_stats.csv' | head -1)
 [ -n "$S" ] && python "$R/tools/trim_stats.py" "$S" "$O/${TAG}_c3_kernel_stats.csv" 40
-"$R/tools/pmc_passes.sh" "$O/pmc" --steps 3 --warmup 1 > /dev/null 2>&1
+"$R/tools/pmc_passes.sh" "$O/pmc" --steps 3 --warmup 1 --no-heavy > /dev/null 2>&1
 cp "$O/pmc/summary.txt" "$O/${TAG}_c3_pmc_summary.txt" 2>/dev/null
 cp "$O/pmc/traffic.json" "$O/${TAG}_c3_pmc_traffic.json" 2>/dev/null
 cd "$R"
 timeout 900 python bench.py --steps 20 --warmup 3 > "$O/${TAG}_c3_bench.json" 2> "$O/bench.err"
-timeout 300 python tools/rows_trace.py C3 > "$O/${TAG}_c3_rows_trace.txt" 2>&1
+timeout 300 python tools/chunk_stats.py C3 > "$O/${TAG}_c3_chunk_stats.txt" 2>&1
+timeout 300 python tools/decoder_bench.py > "$O/${TAG}_d16_iteration.json" 2>/dev/null
 tools/micro/run_all.sh > "$O/${TAG}_micro.txt" 2>&1
 tail -1 "$O/${TAG}_c3_bench.json" | cut -c1-600
