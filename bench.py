@@ -296,6 +296,23 @@ def main():
             if chosen_reduce:
                 args.grad_reduce = chosen_reduce
     step, pc, cam, d_local = build(mode)
+    if world > 1 and mode == "view" and not args.no_overlap:
+        # the overlapped exchange drives RCCL from a second stream: if this stack refuses it, say so and measure the plain
+        # exchange instead of dying (same decision on every rank)
+        ok = 1
+        try:
+            step()
+            torch.cuda.synchronize()
+        except RuntimeError as e:
+            print(f"[bench] rank {rank}: overlapped gradient exchange failed ({e}); using the plain one", file=sys.stderr, flush=True)
+            ok = 0
+        flag = torch.tensor([ok], device=dev)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            args.no_overlap = True
+            del step, pc
+            torch.cuda.empty_cache()
+            step, pc, cam, d_local = build(mode)
 
     for _ in range(args.warmup):
         pkg = step()

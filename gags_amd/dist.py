@@ -46,6 +46,23 @@ def channel_shard(d, rank=None, world_size=None, multiple=16):
 
 
 _AG_IN_PLACE = True
+_RS_IN_PLACE = True
+
+
+def _reduce_scatter_in_place(shard, full):
+    """reduce-scatter whose output is the rank's own slot of the input (NCCL's in-place form).  A backend that refuses
+    aliased buffers gets a staging shard from then on."""
+    global _RS_IN_PLACE
+    if _RS_IN_PLACE:
+        try:
+            dist.reduce_scatter_tensor(shard, full)
+            return
+        except (RuntimeError, ValueError):
+            _RS_IN_PLACE = False
+    tmp = torch.empty_like(shard)
+    dist.reduce_scatter_tensor(tmp, full)
+    shard.copy_(tmp)
+
 
 
 def _all_gather_in_place(out, shard):
@@ -81,7 +98,7 @@ def reduce_feature_grad(grad, mode="rs_ag", average=False, bucket_bytes=BUCKET_B
         for o in range(0, main, per):
             b = flat[o:o + per]
             shard = b.view(ws, per // ws)[dist.get_rank()]
-            dist.reduce_scatter_tensor(shard, b)
+            _reduce_scatter_in_place(shard, b)
             _all_gather_in_place(b, shard)
         if main < numel:
             dist.all_reduce(flat[main:])

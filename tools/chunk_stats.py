@@ -39,10 +39,15 @@ R._backward_staged = spy
 pkg = render(cam, pc, None, torch.zeros(3, device=dev), feature_mode=True)
 (pkg["render"] * G).sum().backward()
 torch.cuda.synchronize()
+cap["flat"] = pkg["info"]["flatten_ids"].cpu().numpy()
 off, blk, rm, I = cap["offsets"], cap["blk"], cap["rm"], cap["I"]
 nt = off.size
 slot_off = ((I + 1) * 4 + 255) // 256 * 256 // 4
 trow, trs = rm[:I + 1], rm[slot_off:]
+hit = np.diff(trow.astype(np.int64)) > 0
+per_g = np.bincount(cap["flat"][hit], minlength=n)
+print(f"tile rows {int(hit.sum())}, Gaussians with rows {int((per_g > 0).sum())}: exactly one row {np.mean(per_g[per_g > 0] == 1):.1%} of them "
+      f"(= {np.sum(per_g == 1) / hit.sum():.1%} of the rows), two {np.mean(per_g[per_g > 0] == 2):.1%}, mean {per_g[per_g > 0].mean():.2f}")
 CMAX = int(os.environ.get("CMAX", 64))
 rows_per_chunk, runs, bursts, chunks_tile, old_tiles = [], [], 0, [], 0
 rng = np.random.default_rng(0)

@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""Step time (render + <render, G> + backward, the harness step of bench.py) of the other BASELINE.json configs and
+variants: C1, C2, C5 with an fp32 / fp16 feature table, 512 + 1 channels, the C3 geometry at D = 16 ... 256.
+Prints one JSON object.  (bench.py's `value` is C3; this table feeds BASELINE.md section 4.)"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from gags_amd import synthetic as syn
+from gags_amd.gaussian_renderer import render
+
+dev = torch.device("cuda", 0)
+
+
+def run(name, n, w, h, d, half=False, steps=8, feature_mode=True):
+    pc = syn.make_model(n, d, w, h, seed=0, device=dev, gen_device=dev)
+    pc.training_setup()
+    if half:
+        master = pc._semantic_feature
+        pc.rewrite_semantic_feature(master.detach().half().requires_grad_(True))
+    cam = syn.make_camera(w, h, device=dev)
+    bg = torch.zeros(3, device=dev)
+    G = syn.make_cotangent(d, h, w, seed=1, device=dev)
+
+    def step():
+        pc._semantic_feature.grad = None
+        pkg = render(cam, pc, None, bg, feature_mode=True)
+        (pkg["render"] * G).sum().backward() if d < 16 else torch.dot(pkg["render"].permute(1, 2, 0).reshape(-1), G.permute(1, 2, 0).reshape(-1)).backward()
+        return pkg
+
+    for _ in range(2):
+        pkg = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    peak = torch.cuda.max_memory_allocated() / 2**30
+    res = {"ms_per_step": round(1e3 * dt, 3), "views_per_s": round(1 / dt, 1), "n_isects": pkg["info"]["n_isects"], "peak_GiB": round(peak, 1)}
+    del pc, G, pkg
+    torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
+    return name, res
+
+
+out = dict([
+    run("C1 10k/256x256/D=3", 10_000, 256, 256, 3),
+    run("C2 500k/1280x720/D=128", 500_000, 1280, 720, 128),
+    run("C3 geometry D=16", 1_500_000, 1920, 1080, 16),
+    run("C3 geometry D=64", 1_500_000, 1920, 1080, 64),
+    run("C3 geometry D=256", 1_500_000, 1920, 1080, 256),
+    run("C5 4M/1080p/D=512 fp32 table", 4_000_000, 1920, 1080, 512),
+    run("C5 4M/1080p/D=512 fp16 table", 4_000_000, 1920, 1080, 512, half=True),
+    run("C5 4M/1080p/D=513 (512+1) fp32", 4_000_000, 1920, 1080, 513, steps=4),
+])
+print(json.dumps(out))
