@@ -83,6 +83,7 @@ GAGS_BWD_COLORS_ONLY = 1
 GAGS_FWD_NO_MFMA = 2
 GAGS_BWD_ATOMIC = 4  # python-side: use the atomic colours-only backward instead of the staged one
 GAGS_FEAT_F16 = 32  # forward: colors is an fp16 table (include/gags_raster.h)
+GAGS_BWD_F16SPLIT = 64  # python-side: staged backward contracts on the 16-bit matrix cores (fp16 head + tail; ~2^-21, opt-in)
 GAGS_FWD_FUSED = 8  # python-side: single-kernel matrix-core forward (no scratch) instead of weights + features
 
 _lib = None

@@ -246,6 +246,201 @@ __global__ __launch_bounds__(256, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void rast
     }
 }
 
+// ---- staged: rows, 16-bit matrix cores (opt-in: GAGS_BWD_F16SPLIT) ---------------------------------------------------
+// The same kernel with the contraction on v_mfma_f32_32x32x16_f16 (16x the fp32 MFMA rate): both operands are split
+// into an fp16 head and an fp16 tail, x = (hi + lo) / scale with
+//   weights   scale 2^12 (alpha*T lies in (4e-7, 1]: every head and tail is a normal fp16 number),
+//   cotangent one power-of-two scale per (pixel block, channel) taken from the column's largest magnitude,
+// and w * v ~ hi*hi + hi*lo + lo*hi (three MFMAs, products exact in the fp32 accumulator; the dropped lo*lo term is
+// 2^-22 relative).  The sums then differ from the fp32 kernel's by ~2^-21 of the column's largest term -- inside the
+// 2e-5 gradient tolerance of the tests, NOT bit-identical to the fp32 kernel; hence opt-in.  Still no atomics and a
+// fixed order: bit-reproducible.  A burst is 48 MFMAs of 32 cycles instead of 128 of 64.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split8(const float (&x)[8], float scale, f16x8 &hi, f16x8 &lo)
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float v = x[i] * scale;
+        const _Float16 h = (_Float16)v;
+        hi[i] = h;
+        lo[i] = (_Float16)(v - (float)h);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
+    int d, int width, int height, int tile_w, int n_tiles, int slice0, int n_slices,
+    const float *__restrict__ v_render_colors, const int32_t *__restrict__ offsets, int n_isects,
+    const int32_t *__restrict__ blk_rows, const int32_t *__restrict__ trow, const float *__restrict__ wt,
+    const int32_t *__restrict__ gid_s, const int32_t *__restrict__ trow_s, float *__restrict__ prow,
+    uint32_t *__restrict__ row_key, int32_t *__restrict__ row_idx)
+{
+    constexpr int NBR = 4, CW = 128, C4 = 32;
+    constexpr float WSCALE = 4096.0f;
+    __shared__ __attribute__((aligned(16))) float stage[4][32][CW];
+    __shared__ uint8_t pos[2][4][CMAX];
+    __shared__ int cand[2][4];
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * n_slices);
+    const int slice = slice0 + logical % n_slices;
+    const int tile = gags_tile_of_order(logical / n_slices, tile_w, n_tiles / tile_w);
+    const int start = offsets[tile];
+    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+    const int R0 = trow[start], R1 = trow[end];
+    if (R1 == R0) return;
+    const int blk = wave;
+    const int cnt = blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk];
+    const int sb = gags_slot_base(start, end, tile, blk);
+    const int ch0 = slice * CW;
+    BlockGeom64 g;
+    g.init(tile, blk, tile_w, width, height, lane);
+    const int p = g.p, k = g.k;  // p: channel group (channels ch0 + 4p + j) / slot; k: which 8 of a K-step's 16 pixels
+
+    // cotangent slab as B operands: K element e = 16 s + 8 k + i of the weight rows' order = pixel e >> 1 of the 8x4 half
+    // e & 1; Bh / Bl[s][j] = the 8 elements of K-step s for channel ch0 + 4 p + j, head and tail, scaled by cs[j]
+    f16x8 Bh[4][NBR], Bl[4][NBR];
+    float inv[NBR];
+    {
+        float raw[4][8][NBR];
+        float mx[NBR] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = 16 * s4 + 8 * k + i;
+                const int pp = e >> 1, hh = e & 1;
+                const int qj = g.bx0 + (pp & 7), qi = g.by0 + 4 * hh + (pp >> 3);
+                const bool ok = (qi < height) && (qj < width) && cnt > 0;
+                const float4 v = *reinterpret_cast<const float4 *>(
+                    v_render_colors + ((size_t)min(qi, height - 1) * width + min(qj, width - 1)) * d + ch0 + NBR * p);
+                raw[s4][i][0] = ok ? v.x : 0.f; raw[s4][i][1] = ok ? v.y : 0.f;
+                raw[s4][i][2] = ok ? v.z : 0.f; raw[s4][i][3] = ok ? v.w : 0.f;
+#pragma unroll
+                for (int j = 0; j < NBR; ++j) mx[j] = fmaxf(mx[j], fabsf(raw[s4][i][j]));
+            }
+#pragma unroll
+        for (int j = 0; j < NBR; ++j) {
+            mx[j] = fmaxf(mx[j], __shfl_xor(mx[j], 32));  // the column's other 32 pixels live in the other half-wave
+            // largest magnitude -> [2^14, 2^15); an all-zero (or non-finite) column keeps scale 1
+            const float cs = (mx[j] > 0.f && mx[j] < 3.0e38f) ? ldexpf(1.0f, 14 - ilogbf(mx[j])) : 1.0f;
+            inv[j] = 1.0f / (cs * WSCALE);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                float col[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) col[i] = raw[s4][i][j];
+                split8(col, cs, Bh[s4][j], Bl[s4][j]);
+            }
+        }
+    }
+
+    int pb = 0;
+    int r0 = R0;
+    int tr = 0x7fffffff, gid = 0;
+    if (lane <= 32 && lane < cnt) {
+        tr = trow_s[sb + lane];
+        gid = gid_s[sb + lane];
+    }
+    // weight tile, raw: lane (slot p, k) holds elements 16 s + 8 k + i of its slot's row
+    float A[32];
+    auto load_A = [&](int first) {
+        const float4 *src = reinterpret_cast<const float4 *>(wt + (size_t)(sb + first + p) * 64 + k * 8);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const float4 u = src[4 * s4], v = src[4 * s4 + 1];
+            A[8 * s4] = u.x; A[8 * s4 + 1] = u.y; A[8 * s4 + 2] = u.z; A[8 * s4 + 3] = u.w;
+            A[8 * s4 + 4] = v.x; A[8 * s4 + 5] = v.y; A[8 * s4 + 6] = v.z; A[8 * s4 + 7] = v.w;
+        }
+    };
+    if (cnt > 0) load_A(0);
+    for (int it = 0; r0 < R1; ++it) {
+        const int par = it & 1;
+        if (threadIdx.x < CMAX) reinterpret_cast<uint32_t *>(&pos[par][0][0])[threadIdx.x] = 0xffffffffu;
+        const int tr32 = __builtin_amdgcn_readlane(tr, 32);
+        if (lane == 0) cand[par][wave] = tr32;
+        __syncthreads();
+        const int r1 = min(min(min(cand[par][0], cand[par][1]), min(cand[par][2], cand[par][3])), min(r0 + CMAX, R1));
+        const bool mine = lane < 32 && tr < r1;
+        const int run = __popcll(__ballot(mine));
+        const int tr_c = tr, gid_c = gid;
+        const int pbn = pb + run;
+        if (run > 0) {
+            if (mine) pos[par][wave][tr_c - r0] = (uint8_t)lane;
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 acc[NBR];
+#pragma unroll
+            for (int j = 0; j < NBR; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                float a8[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a8[i] = A[8 * s4 + i];
+                f16x8 ah, al;
+                split8(a8, WSCALE, ah, al);
+#pragma unroll
+                for (int j = 0; j < NBR; ++j) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bh[s4][j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bl[s4][j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bh[s4][j], acc[j], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (mine && slice == 0) {
+                row_key[tr_c] = (uint32_t)gid_c;
+                row_idx[tr_c] = tr_c;
+            }
+            tr = 0x7fffffff;
+            if (lane <= 32 && pbn + lane < cnt) {
+                tr = trow_s[sb + pbn + lane];
+                gid = gid_s[sb + pbn + lane];
+            }
+            if (pbn < cnt) load_A(pbn);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int slot = (r & 3) + 8 * (r >> 2) + 4 * k;
+                if (slot < run)
+                    *reinterpret_cast<float4 *>(&stage[wave][slot][NBR * p]) =
+                        make_float4(acc[0][r] * inv[0], acc[1][r] * inv[1], acc[2][r] * inv[2], acc[3][r] * inv[3]);
+            }
+        }
+        __syncthreads();
+        const int items = (r1 - r0) * C4;
+        int gt = threadIdx.x;
+        asm volatile("" : "+v"(gt));
+#pragma unroll
+        for (int trip = 0; trip < CMAX * C4 / 256; ++trip) {
+            const int item = gt + 256 * trip;
+            if (item < items) {
+                const int row = item / C4, c4 = item - row * C4;
+                float4 v[4];
+                bool has[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int q = pos[par][b][row];
+                    has[b] = q != 0xff;
+                    v[b] = *reinterpret_cast<const float4 *>(&stage[b][has[b] ? q : 0][4 * c4]);
+                }
+                float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    sum.x += has[b] ? v[b].x : 0.f; sum.y += has[b] ? v[b].y : 0.f;
+                    sum.z += has[b] ? v[b].z : 0.f; sum.w += has[b] ? v[b].w : 0.f;
+                }
+                *reinterpret_cast<float4 *>(prow + (size_t)(r0 + row) * d + ch0 + 4 * c4) = sum;
+            }
+            if (trip & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        pb = pbn;
+        r0 = r1;
+    }
+}
+
 // trow_s[slot] = tile row of the slot's intersection (0x7fffffff for the pad slot of an odd count): one coalesced
 // stream per block for the rows kernel instead of a dependent sidx -> trow gather.  One wave per (tile, block).
 __global__ __launch_bounds__(64) void slot_rows_kernel(int n_tiles, int n_isects, const int32_t *__restrict__ offsets,
@@ -476,7 +671,10 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
 #define GAGS_ROWS_LAUNCH(NBR)                                                                                       \
     hipLaunchKernelGGL((raster_bwd_rows<NBR>), grid, dim3(256), 0, st, d, width, height, tile_w, n_tiles, slice0,  \
                        n_slices, v_out, offsets, n_isects, blk_rows, trow, wt, gid_s, trow_s, prow, key, idx)
-            if (nbr == 4) GAGS_ROWS_LAUNCH(4);
+            if (nbr == 4 && (stage_flags & 32))  // opt-in: contraction on the 16-bit matrix cores (GAGS_BWD_F16SPLIT)
+                hipLaunchKernelGGL(raster_bwd_rows_f16, grid, dim3(256), 0, st, d, width, height, tile_w, n_tiles, slice0,
+                                   n_slices, v_out, offsets, n_isects, blk_rows, trow, wt, gid_s, trow_s, prow, key, idx);
+            else if (nbr == 4) GAGS_ROWS_LAUNCH(4);
             else if (nbr == 2) GAGS_ROWS_LAUNCH(2);
             else GAGS_ROWS_LAUNCH(1);
 #undef GAGS_ROWS_LAUNCH

@@ -251,7 +251,8 @@ class _Rasterize(torch.autograd.Function):
         if backgrounds is not None and ctx.needs_input_grad[4]:
             v_bg = ((1.0 - alphas)[..., None] * v_out).sum(dim=(0, 1))
         if not need_geom and blk_rows is not None:
-            v_colors = _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height)
+            v_colors = _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height,
+                                        32 if (flags & _lib.GAGS_BWD_F16SPLIT) else 0)
             if ctx.half:
                 v_colors = v_colors.half()  # autograd wants the table's dtype; an fp32 master sits behind a .half() cast
             return None, None, v_colors, None, v_bg, None, None, None, None, None, None
@@ -274,7 +275,7 @@ class _Rasterize(torch.autograd.Function):
         return v_m2d, v_con, v_colors, v_opac, v_bg, None, None, None, None, None, None
 
 
-def _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height):
+def _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height, xflag=0):
     """Colours-only backward without atomics: hit flags of the forward -> prefix sum (one row per (tile, Gaussian)
     pair that blended anything) -> one 4-byte readback (total rows) -> merged partial rows -> sort by Gaussian ->
     segmented sum."""
@@ -296,6 +297,7 @@ def _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d,
     v_colors = torch.empty(n, d, device=dev)
 
     def run(stage):
+        stage |= xflag
         check(lib.gags_raster_bwd_colors_staged(d, n, width, height, ptr(offsets), n_isects, ptr(v_out), ptr(blk_rows),
                                                 ptr(trow), rows, ptr(fwd_scratch), fwd_scratch.numel(),
                                                 ptr(scratch), nbytes, ptr(v_colors), stage, st),
@@ -309,7 +311,7 @@ def _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d,
                 with profiler.stage(("bwd_rows", "bwd_sort", "bwd_reduce")[stage - 1]):
                     check(lib.gags_raster_bwd_colors_staged_range(
                         d, n, width, height, ptr(offsets), n_isects, ptr(v_out), ptr(blk_rows), ptr(trow), rows,
-                        ptr(fwd_scratch), fwd_scratch.numel(), ptr(scratch), nbytes, ptr(v_colors), stage, c0,
+                        ptr(fwd_scratch), fwd_scratch.numel(), ptr(scratch), nbytes, ptr(v_colors), stage | xflag, c0,
                         GRAD_RANGE_CHANNELS, st), "gags_raster_bwd_colors_staged_range")
             hook(alias, c0, c0 + GRAD_RANGE_CHANNELS)
     elif profiler.ENABLED:  # one event pair per kernel (group), for the roofline line of bench.py

@@ -156,7 +156,10 @@ int gags_raster_bwd(int d, int width, int height, const float *means2d, const fl
  * gags_raster_bwd_colors_staged: per tile the four pixel blocks' partial rows are merged on chip and stored
  * once per (tile, Gaussian), the rows are sorted by Gaussian and reduced; v_colors[N,D] is written in full
  * (no zero-fill needed).  scratch: gags_bwd_staged_scratch_bytes(rows, n, d) bytes.
- * stage: 0 = all, 1..3 = rows, sort, reduce (per-kernel timing).  Returns 1 when D is not eligible. */
+ * stage: low 4 bits 0 = all, 1..3 = rows, sort, reduce (per-kernel timing); bit 5 (32), D % 128 == 0 only, opt-in: the
+ * rows' contraction runs on the 16-bit matrix cores with both operands split into an fp16 head and tail (~2^-21
+ * relative to a column's largest term instead of fp32 rounding; still atomic-free and bit-reproducible).
+ * Returns 1 when D is not eligible. */
 int64_t gags_bwd_rowmap_elems(int64_t n_isects, int width, int height);
 int64_t gags_bwd_rowmap_scratch_bytes(int64_t n_isects);
 int gags_bwd_rowmap(int64_t n_isects, int width, int height, const int32_t *isect_offsets, const int32_t *blk_rows,

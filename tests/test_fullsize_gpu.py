@@ -194,7 +194,7 @@ def test_colour_gradient_accuracy_against_float64(oracle):
     float64 dense restatement (oracle/dense_ref.py) on a saturated scene the HIP gradient must be at least as
     accurate as the gsplat-order one, and within GRAD_TOL."""
     from oracle import dense_ref as dr
-    n, w, h, d = 2500, 80, 48, 32
+    n, w, h, d = 2500, 80, 48, 128  # D % 128 == 0: the width the 16-bit-matrix-core backward serves
     s = scene_arrays(n, d, w, h, seed=31, view=None, scale_mult=14.0)
     opac = np.clip(s["opacities"] * 0.5 + 0.5, 0.0, 0.995).astype(np.float32)  # opaque: most pixels saturate
     bg = np.full(d, 0.3, np.float32)
@@ -223,5 +223,15 @@ def test_colour_gradient_accuracy_against_float64(oracle):
     (out[0] * to_dev(v_out)).sum().backward()
     e_hip = rel_l2(cols.grad.cpu().numpy(), ref)
     e_gsplat = rel_l2(o_vc, ref)
+    # the opt-in 16-bit-matrix-core backward (fp16 head + tail of both operands) on the same scene
+    from gags_amd import _lib
+    cols2 = to_dev(s["colors"]).requires_grad_(True)
+    out2, _, _ = rasterization(to_dev(s["means"]), to_dev(s["quats"]), to_dev(s["scales"]), to_dev(opac), cols2,
+                               to_dev(s["viewmat"])[None], to_dev(s["K"])[None], w, h, backgrounds=to_dev(bg)[None],
+                               raster_flags=_lib.GAGS_BWD_F16SPLIT)
+    (out2[0] * to_dev(v_out)).sum().backward()
+    e_fast = rel_l2(cols2.grad.cpu().numpy(), ref)
+    print(f"colour gradient vs float64: HIP fp32 {e_hip:.2e}, HIP f16-split {e_fast:.2e}, gsplat-order fp32 {e_gsplat:.2e}")
     assert e_hip <= e_gsplat, (e_hip, e_gsplat)
     assert e_hip <= 2e-6, e_hip
+    assert e_fast <= e_gsplat and e_fast <= 5e-6, (e_fast, e_gsplat)

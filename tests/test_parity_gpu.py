@@ -192,6 +192,34 @@ def test_width_with_extra_channels(oracle, d):
     assert rel_l2(grads["colors"][:, dm:], o_vc[:, dm:]) <= 1e-4           # VALU part: gsplat-order sums, float atomics
 
 
+def test_backward_on_the_16bit_matrix_cores_is_within_tolerance(oracle):
+    """Opt-in GAGS_BWD_F16SPLIT: the staged backward's contraction on v_mfma_f32_32x32x16_f16 with both operands split
+    into an fp16 head and tail.  Stated bound: ~2^-21 relative to a column's largest term; tested: inside the same
+    2e-5 gradient tolerance as the fp32 kernel (cotangents spanning 12 orders of magnitude across channels exercise the
+    per-column scaling), reproducible bit for bit, and the forward is untouched."""
+    from gags_amd import _lib
+    n, w, h, d = 5000, 192, 144, 256
+    s = scene_arrays(n, d, w, h, seed=61, view=4, scale_mult=6.0)
+    bg = np.full(d, 0.3, np.float32)
+    rng = np.random.default_rng(8)
+    v_out = (rng.standard_normal((h, w, d)) * np.exp(rng.uniform(-14, 14, size=d))).astype(np.float32)
+    o_out, o_alpha, oinfo = oracle.rasterization(s["means"], s["quats"], s["scales"], s["opacities"], s["colors"], s["viewmat"],
+                                                 s["K"], bg, w, h)
+    o_vf = oracle.raster_bwd_colors_fwdorder(oinfo["means2d"], oinfo["conics"], s["opacities"], d, w, h, oinfo["isect_offsets"],
+                                             oinfo["flatten_ids"], v_out, n)
+    out, _, _, g_exact = _run_gpu(s, w, h, s["colors"], bg, v_out=v_out)
+    out2, _, _, g_fast = _run_gpu(s, w, h, s["colors"], bg, v_out=v_out, flags=_lib.GAGS_BWD_F16SPLIT)
+    _, _, _, g_fast2 = _run_gpu(s, w, h, s["colors"], bg, v_out=v_out, flags=_lib.GAGS_BWD_F16SPLIT)
+    np.testing.assert_array_equal(out, o_out)
+    np.testing.assert_array_equal(out2, o_out)
+    np.testing.assert_array_equal(g_fast["colors"], g_fast2["colors"])
+    # per channel (the scales differ by 12 orders of magnitude: a global rel-L2 would only see the largest columns)
+    for name, g in (("fp32", g_exact["colors"]), ("f16 split", g_fast["colors"])):
+        num = np.linalg.norm((g.astype(np.float64) - o_vf), axis=0)
+        den = np.maximum(np.linalg.norm(o_vf.astype(np.float64), axis=0), 1e-300)
+        assert (num / den).max() <= GRAD_TOL, (name, float((num / den).max()))
+
+
 def test_backward_by_channel_ranges_is_bit_identical(oracle):
     """The by-view multi-GPU step asks the staged backward for the gradient one 128-channel range at a time
     (rasterization.GRAD_RANGE_HOOK, gags_amd/dist.py): same kernels on a sub-range, so the same bits as the one-shot
