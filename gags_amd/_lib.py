@@ -84,6 +84,7 @@ GAGS_FWD_NO_MFMA = 2
 GAGS_BWD_ATOMIC = 4  # python-side: use the atomic colours-only backward instead of the staged one
 GAGS_FEAT_F16 = 32  # forward: colors is an fp16 table (include/gags_raster.h)
 GAGS_BWD_F16SPLIT = 64  # python-side: staged backward contracts on the 16-bit matrix cores (fp16 head + tail; ~2^-21, opt-in)
+GAGS_FWD_F16MFMA = 128  # python-side: fp16 feature table + D % 128 == 0: feature pass on the 16-bit matrix cores (opt-in; C flag 64)
 GAGS_FWD_FUSED = 8  # python-side: single-kernel matrix-core forward (no scratch) instead of weights + features
 
 _lib = None

@@ -108,7 +108,7 @@ extern "C" int gags_raster_fwd(int d, int n, int width, int height, const float 
                                                 gid_s, (int32_t *)(sb + L.sidx), (int32_t *)(sb + L.hit), blk_rows, tbuf,
                                                 render_alphas, last_ids, st);
             if (rc != GAGS_OK) return rc;
-            return gags_raster_fwd_feat_launch(d, width, height, n, colors, (flags & GAGS_FEAT_F16) ? 1 : 0, backgrounds, isect_offsets, (int)n_isects,
+            return gags_raster_fwd_feat_launch(d, width, height, n, colors, (flags & GAGS_FEAT_F16) ? ((flags & GAGS_FWD_F16MFMA) ? 2 : 1) : 0, backgrounds, isect_offsets, (int)n_isects,
                                                blk_rows, wt, gid_s, tbuf, render_colors, st);
         }
         return gags_raster_fwd_fused_launch(d, width, height, packed, colors, backgrounds, isect_offsets, flatten_ids,

@@ -218,6 +218,129 @@ __global__ __launch_bounds__(64, 2) void raster_fwd_feat(
     }
 }
 
+// ---- feature pass on the 16-bit matrix cores (opt-in: GAGS_FWD_F16MFMA; fp16 feature table, D % 128 == 0) -------------
+// BASELINE.json configs[4] "fp16 features on CDNA4": v_mfma_f32_32x32x16_f16, K = 16 slots per step.  The features ARE
+// fp16, so the B operand is exact; the weights alpha*T (fp32) go in as an fp16 head + tail pair scaled by 2^12 (every
+// head and tail is then a normal fp16 number), two MFMAs per tile, products exact in the fp32 accumulator: the render
+// differs from the fp32 arithmetic by ~2^-22 relative per term (tests: <= 2e-6 rel-L2), not bit-identical -> opt-in.
+// 16 MFMAs of 32 cycles per 16 slots and 128 channels instead of 64 of 64 cycles.
+// K runs over slots, the feature table is slot-major: a lane's B operand is 8 slots x 1 channel.  Each lane therefore
+// fetches 4 consecutive channels (8 bytes) of each of its 8 slots and re-packs them into the four channel tiles'
+// operands (tile j = channels ch0 + 4 n + j: the same "strided" tiles as the fp32 kernel, same float4 epilogue).
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(64, 2) void raster_fwd_feat_f16(
+    int d, int width, int height, int tile_w, int n_tiles, int n_slices, int n_gauss,
+    const __half *__restrict__ colors, const float *__restrict__ backgrounds, const int32_t *__restrict__ offsets,
+    int n_isects, const int32_t *__restrict__ blk_rows, const float *__restrict__ wt,
+    const int32_t *__restrict__ gid_s, const float *__restrict__ Tbuf, float *__restrict__ render_colors)
+{
+    constexpr int NB = 4, CS = 128;
+    constexpr float WSCALE = 4096.0f;
+    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * GAGS_BLOCKS_PER_TILE * n_slices);
+    const int slice = logical % n_slices, rest = logical / n_slices;
+    const int blk = rest & 3;
+    const int tile = gags_tile_of_order(rest >> 2, tile_w, n_tiles / tile_w);
+    const int ch0 = slice * CS;
+    const int lane = threadIdx.x;
+    BlockGeom64 g;
+    g.init(tile, blk, tile_w, width, height, lane);
+    const int p = g.p, k = g.k;  // A operand: pixel p of a half-block; B operand: channel group p; k: which 8 of the step's 16 slots
+    const int start = offsets[tile];
+    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+    const int sb = gags_slot_base(start, end, tile, blk);
+    const int cnt = blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk];
+    const int steps = (cnt + 15) >> 4;
+
+    f32x16 accA[NB], accB[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accA[j][r] = 0.f; accB[j][r] = 0.f; }
+
+    if (steps > 0) {
+        const int gmax = n_gauss - 1;
+        // Raw operands of one step = this lane's 8 slots (8 k + i of the step).  The feature rows are gathers that mostly
+        // miss L2: they are requested TWO steps ahead, the ids three, the weight rows (a stream the slices share) one.
+        auto ids_of = [&](int s, int (&id)[8]) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) id[i] = min(gid_s[sb + min(16 * s + 8 * k + i, cnt - 1)], gmax);
+        };
+        auto fetch_f = [&](const int (&id)[8], uint2 (&f)[8]) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] = *reinterpret_cast<const uint2 *>(colors + (size_t)id[i] * d + ch0 + 4 * p);
+        };
+        auto fetch_w = [&](int s, float2 (&wv)[8]) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int slot = 16 * s + 8 * k + i;
+                wv[i] = *reinterpret_cast<const float2 *>(wt + (size_t)(sb + min(slot, cnt - 1)) * 64 + 2 * p);
+                if (slot >= cnt) wv[i] = make_float2(0.f, 0.f);
+            }
+        };
+        int idn[8];
+        uint2 f0[8], f1[8], f2[8];  // features of steps s, s+1, s+2
+        float2 w0[8], w1[8];        // weights of steps s, s+1
+        ids_of(0, idn); fetch_f(idn, f0); fetch_w(0, w0);
+        ids_of(min(1, steps - 1), idn); fetch_f(idn, f1);
+        ids_of(min(2, steps - 1), idn);
+        for (int s = 0; s < steps; ++s) {
+            fetch_f(idn, f2);                      // step s + 2 (clamped past the end: harmless re-reads)
+            ids_of(min(s + 3, steps - 1), idn);
+            fetch_w(min(s + 1, steps - 1), w1);
+            __builtin_amdgcn_sched_barrier(0);     // keep the prefetches above this step's arithmetic
+            h16x8 ahA, alA, ahB, alB;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float a = w0[i].x * WSCALE, b = w0[i].y * WSCALE;
+                const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+                ahA[i] = ha; alA[i] = (_Float16)(a - (float)ha);
+                ahB[i] = hb; alB[i] = (_Float16)(b - (float)hb);
+            }
+            h16x8 bj[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {  // channel tile j: component j of each slot's four halves
+                union { h16x8 v; unsigned u[4]; } t;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned lo = (j < 2) ? f0[2 * q].x : f0[2 * q].y, hi = (j < 2) ? f0[2 * q + 1].x : f0[2 * q + 1].y;
+                    t.u[q] = (j & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
+                }
+                bj[j] = t.v;
+            }
+            // four independent accumulators between two updates of the same one
+#pragma unroll
+            for (int j = 0; j < NB; ++j) accA[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahA, bj[j], accA[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) accB[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahB, bj[j], accB[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) accA[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alA, bj[j], accA[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) accB[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alB, bj[j], accB[j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { f0[i] = f1[i]; f1[i] = f2[i]; w0[i] = w1[i]; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accA[j][r] *= (1.0f / WSCALE); accB[j][r] *= (1.0f / WSCALE); }
+    float Tq[16];
+    BlockGeom half;
+    half.p = p; half.k = k; half.bx0 = g.bx0;
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+        half.by0 = g.by0 + 4 * hb;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = (r & 3) + 8 * (r >> 2) + 4 * k;
+            const int qj = min(half.bx0 + (q & 7), width - 1), qi = min(half.by0 + (q >> 3), height - 1);
+            Tq[r] = Tbuf[(size_t)qi * width + qj];
+        }
+        epilogue<NB>(hb ? accB : accA, half, width, height, d, ch0, backgrounds, render_colors, Tq);
+    }
+}
+
 template <int NB>
 __global__ __launch_bounds__(64, (NB >= 16 ? 1 : 2)) void raster_fwd_fused(
     int d, int width, int height, int tile_w, int n_tiles, int n_slices, const GRec *__restrict__ packed,
@@ -338,6 +461,15 @@ int gags_raster_fwd_feat_launch(int d, int width, int height, int n_gauss, const
 {
     GAGS_CLEAR_ERR();
 #define ARGS d, width, height, n_gauss, colors, backgrounds, offsets, n_isects, blk_rows, wt, gid_s, Tbuf, out, st
+    if (colors_f16 == 2 && d % 128 == 0) {  // opt-in: the 16-bit matrix cores
+        const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
+        const int n_tiles = tile_w * tile_h, n_slices = d / 128;
+        hipLaunchKernelGGL(raster_fwd_feat_f16, dim3(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices), dim3(64), 0, st, d, width, height,
+                           tile_w, n_tiles, n_slices, n_gauss, reinterpret_cast<const __half *>(colors), backgrounds, offsets,
+                           n_isects, blk_rows, wt, gid_s, Tbuf, out);
+        GAGS_CHECK_LAUNCH();
+        return GAGS_OK;
+    }
     if (colors_f16) {
         if (d % 128 == 0) return launch_feat<4, true>(ARGS);
         if (d % 64 == 0) return launch_feat<2, true>(ARGS);

@@ -225,7 +225,9 @@ class _Rasterize(torch.autograd.Function):
             check(lib.gags_raster_fwd(d, n, width, height, ptr(means2d), ptr(conics), ptr(opacities), ptr(colors),
                                       ptr(backgrounds), ptr(offsets), ptr(flatten_ids), n_isects, ptr(packed),
                                       ptr(out), ptr(alphas), ptr(last_ids), ptr(scratch), nbytes, ptr(blk_rows),
-                                      (flags & 3) | (_lib.GAGS_FEAT_F16 if half else 0), _stream()), "gags_raster_fwd")
+                                      (flags & 3) | (_lib.GAGS_FEAT_F16 if half else 0)
+                                      | (64 if (half and d % 128 == 0 and (flags & _lib.GAGS_FWD_F16MFMA)) else 0),
+                                      _stream()), "gags_raster_fwd")
         staged = (split and _mfma_width(d) and d <= 1024 and ctx.needs_input_grad[2]
                   and not (flags & _lib.GAGS_BWD_ATOMIC))
         ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, packed, alphas,

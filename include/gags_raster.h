@@ -44,6 +44,8 @@ extern "C" {
 #define GAGS_FWD_NO_MFMA 2     /* force the VALU kernels even when D allows the MFMA path */
 #define GAGS_FEAT_F16 32       /* forward: `colors` points to an fp16 [N,D] table (BASELINE.json configs[4]: fp16 feature
                                   storage); widened exactly, same fp32 arithmetic.  Split matrix-core forward only. */
+#define GAGS_FWD_F16MFMA 64    /* with GAGS_FEAT_F16 and D % 128 == 0, opt-in: the feature pass contracts on the 16-bit matrix
+                                  cores (features exact, weights as fp16 head + tail: ~2^-22 per term, not bit-identical) */
 
 int gags_abi_version(void);
 const char *gags_strerror(int code);

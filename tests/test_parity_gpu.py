@@ -169,6 +169,37 @@ def test_fp16_feature_table_is_exact_on_the_rounded_table(oracle):
     assert master.grad.dtype == torch.float32 and rel_l2(master.grad.cpu().numpy(), o_vf) <= 5e-4
 
 
+def test_fp16_table_on_the_16bit_matrix_cores(oracle):
+    """Opt-in GAGS_FWD_F16MFMA (+ GAGS_BWD_F16SPLIT): BASELINE.json configs[4] "fp16 features on CDNA4" on
+    v_mfma_f32_32x32x16_f16.  Features exact, weights as fp16 head + tail: stated ~2^-22 per term, tested <= 2e-6 rel-L2
+    of the oracle's render on the rounded table (indices and alphas stay bit-exact: they never see the feature path)."""
+    from gags_amd import _lib
+    from gags_amd.rasterization import rasterization
+    n, w, h, d = 5000, 208, 160, 256
+    s = scene_arrays(n, d, w, h, seed=71, view=1, scale_mult=6.0)
+    table = torch.from_numpy(s["colors"]).half()
+    bg = np.full(d, 0.4, np.float32)
+    v_out = np.random.default_rng(6).standard_normal((h, w, d)).astype(np.float32)
+    o_out, o_alpha, oinfo = oracle.rasterization(s["means"], s["quats"], s["scales"], s["opacities"], table.float().numpy(),
+                                                 s["viewmat"], s["K"], bg, w, h)
+    o_vf = oracle.raster_bwd_colors_fwdorder(oinfo["means2d"], oinfo["conics"], s["opacities"], d, w, h, oinfo["isect_offsets"],
+                                             oinfo["flatten_ids"], v_out, n)
+    res = []
+    for _ in range(2):
+        cols = table.cuda().requires_grad_(True)
+        out, alphas, info = rasterization(to_dev(s["means"]), to_dev(s["quats"]), to_dev(s["scales"]), to_dev(s["opacities"]), cols,
+                                          to_dev(s["viewmat"])[None], to_dev(s["K"])[None], w, h, backgrounds=to_dev(bg)[None],
+                                          raster_flags=_lib.GAGS_FWD_F16MFMA | _lib.GAGS_BWD_F16SPLIT)
+        (out[0] * to_dev(v_out)).sum().backward()
+        res.append((out[0].detach().cpu().numpy(), cols.grad.float().cpu().numpy()))
+    np.testing.assert_array_equal(alphas[0, ..., 0].detach().cpu().numpy(), o_alpha)
+    np.testing.assert_array_equal(info["last_ids"].cpu().numpy(), oinfo["last_ids"])
+    assert rel_l2(res[0][0], o_out) <= 2e-6
+    assert np.abs(res[0][0] - o_out).max() <= 2e-6 * np.abs(o_out).max()
+    np.testing.assert_array_equal(res[0][0], res[1][0])   # deterministic
+    assert rel_l2(res[0][1], o_vf) <= 5e-4                # gradient returned in fp16
+
+
 @pytest.mark.parametrize("d", [37, 513])
 def test_width_with_extra_channels(oracle, d):
     """D = 4k + r (513 = 512 CLIP channels + 1, configs[4]): matrix cores for the multiple-of-4 part, VALU kernels for

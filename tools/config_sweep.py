@@ -12,11 +12,12 @@ sys.path.insert(0, ROOT)
 import torch
 from gags_amd import synthetic as syn
 from gags_amd.gaussian_renderer import render
+from bench import _CotangentLoss  # loss = <render, G> whose backward hands G itself to the rasterizer (no elementwise pass)
 
 dev = torch.device("cuda", 0)
 
 
-def run(name, n, w, h, d, half=False, steps=8, feature_mode=True):
+def run(name, n, w, h, d, half=False, steps=8, flags=0):
     pc = syn.make_model(n, d, w, h, seed=0, device=dev, gen_device=dev)
     pc.training_setup()
     if half:
@@ -28,8 +29,8 @@ def run(name, n, w, h, d, half=False, steps=8, feature_mode=True):
 
     def step():
         pc._semantic_feature.grad = None
-        pkg = render(cam, pc, None, bg, feature_mode=True)
-        (pkg["render"] * G).sum().backward() if d < 16 else torch.dot(pkg["render"].permute(1, 2, 0).reshape(-1), G.permute(1, 2, 0).reshape(-1)).backward()
+        pkg = render(cam, pc, None, bg, feature_mode=True, raster_flags=flags)
+        _CotangentLoss.apply(pkg["render"].permute(1, 2, 0), G.permute(1, 2, 0)).backward()
         return pkg
 
     for _ in range(2):
@@ -55,6 +56,9 @@ out = dict([
     run("C3 geometry D=256", 1_500_000, 1920, 1080, 256),
     run("C5 4M/1080p/D=512 fp32 table", 4_000_000, 1920, 1080, 512),
     run("C5 4M/1080p/D=512 fp16 table", 4_000_000, 1920, 1080, 512, half=True),
+    run("C5 4M/1080p/D=512 fp16 table, 16-bit matrix cores fwd+bwd (opt-in)", 4_000_000, 1920, 1080, 512, half=True, flags=128 | 64),
+    run("C3 1.5M/1080p/D=512 fp16 table, 16-bit matrix cores fwd+bwd (opt-in)", 1_500_000, 1920, 1080, 512, half=True, flags=128 | 64),
+    run("C3 1.5M/1080p/D=512 fp32 table, 16-bit matrix cores bwd (opt-in)", 1_500_000, 1920, 1080, 512, flags=64),
     run("C5 4M/1080p/D=513 (512+1) fp32", 4_000_000, 1920, 1080, 513, steps=4),
 ])
 print(json.dumps(out))
