@@ -216,6 +216,69 @@ __global__ __launch_bounds__(256) void head_kernel(int64_t P, int C, int ld, int
     }
 }
 
+// The heads for ld <= 512, ld % 32 == 0 (every decoder of the reference): one workgroup = 32 pixels, thread = pixel
+// (tid >> 3) x channels (tid & 7) * 4 + 32 j held in registers, so the logits are read ONCE; the statistics are
+// reduced over the eight lanes of a pixel; the transpose goes through a [channel][pixel ^ (channel & 31)] LDS tile
+// (64 KB, conflict-free on the row side) and leaves as 128-byte rows.
+constexpr int HP = 32;      // pixels per workgroup
+constexpr int HJ = 16;      // float4 per thread (ld <= 512)
+
+__device__ __forceinline__ void head_stats(const float4 (&v)[HJ], int J, int C, int c0, int mode, float &s0, float &s1)
+{
+    float s = 0.f, m = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < HJ; ++j)
+        if (j < J) {
+            const float e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (c0 + 32 * j + k < C) { s = fmaf(e[k], e[k], s); m = fmaxf(m, e[k]); }
+        }
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
+    if (mode == 0) { s0 = fmaxf(sqrtf(s), 1e-12f); s1 = 0.f; return; }
+    float z = 0.f;
+#pragma unroll
+    for (int j = 0; j < HJ; ++j)
+        if (j < J) {
+            const float e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (c0 + 32 * j + k < C) z += expf(e[k] - m);
+        }
+    z += __shfl_xor(z, 1); z += __shfl_xor(z, 2); z += __shfl_xor(z, 4);
+    s0 = m; s1 = z;
+}
+
+__global__ __launch_bounds__(256) void head_fast_kernel(int64_t P, int C, int ld, int mode, const float *__restrict__ x,
+                                                        float *__restrict__ out)
+{
+    __shared__ float tile[512 * HP];
+    const int64_t p0 = (int64_t)blockIdx.x * HP;
+    const int tid = threadIdx.x, px = tid >> 3, c0 = (tid & 7) * 4, J = ld >> 5;
+    const int64_t p = min(p0 + px, P - 1);
+    float4 v[HJ];
+#pragma unroll
+    for (int j = 0; j < HJ; ++j)
+        v[j] = j < J ? *reinterpret_cast<const float4 *>(x + p * ld + c0 + 32 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float s0, s1;
+    head_stats(v, J, C, c0, mode, s0, s1);
+#pragma unroll
+    for (int j = 0; j < HJ; ++j)
+        if (j < J) {
+            const float e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = c0 + 32 * j + k;
+                if (c < C) tile[c * HP + (px ^ (c & 31))] = mode == 0 ? e[k] / s0 : expf(e[k] - s0) / s1;
+            }
+        }
+    __syncthreads();
+    const int lp = tid & 31;
+    if (p0 + lp < P)
+        for (int c = tid >> 5; c < C; c += 8) out[(size_t)c * P + p0 + lp] = tile[c * HP + (lp ^ (c & 31))];
+}
+
 // Weight gradient of one layer: dW[n, k] += sum_p dz[p, n] * (a1[p, k] + a2[p, k]),  db[n] += sum_p dz[p, n].
 // The contraction runs over PIXELS, the slow index of both operands, so the 32-pixel tiles are transposed on their
 // way into LDS (8-byte stores of four pixels of one column) and both MFMA fragments become 16-byte rows again.
@@ -399,6 +462,66 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(int64_t P, int C, int ld,
     }
 }
 
+// backward heads for ld <= 512, ld % 32 == 0: the same 32-pixel tiling as head_fast_kernel; the cotangent tile
+// sits in LDS, the logits in registers, so G and x are each read once.
+__global__ __launch_bounds__(256) void head_bwd_fast_kernel(int64_t P, int C, int ld, int mode, const float *__restrict__ x,
+                                                            const float *__restrict__ G, unsigned short *__restrict__ dz)
+{
+    __shared__ float tile[512 * HP];
+    const int64_t p0 = (int64_t)blockIdx.x * HP;
+    const int tid = threadIdx.x, px = tid >> 3, c0 = (tid & 7) * 4, J = ld >> 5;
+    const int64_t p = min(p0 + px, P - 1);
+    {
+        const int lp = tid & 31;
+        const bool ok = p0 + lp < P;
+        for (int c = tid >> 5; c < C; c += 8) tile[c * HP + (lp ^ (c & 31))] = ok ? G[(size_t)c * P + p0 + lp] : 0.f;
+    }
+    float4 v[HJ];
+#pragma unroll
+    for (int j = 0; j < HJ; ++j)
+        v[j] = j < J ? *reinterpret_cast<const float4 *>(x + p * ld + c0 + 32 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float s0, s1;
+    head_stats(v, J, C, c0, mode, s0, s1);
+    __syncthreads();
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < HJ; ++j)
+        if (j < J) {
+            const float e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = c0 + 32 * j + k;
+                if (c < C) {
+                    const float y = mode == 0 ? e[k] / s0 : expf(e[k] - s0) / s1;
+                    dot = fmaf(y, tile[c * HP + (px ^ (c & 31))], dot);
+                }
+            }
+        }
+    dot += __shfl_xor(dot, 1); dot += __shfl_xor(dot, 2); dot += __shfl_xor(dot, 4);
+    if (p0 + px >= P) return;
+#pragma unroll
+    for (int j = 0; j < HJ; ++j)
+        if (j < J) {
+            const float e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+            unsigned short o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = c0 + 32 * j + k;
+                float d = 0.f;
+                if (c < C) {
+                    const float g = tile[c * HP + (px ^ (c & 31))];
+                    if (mode == 0) d = (g - (e[k] / s0) * dot) / s0;
+                    else d = (expf(e[k] - s0) / s1) * (g - dot);
+                }
+                o[k] = f2bf(d);
+            }
+            uint2 w;
+            w.x = (unsigned)o[0] | ((unsigned)o[1] << 16);
+            w.y = (unsigned)o[2] | ((unsigned)o[3] << 16);
+            *reinterpret_cast<uint2 *>(dz + p * ld + c0 + 32 * j) = w;
+        }
+}
+
 // bf16 [P, ld] -> fp32 [P, C] (first C columns): the input gradient in the rasterizer's [H, W, D] layout
 __global__ __launch_bounds__(256) void unpack_f32_kernel(int64_t P, int C, int ld, const unsigned short *__restrict__ x,
                                                          float *__restrict__ y)
@@ -446,7 +569,11 @@ extern "C" int gags_decoder_head(int64_t n_pix, int c, int ld, int mode, const f
     GAGS_CLEAR_ERR();
     if (n_pix < 0 || c <= 0 || ld < c || (mode != 0 && mode != 1) || (n_pix > 0 && (!x || !out))) return GAGS_EINVAL;
     if (n_pix == 0) return GAGS_OK;
-    hipLaunchKernelGGL(head_kernel, dim3((unsigned)((n_pix + 63) / 64)), dim3(256), 0, (hipStream_t)stream, n_pix, c, ld, mode, x, out);
+    if (ld <= 512 && ld % 32 == 0)
+        hipLaunchKernelGGL(head_fast_kernel, dim3((unsigned)((n_pix + HP - 1) / HP)), dim3(256), 0, (hipStream_t)stream, n_pix, c, ld,
+                           mode, x, out);
+    else
+        hipLaunchKernelGGL(head_kernel, dim3((unsigned)((n_pix + 63) / 64)), dim3(256), 0, (hipStream_t)stream, n_pix, c, ld, mode, x, out);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }
@@ -471,8 +598,12 @@ extern "C" int gags_decoder_head_bwd(int64_t n_pix, int c, int ld, int mode, con
     GAGS_CLEAR_ERR();
     if (n_pix < 0 || c <= 0 || ld < c || (mode != 0 && mode != 1) || (n_pix > 0 && (!x || !g || !dz_bf16))) return GAGS_EINVAL;
     if (n_pix == 0) return GAGS_OK;
-    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((n_pix + 63) / 64)), dim3(256), 0, (hipStream_t)stream, n_pix, c, ld, mode,
-                       x, g, (unsigned short *)dz_bf16);
+    if (ld <= 512 && ld % 32 == 0)
+        hipLaunchKernelGGL(head_bwd_fast_kernel, dim3((unsigned)((n_pix + HP - 1) / HP)), dim3(256), 0, (hipStream_t)stream, n_pix, c,
+                           ld, mode, x, g, (unsigned short *)dz_bf16);
+    else
+        hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((n_pix + 63) / 64)), dim3(256), 0, (hipStream_t)stream, n_pix, c, ld, mode,
+                           x, g, (unsigned short *)dz_bf16);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }

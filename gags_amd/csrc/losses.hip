@@ -55,8 +55,7 @@ __global__ __launch_bounds__(256) void entropy_bwd_kernel(int64_t n, const float
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// per-segment moments.  One wave = 64 consecutive pixels; neighbouring pixels mostly share a segment, so when the
-// whole wave agrees it reduces first and issues ONE double atomic per moment, otherwise every lane adds its own.
+// per-segment moments.  One wave = 64 consecutive pixels.
 __global__ __launch_bounds__(256) void segment_stats_kernel(int64_t n_pix, int c, const float *__restrict__ x,
                                                             const float *__restrict__ seg, int n_seg,
                                                             double *__restrict__ s1, double *__restrict__ s2,
@@ -69,24 +68,22 @@ __global__ __launch_bounds__(256) void segment_stats_kernel(int64_t n_pix, int c
         const float f = seg[p];
         id = (f >= 0.f && f < (float)n_seg) ? (int)f : -1;
     }
-    const int first = __builtin_amdgcn_readfirstlane(id);
-    const bool uniform = __all(id == first);
-    if (uniform) {
-        if (first < 0) return;
-        if (lane == 0) atomicAdd(&cnt[first], 64);
+    // one round per distinct segment id in the wave (neighbouring pixels mostly share one): the lanes of that segment
+    // are summed with a full-wave reduction of their masked values and the leader issues ONE double atomic per moment
+    unsigned long long todo = __ballot(id >= 0);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int cur = __builtin_amdgcn_readlane(id, leader);
+        const unsigned long long grp = __ballot(id == cur);
+        const bool in = id == cur;
+        if (lane == leader) atomicAdd(&cnt[cur], (int)__popcll(grp));
         for (int ch = 0; ch < c; ++ch) {
-            const float v = x[(size_t)ch * n_pix + p];
+            const float v = in ? x[(size_t)ch * n_pix + p] : 0.f;
             double a = v, b = (double)v * (double)v;
-            for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
-            if (lane == 0) { atomicAdd(&s1[(size_t)first * c + ch], a); atomicAdd(&s2[(size_t)first * c + ch], b); }
+            for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
+            if (lane == leader) { atomicAdd(&s1[(size_t)cur * c + ch], a); atomicAdd(&s2[(size_t)cur * c + ch], b); }
         }
-    } else if (id >= 0) {
-        atomicAdd(&cnt[id], 1);
-        for (int ch = 0; ch < c; ++ch) {
-            const float v = x[(size_t)ch * n_pix + p];
-            atomicAdd(&s1[(size_t)id * c + ch], (double)v);
-            atomicAdd(&s2[(size_t)id * c + ch], (double)v * (double)v);
-        }
+        todo &= ~grp;
     }
 }
 

@@ -163,3 +163,29 @@ def test_decoder_backward_kernels_against_fp32_on_the_same_masks():
         errs[f"w{i}"] = ((got[f"w{i}"] - Wf[i].grad[:co, :ci]).double().norm() / Wf[i].grad[:co, :ci].double().norm()).item()
         errs[f"b{i}"] = ((got[f"b{i}"] - Bf[i].grad[:co]).double().norm() / Bf[i].grad[:co].double().norm()).item()
     assert max(errs.values()) <= 1.5e-2, errs
+
+
+@pytest.mark.parametrize("c,ld", [(512, 512), (3, 32), (100, 128), (37, 40), (520, 544)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_head_kernels_against_torch(c, ld, mode):
+    """gags_decoder_head / _head_bwd alone (models/networks.py:192 normalize, :242 softmax) in fp32 against torch, on
+    both kernels behind the entry: the 32-pixel register-resident one (ld <= 512, ld % 32 == 0) and the general one."""
+    from gags_amd import _lib
+    from gags_amd.decoders import _st
+    from gags_amd._lib import check, ptr
+    lib = _lib.load()
+    p = 1000 + 13
+    g = torch.Generator(device="cuda").manual_seed(c + mode)
+    x = torch.zeros(p, ld, device="cuda")
+    x[:, :c] = torch.randn(p, c, device="cuda", generator=g) * 2
+    G = torch.randn(c, p, device="cuda", generator=g)
+    out = torch.empty(c, p, device="cuda")
+    dz = torch.full((p, ld), 7.0, device="cuda", dtype=torch.bfloat16)
+    check(lib.gags_decoder_head(p, c, ld, mode, ptr(x), ptr(out), _st()), "head")
+    check(lib.gags_decoder_head_bwd(p, c, ld, mode, ptr(x), ptr(G), ptr(dz), _st()), "head_bwd")
+    xr = x[:, :c].clone().double().requires_grad_(True)
+    ref = torch.nn.functional.normalize(xr, dim=1) if mode == 0 else torch.softmax(xr, dim=1)
+    (ref * G.t().double()).sum().backward()
+    assert ((out.t().double() - ref).norm() / ref.norm()).item() <= 1e-6
+    assert ((dz[:, :c].double() - xr.grad).norm() / xr.grad.norm()).item() <= 4e-3   # bf16 output
+    assert torch.count_nonzero(dz[:, c:]).item() == 0
