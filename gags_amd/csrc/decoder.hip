@@ -25,8 +25,18 @@ __device__ __forceinline__ unsigned short f2bf(float f)
     return (unsigned short)(u >> 16);
 }
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+// two floats -> packed bf16 pair, round to nearest even, in one instruction (v_cvt_pk_bf16_f32, new on gfx950)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
+{
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
-constexpr int TM = 128, TN = 128, TK = 64;  // workgroup tile: 128 pixels x 128 outputs, K step 64
+constexpr int TM = 128, TK = 64;             // workgroup tile: 128 pixels x (64 NJ) outputs, K step 64
 constexpr int LDK = TK + 8;                  // LDS row pitch in bf16 (144 B: 16-byte aligned, spreads the banks)
 
 struct GemmArgs {
@@ -44,111 +54,174 @@ struct GemmArgs {
 
 __device__ __forceinline__ unsigned add_bf16x2(unsigned x, unsigned y)
 {
-    const float lo = bf2f((unsigned short)(x & 0xffff)) + bf2f((unsigned short)(y & 0xffff));
-    const float hi = bf2f((unsigned short)(x >> 16)) + bf2f((unsigned short)(y >> 16));
-    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+    return pack_bf16(bf_lo(x) + bf_lo(y), bf_hi(x) + bf_hi(y));
 }
 
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs a)
+// NJ = 32-column blocks per wave: the workgroup tile is 128 pixels x TN = 64 NJ outputs (NJ = 4: a 256-wide layer in
+// ONE tile, so the activations are read once).  Wider layers take several column tiles per pixel tile; the workgroup
+// index is decoded so that those land on the SAME XCD back to back (hardware deals workgroups round-robin over the 8
+// XCDs, each with its own L2): the second one finds the activation tile in that L2 instead of re-reading HBM.
+template <int NJ, bool TWO>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a, int n_tiles, unsigned p_tiles)
 {
-    __shared__ __attribute__((aligned(16))) unsigned short As[TM][LDK];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[TN][LDK];
+    constexpr int TN = 64 * NJ;
+    __shared__ __attribute__((aligned(16))) unsigned short smem[(TM + TN) * LDK];
+    unsigned short (*As)[LDK] = reinterpret_cast<unsigned short (*)[LDK]>(smem);
+    unsigned short (*Bs)[LDK] = reinterpret_cast<unsigned short (*)[LDK]>(smem + TM * LDK);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wy = wave >> 1, wx = wave & 1;  // 2 x 2 waves, 64 x 64 outputs each
-    const int64_t p0 = (int64_t)blockIdx.x * TM;
-    const int n0 = blockIdx.y * TN;
-    f32x16 acc[2][2];
+    const int wy = wave >> 1, wx = wave & 1;  // 2 x 2 waves, 64 x (32 NJ) outputs each
+    unsigned pt = blockIdx.x;
+    int nt = 0;
+    if (n_tiles > 1) {
+        const unsigned xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        pt = (slot / n_tiles) * 8 + xcd;
+        nt = slot % n_tiles;
+        if (pt >= p_tiles) return;
+    }
+    const int64_t p0 = (int64_t)pt * TM;
+    const int n0 = nt * TN;
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     // staging identity: 16-byte piece tid % 8 of rows tid / 8 + 32 q (eight consecutive lanes read one row's 128
     // contiguous bytes: fully coalesced); the next K step's operands are requested into registers before the current
-    // one is multiplied (the K loop is only 4-8 steps long: no deeper pipeline)
+    // one is multiplied (the K loop is only 4-8 steps long: no deeper pipeline).  Every address is clamped into the
+    // operand, so the loads are unconditional (a predicated load is a branch and a wait of its own) and what lies
+    // beyond K is zeroed by a select; the second activation source is added when the tile goes to LDS, not when it is
+    // requested.
     const int sr = tid >> 3, sh = (tid & 7) * 8;
-    uint4 ra[4], rb[4];
-    auto fetch = [&](int k0) {
-        const bool ok = k0 + sh < a.K;  // K is a multiple of 32, the step is 64
+    uint4 ra[4], ra2[TWO ? 4 : 1], rb[2 * NJ];
+    unsigned aoff[4], boff[2 * NJ];  // element offsets: P * K < 2^31 is checked by the entry
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int64_t arow = min(p0 + sr + 32 * q, a.P - 1);
-            const int brow = min(n0 + sr + 32 * q, a.N - 1);
-            ra[q] = ok ? *reinterpret_cast<const uint4 *>(a.A1 + arow * a.K + k0 + sh) : make_uint4(0, 0, 0, 0);
-            rb[q] = ok ? *reinterpret_cast<const uint4 *>(a.W + (size_t)brow * a.K + k0 + sh) : make_uint4(0, 0, 0, 0);
-            if (a.A2 && ok) {  // residual sum of two activations: add in fp32, round once
-                const uint4 v = *reinterpret_cast<const uint4 *>(a.A2 + arow * a.K + k0 + sh);
-                ra[q] = make_uint4(add_bf16x2(ra[q].x, v.x), add_bf16x2(ra[q].y, v.y), add_bf16x2(ra[q].z, v.z), add_bf16x2(ra[q].w, v.w));
-            }
+    for (int q = 0; q < 4; ++q) aoff[q] = (unsigned)(min(p0 + sr + 32 * q, a.P - 1) * a.K);
+#pragma unroll
+    for (int q = 0; q < 2 * NJ; ++q) boff[q] = (unsigned)(min(n0 + sr + 32 * q, a.N - 1) * a.K);
+    bool fetched_ok = true;
+    auto fetch = [&](int k0) __attribute__((always_inline)) {
+        fetched_ok = k0 + sh < a.K;  // K is a multiple of 32, the step is 64
+        const int kc = fetched_ok ? k0 + sh : 0;
+#pragma unroll
+        for (int q = 0; q < 2 * NJ; ++q) rb[q] = *reinterpret_cast<const uint4 *>(a.W + boff[q] + kc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ra[q] = *reinterpret_cast<const uint4 *>(a.A1 + aoff[q] + kc);
+        if constexpr (TWO) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ra2[q] = *reinterpret_cast<const uint4 *>(a.A2 + aoff[q] + kc);
         }
+    };
+    auto commit = [&]() __attribute__((always_inline)) {
+        const unsigned keep = fetched_ok ? 0xffffffffu : 0u;  // (a select between two uint4 lvalues would pin them in memory)
+        if constexpr (TWO) {  // residual sum of two activations: add in fp32, round once
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                ra[q] = make_uint4(add_bf16x2(ra[q].x, ra2[q].x), add_bf16x2(ra[q].y, ra2[q].y), add_bf16x2(ra[q].z, ra2[q].z),
+                                   add_bf16x2(ra[q].w, ra2[q].w));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4 *>(&As[sr + 32 * q][sh]) =
+                make_uint4(ra[q].x & keep, ra[q].y & keep, ra[q].z & keep, ra[q].w & keep);
+#pragma unroll
+        for (int q = 0; q < 2 * NJ; ++q) *reinterpret_cast<uint4 *>(&Bs[sr + 32 * q][sh]) =
+                make_uint4(rb[q].x & keep, rb[q].y & keep, rb[q].z & keep, rb[q].w & keep);
     };
     fetch(0);
     for (int k0 = 0; k0 < a.K; k0 += TK) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            *reinterpret_cast<uint4 *>(&As[sr + 32 * q][sh]) = ra[q];
-            *reinterpret_cast<uint4 *>(&Bs[sr + 32 * q][sh]) = rb[q];
-        }
+        commit();
         __syncthreads();
         if (k0 + TK < a.K) fetch(k0 + TK);
 #pragma unroll
         for (int ks = 0; ks < TK; ks += 16) {
-            bf16x8 af[2], bf[2];
+            bf16x8 af[2], bf[NJ];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
                 af[i] = *reinterpret_cast<const bf16x8 *>(&As[wy * 64 + i * 32 + (lane & 31)][ks + 8 * (lane >> 5)]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                bf[j] = *reinterpret_cast<const bf16x8 *>(&Bs[wx * 64 + j * 32 + (lane & 31)][ks + 8 * (lane >> 5)]);
+            for (int j = 0; j < NJ; ++j)
+                bf[j] = *reinterpret_cast<const bf16x8 *>(&Bs[wx * 32 * NJ + j * 32 + (lane & 31)][ks + 8 * (lane >> 5)]);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
-    // The operands were swapped above (weights as "A", activations as "B"): an accumulator's lane then owns ONE pixel
-    // (column = lane & 31) and 16 output channels (rows): channel (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the tile.
+    // The operands were swapped above (weights as "A", activations as "B"): an accumulator's lane owns ONE pixel
+    // (column = lane & 31) and 16 output channels (rows): channel (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of a 32-block.
+    // Stored from there, every instruction would scatter 8-byte pieces 2 N bytes apart and HBM sees partial lines
+    // (measured: 2.4 x the bytes, 25 B per write request).  Instead each wave passes 32 pixels x 64 channels at a time
+    // through its own LDS patch in fp32 (bias and ReLU applied on the way in) and reads it back with 8 consecutive
+    // channels per lane: the skip gradient E and the mask are then 16-byte reads and the results 16 / 32-byte stores,
+    // eight lanes per 128-byte (bf16) or 256-byte (fp32) run of one pixel.
+    constexpr int SP = 68;  // patch pitch in floats (272 B: conflict-free for both the b128 writes and reads)
+    static_assert(4 * 32 * SP * 4 <= (TM + TN) * LDK * 2, "epilogue patches fit in the operand tiles' LDS");
+    float *stg = reinterpret_cast<float *>(smem) + wave * 32 * SP;
+    const int epx = lane & 31, ehalf = lane >> 5, cg = lane & 7;
+    const bool full = p0 + TM <= a.P && n0 + TN <= a.N;  // workgroup-uniform: the interior needs no per-lane tests
+    const float floor_ = a.relu ? 0.f : -3.4e38f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int64_t p = p0 + wy * 64 + i * 32 + (lane & 31);
-        if (p >= a.P) continue;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int jp = 0; jp < NJ / 2; ++jp) {
+            const int nb = n0 + wx * 32 * NJ + jp * 64;  // first channel of this pass (wave-uniform)
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {  // four consecutive channels per group of accumulator registers
-                const int n = n0 + wx * 64 + j * 32 + 8 * rq + 4 * (lane >> 5);
-                if (n >= a.N) continue;
-                float v[4];
+            for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float t = acc[i][j][4 * rq + q] + (a.bias ? a.bias[n + q] : 0.f);
-                    if (a.relu) t = fmaxf(t, 0.f);
-                    v[q] = t;
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int r0 = 4 * rq;
+                    const f32x16 &c = acc[i][2 * jp + jj];
+                    *reinterpret_cast<float4 *>(stg + epx * SP + jj * 32 + 8 * rq + 4 * ehalf) =
+                        make_float4(c[r0], c[r0 + 1], c[r0 + 2], c[r0 + 3]);
                 }
-                const size_t o = (size_t)p * a.N + n;
-                if (a.E) {
-                    const uint2 e = *reinterpret_cast<const uint2 *>(a.E + o);
-                    v[0] += bf2f((unsigned short)(e.x & 0xffff)); v[1] += bf2f((unsigned short)(e.x >> 16));
-                    v[2] += bf2f((unsigned short)(e.y & 0xffff)); v[3] += bf2f((unsigned short)(e.y >> 16));
-                }
-                if (a.Ypre)
-                    *reinterpret_cast<uint2 *>(a.Ypre + o) = make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16),
-                                                                        (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
-                if (a.mask_src) {
-                    const uint2 m = *reinterpret_cast<const uint2 *>(a.mask_src + o);
-                    v[0] = bf2f((unsigned short)(m.x & 0xffff)) > 0.f ? v[0] : 0.f;
-                    v[1] = bf2f((unsigned short)(m.x >> 16)) > 0.f ? v[1] : 0.f;
-                    v[2] = bf2f((unsigned short)(m.y & 0xffff)) > 0.f ? v[2] : 0.f;
-                    v[3] = bf2f((unsigned short)(m.y >> 16)) > 0.f ? v[3] : 0.f;
-                }
-                if (a.Y)
-                    *reinterpret_cast<uint2 *>(a.Y + o) = make_uint2((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16),
-                                                                     (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
-                if (a.Yf) *reinterpret_cast<float4 *>(a.Yf + o) = make_float4(v[0], v[1], v[2], v[3]);
+            __builtin_amdgcn_wave_barrier();
+            const int n = nb + cg * 8;           // this lane's 8 channels: the same in all four pixel groups
+            const int nc = min(n, a.N - 8);
+            float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (a.bias) {
+                const float4 b0 = *reinterpret_cast<const float4 *>(a.bias + nc), b1 = *reinterpret_cast<const float4 *>(a.bias + nc + 4);
+                bs[0] = b0.x; bs[1] = b0.y; bs[2] = b0.z; bs[3] = b0.w; bs[4] = b1.x; bs[5] = b1.y; bs[6] = b1.z; bs[7] = b1.w;
             }
+#pragma unroll
+            for (int t2 = 0; t2 < 4; ++t2) {
+                const int px = t2 * 8 + (lane >> 3);
+                const float4 lo = *reinterpret_cast<const float4 *>(stg + px * SP + cg * 8);
+                const float4 hi = *reinterpret_cast<const float4 *>(stg + px * SP + cg * 8 + 4);
+                float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q] + bs[q], floor_);
+                const int64_t p = p0 + wy * 64 + i * 32 + px;
+                const bool live = full || (p < a.P && n < a.N);
+                const size_t o = (size_t)min(p, a.P - 1) * a.N + nc;  // always a valid address: loads are unconditional
+                if (a.E) {
+                    const uint4 e = *reinterpret_cast<const uint4 *>(a.E + o);
+                    v[0] += bf_lo(e.x); v[1] += bf_hi(e.x); v[2] += bf_lo(e.y); v[3] += bf_hi(e.y);
+                    v[4] += bf_lo(e.z); v[5] += bf_hi(e.z); v[6] += bf_lo(e.w); v[7] += bf_hi(e.w);
+                }
+                if (a.Ypre && live)
+                    *reinterpret_cast<uint4 *>(a.Ypre + o) =
+                        make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+                if (a.mask_src) {
+                    const uint4 m = *reinterpret_cast<const uint4 *>(a.mask_src + o);
+                    const unsigned mw[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        v[2 * q] = bf_lo(mw[q]) > 0.f ? v[2 * q] : 0.f;
+                        v[2 * q + 1] = bf_hi(mw[q]) > 0.f ? v[2 * q + 1] : 0.f;
+                    }
+                }
+                if (a.Y && live)
+                    *reinterpret_cast<uint4 *>(a.Y + o) =
+                        make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+                if (a.Yf && live) {
+                    *reinterpret_cast<float4 *>(a.Yf + o) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4 *>(a.Yf + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -471,18 +544,34 @@ __global__ __launch_bounds__(256) void head_bwd_fast_kernel(int64_t P, int C, in
     const int64_t p0 = (int64_t)blockIdx.x * HP;
     const int tid = threadIdx.x, px = tid >> 3, c0 = (tid & 7) * 4, J = ld >> 5;
     const int64_t p = min(p0 + px, P - 1);
-    {
-        const int lp = tid & 31;
-        const bool ok = p0 + lp < P;
-        for (int c = tid >> 5; c < C; c += 8) tile[c * HP + (lp ^ (c & 31))] = ok ? G[(size_t)c * P + p0 + lp] : 0.f;
-    }
     float4 v[HJ];
 #pragma unroll
     for (int j = 0; j < HJ; ++j)
         v[j] = j < J ? *reinterpret_cast<const float4 *>(x + p * ld + c0 + 32 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+        // the cotangent rows in two batches of 32 loads in flight (a rolled loop would wait for every single row)
+        const int lp = tid & 31, cw = tid >> 5;
+        const int64_t pg = min(p0 + lp, P - 1);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            float g[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int c = cw + 8 * (32 * b + i);
+                g[i] = c < C ? G[(size_t)c * P + pg] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int c = cw + 8 * (32 * b + i);
+                if (c < C) tile[c * HP + (lp ^ (c & 31))] = g[i];
+            }
+        }
+    }
     float s0, s1;
     head_stats(v, J, C, c0, mode, s0, s1);
     __syncthreads();
+    // reciprocals once per pixel: the per-element work is one or two FMAs (the result is rounded to bf16 anyway)
+    const float inv0 = 1.f / s0, inv1 = mode == 1 ? 1.f / s1 : 0.f;
     float dot = 0.f;
 #pragma unroll
     for (int j = 0; j < HJ; ++j)
@@ -492,12 +581,14 @@ __global__ __launch_bounds__(256) void head_bwd_fast_kernel(int64_t P, int C, in
             for (int k = 0; k < 4; ++k) {
                 const int c = c0 + 32 * j + k;
                 if (c < C) {
-                    const float y = mode == 0 ? e[k] / s0 : expf(e[k] - s0) / s1;
+                    const float y = mode == 0 ? e[k] : expf(e[k] - s0) * inv1;   // mode 0: the 1 / norm is applied to the sum
                     dot = fmaf(y, tile[c * HP + (px ^ (c & 31))], dot);
                 }
             }
         }
     dot += __shfl_xor(dot, 1); dot += __shfl_xor(dot, 2); dot += __shfl_xor(dot, 4);
+    if (mode == 0) dot *= inv0;          // <y, g>
+    const float k1 = dot * inv0 * inv0;  // mode 0: dz = g / n - x <y, g> / n^2
     if (p0 + px >= P) return;
 #pragma unroll
     for (int j = 0; j < HJ; ++j)
@@ -510,8 +601,8 @@ __global__ __launch_bounds__(256) void head_bwd_fast_kernel(int64_t P, int C, in
                 float d = 0.f;
                 if (c < C) {
                     const float g = tile[c * HP + (px ^ (c & 31))];
-                    if (mode == 0) d = (g - (e[k] / s0) * dot) / s0;
-                    else d = (expf(e[k] - s0) / s1) * (g - dot);
+                    if (mode == 0) d = fmaf(g, inv0, -e[k] * k1);
+                    else d = (expf(e[k] - s0) * inv1) * (g - dot);
                 }
                 o[k] = f2bf(d);
             }
@@ -550,7 +641,7 @@ extern "C" int gags_decoder_layer(int64_t n_pix, int n_out, int k_in, const void
                                   void *y_premask_bf16, float *y_f32, void *stream)
 {
     GAGS_CLEAR_ERR();
-    if (n_pix < 0 || n_out <= 0 || k_in <= 0 || k_in % 32 != 0 || n_out % 4 != 0 || !a1 || !w ||
+    if (n_pix < 0 || n_out <= 0 || k_in <= 0 || k_in % 32 != 0 || n_out % 8 != 0 || n_pix * k_in >= ((int64_t)1 << 31) || !a1 || !w ||
         (!y_bf16 && !y_f32 && !y_premask_bf16))
         return GAGS_EINVAL;
     if (n_pix == 0) return GAGS_OK;
@@ -558,8 +649,16 @@ extern "C" int gags_decoder_layer(int64_t n_pix, int n_out, int k_in, const void
     g.A1 = (const unsigned short *)a1; g.A2 = (const unsigned short *)a2; g.W = (const unsigned short *)w; g.bias = bias;
     g.mask_src = (const unsigned short *)mask_src; g.E = (const unsigned short *)residual;
     g.Y = (unsigned short *)y_bf16; g.Ypre = (unsigned short *)y_premask_bf16; g.Yf = y_f32; g.P = n_pix; g.N = n_out; g.K = k_in; g.relu = relu;
-    hipLaunchKernelGGL(gemm_bf16_kernel, dim3((unsigned)((n_pix + TM - 1) / TM), (unsigned)((n_out + TN - 1) / TN)), dim3(256), 0,
-                       (hipStream_t)stream, g);
+    const unsigned p_tiles = (unsigned)((n_pix + TM - 1) / TM);
+    if (n_out > 128) {
+        const int n_tiles = (n_out + 255) / 256;
+        const unsigned grid = n_tiles == 1 ? p_tiles : (p_tiles + 7) / 8 * 8 * n_tiles;
+        if (a2) hipLaunchKernelGGL((gemm_bf16_kernel<4, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, g, n_tiles, p_tiles);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<4, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, g, n_tiles, p_tiles);
+    } else {
+        if (a2) hipLaunchKernelGGL((gemm_bf16_kernel<2, true>), dim3(p_tiles), dim3(256), 0, (hipStream_t)stream, g, 1, p_tiles);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<2, false>), dim3(p_tiles), dim3(256), 0, (hipStream_t)stream, g, 1, p_tiles);
+    }
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }

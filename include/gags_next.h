@@ -68,7 +68,7 @@ int gags_decoder_pack_input(int64_t n_pix, int c, int c_pad, const float *x, voi
 /* One 1x1-convolution layer as a GEMM on the 16-bit matrix cores (bf16 operands, fp32 accumulate):
  *     y[p, n] = act( sum_k (a1[p, k] + a2[p, k]) * w[n, k] + bias[n] ) * (mask_src[p, n] > 0) + residual[p, n]
  * a1, a2 (optional: the residual sums x1 + x2 / x3 + x4 of CNN_decoder.forward), w, mask_src (optional), residual
- * (optional), y_bf16: bf16; bias (optional), y_f32 (optional second output): fp32.  k_in % 32 == 0, n_out % 4 == 0.
+ * (optional), y_bf16: bf16; bias (optional), y_f32 (optional second output): fp32.  k_in % 32 == 0, n_out % 8 == 0.
  * The backward's input-gradient GEMM is the same call with w = W^T, mask_src = the layer below's output (its ReLU
  * mask) and residual = the gradient arriving over a skip connection. */
 int gags_decoder_layer(int64_t n_pix, int n_out, int k_in, const void *a1, const void *a2, const void *w,
