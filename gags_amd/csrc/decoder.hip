@@ -456,6 +456,149 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(int64_t P, int N, int K
     }
 }
 
+// Weight gradient for the 256-input layers (8 of CNN_decoder's 9): workgroup = 128 outputs (n) x all 256 inputs (k)
+// x a chunk of pixels.  Both operands stay PIXEL-major in LDS exactly as they sit in memory (16-byte loads, 16-byte
+// LDS writes, no shuffling in registers) and the MFMA fragments, which want eight consecutive PIXELS of one channel
+// per lane, come out of gfx950's transposing LDS read: ds_read_b64_tr_b16 hands lane l of a 16-lane group the four
+// rows of column l of a [4 pixels][16 channels] block.  Row pitches of 64 B mod 256 B put the four pixel rows of a
+// read on four different quarters of the 64 banks.  The LDS image is double-buffered (one barrier per 32-pixel
+// step) and the operands of the step after next are in flight in registers meanwhile; two workgroups per CU.
+constexpr int W2P = 32;                       // pixels per step
+constexpr int W2ZP = 128 * 2 + 64;            // bytes per pixel row, dz image (128 channels)
+constexpr int W2XP = 256 * 2 + 64;            // bytes per pixel row, activation image (256 channels)
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4s *lds_v4s;
+
+template <bool TWO>
+__global__ __launch_bounds__(256, 2) void wgrad256_kernel(int64_t P, int N, const unsigned short *__restrict__ dz,
+                                                          const unsigned short *__restrict__ a1,
+                                                          const unsigned short *__restrict__ a2, float *__restrict__ dW,
+                                                          float *__restrict__ db, int64_t chunk, int n_tiles, unsigned n_chunks)
+{
+    constexpr int K = 256;
+    __shared__ __attribute__((aligned(16))) unsigned char Zi[2][W2P * W2ZP];
+    __shared__ __attribute__((aligned(16))) unsigned char Xi[2][W2P * W2XP];
+    __shared__ float bred[128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wy = wave >> 1, wx = wave & 1;  // 2 x 2 waves: 64 n x 128 k each
+    // the n tiles of one pixel chunk run back to back on the same XCD (they share the activation rows through its L2)
+    unsigned ck = blockIdx.x;
+    int nt = 0;
+    if (n_tiles > 1) {
+        const unsigned xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        ck = (slot / n_tiles) * 8 + xcd;
+        nt = slot % n_tiles;
+        if (ck >= n_chunks) return;
+    }
+    const int n0 = nt * 128;
+    const int64_t pa = (int64_t)ck * chunk, pb = min(pa + chunk, P);
+    if (pa >= pb) return;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // loads: dz piece tid & 15 (8 channels) of rows tid / 16 + 16 q; activation piece tid & 31 of rows tid / 32 + 8 q
+    const int zc = (tid & 15) * 8, zr = tid >> 4, xc = (tid & 31) * 8, xr = tid >> 5;
+    uint4 rz[2], rx[4], rx2[TWO ? 4 : 1];
+    auto fetch = [&](int64_t p0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) rz[q] = *reinterpret_cast<const uint4 *>(dz + min(p0 + zr + 16 * q, pb - 1) * N + n0 + zc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t o = min(p0 + xr + 8 * q, pb - 1) * K + xc;
+            rx[q] = *reinterpret_cast<const uint4 *>(a1 + o);
+            if constexpr (TWO) rx2[q] = *reinterpret_cast<const uint4 *>(a2 + o);
+        }
+    };
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = db != nullptr;
+    auto commit = [&](int buf, int64_t p0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const unsigned keep = p0 + zr + 16 * q < pb ? 0xffffffffu : 0u;  // rows beyond the chunk contribute zero
+            const uint4 v = make_uint4(rz[q].x & keep, rz[q].y & keep, rz[q].z & keep, rz[q].w & keep);
+            *reinterpret_cast<uint4 *>(&Zi[buf][(zr + 16 * q) * W2ZP + zc * 2]) = v;
+            if (do_bias) {
+                bsum[0] += bf_lo(v.x); bsum[1] += bf_hi(v.x); bsum[2] += bf_lo(v.y); bsum[3] += bf_hi(v.y);
+                bsum[4] += bf_lo(v.z); bsum[5] += bf_hi(v.z); bsum[6] += bf_lo(v.w); bsum[7] += bf_hi(v.w);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint4 v = rx[q];
+            if constexpr (TWO)
+                v = make_uint4(add_bf16x2(v.x, rx2[q].x), add_bf16x2(v.y, rx2[q].y), add_bf16x2(v.z, rx2[q].z), add_bf16x2(v.w, rx2[q].w));
+            *reinterpret_cast<uint4 *>(&Xi[buf][(xr + 8 * q) * W2XP + xc * 2]) = v;  // (dz rows are zero there: no mask needed)
+        }
+    };
+    // fragment addresses of this lane inside an image (bytes): pixel row 8 (l >> 5) + ((l & 15) >> 2), channel
+    // 16 ((l >> 4) & 1) + 4 (l & 3) of the 32-channel block; + 4 rows for the second half, + 16 rows for the second k step
+    const int frow = 8 * (lane >> 5) + ((lane & 15) >> 2), fcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const int zoff = frow * W2ZP + (wy * 64 + fcol) * 2, xoff = frow * W2XP + (wx * 128 + fcol) * 2;
+    auto frag = [&](const unsigned char *base) __attribute__((always_inline)) {
+        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)base);
+        return lo;
+    };
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[2], bf[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const unsigned char *b = &Zi[buf][zoff + ks * 16 * W2ZP + i * 64];
+                const v4s lo = frag(b), hi = frag(b + 4 * W2ZP);
+                af[i] = bf16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned char *b = &Xi[buf][xoff + ks * 16 * W2XP + j * 64];
+                const v4s lo = frag(b), hi = frag(b + 4 * W2XP);
+                bf[j] = bf16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    const int64_t steps = (pb - pa + W2P - 1) / W2P;
+    fetch(pa);
+    commit(0, pa);
+    if (steps > 1) fetch(pa + W2P);
+    __syncthreads();
+    // step s computes on image s & 1 while the registers (step s + 1) go to the other image and are refilled for s + 2
+    for (int64_t s = 0; s < steps; ++s) {
+        const int buf = (int)(s & 1);
+        if (s + 1 < steps) commit(buf ^ 1, pa + (s + 1) * W2P);
+        if (s + 2 < steps) fetch(pa + (s + 2) * W2P);
+        compute(buf);
+        __syncthreads();
+    }
+    // accumulator: column = lane & 31 -> k, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -> n; 32 lanes = 128 contiguous bytes
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = wx * 128 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wy * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                __hip_atomic_fetch_add(dW + (size_t)n * K + k, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    if (do_bias) {
+        if (tid < 128) bred[tid] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) atomicAdd(&bred[zc + q], bsum[q]);
+        __syncthreads();
+        if (tid < 128) __hip_atomic_fetch_add(db + n0 + tid, bred[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // backward of the output heads: channel-major cotangent G[C, P] and the saved pixel-major logits x[P, ld] ->
 // pixel-major bf16 dz[P, ld] (columns >= C zero).
 //   mode 0 (y = x / max(||x||, eps)):  dz = (g - y <y, g>) / max(||x||, eps)
@@ -683,6 +826,21 @@ extern "C" int gags_decoder_wgrad(int64_t n_pix, int n_out, int k_in, const void
     GAGS_CLEAR_ERR();
     if (n_pix < 0 || n_out <= 0 || k_in <= 0 || n_out % 16 != 0 || k_in % 16 != 0 || !dz || !a1 || !d_w) return GAGS_EINVAL;
     if (n_pix == 0) return GAGS_OK;
+    if (k_in == 256 && n_out % 128 == 0) {
+        // one workgroup per n tile and pixel chunk, two per CU: 512 chunks of whole 32-pixel steps
+        const int n_tiles = n_out / 128;
+        const int64_t chunk = ((n_pix + 511) / 512 + W2P - 1) / W2P * W2P;
+        const unsigned n_chunks = (unsigned)((n_pix + chunk - 1) / chunk);
+        const unsigned grid = n_tiles == 1 ? n_chunks : (n_chunks + 7) / 8 * 8 * n_tiles;
+        if (a2)
+            hipLaunchKernelGGL(wgrad256_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n_pix, n_out, (const unsigned short *)dz,
+                               (const unsigned short *)a1, (const unsigned short *)a2, d_w, d_b, chunk, n_tiles, n_chunks);
+        else
+            hipLaunchKernelGGL(wgrad256_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n_pix, n_out, (const unsigned short *)dz,
+                               (const unsigned short *)a1, (const unsigned short *)a2, d_w, d_b, chunk, n_tiles, n_chunks);
+        GAGS_CHECK_LAUNCH();
+        return GAGS_OK;
+    }
     hipLaunchKernelGGL(wgrad_bf16_kernel, dim3((unsigned)((n_pix + WCHUNK - 1) / WCHUNK), (unsigned)((n_out + 127) / 128),
                                                (unsigned)((k_in + 127) / 128)),
                        dim3(256), 0, (hipStream_t)stream, n_pix, n_out, k_in, (const unsigned short *)dz,

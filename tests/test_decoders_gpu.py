@@ -189,3 +189,23 @@ def test_head_kernels_against_torch(c, ld, mode):
     assert ((out.t().double() - ref).norm() / ref.norm()).item() <= 1e-6
     assert ((dz[:, :c].double() - xr.grad).norm() / xr.grad.norm()).item() <= 4e-3   # bf16 output
     assert torch.count_nonzero(dz[:, c:]).item() == 0
+
+
+@pytest.mark.parametrize("n,k,two", [(256, 256, False), (256, 256, True), (512, 256, False), (128, 256, True),
+                                     (256, 32, False), (64, 128, True), (32, 64, False)])
+def test_weight_gradient_kernels_against_torch(n, k, two):
+    """gags_decoder_wgrad alone: dW = dz^T (a1 + a2), db = sum_p dz in fp32 on the bf16 operands, on both kernels
+    behind the entry (the transposing-LDS-read one for 256 inputs, the general one), with a pixel count that is not a
+    multiple of anything (the last chunk is ragged) and with random, asymmetric operands."""
+    from gags_amd import decoders as D
+    p = 70000 + 77
+    g = torch.Generator(device="cuda").manual_seed(n + k)
+    dz = torch.randn(p, n, device="cuda", generator=g).to(torch.bfloat16)
+    a1 = torch.randn(p, k, device="cuda", generator=g).to(torch.bfloat16)
+    a2 = torch.randn(p, k, device="cuda", generator=g).to(torch.bfloat16) if two else None
+    dw, db = D._wgrad(p, dz, a1, a2, n, k)
+    a = a1.float() if a2 is None else (a1.float() + a2.float()).to(torch.bfloat16).float()  # the sum is rounded once
+    ref_w = dz.double().t() @ a.double()
+    ref_b = dz.double().sum(0)
+    assert ((dw.double() - ref_w).norm() / ref_w.norm()).item() <= 2e-6
+    assert ((db.double() - ref_b).norm() / ref_b.norm()).item() <= 2e-6
