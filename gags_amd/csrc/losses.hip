@@ -216,6 +216,14 @@ __global__ __launch_bounds__(256) void sam_feature_kernel(int c, int H, int W, i
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;  // MODE 2: |diff| sum in acc0; MODE 1 / 3: v_scale partials
 
     for (int cb = 0; cb < c; cb += CB) {
+        // this block's 16 values of the channel-major operand are requested FIRST, all at once, and arrive while the
+        // embedding rows are gathered (inside the loop below they would be waited for four at a time)
+        float pv[CB / 4];
+        if (MODE != 0) {
+#pragma unroll
+            for (int k = 0; k < CB / 4; ++k) pv[k] = pred[(size_t)min(cb + rb + 4 * k, c - 1) * HW + pBc];
+            __builtin_amdgcn_sched_barrier(0);  // keep the requests up here (the scheduler would sink them to their uses)
+        }
 #pragma unroll
         for (int l = 0; l < 3; ++l) {
             float f[16];
@@ -225,27 +233,27 @@ __global__ __launch_bounds__(256) void sam_feature_kernel(int c, int H, int W, i
             for (int j = 0; j < 16; ++j) F[l][pa][qa * 16 + j] = (c0 < c) ? f[j] : 0.f;
         }
         __syncthreads();
-#pragma unroll 4
+#pragma unroll
         for (int k = 0; k < CB / 4; ++k) {
             const int cl = rb + 4 * k, ch = cb + cl;
-            if (ch >= c) break;
+            const bool live = ch < c && inB;
             const float f0 = F[0][pb][cl], f1 = F[1][pb][cl], f2 = F[2][pb][cl];
-            const size_t o = (size_t)ch * HW + pBc;
+            const size_t o = (size_t)min(ch, c - 1) * HW + pBc;
             if (MODE == 0) {
                 // feature_map_s * scale_map[0] + feature_map_m * scale_map[1] + feature_map_l * scale_map[2]
-                if (inB) out0[o] = (f0 * sc[0] + f1 * sc[1]) + f2 * sc[2];
+                if (live) out0[o] = (f0 * sc[0] + f1 * sc[1]) + f2 * sc[2];
             } else if (MODE == 1) {
-                const float v = inB ? pred[o] : 0.f;
+                const float v = live ? pv[k] : 0.f;
                 acc0 = fmaf(v, f0, acc0); acc1 = fmaf(v, f1, acc1); acc2 = fmaf(v, f2, acc2);
             } else {
                 const float gt = (f0 * sc[0] + f1 * sc[1]) + f2 * sc[2];
-                const float diff = pred[o] * maskB - gt * maskB;
+                const float diff = ch < c ? pv[k] * maskB - gt * maskB : 0.f;
                 if (MODE == 2) {
                     acc0 += fabsf(diff);
                 } else {
                     const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
                     const float g = sgn * vB * maskB;  // d |pred*m - gt*m| / d pred, times v / c
-                    if (inB) out0[o] = g;
+                    if (live) out0[o] = g;
                     acc0 = fmaf(-g, f0, acc0); acc1 = fmaf(-g, f1, acc1); acc2 = fmaf(-g, f2, acc2);
                 }
             }
