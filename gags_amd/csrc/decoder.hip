@@ -599,6 +599,133 @@ __global__ __launch_bounds__(256, 2) void wgrad256_kernel(int64_t P, int N, cons
     }
 }
 
+// Weight gradient of the narrow layers (N = 32 NB outputs, K = 32 KB inputs, NB KB <= 8: the scale decoder and the
+// first layer of CNN_decoder): the whole N x K gradient fits one wave's accumulators, so every WAVE runs its own
+// pipeline over its own range of pixels -- 16 pixels per step, pixel-major rows into a wave-private LDS patch, fragments
+// through the transposing read -- with no workgroup barrier anywhere (LDS executes a wave's accesses in order); the
+// four waves of a workgroup are summed in LDS before the global atomics.
+template <int NB, int KB, bool TWO>
+__global__ __launch_bounds__(256) void wgrad_narrow_kernel(int64_t P, const unsigned short *__restrict__ dz,
+                                                           const unsigned short *__restrict__ a1,
+                                                           const unsigned short *__restrict__ a2, float *__restrict__ dW,
+                                                           float *__restrict__ db, int64_t chunk)
+{
+    constexpr int N = 32 * NB, K = 32 * KB;
+    constexpr int ZP = (N * 2 / 64 | 1) * 64, XP = (K * 2 / 64 | 1) * 64;  // row pitches: odd multiples of 64 B
+    constexpr int PATCH = 16 * (ZP + XP);
+    constexpr int RED = N * K * 4 + N * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(4 * PATCH > RED ? 4 * PATCH : RED)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned char *Zi = smem + wave * PATCH, *Xi = Zi + 16 * ZP;
+    const int64_t pa = ((int64_t)blockIdx.x * 4 + wave) * chunk, pb = min(pa + chunk, P);
+    f32x16 acc[NB][KB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < KB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // 16-byte pieces lane + 64 q of the 16 x (N / 8) resp. 16 x (K / 8) pieces of a step
+    constexpr int ZQ = N / 32, XQ = K / 32, ZR = N / 8, XR = K / 8;
+    uint4 rz[ZQ], rx[XQ], rx2[TWO ? XQ : 1];
+    auto fetch = [&](int64_t p0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < ZQ; ++q) {
+            const int pc = lane + 64 * q;
+            rz[q] = *reinterpret_cast<const uint4 *>(dz + min(p0 + pc / ZR, P - 1) * N + (pc % ZR) * 8);
+        }
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int pc = lane + 64 * q;
+            const int64_t o = min(p0 + pc / XR, P - 1) * K + (pc % XR) * 8;
+            rx[q] = *reinterpret_cast<const uint4 *>(a1 + o);
+            if constexpr (TWO) rx2[q] = *reinterpret_cast<const uint4 *>(a2 + o);
+        }
+    };
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // channels (lane % ZR) * 8 .. + 7 (the same for every q)
+    const bool do_bias = db != nullptr;
+    auto commit = [&](int64_t p0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < ZQ; ++q) {
+            const int pc = lane + 64 * q;
+            const unsigned keep = p0 + pc / ZR < pb ? 0xffffffffu : 0u;  // rows beyond the range contribute zero
+            const uint4 v = make_uint4(rz[q].x & keep, rz[q].y & keep, rz[q].z & keep, rz[q].w & keep);
+            *reinterpret_cast<uint4 *>(Zi + (pc / ZR) * ZP + (pc % ZR) * 16) = v;
+            if (do_bias) {
+                bsum[0] += bf_lo(v.x); bsum[1] += bf_hi(v.x); bsum[2] += bf_lo(v.y); bsum[3] += bf_hi(v.y);
+                bsum[4] += bf_lo(v.z); bsum[5] += bf_hi(v.z); bsum[6] += bf_lo(v.w); bsum[7] += bf_hi(v.w);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int pc = lane + 64 * q;
+            uint4 v = rx[q];
+            if constexpr (TWO)
+                v = make_uint4(add_bf16x2(v.x, rx2[q].x), add_bf16x2(v.y, rx2[q].y), add_bf16x2(v.z, rx2[q].z), add_bf16x2(v.w, rx2[q].w));
+            *reinterpret_cast<uint4 *>(Xi + (pc / XR) * XP + (pc % XR) * 16) = v;
+        }
+    };
+    const int frow = 8 * (lane >> 5) + ((lane & 15) >> 2), fcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    if (pa < pb) {
+        fetch(pa);
+        for (int64_t p0 = pa; p0 < pb; p0 += 16) {
+            commit(p0);
+            if (p0 + 16 < pb) fetch(p0 + 16);
+            bf16x8 af[NB], bf[KB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const unsigned char *b = Zi + frow * ZP + (i * 32 + fcol) * 2;
+                const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)b), hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(b + 4 * ZP));
+                af[i] = bf16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            }
+#pragma unroll
+            for (int j = 0; j < KB; ++j) {
+                const unsigned char *b = Xi + frow * XP + (j * 32 + fcol) * 2;
+                const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)b), hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(b + 4 * XP));
+                bf[j] = bf16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int j = 0; j < KB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // sum the four waves in LDS (the patches are done with), then one global atomic per element and workgroup
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(smem), *bred = red + N * K;
+    for (int e = tid; e < N * K + N; e += 256) red[e] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < KB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                atomicAdd(&red[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * K + j * 32 + (lane & 31)], acc[i][j][r]);
+    if (do_bias) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) atomicAdd(&bred[(lane % ZR) * 8 + q], bsum[q]);
+    }
+    __syncthreads();
+    for (int e = tid; e < N * K; e += 256) __hip_atomic_fetch_add(dW + e, red[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (do_bias)
+        for (int e = tid; e < N; e += 256) __hip_atomic_fetch_add(db + e, bred[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int NB, int KB>
+void launch_wgrad_narrow(int64_t n_pix, const void *dz, const void *a1, const void *a2, float *d_w, float *d_b, hipStream_t stream)
+{
+    const int64_t waves = 4 * 768;  // three workgroups per CU
+    const int64_t chunk = ((n_pix + waves - 1) / waves + 15) / 16 * 16;
+    const unsigned grid = (unsigned)((n_pix + 4 * chunk - 1) / (4 * chunk));
+    if (a2)
+        hipLaunchKernelGGL((wgrad_narrow_kernel<NB, KB, true>), dim3(grid), dim3(256), 0, stream, n_pix, (const unsigned short *)dz,
+                           (const unsigned short *)a1, (const unsigned short *)a2, d_w, d_b, chunk);
+    else
+        hipLaunchKernelGGL((wgrad_narrow_kernel<NB, KB, false>), dim3(grid), dim3(256), 0, stream, n_pix, (const unsigned short *)dz,
+                           (const unsigned short *)a1, (const unsigned short *)a2, d_w, d_b, chunk);
+}
+
 // backward of the output heads: channel-major cotangent G[C, P] and the saved pixel-major logits x[P, ld] ->
 // pixel-major bf16 dz[P, ld] (columns >= C zero).
 //   mode 0 (y = x / max(||x||, eps)):  dz = (g - y <y, g>) / max(||x||, eps)
@@ -826,6 +953,21 @@ extern "C" int gags_decoder_wgrad(int64_t n_pix, int n_out, int k_in, const void
     GAGS_CLEAR_ERR();
     if (n_pix < 0 || n_out <= 0 || k_in <= 0 || n_out % 16 != 0 || k_in % 16 != 0 || !dz || !a1 || !d_w) return GAGS_EINVAL;
     if (n_pix == 0) return GAGS_OK;
+    {
+        // narrow layers: the whole gradient in one wave's accumulators
+        const int nb = n_out / 32, kb = k_in / 32;
+        bool done = true;
+        if (n_out % 32 || k_in % 32) done = false;
+#define GAGS_NARROW(NB_, KB_) else if (nb == NB_ && kb == KB_) launch_wgrad_narrow<NB_, KB_>(n_pix, dz, a1, a2, d_w, d_b, (hipStream_t)stream);
+        GAGS_NARROW(1, 1) GAGS_NARROW(2, 1) GAGS_NARROW(1, 2) GAGS_NARROW(2, 2) GAGS_NARROW(4, 1) GAGS_NARROW(1, 4)
+        GAGS_NARROW(4, 2) GAGS_NARROW(2, 4) GAGS_NARROW(8, 1) GAGS_NARROW(1, 8)
+#undef GAGS_NARROW
+        else done = false;
+        if (done) {
+            GAGS_CHECK_LAUNCH();
+            return GAGS_OK;
+        }
+    }
     if (k_in == 256 && n_out % 128 == 0) {
         // one workgroup per n tile and pixel chunk, two per CU: 512 chunks of whole 32-pixel steps
         const int n_tiles = n_out / 128;

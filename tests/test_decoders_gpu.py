@@ -192,7 +192,8 @@ def test_head_kernels_against_torch(c, ld, mode):
 
 
 @pytest.mark.parametrize("n,k,two", [(256, 256, False), (256, 256, True), (512, 256, False), (128, 256, True),
-                                     (256, 32, False), (64, 128, True), (32, 64, False)])
+                                     (256, 32, False), (64, 128, True), (32, 64, False), (128, 64, False), (64, 32, True),
+                                     (32, 32, False), (48, 32, False), (512, 64, False)])
 def test_weight_gradient_kernels_against_torch(n, k, two):
     """gags_decoder_wgrad alone: dW = dz^T (a1 + a2), db = sum_p dz in fp32 on the bf16 operands, on both kernels
     behind the entry (the transposing-LDS-read one for 256 inputs, the general one), with a pixel count that is not a
