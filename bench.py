@@ -72,6 +72,8 @@ def parse():
                     help="by-view step: bucketed reduce-scatter + all-gather (default) or plain all-reduce")
     ap.add_argument("--no-overlap", action="store_true",
                     help="by-view step: exchange the whole gradient after the backward instead of range by range during it")
+    ap.add_argument("--rows", default="union", choices=["union", "all"],
+                    help="by-view step: exchange only the rows of Gaussians that blended in some rank's view (exact; default) or all N rows")
     ap.add_argument("--wire", default="fp32", choices=["fp32", "bf16"],
                     help="by-view step: dtype of the gradient on the wire (bf16: opt-in, ~1e-2 relative error, halves the bytes)")
     ap.add_argument("--raster-flags", type=int, default=0,
@@ -237,7 +239,7 @@ def main():
 
         exchange = mode == "view" and world > 1 and not args.no_allreduce
         overlap = exchange and not args.no_overlap
-        red = OverlappedGradReducer(mode=grad_reduce, wire=args.wire) if overlap else None
+        red = OverlappedGradReducer(mode=grad_reduce, wire=args.wire, rows=args.rows) if overlap else None
 
         def step_():
             pc_._semantic_feature.grad = None
@@ -428,7 +430,9 @@ def main():
                        "parallel_probe_ms_per_step": probe,
                        "grad_exchange": (None if world == 1 or mode != "view" else
                                          {"overlapped_with_backward": not args.no_overlap, "wire": args.wire,
-                                          "collective": args.grad_reduce, "exposed_ms_last_step": exposed_ms})},
+                                          "collective": args.grad_reduce, "exposed_ms_last_step": exposed_ms,
+                                          "rows": args.rows if not args.no_overlap else "all",
+                                          "rows_exchanged_last_step": (exposed[-1].rows_exchanged if exposed else None)})},
             "roofline": roof,
             "kernels": kernels,
             "stages_ms": {k: round(v[0], 4) for k, v in sorted(stages.items())},

@@ -36,6 +36,7 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
                                   const float *wt, const int32_t *gid_s, const int32_t *trow_s, void *scratch,
                                   int64_t scratch_bytes, float *v_colors, int stage, int ch_begin, int ch_count,
                                   hipStream_t st);
+int gags_blended_mask_launch(int n_isects, const int32_t *hit, const int32_t *flatten_ids, unsigned char *mask, hipStream_t st);
 int gags_bwd_slot_rows_launch(int width, int height, int n_isects, const int32_t *offsets, const int32_t *blk_rows,
                               const int32_t *sidx_s, const int32_t *trow, int32_t *trow_s, hipStream_t st);
 int gags_raster_bwd_atomic_launch(int d, int width, int height, const void *packed, const int32_t *offsets,
@@ -193,6 +194,21 @@ extern "C" int gags_bwd_rowmap(int64_t n_isects, int width, int height, const in
     GAGS_CHECK_LAUNCH();
     return gags_bwd_slot_rows_launch(width, height, (int)n_isects, isect_offsets, blk_rows,
                                      (const int32_t *)(fs + L.sidx), trow, rowmap + rowmap_slot_off(n_isects), st);
+}
+
+extern "C" int gags_blended_mask(int64_t n_isects, int width, int height, int n, const int32_t *flatten_ids,
+                                 const void *fwd_scratch, int64_t fwd_scratch_bytes, unsigned char *mask, void *stream)
+{
+    if (n_isects < 0 || n_isects >= (1ll << 27) || width <= 0 || height <= 0 || n < 0) return GAGS_EINVAL;
+    if (n == 0) return GAGS_OK;
+    if (!mask) return GAGS_EINVAL;
+    if (hipMemsetAsync(mask, 0, (size_t)n, (hipStream_t)stream) != hipSuccess) return GAGS_ELAUNCH;
+    if (n_isects == 0) return GAGS_OK;
+    if (!flatten_ids || !fwd_scratch) return GAGS_EINVAL;
+    const FwdScratch L = fwd_layout(n_isects, width, height);
+    if (fwd_scratch_bytes < L.total) return GAGS_ESCRATCH;
+    return gags_blended_mask_launch((int)n_isects, (const int32_t *)((const char *)fwd_scratch + L.hit), flatten_ids, mask,
+                                    (hipStream_t)stream);
 }
 
 extern "C" int gags_raster_bwd_colors_staged_range(int d, int n, int width, int height, const int32_t *isect_offsets,

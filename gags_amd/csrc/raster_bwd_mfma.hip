@@ -626,6 +626,23 @@ int64_t gags_bwd_staged_scratch_bytes_impl(int64_t rows, int n_gauss, int d)
     return staged_layout(rows > 0 ? rows : 1, n_gauss, d).total;
 }
 
+// mask[g] = 1 for every Gaussian that blended into at least one pixel of the view (the rows of the feature gradient
+// that can be non-zero): hit flag of the forward per sorted intersection -> its Gaussian.  Benign race (all write 1).
+__global__ __launch_bounds__(256) void blended_mask_kernel(int n_isects, const int32_t *__restrict__ hit,
+                                                           const int32_t *__restrict__ flatten_ids, unsigned char *__restrict__ mask)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_isects && hit[i]) mask[flatten_ids[i]] = 1;
+}
+
+int gags_blended_mask_launch(int n_isects, const int32_t *hit, const int32_t *flatten_ids, unsigned char *mask, hipStream_t st)
+{
+    GAGS_CLEAR_ERR();
+    hipLaunchKernelGGL(blended_mask_kernel, dim3((n_isects + 255) / 256), dim3(256), 0, st, n_isects, hit, flatten_ids, mask);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
 int gags_bwd_slot_rows_launch(int width, int height, int n_isects, const int32_t *offsets, const int32_t *blk_rows,
                               const int32_t *sidx_s, const int32_t *trow, int32_t *trow_s, hipStream_t st)
 {

@@ -32,6 +32,10 @@ TILE = 16
 # of the next.  The alias shares storage with the tensor handed to autograd.
 GRAD_RANGE_HOOK = None
 GRAD_RANGE_CHANNELS = 128
+# When set together with GRAD_RANGE_HOOK, the backward first calls GRAD_ROWS_HOOK(mask uint8 [N]): mask[g] = 1 for every
+# Gaussian that blended into a pixel of this view, i.e. the only rows of the gradient that can be non-zero (SURVEY 8e:
+# "gradients are sparse in rows"); the exchange then moves the union of these rows over the ranks instead of all N.
+GRAD_ROWS_HOOK = None
 MAX_ISECTS = 1 << 27  # limit of the C ABI (int32 slot indices: 4 slots per intersection)
 SCRATCH_CHECK_BYTES = 8 << 30  # above this the split forward first checks that its scratch fits in free memory
 
@@ -254,7 +258,7 @@ class _Rasterize(torch.autograd.Function):
             v_bg = ((1.0 - alphas)[..., None] * v_out).sum(dim=(0, 1))
         if not need_geom and blk_rows is not None:
             v_colors = _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height,
-                                        32 if (flags & _lib.GAGS_BWD_F16SPLIT) else 0)
+                                        32 if (flags & _lib.GAGS_BWD_F16SPLIT) else 0, flatten_ids)
             if ctx.half:
                 v_colors = v_colors.half()  # autograd wants the table's dtype; an fp32 master sits behind a .half() cast
             return None, None, v_colors, None, v_bg, None, None, None, None, None, None
@@ -277,12 +281,18 @@ class _Rasterize(torch.autograd.Function):
         return v_m2d, v_con, v_colors, v_opac, v_bg, None, None, None, None, None, None
 
 
-def _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height, xflag=0):
+def _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height, xflag=0,
+                     flatten_ids=None):
     """Colours-only backward without atomics: hit flags of the forward -> prefix sum (one row per (tile, Gaussian)
     pair that blended anything) -> one 4-byte readback (total rows) -> merged partial rows -> sort by Gaussian ->
     segmented sum."""
     dev = v_out.device
     st = _stream()
+    if GRAD_ROWS_HOOK is not None and GRAD_RANGE_HOOK is not None and flatten_ids is not None:
+        mask = torch.empty(n, dtype=torch.uint8, device=dev)
+        check(lib.gags_blended_mask(n_isects, width, height, n, ptr(flatten_ids), ptr(fwd_scratch), fwd_scratch.numel(),
+                                    ptr(mask), st), "gags_blended_mask")
+        GRAD_ROWS_HOOK(mask)  # before the readback below: the ranks agree on the union while the backward starts
     ne = lib.gags_bwd_rowmap_elems(n_isects, width, height)
     trow = torch.empty(ne, dtype=torch.int32, device=dev)
     total = torch.empty(1, dtype=torch.int32, device=dev)

@@ -167,6 +167,11 @@ int64_t gags_bwd_rowmap_scratch_bytes(int64_t n_isects);
 int gags_bwd_rowmap(int64_t n_isects, int width, int height, const int32_t *isect_offsets, const int32_t *blk_rows,
                     const void *fwd_scratch, int64_t fwd_scratch_bytes, int32_t *rowmap, int64_t rowmap_elems,
                     int32_t *total, void *scratch, int64_t scratch_bytes, void *stream);
+/* mask[g] (n bytes, written in full) = 1 for every Gaussian that blended into at least one pixel of the view of a
+ * split gags_raster_fwd (its scratch): exactly the rows of v_colors that can be non-zero.  A by-view multi-GPU step
+ * exchanges only the union of these rows over the ranks (gags_amd/dist.py; SURVEY 8e "gradients are sparse in rows"). */
+int gags_blended_mask(int64_t n_isects, int width, int height, int n, const int32_t *flatten_ids,
+                      const void *fwd_scratch, int64_t fwd_scratch_bytes, unsigned char *mask, void *stream);
 int64_t gags_bwd_staged_scratch_bytes(int64_t rows, int n, int d);
 int gags_raster_bwd_colors_staged(int d, int n, int width, int height, const int32_t *isect_offsets,
                                   int64_t n_isects, const float *v_render_colors,

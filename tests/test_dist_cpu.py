@@ -163,3 +163,46 @@ def test_overlapped_reducer_two_ranks(wire, tol):
     for _, used, err, used2, err2 in res:
         assert used and err <= tol
         assert not used2 and err2 <= 1e-6  # the fallback is always the exact fp32 reduction
+
+
+def _union_worker(rank, world, port, q):
+    """rows="union": every rank's gradient is non-zero in its own subset of rows; the reducer is handed the row mask
+    first (GRAD_ROWS_HOOK), exchanges only the union's rows and must reproduce the plain sum exactly."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gags_amd import rasterization
+    from gags_amd.dist import OverlappedGradReducer
+    n, d = 1001, 256
+    masks = [torch.rand(n, generator=torch.Generator().manual_seed(40 + r)) < 0.2 for r in range(world)]
+    grads = [torch.randn(n, d, generator=torch.Generator().manual_seed(7 + r)) * masks[r][:, None] for r in range(world)]
+    expect = sum(grads)
+    union = int(torch.stack(masks).any(0).sum())
+    grad = grads[rank].clone()
+    red = OverlappedGradReducer(mode="rs_ag", bucket_bytes=8192)
+    with red:
+        assert rasterization.GRAD_ROWS_HOOK is not None
+        rasterization.GRAD_ROWS_HOOK(masks[rank].to(torch.uint8))
+        for c0 in range(0, d, 128):
+            rasterization.GRAD_RANGE_HOOK(grad.detach(), c0, c0 + 128)
+    assert rasterization.GRAD_ROWS_HOOK is None
+    used = red.finish(grad)
+    q.put((rank, used, bool(torch.equal(grad, expect)), red.rows_exchanged, union))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_reducer_exchanges_only_the_union_of_nonzero_rows():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_union_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, used, exact, rows, union in res:
+        assert used and exact           # two addends per element: the sum is exact whatever the order
+        assert rows == union and union < 1001

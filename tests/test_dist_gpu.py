@@ -91,6 +91,67 @@ def test_channel_sharded_step_is_bit_identical_and_exchange_free(tmp_path):
     np.testing.assert_array_equal(np.concatenate([g0, g1], axis=1), ref)
 
 
+def _overlap_step_worker(rank, world, port, out_dir):
+    """By-view step with the REAL kernels and the overlapped, row-compacted exchange: each rank renders its view at
+    D = 256 (two 128-channel ranges), the backward hands the reducer the mask of blended Gaussians and then the
+    ranges; gloo moves the bytes (all-reduce: it has no reduce-scatter for device tensors)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gags_amd import synthetic as syn
+    from gags_amd.dist import OverlappedGradReducer
+    from gags_amd.gaussian_renderer import render
+    dev = torch.device("cuda", 0)
+    d = 256
+    pc = syn.make_model(N, d, W, H, seed=3, device=dev, gen_device=dev, scale0=syn.SCALE0 * 6.0)
+    pc.training_setup()
+    cam = syn.make_camera(W, H, view=rank + 2, device=dev)
+    G = syn.make_cotangent(d, H, W, seed=10 + rank, device=dev)
+    bg = torch.zeros(3, device=dev)
+    red = OverlappedGradReducer(mode="allreduce", rows="union")
+    loss = (render(cam, pc, None, bg, feature_mode=True)["render"] * G).sum()
+    with red:
+        loss.backward()
+    used = red.finish(pc._semantic_feature.grad)
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, f"ogr_{rank}.npy"), pc._semantic_feature.grad.detach().cpu().numpy())
+    np.save(os.path.join(out_dir, f"ogr_meta_{rank}.npy"), np.array([int(used), red.rows_exchanged or -1]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_union_row_exchange_with_the_real_backward(tmp_path):
+    from gags_amd import synthetic as syn
+    from gags_amd.gaussian_renderer import render
+    dev = torch.device("cuda", 0)
+    d = 256
+    pc = syn.make_model(N, d, W, H, seed=3, device=dev, gen_device=dev, scale0=syn.SCALE0 * 6.0)
+    pc.training_setup()
+    bg = torch.zeros(3, device=dev)
+    per_view = []
+    for v in range(2):
+        pc._semantic_feature.grad = None
+        cam = syn.make_camera(W, H, view=v + 2, device=dev)
+        G = syn.make_cotangent(d, H, W, seed=10 + v, device=dev)
+        (render(cam, pc, None, bg, feature_mode=True)["render"] * G).sum().backward()
+        per_view.append(pc._semantic_feature.grad.detach().clone())
+    ref = (per_view[0] + per_view[1]).cpu().numpy()
+    union = int(((per_view[0] != 0).any(1) | (per_view[1] != 0).any(1)).sum())
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_overlap_step_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    for r in range(world):
+        g = np.load(tmp_path / f"ogr_{r}.npy")
+        used, rows = np.load(tmp_path / f"ogr_meta_{r}.npy")
+        np.testing.assert_array_equal(g, ref)   # two addends per element: exact
+        assert used == 1 and rows == union and 0 < union < N
+
+
 def _nccl_worker(rank, world, port, q):
     """The default exchange of the by-view step on DEVICE tensors over RCCL: bucketed reduce-scatter + in-place
     all-gather (gags_amd/dist.py:reduce_feature_grad, mode rs_ag), one GPU per rank."""
