@@ -13,6 +13,11 @@ from helpers import rel_l2, scene_arrays, to_dev
 pytestmark = pytest.mark.gpu
 
 GRAD_TOL = 2e-5
+# vs the gsplat-order oracle (T rebuilt back to front from 1 - alpha): measured <= 5e-7 on unsaturated scenes and
+# 1.4e-4 on the large-splat scene, whose saturated pixels lose digits in 1 - alpha (an error of THAT order of summation,
+# float64 check in tests/test_fullsize_gpu.py); bounds = measured x ~3
+GSPLAT_ORDER_TOL = 2e-6
+GSPLAT_ORDER_TOL_SATURATED = 4e-4
 
 
 def _run_gpu(s, width, height, colors, bg, render_mode="RGB", sh_degree=None, need_geom=False, flags=0,
@@ -97,7 +102,8 @@ def test_forward_and_colour_grad(oracle, n, w, h, d, seed, view, mult, bgv):
     o_vf = oracle.raster_bwd_colors_fwdorder(oinfo["means2d"], oinfo["conics"], s["opacities"], d, w, h,
                                              oinfo["isect_offsets"], oinfo["flatten_ids"], v_out, n)
     assert min(rel_l2(grads["colors"], o_vc), rel_l2(grads["colors"], o_vf)) <= GRAD_TOL
-    assert rel_l2(grads["colors"], o_vc) <= 1e-3
+    e_gsplat = rel_l2(grads["colors"], o_vc)
+    assert e_gsplat <= (GSPLAT_ORDER_TOL_SATURATED if mult >= 16.0 else GSPLAT_ORDER_TOL), e_gsplat
 
 
 def test_mfma_and_valu_paths_agree_bitwise(oracle):
