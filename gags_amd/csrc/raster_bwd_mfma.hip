@@ -716,6 +716,327 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
     return GAGS_OK;
 }
 
+// =========================================================================================================================
+// Geometry gradients at wide D.  The only D-proportional term of d loss / d alpha,
+//     v_alpha(g, px) = T_g <c_g, v_px>  -  ra_g SUM_{g' behind g} f_g' <c_g', v_px>  +  T_f ra_g (v_a - <bg, v_px>),
+// needs the dot products S[g, px] = <c_g, v_px> and nothing else: the "buffer" term is a running sum of f S over the
+// Gaussians behind (linearity).  So:
+//   1. raster_bwd_sdot: S[slot][64 px] for every slot of every 8x8 block on the fp32 matrix cores -- the contraction runs
+//      over the CHANNELS, 256 per pass (wider tables: accumulating passes); the block's cotangent slab [64 px][256 ch]
+//      sits in LDS (66 KB: two workgroups per CU, one loads its slab while the other multiplies), the four waves take
+//      the block's 32-slot tiles in turn, the slots' feature rows are streamed from L2 / HBM eight float4 ahead;
+//   2. raster_bwd_geom: one wave per block walks its slots back to front, one pixel per lane: alpha again from the packed
+//      record, T = f / alpha from the forward's weight, v_alpha from S, the six geometry partials summed over the wave
+//      and stored as ONE 32-byte row per slot (no atomics);
+//   3. the rows are sorted by Gaussian and summed with the kernels of the colours backward (d = 8).
+constexpr int SD_PAD = 4;        // floats of padding per slab row: b128 reads of 32 rows then cover all 64 banks
+constexpr int SD_MAXCH = 256;    // channels per pass (LDS); wider tables take several accumulating passes
+
+template <int DCH>  // channels of this pass, compile-time for the full 256 (everything unrolled), 0 = use `dch`
+__global__ __launch_bounds__(256, 2) void raster_bwd_sdot(int d, int ch0, int dch_rt, int width, int height, int tile_w, int n_tiles,
+                                                       int n_gauss, const float *__restrict__ v_out,
+                                                       const float *__restrict__ colors, const float *__restrict__ backgrounds,
+                                                       const int32_t *__restrict__ offsets, int n_isects,
+                                                       const int32_t *__restrict__ blk_rows, const int32_t *__restrict__ gid_s,
+                                                       float *__restrict__ S, float *__restrict__ bgdot, int accumulate)
+{
+    extern __shared__ __attribute__((aligned(16))) float slab[];  // [64 pixels in wt order e = 2 p + h][dch + SD_PAD]
+    __shared__ float bred[4][64];
+    const int dch = DCH ? DCH : dch_rt;
+    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * GAGS_BLOCKS_PER_TILE);
+    const int blk = logical & 3;
+    const int tile = gags_tile_of_order(logical >> 2, tile_w, n_tiles / tile_w);
+    const int cnt = blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk];
+    if (cnt == 0) return;
+    const int start = offsets[tile];
+    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+    const int sb = gags_slot_base(start, end, tile, blk);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pitch = dch + SD_PAD;
+    const int ty = tile / tile_w, tx = tile - ty * tile_w;
+    const int bx0 = tx * GAGS_TILE + (blk & 1) * 8, by0 = ty * GAGS_TILE + (blk >> 1) * 8;
+    {
+        // slab load, eight float4 per thread in flight (a load-then-store loop would wait for every single one)
+        const int q4 = dch >> 2;  // float4 per pixel row
+        const int total = 64 * q4;
+        for (int i0 = tid; i0 < total; i0 += 8 * 256) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(i0 + u * 256, total - 1);
+                const int e = i / q4, c4 = i - e * q4;
+                const int pp = e >> 1, h = e & 1;
+                const int pj = bx0 + (pp & 7), pi = by0 + (pp >> 3) + 4 * h;
+                const bool in = pi < height && pj < width;
+                v[u] = *reinterpret_cast<const float4 *>(v_out + ((size_t)min(pi, height - 1) * width + min(pj, width - 1)) * d + ch0 + 4 * c4);
+                if (!in) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 256;
+                if (i < total) {
+                    const int e = i / q4, c4 = i - e * q4;
+                    *reinterpret_cast<float4 *>(slab + e * pitch + 4 * c4) = v[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (backgrounds) {  // <bg, v_px> per pixel of the block, for the background term of v_alpha
+        const int e = tid & 63, part = tid >> 6, per = dch >> 2;
+        float acc = 0.f;
+        for (int c = part * per; c < (part + 1) * per; ++c) acc = fmaf(backgrounds[ch0 + c], slab[e * pitch + c], acc);
+        bred[part][e] = acc;
+        __syncthreads();
+        if (tid < 64) {
+            const int pp = tid >> 1, h = tid & 1;
+            const int pj = bx0 + (pp & 7), pi = by0 + (pp >> 3) + 4 * h;
+            if (pi < height && pj < width) {
+                const float t = (bred[0][tid] + bred[1][tid]) + (bred[2][tid] + bred[3][tid]);
+                float *dst = bgdot + (size_t)pi * width + pj;
+                *dst = accumulate ? *dst + t : t;
+            }
+        }
+    }
+    const int m = lane & 31, kh = lane >> 5;
+    const int nj = dch >> 3;  // steps of 8 channels: lane (m, kh) takes channels 8 j + 4 kh .. + 3 of slot m's row
+    for (int t0 = wave * 32; t0 < cnt; t0 += 128) {
+        const int slot = sb + min(t0 + m, cnt - 1);
+        const int gid = min(gid_s[slot], n_gauss - 1);  // the pad slot's row is computed and never used (its weights are 0)
+        const float *crow = colors + (size_t)gid * d + ch0 + 4 * kh;
+        const float *b0 = slab + m * pitch + 4 * kh, *b1 = slab + (32 + m) * pitch + 4 * kh;
+        f32x16 acc0, acc1;
+        if (accumulate) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = min(t0 + (r & 3) + 8 * (r >> 2) + 4 * kh, cnt - 1);
+                acc0[r] = S[(size_t)(sb + row) * 64 + m];
+                acc1[r] = S[(size_t)(sb + row) * 64 + 32 + m];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        }
+        float4 a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = *reinterpret_cast<const float4 *>(crow + 8 * min(u, nj - 1));
+        auto step = [&](int j, int u) __attribute__((always_inline)) {
+            const float4 av = a[u];
+            a[u] = *reinterpret_cast<const float4 *>(crow + 8 * min(j + 8, nj - 1));
+            const float4 x0 = *reinterpret_cast<const float4 *>(b0 + 8 * j), x1 = *reinterpret_cast<const float4 *>(b1 + 8 * j);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, x0.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, x1.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, x0.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, x1.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, x0.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, x1.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, x0.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, x1.w, acc1, 0, 0, 0);
+        };
+        if constexpr (DCH != 0) {  // one basic block: no loop back-edge for the compiler to drain the prefetches at
+#pragma unroll
+            for (int j = 0; j < DCH / 8; ++j) {
+                step(j, j & 7);
+                __builtin_amdgcn_sched_barrier(0);  // (or every LDS read of the tile is hoisted to the top: 256 VGPRs + spills)
+            }
+        } else {
+            for (int jb = 0; jb < nj; jb += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (jb + u < nj) step(jb + u, u);
+            }
+        }
+        // accumulator: column = pixel element m (of half 0 / 1), rows = slots (r & 3) + 8 (r >> 2) + 4 kh
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = t0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (row < cnt) {
+                S[(size_t)(sb + row) * 64 + m] = acc0[r];
+                S[(size_t)(sb + row) * 64 + 32 + m] = acc1[r];
+            }
+        }
+    }
+}
+
+// wave64 sum on the VALU (DPP: quad swaps, row mirrors, row broadcasts; the total lands in lane 63), returned
+// wave-uniform -- __shfl_xor goes through the LDS crossbar, and six sums per slot made that the kernel's bound
+__device__ __forceinline__ float geom_wave_sum(float v)
+{
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+__global__ __launch_bounds__(64) void raster_bwd_geom(int width, int height, int tile_w, int n_tiles, int n_gauss,
+                                                      const GRec *__restrict__ packed, const int32_t *__restrict__ offsets,
+                                                      int n_isects, const int32_t *__restrict__ blk_rows,
+                                                      const float *__restrict__ wt, const int32_t *__restrict__ gid_s,
+                                                      const int32_t *__restrict__ sidx_s, const float *__restrict__ S,
+                                                      const float *__restrict__ Tbuf, const float *__restrict__ v_alphas,
+                                                      const float *__restrict__ bgdot, float *__restrict__ grow,
+                                                      uint32_t *__restrict__ key, int32_t *__restrict__ idx)
+{
+    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * GAGS_BLOCKS_PER_TILE);
+    const int blk = logical & 3;
+    const int tile = gags_tile_of_order(logical >> 2, tile_w, n_tiles / tile_w);
+    const int cnt = blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk];
+    if (cnt == 0) return;
+    const int start = offsets[tile];
+    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+    const int sb = gags_slot_base(start, end, tile, blk);
+    const int lane = threadIdx.x;  // = element e of the weight rows: pixel p = e >> 1 of the 8x4 half h = e & 1
+    const int ty = tile / tile_w, tx = tile - ty * tile_w;
+    const int pj = tx * GAGS_TILE + (blk & 1) * 8 + ((lane >> 1) & 7);
+    const int pi = ty * GAGS_TILE + (blk >> 1) * 8 + (lane >> 4) + 4 * (lane & 1);
+    const bool inside = pi < height && pj < width;
+    const size_t pix = inside ? (size_t)pi * width + pj : 0;
+    const float px = (float)pj + 0.5f, py = (float)pi + 0.5f;
+    const float T_final = inside ? Tbuf[pix] : 1.f;
+    // T_f ra (v_a - <bg, v>): everything but ra is per pixel
+    const float k0 = inside ? T_final * ((v_alphas ? v_alphas[pix] : 0.f) - (bgdot ? bgdot[pix] : 0.f)) : 0.f;
+    float behind = 0.f;  // SUM f S over the slots behind the current one
+    // two-deep software pipeline over the slots (back to front): the slot's ids and rows are requested two slots ahead,
+    // its packed record (addressed by the id) one slot ahead
+    struct Ids { int sx, g; float f, sd; };
+    auto fetch_ids = [&](int j) __attribute__((always_inline)) {
+        Ids q;
+        const int slot = sb + max(j, 0);
+        q.sx = sidx_s[slot]; q.g = gid_s[slot];
+        q.f = wt[(size_t)slot * 64 + lane];
+        q.sd = S[(size_t)slot * 64 + lane];
+        return q;
+    };
+    auto fetch_rec = [&](const Ids &q) __attribute__((always_inline)) {
+        return packed[max(__builtin_amdgcn_readfirstlane(q.sx), 0)];
+    };
+    Ids i1 = fetch_ids(cnt - 1), i2 = fetch_ids(cnt - 2);
+    GRec r1 = fetch_rec(i1);
+    for (int j = cnt - 1; j >= 0; --j) {
+        const Ids cur = i1;
+        const GRec r = r1;
+        i1 = i2;
+        r1 = fetch_rec(i1);
+        i2 = fetch_ids(j - 2);
+        __builtin_amdgcn_sched_barrier(0);  // keep the requests above the arithmetic of the current slot
+        const int slot = sb + j;
+        const int sx = __builtin_amdgcn_readfirstlane(cur.sx);
+        if (sx < 0) continue;  // pad slot
+        const int g = __builtin_amdgcn_readfirstlane(cur.g);
+        const float f = cur.f, sdot = cur.sd;
+        const float dx = r.x - px, dy = r.y - py;
+        const float sigma = 0.5f * (r.a * dx * dx + r.c * dy * dy) + r.b * dx * dy;
+        const float vis = gags_exp_neg(sigma);
+        const float alpha = fminf(GAGS_ALPHA_MAX, r.o * vis);
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, g4 = 0.f, g5 = 0.f;
+        if (f != 0.f) {  // blended (f = alpha T with alpha >= 1/255 and T > 1e-4)
+            const float ra = 1.0f / (1.0f - alpha);
+            const float T = f / alpha;
+            const float v_alpha = T * sdot - ra * behind + k0 * ra;
+            behind = fmaf(f, sdot, behind);
+            if (r.o * vis <= GAGS_ALPHA_MAX) {
+                const float v_sigma = -r.o * vis * v_alpha;
+                g0 = 0.5f * v_sigma * dx * dx;
+                g1 = v_sigma * dx * dy;
+                g2 = 0.5f * v_sigma * dy * dy;
+                g3 = v_sigma * (r.a * dx + r.b * dy);
+                g4 = v_sigma * (r.b * dx + r.c * dy);
+                g5 = vis * v_alpha;
+            }
+        }
+        g0 = geom_wave_sum(g0); g1 = geom_wave_sum(g1); g2 = geom_wave_sum(g2);
+        g3 = geom_wave_sum(g3); g4 = geom_wave_sum(g4); g5 = geom_wave_sum(g5);
+        if (lane < 8) {
+            const float v = lane == 0 ? g0 : lane == 1 ? g1 : lane == 2 ? g2 : lane == 3 ? g3 : lane == 4 ? g4 : lane == 5 ? g5 : 0.f;
+            grow[(size_t)slot * 8 + lane] = v;
+        }
+        if (lane == 0) { key[slot] = (uint32_t)g; idx[slot] = slot; }
+    }
+}
+
+struct GeomLayout {
+    int64_t S, bgdot, grow, key, idx, key_s, idx_s, seg, sort, total;
+};
+inline GeomLayout geom_layout(int64_t n_isects, int width, int height, int n_gauss)
+{
+    const int64_t tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
+    const int64_t slots = GAGS_BLOCKS_PER_TILE * (n_isects + tile_w * tile_h) + 64;
+    GeomLayout L;
+    int64_t o = 0;
+    L.S = o; o += al256(slots * 256);
+    L.bgdot = o; o += al256((int64_t)width * height * 4);
+    L.grow = o; o += al256(slots * 32);
+    L.key = o; o += al256(slots * 4);
+    L.idx = o; o += al256(slots * 4);
+    L.key_s = o; o += al256(slots * 4);
+    L.idx_s = o; o += al256(slots * 4);
+    L.seg = o; o += al256(((int64_t)n_gauss + 2) * 4);
+    L.sort = o; o += al256(gags_sort_u32_scratch_bytes(slots));
+    L.total = o;
+    return L;
+}
+
+int64_t gags_raster_bwd_geom_scratch_bytes_impl(int64_t n_isects, int width, int height, int n_gauss)
+{
+    return geom_layout(n_isects, width, height, n_gauss).total;
+}
+
+// 1 = width not eligible (d % 8 != 0 or d < 32)
+int gags_raster_bwd_geom_launch(int d, int n_gauss, int width, int height, const float *colors, const float *backgrounds,
+                                const int32_t *offsets, int n_isects, const void *packed, const float *v_out,
+                                const float *v_alphas, const int32_t *blk_rows, const float *wt, const int32_t *gid_s,
+                                const int32_t *sidx_s, const float *Tbuf, void *scratch, int64_t scratch_bytes, float *v_geo,
+                                hipStream_t st)
+{
+    GAGS_CLEAR_ERR();
+    if (d < 32 || d % 8 != 0) return 1;
+    const GeomLayout L = geom_layout(n_isects, width, height, n_gauss);
+    if (scratch_bytes < L.total) return GAGS_ESCRATCH;
+    const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
+    const int n_tiles = tile_w * tile_h;
+    const int64_t slots = GAGS_BLOCKS_PER_TILE * ((int64_t)n_isects + n_tiles) + 64;
+    char *sb = (char *)scratch;
+    float *S = (float *)(sb + L.S), *bgdot = backgrounds ? (float *)(sb + L.bgdot) : nullptr, *grow = (float *)(sb + L.grow);
+    uint32_t *key = (uint32_t *)(sb + L.key), *key_s = (uint32_t *)(sb + L.key_s);
+    int32_t *idx = (int32_t *)(sb + L.idx), *idx_s = (int32_t *)(sb + L.idx_s), *seg = (int32_t *)(sb + L.seg);
+    // unused slots of the sparse slot space sort behind every Gaussian
+    if (hipMemsetD32Async((hipDeviceptr_t)key, n_gauss, (size_t)slots, st) != hipSuccess) return GAGS_ELAUNCH;
+    static bool attr_set = false;
+    const int lds_max = 64 * (SD_MAXCH + SD_PAD) * 4;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)raster_bwd_sdot<SD_MAXCH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max) != hipSuccess ||
+            hipFuncSetAttribute((const void *)raster_bwd_sdot<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max) != hipSuccess)
+            return GAGS_ELAUNCH;
+        attr_set = true;
+    }
+    for (int ch0 = 0; ch0 < d; ch0 += SD_MAXCH) {
+        const int dch = min(SD_MAXCH, d - ch0);
+        const dim3 grid(n_tiles * GAGS_BLOCKS_PER_TILE);
+        const size_t lds = (size_t)64 * (dch + SD_PAD) * 4;
+        if (dch == SD_MAXCH)
+            hipLaunchKernelGGL(raster_bwd_sdot<SD_MAXCH>, grid, dim3(256), lds, st, d, ch0, dch, width, height, tile_w, n_tiles, n_gauss,
+                               v_out, colors, backgrounds, offsets, n_isects, blk_rows, gid_s, S, bgdot, ch0 > 0 ? 1 : 0);
+        else
+            hipLaunchKernelGGL(raster_bwd_sdot<0>, grid, dim3(256), lds, st, d, ch0, dch, width, height, tile_w, n_tiles, n_gauss,
+                               v_out, colors, backgrounds, offsets, n_isects, blk_rows, gid_s, S, bgdot, ch0 > 0 ? 1 : 0);
+    }
+    hipLaunchKernelGGL(raster_bwd_geom, dim3(n_tiles * GAGS_BLOCKS_PER_TILE), dim3(64), 0, st, width, height, tile_w, n_tiles,
+                       n_gauss, reinterpret_cast<const GRec *>(packed), offsets, n_isects, blk_rows, wt, gid_s, sidx_s, S, Tbuf,
+                       v_alphas, bgdot, grow, key, idx);
+    GAGS_CHECK_LAUNCH();
+    int nbits = 1;
+    while ((1ll << nbits) <= n_gauss) ++nbits;  // keys in [0, n_gauss]
+    const int rc = gags_sort_pairs_u32(slots, nbits, key, idx, key_s, idx_s, sb + L.sort, L.total - L.sort, st);
+    if (rc != GAGS_OK) return rc;
+    hipLaunchKernelGGL(seg_offsets_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, (int)slots, key_s, n_gauss, seg);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((n_gauss + 127) / 128), dim3(256), 0, st, n_gauss, 8, 0, 8, seg, idx_s, grow, v_geo);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
 // 1 = width not eligible (d % 128 != 0)
 int gags_raster_bwd_atomic_launch(int d, int width, int height, const void *packed, const int32_t *offsets,
                                   const int32_t *flat, int n_isects, const float *v_out, float *v_colors,

@@ -232,8 +232,12 @@ class _Rasterize(torch.autograd.Function):
                                       (flags & 3) | (_lib.GAGS_FEAT_F16 if half else 0)
                                       | (64 if (half and d % 128 == 0 and (flags & _lib.GAGS_FWD_F16MFMA)) else 0),
                                       _stream()), "gags_raster_fwd")
-        staged = (split and _mfma_width(d) and d <= 1024 and ctx.needs_input_grad[2]
+        need_geom = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[3]
+        # wide-D geometry gradients on the matrix cores (gags_raster_bwd_geom) also consume the forward's scratch
+        geom_mfma = split and need_geom and _geom_mfma_width(d) and not half and not (flags & _lib.GAGS_BWD_ATOMIC)
+        staged = (split and _mfma_width(d) and d <= 1024 and (ctx.needs_input_grad[2] or geom_mfma)
                   and not (flags & _lib.GAGS_BWD_ATOMIC))
+        ctx.geom_mfma = bool(geom_mfma and staged)
         ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, packed, alphas,
                               last_ids, scratch if staged else None, blk_rows if staged else None)
         ctx.cfg = (width, height, flags)
@@ -262,6 +266,22 @@ class _Rasterize(torch.autograd.Function):
             if ctx.half:
                 v_colors = v_colors.half()  # autograd wants the table's dtype; an fp32 master sits behind a .half() cast
             return None, None, v_colors, None, v_bg, None, None, None, None, None, None
+        if need_geom and blk_rows is not None and ctx.geom_mfma:
+            # wide D: colours through the staged backward, geometry through the matrix-core dot pass + scalar pass
+            v_colors = None
+            if ctx.needs_input_grad[2]:
+                v_colors = _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height,
+                                            32 if (flags & _lib.GAGS_BWD_F16SPLIT) else 0, flatten_ids)
+            nb = lib.gags_raster_bwd_geom_scratch_bytes(n_isects, width, height, n)
+            gscratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+            v_geo = torch.empty(n, 8, device=dev)
+            with profiler.stage("raster_bwd_geom"):
+                check(lib.gags_raster_bwd_geom(d, n, width, height, ptr(colors), ptr(backgrounds), ptr(offsets), n_isects,
+                                               ptr(packed), ptr(v_out), ptr(v_alphas), ptr(blk_rows), ptr(fwd_scratch),
+                                               fwd_scratch.numel(), ptr(gscratch), nb, ptr(v_geo), _stream()),
+                      "gags_raster_bwd_geom")
+            v_con, v_m2d, v_opac = v_geo[:, 0:3].contiguous(), v_geo[:, 3:5].contiguous(), v_geo[:, 5].contiguous()
+            return v_m2d, v_con, v_colors, v_opac, v_bg, None, None, None, None, None, None
         if ctx.half:
             raise NotImplementedError("fp16 feature table: only the colours-only (feature distillation) backward is implemented")
         v_colors = torch.zeros(n, d, device=dev)
@@ -279,6 +299,11 @@ class _Rasterize(torch.autograd.Function):
                                       ptr(alphas), ptr(last_ids), ptr(v_out), ptr(v_alphas), ptr(v_colors),
                                       ptr(v_opac), ptr(v_m2d), ptr(v_con), bflags, _stream()), "gags_raster_bwd")
         return v_m2d, v_con, v_colors, v_opac, v_bg, None, None, None, None, None, None
+
+
+def _geom_mfma_width(d):
+    """Widths whose geometry gradients run through gags_raster_bwd_geom (below that the VALU kernel is faster)."""
+    return d >= 32 and d % 8 == 0 and d <= 1024
 
 
 def _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height, xflag=0,

@@ -167,6 +167,21 @@ int64_t gags_bwd_rowmap_scratch_bytes(int64_t n_isects);
 int gags_bwd_rowmap(int64_t n_isects, int width, int height, const int32_t *isect_offsets, const int32_t *blk_rows,
                     const void *fwd_scratch, int64_t fwd_scratch_bytes, int32_t *rowmap, int64_t rowmap_elems,
                     int32_t *total, void *scratch, int64_t scratch_bytes, void *stream);
+/* K10, geometry part at wide D (D >= 32, D % 8 == 0) after a split gags_raster_fwd: v_geo[N][8] =
+ * (v_conics[3], v_means2d[2], v_opacities[1], 0, 0) per Gaussian, written in full, no atomics, deterministic.
+ * The D-proportional work -- <colors[g], v_render_colors[px]> for every (slot, pixel) of the forward -- runs on the
+ * fp32 matrix cores; the per-pair chain uses the forward's own weights (T = weight / alpha: front-to-back quantities,
+ * not 1 - render_alpha rebuilt back to front).  Together with gags_raster_bwd_colors_staged this replaces
+ * gags_raster_bwd when geometry needs grad at wide D (gsplat's rasterize_to_pixels backward [EXT]).
+ * backgrounds / v_render_alphas may be NULL.  scratch: gags_raster_bwd_geom_scratch_bytes(n_isects, w, h, n)
+ * (~1.3 KB per tile intersection).  Returns 1 when D is not eligible. */
+int64_t gags_raster_bwd_geom_scratch_bytes(int64_t n_isects, int width, int height, int n);
+int gags_raster_bwd_geom(int d, int n, int width, int height, const float *colors, const float *backgrounds,
+                         const int32_t *isect_offsets, int64_t n_isects, const void *packed,
+                         const float *v_render_colors, const float *v_render_alphas, const int32_t *blk_rows,
+                         const void *fwd_scratch, int64_t fwd_scratch_bytes, void *scratch, int64_t scratch_bytes,
+                         float *v_geo, void *stream);
+
 /* mask[g] (n bytes, written in full) = 1 for every Gaussian that blended into at least one pixel of the view of a
  * split gags_raster_fwd (its scratch): exactly the rows of v_colors that can be non-zero.  A by-view multi-GPU step
  * exchanges only the union of these rows over the ranks (gags_amd/dist.py; SURVEY 8e "gradients are sparse in rows"). */

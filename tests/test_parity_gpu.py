@@ -282,6 +282,10 @@ def test_backward_by_channel_ranges_is_bit_identical(oracle):
     (2000, 112, 80, 48, 9, 5),    # two channel chunks, the second one ragged: per-chunk bg dot, v_alpha on chunk 0 only
     (2000, 112, 80, 64, 10, None),
     (1500, 96, 64, 128, 11, 2),   # C2 width with every geometry gradient
+    (1500, 96, 64, 256, 12, None),
+    (1200, 96, 64, 512, 13, 4),   # C3 width: D >= 32, D % 8 == 0 take gags_raster_bwd_geom (dot pass on the matrix cores)
+    (2000, 112, 80, 40, 14, 1),   # ... including a width that is no multiple of 32
+    (800, 64, 48, 640, 15, None), # two accumulating channel passes of the dot kernel (512 + 128)
 ])
 def test_full_backward(oracle, n, w, h, d, seed, view):
     s = scene_arrays(n, d, w, h, seed=seed, view=view, scale_mult=5.0)
@@ -304,6 +308,26 @@ def test_full_backward(oracle, n, w, h, d, seed, view):
     assert rel_l2(g["means"], o_vmeans) <= 1e-4
     assert rel_l2(g["quats"], o_vq) <= 1e-4
     assert rel_l2(g["scales"], o_vs) <= 1e-4
+
+
+def test_wide_geometry_backward_matches_the_valu_kernel_and_is_deterministic():
+    """gags_raster_bwd_geom (dot products on the matrix cores, front-to-back weights, row-sorted sums) against the VALU
+    backward it replaces at wide D (1 - alpha rebuilt back to front, float atomics), with and without background /
+    alpha cotangent; and bit-for-bit reproducible, which the atomic kernel is not."""
+    from gags_amd import _lib
+    n, w, h, d = 2500, 128, 96, 128
+    s = scene_arrays(n, d, w, h, seed=21, view=2, scale_mult=5.0)
+    rng = np.random.default_rng(5)
+    v_out = rng.standard_normal((h, w, d)).astype(np.float32)
+    v_alpha = rng.standard_normal((h, w)).astype(np.float32)
+    for bg, va in ((np.full(d, 0.3, np.float32), v_alpha), (None, None)):
+        _, _, _, g_new = _run_gpu(s, w, h, s["colors"], bg, need_geom=True, v_out=v_out, v_alpha=va)
+        _, _, _, g_rep = _run_gpu(s, w, h, s["colors"], bg, need_geom=True, v_out=v_out, v_alpha=va)
+        _, _, _, g_old = _run_gpu(s, w, h, s["colors"], bg, need_geom=True, v_out=v_out, v_alpha=va,
+                                  flags=_lib.GAGS_BWD_ATOMIC)
+        for k in ("means", "quats", "scales", "opacities", "means2d", "colors"):
+            np.testing.assert_array_equal(g_new[k], g_rep[k])
+            assert rel_l2(g_new[k], g_old[k]) <= 2e-5, k
 
 
 def test_render_modes_and_sh(oracle):

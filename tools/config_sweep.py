@@ -17,9 +17,13 @@ from bench import _CotangentLoss  # loss = <render, G> whose backward hands G it
 dev = torch.device("cuda", 0)
 
 
-def run(name, n, w, h, d, half=False, steps=8, flags=0):
+def run(name, n, w, h, d, half=False, steps=8, flags=0, full_grad=False):
     pc = syn.make_model(n, d, w, h, seed=0, device=dev, gen_device=dev)
     pc.training_setup()
+    geo = [pc._xyz, pc._scaling, pc._rotation, pc._opacity]
+    if full_grad:  # joint training: every geometry parameter gets its gradient too (SURVEY A9 in full)
+        for q in geo:
+            q.requires_grad_(True)
     if half:
         master = pc._semantic_feature
         pc.rewrite_semantic_feature(master.detach().half().requires_grad_(True))
@@ -29,6 +33,8 @@ def run(name, n, w, h, d, half=False, steps=8, flags=0):
 
     def step():
         pc._semantic_feature.grad = None
+        for q in geo:
+            q.grad = None
         pkg = render(cam, pc, None, bg, feature_mode=True, raster_flags=flags)
         _CotangentLoss.apply(pkg["render"].permute(1, 2, 0), G.permute(1, 2, 0)).backward()
         return pkg
@@ -48,17 +54,25 @@ def run(name, n, w, h, d, half=False, steps=8, flags=0):
     return name, res
 
 
-out = dict([
-    run("C1 10k/256x256/D=3", 10_000, 256, 256, 3),
-    run("C2 500k/1280x720/D=128", 500_000, 1280, 720, 128),
-    run("C3 geometry D=16", 1_500_000, 1920, 1080, 16),
-    run("C3 geometry D=64", 1_500_000, 1920, 1080, 64),
-    run("C3 geometry D=256", 1_500_000, 1920, 1080, 256),
-    run("C5 4M/1080p/D=512 fp32 table", 4_000_000, 1920, 1080, 512),
-    run("C5 4M/1080p/D=512 fp16 table", 4_000_000, 1920, 1080, 512, half=True),
-    run("C5 4M/1080p/D=512 fp16 table, 16-bit matrix cores fwd+bwd (opt-in)", 4_000_000, 1920, 1080, 512, half=True, flags=128 | 64),
-    run("C3 1.5M/1080p/D=512 fp16 table, 16-bit matrix cores fwd+bwd (opt-in)", 1_500_000, 1920, 1080, 512, half=True, flags=128 | 64),
-    run("C3 1.5M/1080p/D=512 fp32 table, 16-bit matrix cores bwd (opt-in)", 1_500_000, 1920, 1080, 512, flags=64),
-    run("C5 4M/1080p/D=513 (512+1) fp32", 4_000_000, 1920, 1080, 513, steps=4),
-])
+C3 = (1_500_000, 1920, 1080)
+C5 = (4_000_000, 1920, 1080)
+CASES = [
+    ("C1 10k/256x256/D=3", (10_000, 256, 256, 3), {}),
+    ("C2 500k/1280x720/D=128", (500_000, 1280, 720, 128), {}),
+    ("C3 geometry D=16", C3 + (16,), {}),
+    ("C3 geometry D=64", C3 + (64,), {}),
+    ("C3 geometry D=256", C3 + (256,), {}),
+    ("C5 4M/1080p/D=512 fp32 table", C5 + (512,), {}),
+    ("C5 4M/1080p/D=512 fp16 table", C5 + (512,), dict(half=True)),
+    ("C5 4M/1080p/D=512 fp16 table, 16-bit matrix cores fwd+bwd (opt-in)", C5 + (512,), dict(half=True, flags=128 | 64)),
+    ("C3 1.5M/1080p/D=512 fp16 table, 16-bit matrix cores fwd+bwd (opt-in)", C3 + (512,), dict(half=True, flags=128 | 64)),
+    ("C3 1.5M/1080p/D=512 fp32 table, 16-bit matrix cores bwd (opt-in)", C3 + (512,), dict(flags=64)),
+    ("C5 4M/1080p/D=513 (512+1) fp32", C5 + (513,), dict(steps=4)),
+    ("C3 1.5M/1080p/D=512, ALL gradients (features + means, quats, scales, opacities)", C3 + (512,), dict(full_grad=True)),
+    ("C3 ALL gradients, VALU + atomics backward (what round 1 ran)", C3 + (512,), dict(full_grad=True, flags=4, steps=3)),
+    ("C2 500k/1280x720/D=128, ALL gradients", (500_000, 1280, 720, 128), dict(full_grad=True)),
+    ("C3 geometry D=16, ALL gradients (VALU kernels)", C3 + (16,), dict(full_grad=True)),
+]
+sel = sys.argv[1] if len(sys.argv) > 1 else ""   # substring filter
+out = dict(run(name, *shape, **kw) for name, shape, kw in CASES if sel in name)
 print(json.dumps(out))
