@@ -47,7 +47,7 @@ SIGNATURES = {
     "gags_bwd_rowmap": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
     "gags_raster_bwd_geom_scratch_bytes": (_i64, [_i64, _i32, _i32, _i32]),
     "gags_raster_bwd_geom": (_i32, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64,
-                                    _vp, _vp]),
+                                    _vp, _vp, _i32, _vp]),
     "gags_blended_mask": (_i32, [_i64, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),
     "gags_bwd_staged_scratch_bytes": (_i64, [_i64, _i32, _i32]),
     "gags_raster_bwd_colors_staged": (_i32, [_i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
@@ -85,6 +85,7 @@ SIGNATURES = {
 
 GAGS_BWD_COLORS_ONLY = 1
 GAGS_FWD_NO_MFMA = 2
+GAGS_RECS_BY_GAUSSIAN = 256  # C flag: `packed` is the per-Gaussian record table (gags_pack_isects with packed = NULL)
 GAGS_BWD_ATOMIC = 4  # python-side: use the atomic colours-only backward instead of the staged one
 GAGS_FEAT_F16 = 32  # forward: colors is an fp16 table (include/gags_raster.h)
 GAGS_BWD_F16SPLIT = 64  # python-side: staged backward contracts on the 16-bit matrix cores (fp16 head + tail; ~2^-21, opt-in)

@@ -17,7 +17,7 @@ int gags_raster_bwd_valu(int d, int width, int height, const float *means2d, con
 // raster_weights.hip
 int gags_pack_isects_launch(int n, int n_isects, const int32_t *flat, const float *means2d, const float *conics,
                             const float *opacities, const int32_t *radii, void *grec, void *packed, hipStream_t st);
-int gags_raster_weights_launch(int width, int height, int n_gauss, const void *packed, const int32_t *offsets,
+int gags_raster_weights_launch(int width, int height, int n_gauss, const void *packed, int by_gauss, const int32_t *offsets,
                                const int32_t *flat, int n_isects, float *wt, int32_t *gid_s, int32_t *sidx_s,
                                int32_t *hit, int32_t *blk_rows, float *Tbuf, float *alphas, int32_t *last_ids,
                                hipStream_t st);
@@ -28,7 +28,7 @@ int gags_raster_fwd_feat_launch(int d, int width, int height, int n_gauss, const
                                 float *out, hipStream_t st);
 int gags_raster_fwd_fused_launch(int d, int width, int height, const void *packed, const float *colors,
                                  const float *backgrounds, const int32_t *offsets, const int32_t *flat, int n_isects,
-                                 float *out, float *alphas, int32_t *last_ids, hipStream_t st);
+                                 float *out, float *alphas, int32_t *last_ids, int by_gauss, hipStream_t st);
 // raster_bwd_mfma.hip
 int64_t gags_bwd_staged_scratch_bytes_impl(int64_t rows, int n_gauss, int d);
 int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, const int32_t *offsets, int n_isects,
@@ -41,13 +41,13 @@ int gags_raster_bwd_geom_launch(int d, int n_gauss, int width, int height, const
                                 const int32_t *offsets, int n_isects, const void *packed, const float *v_out,
                                 const float *v_alphas, const int32_t *blk_rows, const float *wt, const int32_t *gid_s,
                                 const int32_t *sidx_s, const float *Tbuf, void *scratch, int64_t scratch_bytes, float *v_geo,
-                                hipStream_t st);
+                                int by_gauss, hipStream_t st);
 int gags_blended_mask_launch(int n_isects, const int32_t *hit, const int32_t *flatten_ids, unsigned char *mask, hipStream_t st);
 int gags_bwd_slot_rows_launch(int width, int height, int n_isects, const int32_t *offsets, const int32_t *blk_rows,
                               const int32_t *sidx_s, const int32_t *trow, int32_t *trow_s, hipStream_t st);
 int gags_raster_bwd_atomic_launch(int d, int width, int height, const void *packed, const int32_t *offsets,
                                   const int32_t *flat, int n_isects, const float *v_out, float *v_colors,
-                                  hipStream_t st);
+                                  int by_gauss, hipStream_t st);
 
 namespace {
 inline int64_t al256(int64_t x) { return (x + 255) / 256 * 256; }
@@ -79,7 +79,7 @@ extern "C" int gags_pack_isects(int n, int64_t n_isects, const int32_t *flatten_
 {
     if (n < 0 || n_isects < 0 || n_isects >= (1ll << 31)) return GAGS_EINVAL;
     if (n_isects == 0) return GAGS_OK;
-    if (!flatten_ids || !means2d || !conics || !opacities || !packed) return GAGS_EINVAL;
+    if (!flatten_ids || !means2d || !conics || !opacities || (!packed && !grec)) return GAGS_EINVAL;
     return gags_pack_isects_launch(n, (int)n_isects, flatten_ids, means2d, conics, opacities, radii, grec, packed,
                                    (hipStream_t)stream);
 }
@@ -111,7 +111,7 @@ extern "C" int gags_raster_fwd(int d, int n, int width, int height, const float 
             float *wt = (float *)(sb + L.wt);
             int32_t *gid_s = (int32_t *)(sb + L.gid);
             float *tbuf = (float *)(sb + L.tbuf);
-            int rc = gags_raster_weights_launch(width, height, n, packed, isect_offsets, flatten_ids, (int)n_isects, wt,
+            int rc = gags_raster_weights_launch(width, height, n, packed, (flags & GAGS_RECS_BY_GAUSSIAN) ? 1 : 0, isect_offsets, flatten_ids, (int)n_isects, wt,
                                                 gid_s, (int32_t *)(sb + L.sidx), (int32_t *)(sb + L.hit), blk_rows, tbuf,
                                                 render_alphas, last_ids, st);
             if (rc != GAGS_OK) return rc;
@@ -119,7 +119,8 @@ extern "C" int gags_raster_fwd(int d, int n, int width, int height, const float 
                                                blk_rows, wt, gid_s, tbuf, render_colors, st);
         }
         return gags_raster_fwd_fused_launch(d, width, height, packed, colors, backgrounds, isect_offsets, flatten_ids,
-                                            (int)n_isects, render_colors, render_alphas, last_ids, st);
+                                            (int)n_isects, render_colors, render_alphas, last_ids,
+                                            (flags & GAGS_RECS_BY_GAUSSIAN) ? 1 : 0, st);
     }
     return gags_raster_fwd_valu(d, width, height, means2d, conics, opacities, colors, backgrounds, isect_offsets,
                                 flatten_ids, (int)n_isects, render_colors, render_alphas, last_ids, st);
@@ -141,7 +142,8 @@ extern "C" int gags_raster_bwd(int d, int width, int height, const float *means2
     if (geom && (!v_opacities || !v_means2d || !v_conics)) return GAGS_EINVAL;
     if (!geom && !(flags & GAGS_FWD_NO_MFMA) && packed) {
         const int rc = gags_raster_bwd_atomic_launch(d, width, height, packed, isect_offsets, flatten_ids,
-                                                     (int)n_isects, v_render_colors, v_colors, (hipStream_t)stream);
+                                                     (int)n_isects, v_render_colors, v_colors,
+                                                     (flags & GAGS_RECS_BY_GAUSSIAN) ? 1 : 0, (hipStream_t)stream);
         if (rc != 1) return rc;
     }
     return gags_raster_bwd_valu(d, width, height, means2d, conics, opacities, colors, backgrounds, isect_offsets,
@@ -212,8 +214,9 @@ extern "C" int gags_raster_bwd_geom(int d, int n, int width, int height, const f
                                     const int32_t *isect_offsets, int64_t n_isects, const void *packed,
                                     const float *v_render_colors, const float *v_render_alphas, const int32_t *blk_rows,
                                     const void *fwd_scratch, int64_t fwd_scratch_bytes, void *scratch, int64_t scratch_bytes,
-                                    float *v_geo, void *stream)
+                                    float *v_geo, const int32_t *flatten_ids, int flags, void *stream)
 {
+    (void)flatten_ids;  // the slots carry their Gaussian ids (gid_s); kept in the signature for symmetry with the forward
     if (d <= 0 || width <= 0 || height <= 0 || n < 0 || n_isects < 0 || n_isects >= (1ll << 27)) return GAGS_EINVAL;
     if (n == 0) return GAGS_OK;
     if (!colors || !isect_offsets || !packed || !v_render_colors || !blk_rows || !fwd_scratch || !scratch || !v_geo)
@@ -224,7 +227,8 @@ extern "C" int gags_raster_bwd_geom(int d, int n, int width, int height, const f
     return gags_raster_bwd_geom_launch(d, n, width, height, colors, backgrounds, isect_offsets, (int)n_isects, packed,
                                        v_render_colors, v_render_alphas, blk_rows, (const float *)(fs + L.wt),
                                        (const int32_t *)(fs + L.gid), (const int32_t *)(fs + L.sidx),
-                                       (const float *)(fs + L.tbuf), scratch, scratch_bytes, v_geo, (hipStream_t)stream);
+                                       (const float *)(fs + L.tbuf), scratch, scratch_bytes, v_geo,
+                                       (flags & GAGS_RECS_BY_GAUSSIAN) ? 1 : 0, (hipStream_t)stream);
 }
 
 extern "C" int gags_blended_mask(int64_t n_isects, int width, int height, int n, const int32_t *flatten_ids,

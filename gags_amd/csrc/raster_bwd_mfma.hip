@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(int n_gauss, int d, in
 __global__ __launch_bounds__(64, 2) void raster_bwd_atomic(
     int d, int width, int height, int tile_w, int n_tiles, int n_slices, const GRec *__restrict__ packed,
     const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids, int n_isects,
-    const float *__restrict__ v_render_colors, float *__restrict__ v_colors)
+    const float *__restrict__ v_render_colors, float *__restrict__ v_colors, int by_gauss)
 {
     __shared__ __attribute__((aligned(16))) HRec ring[RING];
     __shared__ __attribute__((aligned(16))) float Wt[32 * WT_STRIDE];
@@ -543,6 +543,7 @@ __global__ __launch_bounds__(64, 2) void raster_bwd_atomic(
     PixState st;
     st.T = 1.0f; st.cur = 0; st.done = !g.inside;
     HitStream hs;
+    hs.by_gauss = by_gauss != 0;
     hs.init(ring, packed, flatten_ids, start, end, lane, g);
 
     int nh = 0;
@@ -878,7 +879,7 @@ __global__ __launch_bounds__(64) void raster_bwd_geom(int width, int height, int
                                                       const int32_t *__restrict__ sidx_s, const float *__restrict__ S,
                                                       const float *__restrict__ Tbuf, const float *__restrict__ v_alphas,
                                                       const float *__restrict__ bgdot, float *__restrict__ grow,
-                                                      uint32_t *__restrict__ key, int32_t *__restrict__ idx)
+                                                      uint32_t *__restrict__ key, int32_t *__restrict__ idx, int by_gauss)
 {
     const int logical = gags_xcd_remap(blockIdx.x, n_tiles * GAGS_BLOCKS_PER_TILE);
     const int blk = logical & 3;
@@ -910,8 +911,8 @@ __global__ __launch_bounds__(64) void raster_bwd_geom(int width, int height, int
         q.sd = S[(size_t)slot * 64 + lane];
         return q;
     };
-    auto fetch_rec = [&](const Ids &q) __attribute__((always_inline)) {
-        return packed[max(__builtin_amdgcn_readfirstlane(q.sx), 0)];
+    auto fetch_rec = [&](const Ids &q) __attribute__((always_inline)) {  // (the pad slot's gid is n_gauss: clamped, unused)
+        return packed[by_gauss ? min(__builtin_amdgcn_readfirstlane(q.g), n_gauss - 1) : max(__builtin_amdgcn_readfirstlane(q.sx), 0)];
     };
     Ids i1 = fetch_ids(cnt - 1), i2 = fetch_ids(cnt - 2);
     GRec r1 = fetch_rec(i1);
@@ -989,7 +990,7 @@ int gags_raster_bwd_geom_launch(int d, int n_gauss, int width, int height, const
                                 const int32_t *offsets, int n_isects, const void *packed, const float *v_out,
                                 const float *v_alphas, const int32_t *blk_rows, const float *wt, const int32_t *gid_s,
                                 const int32_t *sidx_s, const float *Tbuf, void *scratch, int64_t scratch_bytes, float *v_geo,
-                                hipStream_t st)
+                                int by_gauss, hipStream_t st)
 {
     GAGS_CLEAR_ERR();
     if (d < 32 || d % 8 != 0) return 1;
@@ -1025,7 +1026,7 @@ int gags_raster_bwd_geom_launch(int d, int n_gauss, int width, int height, const
     }
     hipLaunchKernelGGL(raster_bwd_geom, dim3(n_tiles * GAGS_BLOCKS_PER_TILE), dim3(64), 0, st, width, height, tile_w, n_tiles,
                        n_gauss, reinterpret_cast<const GRec *>(packed), offsets, n_isects, blk_rows, wt, gid_s, sidx_s, S, Tbuf,
-                       v_alphas, bgdot, grow, key, idx);
+                       v_alphas, bgdot, grow, key, idx, by_gauss);
     GAGS_CHECK_LAUNCH();
     int nbits = 1;
     while ((1ll << nbits) <= n_gauss) ++nbits;  // keys in [0, n_gauss]
@@ -1040,7 +1041,7 @@ int gags_raster_bwd_geom_launch(int d, int n_gauss, int width, int height, const
 // 1 = width not eligible (d % 128 != 0)
 int gags_raster_bwd_atomic_launch(int d, int width, int height, const void *packed, const int32_t *offsets,
                                   const int32_t *flat, int n_isects, const float *v_out, float *v_colors,
-                                  hipStream_t st)
+                                  int by_gauss, hipStream_t st)
 {
     GAGS_CLEAR_ERR();
     if (d < CSB || d % CSB != 0) return 1;
@@ -1048,7 +1049,7 @@ int gags_raster_bwd_atomic_launch(int d, int width, int height, const void *pack
     const int n_tiles = tile_w * tile_h, n_slices = d / CSB;
     hipLaunchKernelGGL(raster_bwd_atomic, dim3(n_tiles * 8 * n_slices), dim3(64), 0, st, d, width, height, tile_w,
                        n_tiles, n_slices, reinterpret_cast<const GRec *>(packed), offsets, flat, n_isects, v_out,
-                       v_colors);
+                       v_colors, by_gauss);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64, (NB >= 16 ? 1 : 2)) void raster_fwd_fused(
     int d, int width, int height, int tile_w, int n_tiles, int n_slices, const GRec *__restrict__ packed,
     const float *__restrict__ colors, const float *__restrict__ backgrounds, const int32_t *__restrict__ offsets,
     const int32_t *__restrict__ flatten_ids, int n_isects, float *__restrict__ render_colors,
-    float *__restrict__ render_alphas, int32_t *__restrict__ last_ids)
+    float *__restrict__ render_alphas, int32_t *__restrict__ last_ids, int by_gauss)
 {
     constexpr int CS = FwdCfg<NB>::CS, NG = FwdCfg<NB>::NG;
     __shared__ __attribute__((aligned(16))) HRec ring[RING];
@@ -373,6 +373,7 @@ __global__ __launch_bounds__(64, (NB >= 16 ? 1 : 2)) void raster_fwd_fused(
     PixState st;
     st.T = 1.0f; st.cur = 0; st.done = !g.inside;
     HitStream hs;
+    hs.by_gauss = by_gauss != 0;
     hs.init(ring, packed, flatten_ids, start, end, lane, g);
     hs.refill(6);
     if (!__all(st.done) && hs.rd < hs.nq) {
@@ -441,12 +442,12 @@ int launch_feat(int d, int width, int height, int n_gauss, const float *colors, 
 template <int NB>
 int launch_fused(int d, int width, int height, const GRec *packed, const float *colors, const float *backgrounds,
                  const int32_t *offsets, const int32_t *flat, int n_isects, float *out, float *alphas,
-                 int32_t *last_ids, hipStream_t st)
+                 int32_t *last_ids, int by_gauss, hipStream_t st)
 {
     const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
     const int n_tiles = tile_w * tile_h, n_slices = d / (32 * NB);
     hipLaunchKernelGGL(raster_fwd_fused<NB>, dim3(n_tiles * 8 * n_slices), dim3(64), 0, st, d, width, height, tile_w,
-                       n_tiles, n_slices, packed, colors, backgrounds, offsets, flat, n_isects, out, alphas, last_ids);
+                       n_tiles, n_slices, packed, colors, backgrounds, offsets, flat, n_isects, out, alphas, last_ids, by_gauss);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }
@@ -484,11 +485,11 @@ int gags_raster_fwd_feat_launch(int d, int width, int height, int n_gauss, const
 // single-kernel forward (no scratch)
 int gags_raster_fwd_fused_launch(int d, int width, int height, const void *packed, const float *colors,
                                  const float *backgrounds, const int32_t *offsets, const int32_t *flat, int n_isects,
-                                 float *out, float *alphas, int32_t *last_ids, hipStream_t st)
+                                 float *out, float *alphas, int32_t *last_ids, int by_gauss, hipStream_t st)
 {
     GAGS_CLEAR_ERR();
     const GRec *pk = reinterpret_cast<const GRec *>(packed);
-#define ARGS d, width, height, pk, colors, backgrounds, offsets, flat, n_isects, out, alphas, last_ids, st
+#define ARGS d, width, height, pk, colors, backgrounds, offsets, flat, n_isects, out, alphas, last_ids, by_gauss, st
     if (d % 256 == 0) return launch_fused<8>(ARGS);
     if (d % 128 == 0) return launch_fused<4>(ARGS);
     if (d % 64 == 0) return launch_fused<2>(ARGS);

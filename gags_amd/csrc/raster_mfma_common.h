@@ -144,16 +144,17 @@ struct HitStream {
     GRec pre;        // chunk in flight: one record per lane
     int pre_gid, pre_c;
     bool pending;
+    bool by_gauss = false;  // records indexed by Gaussian id (gathered here) instead of by sorted intersection
 
     __device__ __forceinline__ void issue()
     {
         pre_c = c;
         const int idx = c + lane;
         if (idx < end) {
-            const float4 *src = reinterpret_cast<const float4 *>(packed + idx);
+            pre_gid = flat[idx];
+            const float4 *src = reinterpret_cast<const float4 *>(packed + (by_gauss ? pre_gid : idx));
             const float4 u = src[0], v = src[1];
             pre.x = u.x; pre.y = u.y; pre.a = u.z; pre.b = u.w; pre.c = v.x; pre.o = v.y; pre.ex = v.z; pre.ey = v.w;
-            pre_gid = flat[idx];
         } else {
             pre.x = pre.y = 0.f; pre.ex = pre.ey = -1.f; pre.a = pre.b = pre.c = pre.o = 0.f;
             pre_gid = 0;

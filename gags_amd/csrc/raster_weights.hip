@@ -65,7 +65,7 @@ __global__ __launch_bounds__(64, 8) void raster_weights_kernel(
     const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids, int n_isects,
     float *__restrict__ wt, int32_t *__restrict__ gid_s, int32_t *__restrict__ sidx_s, int32_t *__restrict__ hit,
     int32_t *__restrict__ blk_rows, float *__restrict__ Tbuf, float *__restrict__ render_alphas,
-    int32_t *__restrict__ last_ids)
+    int32_t *__restrict__ last_ids, int by_gauss)
 {
     __shared__ __attribute__((aligned(16))) HRec ring[RING];
 
@@ -86,6 +86,7 @@ __global__ __launch_bounds__(64, 8) void raster_weights_kernel(
     sB.T = 1.0f; sB.cur = 0; sB.done = !g.insideB;
 
     HitStream hs;
+    hs.by_gauss = by_gauss != 0;
     hs.init(ring, packed, flatten_ids, start, end, lane, g);
 
     int row = sb;
@@ -166,7 +167,8 @@ int gags_pack_isects_launch(int n, int n_isects, const int32_t *flat, const floa
     if (grec) {
         hipLaunchKernelGGL(make_grec_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, means2d, conics, opacities,
                            radii, reinterpret_cast<GRec *>(grec));
-        hipLaunchKernelGGL(gather_grec_kernel, dim3((n_isects + 255) / 256), dim3(256), 0, st, n_isects, flat,
+        if (packed)
+            hipLaunchKernelGGL(gather_grec_kernel, dim3((n_isects + 255) / 256), dim3(256), 0, st, n_isects, flat,
                            reinterpret_cast<const GRec *>(grec), reinterpret_cast<GRec *>(packed));
     } else {
         hipLaunchKernelGGL(pack_isects_kernel, dim3((n_isects + 255) / 256), dim3(256), 0, st, n_isects, flat, means2d,
@@ -176,7 +178,7 @@ int gags_pack_isects_launch(int n, int n_isects, const int32_t *flat, const floa
     return GAGS_OK;
 }
 
-int gags_raster_weights_launch(int width, int height, int n_gauss, const void *packed, const int32_t *offsets,
+int gags_raster_weights_launch(int width, int height, int n_gauss, const void *packed, int by_gauss, const int32_t *offsets,
                                const int32_t *flat, int n_isects, float *wt, int32_t *gid_s, int32_t *sidx_s,
                                int32_t *hit, int32_t *blk_rows, float *Tbuf, float *alphas, int32_t *last_ids,
                                hipStream_t st)
@@ -188,7 +190,7 @@ int gags_raster_weights_launch(int width, int height, int n_gauss, const void *p
     if (hipMemsetAsync(hit, 0, sizeof(int32_t) * ((size_t)n_isects + 1), st) != hipSuccess) return GAGS_ELAUNCH;
     hipLaunchKernelGGL(raster_weights_kernel, dim3(n_tiles * GAGS_BLOCKS_PER_TILE), dim3(64), 0, st, width, height, tile_w, n_tiles,
                        n_gauss, reinterpret_cast<const GRec *>(packed), offsets, flat, n_isects, wt, gid_s, sidx_s, hit,
-                       blk_rows, Tbuf, alphas, last_ids);
+                       blk_rows, Tbuf, alphas, last_ids, by_gauss);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }

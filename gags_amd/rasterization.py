@@ -178,10 +178,11 @@ def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height, conics=
     check(lib.gags_tile_offsets(n_isects, ptr(ids_s), n_tiles, ptr(offsets), st), "gags_tile_offsets")
     packed = None
     if conics is not None:
-        packed = torch.empty(max(n_isects, 1), 8, dtype=torch.float32, device=dev)
-        grec = torch.empty(max(n, 1), 8, dtype=torch.float32, device=dev)
+        # one 32-byte record per GAUSSIAN; the raster kernels gather it through flatten_ids themselves
+        # (GAGS_RECS_BY_GAUSSIAN): no per-intersection copy of the records, no gather kernel
+        packed = torch.empty(max(n, 1), 8, dtype=torch.float32, device=dev)
         check(lib.gags_pack_isects(n, n_isects, ptr(flat_s), ptr(means2d), ptr(conics), ptr(opacities), ptr(radii),
-                                   ptr(grec), ptr(packed), st), "gags_pack_isects")
+                                   ptr(packed), None, st), "gags_pack_isects")
     return ids_s[:n_isects], flat_s[:n_isects], offsets, n_isects, packed
 
 
@@ -229,7 +230,7 @@ class _Rasterize(torch.autograd.Function):
             check(lib.gags_raster_fwd(d, n, width, height, ptr(means2d), ptr(conics), ptr(opacities), ptr(colors),
                                       ptr(backgrounds), ptr(offsets), ptr(flatten_ids), n_isects, ptr(packed),
                                       ptr(out), ptr(alphas), ptr(last_ids), ptr(scratch), nbytes, ptr(blk_rows),
-                                      (flags & 3) | (_lib.GAGS_FEAT_F16 if half else 0)
+                                      (flags & 3) | _lib.GAGS_RECS_BY_GAUSSIAN | (_lib.GAGS_FEAT_F16 if half else 0)
                                       | (64 if (half and d % 128 == 0 and (flags & _lib.GAGS_FWD_F16MFMA)) else 0),
                                       _stream()), "gags_raster_fwd")
         need_geom = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[3]
@@ -278,7 +279,8 @@ class _Rasterize(torch.autograd.Function):
             with profiler.stage("raster_bwd_geom"):
                 check(lib.gags_raster_bwd_geom(d, n, width, height, ptr(colors), ptr(backgrounds), ptr(offsets), n_isects,
                                                ptr(packed), ptr(v_out), ptr(v_alphas), ptr(blk_rows), ptr(fwd_scratch),
-                                               fwd_scratch.numel(), ptr(gscratch), nb, ptr(v_geo), _stream()),
+                                               fwd_scratch.numel(), ptr(gscratch), nb, ptr(v_geo), ptr(flatten_ids),
+                                               _lib.GAGS_RECS_BY_GAUSSIAN, _stream()),
                       "gags_raster_bwd_geom")
             v_con, v_m2d, v_opac = v_geo[:, 0:3].contiguous(), v_geo[:, 3:5].contiguous(), v_geo[:, 5].contiguous()
             return v_m2d, v_con, v_colors, v_opac, v_bg, None, None, None, None, None, None
@@ -289,10 +291,10 @@ class _Rasterize(torch.autograd.Function):
             v_opac = torch.zeros(n, device=dev)
             v_m2d = torch.zeros(n, 2, device=dev)
             v_con = torch.zeros(n, 3, device=dev)
-            bflags = flags & 3
+            bflags = (flags & 3) | _lib.GAGS_RECS_BY_GAUSSIAN
         else:
             v_opac = v_m2d = v_con = None
-            bflags = (flags & 3) | _lib.GAGS_BWD_COLORS_ONLY
+            bflags = (flags & 3) | _lib.GAGS_BWD_COLORS_ONLY | _lib.GAGS_RECS_BY_GAUSSIAN
         with profiler.stage("raster_bwd"):
             check(lib.gags_raster_bwd(d, width, height, ptr(means2d), ptr(conics), ptr(opacities), ptr(colors),
                                       ptr(backgrounds), ptr(offsets), ptr(flatten_ids), n_isects, ptr(packed),

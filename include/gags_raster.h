@@ -47,6 +47,10 @@ extern "C" {
 #define GAGS_FWD_F16MFMA 64    /* with GAGS_FEAT_F16 and D % 128 == 0, opt-in: the feature pass contracts on the 16-bit matrix
                                   cores (features exact, weights as fp16 head + tail: ~2^-22 per term, not bit-identical) */
 
+#define GAGS_RECS_BY_GAUSSIAN 256 /* `packed` holds one record per GAUSSIAN (gags_pack_isects with packed = NULL) and the raster
+                                  kernels gather it through flatten_ids themselves: no per-intersection copy (32 B x n_isects
+                                  written and read back) and no gather kernel */
+
 int gags_abi_version(void);
 const char *gags_strerror(int code);
 /* number of HIP devices visible, or a negative error; never throws */
@@ -108,7 +112,9 @@ int gags_tile_offsets(int64_t n_isects, const int64_t *sorted_ids, int n_tiles,
  * half-extent of the alpha >= 1/255 footprint.  The wide-D (MFMA) raster kernels stream this
  * array instead of gathering means2d/conics/opacities per tile.  packed: n_isects * 32 bytes.
  * grec (optional scratch, n * 32 bytes): when given, the record is built once per Gaussian
- * (radii > 0 only, radii may be NULL = all) and the per-intersection pass is a pure gather. */
+ * (radii > 0 only, radii may be NULL = all) and the per-intersection pass is a pure gather.
+ * packed == NULL (grec required): only the per-Gaussian table is built; hand `grec` to the raster entries as
+ * `packed` together with the flag GAGS_RECS_BY_GAUSSIAN. */
 #define GAGS_PACKED_BYTES 32
 int gags_pack_isects(int n, int64_t n_isects, const int32_t *flatten_ids, const float *means2d,
                      const float *conics, const float *opacities, const int32_t *radii, void *grec,
@@ -180,7 +186,8 @@ int gags_raster_bwd_geom(int d, int n, int width, int height, const float *color
                          const int32_t *isect_offsets, int64_t n_isects, const void *packed,
                          const float *v_render_colors, const float *v_render_alphas, const int32_t *blk_rows,
                          const void *fwd_scratch, int64_t fwd_scratch_bytes, void *scratch, int64_t scratch_bytes,
-                         float *v_geo, void *stream);
+                         float *v_geo, const int32_t *flatten_ids /* needed with GAGS_RECS_BY_GAUSSIAN */, int flags,
+                         void *stream);
 
 /* mask[g] (n bytes, written in full) = 1 for every Gaussian that blended into at least one pixel of the view of a
  * split gags_raster_fwd (its scratch): exactly the rows of v_colors that can be non-zero.  A by-view multi-GPU step

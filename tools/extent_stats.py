@@ -20,7 +20,7 @@ cap = {}
 orig = R.tile_binning
 def spy(*a, **k):
     out = orig(*a, **k)
-    cap["ids"], cap["packed"] = out[0], out[4]
+    cap["ids"], cap["packed"] = out[0], out[4][out[1].long()]  # per-Gaussian records -> per sorted intersection
     return out
 R.tile_binning = spy
 orig_b = R._backward_staged
