@@ -879,7 +879,8 @@ __global__ __launch_bounds__(64) void raster_bwd_geom(int width, int height, int
                                                       const int32_t *__restrict__ sidx_s, const float *__restrict__ S,
                                                       const float *__restrict__ Tbuf, const float *__restrict__ v_alphas,
                                                       const float *__restrict__ bgdot, float *__restrict__ grow,
-                                                      uint32_t *__restrict__ key, int32_t *__restrict__ idx, int by_gauss)
+                                                      uint32_t *__restrict__ key, int32_t *__restrict__ idx, int by_gauss,
+                                                      const int32_t *__restrict__ row_base)
 {
     const int logical = gags_xcd_remap(blockIdx.x, n_tiles * GAGS_BLOCKS_PER_TILE);
     const int blk = logical & 3;
@@ -889,6 +890,8 @@ __global__ __launch_bounds__(64) void raster_bwd_geom(int width, int height, int
     const int start = offsets[tile];
     const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
     const int sb = gags_slot_base(start, end, tile, blk);
+    // row of slot j: compact numbering (row_base = exclusive prefix sum of blk_rows) or the sparse slot index itself
+    const int rb = row_base ? row_base[tile * GAGS_BLOCKS_PER_TILE + blk] : sb;
     const int lane = threadIdx.x;  // = element e of the weight rows: pixel p = e >> 1 of the 8x4 half h = e & 1
     const int ty = tile / tile_w, tx = tile - ty * tile_w;
     const int pj = tx * GAGS_TILE + (blk & 1) * 8 + ((lane >> 1) & 7);
@@ -923,9 +926,12 @@ __global__ __launch_bounds__(64) void raster_bwd_geom(int width, int height, int
         r1 = fetch_rec(i1);
         i2 = fetch_ids(j - 2);
         __builtin_amdgcn_sched_barrier(0);  // keep the requests above the arithmetic of the current slot
-        const int slot = sb + j;
+        const int row = rb + j;
         const int sx = __builtin_amdgcn_readfirstlane(cur.sx);
-        if (sx < 0) continue;  // pad slot
+        if (sx < 0) {  // pad slot: sorts behind every Gaussian
+            if (lane == 0) { key[row] = (uint32_t)n_gauss; idx[row] = row; }
+            continue;
+        }
         const int g = __builtin_amdgcn_readfirstlane(cur.g);
         const float f = cur.f, sdot = cur.sd;
         const float dx = r.x - px, dy = r.y - py;
@@ -952,37 +958,39 @@ __global__ __launch_bounds__(64) void raster_bwd_geom(int width, int height, int
         g3 = geom_wave_sum(g3); g4 = geom_wave_sum(g4); g5 = geom_wave_sum(g5);
         if (lane < 8) {
             const float v = lane == 0 ? g0 : lane == 1 ? g1 : lane == 2 ? g2 : lane == 3 ? g3 : lane == 4 ? g4 : lane == 5 ? g5 : 0.f;
-            grow[(size_t)slot * 8 + lane] = v;
+            grow[(size_t)row * 8 + lane] = v;
         }
-        if (lane == 0) { key[slot] = (uint32_t)g; idx[slot] = slot; }
+        if (lane == 0) { key[row] = (uint32_t)g; idx[row] = row; }
     }
 }
 
 struct GeomLayout {
     int64_t S, bgdot, grow, key, idx, key_s, idx_s, seg, sort, total;
 };
-inline GeomLayout geom_layout(int64_t n_isects, int width, int height, int n_gauss)
+// n_rows < 0: one row per slot of the sparse slot space; else the compact row count (sum of blk_rows)
+inline GeomLayout geom_layout(int64_t n_isects, int width, int height, int n_gauss, int64_t n_rows)
 {
     const int64_t tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
     const int64_t slots = GAGS_BLOCKS_PER_TILE * (n_isects + tile_w * tile_h) + 64;
+    const int64_t rows = n_rows < 0 ? slots : (n_rows > 0 ? n_rows : 1);
     GeomLayout L;
     int64_t o = 0;
     L.S = o; o += al256(slots * 256);
     L.bgdot = o; o += al256((int64_t)width * height * 4);
-    L.grow = o; o += al256(slots * 32);
-    L.key = o; o += al256(slots * 4);
-    L.idx = o; o += al256(slots * 4);
-    L.key_s = o; o += al256(slots * 4);
-    L.idx_s = o; o += al256(slots * 4);
+    L.grow = o; o += al256(rows * 32);
+    L.key = o; o += al256(rows * 4);
+    L.idx = o; o += al256(rows * 4);
+    L.key_s = o; o += al256(rows * 4);
+    L.idx_s = o; o += al256(rows * 4);
     L.seg = o; o += al256(((int64_t)n_gauss + 2) * 4);
-    L.sort = o; o += al256(gags_sort_u32_scratch_bytes(slots));
+    L.sort = o; o += al256(gags_sort_u32_scratch_bytes(rows));
     L.total = o;
     return L;
 }
 
-int64_t gags_raster_bwd_geom_scratch_bytes_impl(int64_t n_isects, int width, int height, int n_gauss)
+int64_t gags_raster_bwd_geom_scratch_bytes_impl(int64_t n_isects, int width, int height, int n_gauss, int64_t n_rows)
 {
-    return geom_layout(n_isects, width, height, n_gauss).total;
+    return geom_layout(n_isects, width, height, n_gauss, n_rows).total;
 }
 
 // 1 = width not eligible (d % 8 != 0 or d < 32)
@@ -990,21 +998,22 @@ int gags_raster_bwd_geom_launch(int d, int n_gauss, int width, int height, const
                                 const int32_t *offsets, int n_isects, const void *packed, const float *v_out,
                                 const float *v_alphas, const int32_t *blk_rows, const float *wt, const int32_t *gid_s,
                                 const int32_t *sidx_s, const float *Tbuf, void *scratch, int64_t scratch_bytes, float *v_geo,
-                                int by_gauss, hipStream_t st)
+                                int by_gauss, const int32_t *row_base, int64_t n_rows, hipStream_t st)
 {
     GAGS_CLEAR_ERR();
     if (d < 32 || d % 8 != 0) return 1;
-    const GeomLayout L = geom_layout(n_isects, width, height, n_gauss);
+    if (!row_base) n_rows = -1;
+    const GeomLayout L = geom_layout(n_isects, width, height, n_gauss, n_rows);
     if (scratch_bytes < L.total) return GAGS_ESCRATCH;
     const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
     const int n_tiles = tile_w * tile_h;
-    const int64_t slots = GAGS_BLOCKS_PER_TILE * ((int64_t)n_isects + n_tiles) + 64;
+    const int64_t slots = n_rows < 0 ? GAGS_BLOCKS_PER_TILE * ((int64_t)n_isects + n_tiles) + 64 : n_rows;  // rows to sort
     char *sb = (char *)scratch;
     float *S = (float *)(sb + L.S), *bgdot = backgrounds ? (float *)(sb + L.bgdot) : nullptr, *grow = (float *)(sb + L.grow);
     uint32_t *key = (uint32_t *)(sb + L.key), *key_s = (uint32_t *)(sb + L.key_s);
     int32_t *idx = (int32_t *)(sb + L.idx), *idx_s = (int32_t *)(sb + L.idx_s), *seg = (int32_t *)(sb + L.seg);
-    // unused slots of the sparse slot space sort behind every Gaussian
-    if (hipMemsetD32Async((hipDeviceptr_t)key, n_gauss, (size_t)slots, st) != hipSuccess) return GAGS_ELAUNCH;
+    // unused slots of the sparse slot space sort behind every Gaussian (the compact numbering has none)
+    if (n_rows < 0 && hipMemsetD32Async((hipDeviceptr_t)key, n_gauss, (size_t)slots, st) != hipSuccess) return GAGS_ELAUNCH;
     static bool attr_set = false;
     const int lds_max = 64 * (SD_MAXCH + SD_PAD) * 4;
     if (!attr_set) {
@@ -1026,13 +1035,17 @@ int gags_raster_bwd_geom_launch(int d, int n_gauss, int width, int height, const
     }
     hipLaunchKernelGGL(raster_bwd_geom, dim3(n_tiles * GAGS_BLOCKS_PER_TILE), dim3(64), 0, st, width, height, tile_w, n_tiles,
                        n_gauss, reinterpret_cast<const GRec *>(packed), offsets, n_isects, blk_rows, wt, gid_s, sidx_s, S, Tbuf,
-                       v_alphas, bgdot, grow, key, idx, by_gauss);
+                       v_alphas, bgdot, grow, key, idx, by_gauss, row_base);
     GAGS_CHECK_LAUNCH();
     int nbits = 1;
     while ((1ll << nbits) <= n_gauss) ++nbits;  // keys in [0, n_gauss]
-    const int rc = gags_sort_pairs_u32(slots, nbits, key, idx, key_s, idx_s, sb + L.sort, L.total - L.sort, st);
-    if (rc != GAGS_OK) return rc;
-    hipLaunchKernelGGL(seg_offsets_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, (int)slots, key_s, n_gauss, seg);
+    if (slots > 0) {
+        const int rc = gags_sort_pairs_u32(slots, nbits, key, idx, key_s, idx_s, sb + L.sort, L.total - L.sort, st);
+        if (rc != GAGS_OK) return rc;
+        hipLaunchKernelGGL(seg_offsets_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, (int)slots, key_s, n_gauss, seg);
+    } else {
+        hipLaunchKernelGGL(seg_fill_kernel, dim3((n_gauss + 1 + 255) / 256), dim3(256), 0, st, n_gauss, seg);
+    }
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((n_gauss + 127) / 128), dim3(256), 0, st, n_gauss, 8, 0, 8, seg, idx_s, grow, v_geo);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;

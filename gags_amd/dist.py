@@ -214,6 +214,9 @@ class OverlappedGradReducer:
                 ev = torch.cuda.Event()
                 ev.record()  # the range's kernels, on the compute stream
                 with torch.cuda.stream(self.comm):
+                    # the union's index list BEFORE the exchange stream is made to wait for this range: its host sync
+                    # then covers the mask all-reduce only, while the GPU still has this whole range queued
+                    self._union_rows()
                     self.comm.wait_event(ev)
                     self._exchange(grad, c0, c1)
                 grad.record_stream(self.comm)

@@ -179,14 +179,17 @@ int gags_bwd_rowmap(int64_t n_isects, int width, int height, const int32_t *isec
  * fp32 matrix cores; the per-pair chain uses the forward's own weights (T = weight / alpha: front-to-back quantities,
  * not 1 - render_alpha rebuilt back to front).  Together with gags_raster_bwd_colors_staged this replaces
  * gags_raster_bwd when geometry needs grad at wide D (gsplat's rasterize_to_pixels backward [EXT]).
- * backgrounds / v_render_alphas may be NULL.  scratch: gags_raster_bwd_geom_scratch_bytes(n_isects, w, h, n)
- * (~1.3 KB per tile intersection).  Returns 1 when D is not eligible. */
-int64_t gags_raster_bwd_geom_scratch_bytes(int64_t n_isects, int width, int height, int n);
+ * backgrounds / v_render_alphas may be NULL.  row_base (optional, [tile_h*tile_w*4] int32 = exclusive prefix sum of
+ * blk_rows) with n_rows = sum of blk_rows numbers the per-slot rows compactly, so that only n_rows keys are sorted;
+ * NULL / -1: one row per slot of the sparse slot space (no host-side count needed, ~6x more keys).
+ * scratch: gags_raster_bwd_geom_scratch_bytes(n_isects, w, h, n, n_rows) (~1.1 KB per tile intersection).
+ * Returns 1 when D is not eligible. */
+int64_t gags_raster_bwd_geom_scratch_bytes(int64_t n_isects, int width, int height, int n, int64_t n_rows);
 int gags_raster_bwd_geom(int d, int n, int width, int height, const float *colors, const float *backgrounds,
                          const int32_t *isect_offsets, int64_t n_isects, const void *packed,
                          const float *v_render_colors, const float *v_render_alphas, const int32_t *blk_rows,
                          const void *fwd_scratch, int64_t fwd_scratch_bytes, void *scratch, int64_t scratch_bytes,
-                         float *v_geo, const int32_t *flatten_ids /* needed with GAGS_RECS_BY_GAUSSIAN */, int flags,
+                         float *v_geo, const int32_t *flatten_ids, const int32_t *row_base, int64_t n_rows, int flags,
                          void *stream);
 
 /* mask[g] (n bytes, written in full) = 1 for every Gaussian that blended into at least one pixel of the view of a
