@@ -883,6 +883,71 @@ __global__ __launch_bounds__(256) void head_bwd_fast_kernel(int64_t P, int C, in
         }
 }
 
+// Pixel-major heads (layout 1): y[P][C] right next to the logits' own layout -- no transpose at all.  The [C,H,W]
+// tensor the caller sees is then a permuted view of [H,W,C] memory, like the rasterizer's own output, and what the
+// reference does with it next (compute_relvancy.py:266, evaluate_iou_loc.py:283: .permute(1,2,0)) is free.
+__global__ __launch_bounds__(256) void head_pm_kernel(int64_t P, int C, int ld, int mode, const float *__restrict__ x,
+                                                      float *__restrict__ out)
+{
+    const int tid = threadIdx.x, c0 = (tid & 7) * 4, J = ld >> 5;
+    const int64_t pr = (int64_t)blockIdx.x * HP + (tid >> 3), p = min(pr, P - 1);
+    float4 v[HJ];
+#pragma unroll
+    for (int j = 0; j < HJ; ++j)
+        v[j] = j < J ? *reinterpret_cast<const float4 *>(x + p * ld + c0 + 32 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float s0, s1;
+    head_stats(v, J, C, c0, mode, s0, s1);
+    if (pr >= P) return;
+#pragma unroll
+    for (int j = 0; j < HJ; ++j)
+        if (j < J && c0 + 32 * j < C) {  // C % 4 == 0: the whole float4 is inside
+            const float4 e = v[j];
+            *reinterpret_cast<float4 *>(out + p * C + c0 + 32 * j) =
+                mode == 0 ? make_float4(e.x / s0, e.y / s0, e.z / s0, e.w / s0)
+                          : make_float4(expf(e.x - s0) / s1, expf(e.y - s0) / s1, expf(e.z - s0) / s1, expf(e.w - s0) / s1);
+        }
+}
+
+__global__ __launch_bounds__(256) void head_bwd_pm_kernel(int64_t P, int C, int ld, int mode, const float *__restrict__ x,
+                                                          const float *__restrict__ G, unsigned short *__restrict__ dz)
+{
+    const int tid = threadIdx.x, c0 = (tid & 7) * 4, J = ld >> 5;
+    const int64_t pr = (int64_t)blockIdx.x * HP + (tid >> 3), p = min(pr, P - 1);
+    float4 v[HJ], g[HJ];
+#pragma unroll
+    for (int j = 0; j < HJ; ++j) {
+        v[j] = j < J ? *reinterpret_cast<const float4 *>(x + p * ld + c0 + 32 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        g[j] = (j < J && c0 + 32 * j < C) ? *reinterpret_cast<const float4 *>(G + p * C + c0 + 32 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float s0, s1;
+    head_stats(v, J, C, c0, mode, s0, s1);
+    const float inv0 = 1.f / s0, inv1 = mode == 1 ? 1.f / s1 : 0.f;
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < HJ; ++j)
+        if (j < J && c0 + 32 * j < C) {
+            const float e[4] = {v[j].x, v[j].y, v[j].z, v[j].w}, gg[4] = {g[j].x, g[j].y, g[j].z, g[j].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dot = fmaf(mode == 0 ? e[k] : expf(e[k] - s0) * inv1, gg[k], dot);
+        }
+    dot += __shfl_xor(dot, 1); dot += __shfl_xor(dot, 2); dot += __shfl_xor(dot, 4);
+    if (mode == 0) dot *= inv0;
+    const float k1 = dot * inv0 * inv0;
+    if (pr >= P) return;
+#pragma unroll
+    for (int j = 0; j < HJ; ++j)
+        if (j < J) {
+            const float e[4] = {v[j].x, v[j].y, v[j].z, v[j].w}, gg[4] = {g[j].x, g[j].y, g[j].z, g[j].w};
+            float d[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                d[k] = 0.f;
+                if (c0 + 32 * j + k < C) d[k] = mode == 0 ? fmaf(gg[k], inv0, -e[k] * k1) : (expf(e[k] - s0) * inv1) * (gg[k] - dot);
+            }
+            *reinterpret_cast<uint2 *>(dz + p * ld + c0 + 32 * j) = make_uint2(pack_bf16(d[0], d[1]), pack_bf16(d[2], d[3]));
+        }
+}
+
 // bf16 [P, ld] -> fp32 [P, C] (first C columns): the input gradient in the rasterizer's [H, W, D] layout
 __global__ __launch_bounds__(256) void unpack_f32_kernel(int64_t P, int C, int ld, const unsigned short *__restrict__ x,
                                                          float *__restrict__ y)
@@ -933,11 +998,18 @@ extern "C" int gags_decoder_layer(int64_t n_pix, int n_out, int k_in, const void
     return GAGS_OK;
 }
 
-extern "C" int gags_decoder_head(int64_t n_pix, int c, int ld, int mode, const float *x, float *out, void *stream)
+extern "C" int gags_decoder_head(int64_t n_pix, int c, int ld, int mode, const float *x, float *out, int layout, void *stream)
 {
     GAGS_CLEAR_ERR();
     if (n_pix < 0 || c <= 0 || ld < c || (mode != 0 && mode != 1) || (n_pix > 0 && (!x || !out))) return GAGS_EINVAL;
+    if (layout != 0 && !(layout == 1 && c % 4 == 0 && ld <= 512 && ld % 32 == 0)) return GAGS_EINVAL;
     if (n_pix == 0) return GAGS_OK;
+    if (layout == 1) {
+        hipLaunchKernelGGL(head_pm_kernel, dim3((unsigned)((n_pix + HP - 1) / HP)), dim3(256), 0, (hipStream_t)stream, n_pix, c, ld, mode,
+                           x, out);
+        GAGS_CHECK_LAUNCH();
+        return GAGS_OK;
+    }
     if (ld <= 512 && ld % 32 == 0)
         hipLaunchKernelGGL(head_fast_kernel, dim3((unsigned)((n_pix + HP - 1) / HP)), dim3(256), 0, (hipStream_t)stream, n_pix, c, ld,
                            mode, x, out);
@@ -992,11 +1064,18 @@ extern "C" int gags_decoder_wgrad(int64_t n_pix, int n_out, int k_in, const void
 }
 
 extern "C" int gags_decoder_head_bwd(int64_t n_pix, int c, int ld, int mode, const float *x, const float *g, void *dz_bf16,
-                                     void *stream)
+                                     int layout, void *stream)
 {
     GAGS_CLEAR_ERR();
     if (n_pix < 0 || c <= 0 || ld < c || (mode != 0 && mode != 1) || (n_pix > 0 && (!x || !g || !dz_bf16))) return GAGS_EINVAL;
+    if (layout != 0 && !(layout == 1 && c % 4 == 0 && ld <= 512 && ld % 32 == 0)) return GAGS_EINVAL;
     if (n_pix == 0) return GAGS_OK;
+    if (layout == 1) {
+        hipLaunchKernelGGL(head_bwd_pm_kernel, dim3((unsigned)((n_pix + HP - 1) / HP)), dim3(256), 0, (hipStream_t)stream, n_pix, c, ld,
+                           mode, x, g, (unsigned short *)dz_bf16);
+        GAGS_CHECK_LAUNCH();
+        return GAGS_OK;
+    }
     if (ld <= 512 && ld % 32 == 0)
         hipLaunchKernelGGL(head_bwd_fast_kernel, dim3((unsigned)((n_pix + HP - 1) / HP)), dim3(256), 0, (hipStream_t)stream, n_pix, c,
                            ld, mode, x, g, (unsigned short *)dz_bf16);

@@ -279,6 +279,119 @@ __global__ __launch_bounds__(256) void sam_feature_kernel(int c, int H, int W, i
     }
 }
 
+// The fused distillation L1 on a PIXEL-major prediction pred[P][c] (what gags_decoder_head writes with layout 1: the
+// [C,H,W] tensor the caller sees is a permuted view of it).  Nothing is transposed: thread = (pixel, 4 channels), a
+// pixel's 2 KB row is read as consecutive float4 by consecutive lanes, the embedding rows likewise (L2-resident), the
+// taps of the tile's 32 pixels are computed once and shared through LDS.  MODE 2: forward, 3: backward.
+constexpr int TPM = 32;  // pixels per workgroup
+struct TapsLds {
+    int id[3][4];
+    float wgt[4], mask, sc[3], v;
+};
+
+__device__ __forceinline__ float pm_wave_sum(float v)
+{
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void sam_l1_pm_kernel(int c, int H, int W, int h, int w, int n_emb,
+                                                        const float *__restrict__ pred, const float *__restrict__ img_embed,
+                                                        const float *__restrict__ seg_map, const float *__restrict__ scale_map,
+                                                        const float *__restrict__ v_map, float *__restrict__ out0,
+                                                        float *__restrict__ out1)
+{
+    __shared__ TapsLds tl[TPM];
+    __shared__ float red[TPM][4];  // per pixel: |diff| sum (MODE 2) or the three v_scale sums (MODE 3)
+    const int HW = H * W;
+    const int p0 = blockIdx.x * TPM;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < TPM) {
+        const int pc = min(p0 + tid, HW - 1);
+        const Taps t = make_taps(pc, H, W, h, w, n_emb, seg_map);
+        TapsLds q;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q.id[l][k] = t.id[l][k];
+            q.sc[l] = scale_map[(size_t)l * HW + pc];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q.wgt[k] = t.wgt[k];
+        q.mask = t.mask;
+        q.v = MODE == 3 ? v_map[pc] * (1.0f / (float)c) : 0.f;
+        tl[tid] = q;
+        red[tid][0] = red[tid][1] = red[tid][2] = red[tid][3] = 0.f;
+    }
+    __syncthreads();
+    const int q4 = c >> 2;                 // float4 per pixel
+    const int total = min(TPM, HW - p0) * q4;
+    for (int i = tid; i - lane < total; i += 256) {  // (whole waves stay in the loop: the sums below are wave-wide)
+        const bool live = i < total;
+        const int ic = live ? i : total - 1;
+        const int px = ic / q4, c4 = ic - px * q4;
+        const TapsLds &t = tl[px];
+        const size_t o = ((size_t)(p0 + px) * c) + 4 * c4;
+        const float4 pv = *reinterpret_cast<const float4 *>(pred + o);
+        float f[3][4];
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            f[l][0] = f[l][1] = f[l][2] = f[l][3] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (t.wgt[k] == 0.f) continue;  // identity resize: a single tap
+                const float4 e = *reinterpret_cast<const float4 *>(img_embed + (size_t)t.id[l][k] * c + 4 * c4);
+                f[l][0] = fmaf(t.wgt[k], e.x, f[l][0]); f[l][1] = fmaf(t.wgt[k], e.y, f[l][1]);
+                f[l][2] = fmaf(t.wgt[k], e.z, f[l][2]); f[l][3] = fmaf(t.wgt[k], e.w, f[l][3]);
+            }
+        }
+        const float pe[4] = {pv.x, pv.y, pv.z, pv.w};
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, gq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float gt = (f[0][q] * t.sc[0] + f[1][q] * t.sc[1]) + f[2][q] * t.sc[2];
+            const float diff = live ? pe[q] * t.mask - gt * t.mask : 0.f;
+            if (MODE == 2) {
+                a0 += fabsf(diff);
+            } else {
+                const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+                const float g = sgn * t.v * t.mask;
+                gq[q] = g;
+                a0 = fmaf(-g, f[0][q], a0); a1 = fmaf(-g, f[1][q], a1); a2 = fmaf(-g, f[2][q], a2);
+            }
+        }
+        if (MODE == 3 && live) *reinterpret_cast<float4 *>(out0 + o) = make_float4(gq[0], gq[1], gq[2], gq[3]);
+        // a wave covers 64 consecutive float4 of ONE pixel when c >= 256 (q4 % 64 == 0); otherwise lanes add themselves
+        if ((q4 & 63) == 0) {
+            a0 = pm_wave_sum(a0);
+            if (MODE == 3) { a1 = pm_wave_sum(a1); a2 = pm_wave_sum(a2); }
+            if (lane == 0) {
+                atomicAdd(&red[px][0], a0);
+                if (MODE == 3) { atomicAdd(&red[px][1], a1); atomicAdd(&red[px][2], a2); }
+            }
+        } else if (live) {
+            atomicAdd(&red[px][0], a0);
+            if (MODE == 3) { atomicAdd(&red[px][1], a1); atomicAdd(&red[px][2], a2); }
+        }
+    }
+    __syncthreads();
+    if (tid < TPM && p0 + tid < HW) {
+        if (MODE == 2) {
+            out0[p0 + tid] = red[tid][0] / (float)c;
+            out1[p0 + tid] = tl[tid].mask;
+        } else {
+#pragma unroll
+            for (int l = 0; l < 3; ++l) out1[(size_t)l * HW + p0 + tid] = red[tid][l];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // LERF relevancy (eval/openclip_encoder.py:42-56): one wave per pixel embedding, phrases in LDS.
 constexpr int REL_MAX_PHRASES = 32;
@@ -423,11 +536,19 @@ extern "C" int gags_sam_clip_feature_bwd_scale(int c, int H, int W, int h, int w
 }
 
 extern "C" int gags_distill_l1_map_fwd(int c, int H, int W, int h, int w, int n_emb, const float *pred, const float *img_embed,
-                                       const float *seg_map, const float *scale_map, float *l1_map, float *mask, void *stream)
+                                       const float *seg_map, const float *scale_map, float *l1_map, float *mask, int layout,
+                                       void *stream)
 {
     GAGS_CLEAR_ERR();
-    if (!sam_args_ok(c, H, W, h, w, n_emb) || !pred || !img_embed || !seg_map || !scale_map || !l1_map || !mask)
+    if (!sam_args_ok(c, H, W, h, w, n_emb) || !pred || !img_embed || !seg_map || !scale_map || !l1_map || !mask ||
+        (layout != 0 && layout != 1))
         return GAGS_EINVAL;
+    if (layout == 1) {  // pred is [H, W, c]
+        hipLaunchKernelGGL(sam_l1_pm_kernel<2>, dim3((H * W + TPM - 1) / TPM), dim3(256), 0, (hipStream_t)stream, c, H, W, h, w,
+                           n_emb, pred, img_embed, seg_map, scale_map, (const float *)nullptr, l1_map, mask);
+        GAGS_CHECK_LAUNCH();
+        return GAGS_OK;
+    }
     hipLaunchKernelGGL(sam_feature_kernel<2>, dim3((H * W + TP - 1) / TP), dim3(256), 0, (hipStream_t)stream, c, H, W, h, w,
                        n_emb, pred, img_embed, seg_map, scale_map, (const float *)nullptr, l1_map, mask);
     GAGS_CHECK_LAUNCH();
@@ -436,11 +557,18 @@ extern "C" int gags_distill_l1_map_fwd(int c, int H, int W, int h, int w, int n_
 
 extern "C" int gags_distill_l1_map_bwd(int c, int H, int W, int h, int w, int n_emb, const float *pred, const float *img_embed,
                                        const float *seg_map, const float *scale_map, const float *v_map, float *v_pred,
-                                       float *v_scale, void *stream)
+                                       float *v_scale, int layout, void *stream)
 {
     GAGS_CLEAR_ERR();
-    if (!sam_args_ok(c, H, W, h, w, n_emb) || !pred || !img_embed || !seg_map || !scale_map || !v_map || !v_pred || !v_scale)
+    if (!sam_args_ok(c, H, W, h, w, n_emb) || !pred || !img_embed || !seg_map || !scale_map || !v_map || !v_pred || !v_scale ||
+        (layout != 0 && layout != 1))
         return GAGS_EINVAL;
+    if (layout == 1) {  // pred and v_pred are [H, W, c]
+        hipLaunchKernelGGL(sam_l1_pm_kernel<3>, dim3((H * W + TPM - 1) / TPM), dim3(256), 0, (hipStream_t)stream, c, H, W, h, w,
+                           n_emb, pred, img_embed, seg_map, scale_map, v_map, v_pred, v_scale);
+        GAGS_CHECK_LAUNCH();
+        return GAGS_OK;
+    }
     hipLaunchKernelGGL(sam_feature_kernel<3>, dim3((H * W + TP - 1) / TP), dim3(256), 0, (hipStream_t)stream, c, H, W, h, w,
                        n_emb, pred, img_embed, seg_map, scale_map, v_map, v_pred, v_scale);
     GAGS_CHECK_LAUNCH();

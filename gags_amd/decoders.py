@@ -108,9 +108,15 @@ class _DecoderFn(torch.autograd.Function):
                 if not last:
                     acts.append(a)
             logits = a
-        out = torch.empty(c_out, h, w, device=x.device)
-        check(_lib.load().gags_decoder_head(p, c_out, logits.shape[1], 0 if kind == "decoder" else 1, ptr(logits), ptr(out), _st()),
-              "gags_decoder_head")
+        # CNN_decoder's [C,H,W] output is a permuted view of PIXEL-major memory (like render()'s own output): the head
+        # writes rows, the losses read rows, the reference's next step (.permute(1,2,0)) is free.  The 3-channel scale
+        # map stays channel-major (its consumers index it by plane).
+        pm = kind == "decoder" and c_out % 4 == 0 and logits.shape[1] <= 512
+        out = torch.empty((h, w, c_out) if pm else (c_out, h, w), device=x.device)
+        check(_lib.load().gags_decoder_head(p, c_out, logits.shape[1], 0 if kind == "decoder" else 1, ptr(logits), ptr(out),
+                                            1 if pm else 0, _st()), "gags_decoder_head")
+        if pm:
+            out = out.permute(2, 0, 1)
         ctx.kind, ctx.c_out, ctx.hw, ctx.c_in = kind, c_out, (h, w), xp.shape[1]
         ctx.wb = wb
         ctx.shapes = [tuple(t.shape) for t in weights]
@@ -123,10 +129,13 @@ class _DecoderFn(torch.autograd.Function):
         wb, (h, w), kind = ctx.wb, ctx.hw, ctx.kind
         p = h * w
         lib = _lib.load()
-        g = g if (g.is_contiguous() and g.dtype == torch.float32) else g.contiguous().float()
+        gp = g.permute(1, 2, 0)
+        pm = (g.dtype == torch.float32 and gp.is_contiguous() and not g.is_contiguous() and ctx.c_out % 4 == 0
+              and logits.shape[1] <= 512)  # the cotangent came back in the output's own pixel-major layout
+        g = gp if pm else (g if (g.is_contiguous() and g.dtype == torch.float32) else g.contiguous().float())
         dz = torch.empty(p, logits.shape[1], dtype=torch.bfloat16, device=g.device)
         check(lib.gags_decoder_head_bwd(p, ctx.c_out, logits.shape[1], 0 if kind == "decoder" else 1, ptr(logits), ptr(g), ptr(dz),
-                                        _st()), "gags_decoder_head_bwd")
+                                        1 if pm else 0, _st()), "gags_decoder_head_bwd")
         wt = [wgt.t().contiguous() for wgt, _ in wb]  # [K_pad, N_pad]: the input-gradient GEMM contracts over N
         dws = [None] * len(wb)
 

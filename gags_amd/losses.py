@@ -186,19 +186,29 @@ def read_sam_clip_feature(img_embed, seg_map, scale_map, max_mode=False, median_
     return feat, (mask != 0)[None]
 
 
+def _pixel_major(t):
+    """True when the [C,H,W] tensor is a permuted view of contiguous [H,W,C] fp32 memory (the decoder's and the
+    rasterizer's output layout)."""
+    return (t.is_cuda and t.dtype == torch.float32 and t.dim() == 3 and not t.is_contiguous()
+            and t.permute(1, 2, 0).is_contiguous())
+
+
 class _DistillL1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, img_embed, seg_map, scale_map):
-        p, e, seg, sc = _f(pred), _f(img_embed), _f(seg_map), _f(scale_map)
+        e, seg, sc = _f(img_embed), _f(seg_map), _f(scale_map)
         c, (_, h, w), (_, H, W) = e.shape[1], seg.shape, sc.shape
-        if p.shape != (c, H, W):
-            raise ValueError(f"pred {tuple(p.shape)} vs embeddings of width {c} and a {H}x{W} scale map")
+        if tuple(pred.shape) != (c, H, W):
+            raise ValueError(f"pred {tuple(pred.shape)} vs embeddings of width {c} and a {H}x{W} scale map")
+        pm = _pixel_major(pred) and c % 4 == 0
+        p = pred if pm else _f(pred)  # pixel-major memory is consumed as it is (layout 1): rows in, rows out
         l1 = torch.empty(H, W, device=p.device)
         mask = torch.empty(H, W, device=p.device)
         check(_lib.load().gags_distill_l1_map_fwd(c, H, W, h, w, e.shape[0], ptr(p), ptr(e), ptr(seg), ptr(sc), ptr(l1),
-                                                  ptr(mask), _st()), "gags_distill_l1_map_fwd")
+                                                  ptr(mask), 1 if pm else 0, _st()), "gags_distill_l1_map_fwd")
         ctx.save_for_backward(p, e, seg, sc)
         ctx.dims = (c, H, W, h, w)
+        ctx.pm = pm
         ctx.mark_non_differentiable(mask)
         return l1, mask
 
@@ -206,10 +216,11 @@ class _DistillL1(torch.autograd.Function):
     def backward(ctx, v_map, _v_mask):
         p, e, seg, sc = ctx.saved_tensors
         c, H, W, h, w = ctx.dims
-        vp = torch.empty_like(p)
+        # the gradient in the prediction's own layout: [H,W,c] memory behind a [c,H,W] view when it is pixel-major
+        vp = torch.empty(H, W, c, device=p.device).permute(2, 0, 1) if ctx.pm else torch.empty_like(p)
         vs = torch.empty(3, H, W, device=p.device)
         check(_lib.load().gags_distill_l1_map_bwd(c, H, W, h, w, e.shape[0], ptr(p), ptr(e), ptr(seg), ptr(sc), ptr(_f(v_map)),
-                                                  ptr(vp), ptr(vs), _st()), "gags_distill_l1_map_bwd")
+                                                  ptr(vp), ptr(vs), 1 if ctx.pm else 0, _st()), "gags_distill_l1_map_bwd")
         return vp, None, None, vs
 
 

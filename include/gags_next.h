@@ -53,11 +53,14 @@ int gags_sam_clip_feature_bwd_scale(int c, int H, int W, int h, int w, int n_emb
 /* train.py:165-166 fused: l1_map[H, W] = mean_c |pred * mask - gt * mask| with gt, mask = read_sam_clip_feature(...)
  * WITHOUT materialising the [c, H, W] ground truth (4.25 GB at 1080p x 512) or the two masked copies.
  * Backward for a cotangent v_map[H, W]: v_pred[c, H, W] and v_scale[3, H, W]. */
+/* layout: 0 = pred (and v_pred) are [c, H, W]; 1 = they are [H, W, c] (the memory behind the decoder's output when
+ * gags_decoder_head wrote it pixel-major): nothing is transposed, every access is a row. */
 int gags_distill_l1_map_fwd(int c, int H, int W, int h, int w, int n_emb, const float *pred, const float *img_embed,
-                            const float *seg_map, const float *scale_map, float *l1_map, float *mask, void *stream);
+                            const float *seg_map, const float *scale_map, float *l1_map, float *mask, int layout,
+                            void *stream);
 int gags_distill_l1_map_bwd(int c, int H, int W, int h, int w, int n_emb, const float *pred, const float *img_embed,
                             const float *seg_map, const float *scale_map, const float *v_map, float *v_pred,
-                            float *v_scale, void *stream);
+                            float *v_scale, int layout, void *stream);
 
 /* ---- N1: the per-pixel decoders (models/networks.py:109-248: stacks of 1x1 convolutions) ---------------------- */
 
@@ -82,19 +85,21 @@ int gags_decoder_layer(int64_t n_pix, int n_out, int k_in, const void *a1, const
 int gags_decoder_wgrad(int64_t n_pix, int n_out, int k_in, const void *dz, const void *a1, const void *a2, float *d_w,
                        float *d_b, void *stream);
 
-/* Backward of gags_decoder_head: channel-major cotangent g[c, n_pix] + the saved logits x[n_pix, ld] ->
+/* Backward of gags_decoder_head: cotangent g (layout 0: [c, n_pix], 1: [n_pix, c]) + the saved logits x[n_pix, ld] ->
  * pixel-major bf16 dz[n_pix, ld]. */
 int gags_decoder_head_bwd(int64_t n_pix, int c, int ld, int mode, const float *x, const float *g, void *dz_bf16,
-                          void *stream);
+                          int layout, void *stream);
 
 /* bf16 x[n_pix, ld] -> fp32 y[n_pix, c] (first c columns): the decoder's input gradient in the rasterizer's own
  * [H, W, D] layout. */
 int gags_decoder_unpack_grad(int64_t n_pix, int c, int ld, const void *x_bf16, float *y, void *stream);
 
-/* Output head: pixel-major fp32 logits x[n_pix, ld] (first c columns) -> CHANNEL-major out[c, n_pix] (the
- * reference's [C, H, W]); mode 0 = F.normalize(dim=0) (CNN_decoder, :192), mode 1 = softmax over channels
- * (CNN_scale_decoder, :242). */
-int gags_decoder_head(int64_t n_pix, int c, int ld, int mode, const float *x, float *out, void *stream);
+/* Output head: pixel-major fp32 logits x[n_pix, ld] (first c columns) -> out; mode 0 = F.normalize(dim=0)
+ * (CNN_decoder, :192), mode 1 = softmax over channels (CNN_scale_decoder, :242).
+ * layout 0: CHANNEL-major out[c, n_pix] (the reference's contiguous [C, H, W]); layout 1 (c % 4 == 0, ld <= 512,
+ * ld % 32 == 0): PIXEL-major out[n_pix, c] -- the caller views it as [C, H, W] through a permute, exactly like the
+ * rasterizer's output, and nothing is transposed on the way in or out. */
+int gags_decoder_head(int64_t n_pix, int c, int ld, int mode, const float *x, float *out, int layout, void *stream);
 
 /* ---- N4: query-time relevancy (eval/openclip_encoder.py:42-56, 96-111) ---------------------------------------- */
 

@@ -165,11 +165,13 @@ def test_decoder_backward_kernels_against_fp32_on_the_same_masks():
     assert max(errs.values()) <= 1.5e-2, errs
 
 
-@pytest.mark.parametrize("c,ld", [(512, 512), (3, 32), (100, 128), (37, 40), (520, 544)])
+@pytest.mark.parametrize("c,ld,layout", [(512, 512, 0), (3, 32, 0), (100, 128, 0), (37, 40, 0), (520, 544, 0),
+                                         (512, 512, 1), (100, 128, 1), (16, 32, 1)])
 @pytest.mark.parametrize("mode", [0, 1])
-def test_head_kernels_against_torch(c, ld, mode):
+def test_head_kernels_against_torch(c, ld, layout, mode):
     """gags_decoder_head / _head_bwd alone (models/networks.py:192 normalize, :242 softmax) in fp32 against torch, on
-    both kernels behind the entry: the 32-pixel register-resident one (ld <= 512, ld % 32 == 0) and the general one."""
+    the kernels behind the entry: the 32-pixel register-resident one (ld <= 512, ld % 32 == 0), the general one, and
+    the pixel-major ones (layout 1: output and cotangent as [P, C] rows, nothing transposed)."""
     from gags_amd import _lib
     from gags_amd.decoders import _st
     from gags_amd._lib import check, ptr
@@ -179,10 +181,13 @@ def test_head_kernels_against_torch(c, ld, mode):
     x = torch.zeros(p, ld, device="cuda")
     x[:, :c] = torch.randn(p, c, device="cuda", generator=g) * 2
     G = torch.randn(c, p, device="cuda", generator=g)
-    out = torch.empty(c, p, device="cuda")
+    out = torch.empty((p, c) if layout else (c, p), device="cuda")
+    Gk = G.t().contiguous() if layout else G
     dz = torch.full((p, ld), 7.0, device="cuda", dtype=torch.bfloat16)
-    check(lib.gags_decoder_head(p, c, ld, mode, ptr(x), ptr(out), _st()), "head")
-    check(lib.gags_decoder_head_bwd(p, c, ld, mode, ptr(x), ptr(G), ptr(dz), _st()), "head_bwd")
+    check(lib.gags_decoder_head(p, c, ld, mode, ptr(x), ptr(out), layout, _st()), "head")
+    check(lib.gags_decoder_head_bwd(p, c, ld, mode, ptr(x), ptr(Gk), ptr(dz), layout, _st()), "head_bwd")
+    if layout:
+        out = out.t()
     xr = x[:, :c].clone().double().requires_grad_(True)
     ref = torch.nn.functional.normalize(xr, dim=1) if mode == 0 else torch.softmax(xr, dim=1)
     (ref * G.t().double()).sum().backward()
@@ -210,3 +215,34 @@ def test_weight_gradient_kernels_against_torch(n, k, two):
     ref_b = dz.double().sum(0)
     assert ((dw.double() - ref_w).norm() / ref_w.norm()).item() <= 2e-6
     assert ((db.double() - ref_b).norm() / ref_b.norm()).item() <= 2e-6
+
+
+def test_decoder_output_is_pixel_major_and_its_gradient_flows_without_transposes():
+    """CNN_decoder returns [C,H,W] as a permuted view of [H,W,C] memory (like render()); the fused distillation loss
+    consumes that memory directly and hands its gradient back in the same layout.  Values and gradients equal those of
+    the channel-major (contiguous) route."""
+    from gags_amd import losses as L
+    from gags_amd.decoders import CNN_decoder
+    from make_golden_next import decoder_weights
+    wd, _ = decoder_weights(0)
+    dec = _load(CNN_decoder(16, 512), wd)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    H, W, n_emb = 96, 130, 40
+    x = torch.randn(H, W, 16, device="cuda", generator=g).permute(2, 0, 1)
+    emb = torch.nn.functional.normalize(torch.randn(n_emb, 512, device="cuda", generator=g), dim=-1)
+    seg = torch.randint(-1, n_emb, (4, H, W), device="cuda", generator=g).float()
+    scale = torch.softmax(torch.randn(3, H, W, device="cuda", generator=g), 0)
+    res = []
+    for contiguous in (False, True):
+        xi = x.clone().requires_grad_(True)
+        dec.zero_grad(set_to_none=True)
+        y = dec(xi)
+        assert y.shape == (512, H, W) and not y.is_contiguous() and y.permute(1, 2, 0).is_contiguous()
+        yy = y.contiguous() if contiguous else y
+        l1, mask = L.distill_l1_map(yy, emb, seg, scale)
+        (l1 * torch.linspace(0.5, 1.5, H * W, device="cuda").reshape(H, W)).sum().backward()
+        res.append((l1.detach().clone(), xi.grad.clone(), dec.convs()[-1].weight.grad.clone()))
+    (l1_a, gx_a, gw_a), (l1_b, gx_b, gw_b) = res
+    assert ((l1_a - l1_b).double().norm() / l1_b.double().norm()).item() <= 1e-6
+    assert ((gx_a - gx_b).double().norm() / gx_b.double().norm()).item() <= 2e-2   # bf16 layers behind a different summation order
+    assert ((gw_a - gw_b).double().norm() / gw_b.double().norm()).item() <= 2e-2
