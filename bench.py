@@ -469,6 +469,30 @@ def main():
                         "v_mfma_f32_32x32x16_f16 with weights and cotangent split into fp16 head + tail (~2^-21 of a column's "
                         "largest term; measured 1.8e-7 rel-L2 from float64, the fp32-MFMA backward 1.9e-7)",
                 "value": fsteps / fdt, "unit": "views/s", "ms_per_step": 1e3 * fdt / fsteps, "steps": fsteps}
+        if world == 1 and not (args.no_heavy or args.raster_flags):
+            # north_star's "feature / geometry gradients": the same workload with EVERY parameter requiring grad (joint
+            # training; the reference's GAD stage freezes the geometry).  Reported next to `value`, never as `value`.
+            geo = [pc._xyz, pc._scaling, pc._rotation, pc._opacity]
+            for q in geo:
+                q.requires_grad_(True)
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            gsteps = max(3, min(args.steps, 10))
+            t0 = time.perf_counter()
+            for _ in range(gsteps):
+                for q in geo:
+                    q.grad = None
+                step()
+            torch.cuda.synchronize()
+            gdt = time.perf_counter() - t0
+            for q in geo:
+                q.requires_grad_(False)
+                q.grad = None
+            line["all_gradients"] = {
+                "note": "same workload, gradients of features AND means, quats, scales, opacities (SURVEY A9 + K2): geometry "
+                        "dot products on the fp32 matrix cores (gags_raster_bwd_geom), no atomics",
+                "value": gsteps / gdt, "unit": "views/s", "ms_per_step": 1e3 * gdt / gsteps, "steps": gsteps}
         if world == 1 and args.config == "C3" and not (args.no_heavy or args.n or args.d):
             # second reading of SURVEY 8d (gags_amd/synthetic.py): same N / resolution / D, ~4.4x larger splats
             del step, pc
