@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box call that refreshes everything under profiles/ for a round:
-#   kernel-trace stats, PMC passes, the bench line (with the CPU baseline), the chunk statistics of the rows kernel, the D=16 iteration and the
-#   micro-benchmarks.  Usage (from the repo root, on the GPU box): tools/profile_round.sh r01
+#   kernel-trace stats, PMC passes, the bench line (with the CPU baseline), the chunk statistics of the rows kernel, the D=16 iteration (+ its
+#   kernel stats), the decoder GEMMs alone, the config sweep, the union-of-rows statistics and the micro-benchmarks.  Usage (from the repo root, on the GPU box): tools/profile_round.sh r01
 set -u
 TAG=${1:-r01}
 R=$(cd "$(dirname "$0")/.." && pwd)
@@ -20,5 +20,12 @@ cd "$R"
 timeout 900 python bench.py --steps 20 --warmup 3 > "$O/${TAG}_c3_bench.json" 2> "$O/bench.err"
 timeout 300 python tools/chunk_stats.py C3 > "$O/${TAG}_c3_chunk_stats.txt" 2>&1
 timeout 300 python tools/decoder_bench.py > "$O/${TAG}_d16_iteration.json" 2>/dev/null
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$O/d16stats" -o d16 --output-format csv -- \
+    python "$R/tools/decoder_bench.py" > /dev/null 2>&1 )
+S=$(find "$O/d16stats" -name '*kernel_stats.csv' | head -1)
+[ -n "$S" ] && python "$R/tools/trim_stats.py" "$S" "$O/${TAG}_d16_iteration_kernel_stats.csv" 40
+timeout 300 python tools/gemm_bench.py > "$O/${TAG}_decoder_gemm.json" 2>/dev/null
+timeout 900 python tools/config_sweep.py > "$O/${TAG}_config_sweep.json" 2>/dev/null
+timeout 300 python tools/union_rows.py C3 > "$O/${TAG}_union_rows.json" 2>/dev/null
 tools/micro/run_all.sh > "$O/${TAG}_micro.txt" 2>&1
 tail -1 "$O/${TAG}_c3_bench.json" | cut -c1-600
