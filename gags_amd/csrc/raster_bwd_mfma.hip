@@ -14,6 +14,7 @@
 //   reduce  v_colors[g] = sum of its rows, written once (no zero-fill of v_colors needed).
 // The single-kernel atomic variant (recomputes alpha itself; needs neither scratch nor the forward's
 // slot counts) is kept as the fallback.
+#include <hip/hip_fp16.h>
 #include "raster_mfma_common.h"
 
 using namespace gags_mfma;
@@ -482,11 +483,14 @@ __global__ void seg_fill_kernel(int n_keys, int32_t *__restrict__ seg)
     if (g <= n_keys) seg[g] = 0;
 }
 
-// v_colors[g, :] = sum over the Gaussian's rows, in sorted (= deterministic) order; float4 per lane
+// v_colors[g, :] = sum over the Gaussian's rows, in sorted (= deterministic) order; float4 per lane.
+// HALF: the sum (formed in fp32) is stored as fp16 -- the gradient of an fp16 feature table in the table's own dtype,
+// instead of an fp32 tensor plus a cast pass over it (N x D x 6 bytes of traffic at C5).
+template <bool HALF>
 __global__ __launch_bounds__(256) void reduce_rows_kernel(int n_gauss, int d, int ch_begin, int ch_count,
                                                           const int32_t *__restrict__ seg,
                                                           const int32_t *__restrict__ sorted_rows,
-                                                          const float *__restrict__ prow, float *__restrict__ v_colors)
+                                                          const float *__restrict__ prow, void *__restrict__ v_colors_)
 {
     const int lpg = ch_count >> 2;  // lanes per Gaussian (channels ch_begin .. ch_begin + ch_count - 1 of its row)
     const int gpb = 256 / lpg;
@@ -512,7 +516,15 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(int n_gauss, int d, in
         const float4 v0 = *reinterpret_cast<const float4 *>(prow + (size_t)sorted_rows[i] * d + cl);
         acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
     }
-    *reinterpret_cast<float4 *>(v_colors + (size_t)g * d + cl) = acc;
+    if constexpr (HALF) {
+        const __half2 lo = __floats2half2_rn(acc.x, acc.y), hi = __floats2half2_rn(acc.z, acc.w);
+        uint2 w;
+        w.x = *reinterpret_cast<const unsigned *>(&lo);
+        w.y = *reinterpret_cast<const unsigned *>(&hi);
+        *reinterpret_cast<uint2 *>(reinterpret_cast<__half *>(v_colors_) + (size_t)g * d + cl) = w;
+    } else {
+        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(v_colors_) + (size_t)g * d + cl) = acc;
+    }
 }
 
 // ---- fallback: single kernel, float atomics ------------------------------------------------------------
@@ -710,8 +722,12 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
     }
     if (sR) {
         const int gpb = 256 / (ch_count >> 2);
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3((n_gauss + gpb - 1) / gpb), dim3(256), 0, st, n_gauss, d, ch_begin,
-                           ch_count, seg, idx_s, prow, v_colors);
+        if (stage_flags & 64)  // v_colors is an fp16 tensor
+            hipLaunchKernelGGL(reduce_rows_kernel<true>, dim3((n_gauss + gpb - 1) / gpb), dim3(256), 0, st, n_gauss, d, ch_begin,
+                               ch_count, seg, idx_s, prow, (void *)v_colors);
+        else
+            hipLaunchKernelGGL(reduce_rows_kernel<false>, dim3((n_gauss + gpb - 1) / gpb), dim3(256), 0, st, n_gauss, d, ch_begin,
+                               ch_count, seg, idx_s, prow, (void *)v_colors);
     }
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
@@ -1046,7 +1062,8 @@ int gags_raster_bwd_geom_launch(int d, int n_gauss, int width, int height, const
     } else {
         hipLaunchKernelGGL(seg_fill_kernel, dim3((n_gauss + 1 + 255) / 256), dim3(256), 0, st, n_gauss, seg);
     }
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((n_gauss + 127) / 128), dim3(256), 0, st, n_gauss, 8, 0, 8, seg, idx_s, grow, v_geo);
+    hipLaunchKernelGGL(reduce_rows_kernel<false>, dim3((n_gauss + 127) / 128), dim3(256), 0, st, n_gauss, 8, 0, 8, seg, idx_s, grow,
+                       (void *)v_geo);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }

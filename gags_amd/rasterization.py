@@ -262,10 +262,11 @@ class _Rasterize(torch.autograd.Function):
         if backgrounds is not None and ctx.needs_input_grad[4]:
             v_bg = ((1.0 - alphas)[..., None] * v_out).sum(dim=(0, 1))
         if not need_geom and blk_rows is not None:
+            # an fp16 table gets its gradient in fp16 straight from the reduce kernel (fp32 sums, rounded once): no fp32
+            # tensor + cast pass (autograd wants the table's dtype; an fp32 master sits behind a .half() cast)
             v_colors = _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height,
-                                        32 if (flags & _lib.GAGS_BWD_F16SPLIT) else 0, flatten_ids)
-            if ctx.half:
-                v_colors = v_colors.half()  # autograd wants the table's dtype; an fp32 master sits behind a .half() cast
+                                        (32 if (flags & _lib.GAGS_BWD_F16SPLIT) else 0) | (64 if ctx.half else 0),
+                                        flatten_ids)
             return None, None, v_colors, None, v_bg, None, None, None, None, None, None
         if need_geom and blk_rows is not None and ctx.geom_mfma:
             # wide D: colours through the staged backward, geometry through the matrix-core dot pass + scalar pass
@@ -338,7 +339,7 @@ def _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d,
     rows = int(host.value)
     nbytes = lib.gags_bwd_staged_scratch_bytes(rows, n, d)
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    v_colors = torch.empty(n, d, device=dev)
+    v_colors = torch.empty(n, d, device=dev, dtype=torch.float16 if (xflag & 64) else torch.float32)
 
     def run(stage):
         stage |= xflag

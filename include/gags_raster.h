@@ -166,7 +166,9 @@ int gags_raster_bwd(int d, int width, int height, const float *means2d, const fl
  * (no zero-fill needed).  scratch: gags_bwd_staged_scratch_bytes(rows, n, d) bytes.
  * stage: low 4 bits 0 = all, 1..3 = rows, sort, reduce (per-kernel timing); bit 5 (32), D % 128 == 0 only, opt-in: the
  * rows' contraction runs on the 16-bit matrix cores with both operands split into an fp16 head and tail (~2^-21
- * relative to a column's largest term instead of fp32 rounding; still atomic-free and bit-reproducible).
+ * relative to a column's largest term instead of fp32 rounding; still atomic-free and bit-reproducible);
+ * bit 6 (64): v_colors points to an fp16 [N,D] tensor (the gradient of an fp16 feature table in the table's dtype;
+ * sums are formed in fp32 and rounded once).
  * Returns 1 when D is not eligible. */
 int64_t gags_bwd_rowmap_elems(int64_t n_isects, int width, int height);
 int64_t gags_bwd_rowmap_scratch_bytes(int64_t n_isects);
