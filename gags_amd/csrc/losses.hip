@@ -56,6 +56,18 @@ __global__ __launch_bounds__(256) void entropy_bwd_kernel(int64_t n, const float
 
 // ---------------------------------------------------------------------------------------------------------------
 // per-segment moments.  One wave = 64 consecutive pixels.
+// wave64 sum on the VALU (DPP: a pairwise tree, total in lane 63), returned wave-uniform
+__device__ __forceinline__ float seg_wave_sum(float v)
+{
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 __global__ __launch_bounds__(256) void segment_stats_kernel(int64_t n_pix, int c, const float *__restrict__ x,
                                                             const float *__restrict__ seg, int n_seg,
                                                             double *__restrict__ s1, double *__restrict__ s2,
@@ -68,22 +80,32 @@ __global__ __launch_bounds__(256) void segment_stats_kernel(int64_t n_pix, int c
         const float f = seg[p];
         id = (f >= 0.f && f < (float)n_seg) ? (int)f : -1;
     }
-    // one round per distinct segment id in the wave (neighbouring pixels mostly share one): the lanes of that segment
-    // are summed with a full-wave reduction of their masked values and the leader issues ONE double atomic per moment
-    unsigned long long todo = __ballot(id >= 0);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int cur = __builtin_amdgcn_readlane(id, leader);
-        const unsigned long long grp = __ballot(id == cur);
-        const bool in = id == cur;
-        if (lane == leader) atomicAdd(&cnt[cur], (int)__popcll(grp));
-        for (int ch = 0; ch < c; ++ch) {
-            const float v = in ? x[(size_t)ch * n_pix + p] : 0.f;
-            double a = v, b = (double)v * (double)v;
-            for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
-            if (lane == leader) { atomicAdd(&s1[(size_t)cur * c + ch], a); atomicAdd(&s2[(size_t)cur * c + ch], b); }
+    const int64_t pc = min(p, n_pix - 1);
+    // one round per distinct segment id in the wave (neighbouring pixels mostly share one): the wave's 64 values of a
+    // channel are summed pairwise in fp32 on the VALU (the sums over many waves are the ones that need doubles) and
+    // the leader issues ONE double atomic per moment.  Channels in groups of 16 held in registers: read once.
+    for (int cb = 0; cb < c; cb += 16) {
+        float xv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xv[j] = x[(size_t)min(cb + j, c - 1) * n_pix + pc];
+        unsigned long long todo = __ballot(id >= 0);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int cur = __builtin_amdgcn_readlane(id, leader);
+            const unsigned long long grp = __ballot(id == cur);
+            const bool in = id == cur;
+            if (cb == 0 && lane == leader) atomicAdd(&cnt[cur], (int)__popcll(grp));
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float v = in ? xv[j] : 0.f;
+                const float a = seg_wave_sum(v), b = seg_wave_sum(v * v);
+                if (lane == leader && cb + j < c) {
+                    atomicAdd(&s1[(size_t)cur * c + cb + j], (double)a);
+                    atomicAdd(&s2[(size_t)cur * c + cb + j], (double)b);
+                }
+            }
+            todo &= ~grp;
         }
-        todo &= ~grp;
     }
 }
 
