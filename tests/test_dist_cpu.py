@@ -187,13 +187,15 @@ def _union_worker(rank, world, port, q):
             rasterization.GRAD_RANGE_HOOK(grad.detach(), c0, c0 + 128)
     assert rasterization.GRAD_ROWS_HOOK is None
     used = red.finish(grad)
-    q.put((rank, used, bool(torch.equal(grad, expect)), red.rows_exchanged, union))
+    ok = torch.equal(grad, expect) if world == 2 else bool(((grad - expect).abs() <= 1e-6 * expect.abs().max()).all())
+    q.put((rank, used, bool(ok), red.rows_exchanged, union))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_overlapped_reducer_exchanges_only_the_union_of_nonzero_rows():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 3])
+def test_overlapped_reducer_exchanges_only_the_union_of_nonzero_rows(world):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_union_worker, args=(r, world, port, q)) for r in range(world)]
@@ -204,5 +206,5 @@ def test_overlapped_reducer_exchanges_only_the_union_of_nonzero_rows():
         p.join(timeout=60)
         assert p.exitcode == 0
     for _, used, exact, rows, union in res:
-        assert used and exact           # two addends per element: the sum is exact whatever the order
+        assert used and exact           # (three ranks: every rank adds the same shards in the same order)
         assert rows == union and union < 1001
