@@ -74,6 +74,8 @@ SIGNATURES = {
     "gags_sam_clip_feature_bwd_scale": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "gags_distill_l1_map_fwd": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "gags_distill_l1_map_bwd": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "gags_decoder_head_distill_fwd": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gags_decoder_head_distill_bwd": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_decoder_pack_input": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp]),
     "gags_decoder_layer": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_decoder_wgrad": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),

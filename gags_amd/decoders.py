@@ -76,38 +76,94 @@ def _pack_weights(weights, biases):
     return out
 
 
+def _chain_forward(x, kind, params):
+    """The GEMM chain of a decoder up to its fp32 logits.  Returns (logits [P, ld], activations, packed weights, h, w,
+    c_in)."""
+    weights, biases = params[0::2], params[1::2]
+    wb = _pack_weights(weights, biases)
+    xp, h, w = _pixel_major(x)
+    p = h * w
+    a0 = torch.empty(p, wb[0][0].shape[1], dtype=torch.bfloat16, device=x.device)
+    check(_lib.load().gags_decoder_pack_input(p, xp.shape[1], a0.shape[1], ptr(xp), ptr(a0), _st()), "gags_decoder_pack_input")
+    acts = [a0]
+    if kind == "decoder":
+        x1 = _layer(p, *wb[0], a0)
+        t1 = _layer(p, *wb[1], x1)
+        x2 = _layer(p, *wb[2], t1)
+        x3 = _layer(p, *wb[3], x1, x2)   # conv(x1 + x2)
+        t4 = _layer(p, *wb[4], x3)
+        x4 = _layer(p, *wb[5], t4)
+        t6 = _layer(p, *wb[6], x3, x4)   # conv(x3 + x4)
+        t7 = _layer(p, *wb[7], t6)
+        logits = _layer(p, *wb[8], t7, relu=False, f32=True)
+        acts += [x1, t1, x2, x3, t4, x4, t6, t7]
+    else:
+        a = a0
+        for i, (wt, b) in enumerate(wb):
+            last = i + 1 == len(wb)
+            a = _layer(p, wt, b, a, relu=not last, f32=last)
+            if not last:
+                acts.append(a)
+        logits = a
+    return logits, acts, wb, h, w, xp.shape[1]
+
+
+def _chain_backward(dz, acts, wb, kind, h, w, c_in, shapes):
+    """From the bf16 gradient of the logits dz [P, ld] back through the chain: (input gradient as a [C_in,H,W] view of
+    [H,W,C_in] memory, weight / bias gradients in parameter order)."""
+    p = h * w
+    wt = [wgt.t().contiguous() for wgt, _ in wb]  # [K_pad, N_pad]: the input-gradient GEMM contracts over N
+    dws = [None] * len(wb)
+
+    def wg(i, dz_i, a1, a2=None):
+        dws[i] = _wgrad(p, dz_i, a1, a2, *wb[i][0].shape)
+
+    def dx(i, dz_i, mask_src=None, residual=None, premask=False):
+        return _layer(p, wt[i], None, dz_i, relu=False, mask_src=mask_src, residual=residual, premask=premask)
+
+    if kind == "decoder":
+        a0, x1, t1, x2, x3, t4, x4, t6, t7 = acts
+        wg(8, dz, t7)
+        dz7 = dx(8, dz, mask_src=t7)
+        wg(7, dz7, t6)
+        dz6 = dx(7, dz7, mask_src=t6)
+        wg(6, dz6, x3, x4)
+        dz5, g36 = dx(6, dz6, mask_src=x4, premask=True)     # d(x3 + x4): masked for x4's ReLU, raw for the skip to x3
+        wg(5, dz5, t4)
+        dz4 = dx(5, dz5, mask_src=t4)
+        wg(4, dz4, x3)
+        dz3 = dx(4, dz4, mask_src=x3, residual=g36)           # both paths into x3, then its ReLU
+        wg(3, dz3, x1, x2)
+        dz2, g13 = dx(3, dz3, mask_src=x2, premask=True)
+        wg(2, dz2, t1)
+        dz1 = dx(2, dz2, mask_src=t1)
+        wg(1, dz1, x1)
+        dz0 = dx(1, dz1, mask_src=x1, residual=g13)
+        wg(0, dz0, a0)
+        gin = dx(0, dz0)
+    else:
+        cur = dz
+        for i in range(len(wb) - 1, -1, -1):
+            wg(i, cur, acts[i])
+            cur = dx(i, cur, mask_src=acts[i] if i > 0 else None)
+        gin = cur
+    gx = torch.empty(h, w, c_in, device=dz.device)
+    check(_lib.load().gags_decoder_unpack_grad(p, c_in, gin.shape[1], ptr(gin), ptr(gx), _st()), "gags_decoder_unpack_grad")
+    grads = []
+    for (dw, db), shp in zip(dws, shapes):
+        co, ci = shp[:2]
+        grads += [dw[:co, :ci].reshape(shp).contiguous(), db[:co].contiguous()]
+    return gx.permute(2, 0, 1), grads
+
+
 class _DecoderFn(torch.autograd.Function):
     """Forward and backward of a decoder as GEMM launches.  `kind` = "decoder" (CNN_decoder: two residual sums,
     normalize head) or "scale" (CNN_scale_decoder: plain chain, softmax head).  params = w0, b0, w1, b1, ..."""
 
     @staticmethod
     def forward(ctx, x, kind, c_out, *params):
-        weights, biases = params[0::2], params[1::2]
-        wb = _pack_weights(weights, biases)
-        xp, h, w = _pixel_major(x)
+        logits, acts, wb, h, w, c_in = _chain_forward(x, kind, params)
         p = h * w
-        a0 = torch.empty(p, wb[0][0].shape[1], dtype=torch.bfloat16, device=x.device)
-        check(_lib.load().gags_decoder_pack_input(p, xp.shape[1], a0.shape[1], ptr(xp), ptr(a0), _st()), "gags_decoder_pack_input")
-        acts = [a0]
-        if kind == "decoder":
-            x1 = _layer(p, *wb[0], a0)
-            t1 = _layer(p, *wb[1], x1)
-            x2 = _layer(p, *wb[2], t1)
-            x3 = _layer(p, *wb[3], x1, x2)   # conv(x1 + x2)
-            t4 = _layer(p, *wb[4], x3)
-            x4 = _layer(p, *wb[5], t4)
-            t6 = _layer(p, *wb[6], x3, x4)   # conv(x3 + x4)
-            t7 = _layer(p, *wb[7], t6)
-            logits = _layer(p, *wb[8], t7, relu=False, f32=True)
-            acts += [x1, t1, x2, x3, t4, x4, t6, t7]
-        else:
-            a = a0
-            for i, (wt, b) in enumerate(wb):
-                last = i + 1 == len(wb)
-                a = _layer(p, wt, b, a, relu=not last, f32=last)
-                if not last:
-                    acts.append(a)
-            logits = a
         # CNN_decoder's [C,H,W] output is a permuted view of PIXEL-major memory (like render()'s own output): the head
         # writes rows, the losses read rows, the reference's next step (.permute(1,2,0)) is free.  The 3-channel scale
         # map stays channel-major (its consumers index it by plane).
@@ -117,9 +173,9 @@ class _DecoderFn(torch.autograd.Function):
                                             1 if pm else 0, _st()), "gags_decoder_head")
         if pm:
             out = out.permute(2, 0, 1)
-        ctx.kind, ctx.c_out, ctx.hw, ctx.c_in = kind, c_out, (h, w), xp.shape[1]
+        ctx.kind, ctx.c_out, ctx.hw, ctx.c_in = kind, c_out, (h, w), c_in
         ctx.wb = wb
-        ctx.shapes = [tuple(t.shape) for t in weights]
+        ctx.shapes = [tuple(t.shape) for t in params[0::2]]
         ctx.save_for_backward(logits, *acts)
         return out
 
@@ -136,48 +192,46 @@ class _DecoderFn(torch.autograd.Function):
         dz = torch.empty(p, logits.shape[1], dtype=torch.bfloat16, device=g.device)
         check(lib.gags_decoder_head_bwd(p, ctx.c_out, logits.shape[1], 0 if kind == "decoder" else 1, ptr(logits), ptr(g), ptr(dz),
                                         1 if pm else 0, _st()), "gags_decoder_head_bwd")
-        wt = [wgt.t().contiguous() for wgt, _ in wb]  # [K_pad, N_pad]: the input-gradient GEMM contracts over N
-        dws = [None] * len(wb)
+        gx, grads = _chain_backward(dz, acts, wb, kind, h, w, ctx.c_in, ctx.shapes)
+        return (gx, None, None, *grads)
 
-        def wg(i, dz_i, a1, a2=None):
-            dws[i] = _wgrad(p, dz_i, a1, a2, *wb[i][0].shape)
 
-        def dx(i, dz_i, mask_src=None, residual=None, premask=False):
-            return _layer(p, wt[i], None, dz_i, relu=False, mask_src=mask_src, residual=residual, premask=premask)
+class _DecoderDistillFn(torch.autograd.Function):
+    """CNN_decoder + the distillation L1 of train.py:159-166 with the output head fused into the loss: the GEMM chain up
+    to the fp32 logits, then ONE kernel to l1_map / mask (gags_decoder_head_distill_fwd) and one back to the logits'
+    gradient -- the normalised [512,H,W] map and its gradient are never written or read (21 GB per iteration at 1080p)."""
 
-        if kind == "decoder":
-            a0, x1, t1, x2, x3, t4, x4, t6, t7 = acts
-            wg(8, dz, t7)
-            dz7 = dx(8, dz, mask_src=t7)
-            wg(7, dz7, t6)
-            dz6 = dx(7, dz7, mask_src=t6)
-            wg(6, dz6, x3, x4)
-            dz5, g36 = dx(6, dz6, mask_src=x4, premask=True)     # d(x3 + x4): masked for x4's ReLU, raw for the skip to x3
-            wg(5, dz5, t4)
-            dz4 = dx(5, dz5, mask_src=t4)
-            wg(4, dz4, x3)
-            dz3 = dx(4, dz4, mask_src=x3, residual=g36)           # both paths into x3, then its ReLU
-            wg(3, dz3, x1, x2)
-            dz2, g13 = dx(3, dz3, mask_src=x2, premask=True)
-            wg(2, dz2, t1)
-            dz1 = dx(2, dz2, mask_src=t1)
-            wg(1, dz1, x1)
-            dz0 = dx(1, dz1, mask_src=x1, residual=g13)
-            wg(0, dz0, a0)
-            gin = dx(0, dz0)
-        else:
-            cur = dz
-            for i in range(len(wb) - 1, -1, -1):
-                wg(i, cur, acts[i])
-                cur = dx(i, cur, mask_src=acts[i] if i > 0 else None)
-            gin = cur
-        gx = torch.empty(h, w, ctx.c_in, device=g.device)
-        check(lib.gags_decoder_unpack_grad(p, ctx.c_in, gin.shape[1], ptr(gin), ptr(gx), _st()), "gags_decoder_unpack_grad")
-        grads = []
-        for (dw, db), shp in zip(dws, ctx.shapes):
-            co, ci = shp[:2]
-            grads += [dw[:co, :ci].reshape(shp).contiguous(), db[:co].contiguous()]
-        return (gx.permute(2, 0, 1), None, None, *grads)
+    @staticmethod
+    def forward(ctx, x, img_embed, seg_map, scale_map, c_out, *params):
+        from .losses import _f
+        logits, acts, wb, h, w, c_in = _chain_forward(x, "decoder", params)
+        e, seg, sc = _f(img_embed), _f(seg_map), _f(scale_map)
+        if e.shape[1] != c_out or tuple(sc.shape) != (3, h, w) or seg.dim() != 3 or seg.shape[0] != 4:
+            raise ValueError(f"embeddings {tuple(e.shape)}, seg_map {tuple(seg.shape)}, scale_map {tuple(sc.shape)} "
+                             f"vs a {c_out}-channel {h}x{w} decoder output")
+        l1 = torch.empty(h, w, device=x.device)
+        mask = torch.empty(h, w, device=x.device)
+        check(_lib.load().gags_decoder_head_distill_fwd(c_out, logits.shape[1], h, w, seg.shape[1], seg.shape[2], e.shape[0],
+                                                        ptr(logits), ptr(e), ptr(seg), ptr(sc), ptr(l1), ptr(mask), _st()),
+              "gags_decoder_head_distill_fwd")
+        ctx.c_out, ctx.hw, ctx.c_in, ctx.wb = c_out, (h, w), c_in, wb
+        ctx.shapes = [tuple(t.shape) for t in params[0::2]]
+        ctx.save_for_backward(logits, e, seg, sc, *acts)
+        ctx.mark_non_differentiable(mask)
+        return l1, mask
+
+    @staticmethod
+    def backward(ctx, v_map, _v_mask):
+        from .losses import _f
+        logits, e, seg, sc, *acts = ctx.saved_tensors
+        (h, w), c = ctx.hw, ctx.c_out
+        dz = torch.empty(h * w, logits.shape[1], dtype=torch.bfloat16, device=logits.device)
+        vs = torch.empty(3, h, w, device=logits.device)
+        check(_lib.load().gags_decoder_head_distill_bwd(c, logits.shape[1], h, w, seg.shape[1], seg.shape[2], e.shape[0],
+                                                        ptr(logits), ptr(e), ptr(seg), ptr(sc), ptr(_f(v_map)), ptr(dz), ptr(vs),
+                                                        _st()), "gags_decoder_head_distill_bwd")
+        gx, grads = _chain_backward(dz, acts, ctx.wb, "decoder", h, w, ctx.c_in, ctx.shapes)
+        return (gx, None, None, vs, None, *grads)
 
 
 class _Stack(nn.Module):
@@ -210,6 +264,22 @@ class CNN_decoder(_Stack):
     def __init__(self, input_dim, output_dim):
         super().__init__([input_dim] + [256] * 8, [256] * 8 + [output_dim])
         self.output_dim = output_dim
+
+    def distill_l1(self, x, img_embed, seg_map, scale_map):
+        """train.py:159-166 in one call -- equal to
+            feature_map = self(x); gt, mask = read_sam_clip_feature(img_embed, seg_map, scale_map)
+            l1_loss_map(feature_map * mask, gt * mask), mask
+        with the decoder's normalising head fused into the loss (the [512,H,W] map is never materialised).  Returns
+        (l1_map [H,W], mask [1,H,W] bool); gradients reach x, the decoder's parameters and scale_map.  Not part of the
+        reference's module: an optional fast path."""
+        if not x.is_cuda:
+            raise RuntimeError("gags_amd.decoders: tensors must live on the GPU (there is no CPU path)")
+        if self.output_dim != 512:
+            l1, mask = __import__("gags_amd.losses", fromlist=["distill_l1_map"]).distill_l1_map(self(x), img_embed, seg_map, scale_map)
+            return l1, mask
+        params = [t for m in self.convs() for t in (m.weight, m.bias)]
+        l1, mask = _DecoderDistillFn.apply(x, img_embed, seg_map, scale_map, self.output_dim, *params)
+        return l1, (mask != 0)[None]
 
 
 class CNN_scale_decoder(_Stack):

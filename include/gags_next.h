@@ -62,6 +62,18 @@ int gags_distill_l1_map_bwd(int c, int H, int W, int h, int w, int n_emb, const 
                             const float *seg_map, const float *scale_map, const float *v_map, float *v_pred,
                             float *v_scale, int layout, void *stream);
 
+/* CNN_decoder's normalising head fused with the distillation L1 (train.py:159-166): from the last layer's fp32 logits
+ * x[H*W, ld] (c = ld = 512: the reference's CNN_decoder(16, 512); other widths: GAGS_EINVAL, use the two entries) to
+ *     l1_map[H, W] = mean_c | normalize(x) * mask - gt * mask |,   gt, mask = read_sam_clip_feature(...)
+ * and back: d l1_map -> dz[H*W, ld] bf16 (gradient of the logits; what gags_decoder_head_bwd would have produced from
+ * the loss's [c,H,W] gradient) and v_scale[3, H, W].  The normalised [c,H,W] map and its gradient never exist. */
+int gags_decoder_head_distill_fwd(int c, int ld, int H, int W, int h, int w, int n_emb, const float *x,
+                                  const float *img_embed, const float *seg_map, const float *scale_map,
+                                  float *l1_map, float *mask, void *stream);
+int gags_decoder_head_distill_bwd(int c, int ld, int H, int W, int h, int w, int n_emb, const float *x,
+                                  const float *img_embed, const float *seg_map, const float *scale_map,
+                                  const float *v_map, void *dz_bf16, float *v_scale, void *stream);
+
 /* ---- N1: the per-pixel decoders (models/networks.py:109-248: stacks of 1x1 convolutions) ---------------------- */
 
 /* fp32 pixel-major x[n_pix, c] (the rasterizer's own [H, W, D] output) -> bf16 y[n_pix, c_pad], zero-padded

@@ -246,3 +246,45 @@ def test_decoder_output_is_pixel_major_and_its_gradient_flows_without_transposes
     assert ((l1_a - l1_b).double().norm() / l1_b.double().norm()).item() <= 1e-6
     assert ((gx_a - gx_b).double().norm() / gx_b.double().norm()).item() <= 2e-2   # bf16 layers behind a different summation order
     assert ((gw_a - gw_b).double().norm() / gw_b.double().norm()).item() <= 2e-2
+
+
+@pytest.mark.parametrize("H,W,h,w", [(96, 130, 96, 130), (60, 77, 30, 40)])
+def test_fused_head_and_distillation_loss_equals_the_two_step_route(H, W, h, w):
+    """CNN_decoder.distill_l1 (head fused into the loss: gags_decoder_head_distill_fwd / _bwd) against
+    distill_l1_map(decoder(x), ...): the loss map, the mask, and every gradient (input, all decoder parameters, scale
+    map), with an identity-size and a resized (bilinear, four taps) segmentation map."""
+    from gags_amd import losses as L
+    from gags_amd.decoders import CNN_decoder
+    from make_golden_next import decoder_weights
+    wd, _ = decoder_weights(0)
+    dec = _load(CNN_decoder(16, 512), wd)
+    g = torch.Generator(device="cuda").manual_seed(12)
+    n_emb = 40
+    x = torch.randn(H, W, 16, device="cuda", generator=g).permute(2, 0, 1)
+    emb = torch.nn.functional.normalize(torch.randn(n_emb, 512, device="cuda", generator=g), dim=-1)
+    seg = torch.randint(-1, n_emb, (4, h, w), device="cuda", generator=g).float()
+    scale0 = torch.softmax(torch.randn(3, H, W, device="cuda", generator=g), 0)
+    wgt = torch.linspace(0.5, 1.5, H * W, device="cuda").reshape(H, W)
+    res = []
+    for fused in (False, True):
+        xi = x.clone().requires_grad_(True)
+        sc = scale0.clone().requires_grad_(True)
+        dec.zero_grad(set_to_none=True)
+        if fused:
+            l1, mask = dec.distill_l1(xi, emb, seg, sc)
+        else:
+            l1, mask = L.distill_l1_map(dec(xi), emb, seg, sc)
+        (l1 * wgt).sum().backward()
+        res.append((l1.detach().clone(), mask.clone(), xi.grad.clone(), sc.grad.clone(),
+                    [c.weight.grad.clone() for c in dec.convs()], [c.bias.grad.clone() for c in dec.convs()]))
+    a, b = res
+
+    def rel(u, v):
+        return ((u - v).double().norm() / v.double().norm().clamp_min(1e-300)).item()
+
+    assert torch.equal(a[1], b[1]) and a[1].shape == (1, H, W)
+    assert rel(b[0], a[0]) <= 1e-6
+    assert rel(b[3], a[3]) <= 1e-5                       # scale-map gradient: fp32 on both routes
+    assert rel(b[2], a[2]) <= 2e-2                       # behind bf16 layers (the logits' gradient is rounded to bf16)
+    for u, v in zip(b[4] + b[5], a[4] + a[5]):
+        assert rel(u, v) <= 2e-2

@@ -29,6 +29,9 @@ seg = torch.randint(-1, n_emb, (4, h // 8, w // 8), device=dev, generator=g).flo
 seg = seg[:, :h, :w].contiguous()
 
 
+FUSED = "--two-step" not in sys.argv   # default: the fused head + loss; --two-step: decoder, then distill_l1_map
+
+
 def ev():
     e = torch.cuda.Event(enable_timing=True); e.record(); return e
 
@@ -41,8 +44,11 @@ def iteration(times=None):
     seg_tr = L.get_trained_seg(seg, scale_map)
     reg = L.scale_region_regulation_loss(fmap, seg_tr, mix_seg=True)
     ce = L.scale_regulation_loss(scale_map); marks.append(ev())
-    f512 = dec(fmap); marks.append(ev())
-    l1m, mask = L.distill_l1_map(f512, img_embed, seg, scale_map)
+    if FUSED:  # the decoder's head fused into the distillation L1 (CNN_decoder.distill_l1): one call for train.py:159-166
+        l1m, mask = dec.distill_l1(fmap, img_embed, seg, scale_map); marks.append(ev())
+    else:
+        f512 = dec(fmap); marks.append(ev())
+        l1m, mask = L.distill_l1_map(f512, img_embed, seg, scale_map)
     l1 = L.Scale_balance_loss(l1m, seg_tr, mask.squeeze(0), mix_seg=True)
     loss = 1.0 * l1 + 0.002 * ce + 0.1 * reg; marks.append(ev())
     for m in (dec, sdec):
@@ -66,6 +72,6 @@ for _ in range(K):
     iteration(times)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
-print(json.dumps({"workload": "train.py:142-174 iteration, 1.5M Gaussians, 1920x1080, D=16 -> CNN decoders (bf16 MFMA) -> losses",
+print(json.dumps({"fused_head_loss": FUSED, "workload": "train.py:142-174 iteration, 1.5M Gaussians, 1920x1080, D=16 -> CNN decoders (bf16 MFMA) -> losses",
                   "ms_per_iteration": 1e3 * dt, "iterations_per_s": 1 / dt,
                   "stages_ms": {k: sum(v) / len(v) for k, v in times.items()}}))
