@@ -89,8 +89,10 @@ __global__ __launch_bounds__(256, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void rast
     __shared__ __attribute__((aligned(16))) float stage[4][32][CW];  // partial rows of the chunk, per block
     __shared__ uint8_t pos[2][4][CMAX];  // pos[parity][b][row - r0] = slot of block b's run holding that tile row, 0xff: none
     __shared__ int cand[2][4];
+    __shared__ __attribute__((aligned(16))) float zrow[CW];  // a row of zeros for the merge
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x < CW) zrow[threadIdx.x] = 0.f;  // (visible after the first chunk's barrier)
     const int logical = gags_xcd_remap(blockIdx.x, n_tiles * n_slices);
     const int slice = slice0 + logical % n_slices;
     const int tile = gags_tile_of_order(logical / n_slices, tile_w, n_tiles / tile_w);
@@ -221,20 +223,17 @@ __global__ __launch_bounds__(256, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void rast
             const int item = gt + 256 * trip;
             if (item < items) {
                 const int row = item / C4, c4 = item - row * C4;
+                // a block that does not hold the row reads a row of zeros instead (one select on the address, not
+                // four on the values: x + 0 is exact)
                 float4 v[4];
-                bool has[4];
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const int q = pos[par][b][row];
-                    has[b] = q != 0xff;
-                    v[b] = *reinterpret_cast<const float4 *>(&stage[b][has[b] ? q : 0][4 * c4]);
+                    v[b] = *(q != 0xff ? reinterpret_cast<const float4 *>(&stage[b][q][4 * c4]) : reinterpret_cast<const float4 *>(&zrow[4 * c4]));
                 }
-                float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    sum.x += has[b] ? v[b].x : 0.f; sum.y += has[b] ? v[b].y : 0.f;
-                    sum.z += has[b] ? v[b].z : 0.f; sum.w += has[b] ? v[b].w : 0.f;
-                }
+                float4 sum;
+                sum.x = ((v[0].x + v[1].x) + v[2].x) + v[3].x; sum.y = ((v[0].y + v[1].y) + v[2].y) + v[3].y;
+                sum.z = ((v[0].z + v[1].z) + v[2].z) + v[3].z; sum.w = ((v[0].w + v[1].w) + v[2].w) + v[3].w;
                 if (ch0 + 4 * c4 < d)  // ragged last slice (D % 32 != 0; D % 4 == 0)
                     *reinterpret_cast<float4 *>(prow + (size_t)(r0 + row) * d + ch0 + 4 * c4) = sum;
             }
@@ -281,8 +280,10 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
     __shared__ __attribute__((aligned(16))) float stage[4][32][CW];
     __shared__ uint8_t pos[2][4][CMAX];
     __shared__ int cand[2][4];
+    __shared__ __attribute__((aligned(16))) float zrow[CW];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x < CW) zrow[threadIdx.x] = 0.f;
     const int logical = gags_xcd_remap(blockIdx.x, n_tiles * n_slices);
     const int slice = slice0 + logical % n_slices;
     const int tile = gags_tile_of_order(logical / n_slices, tile_w, n_tiles / tile_w);
@@ -419,20 +420,15 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
             const int item = gt + 256 * trip;
             if (item < items) {
                 const int row = item / C4, c4 = item - row * C4;
-                float4 v[4];
-                bool has[4];
+                float4 v[4];  // (a block that does not hold the row reads the row of zeros: see raster_bwd_rows)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const int q = pos[par][b][row];
-                    has[b] = q != 0xff;
-                    v[b] = *reinterpret_cast<const float4 *>(&stage[b][has[b] ? q : 0][4 * c4]);
+                    v[b] = *(q != 0xff ? reinterpret_cast<const float4 *>(&stage[b][q][4 * c4]) : reinterpret_cast<const float4 *>(&zrow[4 * c4]));
                 }
-                float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    sum.x += has[b] ? v[b].x : 0.f; sum.y += has[b] ? v[b].y : 0.f;
-                    sum.z += has[b] ? v[b].z : 0.f; sum.w += has[b] ? v[b].w : 0.f;
-                }
+                float4 sum;
+                sum.x = ((v[0].x + v[1].x) + v[2].x) + v[3].x; sum.y = ((v[0].y + v[1].y) + v[2].y) + v[3].y;
+                sum.z = ((v[0].z + v[1].z) + v[2].z) + v[3].z; sum.w = ((v[0].w + v[1].w) + v[2].w) + v[3].w;
                 *reinterpret_cast<float4 *>(prow + (size_t)(r0 + row) * d + ch0 + 4 * c4) = sum;
             }
             if (trip & 1) __builtin_amdgcn_sched_barrier(0);
