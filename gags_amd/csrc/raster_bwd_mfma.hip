@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void rast
     constexpr int CW = 32 * NBR;  // channels per slice; this launch covers slices slice0 .. slice0 + n_slices - 1
     constexpr int C4 = CW / 4;    // float4 columns per row of the slice
     __shared__ __attribute__((aligned(16))) float stage[4][32][CW];  // partial rows of the chunk, per block
-    __shared__ uint8_t pos[2][4][CMAX];  // pos[parity][b][row - r0] = slot of block b's run holding that tile row, 0xff: none
+    __shared__ __attribute__((aligned(4))) uint8_t pos[2][CMAX][4];  // pos[parity][row - r0][b] = slot of block b's run holding that tile row, 0xff: none (one 32-bit read per row)
     __shared__ int cand[2][4];
     __shared__ __attribute__((aligned(16))) float zrow[CW];  // a row of zeros for the merge
 
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void rast
         const int tr_c = tr, gid_c = gid;
         const int pbn = pb + run;
         if (run > 0) {
-            if (mine) pos[par][wave][tr_c - r0] = (uint8_t)lane;
+            if (mine) pos[par][tr_c - r0][wave] = (uint8_t)lane;
             // The 32*NBR MFMAs of a weight tile are issued as ONE uninterrupted burst: everything they read is waited
             // for up front and nothing else is scheduled into the burst, so that the waves sharing a SIMD alternate
             // (one multiplies while the other loads / merges) instead of stalling and resuming in lock step.
@@ -226,9 +226,10 @@ __global__ __launch_bounds__(256, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void rast
                 // a block that does not hold the row reads a row of zeros instead (one select on the address, not
                 // four on the values: x + 0 is exact)
                 float4 v[4];
+                const uint32_t q4 = *reinterpret_cast<const uint32_t *>(&pos[par][row][0]);
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    const int q = pos[par][b][row];
+                    const int q = (q4 >> (8 * b)) & 0xff;
                     v[b] = *(q != 0xff ? reinterpret_cast<const float4 *>(&stage[b][q][4 * c4]) : reinterpret_cast<const float4 *>(&zrow[4 * c4]));
                 }
                 float4 sum;
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
     constexpr int NBR = 4, CW = 128, C4 = 32;
     constexpr float WSCALE = 4096.0f;
     __shared__ __attribute__((aligned(16))) float stage[4][32][CW];
-    __shared__ uint8_t pos[2][4][CMAX];
+    __shared__ __attribute__((aligned(4))) uint8_t pos[2][CMAX][4];
     __shared__ int cand[2][4];
     __shared__ __attribute__((aligned(16))) float zrow[CW];
 
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
         const int tr_c = tr, gid_c = gid;
         const int pbn = pb + run;
         if (run > 0) {
-            if (mine) pos[par][wave][tr_c - r0] = (uint8_t)lane;
+            if (mine) pos[par][tr_c - r0][wave] = (uint8_t)lane;
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
@@ -421,9 +422,10 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
             if (item < items) {
                 const int row = item / C4, c4 = item - row * C4;
                 float4 v[4];  // (a block that does not hold the row reads the row of zeros: see raster_bwd_rows)
+                const uint32_t q4 = *reinterpret_cast<const uint32_t *>(&pos[par][row][0]);
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    const int q = pos[par][b][row];
+                    const int q = (q4 >> (8 * b)) & 0xff;
                     v[b] = *(q != 0xff ? reinterpret_cast<const float4 *>(&stage[b][q][4 * c4]) : reinterpret_cast<const float4 *>(&zrow[4 * c4]));
                 }
                 float4 sum;
