@@ -247,179 +247,6 @@ __global__ __launch_bounds__(256, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void rast
     }
 }
 
-// ---- staged: rows, specialised waves (D % 128 == 0) -----------------------------------------------------------------
-// tools/micro/coissue.hip: while a wave streams fp32 MFMAs its SIMD partner gets exactly ONE instruction issued per
-// MFMA, whatever it is; two waves that both multiply only take turns at the pipe, and in raster_bwd_rows the two
-// co-resident workgroups drift into lock step (both multiply, both merge: pipe 54 % busy).  Here a workgroup of EIGHT
-// waves owns a CU: waves 0-3 (one per SIMD) do nothing but the bursts of their block -- the next chunk's weight tile is
-// loaded in place behind the MFMAs that last read each register quad, the partial rows are parked after the burst --
-// and waves 4-7, their SIMD partners, never touch the matrix pipe: they merge and store the PREVIOUS chunk (double-
-// buffered staging area, 128 KB) from the 128 issue slots the bursts leave them plus the full-rate gaps around barriers.
-template <int DBG>  // 0: product; 1: helpers skip the merge; 2: matrix waves skip the burst (timing experiments only)
-__global__ __launch_bounds__(512, 1) void raster_bwd_rows_duo(
-    int d, int width, int height, int tile_w, int n_tiles, int slice0, int n_slices,
-    const float *__restrict__ v_render_colors, const int32_t *__restrict__ offsets, int n_isects,
-    const int32_t *__restrict__ blk_rows, const int32_t *__restrict__ trow, const float *__restrict__ wt,
-    const int32_t *__restrict__ gid_s, const int32_t *__restrict__ trow_s, float *__restrict__ prow,
-    uint32_t *__restrict__ row_key, int32_t *__restrict__ row_idx)
-{
-    constexpr int NBR = 4, CW = 128, C4 = 32;
-    __shared__ __attribute__((aligned(16))) float stage[2][4][32][CW];  // [chunk parity][block][slot]
-    __shared__ __attribute__((aligned(4))) uint8_t pos[2][CMAX][4];
-    __shared__ int cand[2][4];
-    __shared__ __attribute__((aligned(16))) float zrow[CW];
-
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool helper = wave >= 4;
-    if (threadIdx.x < CW) zrow[threadIdx.x] = 0.f;
-    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * n_slices);
-    const int slice = slice0 + logical % n_slices;
-    const int tile = gags_tile_of_order(logical / n_slices, tile_w, n_tiles / tile_w);
-    const int start = offsets[tile];
-    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
-    const int R0 = trow[start], R1 = trow[end];
-    if (R1 == R0) return;  // nothing blended in this tile (uniform over the workgroup)
-    const int ch0 = slice * CW;
-
-    if (helper) {
-        // ---- merge waves: chunk it - 1 between the two barriers of chunk it, the last chunk after the loop ----
-        const int ht = threadIdx.x - 256;
-        int r0 = R0, m_r0 = 0, m_r1 = 0;
-        auto merge = [&](int par, int q0, int q1) __attribute__((always_inline)) {
-            const int items = (q1 - q0) * C4;
-            int gt = ht;
-            asm volatile("" : "+v"(gt));
-#pragma unroll
-            for (int trip = 0; trip < CMAX * C4 / 256; ++trip) {
-                const int item = gt + 256 * trip;
-                if (item < items) {
-                    const int row = item / C4, c4 = item - row * C4;
-                    float4 v[4];
-                    const uint32_t q4 = *reinterpret_cast<const uint32_t *>(&pos[par][row][0]);
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const int q = (q4 >> (8 * b)) & 0xff;
-                        v[b] = *(q != 0xff ? reinterpret_cast<const float4 *>(&stage[par][b][q][4 * c4]) : reinterpret_cast<const float4 *>(&zrow[4 * c4]));
-                    }
-                    float4 sum;  // block order 0..3: bit-reproducible; x + 0 is exact
-                    sum.x = ((v[0].x + v[1].x) + v[2].x) + v[3].x; sum.y = ((v[0].y + v[1].y) + v[2].y) + v[3].y;
-                    sum.z = ((v[0].z + v[1].z) + v[2].z) + v[3].z; sum.w = ((v[0].w + v[1].w) + v[2].w) + v[3].w;
-                    *reinterpret_cast<float4 *>(prow + (size_t)(q0 + row) * d + ch0 + 4 * c4) = sum;
-                }
-            }
-        };
-        if (DBG == 3) return;
-        int it = 0;
-        for (; r0 < R1; ++it) {
-            const int par = it & 1;
-            __syncthreads();  // B1: the blocks' candidates for this chunk's end
-            const int r1 = min(min(min(cand[par][0], cand[par][1]), min(cand[par][2], cand[par][3])), min(r0 + CMAX, R1));
-            if (it > 0 && DBG != 1) merge(par ^ 1, m_r0, m_r1);
-            __syncthreads();  // B2: this chunk's partial rows are parked
-            m_r0 = r0; m_r1 = r1;
-            r0 = r1;
-        }
-        merge((it - 1) & 1, m_r0, m_r1);
-        return;
-    }
-
-    // ---- matrix waves: wave b = block b ----
-    const int blk = wave;
-    const int cnt = blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk];
-    const int sb = gags_slot_base(start, end, tile, blk);
-    BlockGeom64 g;
-    g.init(tile, blk, tile_w, width, height, lane);
-    const int p = g.p, k = g.k;
-    float V[32][NBR];
-#pragma unroll
-    for (int t = 0; t < 32; ++t) {
-        const int px = 16 * k + (t >> 1);
-        const int qj = g.bx0 + (px & 7), qi = g.by0 + 4 * (t & 1) + (px >> 3);
-        const bool ok = (qi < height) && (qj < width) && cnt > 0;
-        const float4 v = *reinterpret_cast<const float4 *>(
-            v_render_colors + ((size_t)min(qi, height - 1) * width + min(qj, width - 1)) * d + ch0 + NBR * p);
-        V[t][0] = ok ? v.x : 0.f; V[t][1] = ok ? v.y : 0.f; V[t][2] = ok ? v.z : 0.f; V[t][3] = ok ? v.w : 0.f;
-    }
-    int pb = 0, r0 = R0;
-    int tr = 0x7fffffff, gid = 0;
-    if (lane <= 32 && lane < cnt) {
-        tr = trow_s[sb + lane];
-        gid = gid_s[sb + lane];
-    }
-    float A[32];
-    const int last_slot = max(cnt - 1, 0);
-    auto wt_row = [&](int first) __attribute__((always_inline)) {  // clamped into the block's slots: always a valid address
-        return reinterpret_cast<const float4 *>(wt + (size_t)(sb + min(first + p, last_slot)) * 64 + k * 32);
-    };
-    {
-        const float4 *src = wt_row(0);
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const float4 v = src[t];
-            A[4 * t] = v.x; A[4 * t + 1] = v.y; A[4 * t + 2] = v.z; A[4 * t + 3] = v.w;
-        }
-    }
-    if (DBG == 3) {  // start-up only: the slab, the first rows / ids / weight tile, one store so that nothing is dead
-        float sacc = A[0] + A[31] + V[0][0] + V[31][3] + (float)tr + (float)gid;
-        if (sacc == 12345.678f) prow[0] = sacc;
-        return;
-    }
-    for (int it = 0; r0 < R1; ++it) {
-        const int par = it & 1;
-        if (threadIdx.x < CMAX) reinterpret_cast<uint32_t *>(&pos[par][0][0])[threadIdx.x] = 0xffffffffu;
-        const int tr32 = __builtin_amdgcn_readlane(tr, 32);
-        if (lane == 0) cand[par][wave] = tr32;
-        __syncthreads();  // B1
-        const int r1 = min(min(min(cand[par][0], cand[par][1]), min(cand[par][2], cand[par][3])), min(r0 + CMAX, R1));
-        const bool mine = lane < 32 && tr < r1;
-        const int run = __popcll(__ballot(mine));
-        const int tr_c = tr, gid_c = gid;
-        const int pbn = pb + run;
-        if (run > 0) {
-            if (mine) {
-                pos[par][tr_c - r0][wave] = (uint8_t)lane;
-                if (slice == 0) {  // row -> Gaussian map for the sort (every block of the row stores the same pair)
-                    row_key[tr_c] = (uint32_t)gid_c;
-                    row_idx[tr_c] = tr_c;
-                }
-            }
-            // next chunk's rows / ids and, quad by quad behind its last readers, its weight tile
-            tr = 0x7fffffff;
-            if (lane <= 32 && pbn + lane < cnt) {
-                tr = trow_s[sb + pbn + lane];
-                gid = gid_s[sb + pbn + lane];
-            }
-            const float4 *wnext = wt_row(pbn);
-            f32x16 acc[NBR];
-#pragma unroll
-            for (int j = 0; j < NBR; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-#pragma unroll
-            for (int seg = 0; seg < 8; ++seg) {
-                if (DBG != 2) {
-#pragma unroll
-                    for (int t = 4 * seg; t < 4 * seg + 4; ++t)
-#pragma unroll
-                        for (int j = 0; j < NBR; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[t], V[t][j], acc[j], 0, 0, 0);
-                }
-                const float4 v = wnext[seg];
-                A[4 * seg] = v.x; A[4 * seg + 1] = v.y; A[4 * seg + 2] = v.z; A[4 * seg + 3] = v.w;
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int slot = (r & 3) + 8 * (r >> 2) + 4 * k;
-                if (slot < run)
-                    *reinterpret_cast<float4 *>(&stage[par][wave][slot][NBR * p]) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
-            }
-        }
-        __syncthreads();  // B2
-        pb = pbn;
-        r0 = r1;
-    }
-}
-
 // ---- staged: rows, 16-bit matrix cores (opt-in: GAGS_BWD_F16SPLIT) ---------------------------------------------------
 // The same kernel with the contraction on v_mfma_f32_32x32x16_f16 (16x the fp32 MFMA rate): both operands are split
 // into an fp16 head and an fp16 tail, x = (hi + lo) / scale with
@@ -875,21 +702,6 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
             if (nbr == 4 && (stage_flags & 32))  // opt-in: contraction on the 16-bit matrix cores (GAGS_BWD_F16SPLIT)
                 hipLaunchKernelGGL(raster_bwd_rows_f16, grid, dim3(256), 0, st, d, width, height, tile_w, n_tiles, slice0,
                                    n_slices, v_out, offsets, n_isects, blk_rows, trow, wt, gid_s, trow_s, prow, key, idx);
-            else if (nbr == 4 && getenv("GAGS_ROWS_DUO")) {
-                const int dbg = atoi(getenv("GAGS_ROWS_DUO"));
-                if (dbg == 2)
-                    hipLaunchKernelGGL(raster_bwd_rows_duo<1>, grid, dim3(512), 0, st, d, width, height, tile_w, n_tiles, slice0, n_slices,
-                                       v_out, offsets, n_isects, blk_rows, trow, wt, gid_s, trow_s, prow, key, idx);
-                else if (dbg == 4)
-                    hipLaunchKernelGGL(raster_bwd_rows_duo<3>, grid, dim3(512), 0, st, d, width, height, tile_w, n_tiles, slice0, n_slices,
-                                       v_out, offsets, n_isects, blk_rows, trow, wt, gid_s, trow_s, prow, key, idx);
-                else if (dbg == 3)
-                    hipLaunchKernelGGL(raster_bwd_rows_duo<2>, grid, dim3(512), 0, st, d, width, height, tile_w, n_tiles, slice0, n_slices,
-                                       v_out, offsets, n_isects, blk_rows, trow, wt, gid_s, trow_s, prow, key, idx);
-                else
-                    hipLaunchKernelGGL(raster_bwd_rows_duo<0>, grid, dim3(512), 0, st, d, width, height, tile_w, n_tiles, slice0, n_slices,
-                                       v_out, offsets, n_isects, blk_rows, trow, wt, gid_s, trow_s, prow, key, idx);
-            }
             else if (nbr == 4) GAGS_ROWS_LAUNCH(4);
             else if (nbr == 2) GAGS_ROWS_LAUNCH(2);
             else GAGS_ROWS_LAUNCH(1);
