@@ -815,22 +815,26 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_sdot(int d, int ch0, int dc
     }
     const int m = lane & 31, kh = lane >> 5;
     const int nj = dch >> 3;  // steps of 8 channels: lane (m, kh) takes channels 8 j + 4 kh .. + 3 of slot m's row
-    for (int t0 = wave * 32; t0 < cnt; t0 += 128) {
+    // work units = (32-slot tile, 32-pixel half of the block), dealt round-robin to the four waves: with whole tiles as
+    // units a block of ~4.75 tiles kept the waves 59 % busy, with half-tiles 79 % (the second reader of a feature row
+    // finds it in the CU's L1)
+    const int n_units = 2 * ((cnt + 31) >> 5);
+    for (int unit = wave; unit < n_units; unit += 4) {
+        const int t0 = (unit >> 1) * 32, hh = unit & 1;
         const int slot = sb + min(t0 + m, cnt - 1);
         const int gid = min(gid_s[slot], n_gauss - 1);  // the pad slot's row is computed and never used (its weights are 0)
         const float *crow = colors + (size_t)gid * d + ch0 + 4 * kh;
-        const float *b0 = slab + m * pitch + 4 * kh, *b1 = slab + (32 + m) * pitch + 4 * kh;
-        f32x16 acc0, acc1;
+        const float *b0 = slab + (32 * hh + m) * pitch + 4 * kh;
+        f32x16 acc0;
         if (accumulate) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = min(t0 + (r & 3) + 8 * (r >> 2) + 4 * kh, cnt - 1);
-                acc0[r] = S[(size_t)(sb + row) * 64 + m];
-                acc1[r] = S[(size_t)(sb + row) * 64 + 32 + m];
+                acc0[r] = S[(size_t)(sb + row) * 64 + 32 * hh + m];
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
         }
         float4 a[8];
 #pragma unroll
@@ -838,15 +842,11 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_sdot(int d, int ch0, int dc
         auto step = [&](int j, int u) __attribute__((always_inline)) {
             const float4 av = a[u];
             a[u] = *reinterpret_cast<const float4 *>(crow + 8 * min(j + 8, nj - 1));
-            const float4 x0 = *reinterpret_cast<const float4 *>(b0 + 8 * j), x1 = *reinterpret_cast<const float4 *>(b1 + 8 * j);
+            const float4 x0 = *reinterpret_cast<const float4 *>(b0 + 8 * j);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, x0.x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, x1.x, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, x0.y, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, x1.y, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, x0.z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, x1.z, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, x0.w, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, x1.w, acc1, 0, 0, 0);
         };
         if constexpr (DCH != 0) {  // one basic block: no loop back-edge for the compiler to drain the prefetches at
 #pragma unroll
@@ -861,14 +861,11 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_sdot(int d, int ch0, int dc
                     if (jb + u < nj) step(jb + u, u);
             }
         }
-        // accumulator: column = pixel element m (of half 0 / 1), rows = slots (r & 3) + 8 (r >> 2) + 4 kh
+        // accumulator: column = pixel element m of half hh, rows = slots (r & 3) + 8 (r >> 2) + 4 kh
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = t0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (row < cnt) {
-                S[(size_t)(sb + row) * 64 + m] = acc0[r];
-                S[(size_t)(sb + row) * 64 + 32 + m] = acc1[r];
-            }
+            if (row < cnt) S[(size_t)(sb + row) * 64 + 32 * hh + m] = acc0[r];
         }
     }
 }
