@@ -79,13 +79,29 @@ class GaussianModel:
         self.optimizer = None
 
     # -- activations: scene/gaussian_model.py:36-42,116-139 -------------------------------
+    def _frozen(self, name, param, fn):
+        """Activation of a FROZEN parameter (requires_grad False: the geometry during the reference's feature training,
+        train.py:62-75), recomputed only when the parameter object, its storage or its version counter changed -- the
+        reference evaluates these getters (scene/gaussian_model.py:116-139) on every render, six small kernels per view.
+        A parameter that requires grad is always evaluated afresh (autograd needs the graph)."""
+        if param.requires_grad or torch.is_grad_enabled() and param.grad_fn is not None:
+            return fn(param)
+        cache = self.__dict__.setdefault("_act_cache", {})
+        key = (id(param), param.data_ptr(), param._version, tuple(param.shape))
+        hit = cache.get(name)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                hit = (key, fn(param))
+            cache[name] = hit
+        return hit[1]
+
     @property
     def get_scaling(self):
-        return torch.exp(self._scaling)
+        return self._frozen("scaling", self._scaling, torch.exp)
 
     @property
     def get_rotation(self):
-        return torch.nn.functional.normalize(self._rotation)
+        return self._frozen("rotation", self._rotation, torch.nn.functional.normalize)
 
     @property
     def get_xyz(self):
@@ -97,7 +113,7 @@ class GaussianModel:
 
     @property
     def get_opacity(self):
-        return torch.sigmoid(self._opacity)
+        return self._frozen("opacity", self._opacity, torch.sigmoid)
 
     @property
     def get_semantic_feature(self):

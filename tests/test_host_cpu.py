@@ -62,3 +62,29 @@ def test_workload_meets_the_declared_intent(oracle):
     assert 0.85 < vis.mean() < 0.99             # ~5 % of the means are off-screen
     assert 5 <= np.median(radii[vis]) <= 9      # median 3-sigma radius ~7 px
     assert 3.0 <= b["n_isects"] / vis.sum() <= 6.5
+
+
+def test_frozen_activations_are_cached_and_invalidated():
+    """GaussianModel getters of frozen geometry (scene/gaussian_model.py:116-139 recomputes exp / normalize / sigmoid on
+    every render): cached per parameter version; an in-place update, a new tensor, or requires_grad bring back a fresh
+    evaluation."""
+    import torch
+    from gags_amd.scene import GaussianModel
+    m = GaussianModel(3)
+    n = 50
+    g = torch.Generator().manual_seed(0)
+    m._scaling = torch.nn.Parameter(torch.randn(n, 3, generator=g), requires_grad=False)
+    m._rotation = torch.nn.Parameter(torch.randn(n, 4, generator=g), requires_grad=False)
+    m._opacity = torch.nn.Parameter(torch.randn(n, 1, generator=g), requires_grad=False)
+    a = m.get_scaling
+    assert m.get_scaling is a and torch.equal(a, torch.exp(m._scaling))
+    with torch.no_grad():
+        m._scaling.add_(1.0)                      # in-place: version bump
+    b = m.get_scaling
+    assert b is not a and torch.equal(b, torch.exp(m._scaling))
+    m._scaling = torch.nn.Parameter(torch.zeros(n, 3), requires_grad=False)   # replaced
+    assert torch.equal(m.get_scaling, torch.ones(n, 3))
+    m._opacity.requires_grad_(True)               # trainable again: always evaluated, with a graph
+    o = m.get_opacity
+    assert o.requires_grad and m.get_opacity is not o
+    assert torch.allclose(m.get_rotation.norm(dim=1), torch.ones(n))
