@@ -286,6 +286,8 @@ def test_backward_by_channel_ranges_is_bit_identical(oracle):
     (1200, 96, 64, 512, 13, 4),   # C3 width: D >= 32, D % 8 == 0 take gags_raster_bwd_geom (dot pass on the matrix cores)
     (2000, 112, 80, 40, 14, 1),   # ... including a width that is no multiple of 32
     (800, 64, 48, 640, 15, None), # two accumulating channel passes of the dot kernel (512 + 128)
+    (2000, 97, 61, 64, 16, 3),    # ragged image (not a multiple of the tile) through the matrix-core geometry path
+    (2500, 130, 100, 256, 17, 6), # ... and at the dot kernel's full pass width
 ])
 def test_full_backward(oracle, n, w, h, d, seed, view):
     s = scene_arrays(n, d, w, h, seed=seed, view=view, scale_mult=5.0)
@@ -328,6 +330,31 @@ def test_wide_geometry_backward_matches_the_valu_kernel_and_is_deterministic():
         for k in ("means", "quats", "scales", "opacities", "means2d", "colors"):
             np.testing.assert_array_equal(g_new[k], g_rep[k])
             assert rel_l2(g_new[k], g_old[k]) <= 2e-5, k
+
+
+def test_wide_geometry_backward_with_nothing_to_render():
+    """Degenerate inputs through the matrix-core geometry path: every Gaussian behind the camera (no intersections at
+    all), and a view that only a handful of Gaussians reach -- gradients are exact zeros where nothing blended."""
+    from gags_amd.rasterization import rasterization
+    n, w, h, d = 500, 64, 48, 64
+    s = scene_arrays(n, d, w, h, seed=3, view=None, scale_mult=4.0)
+    for shift in (-100.0, 0.0):
+        means = s["means"].copy()
+        means[:, 2] += shift                      # shift = -100: everything behind the camera
+        leaves = {k: to_dev(v).requires_grad_(True) for k, v in
+                  dict(means=means, quats=s["quats"], scales=s["scales"], opac=s["opacities"], colors=s["colors"]).items()}
+        out, alphas, info = rasterization(leaves["means"], leaves["quats"], leaves["scales"], leaves["opac"], leaves["colors"],
+                                          to_dev(s["viewmat"])[None], to_dev(s["K"])[None], w, h)
+        (out[0].sum() + alphas.sum()).backward()
+        torch.cuda.synchronize()
+        for k, t in leaves.items():
+            assert t.grad is not None and bool(torch.isfinite(t.grad).all()), k
+        if shift < 0:
+            assert info["n_isects"] == 0
+            assert all(float(t.grad.abs().max()) == 0.0 for t in leaves.values())
+        else:
+            culled = info["radii"][0] == 0
+            assert float(leaves["opac"].grad[culled].abs().max()) == 0.0
 
 
 def test_render_modes_and_sh(oracle):
