@@ -354,7 +354,7 @@ def test_wide_geometry_backward_with_nothing_to_render():
             assert all(float(t.grad.abs().max()) == 0.0 for t in leaves.values())
         else:
             culled = info["radii"][0] == 0
-            assert float(leaves["opac"].grad[culled].abs().max()) == 0.0
+            assert float(leaves["opac"].grad[culled].abs().sum()) == 0.0   # (possibly no Gaussian is culled)
 
 
 def test_render_modes_and_sh(oracle):
