@@ -166,7 +166,7 @@ def test_decoder_backward_kernels_against_fp32_on_the_same_masks():
 
 
 @pytest.mark.parametrize("c,ld,layout", [(512, 512, 0), (3, 32, 0), (100, 128, 0), (37, 40, 0), (520, 544, 0),
-                                         (512, 512, 1), (100, 128, 1), (16, 32, 1)])
+                                         (512, 512, 1), (100, 128, 1), (16, 32, 1), (4, 8, 0), (2, 16, 0)])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_head_kernels_against_torch(c, ld, layout, mode):
     """gags_decoder_head / _head_bwd alone (models/networks.py:192 normalize, :242 softmax) in fp32 against torch, on
