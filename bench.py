@@ -66,7 +66,8 @@ def parse():
     ap.add_argument("--n", "--n-gaussians", dest="n", type=int, default=None)
     ap.add_argument("--d", "--feature-dim", dest="d", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
+    ap.add_argument("--cpu-seconds", type=float, default=30.0,
+                    help="target CPU time of the oracle sample (the whole view when it fits: ~7 s on the GPU box's 128 cores)")
     ap.add_argument("--no-allreduce", action="store_true", help="(debug) skip the gradient reduction at N>1")
     ap.add_argument("--grad-reduce", default="rs_ag", choices=["rs_ag", "allreduce"],
                     help="by-view step: bucketed reduce-scatter + all-gather (default) or plain all-reduce")
@@ -121,8 +122,8 @@ def cpu_baseline(pc, cam, d, width, height, target_s):
         t_b = time.perf_counter() - t2
         return t_f + t_b
 
-    step = max(1, n_tiles // 64)
-    t_s = sample(step)            # pilot (also warms the page cache / allocator)
+    step = max(1, n_tiles // 512)   # pilot: enough tiles to load every host thread a few times (64 tiles on 128
+    t_s = sample(step)              # threads over-estimated the per-tile time 2x); also warms page cache / allocator
     n_s = len(range(0, n_tiles, step))
     per_tile = t_s / n_s
     want = max(1, min(n_tiles, int(target_s / max(per_tile, 1e-9))))
@@ -162,11 +163,18 @@ def host_cpu():
 
 
 # kernels behind each bracketed stage, by their short rocprofv3 names (tools/pmc_summary.py)
+# (matched as prefixes: template arguments differ between rounds, e.g. "raster_fwd_feat<4, false>")
 STAGE_KERNELS = {
-    "raster_fwd": ("raster_weights_kernel", "raster_fwd_feat<4>"),
-    "bwd_rows": ("raster_bwd_rows<4>",),
+    "raster_fwd": ("raster_weights_kernel", "raster_fwd_feat<4"),
+    "bwd_rows": ("raster_bwd_rows<4",),
     "bwd_reduce": ("reduce_rows_kernel",),
 }
+
+
+def _traffic_of(traffic, prefix):
+    """HBM bytes per launch of the kernel whose short rocprofv3 name starts with `prefix` (None when absent or ambiguous)."""
+    hits = [v["hbm_bytes"] for k, v in traffic.items() if k.startswith(prefix)]
+    return hits[0] if len(hits) == 1 else None
 
 
 def pmc_traffic(args):
@@ -404,8 +412,8 @@ def main():
         traffic, traffic_src = pmc_traffic(args) if world == 1 else ({}, None)
         for name, members in STAGE_KERNELS.items():
             if name in kernels:
-                tb = [traffic[m]["hbm_bytes"] for m in members if m in traffic]
-                kernels[name]["traffic"] = sum(tb) if len(tb) == len(members) else None
+                tb = [_traffic_of(traffic, m) for m in members]
+                kernels[name]["traffic"] = sum(tb) if all(t is not None for t in tb) else None
         dom = max(kernels, key=lambda k_: kernels[k_]["avg_launch_ms"])
         roof = dict(kernels[dom], kernel=dom, traffic_source=traffic_src)
         line = {

@@ -15,6 +15,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: only what these headers declare is exported */
+#pragma GCC visibility push(default)
 
 /* ---- N2: losses and ground-truth assembly of train.py:149-172 -------------------------------------------------- */
 
@@ -121,6 +123,7 @@ int gags_decoder_head(int64_t n_pix, int c, int ld, int mode, const float *x, fl
 int gags_relevancy(int64_t n_pix, int c, int n_pos, int n_neg, const float *embed, const float *pos, const float *neg,
                    float *probs, void *stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: only what these headers declare is exported */
+#pragma GCC visibility push(default)
 
 #define GAGS_TILE 16
 
@@ -262,6 +264,7 @@ int64_t gags_dot_scratch_bytes(void);
 int gags_dot_f32(int64_t numel, const float *x, const float *y, float *out, void *scratch,
                  int64_t scratch_bytes, void *stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

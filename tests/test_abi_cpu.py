@@ -37,6 +37,16 @@ def test_library_exports_every_declared_symbol(lib):
     assert set(_lib.SIGNATURES) == decl, "python binding and header disagree"
 
 
+def test_library_exports_nothing_but_the_declared_c_abi(lib):
+    """Built with -fvisibility=hidden: the dynamic symbol table holds the headers' gags_* functions and no internal
+    C++ launcher (17 mangled _Z..._launch symbols used to leak)."""
+    import subprocess
+    from gags_amd import _lib
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = {ln.split()[-1] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in "TW"}
+    assert exported == _declared(), sorted(exported ^ _declared())
+
+
 def test_abi_version_and_error_strings(lib):
     assert lib.gags_abi_version() == 1
     assert lib.gags_strerror(0) == b"ok"
