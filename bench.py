@@ -205,6 +205,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+            args.grad_reduce = "allreduce"  # gloo has no reduce-scatter for device tensors
 
     from gags_amd import _lib, profiler, synthetic as syn
     from gags_amd.gaussian_renderer import render
@@ -247,7 +248,8 @@ def main():
 
         exchange = mode == "view" and world > 1 and not args.no_allreduce
         overlap = exchange and not args.no_overlap
-        red = OverlappedGradReducer(mode=grad_reduce, wire=args.wire, rows=args.rows) if overlap else None
+        red = (OverlappedGradReducer(mode=grad_reduce, wire=args.wire, rows=args.rows, param=pc_._semantic_feature)
+               if overlap else None)
 
         def step_():
             pc_._semantic_feature.grad = None
@@ -374,6 +376,7 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / ms / 1e6 / HBM_PEAK_GBS}
 
     exposed_ms = exposed[-1].exposed_ms() if exposed else None
+    range_ms = exposed[-1].range_ms if exposed else None
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -439,6 +442,7 @@ def main():
                        "grad_exchange": (None if world == 1 or mode != "view" else
                                          {"overlapped_with_backward": not args.no_overlap, "wire": args.wire,
                                           "collective": args.grad_reduce, "exposed_ms_last_step": exposed_ms,
+                                          "range_exchange_ms_last_step": range_ms,
                                           "rows": args.rows if not args.no_overlap else "all",
                                           "rows_exchanged_last_step": (exposed[-1].rows_exchanged if exposed else None)})},
             "roofline": roof,

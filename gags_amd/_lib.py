@@ -61,6 +61,8 @@ SIGNATURES = {
     "gags_sh_bwd": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_ed_normalize": (_i32, [_i64, _i32, _vp, _vp, _vp]),
     "gags_adam_step": (_i32, [_i64, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _f64, _i32, _vp]),
+    "gags_pack_rows": (_i32, [_i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "gags_unpack_rows": (_i32, [_i64, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "gags_dot_scratch_bytes": (_i64, []),
     "gags_dot_f32": (_i32, [_i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     # include/gags_next.h

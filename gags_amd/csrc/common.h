@@ -79,10 +79,11 @@ __device__ __forceinline__ int gags_tile_of_order(int o, int tile_w, int tile_h)
     return (y0 + (r - x * h)) * tile_w + x;
 }
 
-// Feature widths served by the split matrix-core path (weights pass + feature pass, staged backward): multiples
-// of 32, and multiples of 4 from 16 up (32-channel slices, the last one ragged) -- 16 is the width the reference
-// actually rasterizes (train.py:68).  Everything else (RGB, RGB+ED, odd widths) runs the VALU kernels.
-__host__ __device__ __forceinline__ bool gags_mfma_width(int d) { return d >= 16 && (d % 32 == 0 || d % 4 == 0); }
+// Feature widths served by the split matrix-core path (weights pass + feature pass, staged backward): every D >= 16
+// (128-channel slices, then 64, then 32-channel slices of which the last may be ragged) -- 16 is the width the
+// reference actually rasterizes (train.py:68), 513 = 512 + 1 is BASELINE.json configs[4].  Narrower widths (RGB,
+// RGB+ED, depth) run the VALU kernels.
+__host__ __device__ __forceinline__ bool gags_mfma_width(int d) { return d >= 16; }
 
 // Slot space of the matrix-core rasterizer (raster_weights.hip): every (tile, 8x8 block) owns a fixed
 // region of K-step slots sized by the tile's list length, so no counting pass is needed.

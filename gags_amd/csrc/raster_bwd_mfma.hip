@@ -78,13 +78,13 @@ constexpr int CMAX = 64;  // merged rows per chunk (bounds pos[] and the merge l
 
 template <int NBR>
 __global__ __launch_bounds__(256, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void raster_bwd_rows(
-    int d, int width, int height, int tile_w, int n_tiles, int slice0, int n_slices,
+    int d, int width, int height, int tile_w, int n_tiles, int ch_base, int n_slices,
     const float *__restrict__ v_render_colors, const int32_t *__restrict__ offsets, int n_isects,
     const int32_t *__restrict__ blk_rows, const int32_t *__restrict__ trow, const float *__restrict__ wt,
     const int32_t *__restrict__ gid_s, const int32_t *__restrict__ trow_s, float *__restrict__ prow,
     uint32_t *__restrict__ row_key, int32_t *__restrict__ row_idx)
 {
-    constexpr int CW = 32 * NBR;  // channels per slice; this launch covers slices slice0 .. slice0 + n_slices - 1
+    constexpr int CW = 32 * NBR;  // channels per slice; this launch covers channels ch_base .. ch_base + n_slices * CW - 1 (clipped to d)
     constexpr int C4 = CW / 4;    // float4 columns per row of the slice
     __shared__ __attribute__((aligned(16))) float stage[4][32][CW];  // partial rows of the chunk, per block
     __shared__ __attribute__((aligned(4))) uint8_t pos[2][CMAX][4];  // pos[parity][row - r0][b] = slot of block b's run holding that tile row, 0xff: none (one 32-bit read per row)
@@ -94,7 +94,6 @@ __global__ __launch_bounds__(256, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void rast
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (threadIdx.x < CW) zrow[threadIdx.x] = 0.f;  // (visible after the first chunk's barrier)
     const int logical = gags_xcd_remap(blockIdx.x, n_tiles * n_slices);
-    const int slice = slice0 + logical % n_slices;
     const int tile = gags_tile_of_order(logical / n_slices, tile_w, n_tiles / tile_w);
     const int start = offsets[tile];
     const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
@@ -103,7 +102,7 @@ __global__ __launch_bounds__(256, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void rast
     const int blk = wave;
     const int cnt = blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk];
     const int sb = gags_slot_base(start, end, tile, blk);
-    const int ch0 = slice * CW;
+    const int ch0 = ch_base + (logical % n_slices) * CW;
     BlockGeom64 g;
     g.init(tile, blk, tile_w, width, height, lane);
     const int p = g.p, k = g.k;
@@ -189,7 +188,7 @@ __global__ __launch_bounds__(256, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void rast
 #pragma unroll
                 for (int j = 0; j < NBR; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[t], V[t][j], acc[j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (mine && slice == 0) {  // row -> Gaussian map for the sort (every block of the row stores the same pair)
+            if (mine && ch0 == 0) {  // row -> Gaussian map for the sort (every block of the row stores the same pair)
                 row_key[tr_c] = (uint32_t)gid_c;
                 row_idx[tr_c] = tr_c;
             }
@@ -235,8 +234,15 @@ __global__ __launch_bounds__(256, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void rast
                 float4 sum;
                 sum.x = ((v[0].x + v[1].x) + v[2].x) + v[3].x; sum.y = ((v[0].y + v[1].y) + v[2].y) + v[3].y;
                 sum.z = ((v[0].z + v[1].z) + v[2].z) + v[3].z; sum.w = ((v[0].w + v[1].w) + v[2].w) + v[3].w;
-                if (ch0 + 4 * c4 < d)  // ragged last slice (D % 32 != 0; D % 4 == 0)
-                    *reinterpret_cast<float4 *>(prow + (size_t)(r0 + row) * d + ch0 + 4 * c4) = sum;
+                float *dst = prow + (size_t)(r0 + row) * d + ch0 + 4 * c4;
+                if (NBR != 1 || ch0 + 4 * c4 + 3 < d) {
+                    *reinterpret_cast<float4 *>(dst) = sum;
+                } else {  // ragged last slice (D % 32 != 0), possibly D % 4 != 0: never store past the row
+                    const float sv[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (ch0 + 4 * c4 + e < d) dst[e] = sv[e];
+                }
             }
             if (trip & 1) __builtin_amdgcn_sched_barrier(0);
         }
@@ -270,7 +276,7 @@ __device__ __forceinline__ void split8(const float (&x)[8], float scale, f16x8 &
 }
 
 __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
-    int d, int width, int height, int tile_w, int n_tiles, int slice0, int n_slices,
+    int d, int width, int height, int tile_w, int n_tiles, int ch_base, int n_slices,
     const float *__restrict__ v_render_colors, const int32_t *__restrict__ offsets, int n_isects,
     const int32_t *__restrict__ blk_rows, const int32_t *__restrict__ trow, const float *__restrict__ wt,
     const int32_t *__restrict__ gid_s, const int32_t *__restrict__ trow_s, float *__restrict__ prow,
@@ -286,7 +292,6 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (threadIdx.x < CW) zrow[threadIdx.x] = 0.f;
     const int logical = gags_xcd_remap(blockIdx.x, n_tiles * n_slices);
-    const int slice = slice0 + logical % n_slices;
     const int tile = gags_tile_of_order(logical / n_slices, tile_w, n_tiles / tile_w);
     const int start = offsets[tile];
     const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
@@ -295,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
     const int blk = wave;
     const int cnt = blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk];
     const int sb = gags_slot_base(start, end, tile, blk);
-    const int ch0 = slice * CW;
+    const int ch0 = ch_base + (logical % n_slices) * CW;
     BlockGeom64 g;
     g.init(tile, blk, tile_w, width, height, lane);
     const int p = g.p, k = g.k;  // p: channel group (channels ch0 + 4p + j) / slot; k: which 8 of a K-step's 16 pixels
@@ -393,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (mine && slice == 0) {
+            if (mine && ch0 == 0) {
                 row_key[tr_c] = (uint32_t)gid_c;
                 row_idx[tr_c] = tr_c;
             }
@@ -481,47 +486,55 @@ __global__ void seg_fill_kernel(int n_keys, int32_t *__restrict__ seg)
     if (g <= n_keys) seg[g] = 0;
 }
 
-// v_colors[g, :] = sum over the Gaussian's rows, in sorted (= deterministic) order; float4 per lane.
+// v_colors[g, :] = sum over the Gaussian's rows, in sorted (= deterministic) order; VW channels per lane (4: one float4;
+// 1: the 1-3 channels a width that is no multiple of 4 leaves over, e.g. the 513th).
 // HALF: the sum (formed in fp32) is stored as fp16 -- the gradient of an fp16 feature table in the table's own dtype,
 // instead of an fp32 tensor plus a cast pass over it (N x D x 6 bytes of traffic at C5).
-template <bool HALF>
+template <bool HALF, int VW>
 __global__ __launch_bounds__(256) void reduce_rows_kernel(int n_gauss, int d, int ch_begin, int ch_count,
                                                           const int32_t *__restrict__ seg,
                                                           const int32_t *__restrict__ sorted_rows,
                                                           const float *__restrict__ prow, void *__restrict__ v_colors_)
 {
-    const int lpg = ch_count >> 2;  // lanes per Gaussian (channels ch_begin .. ch_begin + ch_count - 1 of its row)
+    const int lpg = ch_count / VW;  // lanes per Gaussian (channels ch_begin .. ch_begin + ch_count - 1 of its row)
     const int gpb = 256 / lpg;
     const int gl = threadIdx.x / lpg;
     const int g = blockIdx.x * gpb + gl;
-    const int cl = ch_begin + (threadIdx.x % lpg) * 4;
+    const int cl = ch_begin + (threadIdx.x % lpg) * VW;
     if (gl >= gpb || g >= n_gauss) return;
     const int b = seg[g], e = seg[g + 1];
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    int i = b;
-    for (; i + 3 < e; i += 4) {
-        const int r0 = sorted_rows[i], r1 = sorted_rows[i + 1], r2 = sorted_rows[i + 2], r3 = sorted_rows[i + 3];
-        const float4 v0 = *reinterpret_cast<const float4 *>(prow + (size_t)r0 * d + cl);
-        const float4 v1 = *reinterpret_cast<const float4 *>(prow + (size_t)r1 * d + cl);
-        const float4 v2 = *reinterpret_cast<const float4 *>(prow + (size_t)r2 * d + cl);
-        const float4 v3 = *reinterpret_cast<const float4 *>(prow + (size_t)r3 * d + cl);
-        acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
-        acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
-        acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
-        acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
-    }
-    for (; i < e; ++i) {
-        const float4 v0 = *reinterpret_cast<const float4 *>(prow + (size_t)sorted_rows[i] * d + cl);
-        acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
-    }
-    if constexpr (HALF) {
-        const __half2 lo = __floats2half2_rn(acc.x, acc.y), hi = __floats2half2_rn(acc.z, acc.w);
-        uint2 w;
-        w.x = *reinterpret_cast<const unsigned *>(&lo);
-        w.y = *reinterpret_cast<const unsigned *>(&hi);
-        *reinterpret_cast<uint2 *>(reinterpret_cast<__half *>(v_colors_) + (size_t)g * d + cl) = w;
+    if constexpr (VW == 1) {
+        float acc = 0.f;
+        for (int i = b; i < e; ++i) acc += prow[(size_t)sorted_rows[i] * d + cl];
+        if constexpr (HALF) reinterpret_cast<__half *>(v_colors_)[(size_t)g * d + cl] = __float2half_rn(acc);
+        else reinterpret_cast<float *>(v_colors_)[(size_t)g * d + cl] = acc;
     } else {
-        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(v_colors_) + (size_t)g * d + cl) = acc;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int i = b;
+        for (; i + 3 < e; i += 4) {
+            const int r0 = sorted_rows[i], r1 = sorted_rows[i + 1], r2 = sorted_rows[i + 2], r3 = sorted_rows[i + 3];
+            const float4 v0 = *reinterpret_cast<const float4 *>(prow + (size_t)r0 * d + cl);
+            const float4 v1 = *reinterpret_cast<const float4 *>(prow + (size_t)r1 * d + cl);
+            const float4 v2 = *reinterpret_cast<const float4 *>(prow + (size_t)r2 * d + cl);
+            const float4 v3 = *reinterpret_cast<const float4 *>(prow + (size_t)r3 * d + cl);
+            acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+            acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+            acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+            acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+        }
+        for (; i < e; ++i) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(prow + (size_t)sorted_rows[i] * d + cl);
+            acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+        }
+        if constexpr (HALF) {
+            const __half2 lo = __floats2half2_rn(acc.x, acc.y), hi = __floats2half2_rn(acc.z, acc.w);
+            uint2 w;
+            w.x = *reinterpret_cast<const unsigned *>(&lo);
+            w.y = *reinterpret_cast<const unsigned *>(&hi);
+            *reinterpret_cast<uint2 *>(reinterpret_cast<__half *>(v_colors_) + (size_t)g * d + cl) = w;
+        } else {
+            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(v_colors_) + (size_t)g * d + cl) = acc;
+        }
     }
 }
 
@@ -679,14 +692,11 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
     const bool sA = stage == 0 || stage == 1, sS = stage == 0 || stage == 2, sR = stage == 0 || stage == 3;
     const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
     const int n_tiles = tile_w * tile_h;
-    const int nbr = d % 128 == 0 ? 4 : (d % 64 == 0 ? 2 : 1);  // channel tiles (of 32) per wave
-    // channel range of this call: whole slices (a by-view step exchanges the gradient slice by slice while the next
-    // slice is computed, gags_amd/dist.py); the default is everything
-    if (ch_count <= 0 || ch_begin < 0 || ch_begin + ch_count > d || ch_begin % (32 * nbr) != 0 ||
-        (ch_count % (32 * nbr) != 0 && ch_begin + ch_count != d))
+    // channel range of this call (a by-view step exchanges the gradient range by range while the next range is computed,
+    // gags_amd/dist.py); the default is everything.  Ranges start on a multiple of 32 and end on one or at d.
+    if (ch_count <= 0 || ch_begin < 0 || ch_begin + ch_count > d || ch_begin % 32 != 0 ||
+        (ch_count % 32 != 0 && ch_begin + ch_count != d))
         return GAGS_EINVAL;
-    const int slice0 = ch_begin / (32 * nbr);
-    const int n_slices = (ch_count + 32 * nbr - 1) / (32 * nbr);  // nbr == 1: ragged last slice
     const StagedLayout L = staged_layout(rows > 0 ? rows : 1, n_gauss, d);
     if (scratch_bytes < L.total) return GAGS_ESCRATCH;
     char *sb = (char *)scratch;
@@ -695,16 +705,23 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
     float *prow = (float *)(sb + L.prow);
     if (rows > 0) {
         if (sA) {
-            const dim3 grid(n_tiles * n_slices);
-#define GAGS_ROWS_LAUNCH(NBR)                                                                                       \
-    hipLaunchKernelGGL((raster_bwd_rows<NBR>), grid, dim3(256), 0, st, d, width, height, tile_w, n_tiles, slice0,  \
-                       n_slices, v_out, offsets, n_isects, blk_rows, trow, wt, gid_s, trow_s, prow, key, idx)
-            if (nbr == 4 && (stage_flags & 32))  // opt-in: contraction on the 16-bit matrix cores (GAGS_BWD_F16SPLIT)
-                hipLaunchKernelGGL(raster_bwd_rows_f16, grid, dim3(256), 0, st, d, width, height, tile_w, n_tiles, slice0,
-                                   n_slices, v_out, offsets, n_isects, blk_rows, trow, wt, gid_s, trow_s, prow, key, idx);
-            else if (nbr == 4) GAGS_ROWS_LAUNCH(4);
-            else if (nbr == 2) GAGS_ROWS_LAUNCH(2);
-            else GAGS_ROWS_LAUNCH(1);
+            // 128-channel slices, then 64, then 32-channel slices (the last one ragged when the range ends at an odd d)
+#define GAGS_ROWS_LAUNCH(KERNEL, CH0, NSL)                                                                           \
+    hipLaunchKernelGGL(KERNEL, dim3(n_tiles * (NSL)), dim3(256), 0, st, d, width, height, tile_w, n_tiles, (CH0), (NSL), \
+                       v_out, offsets, n_isects, blk_rows, trow, wt, gid_s, trow_s, prow, key, idx)
+            int c = ch_begin;
+            const int ce = ch_begin + ch_count;
+            if (ce - c >= 128) {
+                const int nsl = (ce - c) / 128;
+                if (stage_flags & 32) GAGS_ROWS_LAUNCH(raster_bwd_rows_f16, c, nsl);  // opt-in: 16-bit matrix cores (GAGS_BWD_F16SPLIT)
+                else GAGS_ROWS_LAUNCH(raster_bwd_rows<4>, c, nsl);
+                c += 128 * nsl;
+            }
+            if (ce - c >= 64) {
+                GAGS_ROWS_LAUNCH(raster_bwd_rows<2>, c, 1);
+                c += 64;
+            }
+            if (ce - c > 0) GAGS_ROWS_LAUNCH(raster_bwd_rows<1>, c, (ce - c + 31) / 32);
 #undef GAGS_ROWS_LAUNCH
         }
         if (sS) {
@@ -719,13 +736,20 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
         hipLaunchKernelGGL(seg_fill_kernel, dim3((n_gauss + 1 + 255) / 256), dim3(256), 0, st, n_gauss, seg);
     }
     if (sR) {
-        const int gpb = 256 / (ch_count >> 2);
-        if (stage_flags & 64)  // v_colors is an fp16 tensor
-            hipLaunchKernelGGL(reduce_rows_kernel<true>, dim3((n_gauss + gpb - 1) / gpb), dim3(256), 0, st, n_gauss, d, ch_begin,
-                               ch_count, seg, idx_s, prow, (void *)v_colors);
-        else
-            hipLaunchKernelGGL(reduce_rows_kernel<false>, dim3((n_gauss + gpb - 1) / gpb), dim3(256), 0, st, n_gauss, d, ch_begin,
-                               ch_count, seg, idx_s, prow, (void *)v_colors);
+        const bool half = (stage_flags & 64) != 0;  // v_colors is an fp16 tensor
+        const int c4 = ch_count & ~3, c1 = ch_count & 3;  // float4 lanes + the 1-3 channels an odd width leaves over
+        if (c4 > 0) {
+            const int gpb = 256 / (c4 >> 2);
+            const dim3 grid((n_gauss + gpb - 1) / gpb);
+            if (half) hipLaunchKernelGGL((reduce_rows_kernel<true, 4>), grid, dim3(256), 0, st, n_gauss, d, ch_begin, c4, seg, idx_s, prow, (void *)v_colors);
+            else hipLaunchKernelGGL((reduce_rows_kernel<false, 4>), grid, dim3(256), 0, st, n_gauss, d, ch_begin, c4, seg, idx_s, prow, (void *)v_colors);
+        }
+        if (c1 > 0) {
+            const int gpb = 256 / c1;
+            const dim3 grid((n_gauss + gpb - 1) / gpb);
+            if (half) hipLaunchKernelGGL((reduce_rows_kernel<true, 1>), grid, dim3(256), 0, st, n_gauss, d, ch_begin + c4, c1, seg, idx_s, prow, (void *)v_colors);
+            else hipLaunchKernelGGL((reduce_rows_kernel<false, 1>), grid, dim3(256), 0, st, n_gauss, d, ch_begin + c4, c1, seg, idx_s, prow, (void *)v_colors);
+        }
     }
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
@@ -1057,7 +1081,7 @@ int gags_raster_bwd_geom_launch(int d, int n_gauss, int width, int height, const
     } else {
         hipLaunchKernelGGL(seg_fill_kernel, dim3((n_gauss + 1 + 255) / 256), dim3(256), 0, st, n_gauss, seg);
     }
-    hipLaunchKernelGGL(reduce_rows_kernel<false>, dim3((n_gauss + 127) / 128), dim3(256), 0, st, n_gauss, 8, 0, 8, seg, idx_s, grow,
+    hipLaunchKernelGGL((reduce_rows_kernel<false, 4>), dim3((n_gauss + 127) / 128), dim3(256), 0, st, n_gauss, 8, 0, 8, seg, idx_s, grow,
                        (void *)v_geo);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;

@@ -121,7 +121,7 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[NB], const BlockGeo
 // wave holds TWO 32-row accumulator sets of NB channel tiles each (NB = 4: 128 channels, 128 VGPRs).
 template <int NB, bool HALF>
 __global__ __launch_bounds__(64, 2) void raster_fwd_feat(
-    int d, int width, int height, int tile_w, int n_tiles, int n_slices, int n_gauss,
+    int d, int ch_base, int width, int height, int tile_w, int n_tiles, int n_slices, int n_gauss,
     const float *__restrict__ colors, const float *__restrict__ backgrounds, const int32_t *__restrict__ offsets,
     int n_isects, const int32_t *__restrict__ blk_rows, const float *__restrict__ wt,
     const int32_t *__restrict__ gid_s, const float *__restrict__ Tbuf, float *__restrict__ render_colors)
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64, 2) void raster_fwd_feat(
     const int slice = logical % n_slices, rest = logical / n_slices;
     const int blk = rest & 3;
     const int tile = gags_tile_of_order(rest >> 2, tile_w, n_tiles / tile_w);
-    const int ch0 = slice * CS;
+    const int ch0 = ch_base + slice * CS;  // this launch covers channels ch_base .. ch_base + n_slices * CS - 1 (clipped to d)
     const int lane = threadIdx.x;
     BlockGeom64 g;
     g.init(tile, blk, tile_w, width, height, lane);
@@ -425,18 +425,58 @@ __global__ __launch_bounds__(64, (NB >= 16 ? 1 : 2)) void raster_fwd_fused(
     epilogue<NB>(acc, g, width, height, d, ch0, backgrounds, render_colors, Tq);
 }
 
+// channels [ch_base, ch_base + ch_count) in slices of 32 * NB (NB == 1: the last slice may be ragged and must end at d)
 template <int NB, bool HALF>
-int launch_feat(int d, int width, int height, int n_gauss, const float *colors, const float *backgrounds,
-                const int32_t *offsets, int n_isects, const int32_t *blk_rows, const float *wt, const int32_t *gid_s,
-                const float *Tbuf, float *out, hipStream_t st)
+int launch_feat(int d, int ch_base, int ch_count, int width, int height, int n_gauss, const float *colors,
+                const float *backgrounds, const int32_t *offsets, int n_isects, const int32_t *blk_rows, const float *wt,
+                const int32_t *gid_s, const float *Tbuf, float *out, hipStream_t st)
 {
     const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
-    const int n_tiles = tile_w * tile_h, n_slices = (d + 32 * NB - 1) / (32 * NB);  // NB == 1: ragged last slice
-    hipLaunchKernelGGL((raster_fwd_feat<NB, HALF>), dim3(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices), dim3(64), 0, st, d, width, height, tile_w,
-                       n_tiles, n_slices, n_gauss, colors, backgrounds, offsets, n_isects, blk_rows, wt, gid_s, Tbuf,
-                       out);
+    const int n_tiles = tile_w * tile_h, n_slices = (ch_count + 32 * NB - 1) / (32 * NB);
+    hipLaunchKernelGGL((raster_fwd_feat<NB, HALF>), dim3(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices), dim3(64), 0, st, d, ch_base, width,
+                       height, tile_w, n_tiles, n_slices, n_gauss, colors, backgrounds, offsets, n_isects, blk_rows, wt, gid_s,
+                       Tbuf, out);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
+}
+
+// Any width D >= 16 in one call: 128-channel slices first, then 64, then 32-channel slices of which the last may be
+// ragged (masked lanes) -- 513 = 512 CLIP channels + 1 (BASELINE.json configs[4]) is 4 wide slices + one lane of a
+// narrow one, all on the matrix cores and into ONE output tensor.  Rows of an odd width are only 4-byte (fp16 table:
+// 2-byte) aligned; vector loads / stores of global memory tolerate that on this part (unaligned access mode).
+template <bool HALF>
+int launch_feat_any(int d, int width, int height, int n_gauss, const float *colors, int f16_mfma,
+                    const float *backgrounds, const int32_t *offsets, int n_isects, const int32_t *blk_rows,
+                    const float *wt, const int32_t *gid_s, const float *Tbuf, float *out, hipStream_t st)
+{
+    int done = 0, rc = GAGS_OK;
+#define ARGS width, height, n_gauss, colors, backgrounds, offsets, n_isects, blk_rows, wt, gid_s, Tbuf, out, st
+    if (d >= 128) {
+        done = d / 128 * 128;
+        if constexpr (HALF) {
+            if (f16_mfma) {  // opt-in: the 16-bit matrix cores
+                const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
+                const int n_tiles = tile_w * tile_h, n_slices = done / 128;
+                hipLaunchKernelGGL(raster_fwd_feat_f16, dim3(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices), dim3(64), 0, st, d,
+                                   width, height, tile_w, n_tiles, n_slices, n_gauss, reinterpret_cast<const __half *>(colors),
+                                   backgrounds, offsets, n_isects, blk_rows, wt, gid_s, Tbuf, out);
+                GAGS_CHECK_LAUNCH();
+            } else {
+                rc = launch_feat<4, true>(d, 0, done, ARGS);
+            }
+        } else {
+            rc = launch_feat<4, HALF>(d, 0, done, ARGS);
+        }
+        if (rc != GAGS_OK) return rc;
+    }
+    if (d - done >= 64) {
+        rc = launch_feat<2, HALF>(d, done, 64, ARGS);
+        if (rc != GAGS_OK) return rc;
+        done += 64;
+    }
+    if (d - done > 0) rc = launch_feat<1, HALF>(d, done, d - done, ARGS);
+#undef ARGS
+    return rc;
 }
 
 template <int NB>
@@ -461,24 +501,9 @@ int gags_raster_fwd_feat_launch(int d, int width, int height, int n_gauss, const
                                 float *out, hipStream_t st)
 {
     GAGS_CLEAR_ERR();
-#define ARGS d, width, height, n_gauss, colors, backgrounds, offsets, n_isects, blk_rows, wt, gid_s, Tbuf, out, st
-    if (colors_f16 == 2 && d % 128 == 0) {  // opt-in: the 16-bit matrix cores
-        const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
-        const int n_tiles = tile_w * tile_h, n_slices = d / 128;
-        hipLaunchKernelGGL(raster_fwd_feat_f16, dim3(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices), dim3(64), 0, st, d, width, height,
-                           tile_w, n_tiles, n_slices, n_gauss, reinterpret_cast<const __half *>(colors), backgrounds, offsets,
-                           n_isects, blk_rows, wt, gid_s, Tbuf, out);
-        GAGS_CHECK_LAUNCH();
-        return GAGS_OK;
-    }
-    if (colors_f16) {
-        if (d % 128 == 0) return launch_feat<4, true>(ARGS);
-        if (d % 64 == 0) return launch_feat<2, true>(ARGS);
-        return launch_feat<1, true>(ARGS);
-    }
-    if (d % 128 == 0) return launch_feat<4, false>(ARGS);
-    if (d % 64 == 0) return launch_feat<2, false>(ARGS);
-    return launch_feat<1, false>(ARGS);
+#define ARGS backgrounds, offsets, n_isects, blk_rows, wt, gid_s, Tbuf, out, st
+    if (colors_f16) return launch_feat_any<true>(d, width, height, n_gauss, colors, colors_f16 == 2, ARGS);
+    return launch_feat_any<false>(d, width, height, n_gauss, colors, 0, ARGS);
 #undef ARGS
 }
 

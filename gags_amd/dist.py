@@ -16,6 +16,8 @@
   3 GB gradient exchange of the by-view step costs more than the whole compute, so this is the faster
   decomposition there; `bench.py --parallel auto` measures both and keeps the faster one.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -45,37 +47,24 @@ def channel_shard(d, rank=None, world_size=None, multiple=16):
     return min(lo, d), min(hi, d)
 
 
-_AG_IN_PLACE = True
-_RS_IN_PLACE = True
+# NCCL's in-place forms (reduce-scatter into the rank's own slot of the input, all-gather from it) save one staging
+# buffer of bucket / world bytes each.  They are OFF unless GAGS_DIST_INPLACE=1: the decision is made once, here, not by
+# catching an exception in the middle of a step (a collective that raised on one rank leaves the others waiting), and
+# the staging copies cost 2 x 32 MB per 256 MB bucket at 8 ranks -- nothing next to the exchange itself.
+_IN_PLACE = os.environ.get("GAGS_DIST_INPLACE", "0") == "1"
 
 
-def _reduce_scatter_in_place(shard, full):
-    """reduce-scatter whose output is the rank's own slot of the input (NCCL's in-place form).  A backend that refuses
-    aliased buffers gets a staging shard from then on."""
-    global _RS_IN_PLACE
-    if _RS_IN_PLACE:
-        try:
-            dist.reduce_scatter_tensor(shard, full)
-            return
-        except (RuntimeError, ValueError):
-            _RS_IN_PLACE = False
+def _reduce_scatter(shard, full):
+    if _IN_PLACE:
+        dist.reduce_scatter_tensor(shard, full)
+        return
     tmp = torch.empty_like(shard)
     dist.reduce_scatter_tensor(tmp, full)
     shard.copy_(tmp)
 
 
-
-def _all_gather_in_place(out, shard):
-    """all-gather whose input is the rank's own slot of the output (NCCL's in-place form: no staging copy).  A backend
-    that refuses aliased buffers costs one clone per bucket from then on."""
-    global _AG_IN_PLACE
-    if _AG_IN_PLACE:
-        try:
-            dist.all_gather_into_tensor(out, shard)
-            return
-        except (RuntimeError, ValueError):
-            _AG_IN_PLACE = False
-    dist.all_gather_into_tensor(out, shard.clone())
+def _all_gather(out, shard):
+    dist.all_gather_into_tensor(out, shard if _IN_PLACE else shard.clone())
 
 
 def reduce_feature_grad(grad, mode="rs_ag", average=False, bucket_bytes=BUCKET_BYTES):
@@ -98,8 +87,8 @@ def reduce_feature_grad(grad, mode="rs_ag", average=False, bucket_bytes=BUCKET_B
         for o in range(0, main, per):
             b = flat[o:o + per]
             shard = b.view(ws, per // ws)[dist.get_rank()]
-            _reduce_scatter_in_place(shard, b)
-            _all_gather_in_place(b, shard)
+            _reduce_scatter(shard, b)
+            _all_gather(b, shard)
         if main < numel:
             dist.all_reduce(flat[main:])
     else:
@@ -109,16 +98,61 @@ def reduce_feature_grad(grad, mode="rs_ag", average=False, bucket_bytes=BUCKET_B
     return grad
 
 
+_TYPE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+def _pack_rows(grad, idx, c0, c1, wire_dtype):
+    """wire[r, :] = grad[idx[r], c0:c1] (idx None: every row) as a fresh contiguous [rows, c1 - c0] tensor of
+    `wire_dtype`.  Device tensors: gags_pack_rows (HIP); host tensors (the gloo tests of the host logic): torch."""
+    rows = grad.shape[0] if idx is None else idx.numel()
+    if not grad.is_cuda:
+        part = grad[:, c0:c1]
+        return (part if idx is None else part.index_select(0, idx)).to(wire_dtype, copy=True).contiguous()
+    from . import _lib
+    wire = torch.empty(rows, c1 - c0, dtype=wire_dtype, device=grad.device)
+    _lib.check(_lib.load().gags_pack_rows(rows, _lib.ptr(idx), _lib.ptr(grad), _TYPE[grad.dtype], grad.shape[1], c0,
+                                          c1 - c0, _lib.ptr(wire), _TYPE[wire_dtype],
+                                          torch.cuda.current_stream().cuda_stream), "gags_pack_rows")
+    return wire
+
+
+def _unpack_rows(grad, idx, c0, c1, wire, local=None):
+    """grad[idx[r], c0:c1] = wire[r] (local None) or += wire[r] - local[r]."""
+    if not grad.is_cuda:
+        part = grad[:, c0:c1]
+        val = wire.to(grad.dtype) if local is None else (wire.float() - local.float()).to(grad.dtype)
+        if idx is None:
+            part.copy_(val) if local is None else part.add_(val)
+        elif local is None:
+            part.index_copy_(0, idx, val)
+        else:
+            part.index_add_(0, idx, val)
+        return
+    from . import _lib
+    rows = grad.shape[0] if idx is None else idx.numel()
+    _lib.check(_lib.load().gags_unpack_rows(rows, _lib.ptr(idx), _lib.ptr(wire), _TYPE[wire.dtype], _lib.ptr(local),
+                                            _lib.ptr(grad), _TYPE[grad.dtype], grad.shape[1], c0, c1 - c0,
+                                            torch.cuda.current_stream().cuda_stream), "gags_unpack_rows")
+
+
 class OverlappedGradReducer:
     """By-view step with the gradient exchange overlapped with the backward (SURVEY 8e "overlapped with the tail of
-    bwd").  Used as a context manager around `loss.backward()`: the staged backward then produces the feature
+    bwd").  Used as a context manager around ONE `loss.backward()`: the staged backward then produces the feature
     gradient one 128-channel range at a time (gags_amd.rasterization.GRAD_RANGE_HOOK) and every finished range is
-    packed, summed over the ranks and unpacked on a second stream while the next range is still being computed:
+    packed into a private buffer, summed over the ranks on a second stream while the next range is still being computed,
+    and written into the parameter's gradient by finish():
 
-        red = OverlappedGradReducer(mode="rs_ag")
+        red = OverlappedGradReducer(mode="rs_ag", param=pc._semantic_feature)
         with red:
             loss.backward()
         red.finish(pc._semantic_feature.grad)     # compute stream waits for the exchange; exact fp32 sum
+
+    The tensor autograd consumes is never written by the exchange stream (the hook only READS it); the reduced ranges
+    live in the reducer until finish().  finish() then either assigns them -- when the parameter's gradient is this
+    backward's local gradient and nothing else: `param.grad` was None on entry (known when `param` is given), or the
+    gradient tensor is the very tensor the hook saw -- or, when the gradient already holds other terms (accumulation
+    over several views, a clone with unknown history), adds `sum over ranks - local` from the packed local rows it kept.
+    A gradient that has been reduced once is never reduced again.
 
     wire="bf16" (opt-in) halves the bytes on xGMI: the range is rounded to bfloat16, summed in bfloat16 by the
     collective and widened again; the result differs from the fp32 sum by ~1e-2 relative (tests/test_dist_cpu.py
@@ -128,25 +162,30 @@ class OverlappedGradReducer:
     union (a max-all-reduce of N bytes) and every range is exchanged as the [|union|, 128] block of those rows -- the
     same collectives on fewer bytes, the same exact fp32 sum (rows outside the union are zero on every rank).
     rows="all" exchanges all N rows.
-    If autograd did not adopt the tensor the hook saw (another consumer of the gradient forced a copy), finish() falls
-    back to the plain reduction of the final gradient: always correct, overlap lost.
-    `exposed_ms()` = time the compute stream had to wait for the exchange after the backward had finished."""
+    If the backward never called the hook (narrow D, atomic kernels), finish() runs the plain reduction of the
+    untouched gradient.  `exposed_ms()` = time the compute stream spent on the exchange after the backward had finished."""
 
-    def __init__(self, mode="rs_ag", wire=None, bucket_bytes=BUCKET_BYTES, rows="union"):
+    def __init__(self, mode="rs_ag", wire=None, bucket_bytes=BUCKET_BYTES, rows="union", param=None):
         if rows not in ("union", "all"):
             raise ValueError(rows)
-        self.mode, self.wire, self.bucket_bytes, self.rows = mode, wire, bucket_bytes, rows
+        if wire not in (None, "fp32", "bf16"):
+            raise ValueError(wire)
+        self.mode, self.wire, self.bucket_bytes, self.rows, self.param = mode, wire, bucket_bytes, rows, param
         self.comm = torch.cuda.Stream() if torch.cuda.is_available() else None
         self.rows_exchanged = None  # |union| of the last step (None: all rows)
+        self.range_ms = None        # per range of the last step: ms of pack + collective on the exchange stream
         self._reset()
 
     def _reset(self):
-        self._ptr, self._covered, self._ev = None, 0, None
+        self._alias, self._covered, self._entries = None, 0, []
         self._mask, self._idx = None, None
+        self._keep_local = True
 
     def __enter__(self):
         from . import rasterization
         self._reset()
+        # the parameter's gradient will be exactly this backward's local gradient iff it does not exist yet
+        self._keep_local = not (self.param is not None and self.param.grad is None)
         self._prev = (rasterization.GRAD_RANGE_HOOK, rasterization.GRAD_ROWS_HOOK)
         rasterization.GRAD_RANGE_HOOK = self.on_range
         rasterization.GRAD_ROWS_HOOK = self.on_rows if (self.rows == "union" and world() > 1) else None
@@ -160,9 +199,8 @@ class OverlappedGradReducer:
     def on_rows(self, mask):
         """mask uint8 [N] of this rank's view; the union over the ranks is formed on the exchange stream right away
         (N bytes), its index list when the first range arrives (by then it has long finished: no stall)."""
-        if self._mask is not None:  # a second view in the same step: all rows from here on
-            self._mask, self._idx = False, None
-            return
+        if self._mask is not None or self._entries:
+            raise RuntimeError("OverlappedGradReducer: one backward per `with` block (call finish() between views)")
         if mask.is_cuda and self.comm is not None:
             ev = torch.cuda.Event()
             ev.record()
@@ -175,74 +213,82 @@ class OverlappedGradReducer:
         self._mask = mask
 
     def _union_rows(self):
-        if self._idx is None and self._mask is not None and self._mask is not False:
+        if self._idx is None and self._mask is not None:
             self._idx = torch.nonzero(self._mask).squeeze(1)  # one host sync, on the exchange stream's past work only
             self.rows_exchanged = int(self._idx.numel())
         return self._idx
 
     def _exchange(self, grad, c0, c1):
-        part = grad[:, c0:c1]
         idx = self._union_rows()
-        if idx is not None:
-            buf = part.index_select(0, idx)  # pack: the rows of the union only
-            if self.wire == "bf16":
-                w = buf.to(torch.bfloat16)
-                reduce_feature_grad(w, mode=self.mode, bucket_bytes=self.bucket_bytes)
-                buf.copy_(w)
-            elif self.wire in (None, "fp32"):
-                reduce_feature_grad(buf, mode=self.mode, bucket_bytes=self.bucket_bytes)
-            else:
-                raise ValueError(self.wire)
-            part.index_copy_(0, idx, buf)  # unpack; every other row is zero on every rank
-            return
-        self.rows_exchanged = None
-        buf = part.contiguous()  # pack (a copy unless the range is the whole row)
-        if self.wire == "bf16":
-            w = buf.to(torch.bfloat16)
-            reduce_feature_grad(w, mode=self.mode, bucket_bytes=self.bucket_bytes)
-            buf.copy_(w)
-        elif self.wire in (None, "fp32"):
-            reduce_feature_grad(buf, mode=self.mode, bucket_bytes=self.bucket_bytes)
-        else:
-            raise ValueError(self.wire)
-        if buf.data_ptr() != part.data_ptr():
-            part.copy_(buf)  # unpack
+        if idx is None:
+            self.rows_exchanged = None
+        wire = _pack_rows(grad, idx, c0, c1, torch.bfloat16 if self.wire == "bf16" else torch.float32)
+        local = wire.clone() if self._keep_local else None
+        reduce_feature_grad(wire, mode=self.mode, bucket_bytes=self.bucket_bytes)
+        return dict(c0=c0, c1=c1, wire=wire, local=local, idx=idx)
 
     def on_range(self, grad, c0, c1):
-        if world() > 1:
-            if grad.is_cuda and self.comm is not None:
-                ev = torch.cuda.Event()
-                ev.record()  # the range's kernels, on the compute stream
-                with torch.cuda.stream(self.comm):
-                    # the union's index list BEFORE the exchange stream is made to wait for this range: its host sync
-                    # then covers the mask all-reduce only, while the GPU still has this whole range queued
-                    self._union_rows()
-                    self.comm.wait_event(ev)
-                    self._exchange(grad, c0, c1)
-                grad.record_stream(self.comm)
-            else:
-                self._exchange(grad, c0, c1)
-        self._ptr = grad.data_ptr()
+        if any(e["c0"] < c1 and c0 < e["c1"] for e in self._entries) or (
+                self._alias is not None and self._alias.data_ptr() != grad.data_ptr()):
+            raise RuntimeError("OverlappedGradReducer: one backward per `with` block (call finish() between views)")
+        self._alias = grad
         self._covered += c1 - c0
+        if world() == 1:
+            return
+        if grad.is_cuda and self.comm is not None:
+            ev = torch.cuda.Event()
+            ev.record()  # the range's kernels, on the compute stream
+            with torch.cuda.stream(self.comm):
+                # the union's index list BEFORE the exchange stream is made to wait for this range: its host sync
+                # then covers the mask all-reduce only, while the GPU still has this whole range queued
+                self._union_rows()
+                self.comm.wait_event(ev)
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record()
+                e = self._exchange(grad, c0, c1)  # reads `grad`, writes private buffers only
+                t1.record()
+                e["ev"] = (t0, t1)
+            grad.record_stream(self.comm)
+        else:
+            e = self._exchange(grad, c0, c1)
+        self._entries.append(e)
 
     def finish(self, param_grad):
-        """Make the reduced gradient visible to the compute stream; returns True if the overlapped exchange was used."""
+        """Bring the sum over the ranks into `param_grad` on the compute stream; returns True if the overlapped exchange
+        was used (False: plain reduction of the whole gradient)."""
         cuda = param_grad.is_cuda and self.comm is not None
         if cuda:
             self._bwd_done = torch.cuda.Event(enable_timing=True)
             self._bwd_done.record()
             torch.cuda.current_stream().wait_stream(self.comm)
+        ws = world()
+        used = ws > 1 and bool(self._entries) and self._covered == param_grad.shape[1]
+        if self._entries and not used:
+            raise RuntimeError(f"OverlappedGradReducer: the backward delivered {self._covered} of "
+                               f"{param_grad.shape[1]} channels")
+        if used:
+            adopted = self._alias is not None and self._alias.data_ptr() == param_grad.data_ptr()
+            for e in self._entries:
+                assign = (not self._keep_local) or adopted
+                _unpack_rows(param_grad, e["idx"], e["c0"], e["c1"], e["wire"], None if assign else e["local"])
+                if cuda:
+                    e["wire"].record_stream(torch.cuda.current_stream())
+                    if e["local"] is not None:
+                        e["local"].record_stream(torch.cuda.current_stream())
+        elif ws > 1:
+            reduce_feature_grad(param_grad, mode=self.mode, bucket_bytes=self.bucket_bytes)
+        if cuda:
             self._all_done = torch.cuda.Event(enable_timing=True)
             self._all_done.record()
-        used = self._ptr == param_grad.data_ptr() and self._covered == param_grad.shape[1]
-        if not used and world() > 1:
-            reduce_feature_grad(param_grad, mode=self.mode, bucket_bytes=self.bucket_bytes)
+        self._timed = [e["ev"] for e in self._entries if "ev" in e]
+        self._entries, self._alias, self._mask, self._covered = [], None, None, 0
         return used
 
     def exposed_ms(self):
         if getattr(self, "_all_done", None) is None:
             return 0.0
         self._all_done.synchronize()
+        self.range_ms = [float(a.elapsed_time(b)) for a, b in getattr(self, "_timed", [])]
         return float(self._bwd_done.elapsed_time(self._all_done))
 
 

@@ -37,7 +37,6 @@ GRAD_RANGE_CHANNELS = 128
 # "gradients are sparse in rows"); the exchange then moves the union of these rows over the ranks instead of all N.
 GRAD_ROWS_HOOK = None
 MAX_ISECTS = 1 << 27  # limit of the C ABI (int32 slot indices: 4 slots per intersection)
-SCRATCH_CHECK_BYTES = 8 << 30  # above this the split forward first checks that its scratch fits in free memory
 
 
 def _stream():
@@ -187,9 +186,9 @@ def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height, conics=
 
 
 def _mfma_width(d):
-    """Feature widths served by the split matrix-core path (gags_mfma_width in csrc/common.h): multiples of 32, and
-    multiples of 4 from 16 up -- 16 is what the reference rasterizes (train.py:68)."""
-    return d >= 16 and d % 4 == 0
+    """Feature widths served by the split matrix-core path (gags_mfma_width in csrc/common.h): every D >= 16 -- 16 is
+    what the reference rasterizes (train.py:68), 513 = 512 + 1 is BASELINE.json configs[4]."""
+    return d >= 16
 
 
 class _Rasterize(torch.autograd.Function):
@@ -221,21 +220,26 @@ class _Rasterize(torch.autograd.Function):
         nbytes = 0
         if split:
             nbytes = lib.gags_raster_fwd_scratch_bytes(n_isects, width, height)
-            if nbytes > SCRATCH_CHECK_BYTES and nbytes > 0.8 * torch.cuda.mem_get_info(dev)[0]:
-                split, nbytes = False, 0  # slot space (1 KB per intersection) does not fit: scratch-free kernels
+            try:
+                scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            except torch.OutOfMemoryError:
+                # slot space (1 KB per intersection) does not fit even after the caching allocator gave its blocks
+                # back: scratch-free kernels, which read an fp32 table only
+                split, nbytes, scratch = False, 0, None
+                if half:
+                    half, colors = False, colors.float()
         if split:
-            scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             blk_rows = torch.empty(offsets.numel() * 4, dtype=torch.int32, device=dev)  # per 8x8 pixel block
         with profiler.stage("raster_fwd"):
             check(lib.gags_raster_fwd(d, n, width, height, ptr(means2d), ptr(conics), ptr(opacities), ptr(colors),
                                       ptr(backgrounds), ptr(offsets), ptr(flatten_ids), n_isects, ptr(packed),
                                       ptr(out), ptr(alphas), ptr(last_ids), ptr(scratch), nbytes, ptr(blk_rows),
                                       (flags & 3) | _lib.GAGS_RECS_BY_GAUSSIAN | (_lib.GAGS_FEAT_F16 if half else 0)
-                                      | (64 if (half and d % 128 == 0 and (flags & _lib.GAGS_FWD_F16MFMA)) else 0),
+                                      | (64 if (half and d >= 128 and (flags & _lib.GAGS_FWD_F16MFMA)) else 0),
                                       _stream()), "gags_raster_fwd")
         need_geom = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[3]
         # wide-D geometry gradients on the matrix cores (gags_raster_bwd_geom) also consume the forward's scratch
-        geom_mfma = split and need_geom and _geom_mfma_width(d) and not half and not (flags & _lib.GAGS_BWD_ATOMIC)
+        geom_mfma = split and need_geom and _geom_mfma_width(d) and not (flags & _lib.GAGS_BWD_ATOMIC)
         staged = (split and _mfma_width(d) and d <= 1024 and (ctx.needs_input_grad[2] or geom_mfma)
                   and not (flags & _lib.GAGS_BWD_ATOMIC))
         ctx.geom_mfma = bool(geom_mfma and staged)
@@ -273,7 +277,10 @@ class _Rasterize(torch.autograd.Function):
             v_colors = None
             if ctx.needs_input_grad[2]:
                 v_colors = _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height,
-                                            32 if (flags & _lib.GAGS_BWD_F16SPLIT) else 0, flatten_ids)
+                                            (32 if (flags & _lib.GAGS_BWD_F16SPLIT) else 0) | (64 if ctx.half else 0),
+                                            flatten_ids)
+            if ctx.half:  # the geometry kernels read an fp32 table: widen the halves (exact) for this backward
+                colors = colors.float()
             # compact numbering of the per-slot rows: one small prefix sum and a 4-byte readback instead of sorting the
             # whole sparse slot space (6x the keys)
             incl = torch.cumsum(blk_rows, 0, dtype=torch.int32)
@@ -290,8 +297,8 @@ class _Rasterize(torch.autograd.Function):
                       "gags_raster_bwd_geom")
             v_con, v_m2d, v_opac = v_geo[:, 0:3].contiguous(), v_geo[:, 3:5].contiguous(), v_geo[:, 5].contiguous()
             return v_m2d, v_con, v_colors, v_opac, v_bg, None, None, None, None, None, None
-        if ctx.half:
-            raise NotImplementedError("fp16 feature table: only the colours-only (feature distillation) backward is implemented")
+        if ctx.half:  # VALU / atomic kernels read an fp32 table: widen the halves (exact); gradient returned in the table's dtype
+            colors = colors.float()
         v_colors = torch.zeros(n, d, device=dev)
         if need_geom:
             v_opac = torch.zeros(n, device=dev)
@@ -306,6 +313,8 @@ class _Rasterize(torch.autograd.Function):
                                       ptr(backgrounds), ptr(offsets), ptr(flatten_ids), n_isects, ptr(packed),
                                       ptr(alphas), ptr(last_ids), ptr(v_out), ptr(v_alphas), ptr(v_colors),
                                       ptr(v_opac), ptr(v_m2d), ptr(v_con), bflags, _stream()), "gags_raster_bwd")
+        if ctx.half:
+            v_colors = v_colors.half()
         return v_m2d, v_con, v_colors, v_opac, v_bg, None, None, None, None, None, None
 
 
@@ -427,23 +436,14 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
 
     with torch.no_grad(), profiler.stage("binning"):
         dcols = cols.shape[-1]
-        wide = _mfma_width(dcols) or (dcols > 32 and dcols % 4 != 0)  # matrix-core path wants packed records
+        wide = _mfma_width(dcols)  # the matrix-core path wants packed records
         isect_ids, flatten_ids, isect_offsets, n_isects, packed = tile_binning(
             means2d, radii, depths, tiles, width, height, conics if wide else None, _c(opacities) if wide else None)
 
-    dfull = cols.shape[-1]
-    if dfull > 32 and dfull % 4 != 0:
-        # e.g. 513 = 512 CLIP channels + 1 (BASELINE.json configs[4] "512-d feat + granularity"): the multiple-of-4 part
-        # runs on the matrix cores, the 1-3 remaining channels on the VALU kernels; same lists, same alpha / T (A12)
-        dm = dfull - dfull % 4
-        o1, alphas, last_ids = _Rasterize.apply(means2d, conics, cols[:, :dm], opacities, None if bg is None else bg[:dm],
-                                                isect_offsets, flatten_ids, packed, width, height, int(raster_flags))
-        o2, _, _ = _Rasterize.apply(means2d, conics, cols[:, dm:].float(), opacities, None if bg is None else bg[dm:],
-                                    isect_offsets, flatten_ids, None, width, height, int(raster_flags))
-        out = torch.cat([o1, o2], dim=-1)
-    else:
-        out, alphas, last_ids = _Rasterize.apply(means2d, conics, cols, opacities, bg, isect_offsets, flatten_ids,
-                                                 packed, width, height, int(raster_flags))
+    # any width in ONE rasterization: 513 = 512 CLIP channels + 1 (BASELINE.json configs[4] "512-d feat + granularity") is
+    # four 128-channel slices and one lane of a narrow slice on the same matrix-core kernels, into one output tensor
+    out, alphas, last_ids = _Rasterize.apply(means2d, conics, cols, opacities, bg, isect_offsets, flatten_ids,
+                                             packed, width, height, int(raster_flags))
     if render_mode in ("ED", "RGB+ED"):
         if out.requires_grad:
             out = torch.cat([out[..., :-1], out[..., -1:] / alphas[..., None].clamp(min=1e-10)], dim=-1)

@@ -257,6 +257,18 @@ int gags_ed_normalize(int64_t n_pix, int d, float *render_colors, const float *r
 int gags_adam_step(int64_t numel, float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                    double lr, double beta1, double beta2, double eps, int step, void *stream);
 
+/* Multi-GPU by-view step (north_star "RCCL all-reduce of feature/geometry gradients"): the exchange itself is
+ * torch.distributed over RCCL; these two kernels move the rows that can be non-zero between the gradient [N, d] and
+ * the dense wire block [n_rows, cw] of one channel range [c0, c0 + cw).  idx: int64 row numbers (device; NULL = all rows,
+ * n_rows = N).  Element types: 0 fp32, 1 fp16, 2 bf16 (wire only).
+ *   gags_pack_rows  : wire[r, :] = grad[idx[r], c0 : c0 + cw]
+ *   gags_unpack_rows: local == NULL: grad[idx[r], c0 : c0 + cw]  = wire[r, :]
+ *                     local != NULL: grad[idx[r], c0 : c0 + cw] += wire[r, :] - local[r, :]   (local: same type as wire) */
+int gags_pack_rows(int64_t n_rows, const int64_t *idx, const void *grad, int grad_type, int d, int c0, int cw,
+                   void *wire, int wire_type, void *stream);
+int gags_unpack_rows(int64_t n_rows, const int64_t *idx, const void *wire, int wire_type, const void *local,
+                     void *grad, int grad_type, int d, int c0, int cw, void *stream);
+
 /* Harness helper (the build's own synthetic step): out[0] = <x, y> over `numel` floats,
  * the terminal loss `(render * G).sum()` of bench.py; reproducible (fixed grid and order).
  * scratch: gags_dot_scratch_bytes() bytes; x, y 16-B aligned. */

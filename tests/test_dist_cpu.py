@@ -119,7 +119,9 @@ def test_channel_sharded_step_two_ranks():
 
 def _overlap_worker(rank, world, port, wire, q):
     """OverlappedGradReducer fed range by range the way the staged backward feeds it (gags_amd/rasterization.py):
-    exact fp32 sum on the default wire; bfloat16 wire within its stated bound; fallback when autograd copied."""
+    exact fp32 sum on the default wire; bfloat16 wire within its stated bound; and every way autograd may hand the
+    gradient on -- adopted, copied, accumulated onto an existing gradient, behind a dtype cast -- must end with the
+    sum over the ranks ONCE (a copied gradient used to be reduced a second time)."""
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -128,20 +130,69 @@ def _overlap_worker(rank, world, port, wire, q):
     n, d = 333, 512
     grads = [torch.randn(n, d, generator=torch.Generator().manual_seed(7 + r)) for r in range(world)]
     expect = sum(grads)
+    rel = lambda a, b: ((a - b).double().norm() / b.double().norm()).item()
+
+    def feed(red, local):
+        with red:
+            assert rasterization.GRAD_RANGE_HOOK is not None
+            for c0 in range(0, d, 128):
+                rasterization.GRAD_RANGE_HOOK(local.detach(), c0, c0 + 128)  # alias with its own TensorImpl
+        assert rasterization.GRAD_RANGE_HOOK is None
+
+    out = {}
+    mode = "allreduce" if wire == "bf16" else "rs_ag"
+    # 1. adopted: autograd keeps the very tensor the hook saw
     grad = grads[rank].clone()
-    red = OverlappedGradReducer(mode="allreduce" if wire == "bf16" else "rs_ag", wire=wire, bucket_bytes=8192)
+    red = OverlappedGradReducer(mode=mode, wire=wire, bucket_bytes=8192)
+    feed(red, grad)
+    out["adopted"] = (red.finish(grad), rel(grad, expect))
+    # 2. copied: another consumer forced a clone (param unknown: the reducer falls back on local + (sum - local))
+    local = grads[rank].clone()
+    feed(red, local)
+    copied = local * 1.0
+    out["copied"] = (red.finish(copied), rel(copied, expect))
+    assert torch.equal(local, grads[rank])  # the tensor autograd consumed was never written by the exchange
+    # 3. accumulated onto an existing gradient (a second view of the step)
+    old = torch.randn(n, d, generator=torch.Generator().manual_seed(99))
+    local = grads[rank].clone()
+    feed(red, local)
+    acc = old + local
+    out["accumulated"] = (red.finish(acc), rel(acc, old + expect))
+    # 4. param known and its gradient None on entry: assignment even when autograd cloned (bit-identical to case 1)
+    prm = torch.nn.Parameter(torch.zeros(n, d))
+    red_p = OverlappedGradReducer(mode=mode, wire=wire, bucket_bytes=8192, param=prm)
+    local = grads[rank].clone()
+    feed(red_p, local)
+    prm.grad = local.clone()
+    out["param_fresh"] = (red_p.finish(prm.grad), rel(prm.grad, expect), bool(torch.equal(prm.grad, grad)))
+    # 4b. the same parameter with a gradient already there: the next block accumulates
+    local = grads[rank].clone()
+    feed(red_p, local)
+    before = prm.grad.clone()
+    prm.grad += local
+    out["param_accumulate"] = (red_p.finish(prm.grad), rel(prm.grad, before + expect))
+    # 5. an fp32 master gradient behind a cast of the table's fp16 gradient
+    if wire is None:
+        l16 = grads[rank].half()
+        red_h = OverlappedGradReducer(mode=mode, bucket_bytes=8192, param=torch.nn.Parameter(torch.zeros(1)))
+        feed(red_h, l16)
+        master = l16.float()  # what autograd's cast node hands the fp32 master parameter
+        out["cast"] = (red_h.finish(master), rel(master, sum(g.half().float() for g in grads)))
+    # 6. a gradient the hook never saw in this block: finish() reduces it itself, once
     with red:
-        assert rasterization.GRAD_RANGE_HOOK is not None
-        for c0 in range(0, d, 128):
-            rasterization.GRAD_RANGE_HOOK(grad.detach(), c0, c0 + 128)  # alias with its own TensorImpl
-    assert rasterization.GRAD_RANGE_HOOK is None
-    used = red.finish(grad)
-    err = ((grad - expect).double().norm() / expect.double().norm()).item()
-    # a gradient the hook never saw (autograd made a copy): finish() must reduce it itself
+        pass
     other = grads[rank].clone()
-    used2 = red.finish(other)
-    err2 = ((other - expect).double().norm() / expect.double().norm()).item()
-    q.put((rank, used, err, used2, err2))
+    out["unseen"] = (red.finish(other), rel(other, expect))
+    # 7. two backwards inside one block are refused, not silently mixed
+    try:
+        with red:
+            for _ in range(2):
+                rasterization.GRAD_RANGE_HOOK(grads[rank].clone().detach(), 0, 128)
+        out["second_refused"] = False
+    except RuntimeError:
+        out["second_refused"] = True
+        red._reset()
+    q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -160,9 +211,14 @@ def test_overlapped_reducer_two_ranks(wire, tol):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for _, used, err, used2, err2 in res:
-        assert used and err <= tol
-        assert not used2 and err2 <= 1e-6  # the fallback is always the exact fp32 reduction
+    for _, out in res:
+        for case in ("adopted", "copied", "accumulated", "param_fresh", "param_accumulate"):
+            assert out[case][0] and out[case][1] <= tol, (case, out[case])
+        assert out["param_fresh"][2]
+        if wire is None:
+            assert out["cast"][0] and out["cast"][1] <= 1e-6, out["cast"]
+        assert not out["unseen"][0] and out["unseen"][1] <= 1e-6  # the plain path is always the exact fp32 reduction
+        assert out["second_refused"]
 
 
 def _union_worker(rank, world, port, q):

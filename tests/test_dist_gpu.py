@@ -204,3 +204,27 @@ def test_rs_ag_on_device_tensors_over_rccl():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(a and b for _, a, b in res)
+
+
+def test_bench_two_ranks_under_torch_distributed_run():
+    """The whole N > 1 control flow of bench.py exactly as the driver launches it (python -m torch.distributed.run
+    --nproc-per-node 2 ... bench.py --gpus 2), both ranks on the one GPU of this box with gloo as the transport (RCCL
+    needs one GPU per rank): overlapped by-view step, union-of-rows exchange, the JSON line's multi-GPU fields."""
+    import json
+    import subprocess
+    env = dict(os.environ, GAGS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--config", "C2", "--n", "20000", "--d", "256", "--no-cpu-baseline", "--no-heavy"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and line["value"] > 0
+    ge = line["config"]["grad_exchange"]
+    assert ge["overlapped_with_backward"] is True and ge["rows"] == "union"
+    assert ge["exposed_ms_last_step"] is not None and ge["exposed_ms_last_step"] >= 0.0
+    assert 0 < ge["rows_exchanged_last_step"] <= 20000
+    assert len(ge["range_exchange_ms_last_step"]) == 2  # two 128-channel ranges at D = 256
+    assert "view-dp2" in line["config"]["parallelism"]

@@ -206,10 +206,12 @@ def test_fp16_table_on_the_16bit_matrix_cores(oracle):
     assert rel_l2(res[0][1], o_vf) <= 5e-4                # gradient returned in fp16
 
 
-@pytest.mark.parametrize("d", [37, 513])
+@pytest.mark.parametrize("d", [17, 37, 130, 197, 513])
 def test_width_with_extra_channels(oracle, d):
-    """D = 4k + r (513 = 512 CLIP channels + 1, configs[4]): matrix cores for the multiple-of-4 part, VALU kernels for
-    the rest, one binning; bit-exact forward, gradients for every column."""
+    """Any D >= 16 is ONE rasterization on the matrix cores (513 = 512 CLIP channels + 1, BASELINE.json configs[4]): 128-
+    channel slices, then 64, then 32-channel slices with a ragged last one; rows of an odd width are only 4-byte
+    aligned.  Bit-exact forward, every gradient column from the atomic-free staged backward (forward-order sums),
+    bit-reproducible."""
     n, w, h = 2500, 144, 112
     s = scene_arrays(n, d, w, h, seed=52, view=6, scale_mult=5.0)
     bg = np.linspace(0.0, 1.0, d).astype(np.float32)
@@ -221,12 +223,77 @@ def test_width_with_extra_channels(oracle, d):
     np.testing.assert_array_equal(out, o_out)
     o_vf = oracle.raster_bwd_colors_fwdorder(oinfo["means2d"], oinfo["conics"], s["opacities"], d, w, h, oinfo["isect_offsets"],
                                              oinfo["flatten_ids"], v_out, n)
-    o_vc, _, _, _ = oracle.raster_bwd(oinfo["means2d"], oinfo["conics"], s["opacities"], s["colors"], bg, w, h,
-                                      oinfo["isect_offsets"], oinfo["flatten_ids"], o_alpha, oinfo["last_ids"], v_out, None,
-                                      colors_only=True)
-    dm = d - d % 4
-    assert rel_l2(grads["colors"][:, :dm], o_vf[:, :dm]) <= GRAD_TOL       # matrix-core part: forward-order sums
-    assert rel_l2(grads["colors"][:, dm:], o_vc[:, dm:]) <= 1e-4           # VALU part: gsplat-order sums, float atomics
+    assert rel_l2(grads["colors"], o_vf) <= GRAD_TOL
+    for c in range(d - d % 32, d):  # the ragged slice, column by column
+        assert rel_l2(grads["colors"][:, c], o_vf[:, c]) <= GRAD_TOL, c
+    _, _, _, grads2 = _run_gpu(s, w, h, s["colors"], bg, v_out=v_out)
+    np.testing.assert_array_equal(grads["colors"], grads2["colors"])
+
+
+@pytest.mark.parametrize("flags", ["exact", "f16mfma"])
+def test_fp16_table_with_513_channels(oracle, flags):
+    """BASELINE.json configs[4] as stated: fp16 feature table AND 512 + 1 channels together (rows 1026 bytes: 2-byte
+    aligned).  Default: bit-exact on the rounded table; opt-in 16-bit matrix cores: <= 2e-6.  Gradient in fp16."""
+    from gags_amd import _lib
+    from gags_amd.rasterization import rasterization
+    n, w, h, d = 3000, 160, 128, 513
+    s = scene_arrays(n, d, w, h, seed=53, view=3, scale_mult=5.0)
+    table = torch.from_numpy(s["colors"]).half()
+    bg = np.linspace(0.0, 1.0, d).astype(np.float32)
+    v_out = np.random.default_rng(7).standard_normal((h, w, d)).astype(np.float32)
+    o_out, o_alpha, oinfo = oracle.rasterization(s["means"], s["quats"], s["scales"], s["opacities"], table.float().numpy(),
+                                                 s["viewmat"], s["K"], bg, w, h)
+    o_vf = oracle.raster_bwd_colors_fwdorder(oinfo["means2d"], oinfo["conics"], s["opacities"], d, w, h, oinfo["isect_offsets"],
+                                             oinfo["flatten_ids"], v_out, n)
+    cols = table.cuda().requires_grad_(True)
+    rf = 0 if flags == "exact" else (_lib.GAGS_FWD_F16MFMA | _lib.GAGS_BWD_F16SPLIT)
+    out, alphas, info = rasterization(to_dev(s["means"]), to_dev(s["quats"]), to_dev(s["scales"]), to_dev(s["opacities"]), cols,
+                                      to_dev(s["viewmat"])[None], to_dev(s["K"])[None], w, h, backgrounds=to_dev(bg)[None],
+                                      raster_flags=rf)
+    assert out.shape == (1, h, w, d)
+    np.testing.assert_array_equal(alphas[0, ..., 0].detach().cpu().numpy(), o_alpha)
+    if flags == "exact":
+        np.testing.assert_array_equal(out[0].detach().cpu().numpy(), o_out)
+    else:
+        assert rel_l2(out[0].detach().cpu().numpy(), o_out) <= 2e-6
+        np.testing.assert_array_equal(out[0, ..., 512:].detach().cpu().numpy(), o_out[..., 512:])  # the tail slice stays exact
+    (out[0] * to_dev(v_out)).sum().backward()
+    assert cols.grad.dtype == torch.float16 and cols.grad.shape == (n, d)
+    g = cols.grad.float().cpu().numpy()
+    assert rel_l2(g, o_vf) <= 5e-4
+    assert rel_l2(g[:, 512], o_vf[:, 512]) <= 5e-4
+
+
+def test_fp16_table_with_geometry_gradients(oracle):
+    """An fp16 feature table in joint training (every parameter requires grad): geometry gradients are computed from the
+    exactly widened table and agree with the oracle on the rounded table; the table's own gradient comes back in fp16."""
+    from gags_amd.rasterization import rasterization
+    n, w, h, d = 3000, 160, 128, 64
+    s = scene_arrays(n, d, w, h, seed=54, view=2, scale_mult=5.0)
+    table = torch.from_numpy(s["colors"]).half()
+    rounded = table.float().numpy()
+    bg = np.full(d, 0.3, np.float32)
+    rng = np.random.default_rng(9)
+    v_out = rng.standard_normal((h, w, d)).astype(np.float32)
+    v_alpha = rng.standard_normal((h, w)).astype(np.float32)
+    o_out, o_alpha, oinfo = oracle.rasterization(s["means"], s["quats"], s["scales"], s["opacities"], rounded, s["viewmat"],
+                                                 s["K"], bg, w, h)
+    o_vc, o_vo, o_vm, o_vcon = oracle.raster_bwd(oinfo["means2d"], oinfo["conics"], s["opacities"], rounded, bg, w, h,
+                                                 oinfo["isect_offsets"], oinfo["flatten_ids"], o_alpha, oinfo["last_ids"],
+                                                 v_out, v_alpha)
+    cols = table.cuda().requires_grad_(True)
+    opac = to_dev(s["opacities"]).requires_grad_(True)
+    means = to_dev(s["means"]).requires_grad_(True)
+    out, alphas, info = rasterization(means, to_dev(s["quats"]), to_dev(s["scales"]), opac, cols, to_dev(s["viewmat"])[None],
+                                      to_dev(s["K"])[None], w, h, backgrounds=to_dev(bg)[None])
+    np.testing.assert_array_equal(out[0].detach().cpu().numpy(), o_out)
+    info["means2d"].retain_grad()
+    ((out[0] * to_dev(v_out)).sum() + (alphas[0, ..., 0] * to_dev(v_alpha)).sum()).backward()
+    assert cols.grad.dtype == torch.float16
+    assert rel_l2(cols.grad.float().cpu().numpy(), o_vc) <= 5e-4
+    assert rel_l2(opac.grad.cpu().numpy(), o_vo) <= 2e-4
+    assert rel_l2(info["means2d"].grad[0].cpu().numpy(), o_vm) <= 2e-4
+    assert means.grad is not None and torch.isfinite(means.grad).all()
 
 
 def test_backward_on_the_16bit_matrix_cores_is_within_tolerance(oracle):
