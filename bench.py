@@ -243,6 +243,7 @@ def main():
             views = [first + rank] if world > 1 else [None]
         pc_ = syn.make_model(n, dl, width, height, seed=0, device=dev, gen_device=dev, scale0=scale0)
         pc_.training_setup()
+        pc_.cache_activations(True)  # geometry frozen for the whole run (GAD stage, train.py:62-75): getters evaluated once
         cams = [syn.make_camera(width, height, view=(v % 8) if v is not None else None, device=dev) for v in views]
         G_ = syn.make_cotangent(dl, height, width, seed=1, device=dev)  # [D,H,W] view of [H,W,D] memory
 

@@ -79,12 +79,26 @@ class GaussianModel:
         self.optimizer = None
 
     # -- activations: scene/gaussian_model.py:36-42,116-139 -------------------------------
+    def cache_activations(self, on=True):
+        """Opt-in: keep the activations of FROZEN parameters (requires_grad False: the geometry during the reference's
+        feature training, train.py:62-75) between renders instead of re-evaluating exp / normalize / sigmoid on every
+        getter call as scene/gaussian_model.py:116-139 does (six small kernels per view).  OFF by default: a cached value
+        cannot see writes that bypass autograd's version counter (`p.data.add_(...)`, `p.data.copy_(...)` -- idiomatic
+        in 3DGS code for opacity resets, clamping and weight loading), so whoever turns this on promises to call
+        `invalidate_activations()` after such a write.  In-place ops on the parameter itself, replacing the parameter,
+        load_ply / restore, and requires_grad are noticed without help."""
+        self._cache_on = bool(on)
+        self.invalidate_activations()
+        return self
+
+    def invalidate_activations(self):
+        self.__dict__["_act_cache"] = {}
+
     def _frozen(self, name, param, fn):
-        """Activation of a FROZEN parameter (requires_grad False: the geometry during the reference's feature training,
-        train.py:62-75), recomputed only when the parameter object, its storage or its version counter changed -- the
-        reference evaluates these getters (scene/gaussian_model.py:116-139) on every render, six small kernels per view.
-        A parameter that requires grad is always evaluated afresh (autograd needs the graph)."""
-        if param.requires_grad or torch.is_grad_enabled() and param.grad_fn is not None:
+        """Activation of a parameter: evaluated afresh on every call (the reference's behaviour) unless
+        cache_activations() was turned on and the parameter is frozen."""
+        if (not getattr(self, "_cache_on", False) or param.requires_grad
+                or torch.is_grad_enabled() and param.grad_fn is not None):
             return fn(param)
         cache = self.__dict__.setdefault("_act_cache", {})
         key = (id(param), param.data_ptr(), param._version, tuple(param.shape))
@@ -150,6 +164,7 @@ class GaussianModel:
                              self._rotation, self._semantic_feature)
 
     def load_ply(self, path, device="cuda"):
+        self.invalidate_activations()
         from . import io_formats
         t = {k: (None if v is None else torch.from_numpy(np.array(v)).to(device)) for k, v in
              io_formats.read_ply(path, self.max_sh_degree).items()}
@@ -174,6 +189,7 @@ class GaussianModel:
     def restore(self, model_args, semantic_feature_lr=0.001, semantic_dim=16):
         """12-tuple (RGB field: features start from zeros, train.py:82-94) or 13-tuple (feature field: features and
         optimizer state are taken over), as scene/gaussian_model.py:80-113."""
+        self.invalidate_activations()
         if len(model_args) not in (12, 13):
             raise ValueError("checkpoint tuple must have 12 or 13 entries")
         (self.active_sh_degree, self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation,

@@ -67,11 +67,17 @@ def test_workload_meets_the_declared_intent(oracle):
 def test_frozen_activations_are_cached_and_invalidated():
     """GaussianModel getters of frozen geometry (scene/gaussian_model.py:116-139 recomputes exp / normalize / sigmoid on
     every render): cached per parameter version; an in-place update, a new tensor, or requires_grad bring back a fresh
-    evaluation."""
+    evaluation.  The cache is OPT-IN (`.data` writes bypass the version counter): by default every getter
+    call evaluates afresh, exactly like the reference."""
     import torch
     from gags_amd.scene import GaussianModel
     m = GaussianModel(3)
     n = 50
+    m._scaling = torch.nn.Parameter(torch.zeros(n, 3), requires_grad=False)
+    first = m.get_scaling
+    m._scaling.data.add_(1.0)                     # invisible to _version
+    assert m.get_scaling is not first and torch.equal(m.get_scaling, torch.exp(m._scaling))
+    m.cache_activations(True)
     g = torch.Generator().manual_seed(0)
     m._scaling = torch.nn.Parameter(torch.randn(n, 3, generator=g), requires_grad=False)
     m._rotation = torch.nn.Parameter(torch.randn(n, 4, generator=g), requires_grad=False)
@@ -84,6 +90,11 @@ def test_frozen_activations_are_cached_and_invalidated():
     assert b is not a and torch.equal(b, torch.exp(m._scaling))
     m._scaling = torch.nn.Parameter(torch.zeros(n, 3), requires_grad=False)   # replaced
     assert torch.equal(m.get_scaling, torch.ones(n, 3))
+    stale = m.get_scaling
+    m._scaling.data.add_(1.0)                     # the documented blind spot of the opt-in cache ...
+    assert m.get_scaling is stale
+    m.invalidate_activations()                    # ... and its remedy
+    assert torch.equal(m.get_scaling, torch.exp(m._scaling))
     m._opacity.requires_grad_(True)               # trainable again: always evaluated, with a graph
     o = m.get_opacity
     assert o.requires_grad and m.get_opacity is not o

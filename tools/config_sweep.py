@@ -20,6 +20,7 @@ dev = torch.device("cuda", 0)
 def run(name, n, w, h, d, half=False, steps=8, flags=0, full_grad=False):
     pc = syn.make_model(n, d, w, h, seed=0, device=dev, gen_device=dev)
     pc.training_setup()
+    pc.cache_activations(True)  # geometry frozen for the whole run (GAD stage, train.py:62-75): getters evaluated once
     geo = [pc._xyz, pc._scaling, pc._rotation, pc._opacity]
     if full_grad:  # joint training: every geometry parameter gets its gradient too (SURVEY A9 in full)
         for q in geo:
@@ -68,6 +69,8 @@ CASES = [
     ("C3 1.5M/1080p/D=512 fp16 table, 16-bit matrix cores fwd+bwd (opt-in)", C3 + (512,), dict(half=True, flags=128 | 64)),
     ("C3 1.5M/1080p/D=512 fp32 table, 16-bit matrix cores bwd (opt-in)", C3 + (512,), dict(flags=64)),
     ("C5 4M/1080p/D=513 (512+1) fp32", C5 + (513,), dict(steps=4)),
+    ("C5 4M/1080p/D=513 (512+1) fp16 table -- BASELINE.json configs[4] as stated", C5 + (513,), dict(half=True, steps=4)),
+    ("C5 4M/1080p/D=513 (512+1) fp16 table, 16-bit matrix cores fwd+bwd (opt-in)", C5 + (513,), dict(half=True, flags=128 | 64, steps=4)),
     ("C3 1.5M/1080p/D=512, ALL gradients (features + means, quats, scales, opacities)", C3 + (512,), dict(full_grad=True)),
     ("C3 ALL gradients, VALU + atomics backward (what round 1 ran)", C3 + (512,), dict(full_grad=True, flags=4, steps=3)),
     ("C2 500k/1280x720/D=128, ALL gradients", (500_000, 1280, 720, 128), dict(full_grad=True)),

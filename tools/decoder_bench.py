@@ -19,6 +19,7 @@ cfg = syn.CONFIGS["C3"]
 n, w, h, d = cfg["n"], cfg["width"], cfg["height"], 16
 pc = syn.make_model(n, d, w, h, seed=0, device=dev, gen_device=dev)
 pc.training_setup()
+pc.cache_activations(True)  # geometry frozen for the whole run (GAD stage, train.py:62-75): getters evaluated once
 cam = syn.make_camera(w, h, device=dev)
 bg = torch.zeros(3, device=dev)
 dec, sdec = CNN_decoder(16, 512).to(dev), CNN_scale_decoder(16, 3).to(dev)
