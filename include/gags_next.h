@@ -123,6 +123,22 @@ int gags_decoder_head(int64_t n_pix, int c, int ld, int mode, const float *x, fl
 int gags_relevancy(int64_t n_pix, int c, int n_pos, int n_neg, const float *embed, const float *pos, const float *neg,
                    float *probs, void *stream);
 
+/* The rest of the query path of one view (evaluate_iou_loc.py:100-146 `activate_stream`, :163-176
+ * `lerf_localization`), for all phrases at once and without leaving the GPU.  valid_map[n_phrases, h, w] = the
+ * relevancy maps get_max_across returned (one level).  Per phrase:
+ *   avg      = 30x30 box mean of valid_map (cv2.filter2D with ones/900: anchor box/2, BORDER_REFLECT_101)   (:108-111)
+ *   blended  = 0.5 * (avg + valid_map)                                      the heat map                      (:113)
+ *   output   = clip(((blended - min) / (max - min + 1e-9)) * 2 - 1, 0, 1)                                     (:131-135)
+ *   mask_pred   = output > thresh                                            uint8                             (:137)
+ *   mask_smooth = eval/utils.py:55-64 smooth(mask_pred): (2 s + 1)^2 majority with the reference's own window bounds (:138)
+ *   stats[k] = {min(blended), max(blended), max(avg)}; max(avg) is lerf_localization's score (:174), its position(s)
+ *              are where avg == stats[k][2].
+ * scratch: gags_relevancy_activate_scratch_bytes() bytes. */
+int64_t gags_relevancy_activate_scratch_bytes(int n_phrases, int h, int w);
+int gags_relevancy_activate(int n_phrases, int h, int w, const float *valid_map, float thresh, int box, int smooth_scale,
+                            float *avg, float *blended, float *output, unsigned char *mask_pred,
+                            unsigned char *mask_smooth, float *stats, void *scratch, int64_t scratch_bytes, void *stream);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

@@ -215,7 +215,8 @@ def test_bench_two_ranks_under_torch_distributed_run():
     env = dict(os.environ, GAGS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--config", "C2", "--n", "20000", "--d", "256", "--no-cpu-baseline", "--no-heavy"]
+           "--config", "C2", "--n-gaussians", "20000", "--feature-dim", "256",  # (torchrun's argparse claims a bare --n)
+            "--no-cpu-baseline", "--no-heavy"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
