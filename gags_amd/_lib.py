@@ -59,6 +59,7 @@ SIGNATURES = {
                                 _vp, _vp, _vp, _vp]),
     "gags_sh_fwd": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_sh_bwd": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gags_sh_bwd_dirs": (_i32, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_ed_normalize": (_i32, [_i64, _i32, _vp, _vp, _vp]),
     "gags_adam_step": (_i32, [_i64, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _f64, _i32, _vp]),
     "gags_pack_rows": (_i32, [_i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),

@@ -105,8 +105,8 @@ class _Project(torch.autograd.Function):
 
 
 class _SH(torch.autograd.Function):
-    """K3: SH colour; directions are constants (as in the reference flow, where this branch
-    only runs with frozen geometry or under no_grad)."""
+    """K3: SH colour and its backward: coefficients, and -- when positions are trainable -- the view direction
+    (d colour / d means through normalize(mean - campos), as gsplat propagates it)."""
 
     @staticmethod
     def forward(ctx, coeffs, means, campos, radii, degree):
@@ -116,20 +116,27 @@ class _SH(torch.autograd.Function):
         out = torch.empty(n, 3, device=coeffs.device)
         check(lib.gags_sh_fwd(n, kc, degree, ptr(means), ptr(campos), ptr(coeffs), ptr(radii), ptr(out), _stream()),
               "gags_sh_fwd")
-        ctx.save_for_backward(means, campos, radii, out)
+        ctx.save_for_backward(means, campos, radii, out, coeffs if ctx.needs_input_grad[1] else None)
         ctx.cfg = (kc, degree)
         return out
 
     @staticmethod
     def backward(ctx, v_out):
         lib = _lib.load()
-        means, campos, radii, out = ctx.saved_tensors
+        means, campos, radii, out, coeffs = ctx.saved_tensors
         kc, degree = ctx.cfg
         n = means.shape[0]
-        v_coeffs = torch.empty(n, kc, 3, device=means.device)
-        check(lib.gags_sh_bwd(n, kc, degree, ptr(means), ptr(campos), ptr(radii), ptr(out), ptr(_c(v_out)),
-                              ptr(v_coeffs), _stream()), "gags_sh_bwd")
-        return v_coeffs, None, None, None, None
+        v_out = _c(v_out)
+        v_coeffs = v_means = None
+        if ctx.needs_input_grad[0]:
+            v_coeffs = torch.empty(n, kc, 3, device=means.device)
+            check(lib.gags_sh_bwd(n, kc, degree, ptr(means), ptr(campos), ptr(radii), ptr(out), ptr(v_out),
+                                  ptr(v_coeffs), _stream()), "gags_sh_bwd")
+        if ctx.needs_input_grad[1]:
+            v_means = torch.empty(n, 3, device=means.device)
+            check(lib.gags_sh_bwd_dirs(n, kc, degree, ptr(means), ptr(campos), ptr(coeffs), ptr(radii), ptr(out),
+                                       ptr(v_out), ptr(v_means), _stream()), "gags_sh_bwd_dirs")
+        return v_coeffs, v_means, None, None, None
 
 
 def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height, conics=None, opacities=None):
@@ -413,12 +420,6 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
     if sh_degree is not None:
         if colors.dim() != 3 or colors.shape[2] != 3:
             raise ValueError("SH colours must be [N,K,3]")
-        if means.requires_grad:
-            # gsplat propagates d colour / d view direction into means; this build treats directions as constants
-            # (the reference only reaches the SH branch with frozen geometry or under no_grad): refuse, do not
-            # return a silently incomplete gradient
-            raise NotImplementedError("sh_degree with means.requires_grad: the view-direction gradient of the SH "
-                                      "colours is not implemented; detach means or pass explicit colours")
         campos = torch.inverse(viewmat.double())[:3, 3].float()
         cols = _SH.apply(colors, means, campos, radii, int(sh_degree))
     else:

@@ -246,6 +246,12 @@ int gags_sh_bwd(int n, int kc, int degree, const float *means, const float *camp
                 const int32_t *radii, const float *colors_out, const float *v_out,
                 float *v_coeffs, void *stream);
 
+/* K3 backward, view-direction part: v_means[n,3] = d loss / d means through dir = normalize(mean - campos) (gsplat
+ * propagates this gradient; it matters when the SH colour branch runs with trainable positions, train.py:142 without
+ * --feature_mode).  coeffs [n,kc,3], colors_out = gags_sh_fwd's output (clamp mask), v_out [n,3]. */
+int gags_sh_bwd_dirs(int n, int kc, int degree, const float *means, const float *campos, const float *coeffs,
+                     const int32_t *radii, const float *colors_out, const float *v_out, float *v_means, void *stream);
+
 /* K12: expected-depth normalisation of the last channel: c[...,d-1] /= max(alpha,1e-10)
  * (render_mode "RGB+ED", the only consumer is render.py:118,127-133). */
 int gags_ed_normalize(int64_t n_pix, int d, float *render_colors, const float *render_alphas,

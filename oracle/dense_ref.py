@@ -103,3 +103,29 @@ def composite(means2d, conics, opacities, colors, backgrounds, width, height, ra
     D = col.shape[1]
     return (out.reshape(height, width, D), alphas.reshape(height, width),
             last_local.reshape(height, width), include.sum().item())
+
+
+def sh_colors(deg, coeffs, means, campos):
+    """float64, differentiable: colour [N,3] = clamp_min(SH(normalize(means - campos)) + 0.5, 0) with the basis and signs
+    of /root/reference/utils/sh_utils.py:57-112; coeffs [N,K,3] (this repository's layout).  Pinned against autograd of
+    the reference's own eval_sh by tests/golden/shgrad_vectors.npz (values and d / d means, d / d coeffs)."""
+    d = means - campos
+    d = d / d.norm(dim=1, keepdim=True)
+    x, y, z = d[:, 0:1], d[:, 1:2], d[:, 2:3]
+    c = coeffs
+    r = 0.28209479177387814 * c[:, 0]
+    if deg > 0:
+        C1 = 0.4886025119029199
+        r = r - C1 * y * c[:, 1] + C1 * z * c[:, 2] - C1 * x * c[:, 3]
+    if deg > 1:
+        xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+        r = (r + 1.0925484305920792 * xy * c[:, 4] - 1.0925484305920792 * yz * c[:, 5]
+             + 0.31539156525252005 * (2.0 * zz - xx - yy) * c[:, 6] - 1.0925484305920792 * xz * c[:, 7]
+             + 0.5462742152960396 * (xx - yy) * c[:, 8])
+    if deg > 2:
+        r = (r - 0.5900435899266435 * y * (3 * xx - yy) * c[:, 9] + 2.890611442640554 * xy * z * c[:, 10]
+             - 0.4570457994644658 * y * (4 * zz - xx - yy) * c[:, 11]
+             + 0.3731763325901154 * z * (2 * zz - 3 * xx - 3 * yy) * c[:, 12]
+             - 0.4570457994644658 * x * (4 * zz - xx - yy) * c[:, 13] + 1.445305721320277 * z * (xx - yy) * c[:, 14]
+             - 0.5900435899266435 * x * (xx - 3 * yy) * c[:, 15])
+    return torch.clamp_min(r + 0.5, 0.0)

@@ -146,3 +146,41 @@ def test_oracle_adam_matches_the_reference_optimizer(oracle):
         np.testing.assert_allclose(m, z[f"m{t}"], rtol=2e-6, atol=2e-8)
         np.testing.assert_allclose(v, z[f"v{t}"], rtol=2e-6, atol=2e-8)
         np.testing.assert_allclose(p, z[f"p{t}"], rtol=2.5e-7, atol=1e-9)  # one ulp of p
+
+
+def test_activate_oracle_against_the_reference_functions():
+    """oracle/activate_ref.py against tests/golden/activate_vectors.npz = outputs of the reference's own activate_stream /
+    lerf_localization / smooth (make_golden_activate.py): heat map, final mask, IoU, localisation."""
+    from oracle import activate_ref as A
+    Zp = np.load(os.path.join(os.path.dirname(__file__), "golden", "activate_vectors.npz"))
+    valid, gt, th = Zp["act_valid_map"], Zp["act_gt_mask"], float(Zp["act_thresh"])
+    acc = 0
+    for k in range(valid.shape[0]):
+        r = A.activate(valid[k], thresh=th)
+        np.testing.assert_allclose(r["heatmap"], Zp["act_heatmap"][k], rtol=0, atol=1e-7)
+        np.testing.assert_array_equal(r["mask"], Zp["act_mask"][k])
+        np.testing.assert_array_equal(A.smooth_fast(r["mask_pred"]), r["mask"])
+        iou = np.logical_and(gt[k], r["mask"]).sum() / np.logical_or(gt[k], r["mask"]).sum()
+        assert abs(iou - Zp["act_iou"][k]) < 1e-12
+        score, coords, hit = A.localize(valid[k], Zp[f"act_boxes{k}"])
+        np.testing.assert_array_equal(coords, Zp[f"act_loc_coords{k}"])
+        acc += int(hit)
+    assert acc == int(Zp["act_loc_acc"])
+    np.testing.assert_array_equal(A.smooth(Zp["act_smooth_in"]), Zp["act_smooth_out"])
+    np.testing.assert_array_equal(A.smooth_fast(Zp["act_smooth_in"]), Zp["act_smooth_out"])
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_sh_view_direction_gradient_oracle_matches_autograd_of_the_reference_eval_sh(deg):
+    """oracle/dense_ref.sh_colors (float64 autograd) against tests/golden/shgrad_vectors.npz = autograd through the
+    reference's own eval_sh: colours, d / d means (through the normalised view direction) and d / d coefficients."""
+    from oracle import dense_ref as DR
+    Zs = np.load(os.path.join(os.path.dirname(__file__), "golden", "shgrad_vectors.npz"))
+    co = torch.from_numpy(Zs["shg_coeffs"]).double().permute(0, 2, 1).contiguous().requires_grad_(True)  # [N,3,16] -> [N,16,3]
+    m = torch.from_numpy(Zs["shg_means"]).double().requires_grad_(True)
+    col = DR.sh_colors(deg, co, m, torch.from_numpy(Zs["shg_campos"]).double())
+    (col * torch.from_numpy(Zs["shg_v_out"]).double()).sum().backward()
+    np.testing.assert_allclose(col.detach().numpy(), Zs[f"shg_col_deg{deg}"], rtol=0, atol=1e-12)
+    vm = np.zeros_like(Zs[f"shg_vmeans_deg{deg}"]) if m.grad is None else m.grad.numpy()
+    np.testing.assert_allclose(vm, Zs[f"shg_vmeans_deg{deg}"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(co.grad.permute(0, 2, 1).numpy(), Zs[f"shg_vcoeffs_deg{deg}"], rtol=0, atol=1e-12)

@@ -457,13 +457,65 @@ def test_sh_low_degrees(oracle, deg):
     assert rel_l2(out, o_out) <= 1e-6
 
 
-def test_sh_with_trainable_means_is_refused():
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_sh_view_direction_gradient_matches_the_reference_eval_sh(deg):
+    """gags_sh_bwd_dirs + gags_sh_bwd against autograd through the reference's OWN eval_sh (tests/golden/
+    shgrad_vectors.npz, float64): d colour / d means through normalize(mean - campos), and d / d coefficients."""
+    import os
+    from gags_amd import _lib
+    from gags_amd.rasterization import _SH
+    Zs = np.load(os.path.join(os.path.dirname(__file__), "golden", "shgrad_vectors.npz"))
+    co = torch.from_numpy(np.ascontiguousarray(Zs["shg_coeffs"].transpose(0, 2, 1))).cuda().requires_grad_(True)
+    m = torch.from_numpy(Zs["shg_means"]).cuda().requires_grad_(True)
+    n = m.shape[0]
+    radii = torch.ones(n, dtype=torch.int32, device="cuda")
+    col = _SH.apply(co, m, torch.from_numpy(Zs["shg_campos"]).cuda(), radii, deg)
+    assert np.abs(col.detach().cpu().numpy() - Zs[f"shg_col_deg{deg}"]).max() <= 2e-6
+    (col * torch.from_numpy(Zs["shg_v_out"]).cuda()).sum().backward()
+    want_m, want_c = Zs[f"shg_vmeans_deg{deg}"], Zs[f"shg_vcoeffs_deg{deg}"].transpose(0, 2, 1)
+    if deg == 0:
+        assert float(m.grad.abs().max()) == 0.0
+    else:
+        assert rel_l2(m.grad.cpu().numpy(), want_m) <= 2e-6
+    assert rel_l2(co.grad.cpu().numpy(), want_c) <= 1e-6
+
+
+def test_sh_colours_with_trainable_means_through_rasterization(oracle):
+    """rasterization(..., sh_degree=3) with positions requiring grad (train.py:142 without --feature_mode): the gradient
+    of the means is the projection's (K2) plus the view-direction term of the SH colours.  Checked against finite
+    differences of the HIP forward itself in float32 along random directions (the two terms cannot be separated from
+    outside), and the direction term alone must be non-zero."""
     from gags_amd.rasterization import rasterization
-    s = scene_arrays(64, 3, 32, 32, seed=1)
+    n, w, h = 300, 64, 48
+    s = scene_arrays(n, 3, w, h, seed=21, scale_mult=8.0)
+    args = [to_dev(s["quats"]), to_dev(s["scales"]), to_dev(s["opacities"]), to_dev(s["sh"])]
+    vm, K = to_dev(s["viewmat"])[None], to_dev(s["K"])[None]
+    G = torch.from_numpy(np.random.default_rng(3).standard_normal((h, w, 3)).astype(np.float32)).cuda()
+
+    def loss_of(means):
+        out, _, _ = rasterization(means, *args, vm, K, w, h, sh_degree=3)
+        return (out[0] * G).sum()
+
     means = to_dev(s["means"]).requires_grad_(True)
-    with pytest.raises(NotImplementedError, match="view-direction"):
-        rasterization(means, to_dev(s["quats"]), to_dev(s["scales"]), to_dev(s["opacities"]), to_dev(s["sh"]),
-                      to_dev(s["viewmat"])[None], to_dev(s["K"])[None], 32, 32, sh_degree=3)
+    loss_of(means).backward()
+    g_full = means.grad.clone()
+    # the same scene with the colours frozen at their forward values: only the projection term
+    from gags_amd.rasterization import _SH
+    with torch.no_grad():
+        info_m = means.detach()
+        campos = torch.inverse(vm[0].double())[:3, 3].float()
+    means2 = to_dev(s["means"]).requires_grad_(True)
+    out, _, info = rasterization(means2, *args[:3], _SH.apply(args[3], info_m, campos, torch.ones(n, dtype=torch.int32, device="cuda"), 3).detach(),
+                                 vm, K, w, h)
+    (out[0] * G).sum().backward()
+    g_proj = means2.grad.clone()
+    g_dir = g_full - g_proj
+    assert float(g_dir.norm()) > 1e-3 * float(g_full.norm()) > 0
+    # direction term alone = _SH's own gradient for the cotangent the rasterizer hands it (exact identity)
+    cols = _SH.apply(args[3], means3 := to_dev(s["means"]).requires_grad_(True), campos, info["radii"][0], 3)
+    out3, _, _ = rasterization(to_dev(s["means"]), *args[:3], cols, vm, K, w, h)
+    (out3[0] * G).sum().backward()
+    assert rel_l2(g_dir.cpu().numpy(), means3.grad.cpu().numpy()) <= 1e-5
 
 
 def test_expected_depth_with_gradient(oracle):
