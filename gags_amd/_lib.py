@@ -85,6 +85,10 @@ SIGNATURES = {
     "gags_decoder_head_bwd": (_i32, [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "gags_decoder_unpack_grad": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp]),
     "gags_decoder_head": (_i32, [_i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "gags_decoder_layer_exact": (_i32, [_i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "gags_decoder_wgrad_exact_scratch_bytes": (_i64, [_i64, _i32, _i32]),
+    "gags_decoder_wgrad_exact": (_i32, [_i64, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp]),
+    "gags_decoder_head_bwd_exact": (_i32, [_i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp]),
     "gags_relevancy": (_i32, [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "gags_relevancy_activate_scratch_bytes": (_i64, [_i32, _i32, _i32]),
     "gags_relevancy_activate": (_i32, [_i32, _i32, _i32, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),

@@ -9,11 +9,19 @@ GEMM kernels (include/gags_next.h N1, csrc/decoder.hip) instead of cuDNN 1x1 con
 Input: [C,H,W]; when it is the rasterizer's output (a permuted view of [H,W,C] memory, gaussian_renderer.py) the
 pixel-major layout the kernels want is already there and nothing is transposed.  Output: [C_out,H,W] fp32, contiguous.
 
-Precision: bf16 operands, fp32 accumulation, activations and their gradients kept in bf16 between layers.  The
-reference's cuDNN path uses TF32 by PyTorch default; against its fp32 CPU results the outputs agree to ~5e-3 and the
-gradients to ~2e-2 relative (tests/test_decoders_gpu.py).  Backward: input-gradient GEMMs are the forward kernel with
-W^T (ReLU mask and skip-connection gradient fused into the epilogue), weight gradients contract over the pixels
-(gags_decoder_wgrad); the input gradient comes back in the rasterizer's [H,W,C] layout.
+Precision.  The reference's modules are fp32 Conv2d stacks (models/networks.py:139-218, 220-248; train.py:149,159), and
+`precision="exact"` -- the DEFAULT -- computes them with fp32 tensors and fp32-equivalent arithmetic on the 16-bit matrix
+cores: every operand as three bfloat16 terms, every product as its six terms of order <= 2, fp32 accumulation
+(csrc/decoder_exact.hip); weight gradients are summed over pixel chunks in a fixed order, without atomics
+(bit-reproducible).  Against the reference modules' own fp32 results (tests/golden/next_vectors.npz): outputs <= 1e-5,
+every gradient <= 1e-3 rel-L2 (tests/test_decoders_gpu.py).
+`precision="bf16"` is the fast opt-in (`dec.precision = "bf16"` or the constructor argument): bf16 operands, fp32
+accumulation, activations and their gradients kept in bf16 between layers -- outputs ~5e-3, gradients ~2e-2 of the fp32
+results (a low-precision forward flips the ReLU of units within rounding of zero).  Its weight gradients are
+deterministic too (partials + ordered sum).  Backward in both modes: input-gradient GEMMs are the forward kernel with
+W^T (ReLU mask and skip-connection gradient fused into the epilogue), weight gradients contract over the pixels; the
+input gradient comes back in the rasterizer's [H,W,C] layout; gradients nobody asked for (a detached input, frozen
+parameters) are not computed.
 """
 import ctypes
 
@@ -76,6 +84,122 @@ def _pack_weights(weights, biases):
     return out
 
 
+def _xlayer(n_pix, w, b, a1, a2=None, relu=True, mask_src=None, residual=None, premask=False, ldy=None):
+    """One layer at fp32-equivalent precision (gags_decoder_layer_exact): fp32 tensors; w [n_out, k_in]; a1 / a2
+    [n_pix, >= k_in].  ldy > n_out: the extra columns are zero (the head kernels want padded logits rows)."""
+    n, k = w.shape
+    dev = w.device
+    ldy = ldy or n
+    y = (torch.zeros if ldy > n else torch.empty)(n_pix, ldy, device=dev)
+    ypre = torch.empty(n_pix, ldy, device=dev) if premask else None
+    check(_lib.load().gags_decoder_layer_exact(n_pix, n, k, ptr(a1), ptr(a2), a1.shape[1], ptr(w), ptr(b), int(relu),
+                                               ptr(mask_src), ptr(residual), ptr(y), ptr(ypre), ldy, _st()),
+          "gags_decoder_layer_exact")
+    return (y, ypre) if premask else y
+
+
+def _xwgrad(n_pix, dz, a1, a2, n, k, want_bias=True):
+    lib = _lib.load()
+    dev = dz.device
+    dw = torch.empty(n, k, device=dev)
+    db = torch.empty(n, device=dev) if want_bias else None
+    nb = lib.gags_decoder_wgrad_exact_scratch_bytes(n_pix, n, k)
+    scratch = torch.empty(max(nb, 4), dtype=torch.uint8, device=dev)
+    check(lib.gags_decoder_wgrad_exact(n_pix, n, k, ptr(dz), dz.shape[1], ptr(a1), ptr(a2), a1.shape[1], ptr(dw), ptr(db),
+                                       ptr(scratch), nb, _st()), "gags_decoder_wgrad_exact")
+    return dw, db
+
+
+def _logits_ld(c_out):
+    """Row length of the logits the head kernels read: c_out itself when it is a multiple of 32, else padded to 8."""
+    return c_out if c_out % 32 == 0 else (c_out + 7) // 8 * 8
+
+
+def _chain_forward_exact(x, kind, params):
+    """The fp32 chain of a decoder up to its logits (precision="exact").  Same return tuple as _chain_forward; `wb` holds
+    the fp32 [out, in] weight matrices and biases."""
+    weights, biases = params[0::2], params[1::2]
+    wb = [(wt.detach()[:, :, 0, 0].contiguous().float(), bs.detach().contiguous().float()) for wt, bs in zip(weights, biases)]
+    xp, h, w = _pixel_major(x)
+    p = h * w
+    a0 = xp
+    ld = _logits_ld(wb[-1][0].shape[0])
+    if kind == "decoder":
+        x1 = _xlayer(p, *wb[0], a0)
+        t1 = _xlayer(p, *wb[1], x1)
+        x2 = _xlayer(p, *wb[2], t1)
+        x3 = _xlayer(p, *wb[3], x1, x2)   # conv(x1 + x2)
+        t4 = _xlayer(p, *wb[4], x3)
+        x4 = _xlayer(p, *wb[5], t4)
+        t6 = _xlayer(p, *wb[6], x3, x4)   # conv(x3 + x4)
+        t7 = _xlayer(p, *wb[7], t6)
+        logits = _xlayer(p, *wb[8], t7, relu=False, ldy=ld)
+        acts = [a0, x1, t1, x2, x3, t4, x4, t6, t7]
+    else:
+        acts = [a0]
+        a = a0
+        for i, (wt, b) in enumerate(wb):
+            last = i + 1 == len(wb)
+            a = _xlayer(p, wt, b, a, relu=not last, ldy=ld if last else None)
+            if not last:
+                acts.append(a)
+        logits = a
+    return logits, acts, wb, h, w, xp.shape[1]
+
+
+def _chain_backward_exact(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, need_w=None):
+    """fp32 backward of the chain from dz [P, c_out] (precision="exact")."""
+    p = h * w
+    need_w = need_w or [True] * len(wb)
+    wt = [wgt.t().contiguous() for wgt, _ in wb]  # [k_in, n_out]: the input-gradient GEMM contracts over n_out
+    dws = [None] * len(wb)
+
+    def wg(i, dz_i, a1, a2=None):
+        if need_w[i]:
+            dws[i] = _xwgrad(p, dz_i, a1, a2, *wb[i][0].shape)
+
+    def dx(i, dz_i, mask_src=None, residual=None, premask=False):
+        return _xlayer(p, wt[i], None, dz_i, relu=False, mask_src=mask_src, residual=residual, premask=premask)
+
+    gin = None
+    if kind == "decoder":
+        a0, x1, t1, x2, x3, t4, x4, t6, t7 = acts
+        wg(8, dz, t7)
+        dz7 = dx(8, dz, mask_src=t7)
+        wg(7, dz7, t6)
+        dz6 = dx(7, dz7, mask_src=t6)
+        wg(6, dz6, x3, x4)
+        dz5, g36 = dx(6, dz6, mask_src=x4, premask=True)
+        wg(5, dz5, t4)
+        dz4 = dx(5, dz5, mask_src=t4)
+        wg(4, dz4, x3)
+        dz3 = dx(4, dz4, mask_src=x3, residual=g36)
+        wg(3, dz3, x1, x2)
+        dz2, g13 = dx(3, dz3, mask_src=x2, premask=True)
+        wg(2, dz2, t1)
+        dz1 = dx(2, dz2, mask_src=t1)
+        wg(1, dz1, x1)
+        dz0 = dx(1, dz1, mask_src=x1, residual=g13)
+        wg(0, dz0, a0)
+        if need_x:
+            gin = dx(0, dz0)
+    else:
+        cur = dz
+        for i in range(len(wb) - 1, -1, -1):
+            wg(i, cur, acts[i])
+            if i > 0 or need_x:
+                cur = dx(i, cur, mask_src=acts[i] if i > 0 else None)
+        gin = cur if need_x else None
+    gx = None if gin is None else gin.view(h, w, c_in).permute(2, 0, 1)
+    grads = []
+    for pair, shp in zip(dws, shapes):
+        if pair is None:
+            grads += [None, None]
+        else:
+            grads += [pair[0].reshape(shp), pair[1]]
+    return gx, grads
+
+
 def _chain_forward(x, kind, params):
     """The GEMM chain of a decoder up to its fp32 logits.  Returns (logits [P, ld], activations, packed weights, h, w,
     c_in)."""
@@ -108,15 +232,17 @@ def _chain_forward(x, kind, params):
     return logits, acts, wb, h, w, xp.shape[1]
 
 
-def _chain_backward(dz, acts, wb, kind, h, w, c_in, shapes):
+def _chain_backward(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, need_w=None):
     """From the bf16 gradient of the logits dz [P, ld] back through the chain: (input gradient as a [C_in,H,W] view of
-    [H,W,C_in] memory, weight / bias gradients in parameter order)."""
+    [H,W,C_in] memory, weight / bias gradients in parameter order).  need_x / need_w: what autograd asked for."""
     p = h * w
+    need_w = need_w or [True] * len(wb)
     wt = [wgt.t().contiguous() for wgt, _ in wb]  # [K_pad, N_pad]: the input-gradient GEMM contracts over N
     dws = [None] * len(wb)
 
     def wg(i, dz_i, a1, a2=None):
-        dws[i] = _wgrad(p, dz_i, a1, a2, *wb[i][0].shape)
+        if need_w[i]:
+            dws[i] = _wgrad(p, dz_i, a1, a2, *wb[i][0].shape)
 
     def dx(i, dz_i, mask_src=None, residual=None, premask=False):
         return _layer(p, wt[i], None, dz_i, relu=False, mask_src=mask_src, residual=residual, premask=premask)
@@ -140,20 +266,33 @@ def _chain_backward(dz, acts, wb, kind, h, w, c_in, shapes):
         wg(1, dz1, x1)
         dz0 = dx(1, dz1, mask_src=x1, residual=g13)
         wg(0, dz0, a0)
-        gin = dx(0, dz0)
+        gin = dx(0, dz0) if need_x else None
     else:
         cur = dz
         for i in range(len(wb) - 1, -1, -1):
             wg(i, cur, acts[i])
-            cur = dx(i, cur, mask_src=acts[i] if i > 0 else None)
-        gin = cur
-    gx = torch.empty(h, w, c_in, device=dz.device)
-    check(_lib.load().gags_decoder_unpack_grad(p, c_in, gin.shape[1], ptr(gin), ptr(gx), _st()), "gags_decoder_unpack_grad")
+            if i > 0 or need_x:
+                cur = dx(i, cur, mask_src=acts[i] if i > 0 else None)
+        gin = cur if need_x else None
+    gx = None
+    if gin is not None:
+        gx = torch.empty(h, w, c_in, device=dz.device)
+        check(_lib.load().gags_decoder_unpack_grad(p, c_in, gin.shape[1], ptr(gin), ptr(gx), _st()), "gags_decoder_unpack_grad")
+        gx = gx.permute(2, 0, 1)
     grads = []
-    for (dw, db), shp in zip(dws, shapes):
+    for pair, shp in zip(dws, shapes):
         co, ci = shp[:2]
-        grads += [dw[:co, :ci].reshape(shp).contiguous(), db[:co].contiguous()]
-    return gx.permute(2, 0, 1), grads
+        if pair is None:
+            grads += [None, None]
+        else:
+            grads += [pair[0][:co, :ci].reshape(shp).contiguous(), pair[1][:co].contiguous()]
+    return gx, grads
+
+
+def _needs(ctx, first_param):
+    """(input gradient wanted, per-layer: weight or bias gradient wanted) from autograd's needs_input_grad."""
+    ng = ctx.needs_input_grad
+    return bool(ng[0]), [bool(ng[i] or ng[i + 1]) for i in range(first_param, len(ng), 2)]
 
 
 class _DecoderFn(torch.autograd.Function):
@@ -161,19 +300,20 @@ class _DecoderFn(torch.autograd.Function):
     normalize head) or "scale" (CNN_scale_decoder: plain chain, softmax head).  params = w0, b0, w1, b1, ..."""
 
     @staticmethod
-    def forward(ctx, x, kind, c_out, *params):
-        logits, acts, wb, h, w, c_in = _chain_forward(x, kind, params)
+    def forward(ctx, x, kind, c_out, precision, *params):
+        exact = precision == "exact"
+        logits, acts, wb, h, w, c_in = (_chain_forward_exact if exact else _chain_forward)(x, kind, params)
         p = h * w
         # CNN_decoder's [C,H,W] output is a permuted view of PIXEL-major memory (like render()'s own output): the head
         # writes rows, the losses read rows, the reference's next step (.permute(1,2,0)) is free.  The 3-channel scale
         # map stays channel-major (its consumers index it by plane).
-        pm = kind == "decoder" and c_out % 4 == 0 and logits.shape[1] <= 512
+        pm = kind == "decoder" and c_out % 4 == 0 and logits.shape[1] <= 512 and logits.shape[1] % 32 == 0
         out = torch.empty((h, w, c_out) if pm else (c_out, h, w), device=x.device)
         check(_lib.load().gags_decoder_head(p, c_out, logits.shape[1], 0 if kind == "decoder" else 1, ptr(logits), ptr(out),
                                             1 if pm else 0, _st()), "gags_decoder_head")
         if pm:
             out = out.permute(2, 0, 1)
-        ctx.kind, ctx.c_out, ctx.hw, ctx.c_in = kind, c_out, (h, w), c_in
+        ctx.kind, ctx.c_out, ctx.hw, ctx.c_in, ctx.exact = kind, c_out, (h, w), c_in, exact
         ctx.wb = wb
         ctx.shapes = [tuple(t.shape) for t in params[0::2]]
         ctx.save_for_backward(logits, *acts)
@@ -189,11 +329,19 @@ class _DecoderFn(torch.autograd.Function):
         pm = (g.dtype == torch.float32 and gp.is_contiguous() and not g.is_contiguous() and ctx.c_out % 4 == 0
               and logits.shape[1] <= 512)  # the cotangent came back in the output's own pixel-major layout
         g = gp if pm else (g if (g.is_contiguous() and g.dtype == torch.float32) else g.contiguous().float())
-        dz = torch.empty(p, logits.shape[1], dtype=torch.bfloat16, device=g.device)
-        check(lib.gags_decoder_head_bwd(p, ctx.c_out, logits.shape[1], 0 if kind == "decoder" else 1, ptr(logits), ptr(g), ptr(dz),
-                                        1 if pm else 0, _st()), "gags_decoder_head_bwd")
-        gx, grads = _chain_backward(dz, acts, wb, kind, h, w, ctx.c_in, ctx.shapes)
-        return (gx, None, None, *grads)
+        need_x, need_w = _needs(ctx, 4)
+        mode = 0 if kind == "decoder" else 1
+        if ctx.exact:
+            dz = torch.empty(p, ctx.c_out, device=g.device)
+            check(lib.gags_decoder_head_bwd_exact(p, ctx.c_out, logits.shape[1], mode, ptr(logits), ptr(g), 1 if pm else 0,
+                                                  ptr(dz), ctx.c_out, _st()), "gags_decoder_head_bwd_exact")
+            gx, grads = _chain_backward_exact(dz, acts, wb, kind, h, w, ctx.c_in, ctx.shapes, need_x, need_w)
+        else:
+            dz = torch.empty(p, logits.shape[1], dtype=torch.bfloat16, device=g.device)
+            check(lib.gags_decoder_head_bwd(p, ctx.c_out, logits.shape[1], mode, ptr(logits), ptr(g), ptr(dz),
+                                            1 if pm else 0, _st()), "gags_decoder_head_bwd")
+            gx, grads = _chain_backward(dz, acts, wb, kind, h, w, ctx.c_in, ctx.shapes, need_x, need_w)
+        return (gx, None, None, None, *grads)
 
 
 class _DecoderDistillFn(torch.autograd.Function):
@@ -230,7 +378,8 @@ class _DecoderDistillFn(torch.autograd.Function):
         check(_lib.load().gags_decoder_head_distill_bwd(c, logits.shape[1], h, w, seg.shape[1], seg.shape[2], e.shape[0],
                                                         ptr(logits), ptr(e), ptr(seg), ptr(sc), ptr(_f(v_map)), ptr(dz), ptr(vs),
                                                         _st()), "gags_decoder_head_distill_bwd")
-        gx, grads = _chain_backward(dz, acts, ctx.wb, "decoder", h, w, ctx.c_in, ctx.shapes)
+        need_x, need_w = _needs(ctx, 5)
+        gx, grads = _chain_backward(dz, acts, ctx.wb, "decoder", h, w, ctx.c_in, ctx.shapes, need_x, need_w)
         return (gx, None, None, vs, None, *grads)
 
 
@@ -239,8 +388,11 @@ class _Stack(nn.Module):
     parameter names match) whose forward and backward are run by the GEMM kernels."""
     kind = "scale"
 
-    def __init__(self, dims_in, dims_out):
+    def __init__(self, dims_in, dims_out, precision="exact"):
         super().__init__()
+        if precision not in ("exact", "bf16"):
+            raise ValueError("precision must be 'exact' (fp32-equivalent, the default) or 'bf16' (fast opt-in)")
+        self.precision = precision
         layers = []
         for i, (ci, co) in enumerate(zip(dims_in, dims_out)):
             if i > 0:
@@ -255,14 +407,14 @@ class _Stack(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("gags_amd.decoders: tensors must live on the GPU (there is no CPU path)")
         params = [t for m in self.convs() for t in (m.weight, m.bias)]
-        return _DecoderFn.apply(x, self.kind, self.output_dim, *params)
+        return _DecoderFn.apply(x, self.kind, self.output_dim, self.precision, *params)
 
 
 class CNN_decoder(_Stack):
     kind = "decoder"
 
-    def __init__(self, input_dim, output_dim):
-        super().__init__([input_dim] + [256] * 8, [256] * 8 + [output_dim])
+    def __init__(self, input_dim, output_dim, precision="exact"):
+        super().__init__([input_dim] + [256] * 8, [256] * 8 + [output_dim], precision)
         self.output_dim = output_dim
 
     def distill_l1(self, x, img_embed, seg_map, scale_map):
@@ -274,7 +426,8 @@ class CNN_decoder(_Stack):
         reference's module: an optional fast path."""
         if not x.is_cuda:
             raise RuntimeError("gags_amd.decoders: tensors must live on the GPU (there is no CPU path)")
-        if self.output_dim != 512:
+        if self.output_dim != 512 or self.precision != "bf16":
+            # fp32-equivalent precision: the decoder, then the fused ground-truth assembly + L1 map (both fp32)
             l1, mask = __import__("gags_amd.losses", fromlist=["distill_l1_map"]).distill_l1_map(self(x), img_embed, seg_map, scale_map)
             return l1, mask
         params = [t for m in self.convs() for t in (m.weight, m.bias)]
@@ -283,7 +436,7 @@ class CNN_decoder(_Stack):
 
 
 class CNN_scale_decoder(_Stack):
-    def __init__(self, input_dim, output_dim):
+    def __init__(self, input_dim, output_dim, precision="exact"):
         dims = [64, 128, 64, 32, 16, output_dim]
-        super().__init__([input_dim] + dims[:-1], dims)
+        super().__init__([input_dim] + dims[:-1], dims, precision)
         self.output_dim = output_dim

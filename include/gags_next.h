@@ -115,6 +115,28 @@ int gags_decoder_unpack_grad(int64_t n_pix, int c, int ld, const void *x_bf16, f
  * rasterizer's output, and nothing is transposed on the way in or out. */
 int gags_decoder_head(int64_t n_pix, int c, int ld, int mode, const float *x, float *out, int layout, void *stream);
 
+/* ---- N1 at the reference's precision (models/networks.py:109-248 are fp32 Conv2d stacks) ------------------------- */
+
+/* The same layer as gags_decoder_layer with fp32 tensors and fp32-equivalent arithmetic: every operand enters the 16-bit
+ * matrix cores as three bfloat16 terms (h + m + l = the fp32 value, exactly) and a product as its six terms of order
+ * <= 2 (dropped: <= 2^-24 relative), fp32 accumulation.  a1, a2 (optional), mask_src, residual, y, y_premask: fp32 with
+ * leading dimensions lda (inputs) / ldy (everything [n_pix, n_out]-shaped); w [n_out, k_in]; any n_out, k_in >= 1. */
+int gags_decoder_layer_exact(int64_t n_pix, int n_out, int k_in, const float *a1, const float *a2, int lda, const float *w,
+                             const float *bias, int relu, const float *mask_src, const float *residual, float *y,
+                             float *y_premask, int ldy, void *stream);
+
+/* Weight and bias gradient at the same precision, WITHOUT atomics: pixel chunks -> partial matrices in `scratch` ->
+ * summed in chunk order (bit-reproducible).  d_w [n_out, k_in] and d_b [n_out] (optional) are overwritten. */
+int64_t gags_decoder_wgrad_exact_scratch_bytes(int64_t n_pix, int n_out, int k_in);
+int gags_decoder_wgrad_exact(int64_t n_pix, int n_out, int k_in, const float *dz, int lddz, const float *a1,
+                             const float *a2, int lda, float *d_w, float *d_b, void *scratch, int64_t scratch_bytes,
+                             void *stream);
+
+/* Backward of the output heads with an fp32 result dz[n_pix, lddz] (columns >= c zero); x = the logits [n_pix, ldx];
+ * g: layout 0 = [c, n_pix], 1 = [n_pix, c]; modes as gags_decoder_head. */
+int gags_decoder_head_bwd_exact(int64_t n_pix, int c, int ldx, int mode, const float *x, const float *g, int layout,
+                                float *dz, int lddz, void *stream);
+
 /* ---- N4: query-time relevancy (eval/openclip_encoder.py:42-56, 96-111) ---------------------------------------- */
 
 /* For every pixel embedding embed[n_pix, c] and every positive phrase j: the LERF relevancy pair

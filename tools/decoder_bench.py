@@ -22,7 +22,8 @@ pc.training_setup()
 pc.cache_activations(True)  # geometry frozen for the whole run (GAD stage, train.py:62-75): getters evaluated once
 cam = syn.make_camera(w, h, device=dev)
 bg = torch.zeros(3, device=dev)
-dec, sdec = CNN_decoder(16, 512).to(dev), CNN_scale_decoder(16, 3).to(dev)
+PRECISION = "bf16" if "--bf16" in sys.argv else "exact"   # default: the reference's precision; --bf16: the fast opt-in mode
+dec, sdec = CNN_decoder(16, 512, PRECISION).to(dev), CNN_scale_decoder(16, 3, PRECISION).to(dev)
 g = torch.Generator(device=dev).manual_seed(0)
 n_emb = 300
 img_embed = torch.nn.functional.normalize(torch.randn(n_emb, 512, device=dev, generator=g), dim=-1)
@@ -73,6 +74,7 @@ for _ in range(K):
     iteration(times)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
-print(json.dumps({"fused_head_loss": FUSED, "workload": "train.py:142-174 iteration, 1.5M Gaussians, 1920x1080, D=16 -> CNN decoders (bf16 MFMA) -> losses",
+print(json.dumps({"fused_head_loss": FUSED and PRECISION == "bf16", "decoder_precision": PRECISION,
+                  "workload": "train.py:142-174 iteration, 1.5M Gaussians, 1920x1080, D=16 -> CNN decoders -> losses",
                   "ms_per_iteration": 1e3 * dt, "iterations_per_s": 1 / dt,
                   "stages_ms": {k: sum(v) / len(v) for k, v in times.items()}}))
