@@ -25,9 +25,12 @@ __device__ __forceinline__ unsigned f2key(float f)
 }
 __device__ __forceinline__ float key2f(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 
-// horizontal pass: rowsum[k, y, x] = sum_{dx = -a .. box-1-a} src[k, y, reflect(x + dx)],  a = box / 2 (cv2's anchor)
+// horizontal pass: rowsum[k, y, x] = sum_{dx = -a .. box-1-a} src[k, y, reflect(x + dx)],  a = box / 2 (cv2's anchor).
+// Sums in double, rounded once at the end of the vertical pass: the reflected border makes neighbouring windows hold the
+// same multiset of pixels, and lerf_localization takes EVERY position that attains the maximum (:174-176) -- fp32 partial
+// sums in window order would break such exact ties.
 __global__ __launch_bounds__(256) void box_rows_kernel(int h, int w, int box, const float *__restrict__ src,
-                                                       float *__restrict__ rowsum)
+                                                       double *__restrict__ rowsum)
 {
     extern __shared__ float seg[];  // 256 + box values of the row
     const int y = blockIdx.y, k = blockIdx.z, x0 = blockIdx.x * 256, a = box / 2;
@@ -36,15 +39,15 @@ __global__ __launch_bounds__(256) void box_rows_kernel(int h, int w, int box, co
     __syncthreads();
     const int x = x0 + threadIdx.x;
     if (x >= w) return;
-    float s = 0.f;
-    for (int i = 0; i < box; ++i) s += seg[threadIdx.x + i];
+    double s = 0.0;
+    for (int i = 0; i < box; ++i) s += (double)seg[threadIdx.x + i];
     rowsum[((size_t)k * h + y) * w + x] = s;
 }
 
 // vertical pass + blend: avg = (sum over the column window) / box^2, blended = 0.5 (avg + src); min / max of the blended
 // map and max of avg per phrase (keys[k] = {min blended, max blended, max avg})
 __global__ __launch_bounds__(256) void box_cols_kernel(int h, int w, int box, const float *__restrict__ src,
-                                                       const float *__restrict__ rowsum, float *__restrict__ avg,
+                                                       const double *__restrict__ rowsum, float *__restrict__ avg,
                                                        float *__restrict__ blended, unsigned *__restrict__ keys)
 {
     __shared__ unsigned red[3][4];
@@ -52,10 +55,10 @@ __global__ __launch_bounds__(256) void box_cols_kernel(int h, int w, int box, co
     const bool in = x < w;
     float av = 0.f, bl = 0.f;
     if (in) {
-        const float *col = rowsum + (size_t)k * h * w + x;
-        float s = 0.f;
+        const double *col = rowsum + (size_t)k * h * w + x;
+        double s = 0.0;
         for (int i = 0; i < box; ++i) s += col[(size_t)reflect101(y + i - a, h) * w];
-        av = s * (1.0f / (float)(box * box));
+        av = (float)(s / (double)(box * box));
         const size_t o = ((size_t)k * h + y) * w + x;
         bl = 0.5f * (av + src[o]);
         avg[o] = av;
@@ -125,7 +128,7 @@ inline int64_t al256(int64_t x) { return (x + 255) / 256 * 256; }
 extern "C" int64_t gags_relevancy_activate_scratch_bytes(int n_phrases, int h, int w)
 {
     if (n_phrases <= 0 || h <= 0 || w <= 0) return 0;
-    return al256((int64_t)n_phrases * h * w * 4) + al256((int64_t)n_phrases * 3 * 4);
+    return al256((int64_t)n_phrases * h * w * 8) + al256((int64_t)n_phrases * 3 * 4);
 }
 
 extern "C" int gags_relevancy_activate(int n_phrases, int h, int w, const float *valid_map, float thresh, int box,
@@ -139,8 +142,8 @@ extern "C" int gags_relevancy_activate(int n_phrases, int h, int w, const float 
     if (!valid_map || !avg || !blended || !output || !mask_pred || !mask_smooth || !stats || !scratch) return GAGS_EINVAL;
     if (scratch_bytes < gags_relevancy_activate_scratch_bytes(n_phrases, h, w)) return GAGS_ESCRATCH;
     hipStream_t st = (hipStream_t)stream;
-    float *rowsum = (float *)scratch;
-    unsigned *keys = (unsigned *)((char *)scratch + al256((int64_t)n_phrases * h * w * 4));
+    double *rowsum = (double *)scratch;
+    unsigned *keys = (unsigned *)((char *)scratch + al256((int64_t)n_phrases * h * w * 8));
     const dim3 grid((w + 255) / 256, h, n_phrases);
     hipLaunchKernelGGL(keys_init_kernel, dim3((3 * n_phrases + 63) / 64), dim3(64), 0, st, n_phrases, keys);
     hipLaunchKernelGGL(box_rows_kernel, grid, dim3(256), (size_t)(256 + box) * 4, st, h, w, box, valid_map, rowsum);

@@ -367,6 +367,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(int64_t P, int N, int K
 {
     __shared__ __attribute__((aligned(16))) unsigned short At[128][LDP2];  // [n][p]
     __shared__ __attribute__((aligned(16))) unsigned short Bt[128][LDP2];  // [k][p]
+    __shared__ float bsh[8][128];  // bias partial sums per pixel-row group: summed in a fixed order (no atomics)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wy = wave >> 1, wx = wave & 1;
     const int n0 = blockIdx.y * 128, k0 = blockIdx.z * 128;
@@ -446,13 +447,19 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(int64_t P, int N, int K
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wy * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (n < N) __hip_atomic_fetch_add(dW + (size_t)n * K + k, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (n < N) dW[((size_t)blockIdx.x * N + n) * K + k] = acc[i][j][r];  // this pixel chunk's partial matrix
             }
         }
-    if (do_bias) {
+    if (db != nullptr && blockIdx.z == 0) {  // (uniform over the workgroup)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (n0 + sc + c < N) __hip_atomic_fetch_add(db + n0 + sc + c, bsum[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int c = 0; c < 4; ++c) bsh[tid >> 5][sc + c] = bsum[c];
+        __syncthreads();
+        if (tid < 128 && n0 + tid < N) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += bsh[q][tid];
+            db[(size_t)blockIdx.x * N + n0 + tid] = t;
+        }
     }
 }
 
@@ -478,7 +485,7 @@ __global__ __launch_bounds__(256, 2) void wgrad256_kernel(int64_t P, int N, cons
     constexpr int K = 256;
     __shared__ __attribute__((aligned(16))) unsigned char Zi[2][W2P * W2ZP];
     __shared__ __attribute__((aligned(16))) unsigned char Xi[2][W2P * W2XP];
-    __shared__ float bred[128];
+    __shared__ float bsh[16][128];  // bias partial sums per pixel-row group: summed in a fixed order (no atomics)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wy = wave >> 1, wx = wave & 1;  // 2 x 2 waves: 64 n x 128 k each
     // the n tiles of one pixel chunk run back to back on the same XCD (they share the activation rows through its L2)
@@ -586,16 +593,19 @@ __global__ __launch_bounds__(256, 2) void wgrad256_kernel(int64_t P, int N, cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wy * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                __hip_atomic_fetch_add(dW + (size_t)n * K + k, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dW[((size_t)ck * N + n) * K + k] = acc[i][j][r];  // this pixel chunk's partial matrix
             }
         }
     if (do_bias) {
-        if (tid < 128) bred[tid] = 0.f;
-        __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 8; ++q) atomicAdd(&bred[zc + q], bsum[q]);
+        for (int q = 0; q < 8; ++q) bsh[zr][zc + q] = bsum[q];
         __syncthreads();
-        if (tid < 128) __hip_atomic_fetch_add(db + n0 + tid, bred[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < 128) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += bsh[q][tid];
+            db[(size_t)ck * N + n0 + tid] = t;
+        }
     }
 }
 
@@ -615,6 +625,7 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(int64_t P, const unsi
     constexpr int PATCH = 16 * (ZP + XP);
     constexpr int RED = N * K * 4 + N * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[(4 * PATCH > RED ? 4 * PATCH : RED)];
+    __shared__ float bsh[4][64][8];  // bias partial sums per wave and lane: summed in a fixed order (no atomics)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned char *Zi = smem + wave * PATCH, *Xi = Zi + 16 * ZP;
     const int64_t pa = ((int64_t)blockIdx.x * 4 + wave) * chunk, pb = min(pa + chunk, P);
@@ -690,40 +701,67 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(int64_t P, const unsi
                 for (int j = 0; j < KB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
     }
-    // sum the four waves in LDS (the patches are done with), then one global atomic per element and workgroup
+    // sum the four waves in LDS (the patches are done with) -- one wave at a time, in wave order, plain read-modify-
+    // write: a fixed order, hence reproducible bits -- then store the workgroup's partial matrix
     __syncthreads();
-    float *red = reinterpret_cast<float *>(smem), *bred = red + N * K;
-    for (int e = tid; e < N * K + N; e += 256) red[e] = 0.f;
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NB; ++i)
-#pragma unroll
-        for (int j = 0; j < KB; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                atomicAdd(&red[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * K + j * 32 + (lane & 31)], acc[i][j][r]);
+    float *red = reinterpret_cast<float *>(smem);
+    for (int e = tid; e < N * K; e += 256) red[e] = 0.f;
     if (do_bias) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) atomicAdd(&bred[(lane % ZR) * 8 + q], bsum[q]);
+        for (int q = 0; q < 8; ++q) bsh[wave][lane][q] = bsum[q];
     }
     __syncthreads();
-    for (int e = tid; e < N * K; e += 256) __hip_atomic_fetch_add(dW + e, red[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int j = 0; j < KB; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        red[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * K + j * 32 + (lane & 31)] += acc[i][j][r];
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < N * K; e += 256) dW[(size_t)blockIdx.x * N * K + e] = red[e];
     if (do_bias)
-        for (int e = tid; e < N; e += 256) __hip_atomic_fetch_add(db + e, bred[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int c = tid; c < N; c += 256) {  // column c: lanes c / 8 + ZR m of every wave, element c % 8
+            float t = 0.f;
+            for (int wv = 0; wv < 4; ++wv)
+                for (int l = c >> 3; l < 64; l += ZR) t += bsh[wv][l][c & 7];
+            db[(size_t)blockIdx.x * N + c] = t;
+        }
 }
+
+inline int64_t narrow_chunk(int64_t n_pix)
+{
+    const int64_t waves = 4 * 768;  // three workgroups per CU
+    return ((n_pix + waves - 1) / waves + 15) / 16 * 16;
+}
+inline unsigned narrow_parts(int64_t n_pix) { const int64_t c = narrow_chunk(n_pix); return (unsigned)((n_pix + 4 * c - 1) / (4 * c)); }
 
 template <int NB, int KB>
 void launch_wgrad_narrow(int64_t n_pix, const void *dz, const void *a1, const void *a2, float *d_w, float *d_b, hipStream_t stream)
 {
-    const int64_t waves = 4 * 768;  // three workgroups per CU
-    const int64_t chunk = ((n_pix + waves - 1) / waves + 15) / 16 * 16;
-    const unsigned grid = (unsigned)((n_pix + 4 * chunk - 1) / (4 * chunk));
+    const int64_t chunk = narrow_chunk(n_pix);
+    const unsigned grid = narrow_parts(n_pix);
     if (a2)
         hipLaunchKernelGGL((wgrad_narrow_kernel<NB, KB, true>), dim3(grid), dim3(256), 0, stream, n_pix, (const unsigned short *)dz,
                            (const unsigned short *)a1, (const unsigned short *)a2, d_w, d_b, chunk);
     else
         hipLaunchKernelGGL((wgrad_narrow_kernel<NB, KB, false>), dim3(grid), dim3(256), 0, stream, n_pix, (const unsigned short *)dz,
                            (const unsigned short *)a1, (const unsigned short *)a2, d_w, d_b, chunk);
+}
+
+// out[e] = sum of the partial results over the pixel chunks, in chunk order (fixed => reproducible)
+__global__ __launch_bounds__(256) void sum_wparts_kernel(int n_parts, int64_t elems, const float *__restrict__ part,
+                                                         float *__restrict__ out)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= elems) return;
+    float t = 0.f;
+    for (int c = 0; c < n_parts; ++c) t += part[(size_t)c * elems + e];
+    out[e] = t;
 }
 
 // backward of the output heads: channel-major cotangent G[C, P] and the saved pixel-major logits x[P, ld] ->
@@ -1083,46 +1121,79 @@ extern "C" int gags_decoder_head(int64_t n_pix, int c, int ld, int mode, const f
     return GAGS_OK;
 }
 
+namespace {
+// which kernel serves a shape, and how many partial matrices (pixel chunks) it leaves
+enum { WG_NARROW = 0, WG_256 = 1, WG_GENERAL = 2 };
+inline bool narrow_shape(int n_out, int k_in)
+{
+    if (n_out % 32 || k_in % 32) return false;
+    const int nb = n_out / 32, kb = k_in / 32;
+    return (nb == 1 && (kb == 1 || kb == 2 || kb == 4 || kb == 8)) || (nb == 2 && (kb == 1 || kb == 2 || kb == 4)) ||
+           (nb == 4 && (kb == 1 || kb == 2)) || (nb == 8 && kb == 1);
+}
+inline int64_t w256_chunk(int64_t n_pix) { return ((n_pix + 511) / 512 + W2P - 1) / W2P * W2P; }
+inline int wgrad_plan(int64_t n_pix, int n_out, int k_in, int64_t &parts)
+{
+    if (narrow_shape(n_out, k_in)) { parts = narrow_parts(n_pix); return WG_NARROW; }
+    if (k_in == 256 && n_out % 128 == 0) { const int64_t c = w256_chunk(n_pix); parts = (n_pix + c - 1) / c; return WG_256; }
+    parts = (n_pix + WCHUNK - 1) / WCHUNK;
+    return WG_GENERAL;
+}
+}  // namespace
+
+extern "C" int64_t gags_decoder_wgrad_scratch_bytes(int64_t n_pix, int n_out, int k_in)
+{
+    if (n_pix <= 0 || n_out <= 0 || k_in <= 0) return 0;
+    int64_t parts;
+    wgrad_plan(n_pix, n_out, k_in, parts);
+    return (parts * ((int64_t)n_out * k_in + n_out) * 4 + 255) / 256 * 256;
+}
+
 extern "C" int gags_decoder_wgrad(int64_t n_pix, int n_out, int k_in, const void *dz, const void *a1, const void *a2,
-                                  float *d_w, float *d_b, void *stream)
+                                  float *d_w, float *d_b, void *scratch, int64_t scratch_bytes, void *stream)
 {
     GAGS_CLEAR_ERR();
     if (n_pix < 0 || n_out <= 0 || k_in <= 0 || n_out % 16 != 0 || k_in % 16 != 0 || !dz || !a1 || !d_w) return GAGS_EINVAL;
-    if (n_pix == 0) return GAGS_OK;
-    {
-        // narrow layers: the whole gradient in one wave's accumulators
+    hipStream_t st = (hipStream_t)stream;
+    if (n_pix == 0) {
+        if (hipMemsetAsync(d_w, 0, sizeof(float) * (size_t)n_out * k_in, st) != hipSuccess) return GAGS_ELAUNCH;
+        if (d_b && hipMemsetAsync(d_b, 0, sizeof(float) * (size_t)n_out, st) != hipSuccess) return GAGS_ELAUNCH;
+        return GAGS_OK;
+    }
+    if (!scratch || scratch_bytes < gags_decoder_wgrad_scratch_bytes(n_pix, n_out, k_in)) return GAGS_ESCRATCH;
+    int64_t parts;
+    const int plan = wgrad_plan(n_pix, n_out, k_in, parts);
+    // every pixel chunk leaves a partial matrix (and bias row) in scratch; they are summed in chunk order: no atomics
+    float *pw = (float *)scratch, *pb = d_b ? pw + (size_t)parts * n_out * k_in : nullptr;
+    if (plan == WG_NARROW) {
         const int nb = n_out / 32, kb = k_in / 32;
-        bool done = true;
-        if (n_out % 32 || k_in % 32) done = false;
-#define GAGS_NARROW(NB_, KB_) else if (nb == NB_ && kb == KB_) launch_wgrad_narrow<NB_, KB_>(n_pix, dz, a1, a2, d_w, d_b, (hipStream_t)stream);
+        if (false) {}
+#define GAGS_NARROW(NB_, KB_) else if (nb == NB_ && kb == KB_) launch_wgrad_narrow<NB_, KB_>(n_pix, dz, a1, a2, pw, pb, st);
         GAGS_NARROW(1, 1) GAGS_NARROW(2, 1) GAGS_NARROW(1, 2) GAGS_NARROW(2, 2) GAGS_NARROW(4, 1) GAGS_NARROW(1, 4)
         GAGS_NARROW(4, 2) GAGS_NARROW(2, 4) GAGS_NARROW(8, 1) GAGS_NARROW(1, 8)
 #undef GAGS_NARROW
-        else done = false;
-        if (done) {
-            GAGS_CHECK_LAUNCH();
-            return GAGS_OK;
-        }
-    }
-    if (k_in == 256 && n_out % 128 == 0) {
+    } else if (plan == WG_256) {
         // one workgroup per n tile and pixel chunk, two per CU: 512 chunks of whole 32-pixel steps
         const int n_tiles = n_out / 128;
-        const int64_t chunk = ((n_pix + 511) / 512 + W2P - 1) / W2P * W2P;
-        const unsigned n_chunks = (unsigned)((n_pix + chunk - 1) / chunk);
+        const int64_t chunk = w256_chunk(n_pix);
+        const unsigned n_chunks = (unsigned)parts;
         const unsigned grid = n_tiles == 1 ? n_chunks : (n_chunks + 7) / 8 * 8 * n_tiles;
         if (a2)
-            hipLaunchKernelGGL(wgrad256_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n_pix, n_out, (const unsigned short *)dz,
-                               (const unsigned short *)a1, (const unsigned short *)a2, d_w, d_b, chunk, n_tiles, n_chunks);
+            hipLaunchKernelGGL(wgrad256_kernel<true>, dim3(grid), dim3(256), 0, st, n_pix, n_out, (const unsigned short *)dz,
+                               (const unsigned short *)a1, (const unsigned short *)a2, pw, pb, chunk, n_tiles, n_chunks);
         else
-            hipLaunchKernelGGL(wgrad256_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n_pix, n_out, (const unsigned short *)dz,
-                               (const unsigned short *)a1, (const unsigned short *)a2, d_w, d_b, chunk, n_tiles, n_chunks);
-        GAGS_CHECK_LAUNCH();
-        return GAGS_OK;
+            hipLaunchKernelGGL(wgrad256_kernel<false>, dim3(grid), dim3(256), 0, st, n_pix, n_out, (const unsigned short *)dz,
+                               (const unsigned short *)a1, (const unsigned short *)a2, pw, pb, chunk, n_tiles, n_chunks);
+    } else {
+        hipLaunchKernelGGL(wgrad_bf16_kernel, dim3((unsigned)parts, (unsigned)((n_out + 127) / 128), (unsigned)((k_in + 127) / 128)),
+                           dim3(256), 0, st, n_pix, n_out, k_in, (const unsigned short *)dz, (const unsigned short *)a1,
+                           (const unsigned short *)a2, pw, pb);
     }
-    hipLaunchKernelGGL(wgrad_bf16_kernel, dim3((unsigned)((n_pix + WCHUNK - 1) / WCHUNK), (unsigned)((n_out + 127) / 128),
-                                               (unsigned)((k_in + 127) / 128)),
-                       dim3(256), 0, (hipStream_t)stream, n_pix, n_out, k_in, (const unsigned short *)dz,
-                       (const unsigned short *)a1, (const unsigned short *)a2, d_w, d_b);
+    const int64_t elems = (int64_t)n_out * k_in;
+    hipLaunchKernelGGL(sum_wparts_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, (int)parts, elems, pw, d_w);
+    if (d_b)
+        hipLaunchKernelGGL(sum_wparts_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, (int)parts, (int64_t)n_out, pb,
+                           d_b);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }

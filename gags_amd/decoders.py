@@ -64,9 +64,13 @@ def _layer(n_pix, w, b, a1, a2=None, relu=True, f32=False, mask_src=None, residu
 
 
 def _wgrad(n_pix, dz, a1, a2, n, k):
-    dw = torch.zeros(n, k, device=dz.device)
-    db = torch.zeros(n, device=dz.device)
-    check(_lib.load().gags_decoder_wgrad(n_pix, n, k, ptr(dz), ptr(a1), ptr(a2), ptr(dw), ptr(db), _st()), "gags_decoder_wgrad")
+    lib = _lib.load()
+    dw = torch.empty(n, k, device=dz.device)
+    db = torch.empty(n, device=dz.device)
+    nb = lib.gags_decoder_wgrad_scratch_bytes(n_pix, n, k)
+    scratch = torch.empty(max(nb, 4), dtype=torch.uint8, device=dz.device)  # partial matrices per pixel chunk
+    check(lib.gags_decoder_wgrad(n_pix, n, k, ptr(dz), ptr(a1), ptr(a2), ptr(dw), ptr(db), ptr(scratch), nb, _st()),
+          "gags_decoder_wgrad")
     return dw, db
 
 

@@ -93,11 +93,13 @@ int gags_decoder_layer(int64_t n_pix, int n_out, int k_in, const void *a1, const
                        void *y_premask_bf16, float *y_f32, void *stream);
 /* (y_premask_bf16, optional: the value before the mask -- the gradient that also travels over a skip connection.) */
 
-/* Weight and bias gradient of one layer: d_w[n_out, k_in] += sum_p dz[p, n] * (a1[p, k] + a2[p, k]),
- * d_b[n_out] += sum_p dz[p, n] (d_b optional); both fp32, zeroed by the caller, accumulated with float atomics over
- * pixel chunks.  dz, a1, a2 (optional): bf16 pixel-major.  n_out % 16 == 0, k_in % 16 == 0. */
+/* Weight and bias gradient of one layer: d_w[n_out, k_in] = sum_p dz[p, n] * (a1[p, k] + a2[p, k]),
+ * d_b[n_out] = sum_p dz[p, n] (d_b optional); both fp32, OVERWRITTEN.  No atomics: every pixel chunk leaves a partial
+ * matrix in `scratch` (gags_decoder_wgrad_scratch_bytes) and the partials are summed in chunk order -- bit-reproducible.
+ * dz, a1, a2 (optional): bf16 pixel-major.  n_out % 16 == 0, k_in % 16 == 0. */
+int64_t gags_decoder_wgrad_scratch_bytes(int64_t n_pix, int n_out, int k_in);
 int gags_decoder_wgrad(int64_t n_pix, int n_out, int k_in, const void *dz, const void *a1, const void *a2, float *d_w,
-                       float *d_b, void *stream);
+                       float *d_b, void *scratch, int64_t scratch_bytes, void *stream);
 
 /* Backward of gags_decoder_head: cotangent g (layout 0: [c, n_pix], 1: [n_pix, c]) + the saved logits x[n_pix, ld] ->
  * pixel-major bf16 dz[n_pix, ld]. */
