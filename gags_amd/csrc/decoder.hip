@@ -760,7 +760,15 @@ __global__ __launch_bounds__(256) void sum_wparts_kernel(int n_parts, int64_t el
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= elems) return;
     float t = 0.f;
-    for (int c = 0; c < n_parts; ++c) t += part[(size_t)c * elems + e];
+    int c = 0;
+    for (; c + 16 <= n_parts; c += 16) {  // 16 loads in flight, adds in chunk order (a plain loop waits one latency per chunk)
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = part[(size_t)(c + i) * elems + e];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += v[i];
+    }
+    for (; c < n_parts; ++c) t += part[(size_t)c * elems + e];
     out[e] = t;
 }
 

@@ -24,21 +24,23 @@ constexpr int XM = 128, XN = 128, XK = 32;  // workgroup tile: 128 x 128 outputs
 constexpr int XLD = XK + 8;                 // LDS row pitch in bf16 (80 B: 16-byte aligned rows, banks spread)
 constexpr int NTERM = 3;
 
-__device__ __forceinline__ unsigned short xf2bf(float f)
+// two floats -> packed bf16 pair, round to nearest even, in one instruction (v_cvt_pk_bf16_f32, new on gfx950)
+typedef __bf16 xbf16x2_t __attribute__((ext_vector_type(2)));
+typedef float xf32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned xpack(float lo, float hi)
 {
-    unsigned u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even (operands are finite)
-    return (unsigned short)(u >> 16);
+    const xf32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, xbf16x2_t));
 }
-__device__ __forceinline__ float xbf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 
-__device__ __forceinline__ void split3(float a, unsigned short (&t)[NTERM])
+// (a, b) -> three packed bf16 pairs t[s] = (term s of a) | (term s of b) << 16 with  x = h + m + l  exactly
+__device__ __forceinline__ void split3x2(float a, float b, unsigned (&t)[NTERM])
 {
-    t[0] = xf2bf(a);
-    float r = a - xbf2f(t[0]);
-    t[1] = xf2bf(r);
-    r = r - xbf2f(t[1]);
-    t[2] = xf2bf(r);
+    t[0] = xpack(a, b);
+    float ra = a - __uint_as_float(t[0] << 16), rb = b - __uint_as_float(t[0] & 0xffff0000u);
+    t[1] = xpack(ra, rb);
+    ra -= __uint_as_float(t[1] << 16); rb -= __uint_as_float(t[1] & 0xffff0000u);
+    t[2] = xpack(ra, rb);
 }
 
 struct XArgs {
@@ -53,83 +55,90 @@ struct XArgs {
     int Mo, No;             // TN: output rows (n_out) / columns (k_in)
     int64_t P, chunk;       // TN: contraction length and pixels per workgroup
     float *part;            // TN: partial outputs [n_chunks][Mo * No]
+    float *bias_part;       // TN: partial column sums of A1 (the bias gradient) [n_chunks][Mo], or null
 };
 
-// rows [r0, r0 + 128) x contraction [k0, k0 + 32) of a row-major fp32 matrix (+ optional second summand) -> three bf16 planes
+// Staging is split in two so that the global loads of step s + 1 are in flight while step s multiplies:
+//   fetch_*  : global -> registers (4 x float4 per thread and operand; addresses clamped, out-of-range elements zeroed)
+//   commit_* : registers -> split into three bf16 planes -> LDS
+// rows [r0, r0 + 128) x contraction [k0, k0 + 32) of a row-major fp32 matrix (+ optional second summand)
 template <bool TWO>
-__device__ __forceinline__ void stage_rows(unsigned short (*S)[XM][XLD], const float *__restrict__ a1, const float *__restrict__ a2,
-                                           int ld, int64_t r0, int64_t rows, int k0, int K, bool vec, int tid)
+__device__ __forceinline__ void fetch_rows(float (&v)[4][4], const float *__restrict__ a1, const float *__restrict__ a2, int ld,
+                                           int64_t r0, int64_t rows, int k0, int K, bool vec, int tid)
 {
     const int kc = (tid & 7) * 4;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int r = (tid >> 3) + 32 * q;
-        const int64_t rg = r0 + r;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        const int64_t rg = r0 + (tid >> 3) + 32 * q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[q][e] = 0.f;
         if (rg < rows) {
             const float *p1 = a1 + rg * ld + k0 + kc;
             if (vec && k0 + kc + 3 < K) {
                 const float4 u = *reinterpret_cast<const float4 *>(p1);
-                v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
+                v[q][0] = u.x; v[q][1] = u.y; v[q][2] = u.z; v[q][3] = u.w;
                 if constexpr (TWO) {
                     const float4 w = *reinterpret_cast<const float4 *>(a2 + rg * ld + k0 + kc);
-                    v[0] += w.x; v[1] += w.y; v[2] += w.z; v[3] += w.w;
+                    v[q][0] += w.x; v[q][1] += w.y; v[q][2] += w.z; v[q][3] += w.w;
                 }
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (k0 + kc + e < K) {
-                        v[e] = p1[e];
-                        if constexpr (TWO) v[e] += a2[rg * ld + k0 + kc + e];
+                        v[q][e] = p1[e];
+                        if constexpr (TWO) v[q][e] += a2[rg * ld + k0 + kc + e];
                     }
             }
         }
-        unsigned short t[4][NTERM];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) split3(v[e], t[e]);
-#pragma unroll
-        for (int s = 0; s < NTERM; ++s)
-            *reinterpret_cast<uint2 *>(&S[s][r][kc]) =
-                make_uint2((unsigned)t[0][s] | ((unsigned)t[1][s] << 16), (unsigned)t[2][s] | ((unsigned)t[3][s] << 16));
     }
 }
 
-// TN: pixels [p0, p0 + 32) x columns [c0, c0 + 128) of src [P, C] -> S[term][column][pixel] (transposed on the way in)
-template <bool TWO>
-__device__ __forceinline__ void stage_cols(unsigned short (*S)[XM][XLD], const float *__restrict__ s1, const float *__restrict__ s2,
-                                           int ld, int64_t p0, int64_t p_end, int c0, int C, bool vec, int tid)
+__device__ __forceinline__ void commit_rows(unsigned short (*S)[XM][XLD], const float (&v)[4][4], int tid)
 {
-    const int cc = (tid & 31) * 4;
+    const int kc = (tid & 7) * 4;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int pr = (tid >> 5) + 8 * q;
-        const int64_t pg = p0 + pr;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (pg < p_end) {
-            const float *src = s1 + pg * ld + c0 + cc;
-            if (vec && c0 + cc + 3 < C) {
-                const float4 u = *reinterpret_cast<const float4 *>(src);
-                v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
-                if constexpr (TWO) {
-                    const float4 w = *reinterpret_cast<const float4 *>(s2 + pg * ld + c0 + cc);
-                    v[0] += w.x; v[1] += w.y; v[2] += w.z; v[3] += w.w;
-                }
-            } else {
+        const int r = (tid >> 3) + 32 * q;
+        unsigned t01[NTERM], t23[NTERM];
+        split3x2(v[q][0], v[q][1], t01);
+        split3x2(v[q][2], v[q][3], t23);
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (c0 + cc + e < C) {
-                        v[e] = src[e];
-                        if constexpr (TWO) v[e] += s2[pg * ld + c0 + cc + e];
-                    }
-            }
-        }
+        for (int s = 0; s < NTERM; ++s) *reinterpret_cast<uint2 *>(&S[s][r][kc]) = make_uint2(t01[s], t23[s]);
+    }
+}
+
+// TN: pixels [p0, p0 + 32) x columns [c0, c0 + 128) of src [P, C]: thread = ONE column x 16 consecutive pixels.  The
+// lanes of a wave read 64 consecutive floats of a pixel row (coalesced) and later write 64 consecutive LDS rows (banks
+// spread); with four columns per thread the rows written by a wave were 320 B apart: 8-way bank conflicts.
+template <bool TWO>
+__device__ __forceinline__ void fetch_cols(float (&v)[16], const float *__restrict__ s1, const float *__restrict__ s2, int ld,
+                                           int64_t p0, int64_t p_end, int c0, int C, int tid)
+{
+    const int c = c0 + (tid & 127);
+    const int64_t pg0 = p0 + 16 * (tid >> 7);
+    const bool cin = c < C;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            unsigned short t[NTERM];
-            split3(v[e], t);
+    for (int i = 0; i < 16; ++i) {
+        const int64_t pg = pg0 + i;
+        const bool ok = cin && pg < p_end;
+        const size_t o = (size_t)(ok ? pg : p0) * ld + (cin ? c : c0);  // clamped: the load itself is unconditional
+        float x = s1[o];
+        if constexpr (TWO) x += s2[o];
+        v[i] = ok ? x : 0.f;
+    }
+}
+
+// ... -> S[term][column][pixel]: four 8-byte stores per term (four consecutive pixels each: the transposition)
+__device__ __forceinline__ void commit_cols(unsigned short (*S)[XM][XLD], const float (&v)[16], int tid)
+{
+    const int c = tid & 127, sp = 16 * (tid >> 7);
 #pragma unroll
-            for (int s = 0; s < NTERM; ++s) S[s][cc + e][pr] = t[s];
-        }
+    for (int j = 0; j < 4; ++j) {
+        unsigned t01[NTERM], t23[NTERM];
+        split3x2(v[4 * j], v[4 * j + 1], t01);
+        split3x2(v[4 * j + 2], v[4 * j + 3], t23);
+#pragma unroll
+        for (int s = 0; s < NTERM; ++s) *reinterpret_cast<uint2 *>(&S[s][c][sp + 4 * j]) = make_uint2(t01[s], t23[s]);
     }
 }
 
@@ -180,10 +189,17 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_nt_kernel(XArgs g)
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float va[4][4], vb[4][4];
+    fetch_rows<TWO>(va, g.A1, g.A2, g.lda, m0, g.M, 0, g.K, veca, tid);
+    fetch_rows<false>(vb, g.B, nullptr, g.ldb, n0, g.N, 0, g.K, vecb, tid);
     for (int k0 = 0; k0 < g.K; k0 += XK) {
-        stage_rows<TWO>(Xs, g.A1, g.A2, g.lda, m0, g.M, k0, g.K, veca, tid);
-        stage_rows<false>(Ys, g.B, nullptr, g.ldb, n0, g.N, k0, g.K, vecb, tid);
+        commit_rows(Xs, va, tid);
+        commit_rows(Ys, vb, tid);
         __syncthreads();
+        if (k0 + XK < g.K) {  // next step's operands: in flight while this one multiplies
+            fetch_rows<TWO>(va, g.A1, g.A2, g.lda, m0, g.M, k0 + XK, g.K, veca, tid);
+            fetch_rows<false>(vb, g.B, nullptr, g.ldb, n0, g.N, k0 + XK, g.K, vecb, tid);
+        }
         tile_step(acc, Xs, Ys, wy, wx, lane);
         __syncthreads();
     }
@@ -215,12 +231,10 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_tn_kernel(XArgs g)
 {
     __shared__ __attribute__((aligned(16))) unsigned short Xs[NTERM][XM][XLD];
     __shared__ __attribute__((aligned(16))) unsigned short Ys[NTERM][XN][XLD];
+    __shared__ float bsh[2][XM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wy = wave >> 1, wx = wave & 1;
     const int64_t pa = (int64_t)blockIdx.x * g.chunk, pb = min(pa + g.chunk, g.P);
     const int m0 = blockIdx.y * XM, n0 = blockIdx.z * XN;
-    const bool veca = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A1) & 15) == 0);
-    const bool vecb = (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0) &&
-                      (!TWO || (reinterpret_cast<uintptr_t>(g.B2) & 15) == 0);
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -228,10 +242,24 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_tn_kernel(XArgs g)
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // bias gradient on the way: column sums of dz over the chunk, this thread's column and pixel half, in pixel order
+    const bool do_bias = g.bias_part != nullptr && blockIdx.z == 0;
+    float bsum = 0.f;
+    float va[16], vb[16];
+    fetch_cols<false>(va, g.A1, nullptr, g.lda, pa, pb, m0, g.Mo, tid);
+    fetch_cols<TWO>(vb, g.B, g.B2, g.ldb, pa, pb, n0, g.No, tid);
     for (int64_t p0 = pa; p0 < pb; p0 += XK) {
-        stage_cols<false>(Xs, g.A1, nullptr, g.lda, p0, pb, m0, g.Mo, veca, tid);
-        stage_cols<TWO>(Ys, g.B, g.B2, g.ldb, p0, pb, n0, g.No, vecb, tid);
+        commit_cols(Xs, va, tid);
+        commit_cols(Ys, vb, tid);
+        if (do_bias) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bsum += va[i];
+        }
         __syncthreads();
+        if (p0 + XK < pb) {  // next step's operands: in flight while this one multiplies
+            fetch_cols<false>(va, g.A1, nullptr, g.lda, p0 + XK, pb, m0, g.Mo, tid);
+            fetch_cols<TWO>(vb, g.B, g.B2, g.ldb, p0 + XK, pb, n0, g.No, tid);
+        }
         tile_step(acc, Xs, Ys, wy, wx, lane);
         __syncthreads();
     }
@@ -248,33 +276,36 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_tn_kernel(XArgs g)
                 if (n < g.Mo) out[(size_t)n * g.No + k] = acc[i][j][r];
             }
         }
+    if (do_bias) {  // (uniform over the workgroup)
+        bsh[tid >> 7][tid & 127] = bsum;
+        __syncthreads();
+        if (tid < XM && m0 + tid < g.Mo) g.bias_part[(size_t)blockIdx.x * g.Mo + m0 + tid] = bsh[0][tid] + bsh[1][tid];
+    }
 }
 
-// out[e] = sum over the chunks, in chunk order (fixed => reproducible)
+// out[e] = sum over the chunks, in chunk order (fixed => reproducible); the loads of 16 chunks are issued together (a
+// plain loop waited one memory latency per chunk: 0.14 ms per call with 512 chunks)
 __global__ __launch_bounds__(256) void sum_parts_kernel(int n_chunks, int64_t elems, const float *__restrict__ part,
                                                         float *__restrict__ out)
 {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= elems) return;
     float s = 0.f;
-    for (int c = 0; c < n_chunks; ++c) s += part[(size_t)c * elems + e];
+    int c = 0;
+    for (; c + 16 <= n_chunks; c += 16) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = part[(size_t)(c + i) * elems + e];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += v[i];
+    }
+    for (; c < n_chunks; ++c) s += part[(size_t)c * elems + e];
     out[e] = s;
-}
-
-// column sums of dz[P, C] over a chunk of pixels (the bias gradient), one thread per column, rows in order
-__global__ __launch_bounds__(256) void colsum_kernel(int64_t P, int C, int ld, int64_t chunk, const float *__restrict__ dz,
-                                                     float *__restrict__ part)
-{
-    const int c = blockIdx.y * 256 + threadIdx.x;
-    if (c >= C) return;
-    const int64_t pa = (int64_t)blockIdx.x * chunk, pb = min(pa + chunk, P);
-    float s = 0.f;
-    for (int64_t p = pa; p < pb; ++p) s += dz[p * ld + c];
-    part[(size_t)blockIdx.x * C + c] = s;
 }
 
 // backward of the output heads in fp32 (see decoder.hip head_bwd_kernel): one wave per pixel
 //   mode 0 (y = x / max(||x||, eps)):  dz = (g - y <y, g>) / max(||x||, eps);   mode 1 (softmax):  dz = y (g - <y, g>)
+constexpr int HX_MAX = 16;  // values of a row per lane: C <= 1024
 __global__ __launch_bounds__(256) void head_bwd_exact_kernel(int64_t P, int C, int ldx, int mode, const float *__restrict__ x,
                                                              const float *__restrict__ G, int layout, float *__restrict__ dz,
                                                              int lddz)
@@ -282,35 +313,39 @@ __global__ __launch_bounds__(256) void head_bwd_exact_kernel(int64_t P, int C, i
     const int lane = threadIdx.x & 63;
     const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (p >= P) return;
+    float xv[HX_MAX], gv[HX_MAX];  // the logits and the cotangent of this pixel: read once
     float s = 0.f, m = -3.0e38f;
-    for (int c = lane; c < C; c += 64) {
-        const float v = x[p * ldx + c];
-        s = fmaf(v, v, s);
-        m = fmaxf(m, v);
+#pragma unroll
+    for (int q = 0; q < HX_MAX; ++q) {
+        const int c = lane + 64 * q;
+        xv[q] = gv[q] = 0.f;
+        if (c < C) {
+            xv[q] = x[p * ldx + c];
+            gv[q] = layout == 1 ? G[p * C + c] : G[(size_t)c * P + p];
+            s = fmaf(xv[q], xv[q], s);
+            m = fmaxf(m, xv[q]);
+        }
     }
     for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off, 64); m = fmaxf(m, __shfl_xor(m, off, 64)); }
     float z = 0.f;
     if (mode == 1) {
-        for (int c = lane; c < C; c += 64) z += expf(x[p * ldx + c] - m);
+#pragma unroll
+        for (int q = 0; q < HX_MAX; ++q)
+            if (lane + 64 * q < C) z += expf(xv[q] - m);
         for (int off = 32; off > 0; off >>= 1) z += __shfl_xor(z, off, 64);
     }
     const float nrm = fmaxf(sqrtf(s), 1e-12f);
     float dot = 0.f;
-    for (int c = lane; c < C; c += 64) {
-        const float v = x[p * ldx + c];
-        const float y = mode == 0 ? v / nrm : expf(v - m) / z;
-        const float gv = layout == 1 ? G[p * C + c] : G[(size_t)c * P + p];
-        dot = fmaf(y, gv, dot);
-    }
+#pragma unroll
+    for (int q = 0; q < HX_MAX; ++q)
+        if (lane + 64 * q < C) dot = fmaf(mode == 0 ? xv[q] / nrm : expf(xv[q] - m) / z, gv[q], dot);
     for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
-    for (int c = lane; c < lddz; c += 64) {
+#pragma unroll
+    for (int q = 0; q < HX_MAX; ++q) {
+        const int c = lane + 64 * q;
+        if (c >= lddz) continue;
         float d = 0.f;
-        if (c < C) {
-            const float v = x[p * ldx + c];
-            const float gv = layout == 1 ? G[p * C + c] : G[(size_t)c * P + p];
-            if (mode == 0) d = (gv - (v / nrm) * dot) / nrm;
-            else d = (expf(v - m) / z) * (gv - dot);
-        }
+        if (c < C) d = mode == 0 ? (gv[q] - (xv[q] / nrm) * dot) / nrm : (expf(xv[q] - m) / z) * (gv[q] - dot);
         dz[p * lddz + c] = d;
     }
 }
@@ -366,17 +401,15 @@ extern "C" int gags_decoder_wgrad_exact(int64_t n_pix, int n_out, int k_in, cons
     float *part = (float *)scratch, *part_b = part + (size_t)n_chunks * n_out * k_in;
     XArgs g = {};
     g.A1 = dz; g.lda = lddz; g.B = a1; g.B2 = a2; g.ldb = lda; g.Mo = n_out; g.No = k_in; g.P = n_pix; g.chunk = chunk; g.part = part;
+    g.bias_part = d_b ? part_b : nullptr;
     const dim3 grid((unsigned)n_chunks, (unsigned)((n_out + XM - 1) / XM), (unsigned)((k_in + XN - 1) / XN));
     if (a2) hipLaunchKernelGGL(gemm_x3_tn_kernel<true>, grid, dim3(256), 0, st, g);
     else hipLaunchKernelGGL(gemm_x3_tn_kernel<false>, grid, dim3(256), 0, st, g);
     const int64_t elems = (int64_t)n_out * k_in;
     hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, n_chunks, elems, part, d_w);
-    if (d_b) {
-        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)n_chunks, (unsigned)((n_out + 255) / 256)), dim3(256), 0, st, n_pix, n_out,
-                           lddz, chunk, dz, part_b);
+    if (d_b)
         hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, n_chunks, (int64_t)n_out, part_b,
                            d_b);
-    }
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }
@@ -385,7 +418,7 @@ extern "C" int gags_decoder_head_bwd_exact(int64_t n_pix, int c, int ldx, int mo
                                            float *dz, int lddz, void *stream)
 {
     GAGS_CLEAR_ERR();
-    if (n_pix < 0 || c <= 0 || ldx < c || lddz < c || (mode != 0 && mode != 1) || (layout != 0 && layout != 1) ||
+    if (n_pix < 0 || c <= 0 || c > 64 * HX_MAX || lddz > 64 * HX_MAX || ldx < c || lddz < c || (mode != 0 && mode != 1) || (layout != 0 && layout != 1) ||
         (n_pix > 0 && (!x || !g || !dz)))
         return GAGS_EINVAL;
     if (n_pix == 0) return GAGS_OK;
