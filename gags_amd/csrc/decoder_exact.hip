@@ -55,6 +55,7 @@ struct XArgs {
     int Mo, No;             // TN: output rows (n_out) / columns (k_in)
     int64_t P, chunk;       // TN: contraction length and pixels per workgroup
     float *part;            // TN: partial outputs [n_chunks][Mo * No]
+    unsigned m_tiles, n_tiles;  // NT: tile counts (the workgroup index is decoded XCD-aware)
     float *bias_part;       // TN: partial column sums of A1 (the bias gradient) [n_chunks][Mo], or null
 };
 
@@ -62,32 +63,36 @@ struct XArgs {
 //   fetch_*  : global -> registers (4 x float4 per thread and operand; addresses clamped, out-of-range elements zeroed)
 //   commit_* : registers -> split into three bf16 planes -> LDS
 // rows [r0, r0 + 128) x contraction [k0, k0 + 32) of a row-major fp32 matrix (+ optional second summand)
-template <bool TWO>
+// Every load is unconditional (addresses clamped into the matrix, out-of-range elements replaced by zero afterwards): a
+// guarded load is a branch and a wait of its own, and eight of them in a row serialise the whole prefetch.
+// VEC: K % 4 == 0, ld % 4 == 0 and 16-byte aligned bases (checked by the entry) -> one float4 per row piece.
+template <bool TWO, bool VEC>
 __device__ __forceinline__ void fetch_rows(float (&v)[4][4], const float *__restrict__ a1, const float *__restrict__ a2, int ld,
-                                           int64_t r0, int64_t rows, int k0, int K, bool vec, int tid)
+                                           int64_t r0, int64_t rows, int k0, int K, int tid)
 {
-    const int kc = (tid & 7) * 4;
+    const int kc = k0 + (tid & 7) * 4;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int64_t rg = r0 + (tid >> 3) + 32 * q;
+        const bool rok = rg < rows;
+        const size_t base = (size_t)(rok ? rg : rows - 1) * ld;
+        if constexpr (VEC) {
+            const bool ok = rok && kc < K;  // K % 4 == 0: the piece is inside or outside as a whole
+            const size_t o = base + (kc < K ? kc : 0);
+            float4 u = *reinterpret_cast<const float4 *>(a1 + o);
+            if constexpr (TWO) {
+                const float4 w = *reinterpret_cast<const float4 *>(a2 + o);
+                u.x += w.x; u.y += w.y; u.z += w.z; u.w += w.w;
+            }
+            v[q][0] = ok ? u.x : 0.f; v[q][1] = ok ? u.y : 0.f; v[q][2] = ok ? u.z : 0.f; v[q][3] = ok ? u.w : 0.f;
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[q][e] = 0.f;
-        if (rg < rows) {
-            const float *p1 = a1 + rg * ld + k0 + kc;
-            if (vec && k0 + kc + 3 < K) {
-                const float4 u = *reinterpret_cast<const float4 *>(p1);
-                v[q][0] = u.x; v[q][1] = u.y; v[q][2] = u.z; v[q][3] = u.w;
-                if constexpr (TWO) {
-                    const float4 w = *reinterpret_cast<const float4 *>(a2 + rg * ld + k0 + kc);
-                    v[q][0] += w.x; v[q][1] += w.y; v[q][2] += w.z; v[q][3] += w.w;
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (k0 + kc + e < K) {
-                        v[q][e] = p1[e];
-                        if constexpr (TWO) v[q][e] += a2[rg * ld + k0 + kc + e];
-                    }
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = rok && kc + e < K;
+                const size_t o = base + (kc + e < K ? kc + e : 0);
+                float x = a1[o];
+                if constexpr (TWO) x += a2[o];
+                v[q][e] = ok ? x : 0.f;
             }
         }
     }
@@ -121,7 +126,7 @@ __device__ __forceinline__ void fetch_cols(float (&v)[16], const float *__restri
     for (int i = 0; i < 16; ++i) {
         const int64_t pg = pg0 + i;
         const bool ok = cin && pg < p_end;
-        const size_t o = (size_t)(ok ? pg : p0) * ld + (cin ? c : c0);  // clamped: the load itself is unconditional
+        const size_t o = (size_t)(ok ? pg : p_end - 1) * ld + (cin ? c : c0);  // clamped: the load itself is unconditional
         float x = s1[o];
         if constexpr (TWO) x += s2[o];
         v[i] = ok ? x : 0.f;
@@ -171,17 +176,19 @@ __device__ __forceinline__ void tile_step(f32x16 (&acc)[2][2], unsigned short (*
     }
 }
 
-template <bool TWO>
+template <bool TWO, bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_x3_nt_kernel(XArgs g)
 {
     __shared__ __attribute__((aligned(16))) unsigned short Xs[NTERM][XM][XLD];
     __shared__ __attribute__((aligned(16))) unsigned short Ys[NTERM][XN][XLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wy = wave >> 1, wx = wave & 1;
-    const int64_t m0 = (int64_t)blockIdx.x * XM;
-    const int n0 = blockIdx.y * XN;
-    const bool veca = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A1) & 15) == 0) &&
-                      (!TWO || (reinterpret_cast<uintptr_t>(g.A2) & 15) == 0);
-    const bool vecb = (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
+    // the column tiles of one pixel tile run back to back on the SAME XCD (workgroups are dealt round-robin over the 8
+    // XCDs, each with its own L2): the second one finds the activation rows in that L2 instead of re-reading HBM
+    const unsigned xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const unsigned mt = (slot / g.n_tiles) * 8 + xcd;
+    if (mt >= g.m_tiles) return;
+    const int64_t m0 = (int64_t)mt * XM;
+    const int n0 = (int)(slot % g.n_tiles) * XN;
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -190,38 +197,54 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_nt_kernel(XArgs g)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     float va[4][4], vb[4][4];
-    fetch_rows<TWO>(va, g.A1, g.A2, g.lda, m0, g.M, 0, g.K, veca, tid);
-    fetch_rows<false>(vb, g.B, nullptr, g.ldb, n0, g.N, 0, g.K, vecb, tid);
+    fetch_rows<TWO, VEC>(va, g.A1, g.A2, g.lda, m0, g.M, 0, g.K, tid);
+    fetch_rows<false, VEC>(vb, g.B, nullptr, g.ldb, n0, g.N, 0, g.K, tid);
     for (int k0 = 0; k0 < g.K; k0 += XK) {
         commit_rows(Xs, va, tid);
         commit_rows(Ys, vb, tid);
         __syncthreads();
-        if (k0 + XK < g.K) {  // next step's operands: in flight while this one multiplies
-            fetch_rows<TWO>(va, g.A1, g.A2, g.lda, m0, g.M, k0 + XK, g.K, veca, tid);
-            fetch_rows<false>(vb, g.B, nullptr, g.ldb, n0, g.N, k0 + XK, g.K, vecb, tid);
-        }
+        // next step's operands: in flight while this one multiplies (past the end: clamped re-reads, never committed)
+        fetch_rows<TWO, VEC>(va, g.A1, g.A2, g.lda, m0, g.M, k0 + XK, g.K, tid);
+        fetch_rows<false, VEC>(vb, g.B, nullptr, g.ldb, n0, g.N, k0 + XK, g.K, tid);
+        __builtin_amdgcn_sched_barrier(0);  // (the scheduler would sink the loads to their use after the MFMAs)
         tile_step(acc, Xs, Ys, wy, wx, lane);
         __syncthreads();
     }
-    // accumulator of tile (i, j): column = lane & 31 -> n, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -> pixel
+    // accumulator of tile (i, j): column = lane & 31 -> n, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -> pixel.
+    // The residual / mask rows of a tile are requested together, unconditionally (clamped addresses), before any of
+    // them is used: sixteen guarded loads in a row would cost sixteen memory latencies.
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + wx * 64 + j * 32 + (lane & 31);
-            if (n >= g.N) continue;
-            const float bv = g.bias ? g.bias[n] : 0.f;
+            const int nc = min(n, g.N - 1);
+            const float bv = g.bias ? g.bias[nc] : 0.f;
+            size_t o[16];
+            float ev[16], mv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t p = m0 + wy * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (p >= g.M) continue;
+                o[r] = (size_t)min(p, g.M - 1) * g.ldy + nc;
+            }
+            if (g.E) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ev[r] = g.E[o[r]];
+            }
+            if (g.mask_src) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mv[r] = g.mask_src[o[r]];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t p = m0 + wy * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 float v = acc[i][j][r] + bv;
                 if (g.relu) v = fmaxf(v, 0.f);
-                const size_t o = (size_t)p * g.ldy + n;
-                if (g.E) v += g.E[o];
-                if (g.Ypre) g.Ypre[o] = v;
-                if (g.mask_src) v = g.mask_src[o] > 0.f ? v : 0.f;
-                if (g.Y) g.Y[o] = v;
+                if (g.E) v += ev[r];
+                const bool in = p < g.M && n < g.N;
+                if (g.Ypre && in) g.Ypre[o[r]] = v;
+                if (g.mask_src) v = mv[r] > 0.f ? v : 0.f;
+                if (g.Y && in) g.Y[o[r]] = v;
             }
         }
 }
@@ -256,10 +279,10 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_tn_kernel(XArgs g)
             for (int i = 0; i < 16; ++i) bsum += va[i];
         }
         __syncthreads();
-        if (p0 + XK < pb) {  // next step's operands: in flight while this one multiplies
-            fetch_cols<false>(va, g.A1, nullptr, g.lda, p0 + XK, pb, m0, g.Mo, tid);
-            fetch_cols<TWO>(vb, g.B, g.B2, g.ldb, p0 + XK, pb, n0, g.No, tid);
-        }
+        // next step's operands: in flight while this one multiplies (past the end: clamped re-reads, never committed)
+        fetch_cols<false>(va, g.A1, nullptr, g.lda, p0 + XK, pb, m0, g.Mo, tid);
+        fetch_cols<TWO>(vb, g.B, g.B2, g.ldb, p0 + XK, pb, n0, g.No, tid);
+        __builtin_amdgcn_sched_barrier(0);
         tile_step(acc, Xs, Ys, wy, wx, lane);
         __syncthreads();
     }
@@ -369,9 +392,19 @@ extern "C" int gags_decoder_layer_exact(int64_t n_pix, int n_out, int k_in, cons
     XArgs g = {};
     g.A1 = a1; g.A2 = a2; g.B = w; g.bias = bias; g.mask_src = mask_src; g.E = residual; g.Y = y; g.Ypre = y_premask;
     g.M = n_pix; g.N = n_out; g.K = k_in; g.lda = lda; g.ldb = k_in; g.ldy = ldy; g.relu = relu;
-    const dim3 grid((unsigned)((n_pix + XM - 1) / XM), (unsigned)((n_out + XN - 1) / XN));
-    if (a2) hipLaunchKernelGGL(gemm_x3_nt_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, g);
-    else hipLaunchKernelGGL(gemm_x3_nt_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, g);
+    g.m_tiles = (unsigned)((n_pix + XM - 1) / XM);
+    g.n_tiles = (unsigned)((n_out + XN - 1) / XN);
+    const dim3 grid((g.m_tiles + 7) / 8 * 8 * g.n_tiles);
+    const bool vec = k_in % 4 == 0 && lda % 4 == 0 && ((reinterpret_cast<uintptr_t>(a1) | reinterpret_cast<uintptr_t>(a2) |
+                                                          reinterpret_cast<uintptr_t>(w)) & 15) == 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (a2) {
+        if (vec) hipLaunchKernelGGL((gemm_x3_nt_kernel<true, true>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((gemm_x3_nt_kernel<true, false>), grid, dim3(256), 0, st, g);
+    } else {
+        if (vec) hipLaunchKernelGGL((gemm_x3_nt_kernel<false, true>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((gemm_x3_nt_kernel<false, false>), grid, dim3(256), 0, st, g);
+    }
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }
