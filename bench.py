@@ -78,7 +78,8 @@ def parse():
     ap.add_argument("--wire", default="fp32", choices=["fp32", "bf16"],
                     help="by-view step: dtype of the gradient on the wire (bf16: opt-in, ~1e-2 relative error, halves the bytes)")
     ap.add_argument("--raster-flags", type=int, default=0,
-                    help="gags_amd._lib flags; 64 = GAGS_BWD_F16SPLIT (backward contraction on the 16-bit matrix cores, opt-in)")
+                    help="gags_amd._lib flags; 64 = GAGS_BWD_F32MFMA (backward contraction on the fp32 matrix instructions "
+                         "instead of the default fp32-equivalent split operands on the 16-bit matrix cores)")
     ap.add_argument("--parallel", default="view", choices=["auto", "view", "channel"],
                     help="N>1: one view per GPU + gradient exchange (view: north_star's decomposition, the default), "
                          "every GPU renders all N views for its channel shard with no exchange (channel), or whichever "
@@ -166,7 +167,7 @@ def host_cpu():
 # (matched as prefixes: template arguments differ between rounds, e.g. "raster_fwd_feat<4, false>")
 STAGE_KERNELS = {
     "raster_fwd": ("raster_weights_kernel", "raster_fwd_feat<4"),
-    "bwd_rows": ("raster_bwd_rows<4",),
+    "bwd_rows": ("raster_bwd_rows_f16",),
     "bwd_reduce": ("reduce_rows_kernel",),
 }
 
@@ -418,6 +419,9 @@ def main():
             if name in kernels:
                 tb = [_traffic_of(traffic, m) for m in members]
                 kernels[name]["traffic"] = sum(tb) if all(t is not None for t in tb) else None
+        if "bwd_rows" in kernels and not (args.raster_flags & _lib.GAGS_BWD_F32MFMA):
+            kernels["bwd_rows"]["note"] = ("algorithmic fp32 flops (2 D Q_blend) against the fp32 matrix peak; the kernel issues them as "
+                                           "5 v_mfma_f32_32x32x16_f16 terms per product on split operands (fp32-equivalent, DESIGN.md 4)")
         dom = max(kernels, key=lambda k_: kernels[k_]["avg_launch_ms"])
         roof = dict(kernels[dom], kernel=dom, traffic_source=traffic_src)
         line = {
@@ -425,6 +429,8 @@ def main():
             "value": value, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "dtype_note": "fp32 tensors and fp32(-equivalent) arithmetic: forward on v_mfma_f32_32x32x2_f32 (bit-identical to the oracle); "
+                          "backward contraction on v_mfma_f32_32x32x16_f16 with fp32-equivalent split operands, fp32 accumulation",
             "config": {"workload": f"{args.config}: {n} Gaussians, {width}x{height}, D={d}, {world} view(s)/step"
                                    + (f", every GPU renders all {world} views for its {d_local} channels"
                                       if mode == "channel" else ", 1 view/GPU/step"),
@@ -464,9 +470,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pc, cam, d, width, height, args.cpu_seconds)
         if world == 1 and d % 128 == 0 and not (args.no_heavy or args.raster_flags):
-            # opt-in mode, reported next to `value` (never as `value`): the staged backward's contraction on the 16-bit
-            # matrix cores, both operands as fp16 head + tail (gags_amd._lib.GAGS_BWD_F16SPLIT)
-            args.raster_flags = _lib.GAGS_BWD_F16SPLIT
+            # the same workload with the backward's contraction on the fp32 matrix instructions (rounds 1-2's default,
+            # gags_amd._lib.GAGS_BWD_F32MFMA), reported next to `value` for comparison; DESIGN.md section 4
+            args.raster_flags = _lib.GAGS_BWD_F32MFMA
             for _ in range(2):
                 step()
             torch.cuda.synchronize()
@@ -477,10 +483,10 @@ def main():
             torch.cuda.synchronize()
             fdt = time.perf_counter() - t0
             args.raster_flags = 0
-            line["backward_f16split"] = {
-                "note": "opt-in: same workload, forward unchanged (bit-identical to the oracle); the backward contracts on "
-                        "v_mfma_f32_32x32x16_f16 with weights and cotangent split into fp16 head + tail (~2^-21 of a column's "
-                        "largest term; measured 1.8e-7 rel-L2 from float64, the fp32-MFMA backward 1.9e-7)",
+            line["backward_f32mfma"] = {
+                "note": "same workload, forward unchanged; the backward contracts with v_mfma_f32_32x32x2_f32 (rounds 1-2's kernel) "
+                        "instead of the default: v_mfma_f32_32x32x16_f16 on split operands (weights as three fp16 terms: exact; "
+                        "cotangent as two: one fp32 rounding; five MFMA terms per product; vs float64 as close as this kernel)",
                 "value": fsteps / fdt, "unit": "views/s", "ms_per_step": 1e3 * fdt / fsteps, "steps": fsteps}
         if world == 1 and not (args.no_heavy or args.raster_flags):
             # north_star's "feature / geometry gradients": the same workload with EVERY parameter requiring grad (joint

@@ -100,7 +100,9 @@ GAGS_FWD_NO_MFMA = 2
 GAGS_RECS_BY_GAUSSIAN = 256  # C flag: `packed` is the per-Gaussian record table (gags_pack_isects with packed = NULL)
 GAGS_BWD_ATOMIC = 4  # python-side: use the atomic colours-only backward instead of the staged one
 GAGS_FEAT_F16 = 32  # forward: colors is an fp16 table (include/gags_raster.h)
-GAGS_BWD_F16SPLIT = 64  # python-side: staged backward contracts on the 16-bit matrix cores (fp16 head + tail; ~2^-21, opt-in)
+GAGS_BWD_F32MFMA = 64  # python-side: staged backward contracts with v_mfma_f32_32x32x2_f32 (round 1-2's kernel) instead of the
+#                        default fp32-equivalent split operands on the 16-bit matrix cores (csrc/raster_bwd_mfma.hip)
+GAGS_BWD_F16SPLIT = 0   # (round 2's opt-in flag: that kernel, made exact, is the default now)
 GAGS_FWD_F16MFMA = 128  # python-side: fp16 feature table + D % 128 == 0: feature pass on the 16-bit matrix cores (opt-in; C flag 64)
 GAGS_FWD_FUSED = 8  # python-side: single-kernel matrix-core forward (no scratch) instead of weights + features
 

@@ -253,15 +253,21 @@ __global__ __launch_bounds__(256, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void rast
     }
 }
 
-// ---- staged: rows, 16-bit matrix cores (opt-in: GAGS_BWD_F16SPLIT) ---------------------------------------------------
-// The same kernel with the contraction on v_mfma_f32_32x32x16_f16 (16x the fp32 MFMA rate): both operands are split
-// into an fp16 head and an fp16 tail, x = (hi + lo) / scale with
-//   weights   scale 2^12 (alpha*T lies in (4e-7, 1]: every head and tail is a normal fp16 number),
-//   cotangent one power-of-two scale per (pixel block, channel) taken from the column's largest magnitude,
-// and w * v ~ hi*hi + hi*lo + lo*hi (three MFMAs, products exact in the fp32 accumulator; the dropped lo*lo term is
-// 2^-22 relative).  The sums then differ from the fp32 kernel's by ~2^-21 of the column's largest term -- inside the
-// 2e-5 gradient tolerance of the tests, NOT bit-identical to the fp32 kernel; hence opt-in.  Still no atomics and a
-// fixed order: bit-reproducible.  A burst is 48 MFMAs of 32 cycles instead of 128 of 64.
+// ---- staged: rows on the 16-bit matrix cores, fp32-equivalent (the DEFAULT; GAGS_BWD_F32MFMA selects the kernel above) ----
+// The same kernel with the contraction on v_mfma_f32_32x32x16_f16 (16x the fp32 MFMA rate).  Operands are written as sums of
+// fp16 terms, each obtained by round-to-nearest of what the previous terms left over, after an exact power-of-two scaling:
+//   weights    w = (a0 + a1 + a2) / rs   three terms: 33 significand bits >= fp32's 24, i.e. EXACT; rs = one power of two
+//                                        per slot row (its largest weight -> [2^14, 2^15): heads and tails of the weights
+//                                        that matter are normal fp16 numbers);
+//   cotangent  v = (b0 + b1) / cs        two terms: |v cs - b0 - b1| <= 2^-24 |v cs| (each rounding leaves at most half an
+//                                        ulp of an 11-bit significand): ONE fp32 rounding of the input; cs = one power of two
+//                                        per (pixel block, channel), from the column's largest magnitude;
+// and a product as the five terms of order <= 2:   w v ~ a0 b0 + a0 b1 + a1 b0 + a1 b1 + a2 b0   (dropped: a2 b1, 2^-36).
+// Every partial product of two fp16 numbers is exact in the fp32 accumulator.  Net effect: each product w v enters the sum
+// with a relative error <= 2^-24 -- the cotangent rounded once -- which is below the rounding an fp32 dot product of these
+// 64-pixel columns commits in its own additions.  Against float64 (tests/test_fullsize_gpu.py
+// ::test_colour_gradient_accuracy_against_float64) it is at least as close as the fp32-MFMA kernel; no atomics, fixed
+// order: bit-reproducible.  A burst is 80 MFMAs of 32 cycles instead of 128 of 64.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void split8(const float (&x)[8], float scale, f16x8 &hi, f16x8 &lo)
@@ -275,6 +281,20 @@ __device__ __forceinline__ void split8(const float (&x)[8], float scale, f16x8 &
     }
 }
 
+__device__ __forceinline__ void split8x3(const float (&x)[8], float scale, f16x8 &t0, f16x8 &t1, f16x8 &t2)
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float v = x[i] * scale;
+        const _Float16 h = (_Float16)v;
+        const float r = v - (float)h;
+        const _Float16 m = (_Float16)r;
+        t0[i] = h;
+        t1[i] = m;
+        t2[i] = (_Float16)(r - (float)m);
+    }
+}
+
 __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
     int d, int width, int height, int tile_w, int n_tiles, int ch_base, int n_slices,
     const float *__restrict__ v_render_colors, const int32_t *__restrict__ offsets, int n_isects,
@@ -283,7 +303,6 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
     uint32_t *__restrict__ row_key, int32_t *__restrict__ row_idx)
 {
     constexpr int NBR = 4, CW = 128, C4 = 32;
-    constexpr float WSCALE = 4096.0f;
     __shared__ __attribute__((aligned(16))) float stage[4][32][CW];
     __shared__ __attribute__((aligned(4))) uint8_t pos[2][CMAX][4];
     __shared__ int cand[2][4];
@@ -332,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
             mx[j] = fmaxf(mx[j], __shfl_xor(mx[j], 32));  // the column's other 32 pixels live in the other half-wave
             // largest magnitude -> [2^14, 2^15); an all-zero (or non-finite) column keeps scale 1
             const float cs = (mx[j] > 0.f && mx[j] < 3.0e38f) ? ldexpf(1.0f, 14 - ilogbf(mx[j])) : 1.0f;
-            inv[j] = 1.0f / (cs * WSCALE);
+            inv[j] = 1.0f / cs;
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 float col[8];
@@ -378,6 +397,16 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            // power-of-two scale of this lane's slot row: its largest weight (weights are >= 0) -> [2^14, 2^15); exponent
+            // arithmetic on the bits.  A row of zeros (pad slot, rows past the run: never stored) keeps scale 1.
+            float wmx = 0.f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) wmx = fmaxf(wmx, A[i]);
+            wmx = fmaxf(wmx, __shfl_xor(wmx, 32));
+            const int ebits = (int)((__float_as_uint(wmx) >> 23) & 0xffu);
+            const bool sane = ebits >= 15 && ebits <= 200;  // alpha*T lies in (4e-7, 1]; anything else (0, garbage past the block): 1
+            const float rs = sane ? __uint_as_float((unsigned)(268 - ebits) << 23) : 1.0f;       // 2^(14 - exponent)
+            const unsigned rinv = sane ? ((unsigned)(ebits - 14) << 23) : 0x3f800000u;           // its inverse, as bits
             f32x16 acc[NBR];
 #pragma unroll
             for (int j = 0; j < NBR; ++j)
@@ -388,14 +417,17 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
                 float a8[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) a8[i] = A[8 * s4 + i];
-                f16x8 ah, al;
-                split8(a8, WSCALE, ah, al);
+                f16x8 a0, a1, a2;
+                split8x3(a8, rs, a0, a1, a2);
 #pragma unroll
-                for (int j = 0; j < NBR; ++j) {
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bh[s4][j], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, Bl[s4][j], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, Bh[s4][j], acc[j], 0, 0, 0);
+                for (int j = 0; j < NBR; ++j) {  // smallest terms first
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, Bh[s4][j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, Bl[s4][j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, Bh[s4][j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, Bl[s4][j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, Bh[s4][j], acc[j], 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);  // one K-step's terms at a time (hoisted together they spill)
             }
             __builtin_amdgcn_sched_barrier(0);
             if (mine && ch0 == 0) {
@@ -411,10 +443,15 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int slot = (r & 3) + 8 * (r >> 2) + 4 * k;
+                // accumulator row r of this lane = slot (r & 3) + 8 (r >> 2) + 4 k: that row's inverse scale sits in lane `slot`
+                const int s0 = (r & 3) + 8 * (r >> 2);
+                const unsigned i0 = __builtin_amdgcn_readlane(rinv, s0), i1 = __builtin_amdgcn_readlane(rinv, s0 + 4);
+                const float ri = __uint_as_float(k ? i1 : i0);
+                const int slot = s0 + 4 * k;
                 if (slot < run)
                     *reinterpret_cast<float4 *>(&stage[wave][slot][NBR * p]) =
-                        make_float4(acc[0][r] * inv[0], acc[1][r] * inv[1], acc[2][r] * inv[2], acc[3][r] * inv[3]);
+                        make_float4(acc[0][r] * (inv[0] * ri), acc[1][r] * (inv[1] * ri), acc[2][r] * (inv[2] * ri),
+                                    acc[3][r] * (inv[3] * ri));
             }
         }
         __syncthreads();
@@ -713,8 +750,8 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
             const int ce = ch_begin + ch_count;
             if (ce - c >= 128) {
                 const int nsl = (ce - c) / 128;
-                if (stage_flags & 32) GAGS_ROWS_LAUNCH(raster_bwd_rows_f16, c, nsl);  // opt-in: 16-bit matrix cores (GAGS_BWD_F16SPLIT)
-                else GAGS_ROWS_LAUNCH(raster_bwd_rows<4>, c, nsl);
+                if (stage_flags & 32) GAGS_ROWS_LAUNCH(raster_bwd_rows<4>, c, nsl);  // GAGS_BWD_F32MFMA: the fp32 matrix instructions
+                else GAGS_ROWS_LAUNCH(raster_bwd_rows_f16, c, nsl);  // default: 16-bit matrix cores, fp32-equivalent split operands
                 c += 128 * nsl;
             }
             if (ce - c >= 64) {

@@ -65,12 +65,12 @@ CASES = [
     ("C3 geometry D=256", C3 + (256,), {}),
     ("C5 4M/1080p/D=512 fp32 table", C5 + (512,), {}),
     ("C5 4M/1080p/D=512 fp16 table", C5 + (512,), dict(half=True)),
-    ("C5 4M/1080p/D=512 fp16 table, 16-bit matrix cores fwd+bwd (opt-in)", C5 + (512,), dict(half=True, flags=128 | 64)),
-    ("C3 1.5M/1080p/D=512 fp16 table, 16-bit matrix cores fwd+bwd (opt-in)", C3 + (512,), dict(half=True, flags=128 | 64)),
-    ("C3 1.5M/1080p/D=512 fp32 table, 16-bit matrix cores bwd (opt-in)", C3 + (512,), dict(flags=64)),
+    ("C5 4M/1080p/D=512 fp16 table, 16-bit matrix cores forward too (opt-in)", C5 + (512,), dict(half=True, flags=128)),
+    ("C3 1.5M/1080p/D=512 fp16 table, 16-bit matrix cores forward too (opt-in)", C3 + (512,), dict(half=True, flags=128)),
+    ("C3 1.5M/1080p/D=512 fp32 table, backward on the fp32 matrix instructions (GAGS_BWD_F32MFMA)", C3 + (512,), dict(flags=64)),
     ("C5 4M/1080p/D=513 (512+1) fp32", C5 + (513,), dict(steps=4)),
     ("C5 4M/1080p/D=513 (512+1) fp16 table -- BASELINE.json configs[4] as stated", C5 + (513,), dict(half=True, steps=4)),
-    ("C5 4M/1080p/D=513 (512+1) fp16 table, 16-bit matrix cores fwd+bwd (opt-in)", C5 + (513,), dict(half=True, flags=128 | 64, steps=4)),
+    ("C5 4M/1080p/D=513 (512+1) fp16 table, 16-bit matrix cores forward too (opt-in)", C5 + (513,), dict(half=True, flags=128, steps=4)),
     ("C3 1.5M/1080p/D=512, ALL gradients (features + means, quats, scales, opacities)", C3 + (512,), dict(full_grad=True)),
     ("C3 ALL gradients, VALU + atomics backward (what round 1 ran)", C3 + (512,), dict(full_grad=True, flags=4, steps=3)),
     ("C2 500k/1280x720/D=128, ALL gradients", (500_000, 1280, 720, 128), dict(full_grad=True)),
