@@ -281,17 +281,22 @@ __device__ __forceinline__ void split8(const float (&x)[8], float scale, f16x8 &
     }
 }
 
+// pairs through v_cvt_pk_f16_f32 (round to nearest even, new on gfx950): one conversion instruction per two values and term
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2v_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split8x3(const float (&x)[8], float scale, f16x8 &t0, f16x8 &t1, f16x8 &t2)
 {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float v = x[i] * scale;
-        const _Float16 h = (_Float16)v;
-        const float r = v - (float)h;
-        const _Float16 m = (_Float16)r;
-        t0[i] = h;
-        t1[i] = m;
-        t2[i] = (_Float16)(r - (float)m);
+    for (int i = 0; i < 8; i += 2) {
+        const f32x2v_t v = {x[i] * scale, x[i + 1] * scale};
+        const f16x2_t h = __builtin_convertvector(v, f16x2_t);
+        const f32x2v_t r = v - __builtin_convertvector(h, f32x2v_t);
+        const f16x2_t m = __builtin_convertvector(r, f16x2_t);
+        const f32x2v_t q = r - __builtin_convertvector(m, f32x2v_t);
+        const f16x2_t l = __builtin_convertvector(q, f16x2_t);
+        t0[i] = h[0]; t0[i + 1] = h[1];
+        t1[i] = m[0]; t1[i + 1] = m[1];
+        t2[i] = l[0]; t2[i + 1] = l[1];
     }
 }
 

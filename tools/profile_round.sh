@@ -19,9 +19,11 @@ cp "$O/pmc/traffic.json" "$O/${TAG}_c3_pmc_traffic.json" 2>/dev/null
 cd "$R"
 timeout 900 python bench.py --steps 20 --warmup 3 > "$O/${TAG}_c3_bench.json" 2> "$O/bench.err"
 timeout 300 python tools/chunk_stats.py C3 > "$O/${TAG}_c3_chunk_stats.txt" 2>&1
-timeout 300 python tools/decoder_bench.py > "$O/${TAG}_d16_iteration.json" 2>/dev/null
+timeout 300 python tools/slot_support.py C3 > "$O/${TAG}_c3_slot_support.txt" 2>&1
+timeout 300 python tools/decoder_bench.py > "$O/${TAG}_d16_iteration_exact.json" 2>/dev/null
+timeout 300 python tools/decoder_bench.py --bf16 > "$O/${TAG}_d16_iteration.json" 2>/dev/null
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$O/d16stats" -o d16 --output-format csv -- \
-    python "$R/tools/decoder_bench.py" > /dev/null 2>&1 )
+    python "$R/tools/decoder_bench.py" --bf16 > /dev/null 2>&1 )
 S=$(find "$O/d16stats" -name '*kernel_stats.csv' | head -1)
 [ -n "$S" ] && python "$R/tools/trim_stats.py" "$S" "$O/${TAG}_d16_iteration_kernel_stats.csv" 40
 timeout 300 python tools/gemm_bench.py > "$O/${TAG}_decoder_gemm.json" 2>/dev/null

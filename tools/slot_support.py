@@ -54,3 +54,39 @@ print("4x4 quadrants touched: " + "  ".join("%d: %.3f" % (i, (k == i).float().me
 rows = torch.stack([nz[:, hh::2][:, (p >> 3) == rr].any(1) for hh in range(2) for rr in range(4)], 1)
 print("pixel rows touched (of 8): mean %.2f" % rows.sum(1).float().mean().item())
 # MFMA K-steps needed if a 32-slot tile could skip K-steps that are zero for ALL its slots (depth order kept)
+# ---- "the backward may reorder slots inside a run: measure what grouping by 8x4-half occupancy saves
+# when single-half groups issue 16 K-steps instead of 32, at zero extra slots".  A run = 32 consecutive slots of a block
+# (the rows kernel's chunks end earlier on average -- 26 of 32 -- so this is the optimistic fill).  Unit of cost: one
+# K-step of a 32-row MFMA tile (v_mfma_f32_32x32x2_f32: two pixels x 32 slot rows), per 32 channels.
+blk_id = torch.repeat_interleave(torch.arange(base.numel(), device=dev), cnt)
+first = torch.cumsum(cnt, 0) - cnt
+j = torch.arange(W.shape[0], device=dev) - torch.repeat_interleave(first, cnt)
+run = blk_id * 4096 + j // 32
+_, inv_run = torch.unique(run, return_inverse=True)
+n_runs = int(inv_run.max().item()) + 1
+cls_up, cls_lo, cls_both = (up & ~lo), (lo & ~up), (up & lo)
+cnt_run = torch.bincount(inv_run, minlength=n_runs).float()
+n_up = torch.bincount(inv_run, weights=cls_up.float(), minlength=n_runs)
+n_lo = torch.bincount(inv_run, weights=cls_lo.float(), minlength=n_runs)
+n_bo = torch.bincount(inv_run, weights=cls_both.float(), minlength=n_runs)
+base_cost = 32.0 * n_runs                                   # today: every run is one 32-row tile over all 64 pixels
+# (A) M = 32 tiles, a run split by class into up to three 32-row tiles (16 / 16 / 32 K-steps), or left alone
+split_cost = 16.0 * (n_up > 0) + 16.0 * (n_lo > 0) + 32.0 * (n_bo > 0)
+costA = torch.minimum(split_cost, torch.full_like(split_cost, 32.0)).sum().item()
+# (B) M = 16 tiles (v_mfma_f32_16x16x4_f32, same flops per cycle): half a 32-row tile per 16 rows; single-half tiles
+#     cost half of that again; leftovers of the two single-half classes may share one full-K tile
+ceil16 = lambda t: torch.ceil(t / 16.0)
+costB_plain = (16.0 * ceil16(cnt_run)).sum().item()
+t_bo, t_up, t_lo = ceil16(n_bo), ceil16(n_up), ceil16(n_lo)
+costB = (16.0 * t_bo + 8.0 * t_up + 8.0 * t_lo).sum().item()
+# ... and with the remainders of all three classes packed into full-K tiles when that is cheaper
+rem = (n_bo % 16) + (n_up % 16) + (n_lo % 16)
+full = torch.floor(n_bo / 16) * 16.0 + torch.floor(n_up / 16) * 8.0 + torch.floor(n_lo / 16) * 8.0
+costB_pack = torch.minimum(16.0 * t_bo + 8.0 * t_up + 8.0 * t_lo, full + 16.0 * ceil16(rem)).sum().item()
+print("runs of <= 32 slots: %d, mean length %.1f; classes per run: upper-only %.2f lower-only %.2f both %.2f" % (
+    n_runs, cnt_run.mean().item(), n_up.mean().item(), n_lo.mean().item(), n_bo.mean().item()))
+print("issued K-steps relative to today's kernel (1.000 = one 32-row x 64-pixel tile per run):")
+print("  (A) 32-row tiles, runs split by half occupancy where that is cheaper : %.3f" % (costA / base_cost))
+print("  (B) 16-row tiles (16x16x4), no grouping                              : %.3f" % (costB_plain / base_cost))
+print("  (B) 16-row tiles, grouped by half occupancy (single-half: 16 K-steps)  : %.3f" % (costB / base_cost))
+print("  (B) ... remainders of the three classes packed into full-K tiles      : %.3f" % (costB_pack / base_cost))
