@@ -204,6 +204,16 @@ def _chain_backward_exact(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, n
     return gx, grads
 
 
+FUSED = True  # bf16 mode: CNN_decoder's forward (and input-gradient) chain as one kernel each; False: layer by layer
+
+
+def _fusable(wb, c_in):
+    """The reference's CNN_decoder shape: 9 layers, 256 hidden, c_in <= 32, an output width that is a multiple of 256."""
+    shapes = [tuple(w.shape) for w, _ in wb]
+    return (len(wb) == 9 and c_in <= 32 and shapes[0] == (256, 32) and all(sh == (256, 256) for sh in shapes[1:8])
+            and shapes[8][1] == 256 and shapes[8][0] % 256 == 0)
+
+
 def _chain_forward(x, kind, params):
     """The GEMM chain of a decoder up to its fp32 logits.  Returns (logits [P, ld], activations, packed weights, h, w,
     c_in)."""
@@ -212,8 +222,20 @@ def _chain_forward(x, kind, params):
     xp, h, w = _pixel_major(x)
     p = h * w
     a0 = torch.empty(p, wb[0][0].shape[1], dtype=torch.bfloat16, device=x.device)
-    check(_lib.load().gags_decoder_pack_input(p, xp.shape[1], a0.shape[1], ptr(xp), ptr(a0), _st()), "gags_decoder_pack_input")
+    fused = kind == "decoder" and FUSED and _fusable(wb, xp.shape[1])
+    if not fused:  # (the fused kernel converts its input tile itself and keeps it as a0)
+        check(_lib.load().gags_decoder_pack_input(p, xp.shape[1], a0.shape[1], ptr(xp), ptr(a0), _st()), "gags_decoder_pack_input")
     acts = [a0]
+    if fused:
+        # the nine layers in one kernel, activations resident in LDS (csrc/decoder_fused.hip): bit-identical to the chain below
+        dev = x.device
+        acts = [a0] + [torch.empty(p, 256, dtype=torch.bfloat16, device=dev) for _ in range(8)]
+        logits = torch.empty(p, wb[8][0].shape[0], device=dev)
+        arr = ctypes.c_void_p * 9
+        check(_lib.load().gags_decoder_fwd_fused(p, xp.shape[1], logits.shape[1], ptr(xp), arr(*[w.data_ptr() for w, _ in wb]),
+                                                 arr(*[b.data_ptr() for _, b in wb]), arr(*[t.data_ptr() for t in acts]),
+                                                 ptr(logits), _st()), "gags_decoder_fwd_fused")
+        return logits, acts, wb, h, w, xp.shape[1]
     if kind == "decoder":
         x1 = _layer(p, *wb[0], a0)
         t1 = _layer(p, *wb[1], x1)

@@ -117,6 +117,15 @@ int gags_decoder_unpack_grad(int64_t n_pix, int c, int ld, const void *x_bf16, f
  * rasterizer's output, and nothing is transposed on the way in or out. */
 int gags_decoder_head(int64_t n_pix, int c, int ld, int mode, const float *x, float *out, int layout, void *stream);
 
+/* CNN_decoder's whole forward chain (models/networks.py:172-190: nine 1x1 convolutions, x3 = conv(x1 + x2),
+ * x5 = conv(x3 + x4)) in ONE kernel, bf16 mode: 64-pixel tiles, activations resident in LDS, weights streamed from L2.
+ * x [n_pix, c_in] fp32 (c_in <= 32); w_bf16[9]: the padded bf16 matrices gags_decoder_layer takes ([256, 32], 7 x [256,
+ * 256], [n_last, 256]); bias[9] fp32; acts_bf16[9] (or NULL, or NULL entries): a0 [n_pix, 32] and the eight hidden
+ * activations [n_pix, 256] kept for the backward; logits [n_pix, n_last] fp32, n_last % 256 == 0.  Bit-identical to the
+ * same chain run through gags_decoder_layer. */
+int gags_decoder_fwd_fused(int64_t n_pix, int c_in, int n_last, const float *x, const void *const *w_bf16,
+                           const float *const *bias, void *const *acts_bf16, float *logits, void *stream);
+
 /* ---- N1 at the reference's precision (models/networks.py:109-248 are fp32 Conv2d stacks) ------------------------- */
 
 /* The same layer as gags_decoder_layer with fp32 tensors and fp32-equivalent arithmetic: every operand enters the 16-bit

@@ -407,3 +407,39 @@ def test_exact_head_backward_against_float64(c, ldx, layout, mode):
     ref = torch.nn.functional.normalize(xr, dim=1) if mode == 0 else torch.softmax(xr, dim=1)
     (ref * G.t().double()).sum().backward()
     assert ((dz.double() - xr.grad).norm() / xr.grad.norm()).item() <= 2e-6
+
+
+def test_fused_decoder_kernels_are_bit_identical_to_the_layer_by_layer_chain():
+    """bf16 mode: CNN_decoder's forward as ONE kernel (activations resident in LDS, csrc/decoder_fused.hip) and its input-
+    gradient chain as one kernel against the same chain run layer by layer through gags_decoder_layer: the arithmetic is
+    the same (bf16 operands, fp32 accumulation in ascending k, one rounding per activation), so every output, every kept
+    activation and every gradient must be IDENTICAL; ragged pixel count (not a multiple of the 64-pixel tile)."""
+    from gags_amd import decoders as D
+    from make_golden_next import decoder_weights
+    wd, _ = decoder_weights(0)
+    dec = _load(D.CNN_decoder(16, 512, "bf16"), wd)
+    g = torch.Generator(device="cuda").manual_seed(21)
+    H, W = 67, 93
+    x = torch.randn(H, W, 16, device="cuda", generator=g).permute(2, 0, 1)
+    G = torch.randn(512, H, W, device="cuda", generator=g)
+    res = []
+    for fused in (True, False):
+        D.FUSED = fused
+        try:
+            xi = x.clone().requires_grad_(True)
+            dec.zero_grad(set_to_none=True)
+            params = [t for m in dec.convs() for t in (m.weight, m.bias)]
+            logits, acts, wb, h, w, c_in = D._chain_forward(xi.detach(), "decoder", params)
+            y = dec(xi)
+            (y * G).sum().backward()
+            res.append((logits.clone(), [a.clone() for a in acts], y.detach().clone(), xi.grad.clone(),
+                        [c.weight.grad.clone() for c in dec.convs()], [c.bias.grad.clone() for c in dec.convs()]))
+        finally:
+            D.FUSED = True
+    a, b = res
+    assert torch.equal(a[0], b[0]), "logits"
+    for i, (u, v) in enumerate(zip(a[1], b[1])):
+        assert torch.equal(u, v), f"activation {i}"
+    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    for u, v in zip(a[4] + a[5], b[4] + b[5]):
+        assert torch.equal(u, v)
