@@ -32,7 +32,7 @@ __device__ __forceinline__ float fhi(unsigned u) { return __uint_as_float(u & 0x
 constexpr int FT = 64;        // pixels per tile
 constexpr int FH = 256;       // hidden width
 constexpr int FLD = FH + 8;   // LDS row pitch in bf16 (528 B: 16-byte aligned rows, consecutive rows 4 banks apart)
-constexpr int FPD = 4;        // weight fragments are requested this many K-steps ahead
+constexpr int FPD = 8;        // weight fragments are requested this many K-steps ahead
 
 typedef unsigned short (*Tile)[FLD];
 
@@ -198,26 +198,219 @@ __global__ __launch_bounds__(256, 2) void decoder_fwd_fused_kernel(FwdArgs a)
     epilogue_hidden(acc, a.b[7], n_base, bufB, lane);
     __syncthreads();
     store_tile(a.act[8], p0, a.P, bufB, tid);
-    // L8: t7 (B) -> fp32 logits [P, n_last], 256 channels per pass, straight from the accumulators (32 contiguous bytes per
-    // pixel and store instruction; the four instructions of a channel block complete its 128-byte line)
+    // L8: t7 (B) -> fp32 logits [P, n_last], 256 channels per pass.  Stored straight from the accumulators every
+    // instruction would scatter 32-byte pieces 4 n_last bytes apart and HBM sees partial lines (csrc/decoder.hip measured
+    // 2.4 x the bytes for that pattern); instead the two halves of a pass go through bufA (free by now: 64 pixels x 128
+    // fp32 channels) and leave as whole 512-byte rows, 16 bytes per lane.
+    float (*patch)[FLD / 2] = reinterpret_cast<float (*)[FLD / 2]>(&bufA[0][0]);  // [64][132] floats, same 528-byte pitch
     const int p = lane & 31, h = lane >> 5;
     for (int nb = 0; nb < a.n_last; nb += FH) {
         layer_mma(acc, a.W[8] + (size_t)nb * FH, FH, n_base, 16, bufB, lane, true);
+        for (int half = 0; half < 2; ++half) {
+            if ((wave >> 1) == half) {  // waves 2 half, 2 half + 1 hold channels 128 half .. + 127 of the pass
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = nb + n_base + 32 * i + 8 * g + 4 * h;
-                const float4 b = *reinterpret_cast<const float4 *>(a.b[8] + n);
+                    for (int g = 0; g < 4; ++g) {
+                        const int nl = (n_base & 127) + 32 * i + 8 * g + 4 * h;
+                        const float4 b = *reinterpret_cast<const float4 *>(a.b[8] + nb + 128 * half + nl);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int64_t pg = p0 + 32 * j + p;
-                    if (pg < a.P)
-                        *reinterpret_cast<float4 *>(a.logits + (size_t)pg * a.n_last + n) =
-                            make_float4(acc[i][j][4 * g] + b.x, acc[i][j][4 * g + 1] + b.y, acc[i][j][4 * g + 2] + b.z,
-                                        acc[i][j][4 * g + 3] + b.w);
-                }
+                        for (int j = 0; j < 2; ++j)
+                            *reinterpret_cast<float4 *>(&patch[32 * j + p][nl]) =
+                                make_float4(acc[i][j][4 * g] + b.x, acc[i][j][4 * g + 1] + b.y, acc[i][j][4 * g + 2] + b.z,
+                                            acc[i][j][4 * g + 3] + b.w);
+                    }
             }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int id = tid + 256 * q, row = id >> 5, c = (id & 31) * 4;
+                if (p0 + row < a.P)
+                    *reinterpret_cast<float4 *>(a.logits + (size_t)(p0 + row) * a.n_last + nb + 128 * half + c) =
+                        *reinterpret_cast<const float4 *>(&patch[row][c]);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---- backward: the nine input-gradient GEMMs of CNN_decoder in one kernel --------------------------------------------
+//   dz7 = (W8^T dz8) * [t7 > 0]      dz6 = (W7^T dz7) * [t6 > 0]      g36 = W6^T dz6,  dz5 = g36 * [x4 > 0]
+//   dz4 = (W5^T dz5) * [t4 > 0]      dz3 = (W4^T dz4 + g36) * [x3 > 0]   g13 = W3^T dz3,  dz2 = g13 * [x2 > 0]
+//   dz1 = (W2^T dz2) * [t1 > 0]      dz0 = (W1^T dz1 + g13) * [x1 > 0]   d x = W0^T dz0
+// Per 64-pixel tile: dz of the layer above in one LDS buffer, the ReLU-mask activations of the layer below fetched into the
+// other one (requested before the K loop, written after it), the result written over the mask in place.  Every dz leaves
+// once (the weight gradients contract them over the pixels afterwards); the two skip gradients take a round trip through
+// a bf16 scratch tensor (same lanes write and read them: L2).  Arithmetic and roundings as gags_decoder_layer with
+// mask_src / residual / y_premask: bit-identical to the layer-by-layer backward.
+struct BwdArgs {
+    const unsigned short *dz8;    // [P, n_last] bf16
+    const unsigned short *Wt[9];  // W_i^T, bf16: [32, 256], 7 x [256, 256], [256, n_last]
+    const unsigned short *act[9]; // a0 (unused), x1, t1, x2, x3, t4, x4, t6, t7 [P, 256]
+    unsigned short *dz[8];        // dz0 .. dz7 [P, 256] out
+    unsigned short *g36, *g13;    // scratch [P, 256]
+    float *gin;                   // [P, c_in] fp32 out, or null
+    int64_t P;
+    int c_in, n_last;
+};
+
+__device__ __forceinline__ void fetch_tile(uint4 (&r)[8], const unsigned short *__restrict__ src, int ld, int col0, int64_t p0,
+                                           int64_t P, int tid)
+{
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int id = tid + 256 * q, row = id >> 5, c = (id & 31) * 8;
+        const int64_t pg = min(p0 + row, P - 1);  // clamped: unconditional loads; rows past the image are never stored
+        r[q] = *reinterpret_cast<const uint4 *>(src + (size_t)pg * ld + col0 + c);
+    }
+}
+__device__ __forceinline__ void commit_tile(Tile dst, const uint4 (&r)[8], int tid)
+{
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int id = tid + 256 * q, row = id >> 5, c = (id & 31) * 8;
+        *reinterpret_cast<uint4 *>(&dst[row][c]) = r[q];
+    }
+}
+
+// out[p][n] = bf16(acc (+ res[p][n])) * [mask[p][n] > 0];  pre[p][n] = the value before the mask (optional).
+// `out` may be the mask buffer itself (each element is read, then written, by the same lane).
+__device__ __forceinline__ void epilogue_dgrad(const f32x16 (&acc)[2][2], int n_base, Tile mask, Tile res, Tile out, Tile pre, int lane)
+{
+    const int p = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = n_base + 32 * i + 8 * g + 4 * h;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float v0 = acc[i][j][4 * g], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
+                if (res) {
+                    const uint2 e = *reinterpret_cast<const uint2 *>(&res[32 * j + p][n]);
+                    v0 += flo(e.x); v1 += fhi(e.x); v2 += flo(e.y); v3 += fhi(e.y);
+                }
+                if (pre) *reinterpret_cast<uint2 *>(&pre[32 * j + p][n]) = make_uint2(fpack(v0, v1), fpack(v2, v3));
+                const uint2 m = *reinterpret_cast<const uint2 *>(&mask[32 * j + p][n]);
+                v0 = flo(m.x) > 0.f ? v0 : 0.f; v1 = fhi(m.x) > 0.f ? v1 : 0.f;
+                v2 = flo(m.y) > 0.f ? v2 : 0.f; v3 = fhi(m.y) > 0.f ? v3 : 0.f;
+                *reinterpret_cast<uint2 *>(&out[32 * j + p][n]) = make_uint2(fpack(v0, v1), fpack(v2, v3));
+            }
+        }
+}
+
+__global__ __launch_bounds__(256, 2) void decoder_bwd_fused_kernel(BwdArgs a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short bufA[FT][FLD];
+    __shared__ __attribute__((aligned(16))) unsigned short bufB[FT][FLD];
+    Tile X = bufA, Y = bufB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t p0 = (int64_t)blockIdx.x * FT;
+    const int n_base = 64 * wave;
+    f32x16 acc[2][2];
+    uint4 pm[8], pr[8];  // mask / residual tiles in flight
+
+    // L8: dz8 [64, n_last] through X in slabs of 256 columns -> dz7 (Y)
+    fetch_tile(pm, a.act[8], FH, 0, p0, a.P, tid);
+    for (int kb = 0; kb < a.n_last; kb += FH) {
+        fetch_tile(pr, a.dz8, a.n_last, kb, p0, a.P, tid);
+        if (kb) __syncthreads();  // the previous slab has been multiplied
+        commit_tile(X, pr, tid);
+        __syncthreads();
+        layer_mma(acc, a.Wt[8] + kb, a.n_last, n_base, 16, X, lane, kb == 0);
+    }
+    commit_tile(Y, pm, tid);
+    __syncthreads();
+    epilogue_dgrad(acc, n_base, Y, nullptr, Y, nullptr, lane);
+    __syncthreads();
+    store_tile(a.dz[7], p0, a.P, Y, tid);
+    // L7: dz7 (Y) -> dz6 (X)
+    fetch_tile(pm, a.act[7], FH, 0, p0, a.P, tid);
+    layer_mma(acc, a.Wt[7], FH, n_base, 16, Y, lane, true);
+    commit_tile(X, pm, tid);
+    __syncthreads();
+    epilogue_dgrad(acc, n_base, X, nullptr, X, nullptr, lane);
+    __syncthreads();
+    store_tile(a.dz[6], p0, a.P, X, tid);
+    // L6: dz6 (X) -> g36 (kept in X, and in scratch), dz5 = g36 * [x4 > 0] (Y)
+    fetch_tile(pm, a.act[6], FH, 0, p0, a.P, tid);
+    layer_mma(acc, a.Wt[6], FH, n_base, 16, X, lane, true);
+    commit_tile(Y, pm, tid);
+    __syncthreads();  // every wave is done reading dz6: X may take the pre-mask value
+    epilogue_dgrad(acc, n_base, Y, nullptr, Y, X, lane);
+    __syncthreads();
+    store_tile(a.g36, p0, a.P, X, tid);
+    store_tile(a.dz[5], p0, a.P, Y, tid);
+    // L5: dz5 (Y) -> dz4 (X)
+    fetch_tile(pm, a.act[5], FH, 0, p0, a.P, tid);
+    layer_mma(acc, a.Wt[5], FH, n_base, 16, Y, lane, true);
+    commit_tile(X, pm, tid);
+    __syncthreads();
+    epilogue_dgrad(acc, n_base, X, nullptr, X, nullptr, lane);
+    __syncthreads();
+    store_tile(a.dz[4], p0, a.P, X, tid);
+    // L4: dz4 (X) + g36 -> dz3 (Y)
+    fetch_tile(pm, a.act[4], FH, 0, p0, a.P, tid);
+    fetch_tile(pr, a.g36, FH, 0, p0, a.P, tid);
+    layer_mma(acc, a.Wt[4], FH, n_base, 16, X, lane, true);
+    commit_tile(Y, pm, tid);
+    __syncthreads();  // dz4 has been multiplied: X takes the skip gradient
+    commit_tile(X, pr, tid);
+    __syncthreads();
+    epilogue_dgrad(acc, n_base, Y, X, Y, nullptr, lane);
+    __syncthreads();
+    store_tile(a.dz[3], p0, a.P, Y, tid);
+    // L3: dz3 (Y) -> g13 (Y, scratch), dz2 = g13 * [x2 > 0] (X)
+    fetch_tile(pm, a.act[3], FH, 0, p0, a.P, tid);
+    layer_mma(acc, a.Wt[3], FH, n_base, 16, Y, lane, true);
+    commit_tile(X, pm, tid);
+    __syncthreads();
+    epilogue_dgrad(acc, n_base, X, nullptr, X, Y, lane);
+    __syncthreads();
+    store_tile(a.g13, p0, a.P, Y, tid);
+    store_tile(a.dz[2], p0, a.P, X, tid);
+    // L2: dz2 (X) -> dz1 (Y)
+    fetch_tile(pm, a.act[2], FH, 0, p0, a.P, tid);
+    layer_mma(acc, a.Wt[2], FH, n_base, 16, X, lane, true);
+    commit_tile(Y, pm, tid);
+    __syncthreads();
+    epilogue_dgrad(acc, n_base, Y, nullptr, Y, nullptr, lane);
+    __syncthreads();
+    store_tile(a.dz[1], p0, a.P, Y, tid);
+    // L1: dz1 (Y) + g13 -> dz0 (X)
+    fetch_tile(pm, a.act[1], FH, 0, p0, a.P, tid);
+    fetch_tile(pr, a.g13, FH, 0, p0, a.P, tid);
+    layer_mma(acc, a.Wt[1], FH, n_base, 16, Y, lane, true);
+    commit_tile(X, pm, tid);
+    __syncthreads();
+    commit_tile(Y, pr, tid);
+    __syncthreads();
+    epilogue_dgrad(acc, n_base, X, Y, X, nullptr, lane);
+    __syncthreads();
+    store_tile(a.dz[0], p0, a.P, X, tid);
+    // L0: d x[p][c] = sum_n dz0[p][n] W0[n][c]: 32 (padded) channels x 64 pixels = two accumulator tiles, waves 0 and 1;
+    // rounded to bf16 and widened, as the layer-by-layer path hands it over (gags_decoder_unpack_grad)
+    if (a.gin && wave < 2) {
+        f32x16 c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = 0.f;
+        const unsigned short *w0 = a.Wt[0] + (size_t)(lane & 31) * FH + 8 * (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const bf16x8 wf = *reinterpret_cast<const bf16x8 *>(w0 + 16 * ks);
+            const bf16x8 bf = *reinterpret_cast<const bf16x8 *>(&X[32 * wave + (lane & 31)][16 * ks + 8 * (lane >> 5)]);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, bf, c, 0, 0, 0);
+        }
+        const int64_t pg = p0 + 32 * wave + (lane & 31);
+        if (pg < a.P) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ch = 8 * g + 4 * (lane >> 5) + e;
+                    if (ch < a.c_in) a.gin[pg * a.c_in + ch] = flo(fpack(c[4 * g + e], 0.f));
+                }
+        }
     }
 }
 
@@ -239,6 +432,32 @@ extern "C" int gags_decoder_fwd_fused(int64_t n_pix, int c_in, int n_last, const
         a.act[i] = acts_bf16 ? (unsigned short *)acts_bf16[i] : nullptr;
     }
     hipLaunchKernelGGL(decoder_fwd_fused_kernel, dim3((unsigned)((n_pix + FT - 1) / FT)), dim3(256), 0, (hipStream_t)stream, a);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+extern "C" int gags_decoder_bwd_fused(int64_t n_pix, int c_in, int n_last, const void *dz_last_bf16, const void *const *wt_bf16,
+                                      const void *const *acts_bf16, void *const *dz_bf16, void *g36_bf16, void *g13_bf16,
+                                      float *gin, void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (n_pix < 0 || c_in <= 0 || c_in > 32 || n_last <= 0 || n_last % FH != 0 || !dz_last_bf16 || !wt_bf16 || !acts_bf16 || !dz_bf16 ||
+        !g36_bf16 || !g13_bf16)
+        return GAGS_EINVAL;
+    if (n_pix == 0) return GAGS_OK;
+    BwdArgs a;
+    a.dz8 = (const unsigned short *)dz_last_bf16; a.g36 = (unsigned short *)g36_bf16; a.g13 = (unsigned short *)g13_bf16;
+    a.gin = gin; a.P = n_pix; a.c_in = c_in; a.n_last = n_last;
+    for (int i = 0; i < 9; ++i) {
+        if (!wt_bf16[i] || (i > 0 && !acts_bf16[i])) return GAGS_EINVAL;
+        a.Wt[i] = (const unsigned short *)wt_bf16[i];
+        a.act[i] = (const unsigned short *)acts_bf16[i];
+    }
+    for (int i = 0; i < 8; ++i) {
+        if (!dz_bf16[i]) return GAGS_EINVAL;
+        a.dz[i] = (unsigned short *)dz_bf16[i];
+    }
+    hipLaunchKernelGGL(decoder_bwd_fused_kernel, dim3((unsigned)((n_pix + FT - 1) / FT)), dim3(256), 0, (hipStream_t)stream, a);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }
