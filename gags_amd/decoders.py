@@ -166,25 +166,6 @@ def _chain_backward_exact(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, n
         return _xlayer(p, wt[i], None, dz_i, relu=False, mask_src=mask_src, residual=residual, premask=premask)
 
     gin = None
-    if kind == "decoder" and FUSED and _fusable(wb, c_in) and dz.shape[1] == wb[8][0].shape[0]:
-        # the nine input-gradient GEMMs in one kernel (csrc/decoder_fused.hip), then the weight gradients
-        a0, x1, t1, x2, x3, t4, x4, t6, t7 = acts
-        dev = dz.device
-        dzs = [torch.empty(p, 256, dtype=torch.bfloat16, device=dev) for _ in range(8)]
-        g36, g13 = (torch.empty(p, 256, dtype=torch.bfloat16, device=dev) for _ in range(2))
-        gx = torch.empty(h, w, c_in, device=dev) if need_x else None
-        arr = ctypes.c_void_p * 9
-        arr8 = ctypes.c_void_p * 8
-        check(_lib.load().gags_decoder_bwd_fused(p, c_in, dz.shape[1], ptr(dz), arr(*[t.data_ptr() for t in wt]),
-                                                 arr(*[t.data_ptr() for t in acts]), arr8(*[t.data_ptr() for t in dzs]),
-                                                 ptr(g36), ptr(g13), ptr(gx), _st()), "gags_decoder_bwd_fused")
-        wg(8, dz, t7); wg(7, dzs[7], t6); wg(6, dzs[6], x3, x4); wg(5, dzs[5], t4); wg(4, dzs[4], x3)
-        wg(3, dzs[3], x1, x2); wg(2, dzs[2], t1); wg(1, dzs[1], x1); wg(0, dzs[0], a0)
-        grads = []
-        for pair, shp in zip(dws, shapes):
-            co, ci = shp[:2]
-            grads += [None, None] if pair is None else [pair[0][:co, :ci].reshape(shp).contiguous(), pair[1][:co].contiguous()]
-        return (None if gx is None else gx.permute(2, 0, 1)), grads
     if kind == "decoder":
         a0, x1, t1, x2, x3, t4, x4, t6, t7 = acts
         wg(8, dz, t7)
@@ -292,6 +273,25 @@ def _chain_backward(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, need_w=
     def dx(i, dz_i, mask_src=None, residual=None, premask=False):
         return _layer(p, wt[i], None, dz_i, relu=False, mask_src=mask_src, residual=residual, premask=premask)
 
+    if kind == "decoder" and FUSED and _fusable(wb, c_in) and dz.shape[1] == wb[8][0].shape[0]:
+        # the nine input-gradient GEMMs in one kernel (csrc/decoder_fused.hip), then the weight gradients
+        a0, x1, t1, x2, x3, t4, x4, t6, t7 = acts
+        dev = dz.device
+        dzs = [torch.empty(p, 256, dtype=torch.bfloat16, device=dev) for _ in range(8)]
+        g36, g13 = (torch.empty(p, 256, dtype=torch.bfloat16, device=dev) for _ in range(2))
+        gx = torch.empty(h, w, c_in, device=dev) if need_x else None
+        arr = ctypes.c_void_p * 9
+        arr8 = ctypes.c_void_p * 8
+        check(_lib.load().gags_decoder_bwd_fused(p, c_in, dz.shape[1], ptr(dz), arr(*[t.data_ptr() for t in wt]),
+                                                 arr(*[t.data_ptr() for t in acts]), arr8(*[t.data_ptr() for t in dzs]),
+                                                 ptr(g36), ptr(g13), ptr(gx), _st()), "gags_decoder_bwd_fused")
+        wg(8, dz, t7); wg(7, dzs[7], t6); wg(6, dzs[6], x3, x4); wg(5, dzs[5], t4); wg(4, dzs[4], x3)
+        wg(3, dzs[3], x1, x2); wg(2, dzs[2], t1); wg(1, dzs[1], x1); wg(0, dzs[0], a0)
+        grads = []
+        for pair, shp in zip(dws, shapes):
+            co, ci = shp[:2]
+            grads += [None, None] if pair is None else [pair[0][:co, :ci].reshape(shp).contiguous(), pair[1][:co].contiguous()]
+        return (None if gx is None else gx.permute(2, 0, 1)), grads
     if kind == "decoder":
         a0, x1, t1, x2, x3, t4, x4, t6, t7 = acts
         wg(8, dz, t7)
