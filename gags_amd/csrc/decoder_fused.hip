@@ -36,9 +36,14 @@ constexpr int FPD = 8;        // weight fragments are requested this many K-step
 
 typedef unsigned short (*Tile)[FLD];
 
-// acc[i][j] (i: 32 channels 64 w + 32 i.., j: 32 pixels 32 j..) = sum over K = 16 ksteps of W[n][k] in[p][k]
-__device__ __forceinline__ void layer_mma(f32x16 (&acc)[2][2], const unsigned short *__restrict__ W, int ldw, int n_base, int ksteps,
-                                          Tile in, int lane, bool zero)
+// Weights arrive in MFMA-FRAGMENT order (gags_amd/decoders.py: _frag_layout): Wf[n_tile][k_step][lane][8] with lane =
+// 32 kh + n and the eight values k = 16 k_step + 8 kh + 0..7 of row 32 n_tile + n -- the A operand of one MFMA is one
+// contiguous, fully coalesced kilobyte, and every weight byte travels from L2 exactly once per tile.  (Read from the
+// row-major matrix, a fragment is 32 row pieces of 32 bytes, one per 128-byte line: the eight waves of a CU keep 64 KB of
+// such lines in flight, the L1 thrashes, and every line is fetched four times -- measured 5.8 ms instead of 2.)
+// acc[i][j] (i: 32 channels of n-tile nt0 + i, j: 32 pixels 32 j..) = sum over k-steps ks0 .. ks0 + ksteps - 1 of W[n][k] in[p][k]
+__device__ __forceinline__ void layer_mma(f32x16 (&acc)[2][2], const unsigned short *__restrict__ Wf, int ksteps_total, int nt0, int ks0,
+                                          int ksteps, Tile in, int lane, bool zero)
 {
     if (zero) {
 #pragma unroll
@@ -48,14 +53,14 @@ __device__ __forceinline__ void layer_mma(f32x16 (&acc)[2][2], const unsigned sh
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     }
-    const unsigned short *w0 = W + (size_t)(n_base + (lane & 31)) * ldw + 8 * (lane >> 5);
-    const unsigned short *w1 = w0 + (size_t)32 * ldw;
+    const unsigned short *w0 = Wf + ((size_t)nt0 * ksteps_total + ks0) * 512 + lane * 8;
+    const unsigned short *w1 = w0 + (size_t)ksteps_total * 512;
     bf16x8 a0[FPD], a1[FPD];
 #pragma unroll
     for (int q = 0; q < FPD; ++q) {
         const int ks = min(q, ksteps - 1);
-        a0[q] = *reinterpret_cast<const bf16x8 *>(w0 + 16 * ks);
-        a1[q] = *reinterpret_cast<const bf16x8 *>(w1 + 16 * ks);
+        a0[q] = *reinterpret_cast<const bf16x8 *>(w0 + 512 * ks);
+        a1[q] = *reinterpret_cast<const bf16x8 *>(w1 + 512 * ks);
     }
     for (int k0 = 0; k0 < ksteps; k0 += FPD) {
 #pragma unroll
@@ -63,8 +68,8 @@ __device__ __forceinline__ void layer_mma(f32x16 (&acc)[2][2], const unsigned sh
             const int ks = k0 + q;
             const bf16x8 c0 = a0[q], c1 = a1[q];
             const int kn = min(ks + FPD, ksteps - 1);  // (past the end: a harmless re-read)
-            a0[q] = *reinterpret_cast<const bf16x8 *>(w0 + 16 * kn);
-            a1[q] = *reinterpret_cast<const bf16x8 *>(w1 + 16 * kn);
+            a0[q] = *reinterpret_cast<const bf16x8 *>(w0 + 512 * kn);
+            a1[q] = *reinterpret_cast<const bf16x8 *>(w1 + 512 * kn);
             if (ks < ksteps) {  // (uniform)
                 const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(&in[(lane & 31)][16 * ks + 8 * (lane >> 5)]);
                 const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(&in[32 + (lane & 31)][16 * ks + 8 * (lane >> 5)]);
@@ -125,7 +130,7 @@ __device__ __forceinline__ void add_tile(Tile dst, Tile add, int tid)
 
 struct FwdArgs {
     const float *x;              // [P, c_in] fp32 pixel-major (the rasterizer's own output), c_in <= 32
-    const unsigned short *W[9];  // bf16, K contiguous, padded: [256, 32], 7 x [256, 256], [n_last, 256]
+    const unsigned short *W[9];  // bf16 in MFMA-fragment order (see layer_mma) of the padded [256, 32], 7 x [256, 256], [n_last, 256]
     const float *b[9];
     unsigned short *act[9];      // a0 [P, 32], then x1, t1, x2, x3, t4, x4, t6, t7 [P, 256]: null = not kept (inference)
     float *logits;               // [P, n_last] fp32
@@ -153,17 +158,17 @@ __global__ __launch_bounds__(256, 2) void decoder_fwd_fused_kernel(FwdArgs a)
     }
     __syncthreads();
     // L0: a0 (B) -> x1 (A)
-    layer_mma(acc, a.W[0], 32, n_base, 2, bufB, lane, true);
+    layer_mma(acc, a.W[0], 2, 2 * wave, 0, 2, bufB, lane, true);
     epilogue_hidden(acc, a.b[0], n_base, bufA, lane);
     __syncthreads();
     store_tile(a.act[1], p0, a.P, bufA, tid);
     // L1: x1 (A) -> t1 (B)
-    layer_mma(acc, a.W[1], FH, n_base, 16, bufA, lane, true);
+    layer_mma(acc, a.W[1], 16, 2 * wave, 0, 16, bufA, lane, true);
     epilogue_hidden(acc, a.b[1], n_base, bufB, lane);
     __syncthreads();
     store_tile(a.act[2], p0, a.P, bufB, tid);
     // L2: t1 (B) -> x2, written over t1 once every wave is done reading it; then A = x1 + x2
-    layer_mma(acc, a.W[2], FH, n_base, 16, bufB, lane, true);
+    layer_mma(acc, a.W[2], 16, 2 * wave, 0, 16, bufB, lane, true);
     __syncthreads();
     epilogue_hidden(acc, a.b[2], n_base, bufB, lane);
     __syncthreads();
@@ -171,17 +176,17 @@ __global__ __launch_bounds__(256, 2) void decoder_fwd_fused_kernel(FwdArgs a)
     add_tile(bufA, bufB, tid);
     __syncthreads();
     // L3: x1 + x2 (A) -> x3 (B)
-    layer_mma(acc, a.W[3], FH, n_base, 16, bufA, lane, true);
+    layer_mma(acc, a.W[3], 16, 2 * wave, 0, 16, bufA, lane, true);
     epilogue_hidden(acc, a.b[3], n_base, bufB, lane);
     __syncthreads();
     store_tile(a.act[4], p0, a.P, bufB, tid);
     // L4: x3 (B) -> t4 (A)
-    layer_mma(acc, a.W[4], FH, n_base, 16, bufB, lane, true);
+    layer_mma(acc, a.W[4], 16, 2 * wave, 0, 16, bufB, lane, true);
     epilogue_hidden(acc, a.b[4], n_base, bufA, lane);
     __syncthreads();
     store_tile(a.act[5], p0, a.P, bufA, tid);
     // L5: t4 (A) -> x4 over t4; then B = x3 + x4
-    layer_mma(acc, a.W[5], FH, n_base, 16, bufA, lane, true);
+    layer_mma(acc, a.W[5], 16, 2 * wave, 0, 16, bufA, lane, true);
     __syncthreads();
     epilogue_hidden(acc, a.b[5], n_base, bufA, lane);
     __syncthreads();
@@ -189,12 +194,12 @@ __global__ __launch_bounds__(256, 2) void decoder_fwd_fused_kernel(FwdArgs a)
     add_tile(bufB, bufA, tid);
     __syncthreads();
     // L6: x3 + x4 (B) -> t6 (A)
-    layer_mma(acc, a.W[6], FH, n_base, 16, bufB, lane, true);
+    layer_mma(acc, a.W[6], 16, 2 * wave, 0, 16, bufB, lane, true);
     epilogue_hidden(acc, a.b[6], n_base, bufA, lane);
     __syncthreads();
     store_tile(a.act[7], p0, a.P, bufA, tid);
     // L7: t6 (A) -> t7 (B)
-    layer_mma(acc, a.W[7], FH, n_base, 16, bufA, lane, true);
+    layer_mma(acc, a.W[7], 16, 2 * wave, 0, 16, bufA, lane, true);
     epilogue_hidden(acc, a.b[7], n_base, bufB, lane);
     __syncthreads();
     store_tile(a.act[8], p0, a.P, bufB, tid);
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void decoder_fwd_fused_kernel(FwdArgs a)
     float (*patch)[FLD / 2] = reinterpret_cast<float (*)[FLD / 2]>(&bufA[0][0]);  // [64][132] floats, same 528-byte pitch
     const int p = lane & 31, h = lane >> 5;
     for (int nb = 0; nb < a.n_last; nb += FH) {
-        layer_mma(acc, a.W[8] + (size_t)nb * FH, FH, n_base, 16, bufB, lane, true);
+        layer_mma(acc, a.W[8], 16, nb / 32 + 2 * wave, 0, 16, bufB, lane, true);
         for (int half = 0; half < 2; ++half) {
             if ((wave >> 1) == half) {  // waves 2 half, 2 half + 1 hold channels 128 half .. + 127 of the pass
 #pragma unroll
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void decoder_fwd_fused_kernel(FwdArgs a)
 // mask_src / residual / y_premask: bit-identical to the layer-by-layer backward.
 struct BwdArgs {
     const unsigned short *dz8;    // [P, n_last] bf16
-    const unsigned short *Wt[9];  // W_i^T, bf16: [32, 256], 7 x [256, 256], [256, n_last]
+    const unsigned short *Wt[9];  // W_i^T, bf16 in MFMA-fragment order: [32, 256], 7 x [256, 256], [256, n_last]
     const unsigned short *act[9]; // a0 (unused), x1, t1, x2, x3, t4, x4, t6, t7 [P, 256]
     unsigned short *dz[8];        // dz0 .. dz7 [P, 256] out
     unsigned short *g36, *g13;    // scratch [P, 256]
@@ -317,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void decoder_bwd_fused_kernel(BwdArgs a)
         if (kb) __syncthreads();  // the previous slab has been multiplied
         commit_tile(X, pr, tid);
         __syncthreads();
-        layer_mma(acc, a.Wt[8] + kb, a.n_last, n_base, 16, X, lane, kb == 0);
+        layer_mma(acc, a.Wt[8], a.n_last / 16, 2 * wave, kb / 16, 16, X, lane, kb == 0);
     }
     commit_tile(Y, pm, tid);
     __syncthreads();
@@ -326,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void decoder_bwd_fused_kernel(BwdArgs a)
     store_tile(a.dz[7], p0, a.P, Y, tid);
     // L7: dz7 (Y) -> dz6 (X)
     fetch_tile(pm, a.act[7], FH, 0, p0, a.P, tid);
-    layer_mma(acc, a.Wt[7], FH, n_base, 16, Y, lane, true);
+    layer_mma(acc, a.Wt[7], 16, 2 * wave, 0, 16, Y, lane, true);
     commit_tile(X, pm, tid);
     __syncthreads();
     epilogue_dgrad(acc, n_base, X, nullptr, X, nullptr, lane);
@@ -334,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void decoder_bwd_fused_kernel(BwdArgs a)
     store_tile(a.dz[6], p0, a.P, X, tid);
     // L6: dz6 (X) -> g36 (kept in X, and in scratch), dz5 = g36 * [x4 > 0] (Y)
     fetch_tile(pm, a.act[6], FH, 0, p0, a.P, tid);
-    layer_mma(acc, a.Wt[6], FH, n_base, 16, X, lane, true);
+    layer_mma(acc, a.Wt[6], 16, 2 * wave, 0, 16, X, lane, true);
     commit_tile(Y, pm, tid);
     __syncthreads();  // every wave is done reading dz6: X may take the pre-mask value
     epilogue_dgrad(acc, n_base, Y, nullptr, Y, X, lane);
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void decoder_bwd_fused_kernel(BwdArgs a)
     store_tile(a.dz[5], p0, a.P, Y, tid);
     // L5: dz5 (Y) -> dz4 (X)
     fetch_tile(pm, a.act[5], FH, 0, p0, a.P, tid);
-    layer_mma(acc, a.Wt[5], FH, n_base, 16, Y, lane, true);
+    layer_mma(acc, a.Wt[5], 16, 2 * wave, 0, 16, Y, lane, true);
     commit_tile(X, pm, tid);
     __syncthreads();
     epilogue_dgrad(acc, n_base, X, nullptr, X, nullptr, lane);
@@ -352,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void decoder_bwd_fused_kernel(BwdArgs a)
     // L4: dz4 (X) + g36 -> dz3 (Y)
     fetch_tile(pm, a.act[4], FH, 0, p0, a.P, tid);
     fetch_tile(pr, a.g36, FH, 0, p0, a.P, tid);
-    layer_mma(acc, a.Wt[4], FH, n_base, 16, X, lane, true);
+    layer_mma(acc, a.Wt[4], 16, 2 * wave, 0, 16, X, lane, true);
     commit_tile(Y, pm, tid);
     __syncthreads();  // dz4 has been multiplied: X takes the skip gradient
     commit_tile(X, pr, tid);
@@ -362,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void decoder_bwd_fused_kernel(BwdArgs a)
     store_tile(a.dz[3], p0, a.P, Y, tid);
     // L3: dz3 (Y) -> g13 (Y, scratch), dz2 = g13 * [x2 > 0] (X)
     fetch_tile(pm, a.act[3], FH, 0, p0, a.P, tid);
-    layer_mma(acc, a.Wt[3], FH, n_base, 16, Y, lane, true);
+    layer_mma(acc, a.Wt[3], 16, 2 * wave, 0, 16, Y, lane, true);
     commit_tile(X, pm, tid);
     __syncthreads();
     epilogue_dgrad(acc, n_base, X, nullptr, X, Y, lane);
@@ -371,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void decoder_bwd_fused_kernel(BwdArgs a)
     store_tile(a.dz[2], p0, a.P, X, tid);
     // L2: dz2 (X) -> dz1 (Y)
     fetch_tile(pm, a.act[2], FH, 0, p0, a.P, tid);
-    layer_mma(acc, a.Wt[2], FH, n_base, 16, X, lane, true);
+    layer_mma(acc, a.Wt[2], 16, 2 * wave, 0, 16, X, lane, true);
     commit_tile(Y, pm, tid);
     __syncthreads();
     epilogue_dgrad(acc, n_base, Y, nullptr, Y, nullptr, lane);
@@ -380,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void decoder_bwd_fused_kernel(BwdArgs a)
     // L1: dz1 (Y) + g13 -> dz0 (X)
     fetch_tile(pm, a.act[1], FH, 0, p0, a.P, tid);
     fetch_tile(pr, a.g13, FH, 0, p0, a.P, tid);
-    layer_mma(acc, a.Wt[1], FH, n_base, 16, Y, lane, true);
+    layer_mma(acc, a.Wt[1], 16, 2 * wave, 0, 16, Y, lane, true);
     commit_tile(X, pm, tid);
     __syncthreads();
     commit_tile(Y, pr, tid);
@@ -394,10 +399,10 @@ __global__ __launch_bounds__(256, 2) void decoder_bwd_fused_kernel(BwdArgs a)
         f32x16 c;
 #pragma unroll
         for (int r = 0; r < 16; ++r) c[r] = 0.f;
-        const unsigned short *w0 = a.Wt[0] + (size_t)(lane & 31) * FH + 8 * (lane >> 5);
+        const unsigned short *w0 = a.Wt[0] + lane * 8;  // fragment order: [n_tile 0][k_step][lane][8]
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
-            const bf16x8 wf = *reinterpret_cast<const bf16x8 *>(w0 + 16 * ks);
+            const bf16x8 wf = *reinterpret_cast<const bf16x8 *>(w0 + 512 * ks);
             const bf16x8 bf = *reinterpret_cast<const bf16x8 *>(&X[32 * wave + (lane & 31)][16 * ks + 8 * (lane >> 5)]);
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, bf, c, 0, 0, 0);
         }

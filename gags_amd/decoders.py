@@ -207,6 +207,13 @@ def _chain_backward_exact(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, n
 FUSED = True  # bf16 mode: CNN_decoder's forward (and input-gradient) chain as one kernel each; False: layer by layer
 
 
+def _frag_layout(w):
+    """bf16 [N, K] (N % 32 == 0, K % 16 == 0) -> [N / 32, K / 16, 64, 8]: the A operand of one v_mfma_f32_32x32x16_bf16 (lane
+    32 kh + n holds k = 16 s + 8 kh .. + 7 of row 32 t + n) as one contiguous kilobyte (csrc/decoder_fused.hip: layer_mma)."""
+    n, k = w.shape
+    return w.view(n // 32, 32, k // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+
+
 def _fusable(wb, c_in):
     """The reference's CNN_decoder shape: 9 layers, 256 hidden, c_in <= 32, an output width that is a multiple of 256."""
     shapes = [tuple(w.shape) for w, _ in wb]
@@ -232,7 +239,8 @@ def _chain_forward(x, kind, params):
         acts = [a0] + [torch.empty(p, 256, dtype=torch.bfloat16, device=dev) for _ in range(8)]
         logits = torch.empty(p, wb[8][0].shape[0], device=dev)
         arr = ctypes.c_void_p * 9
-        check(_lib.load().gags_decoder_fwd_fused(p, xp.shape[1], logits.shape[1], ptr(xp), arr(*[w.data_ptr() for w, _ in wb]),
+        wf = [_frag_layout(wgt) for wgt, _ in wb]
+        check(_lib.load().gags_decoder_fwd_fused(p, xp.shape[1], logits.shape[1], ptr(xp), arr(*[t.data_ptr() for t in wf]),
                                                  arr(*[b.data_ptr() for _, b in wb]), arr(*[t.data_ptr() for t in acts]),
                                                  ptr(logits), _st()), "gags_decoder_fwd_fused")
         return logits, acts, wb, h, w, xp.shape[1]
@@ -282,7 +290,8 @@ def _chain_backward(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, need_w=
         gx = torch.empty(h, w, c_in, device=dev) if need_x else None
         arr = ctypes.c_void_p * 9
         arr8 = ctypes.c_void_p * 8
-        check(_lib.load().gags_decoder_bwd_fused(p, c_in, dz.shape[1], ptr(dz), arr(*[t.data_ptr() for t in wt]),
+        wtf = [_frag_layout(t) for t in wt]
+        check(_lib.load().gags_decoder_bwd_fused(p, c_in, dz.shape[1], ptr(dz), arr(*[t.data_ptr() for t in wtf]),
                                                  arr(*[t.data_ptr() for t in acts]), arr8(*[t.data_ptr() for t in dzs]),
                                                  ptr(g36), ptr(g13), ptr(gx), _st()), "gags_decoder_bwd_fused")
         wg(8, dz, t7); wg(7, dzs[7], t6); wg(6, dzs[6], x3, x4); wg(5, dzs[5], t4); wg(4, dzs[4], x3)

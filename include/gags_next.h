@@ -120,7 +120,7 @@ int gags_decoder_head(int64_t n_pix, int c, int ld, int mode, const float *x, fl
 /* CNN_decoder's whole forward chain (models/networks.py:172-190: nine 1x1 convolutions, x3 = conv(x1 + x2),
  * x5 = conv(x3 + x4)) in ONE kernel, bf16 mode: 64-pixel tiles, activations resident in LDS, weights streamed from L2.
  * x [n_pix, c_in] fp32 (c_in <= 32); w_bf16[9]: the padded bf16 matrices gags_decoder_layer takes ([256, 32], 7 x [256,
- * 256], [n_last, 256]); bias[9] fp32; acts_bf16[9] (or NULL, or NULL entries): a0 [n_pix, 32] and the eight hidden
+ * 256], [n_last, 256]) re-ordered into MFMA fragments: [N / 32][K / 16][lane = 32 kh + n][8 values k = 16 s + 8 kh ..]; bias[9] fp32; acts_bf16[9] (or NULL, or NULL entries): a0 [n_pix, 32] and the eight hidden
  * activations [n_pix, 256] kept for the backward; logits [n_pix, n_last] fp32, n_last % 256 == 0.  Bit-identical to the
  * same chain run through gags_decoder_layer. */
 int gags_decoder_fwd_fused(int64_t n_pix, int c_in, int n_last, const float *x, const void *const *w_bf16,
@@ -129,7 +129,7 @@ int gags_decoder_fwd_fused(int64_t n_pix, int c_in, int n_last, const float *x, 
 /* ... and the nine input-gradient GEMMs of its backward in one kernel: dz_last [n_pix, n_last] bf16 (from the head's
  * backward) -> dz_bf16[0..7] = the gradients at the outputs of layers 0..7 ([n_pix, 256] bf16 each, what the weight
  * gradients contract), gin [n_pix, c_in] fp32 (optional).  wt_bf16[9]: the TRANSPOSED padded matrices ([32, 256], 7 x
- * [256, 256], [256, n_last]); acts_bf16: what gags_decoder_fwd_fused kept; g36 / g13: bf16 scratch [n_pix, 256] for the two
+ * [256, 256], [256, n_last]) in the same fragment order; acts_bf16: what gags_decoder_fwd_fused kept; g36 / g13: bf16 scratch [n_pix, 256] for the two
  * skip gradients.  Bit-identical to the chain of gags_decoder_layer calls with mask_src / residual / y_premask. */
 int gags_decoder_bwd_fused(int64_t n_pix, int c_in, int n_last, const void *dz_last_bf16, const void *const *wt_bf16,
                            const void *const *acts_bf16, void *const *dz_bf16, void *g36_bf16, void *g13_bf16, float *gin,
