@@ -84,11 +84,14 @@ __device__ __forceinline__ void layer_mma(f32x16 (&acc)[2][2], const unsigned sh
 }
 
 // accumulator element (i, j, 4 g + e) of lane (p = lane & 31, h = lane >> 5): pixel 32 j + p, channel n_base + 32 i + 8 g + 4 h + e
-// hidden-layer epilogue: out[p][n] = bf16(relu(acc + bias[n]))
+// hidden-layer epilogue: out[p][n] = bf16(relu(acc + bias[n])); and, for the backward, the ReLU decisions as BITS:
+// mask[(p0 + pixel) * 8 + n / 32] bit n % 32 = [out > 0] -- 32 bytes per pixel and layer instead of the 512-byte activation row
+// the input-gradient chain would otherwise re-read just for its sign.
 __device__ __forceinline__ void epilogue_hidden(const f32x16 (&acc)[2][2], const float *__restrict__ bias, int n_base, Tile out,
-                                                int lane)
+                                                int lane, unsigned *__restrict__ mask, int64_t p0, int64_t P)
 {
     const int p = lane & 31, h = lane >> 5;
+    unsigned bits[2][2] = {{0u, 0u}, {0u, 0u}};
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -99,9 +102,25 @@ __device__ __forceinline__ void epilogue_hidden(const f32x16 (&acc)[2][2], const
             for (int j = 0; j < 2; ++j) {
                 const float v0 = fmaxf(acc[i][j][4 * g] + b.x, 0.f), v1 = fmaxf(acc[i][j][4 * g + 1] + b.y, 0.f);
                 const float v2 = fmaxf(acc[i][j][4 * g + 2] + b.z, 0.f), v3 = fmaxf(acc[i][j][4 * g + 3] + b.w, 0.f);
-                *reinterpret_cast<uint2 *>(&out[32 * j + p][n]) = make_uint2(fpack(v0, v1), fpack(v2, v3));
+                const unsigned u0 = fpack(v0, v1), u1 = fpack(v2, v3);
+                *reinterpret_cast<uint2 *>(&out[32 * j + p][n]) = make_uint2(u0, u1);
+                const unsigned nib = ((u0 & 0x7fffu) ? 1u : 0u) | ((u0 & 0x7fff0000u) ? 2u : 0u) | ((u1 & 0x7fffu) ? 4u : 0u) |
+                                     ((u1 & 0x7fff0000u) ? 8u : 0u);
+                bits[i][j] |= nib << (8 * g);
             }
         }
+    if (mask) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const unsigned mine = bits[i][j] << (4 * h);  // this half-wave's nibbles sit at bits 8 g + 4 h
+                const auto sw = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
+                const unsigned word = sw[0] | sw[1];
+                const int64_t pg = p0 + 32 * j + p;
+                if (h == 0 && pg < P) mask[pg * 8 + (n_base >> 5) + i] = word;
+            }
+    }
 }
 
 // the workgroup copies a [64][256] bf16 tile from LDS to its rows of a pixel-major tensor (16 bytes per lane, whole rows)
@@ -133,6 +152,7 @@ struct FwdArgs {
     const unsigned short *W[9];  // bf16 in MFMA-fragment order (see layer_mma) of the padded [256, 32], 7 x [256, 256], [n_last, 256]
     const float *b[9];
     unsigned short *act[9];      // a0 [P, 32], then x1, t1, x2, x3, t4, x4, t6, t7 [P, 256]: null = not kept (inference)
+    unsigned *mask[9];           // [1..8]: ReLU bit masks [P, 8] of the same activations (null = not kept)
     float *logits;               // [P, n_last] fp32
     int64_t P;
     int c_in, n_last;            // n_last % 256 == 0
@@ -159,48 +179,48 @@ __global__ __launch_bounds__(256, 2) void decoder_fwd_fused_kernel(FwdArgs a)
     __syncthreads();
     // L0: a0 (B) -> x1 (A)
     layer_mma(acc, a.W[0], 2, 2 * wave, 0, 2, bufB, lane, true);
-    epilogue_hidden(acc, a.b[0], n_base, bufA, lane);
+    epilogue_hidden(acc, a.b[0], n_base, bufA, lane, a.mask[1], p0, a.P);
     __syncthreads();
     store_tile(a.act[1], p0, a.P, bufA, tid);
     // L1: x1 (A) -> t1 (B)
     layer_mma(acc, a.W[1], 16, 2 * wave, 0, 16, bufA, lane, true);
-    epilogue_hidden(acc, a.b[1], n_base, bufB, lane);
+    epilogue_hidden(acc, a.b[1], n_base, bufB, lane, a.mask[2], p0, a.P);
     __syncthreads();
     store_tile(a.act[2], p0, a.P, bufB, tid);
     // L2: t1 (B) -> x2, written over t1 once every wave is done reading it; then A = x1 + x2
     layer_mma(acc, a.W[2], 16, 2 * wave, 0, 16, bufB, lane, true);
     __syncthreads();
-    epilogue_hidden(acc, a.b[2], n_base, bufB, lane);
+    epilogue_hidden(acc, a.b[2], n_base, bufB, lane, a.mask[3], p0, a.P);
     __syncthreads();
     store_tile(a.act[3], p0, a.P, bufB, tid);
     add_tile(bufA, bufB, tid);
     __syncthreads();
     // L3: x1 + x2 (A) -> x3 (B)
     layer_mma(acc, a.W[3], 16, 2 * wave, 0, 16, bufA, lane, true);
-    epilogue_hidden(acc, a.b[3], n_base, bufB, lane);
+    epilogue_hidden(acc, a.b[3], n_base, bufB, lane, a.mask[4], p0, a.P);
     __syncthreads();
     store_tile(a.act[4], p0, a.P, bufB, tid);
     // L4: x3 (B) -> t4 (A)
     layer_mma(acc, a.W[4], 16, 2 * wave, 0, 16, bufB, lane, true);
-    epilogue_hidden(acc, a.b[4], n_base, bufA, lane);
+    epilogue_hidden(acc, a.b[4], n_base, bufA, lane, a.mask[5], p0, a.P);
     __syncthreads();
     store_tile(a.act[5], p0, a.P, bufA, tid);
     // L5: t4 (A) -> x4 over t4; then B = x3 + x4
     layer_mma(acc, a.W[5], 16, 2 * wave, 0, 16, bufA, lane, true);
     __syncthreads();
-    epilogue_hidden(acc, a.b[5], n_base, bufA, lane);
+    epilogue_hidden(acc, a.b[5], n_base, bufA, lane, a.mask[6], p0, a.P);
     __syncthreads();
     store_tile(a.act[6], p0, a.P, bufA, tid);
     add_tile(bufB, bufA, tid);
     __syncthreads();
     // L6: x3 + x4 (B) -> t6 (A)
     layer_mma(acc, a.W[6], 16, 2 * wave, 0, 16, bufB, lane, true);
-    epilogue_hidden(acc, a.b[6], n_base, bufA, lane);
+    epilogue_hidden(acc, a.b[6], n_base, bufA, lane, a.mask[7], p0, a.P);
     __syncthreads();
     store_tile(a.act[7], p0, a.P, bufA, tid);
     // L7: t6 (A) -> t7 (B)
     layer_mma(acc, a.W[7], 16, 2 * wave, 0, 16, bufA, lane, true);
-    epilogue_hidden(acc, a.b[7], n_base, bufB, lane);
+    epilogue_hidden(acc, a.b[7], n_base, bufB, lane, a.mask[8], p0, a.P);
     __syncthreads();
     store_tile(a.act[8], p0, a.P, bufB, tid);
     // L8: t7 (B) -> fp32 logits [P, n_last], 256 channels per pass.  Stored straight from the accumulators every
@@ -243,17 +263,16 @@ __global__ __launch_bounds__(256, 2) void decoder_fwd_fused_kernel(FwdArgs a)
 //   dz7 = (W8^T dz8) * [t7 > 0]      dz6 = (W7^T dz7) * [t6 > 0]      g36 = W6^T dz6,  dz5 = g36 * [x4 > 0]
 //   dz4 = (W5^T dz5) * [t4 > 0]      dz3 = (W4^T dz4 + g36) * [x3 > 0]   g13 = W3^T dz3,  dz2 = g13 * [x2 > 0]
 //   dz1 = (W2^T dz2) * [t1 > 0]      dz0 = (W1^T dz1 + g13) * [x1 > 0]   d x = W0^T dz0
-// Per 64-pixel tile: dz of the layer above in one LDS buffer, the ReLU-mask activations of the layer below fetched into the
-// other one (requested before the K loop, written after it), the result written over the mask in place.  Every dz leaves
-// once (the weight gradients contract them over the pixels afterwards); the two skip gradients take a round trip through
-// a bf16 scratch tensor (same lanes write and read them: L2).  Arithmetic and roundings as gags_decoder_layer with
-// mask_src / residual / y_premask: bit-identical to the layer-by-layer backward.
+// Per 64-pixel tile the dz of the layer above sits in one LDS buffer and the result goes to the other; the ReLU decisions
+// come as the forward's bit masks (four words per lane and layer, requested before the K loop), and the two skip
+// gradients never leave the registers of the lanes that produced them (the accumulator -> (pixel, channel) mapping is the
+// same in every layer: 32 VGPRs of packed bf16).  Every dz leaves once, for the weight gradients.  Arithmetic and
+// roundings as gags_decoder_layer with mask_src / residual / y_premask: bit-identical to the layer-by-layer backward.
 struct BwdArgs {
     const unsigned short *dz8;    // [P, n_last] bf16
     const unsigned short *Wt[9];  // W_i^T, bf16 in MFMA-fragment order: [32, 256], 7 x [256, 256], [256, n_last]
-    const unsigned short *act[9]; // a0 (unused), x1, t1, x2, x3, t4, x4, t6, t7 [P, 256]
+    const unsigned *mask[9];      // [1..8]: ReLU bit masks [P, 8] of x1, t1, x2, x3, t4, x4, t6, t7
     unsigned short *dz[8];        // dz0 .. dz7 [P, 256] out
-    unsigned short *g36, *g13;    // scratch [P, 256]
     float *gin;                   // [P, c_in] fp32 out, or null
     int64_t P;
     int c_in, n_last;
@@ -278,9 +297,20 @@ __device__ __forceinline__ void commit_tile(Tile dst, const uint4 (&r)[8], int t
     }
 }
 
-// out[p][n] = bf16(acc (+ res[p][n])) * [mask[p][n] > 0];  pre[p][n] = the value before the mask (optional).
-// `out` may be the mask buffer itself (each element is read, then written, by the same lane).
-__device__ __forceinline__ void epilogue_dgrad(const f32x16 (&acc)[2][2], int n_base, Tile mask, Tile res, Tile out, Tile pre, int lane)
+// the four mask words of this lane: pixels p0 + 32 j + p, channels 32 (2 wave + i) .. + 31
+__device__ __forceinline__ void fetch_mask(unsigned (&mw)[2][2], const unsigned *__restrict__ mask, int64_t p0, int64_t P, int wave, int lane)
+{
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mw[i][j] = mask[min(p0 + 32 * j + (lane & 31), P - 1) * 8 + 2 * wave + i];
+}
+
+// out[p][n] = bf16(acc (+ res)) * [mask bit];  KEEP: the value before the mask stays in `keep` (packed bf16: a skip gradient);
+// ADD: `res` (a kept skip gradient) is added before the rounding.
+template <bool KEEP, bool ADD>
+__device__ __forceinline__ void epilogue_dgrad(const f32x16 (&acc)[2][2], int n_base, const unsigned (&mw)[2][2], Tile out,
+                                               uint2 (&keep)[2][4][2], int lane)
 {
     const int p = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -291,14 +321,13 @@ __device__ __forceinline__ void epilogue_dgrad(const f32x16 (&acc)[2][2], int n_
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 float v0 = acc[i][j][4 * g], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
-                if (res) {
-                    const uint2 e = *reinterpret_cast<const uint2 *>(&res[32 * j + p][n]);
+                if constexpr (ADD) {
+                    const uint2 e = keep[i][g][j];
                     v0 += flo(e.x); v1 += fhi(e.x); v2 += flo(e.y); v3 += fhi(e.y);
                 }
-                if (pre) *reinterpret_cast<uint2 *>(&pre[32 * j + p][n]) = make_uint2(fpack(v0, v1), fpack(v2, v3));
-                const uint2 m = *reinterpret_cast<const uint2 *>(&mask[32 * j + p][n]);
-                v0 = flo(m.x) > 0.f ? v0 : 0.f; v1 = fhi(m.x) > 0.f ? v1 : 0.f;
-                v2 = flo(m.y) > 0.f ? v2 : 0.f; v3 = fhi(m.y) > 0.f ? v3 : 0.f;
+                if constexpr (KEEP) keep[i][g][j] = make_uint2(fpack(v0, v1), fpack(v2, v3));
+                const unsigned nib = mw[i][j] >> (8 * g + 4 * h);
+                v0 = (nib & 1u) ? v0 : 0.f; v1 = (nib & 2u) ? v1 : 0.f; v2 = (nib & 4u) ? v2 : 0.f; v3 = (nib & 8u) ? v3 : 0.f;
                 *reinterpret_cast<uint2 *>(&out[32 * j + p][n]) = make_uint2(fpack(v0, v1), fpack(v2, v3));
             }
         }
@@ -313,84 +342,62 @@ __global__ __launch_bounds__(256, 2) void decoder_bwd_fused_kernel(BwdArgs a)
     const int64_t p0 = (int64_t)blockIdx.x * FT;
     const int n_base = 64 * wave;
     f32x16 acc[2][2];
-    uint4 pm[8], pr[8];  // mask / residual tiles in flight
+    uint2 skip[2][4][2];  // the skip gradient in flight (g36, later g13): this lane's own 32 values, packed bf16
+    unsigned mw[2][2];
+    uint4 slab[8];
 
     // L8: dz8 [64, n_last] through X in slabs of 256 columns -> dz7 (Y)
-    fetch_tile(pm, a.act[8], FH, 0, p0, a.P, tid);
+    fetch_mask(mw, a.mask[8], p0, a.P, wave, lane);
     for (int kb = 0; kb < a.n_last; kb += FH) {
-        fetch_tile(pr, a.dz8, a.n_last, kb, p0, a.P, tid);
+        fetch_tile(slab, a.dz8, a.n_last, kb, p0, a.P, tid);
         if (kb) __syncthreads();  // the previous slab has been multiplied
-        commit_tile(X, pr, tid);
+        commit_tile(X, slab, tid);
         __syncthreads();
         layer_mma(acc, a.Wt[8], a.n_last / 16, 2 * wave, kb / 16, 16, X, lane, kb == 0);
     }
-    commit_tile(Y, pm, tid);
-    __syncthreads();
-    epilogue_dgrad(acc, n_base, Y, nullptr, Y, nullptr, lane);
+    epilogue_dgrad<false, false>(acc, n_base, mw, Y, skip, lane);
     __syncthreads();
     store_tile(a.dz[7], p0, a.P, Y, tid);
     // L7: dz7 (Y) -> dz6 (X)
-    fetch_tile(pm, a.act[7], FH, 0, p0, a.P, tid);
+    fetch_mask(mw, a.mask[7], p0, a.P, wave, lane);
     layer_mma(acc, a.Wt[7], 16, 2 * wave, 0, 16, Y, lane, true);
-    commit_tile(X, pm, tid);
-    __syncthreads();
-    epilogue_dgrad(acc, n_base, X, nullptr, X, nullptr, lane);
+    epilogue_dgrad<false, false>(acc, n_base, mw, X, skip, lane);
     __syncthreads();
     store_tile(a.dz[6], p0, a.P, X, tid);
-    // L6: dz6 (X) -> g36 (kept in X, and in scratch), dz5 = g36 * [x4 > 0] (Y)
-    fetch_tile(pm, a.act[6], FH, 0, p0, a.P, tid);
+    // L6: dz6 (X) -> g36 (kept), dz5 = g36 * [x4 > 0] (Y)
+    fetch_mask(mw, a.mask[6], p0, a.P, wave, lane);
     layer_mma(acc, a.Wt[6], 16, 2 * wave, 0, 16, X, lane, true);
-    commit_tile(Y, pm, tid);
-    __syncthreads();  // every wave is done reading dz6: X may take the pre-mask value
-    epilogue_dgrad(acc, n_base, Y, nullptr, Y, X, lane);
+    epilogue_dgrad<true, false>(acc, n_base, mw, Y, skip, lane);
     __syncthreads();
-    store_tile(a.g36, p0, a.P, X, tid);
     store_tile(a.dz[5], p0, a.P, Y, tid);
     // L5: dz5 (Y) -> dz4 (X)
-    fetch_tile(pm, a.act[5], FH, 0, p0, a.P, tid);
+    fetch_mask(mw, a.mask[5], p0, a.P, wave, lane);
     layer_mma(acc, a.Wt[5], 16, 2 * wave, 0, 16, Y, lane, true);
-    commit_tile(X, pm, tid);
-    __syncthreads();
-    epilogue_dgrad(acc, n_base, X, nullptr, X, nullptr, lane);
+    epilogue_dgrad<false, false>(acc, n_base, mw, X, skip, lane);
     __syncthreads();
     store_tile(a.dz[4], p0, a.P, X, tid);
     // L4: dz4 (X) + g36 -> dz3 (Y)
-    fetch_tile(pm, a.act[4], FH, 0, p0, a.P, tid);
-    fetch_tile(pr, a.g36, FH, 0, p0, a.P, tid);
+    fetch_mask(mw, a.mask[4], p0, a.P, wave, lane);
     layer_mma(acc, a.Wt[4], 16, 2 * wave, 0, 16, X, lane, true);
-    commit_tile(Y, pm, tid);
-    __syncthreads();  // dz4 has been multiplied: X takes the skip gradient
-    commit_tile(X, pr, tid);
-    __syncthreads();
-    epilogue_dgrad(acc, n_base, Y, X, Y, nullptr, lane);
+    epilogue_dgrad<false, true>(acc, n_base, mw, Y, skip, lane);
     __syncthreads();
     store_tile(a.dz[3], p0, a.P, Y, tid);
-    // L3: dz3 (Y) -> g13 (Y, scratch), dz2 = g13 * [x2 > 0] (X)
-    fetch_tile(pm, a.act[3], FH, 0, p0, a.P, tid);
+    // L3: dz3 (Y) -> g13 (kept), dz2 = g13 * [x2 > 0] (X)
+    fetch_mask(mw, a.mask[3], p0, a.P, wave, lane);
     layer_mma(acc, a.Wt[3], 16, 2 * wave, 0, 16, Y, lane, true);
-    commit_tile(X, pm, tid);
+    epilogue_dgrad<true, false>(acc, n_base, mw, X, skip, lane);
     __syncthreads();
-    epilogue_dgrad(acc, n_base, X, nullptr, X, Y, lane);
-    __syncthreads();
-    store_tile(a.g13, p0, a.P, Y, tid);
     store_tile(a.dz[2], p0, a.P, X, tid);
     // L2: dz2 (X) -> dz1 (Y)
-    fetch_tile(pm, a.act[2], FH, 0, p0, a.P, tid);
+    fetch_mask(mw, a.mask[2], p0, a.P, wave, lane);
     layer_mma(acc, a.Wt[2], 16, 2 * wave, 0, 16, X, lane, true);
-    commit_tile(Y, pm, tid);
-    __syncthreads();
-    epilogue_dgrad(acc, n_base, Y, nullptr, Y, nullptr, lane);
+    epilogue_dgrad<false, false>(acc, n_base, mw, Y, skip, lane);
     __syncthreads();
     store_tile(a.dz[1], p0, a.P, Y, tid);
     // L1: dz1 (Y) + g13 -> dz0 (X)
-    fetch_tile(pm, a.act[1], FH, 0, p0, a.P, tid);
-    fetch_tile(pr, a.g13, FH, 0, p0, a.P, tid);
+    fetch_mask(mw, a.mask[1], p0, a.P, wave, lane);
     layer_mma(acc, a.Wt[1], 16, 2 * wave, 0, 16, Y, lane, true);
-    commit_tile(X, pm, tid);
-    __syncthreads();
-    commit_tile(Y, pr, tid);
-    __syncthreads();
-    epilogue_dgrad(acc, n_base, X, Y, X, nullptr, lane);
+    epilogue_dgrad<false, true>(acc, n_base, mw, X, skip, lane);
     __syncthreads();
     store_tile(a.dz[0], p0, a.P, X, tid);
     // L0: d x[p][c] = sum_n dz0[p][n] W0[n][c]: 32 (padded) channels x 64 pixels = two accumulator tiles, waves 0 and 1;
@@ -422,7 +429,8 @@ __global__ __launch_bounds__(256, 2) void decoder_bwd_fused_kernel(BwdArgs a)
 }  // namespace
 
 extern "C" int gags_decoder_fwd_fused(int64_t n_pix, int c_in, int n_last, const float *x, const void *const *w_bf16,
-                                      const float *const *bias, void *const *acts_bf16, float *logits, void *stream)
+                                      const float *const *bias, void *const *acts_bf16, void *masks, float *logits,
+                                      void *stream)
 {
     GAGS_CLEAR_ERR();
     if (n_pix < 0 || c_in <= 0 || c_in > 32 || n_last <= 0 || n_last % FH != 0 || !w_bf16 || !bias || !logits || (n_pix > 0 && !x))
@@ -435,6 +443,7 @@ extern "C" int gags_decoder_fwd_fused(int64_t n_pix, int c_in, int n_last, const
         a.W[i] = (const unsigned short *)w_bf16[i];
         a.b[i] = bias[i];
         a.act[i] = acts_bf16 ? (unsigned short *)acts_bf16[i] : nullptr;
+        a.mask[i] = (masks && i > 0) ? (unsigned *)masks + (size_t)(i - 1) * n_pix * 8 : nullptr;
     }
     hipLaunchKernelGGL(decoder_fwd_fused_kernel, dim3((unsigned)((n_pix + FT - 1) / FT)), dim3(256), 0, (hipStream_t)stream, a);
     GAGS_CHECK_LAUNCH();
@@ -442,21 +451,19 @@ extern "C" int gags_decoder_fwd_fused(int64_t n_pix, int c_in, int n_last, const
 }
 
 extern "C" int gags_decoder_bwd_fused(int64_t n_pix, int c_in, int n_last, const void *dz_last_bf16, const void *const *wt_bf16,
-                                      const void *const *acts_bf16, void *const *dz_bf16, void *g36_bf16, void *g13_bf16,
-                                      float *gin, void *stream)
+                                      const void *masks, void *const *dz_bf16, float *gin, void *stream)
 {
     GAGS_CLEAR_ERR();
-    if (n_pix < 0 || c_in <= 0 || c_in > 32 || n_last <= 0 || n_last % FH != 0 || !dz_last_bf16 || !wt_bf16 || !acts_bf16 || !dz_bf16 ||
-        !g36_bf16 || !g13_bf16)
+    if (n_pix < 0 || c_in <= 0 || c_in > 32 || n_last <= 0 || n_last % FH != 0 || !dz_last_bf16 || !wt_bf16 || !masks || !dz_bf16)
         return GAGS_EINVAL;
     if (n_pix == 0) return GAGS_OK;
     BwdArgs a;
-    a.dz8 = (const unsigned short *)dz_last_bf16; a.g36 = (unsigned short *)g36_bf16; a.g13 = (unsigned short *)g13_bf16;
+    a.dz8 = (const unsigned short *)dz_last_bf16;
     a.gin = gin; a.P = n_pix; a.c_in = c_in; a.n_last = n_last;
     for (int i = 0; i < 9; ++i) {
-        if (!wt_bf16[i] || (i > 0 && !acts_bf16[i])) return GAGS_EINVAL;
+        if (!wt_bf16[i]) return GAGS_EINVAL;
         a.Wt[i] = (const unsigned short *)wt_bf16[i];
-        a.act[i] = (const unsigned short *)acts_bf16[i];
+        a.mask[i] = i > 0 ? (const unsigned *)masks + (size_t)(i - 1) * n_pix * 8 : nullptr;
     }
     for (int i = 0; i < 8; ++i) {
         if (!dz_bf16[i]) return GAGS_EINVAL;

@@ -240,10 +240,11 @@ def _chain_forward(x, kind, params):
         logits = torch.empty(p, wb[8][0].shape[0], device=dev)
         arr = ctypes.c_void_p * 9
         wf = [_frag_layout(wgt) for wgt, _ in wb]
+        masks = torch.empty(8, p, 8, dtype=torch.int32, device=dev)  # the ReLU decisions as bits, for the fused backward
         check(_lib.load().gags_decoder_fwd_fused(p, xp.shape[1], logits.shape[1], ptr(xp), arr(*[t.data_ptr() for t in wf]),
                                                  arr(*[b.data_ptr() for _, b in wb]), arr(*[t.data_ptr() for t in acts]),
-                                                 ptr(logits), _st()), "gags_decoder_fwd_fused")
-        return logits, acts, wb, h, w, xp.shape[1]
+                                                 ptr(masks), ptr(logits), _st()), "gags_decoder_fwd_fused")
+        return logits, acts + [masks], wb, h, w, xp.shape[1]
     if kind == "decoder":
         x1 = _layer(p, *wb[0], a0)
         t1 = _layer(p, *wb[1], x1)
@@ -281,19 +282,17 @@ def _chain_backward(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, need_w=
     def dx(i, dz_i, mask_src=None, residual=None, premask=False):
         return _layer(p, wt[i], None, dz_i, relu=False, mask_src=mask_src, residual=residual, premask=premask)
 
-    if kind == "decoder" and FUSED and _fusable(wb, c_in) and dz.shape[1] == wb[8][0].shape[0]:
+    if kind == "decoder" and len(acts) == 10:  # the fused forward ran (its bit masks ride along as the tenth entry)
         # the nine input-gradient GEMMs in one kernel (csrc/decoder_fused.hip), then the weight gradients
-        a0, x1, t1, x2, x3, t4, x4, t6, t7 = acts
+        a0, x1, t1, x2, x3, t4, x4, t6, t7, masks = acts
         dev = dz.device
         dzs = [torch.empty(p, 256, dtype=torch.bfloat16, device=dev) for _ in range(8)]
-        g36, g13 = (torch.empty(p, 256, dtype=torch.bfloat16, device=dev) for _ in range(2))
         gx = torch.empty(h, w, c_in, device=dev) if need_x else None
         arr = ctypes.c_void_p * 9
         arr8 = ctypes.c_void_p * 8
         wtf = [_frag_layout(t) for t in wt]
-        check(_lib.load().gags_decoder_bwd_fused(p, c_in, dz.shape[1], ptr(dz), arr(*[t.data_ptr() for t in wtf]),
-                                                 arr(*[t.data_ptr() for t in acts]), arr8(*[t.data_ptr() for t in dzs]),
-                                                 ptr(g36), ptr(g13), ptr(gx), _st()), "gags_decoder_bwd_fused")
+        check(_lib.load().gags_decoder_bwd_fused(p, c_in, dz.shape[1], ptr(dz), arr(*[t.data_ptr() for t in wtf]), ptr(masks),
+                                                 arr8(*[t.data_ptr() for t in dzs]), ptr(gx), _st()), "gags_decoder_bwd_fused")
         wg(8, dz, t7); wg(7, dzs[7], t6); wg(6, dzs[6], x3, x4); wg(5, dzs[5], t4); wg(4, dzs[4], x3)
         wg(3, dzs[3], x1, x2); wg(2, dzs[2], t1); wg(1, dzs[1], x1); wg(0, dzs[0], a0)
         grads = []

@@ -124,16 +124,16 @@ int gags_decoder_head(int64_t n_pix, int c, int ld, int mode, const float *x, fl
  * activations [n_pix, 256] kept for the backward; logits [n_pix, n_last] fp32, n_last % 256 == 0.  Bit-identical to the
  * same chain run through gags_decoder_layer. */
 int gags_decoder_fwd_fused(int64_t n_pix, int c_in, int n_last, const float *x, const void *const *w_bf16,
-                           const float *const *bias, void *const *acts_bf16, float *logits, void *stream);
+                           const float *const *bias, void *const *acts_bf16, void *masks, float *logits, void *stream);
+/* (masks, optional: uint32 [8, n_pix, 8] -- the ReLU decisions of the eight hidden activations as bits, word n / 32 bit
+ * n % 32 of a pixel = [activation > 0]; what gags_decoder_bwd_fused reads instead of the activations themselves.) */
 
 /* ... and the nine input-gradient GEMMs of its backward in one kernel: dz_last [n_pix, n_last] bf16 (from the head's
  * backward) -> dz_bf16[0..7] = the gradients at the outputs of layers 0..7 ([n_pix, 256] bf16 each, what the weight
  * gradients contract), gin [n_pix, c_in] fp32 (optional).  wt_bf16[9]: the TRANSPOSED padded matrices ([32, 256], 7 x
- * [256, 256], [256, n_last]) in the same fragment order; acts_bf16: what gags_decoder_fwd_fused kept; g36 / g13: bf16 scratch [n_pix, 256] for the two
- * skip gradients.  Bit-identical to the chain of gags_decoder_layer calls with mask_src / residual / y_premask. */
+ * [256, 256], [256, n_last]) in the same fragment order; masks: the bit masks gags_decoder_fwd_fused kept (the two skip gradients stay in registers).  Bit-identical to the chain of gags_decoder_layer calls with mask_src / residual / y_premask. */
 int gags_decoder_bwd_fused(int64_t n_pix, int c_in, int n_last, const void *dz_last_bf16, const void *const *wt_bf16,
-                           const void *const *acts_bf16, void *const *dz_bf16, void *g36_bf16, void *g13_bf16, float *gin,
-                           void *stream);
+                           const void *masks, void *const *dz_bf16, float *gin, void *stream);
 
 /* ---- N1 at the reference's precision (models/networks.py:109-248 are fp32 Conv2d stacks) ------------------------- */
 
