@@ -11,6 +11,7 @@
 // 64 w .. 64 w + 63.  Two LDS buffers ping-pong; the residual sums x1 + x2 and x3 + x4 are formed in place.
 // Arithmetic is that of gags_decoder_layer (bf16 operands, fp32 accumulate in ascending k, bias + ReLU in fp32, one
 // rounding to bf16): the results are BIT-IDENTICAL to the layer-by-layer path (tests/test_decoders_gpu.py).
+#include <stdlib.h>
 #include "common.h"
 #include "gags_next.h"
 
@@ -29,7 +30,7 @@ __device__ __forceinline__ unsigned fpack(float lo, float hi)
 __device__ __forceinline__ float flo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float fhi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
-constexpr int FT = 64;        // pixels per tile
+constexpr int FT = 64;        // pixels per tile and group of four waves; a workgroup holds PH such groups (tile = 64 PH pixels)
 constexpr int FH = 256;       // hidden width
 constexpr int FLD = FH + 8;   // LDS row pitch in bf16 (528 B: 16-byte aligned rows, consecutive rows 4 banks apart)
 constexpr int FPD = 8;        // weight fragments are requested this many K-steps ahead
@@ -43,7 +44,7 @@ typedef unsigned short (*Tile)[FLD];
 // such lines in flight, the L1 thrashes, and every line is fetched four times -- measured 5.8 ms instead of 2.)
 // acc[i][j] (i: 32 channels of n-tile nt0 + i, j: 32 pixels 32 j..) = sum over k-steps ks0 .. ks0 + ksteps - 1 of W[n][k] in[p][k]
 __device__ __forceinline__ void layer_mma(f32x16 (&acc)[2][2], const unsigned short *__restrict__ Wf, int ksteps_total, int nt0, int ks0,
-                                          int ksteps, Tile in, int lane, bool zero)
+                                          int ksteps, Tile in, int lane, bool zero, int poff)
 {
     if (zero) {
 #pragma unroll
@@ -71,8 +72,8 @@ __device__ __forceinline__ void layer_mma(f32x16 (&acc)[2][2], const unsigned sh
             a0[q] = *reinterpret_cast<const bf16x8 *>(w0 + 512 * kn);
             a1[q] = *reinterpret_cast<const bf16x8 *>(w1 + 512 * kn);
             if (ks < ksteps) {  // (uniform)
-                const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(&in[(lane & 31)][16 * ks + 8 * (lane >> 5)]);
-                const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(&in[32 + (lane & 31)][16 * ks + 8 * (lane >> 5)]);
+                const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(&in[poff + (lane & 31)][16 * ks + 8 * (lane >> 5)]);
+                const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(&in[poff + 32 + (lane & 31)][16 * ks + 8 * (lane >> 5)]);
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0, b0, acc[0][0], 0, 0, 0);
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0, b1, acc[0][1], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, b0, acc[1][0], 0, 0, 0);
@@ -88,7 +89,7 @@ __device__ __forceinline__ void layer_mma(f32x16 (&acc)[2][2], const unsigned sh
 // mask[(p0 + pixel) * 8 + n / 32] bit n % 32 = [out > 0] -- 32 bytes per pixel and layer instead of the 512-byte activation row
 // the input-gradient chain would otherwise re-read just for its sign.
 __device__ __forceinline__ void epilogue_hidden(const f32x16 (&acc)[2][2], const float *__restrict__ bias, int n_base, Tile out,
-                                                int lane, unsigned *__restrict__ mask, int64_t p0, int64_t P)
+                                                int lane, unsigned *__restrict__ mask, int64_t p0, int64_t P, int poff)
 {
     const int p = lane & 31, h = lane >> 5;
     unsigned bits[2][2] = {{0u, 0u}, {0u, 0u}};
@@ -103,7 +104,7 @@ __device__ __forceinline__ void epilogue_hidden(const f32x16 (&acc)[2][2], const
                 const float v0 = fmaxf(acc[i][j][4 * g] + b.x, 0.f), v1 = fmaxf(acc[i][j][4 * g + 1] + b.y, 0.f);
                 const float v2 = fmaxf(acc[i][j][4 * g + 2] + b.z, 0.f), v3 = fmaxf(acc[i][j][4 * g + 3] + b.w, 0.f);
                 const unsigned u0 = fpack(v0, v1), u1 = fpack(v2, v3);
-                *reinterpret_cast<uint2 *>(&out[32 * j + p][n]) = make_uint2(u0, u1);
+                *reinterpret_cast<uint2 *>(&out[poff + 32 * j + p][n]) = make_uint2(u0, u1);
                 const unsigned nib = ((u0 & 0x7fffu) ? 1u : 0u) | ((u0 & 0x7fff0000u) ? 2u : 0u) | ((u1 & 0x7fffu) ? 4u : 0u) |
                                      ((u1 & 0x7fff0000u) ? 8u : 0u);
                 bits[i][j] |= nib << (8 * g);
@@ -117,29 +118,31 @@ __device__ __forceinline__ void epilogue_hidden(const f32x16 (&acc)[2][2], const
                 const unsigned mine = bits[i][j] << (4 * h);  // this half-wave's nibbles sit at bits 8 g + 4 h
                 const auto sw = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
                 const unsigned word = sw[0] | sw[1];
-                const int64_t pg = p0 + 32 * j + p;
+                const int64_t pg = p0 + poff + 32 * j + p;
                 if (h == 0 && pg < P) mask[pg * 8 + (n_base >> 5) + i] = word;
             }
     }
 }
 
 // the workgroup copies a [64][256] bf16 tile from LDS to its rows of a pixel-major tensor (16 bytes per lane, whole rows)
+template <int NT>
 __device__ __forceinline__ void store_tile(unsigned short *__restrict__ dst, int64_t p0, int64_t P, Tile src, int tid)
 {
     if (!dst) return;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        const int id = tid + 256 * q, row = id >> 5, c = (id & 31) * 8;
+        const int id = tid + NT * q, row = id >> 5, c = (id & 31) * 8;
         if (p0 + row < P) *reinterpret_cast<uint4 *>(dst + (size_t)(p0 + row) * FH + c) = *reinterpret_cast<const uint4 *>(&src[row][c]);
     }
 }
 
 // dst[p][:] = bf16(dst + add) element-wise (fp32 add, one rounding: what gags_decoder_layer does with two sources)
+template <int NT>
 __device__ __forceinline__ void add_tile(Tile dst, Tile add, int tid)
 {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        const int id = tid + 256 * q, row = id >> 5, c = (id & 31) * 8;
+        const int id = tid + NT * q, row = id >> 5, c = (id & 31) * 8;
         const uint4 x = *reinterpret_cast<const uint4 *>(&dst[row][c]), y = *reinterpret_cast<const uint4 *>(&add[row][c]);
         *reinterpret_cast<uint4 *>(&dst[row][c]) =
             make_uint4(fpack(flo(x.x) + flo(y.x), fhi(x.x) + fhi(y.x)), fpack(flo(x.y) + flo(y.y), fhi(x.y) + fhi(y.y)),
@@ -158,17 +161,19 @@ struct FwdArgs {
     int c_in, n_last;            // n_last % 256 == 0
 };
 
-__global__ __launch_bounds__(256, 2) void decoder_fwd_fused_kernel(FwdArgs a)
+template <int PH>
+__global__ __launch_bounds__(256 * PH, 2 / PH) void decoder_fwd_fused_kernel(FwdArgs a)
 {
-    __shared__ __attribute__((aligned(16))) unsigned short bufA[FT][FLD];
-    __shared__ __attribute__((aligned(16))) unsigned short bufB[FT][FLD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t p0 = (int64_t)blockIdx.x * FT;
+    __shared__ __attribute__((aligned(16))) unsigned short bufA[FT * PH][FLD];
+    __shared__ __attribute__((aligned(16))) unsigned short bufB[FT * PH][FLD];
+    constexpr int TP = FT * PH, NT = 256 * PH;  // pixels per tile, threads: PH groups of four waves, 64 pixels each
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, poff = FT * (tid >> 8);
+    const int64_t p0 = (int64_t)blockIdx.x * TP;
     const int n_base = 64 * wave;
     f32x16 acc[2][2];
 
     // input tile -> bufB[p][0..31] bf16 (zero-padded), also kept as a0 for the first layer's weight gradient
-    for (int e = tid; e < FT * 32; e += 256) {
+    for (int e = tid; e < TP * 32; e += NT) {
         const int row = e >> 5, c = e & 31;
         const int64_t p = p0 + row;
         const float v = (p < a.P && c < a.c_in) ? a.x[p * a.c_in + c] : 0.f;
@@ -178,59 +183,59 @@ __global__ __launch_bounds__(256, 2) void decoder_fwd_fused_kernel(FwdArgs a)
     }
     __syncthreads();
     // L0: a0 (B) -> x1 (A)
-    layer_mma(acc, a.W[0], 2, 2 * wave, 0, 2, bufB, lane, true);
-    epilogue_hidden(acc, a.b[0], n_base, bufA, lane, a.mask[1], p0, a.P);
+    layer_mma(acc, a.W[0], 2, 2 * wave, 0, 2, bufB, lane, true, poff);
+    epilogue_hidden(acc, a.b[0], n_base, bufA, lane, a.mask[1], p0, a.P, poff);
     __syncthreads();
-    store_tile(a.act[1], p0, a.P, bufA, tid);
+    store_tile<NT>(a.act[1], p0, a.P, bufA, tid);
     // L1: x1 (A) -> t1 (B)
-    layer_mma(acc, a.W[1], 16, 2 * wave, 0, 16, bufA, lane, true);
-    epilogue_hidden(acc, a.b[1], n_base, bufB, lane, a.mask[2], p0, a.P);
+    layer_mma(acc, a.W[1], 16, 2 * wave, 0, 16, bufA, lane, true, poff);
+    epilogue_hidden(acc, a.b[1], n_base, bufB, lane, a.mask[2], p0, a.P, poff);
     __syncthreads();
-    store_tile(a.act[2], p0, a.P, bufB, tid);
+    store_tile<NT>(a.act[2], p0, a.P, bufB, tid);
     // L2: t1 (B) -> x2, written over t1 once every wave is done reading it; then A = x1 + x2
-    layer_mma(acc, a.W[2], 16, 2 * wave, 0, 16, bufB, lane, true);
+    layer_mma(acc, a.W[2], 16, 2 * wave, 0, 16, bufB, lane, true, poff);
     __syncthreads();
-    epilogue_hidden(acc, a.b[2], n_base, bufB, lane, a.mask[3], p0, a.P);
+    epilogue_hidden(acc, a.b[2], n_base, bufB, lane, a.mask[3], p0, a.P, poff);
     __syncthreads();
-    store_tile(a.act[3], p0, a.P, bufB, tid);
-    add_tile(bufA, bufB, tid);
+    store_tile<NT>(a.act[3], p0, a.P, bufB, tid);
+    add_tile<NT>(bufA, bufB, tid);
     __syncthreads();
     // L3: x1 + x2 (A) -> x3 (B)
-    layer_mma(acc, a.W[3], 16, 2 * wave, 0, 16, bufA, lane, true);
-    epilogue_hidden(acc, a.b[3], n_base, bufB, lane, a.mask[4], p0, a.P);
+    layer_mma(acc, a.W[3], 16, 2 * wave, 0, 16, bufA, lane, true, poff);
+    epilogue_hidden(acc, a.b[3], n_base, bufB, lane, a.mask[4], p0, a.P, poff);
     __syncthreads();
-    store_tile(a.act[4], p0, a.P, bufB, tid);
+    store_tile<NT>(a.act[4], p0, a.P, bufB, tid);
     // L4: x3 (B) -> t4 (A)
-    layer_mma(acc, a.W[4], 16, 2 * wave, 0, 16, bufB, lane, true);
-    epilogue_hidden(acc, a.b[4], n_base, bufA, lane, a.mask[5], p0, a.P);
+    layer_mma(acc, a.W[4], 16, 2 * wave, 0, 16, bufB, lane, true, poff);
+    epilogue_hidden(acc, a.b[4], n_base, bufA, lane, a.mask[5], p0, a.P, poff);
     __syncthreads();
-    store_tile(a.act[5], p0, a.P, bufA, tid);
+    store_tile<NT>(a.act[5], p0, a.P, bufA, tid);
     // L5: t4 (A) -> x4 over t4; then B = x3 + x4
-    layer_mma(acc, a.W[5], 16, 2 * wave, 0, 16, bufA, lane, true);
+    layer_mma(acc, a.W[5], 16, 2 * wave, 0, 16, bufA, lane, true, poff);
     __syncthreads();
-    epilogue_hidden(acc, a.b[5], n_base, bufA, lane, a.mask[6], p0, a.P);
+    epilogue_hidden(acc, a.b[5], n_base, bufA, lane, a.mask[6], p0, a.P, poff);
     __syncthreads();
-    store_tile(a.act[6], p0, a.P, bufA, tid);
-    add_tile(bufB, bufA, tid);
+    store_tile<NT>(a.act[6], p0, a.P, bufA, tid);
+    add_tile<NT>(bufB, bufA, tid);
     __syncthreads();
     // L6: x3 + x4 (B) -> t6 (A)
-    layer_mma(acc, a.W[6], 16, 2 * wave, 0, 16, bufB, lane, true);
-    epilogue_hidden(acc, a.b[6], n_base, bufA, lane, a.mask[7], p0, a.P);
+    layer_mma(acc, a.W[6], 16, 2 * wave, 0, 16, bufB, lane, true, poff);
+    epilogue_hidden(acc, a.b[6], n_base, bufA, lane, a.mask[7], p0, a.P, poff);
     __syncthreads();
-    store_tile(a.act[7], p0, a.P, bufA, tid);
+    store_tile<NT>(a.act[7], p0, a.P, bufA, tid);
     // L7: t6 (A) -> t7 (B)
-    layer_mma(acc, a.W[7], 16, 2 * wave, 0, 16, bufA, lane, true);
-    epilogue_hidden(acc, a.b[7], n_base, bufB, lane, a.mask[8], p0, a.P);
+    layer_mma(acc, a.W[7], 16, 2 * wave, 0, 16, bufA, lane, true, poff);
+    epilogue_hidden(acc, a.b[7], n_base, bufB, lane, a.mask[8], p0, a.P, poff);
     __syncthreads();
-    store_tile(a.act[8], p0, a.P, bufB, tid);
+    store_tile<NT>(a.act[8], p0, a.P, bufB, tid);
     // L8: t7 (B) -> fp32 logits [P, n_last], 256 channels per pass.  Stored straight from the accumulators every
     // instruction would scatter 32-byte pieces 4 n_last bytes apart and HBM sees partial lines (csrc/decoder.hip measured
     // 2.4 x the bytes for that pattern); instead the two halves of a pass go through bufA (free by now: 64 pixels x 128
     // fp32 channels) and leave as whole 512-byte rows, 16 bytes per lane.
-    float (*patch)[FLD / 2] = reinterpret_cast<float (*)[FLD / 2]>(&bufA[0][0]);  // [64][132] floats, same 528-byte pitch
+    float (*patch)[FLD / 2] = reinterpret_cast<float (*)[FLD / 2]>(&bufA[0][0]);  // [TP][132] floats, same 528-byte pitch
     const int p = lane & 31, h = lane >> 5;
     for (int nb = 0; nb < a.n_last; nb += FH) {
-        layer_mma(acc, a.W[8], 16, nb / 32 + 2 * wave, 0, 16, bufB, lane, true);
+        layer_mma(acc, a.W[8], 16, nb / 32 + 2 * wave, 0, 16, bufB, lane, true, poff);
         for (int half = 0; half < 2; ++half) {
             if ((wave >> 1) == half) {  // waves 2 half, 2 half + 1 hold channels 128 half .. + 127 of the pass
 #pragma unroll
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void decoder_fwd_fused_kernel(FwdArgs a)
                         const float4 b = *reinterpret_cast<const float4 *>(a.b[8] + nb + 128 * half + nl);
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
-                            *reinterpret_cast<float4 *>(&patch[32 * j + p][nl]) =
+                            *reinterpret_cast<float4 *>(&patch[poff + 32 * j + p][nl]) =
                                 make_float4(acc[i][j][4 * g] + b.x, acc[i][j][4 * g + 1] + b.y, acc[i][j][4 * g + 2] + b.z,
                                             acc[i][j][4 * g + 3] + b.w);
                     }
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void decoder_fwd_fused_kernel(FwdArgs a)
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const int id = tid + 256 * q, row = id >> 5, c = (id & 31) * 4;
+                const int id = tid + NT * q, row = id >> 5, c = (id & 31) * 4;
                 if (p0 + row < a.P)
                     *reinterpret_cast<float4 *>(a.logits + (size_t)(p0 + row) * a.n_last + nb + 128 * half + c) =
                         *reinterpret_cast<const float4 *>(&patch[row][c]);
@@ -278,39 +283,41 @@ struct BwdArgs {
     int c_in, n_last;
 };
 
+template <int NT>
 __device__ __forceinline__ void fetch_tile(uint4 (&r)[8], const unsigned short *__restrict__ src, int ld, int col0, int64_t p0,
                                            int64_t P, int tid)
 {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        const int id = tid + 256 * q, row = id >> 5, c = (id & 31) * 8;
+        const int id = tid + NT * q, row = id >> 5, c = (id & 31) * 8;
         const int64_t pg = min(p0 + row, P - 1);  // clamped: unconditional loads; rows past the image are never stored
         r[q] = *reinterpret_cast<const uint4 *>(src + (size_t)pg * ld + col0 + c);
     }
 }
+template <int NT>
 __device__ __forceinline__ void commit_tile(Tile dst, const uint4 (&r)[8], int tid)
 {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        const int id = tid + 256 * q, row = id >> 5, c = (id & 31) * 8;
+        const int id = tid + NT * q, row = id >> 5, c = (id & 31) * 8;
         *reinterpret_cast<uint4 *>(&dst[row][c]) = r[q];
     }
 }
 
 // the four mask words of this lane: pixels p0 + 32 j + p, channels 32 (2 wave + i) .. + 31
-__device__ __forceinline__ void fetch_mask(unsigned (&mw)[2][2], const unsigned *__restrict__ mask, int64_t p0, int64_t P, int wave, int lane)
+__device__ __forceinline__ void fetch_mask(unsigned (&mw)[2][2], const unsigned *__restrict__ mask, int64_t p0, int64_t P, int wave, int lane, int poff)
 {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) mw[i][j] = mask[min(p0 + 32 * j + (lane & 31), P - 1) * 8 + 2 * wave + i];
+        for (int j = 0; j < 2; ++j) mw[i][j] = mask[min(p0 + poff + 32 * j + (lane & 31), P - 1) * 8 + 2 * wave + i];
 }
 
 // out[p][n] = bf16(acc (+ res)) * [mask bit];  KEEP: the value before the mask stays in `keep` (packed bf16: a skip gradient);
 // ADD: `res` (a kept skip gradient) is added before the rounding.
 template <bool KEEP, bool ADD>
 __device__ __forceinline__ void epilogue_dgrad(const f32x16 (&acc)[2][2], int n_base, const unsigned (&mw)[2][2], Tile out,
-                                               uint2 (&keep)[2][4][2], int lane)
+                                               uint2 (&keep)[2][4][2], int lane, int poff)
 {
     const int p = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -328,18 +335,20 @@ __device__ __forceinline__ void epilogue_dgrad(const f32x16 (&acc)[2][2], int n_
                 if constexpr (KEEP) keep[i][g][j] = make_uint2(fpack(v0, v1), fpack(v2, v3));
                 const unsigned nib = mw[i][j] >> (8 * g + 4 * h);
                 v0 = (nib & 1u) ? v0 : 0.f; v1 = (nib & 2u) ? v1 : 0.f; v2 = (nib & 4u) ? v2 : 0.f; v3 = (nib & 8u) ? v3 : 0.f;
-                *reinterpret_cast<uint2 *>(&out[32 * j + p][n]) = make_uint2(fpack(v0, v1), fpack(v2, v3));
+                *reinterpret_cast<uint2 *>(&out[poff + 32 * j + p][n]) = make_uint2(fpack(v0, v1), fpack(v2, v3));
             }
         }
 }
 
-__global__ __launch_bounds__(256, 2) void decoder_bwd_fused_kernel(BwdArgs a)
+template <int PH>
+__global__ __launch_bounds__(256 * PH, 2 / PH) void decoder_bwd_fused_kernel(BwdArgs a)
 {
-    __shared__ __attribute__((aligned(16))) unsigned short bufA[FT][FLD];
-    __shared__ __attribute__((aligned(16))) unsigned short bufB[FT][FLD];
+    __shared__ __attribute__((aligned(16))) unsigned short bufA[FT * PH][FLD];
+    __shared__ __attribute__((aligned(16))) unsigned short bufB[FT * PH][FLD];
     Tile X = bufA, Y = bufB;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t p0 = (int64_t)blockIdx.x * FT;
+    constexpr int TP = FT * PH, NT = 256 * PH;  // pixels per tile, threads: PH groups of four waves, 64 pixels each
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, poff = FT * (tid >> 8);
+    const int64_t p0 = (int64_t)blockIdx.x * TP;
     const int n_base = 64 * wave;
     f32x16 acc[2][2];
     uint2 skip[2][4][2];  // the skip gradient in flight (g36, later g13): this lane's own 32 values, packed bf16
@@ -347,62 +356,62 @@ __global__ __launch_bounds__(256, 2) void decoder_bwd_fused_kernel(BwdArgs a)
     uint4 slab[8];
 
     // L8: dz8 [64, n_last] through X in slabs of 256 columns -> dz7 (Y)
-    fetch_mask(mw, a.mask[8], p0, a.P, wave, lane);
+    fetch_mask(mw, a.mask[8], p0, a.P, wave, lane, poff);
     for (int kb = 0; kb < a.n_last; kb += FH) {
-        fetch_tile(slab, a.dz8, a.n_last, kb, p0, a.P, tid);
+        fetch_tile<NT>(slab, a.dz8, a.n_last, kb, p0, a.P, tid);
         if (kb) __syncthreads();  // the previous slab has been multiplied
-        commit_tile(X, slab, tid);
+        commit_tile<NT>(X, slab, tid);
         __syncthreads();
-        layer_mma(acc, a.Wt[8], a.n_last / 16, 2 * wave, kb / 16, 16, X, lane, kb == 0);
+        layer_mma(acc, a.Wt[8], a.n_last / 16, 2 * wave, kb / 16, 16, X, lane, kb == 0, poff);
     }
-    epilogue_dgrad<false, false>(acc, n_base, mw, Y, skip, lane);
+    epilogue_dgrad<false, false>(acc, n_base, mw, Y, skip, lane, poff);
     __syncthreads();
-    store_tile(a.dz[7], p0, a.P, Y, tid);
+    store_tile<NT>(a.dz[7], p0, a.P, Y, tid);
     // L7: dz7 (Y) -> dz6 (X)
-    fetch_mask(mw, a.mask[7], p0, a.P, wave, lane);
-    layer_mma(acc, a.Wt[7], 16, 2 * wave, 0, 16, Y, lane, true);
-    epilogue_dgrad<false, false>(acc, n_base, mw, X, skip, lane);
+    fetch_mask(mw, a.mask[7], p0, a.P, wave, lane, poff);
+    layer_mma(acc, a.Wt[7], 16, 2 * wave, 0, 16, Y, lane, true, poff);
+    epilogue_dgrad<false, false>(acc, n_base, mw, X, skip, lane, poff);
     __syncthreads();
-    store_tile(a.dz[6], p0, a.P, X, tid);
+    store_tile<NT>(a.dz[6], p0, a.P, X, tid);
     // L6: dz6 (X) -> g36 (kept), dz5 = g36 * [x4 > 0] (Y)
-    fetch_mask(mw, a.mask[6], p0, a.P, wave, lane);
-    layer_mma(acc, a.Wt[6], 16, 2 * wave, 0, 16, X, lane, true);
-    epilogue_dgrad<true, false>(acc, n_base, mw, Y, skip, lane);
+    fetch_mask(mw, a.mask[6], p0, a.P, wave, lane, poff);
+    layer_mma(acc, a.Wt[6], 16, 2 * wave, 0, 16, X, lane, true, poff);
+    epilogue_dgrad<true, false>(acc, n_base, mw, Y, skip, lane, poff);
     __syncthreads();
-    store_tile(a.dz[5], p0, a.P, Y, tid);
+    store_tile<NT>(a.dz[5], p0, a.P, Y, tid);
     // L5: dz5 (Y) -> dz4 (X)
-    fetch_mask(mw, a.mask[5], p0, a.P, wave, lane);
-    layer_mma(acc, a.Wt[5], 16, 2 * wave, 0, 16, Y, lane, true);
-    epilogue_dgrad<false, false>(acc, n_base, mw, X, skip, lane);
+    fetch_mask(mw, a.mask[5], p0, a.P, wave, lane, poff);
+    layer_mma(acc, a.Wt[5], 16, 2 * wave, 0, 16, Y, lane, true, poff);
+    epilogue_dgrad<false, false>(acc, n_base, mw, X, skip, lane, poff);
     __syncthreads();
-    store_tile(a.dz[4], p0, a.P, X, tid);
+    store_tile<NT>(a.dz[4], p0, a.P, X, tid);
     // L4: dz4 (X) + g36 -> dz3 (Y)
-    fetch_mask(mw, a.mask[4], p0, a.P, wave, lane);
-    layer_mma(acc, a.Wt[4], 16, 2 * wave, 0, 16, X, lane, true);
-    epilogue_dgrad<false, true>(acc, n_base, mw, Y, skip, lane);
+    fetch_mask(mw, a.mask[4], p0, a.P, wave, lane, poff);
+    layer_mma(acc, a.Wt[4], 16, 2 * wave, 0, 16, X, lane, true, poff);
+    epilogue_dgrad<false, true>(acc, n_base, mw, Y, skip, lane, poff);
     __syncthreads();
-    store_tile(a.dz[3], p0, a.P, Y, tid);
+    store_tile<NT>(a.dz[3], p0, a.P, Y, tid);
     // L3: dz3 (Y) -> g13 (kept), dz2 = g13 * [x2 > 0] (X)
-    fetch_mask(mw, a.mask[3], p0, a.P, wave, lane);
-    layer_mma(acc, a.Wt[3], 16, 2 * wave, 0, 16, Y, lane, true);
-    epilogue_dgrad<true, false>(acc, n_base, mw, X, skip, lane);
+    fetch_mask(mw, a.mask[3], p0, a.P, wave, lane, poff);
+    layer_mma(acc, a.Wt[3], 16, 2 * wave, 0, 16, Y, lane, true, poff);
+    epilogue_dgrad<true, false>(acc, n_base, mw, X, skip, lane, poff);
     __syncthreads();
-    store_tile(a.dz[2], p0, a.P, X, tid);
+    store_tile<NT>(a.dz[2], p0, a.P, X, tid);
     // L2: dz2 (X) -> dz1 (Y)
-    fetch_mask(mw, a.mask[2], p0, a.P, wave, lane);
-    layer_mma(acc, a.Wt[2], 16, 2 * wave, 0, 16, X, lane, true);
-    epilogue_dgrad<false, false>(acc, n_base, mw, Y, skip, lane);
+    fetch_mask(mw, a.mask[2], p0, a.P, wave, lane, poff);
+    layer_mma(acc, a.Wt[2], 16, 2 * wave, 0, 16, X, lane, true, poff);
+    epilogue_dgrad<false, false>(acc, n_base, mw, Y, skip, lane, poff);
     __syncthreads();
-    store_tile(a.dz[1], p0, a.P, Y, tid);
+    store_tile<NT>(a.dz[1], p0, a.P, Y, tid);
     // L1: dz1 (Y) + g13 -> dz0 (X)
-    fetch_mask(mw, a.mask[1], p0, a.P, wave, lane);
-    layer_mma(acc, a.Wt[1], 16, 2 * wave, 0, 16, Y, lane, true);
-    epilogue_dgrad<false, true>(acc, n_base, mw, X, skip, lane);
+    fetch_mask(mw, a.mask[1], p0, a.P, wave, lane, poff);
+    layer_mma(acc, a.Wt[1], 16, 2 * wave, 0, 16, Y, lane, true, poff);
+    epilogue_dgrad<false, true>(acc, n_base, mw, X, skip, lane, poff);
     __syncthreads();
-    store_tile(a.dz[0], p0, a.P, X, tid);
+    store_tile<NT>(a.dz[0], p0, a.P, X, tid);
     // L0: d x[p][c] = sum_n dz0[p][n] W0[n][c]: 32 (padded) channels x 64 pixels = two accumulator tiles, waves 0 and 1;
     // rounded to bf16 and widened, as the layer-by-layer path hands it over (gags_decoder_unpack_grad)
-    if (a.gin && wave < 2) {
+    if (a.gin && wave < 2) {  // (of every group of four)
         f32x16 c;
 #pragma unroll
         for (int r = 0; r < 16; ++r) c[r] = 0.f;
@@ -410,10 +419,10 @@ __global__ __launch_bounds__(256, 2) void decoder_bwd_fused_kernel(BwdArgs a)
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
             const bf16x8 wf = *reinterpret_cast<const bf16x8 *>(w0 + 512 * ks);
-            const bf16x8 bf = *reinterpret_cast<const bf16x8 *>(&X[32 * wave + (lane & 31)][16 * ks + 8 * (lane >> 5)]);
+            const bf16x8 bf = *reinterpret_cast<const bf16x8 *>(&X[poff + 32 * wave + (lane & 31)][16 * ks + 8 * (lane >> 5)]);
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, bf, c, 0, 0, 0);
         }
-        const int64_t pg = p0 + 32 * wave + (lane & 31);
+        const int64_t pg = p0 + poff + 32 * wave + (lane & 31);
         if (pg < a.P) {
 #pragma unroll
             for (int g = 0; g < 4; ++g)
@@ -424,6 +433,13 @@ __global__ __launch_bounds__(256, 2) void decoder_bwd_fused_kernel(BwdArgs a)
                 }
         }
     }
+}
+
+// tile size experiment switch (GAGS_FUSED_PH=1|2: 64- or 128-pixel tiles), read once
+inline int fused_ph()
+{
+    static const int ph = [] { const char *e = getenv("GAGS_FUSED_PH"); return (e && e[0] == '2') ? 2 : 1; }();
+    return ph;
 }
 
 }  // namespace
@@ -445,7 +461,10 @@ extern "C" int gags_decoder_fwd_fused(int64_t n_pix, int c_in, int n_last, const
         a.act[i] = acts_bf16 ? (unsigned short *)acts_bf16[i] : nullptr;
         a.mask[i] = (masks && i > 0) ? (unsigned *)masks + (size_t)(i - 1) * n_pix * 8 : nullptr;
     }
-    hipLaunchKernelGGL(decoder_fwd_fused_kernel, dim3((unsigned)((n_pix + FT - 1) / FT)), dim3(256), 0, (hipStream_t)stream, a);
+    if (fused_ph() == 2)
+        hipLaunchKernelGGL(decoder_fwd_fused_kernel<2>, dim3((unsigned)((n_pix + 2 * FT - 1) / (2 * FT))), dim3(512), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(decoder_fwd_fused_kernel<1>, dim3((unsigned)((n_pix + FT - 1) / FT)), dim3(256), 0, (hipStream_t)stream, a);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }
@@ -469,7 +488,10 @@ extern "C" int gags_decoder_bwd_fused(int64_t n_pix, int c_in, int n_last, const
         if (!dz_bf16[i]) return GAGS_EINVAL;
         a.dz[i] = (unsigned short *)dz_bf16[i];
     }
-    hipLaunchKernelGGL(decoder_bwd_fused_kernel, dim3((unsigned)((n_pix + FT - 1) / FT)), dim3(256), 0, (hipStream_t)stream, a);
+    if (fused_ph() == 2)
+        hipLaunchKernelGGL(decoder_bwd_fused_kernel<2>, dim3((unsigned)((n_pix + 2 * FT - 1) / (2 * FT))), dim3(512), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(decoder_bwd_fused_kernel<1>, dim3((unsigned)((n_pix + FT - 1) / FT)), dim3(256), 0, (hipStream_t)stream, a);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }
