@@ -43,8 +43,27 @@ typedef unsigned short (*Tile)[FLD];
 // row-major matrix, a fragment is 32 row pieces of 32 bytes, one per 128-byte line: the eight waves of a CU keep 64 KB of
 // such lines in flight, the L1 thrashes, and every line is fetched four times -- measured 5.8 ms instead of 2.)
 // acc[i][j] (i: 32 channels of n-tile nt0 + i, j: 32 pixels 32 j..) = sum over k-steps ks0 .. ks0 + ksteps - 1 of W[n][k] in[p][k]
-__device__ __forceinline__ void layer_mma(f32x16 (&acc)[2][2], const unsigned short *__restrict__ Wf, int ksteps_total, int nt0, int ks0,
-                                          int ksteps, Tile in, int lane, bool zero, int poff)
+struct WFrag {
+    bf16x8 a0[FPD], a1[FPD];
+};
+
+// the first FPD K-steps' weight fragments of a layer: issued BEFORE the epilogue of the layer above (and before its tile
+// stores), so that their L2 latency hides behind that epilogue instead of opening every layer
+__device__ __forceinline__ void wprefetch(WFrag &f, const unsigned short *__restrict__ Wf, int ksteps_total, int nt0, int ks0, int ksteps,
+                                          int lane)
+{
+    const unsigned short *w0 = Wf + ((size_t)nt0 * ksteps_total + ks0) * 512 + lane * 8;
+    const unsigned short *w1 = w0 + (size_t)ksteps_total * 512;
+#pragma unroll
+    for (int q = 0; q < FPD; ++q) {
+        const int ks = min(q, ksteps - 1);
+        f.a0[q] = *reinterpret_cast<const bf16x8 *>(w0 + 512 * ks);
+        f.a1[q] = *reinterpret_cast<const bf16x8 *>(w1 + 512 * ks);
+    }
+}
+
+__device__ __forceinline__ void layer_main(f32x16 (&acc)[2][2], WFrag &f, const unsigned short *__restrict__ Wf, int ksteps_total, int nt0,
+                                           int ks0, int ksteps, Tile in, int lane, bool zero, int poff)
 {
     if (zero) {
 #pragma unroll
@@ -56,21 +75,14 @@ __device__ __forceinline__ void layer_mma(f32x16 (&acc)[2][2], const unsigned sh
     }
     const unsigned short *w0 = Wf + ((size_t)nt0 * ksteps_total + ks0) * 512 + lane * 8;
     const unsigned short *w1 = w0 + (size_t)ksteps_total * 512;
-    bf16x8 a0[FPD], a1[FPD];
-#pragma unroll
-    for (int q = 0; q < FPD; ++q) {
-        const int ks = min(q, ksteps - 1);
-        a0[q] = *reinterpret_cast<const bf16x8 *>(w0 + 512 * ks);
-        a1[q] = *reinterpret_cast<const bf16x8 *>(w1 + 512 * ks);
-    }
     for (int k0 = 0; k0 < ksteps; k0 += FPD) {
 #pragma unroll
         for (int q = 0; q < FPD; ++q) {
             const int ks = k0 + q;
-            const bf16x8 c0 = a0[q], c1 = a1[q];
+            const bf16x8 c0 = f.a0[q], c1 = f.a1[q];
             const int kn = min(ks + FPD, ksteps - 1);  // (past the end: a harmless re-read)
-            a0[q] = *reinterpret_cast<const bf16x8 *>(w0 + 512 * kn);
-            a1[q] = *reinterpret_cast<const bf16x8 *>(w1 + 512 * kn);
+            f.a0[q] = *reinterpret_cast<const bf16x8 *>(w0 + 512 * kn);
+            f.a1[q] = *reinterpret_cast<const bf16x8 *>(w1 + 512 * kn);
             if (ks < ksteps) {  // (uniform)
                 const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(&in[poff + (lane & 31)][16 * ks + 8 * (lane >> 5)]);
                 const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(&in[poff + 32 + (lane & 31)][16 * ks + 8 * (lane >> 5)]);
@@ -171,6 +183,8 @@ __global__ __launch_bounds__(256 * PH, 2 / PH) void decoder_fwd_fused_kernel(Fwd
     const int64_t p0 = (int64_t)blockIdx.x * TP;
     const int n_base = 64 * wave;
     f32x16 acc[2][2];
+    WFrag wf;
+    wprefetch(wf, a.W[0], 2, 2 * wave, 0, 2, lane);
 
     // input tile -> bufB[p][0..31] bf16 (zero-padded), also kept as a0 for the first layer's weight gradient
     for (int e = tid; e < TP * 32; e += NT) {
@@ -183,17 +197,20 @@ __global__ __launch_bounds__(256 * PH, 2 / PH) void decoder_fwd_fused_kernel(Fwd
     }
     __syncthreads();
     // L0: a0 (B) -> x1 (A)
-    layer_mma(acc, a.W[0], 2, 2 * wave, 0, 2, bufB, lane, true, poff);
+    layer_main(acc, wf, a.W[0], 2, 2 * wave, 0, 2, bufB, lane, true, poff);
+    wprefetch(wf, a.W[1], 16, 2 * wave, 0, 16, lane);
     epilogue_hidden(acc, a.b[0], n_base, bufA, lane, a.mask[1], p0, a.P, poff);
     __syncthreads();
     store_tile<NT>(a.act[1], p0, a.P, bufA, tid);
     // L1: x1 (A) -> t1 (B)
-    layer_mma(acc, a.W[1], 16, 2 * wave, 0, 16, bufA, lane, true, poff);
+    layer_main(acc, wf, a.W[1], 16, 2 * wave, 0, 16, bufA, lane, true, poff);
+    wprefetch(wf, a.W[2], 16, 2 * wave, 0, 16, lane);
     epilogue_hidden(acc, a.b[1], n_base, bufB, lane, a.mask[2], p0, a.P, poff);
     __syncthreads();
     store_tile<NT>(a.act[2], p0, a.P, bufB, tid);
     // L2: t1 (B) -> x2, written over t1 once every wave is done reading it; then A = x1 + x2
-    layer_mma(acc, a.W[2], 16, 2 * wave, 0, 16, bufB, lane, true, poff);
+    layer_main(acc, wf, a.W[2], 16, 2 * wave, 0, 16, bufB, lane, true, poff);
+    wprefetch(wf, a.W[3], 16, 2 * wave, 0, 16, lane);
     __syncthreads();
     epilogue_hidden(acc, a.b[2], n_base, bufB, lane, a.mask[3], p0, a.P, poff);
     __syncthreads();
@@ -201,17 +218,20 @@ __global__ __launch_bounds__(256 * PH, 2 / PH) void decoder_fwd_fused_kernel(Fwd
     add_tile<NT>(bufA, bufB, tid);
     __syncthreads();
     // L3: x1 + x2 (A) -> x3 (B)
-    layer_mma(acc, a.W[3], 16, 2 * wave, 0, 16, bufA, lane, true, poff);
+    layer_main(acc, wf, a.W[3], 16, 2 * wave, 0, 16, bufA, lane, true, poff);
+    wprefetch(wf, a.W[4], 16, 2 * wave, 0, 16, lane);
     epilogue_hidden(acc, a.b[3], n_base, bufB, lane, a.mask[4], p0, a.P, poff);
     __syncthreads();
     store_tile<NT>(a.act[4], p0, a.P, bufB, tid);
     // L4: x3 (B) -> t4 (A)
-    layer_mma(acc, a.W[4], 16, 2 * wave, 0, 16, bufB, lane, true, poff);
+    layer_main(acc, wf, a.W[4], 16, 2 * wave, 0, 16, bufB, lane, true, poff);
+    wprefetch(wf, a.W[5], 16, 2 * wave, 0, 16, lane);
     epilogue_hidden(acc, a.b[4], n_base, bufA, lane, a.mask[5], p0, a.P, poff);
     __syncthreads();
     store_tile<NT>(a.act[5], p0, a.P, bufA, tid);
     // L5: t4 (A) -> x4 over t4; then B = x3 + x4
-    layer_mma(acc, a.W[5], 16, 2 * wave, 0, 16, bufA, lane, true, poff);
+    layer_main(acc, wf, a.W[5], 16, 2 * wave, 0, 16, bufA, lane, true, poff);
+    wprefetch(wf, a.W[6], 16, 2 * wave, 0, 16, lane);
     __syncthreads();
     epilogue_hidden(acc, a.b[5], n_base, bufA, lane, a.mask[6], p0, a.P, poff);
     __syncthreads();
@@ -219,12 +239,13 @@ __global__ __launch_bounds__(256 * PH, 2 / PH) void decoder_fwd_fused_kernel(Fwd
     add_tile<NT>(bufB, bufA, tid);
     __syncthreads();
     // L6: x3 + x4 (B) -> t6 (A)
-    layer_mma(acc, a.W[6], 16, 2 * wave, 0, 16, bufB, lane, true, poff);
+    layer_main(acc, wf, a.W[6], 16, 2 * wave, 0, 16, bufB, lane, true, poff);
+    wprefetch(wf, a.W[7], 16, 2 * wave, 0, 16, lane);
     epilogue_hidden(acc, a.b[6], n_base, bufA, lane, a.mask[7], p0, a.P, poff);
     __syncthreads();
     store_tile<NT>(a.act[7], p0, a.P, bufA, tid);
     // L7: t6 (A) -> t7 (B)
-    layer_mma(acc, a.W[7], 16, 2 * wave, 0, 16, bufA, lane, true, poff);
+    layer_main(acc, wf, a.W[7], 16, 2 * wave, 0, 16, bufA, lane, true, poff);
     epilogue_hidden(acc, a.b[7], n_base, bufB, lane, a.mask[8], p0, a.P, poff);
     __syncthreads();
     store_tile<NT>(a.act[8], p0, a.P, bufB, tid);
@@ -235,7 +256,8 @@ __global__ __launch_bounds__(256 * PH, 2 / PH) void decoder_fwd_fused_kernel(Fwd
     float (*patch)[FLD / 2] = reinterpret_cast<float (*)[FLD / 2]>(&bufA[0][0]);  // [TP][132] floats, same 528-byte pitch
     const int p = lane & 31, h = lane >> 5;
     for (int nb = 0; nb < a.n_last; nb += FH) {
-        layer_mma(acc, a.W[8], 16, nb / 32 + 2 * wave, 0, 16, bufB, lane, true, poff);
+        wprefetch(wf, a.W[8], 16, nb / 32 + 2 * wave, 0, 16, lane);
+        layer_main(acc, wf, a.W[8], 16, nb / 32 + 2 * wave, 0, 16, bufB, lane, true, poff);
         for (int half = 0; half < 2; ++half) {
             if ((wave >> 1) == half) {  // waves 2 half, 2 half + 1 hold channels 128 half .. + 127 of the pass
 #pragma unroll
@@ -354,6 +376,7 @@ __global__ __launch_bounds__(256 * PH, 2 / PH) void decoder_bwd_fused_kernel(Bwd
     uint2 skip[2][4][2];  // the skip gradient in flight (g36, later g13): this lane's own 32 values, packed bf16
     unsigned mw[2][2];
     uint4 slab[8];
+    WFrag wf;
 
     // L8: dz8 [64, n_last] through X in slabs of 256 columns -> dz7 (Y)
     fetch_mask(mw, a.mask[8], p0, a.P, wave, lane, poff);
@@ -362,50 +385,58 @@ __global__ __launch_bounds__(256 * PH, 2 / PH) void decoder_bwd_fused_kernel(Bwd
         if (kb) __syncthreads();  // the previous slab has been multiplied
         commit_tile<NT>(X, slab, tid);
         __syncthreads();
-        layer_mma(acc, a.Wt[8], a.n_last / 16, 2 * wave, kb / 16, 16, X, lane, kb == 0, poff);
+        wprefetch(wf, a.Wt[8], a.n_last / 16, 2 * wave, kb / 16, 16, lane);
+        layer_main(acc, wf, a.Wt[8], a.n_last / 16, 2 * wave, kb / 16, 16, X, lane, kb == 0, poff);
     }
+    wprefetch(wf, a.Wt[7], 16, 2 * wave, 0, 16, lane);
     epilogue_dgrad<false, false>(acc, n_base, mw, Y, skip, lane, poff);
     __syncthreads();
     store_tile<NT>(a.dz[7], p0, a.P, Y, tid);
     // L7: dz7 (Y) -> dz6 (X)
     fetch_mask(mw, a.mask[7], p0, a.P, wave, lane, poff);
-    layer_mma(acc, a.Wt[7], 16, 2 * wave, 0, 16, Y, lane, true, poff);
+    layer_main(acc, wf, a.Wt[7], 16, 2 * wave, 0, 16, Y, lane, true, poff);
+    wprefetch(wf, a.Wt[6], 16, 2 * wave, 0, 16, lane);
     epilogue_dgrad<false, false>(acc, n_base, mw, X, skip, lane, poff);
     __syncthreads();
     store_tile<NT>(a.dz[6], p0, a.P, X, tid);
     // L6: dz6 (X) -> g36 (kept), dz5 = g36 * [x4 > 0] (Y)
     fetch_mask(mw, a.mask[6], p0, a.P, wave, lane, poff);
-    layer_mma(acc, a.Wt[6], 16, 2 * wave, 0, 16, X, lane, true, poff);
+    layer_main(acc, wf, a.Wt[6], 16, 2 * wave, 0, 16, X, lane, true, poff);
+    wprefetch(wf, a.Wt[5], 16, 2 * wave, 0, 16, lane);
     epilogue_dgrad<true, false>(acc, n_base, mw, Y, skip, lane, poff);
     __syncthreads();
     store_tile<NT>(a.dz[5], p0, a.P, Y, tid);
     // L5: dz5 (Y) -> dz4 (X)
     fetch_mask(mw, a.mask[5], p0, a.P, wave, lane, poff);
-    layer_mma(acc, a.Wt[5], 16, 2 * wave, 0, 16, Y, lane, true, poff);
+    layer_main(acc, wf, a.Wt[5], 16, 2 * wave, 0, 16, Y, lane, true, poff);
+    wprefetch(wf, a.Wt[4], 16, 2 * wave, 0, 16, lane);
     epilogue_dgrad<false, false>(acc, n_base, mw, X, skip, lane, poff);
     __syncthreads();
     store_tile<NT>(a.dz[4], p0, a.P, X, tid);
     // L4: dz4 (X) + g36 -> dz3 (Y)
     fetch_mask(mw, a.mask[4], p0, a.P, wave, lane, poff);
-    layer_mma(acc, a.Wt[4], 16, 2 * wave, 0, 16, X, lane, true, poff);
+    layer_main(acc, wf, a.Wt[4], 16, 2 * wave, 0, 16, X, lane, true, poff);
+    wprefetch(wf, a.Wt[3], 16, 2 * wave, 0, 16, lane);
     epilogue_dgrad<false, true>(acc, n_base, mw, Y, skip, lane, poff);
     __syncthreads();
     store_tile<NT>(a.dz[3], p0, a.P, Y, tid);
     // L3: dz3 (Y) -> g13 (kept), dz2 = g13 * [x2 > 0] (X)
     fetch_mask(mw, a.mask[3], p0, a.P, wave, lane, poff);
-    layer_mma(acc, a.Wt[3], 16, 2 * wave, 0, 16, Y, lane, true, poff);
+    layer_main(acc, wf, a.Wt[3], 16, 2 * wave, 0, 16, Y, lane, true, poff);
+    wprefetch(wf, a.Wt[2], 16, 2 * wave, 0, 16, lane);
     epilogue_dgrad<true, false>(acc, n_base, mw, X, skip, lane, poff);
     __syncthreads();
     store_tile<NT>(a.dz[2], p0, a.P, X, tid);
     // L2: dz2 (X) -> dz1 (Y)
     fetch_mask(mw, a.mask[2], p0, a.P, wave, lane, poff);
-    layer_mma(acc, a.Wt[2], 16, 2 * wave, 0, 16, X, lane, true, poff);
+    layer_main(acc, wf, a.Wt[2], 16, 2 * wave, 0, 16, X, lane, true, poff);
+    wprefetch(wf, a.Wt[1], 16, 2 * wave, 0, 16, lane);
     epilogue_dgrad<false, false>(acc, n_base, mw, Y, skip, lane, poff);
     __syncthreads();
     store_tile<NT>(a.dz[1], p0, a.P, Y, tid);
     // L1: dz1 (Y) + g13 -> dz0 (X)
     fetch_mask(mw, a.mask[1], p0, a.P, wave, lane, poff);
-    layer_mma(acc, a.Wt[1], 16, 2 * wave, 0, 16, Y, lane, true, poff);
+    layer_main(acc, wf, a.Wt[1], 16, 2 * wave, 0, 16, Y, lane, true, poff);
     epilogue_dgrad<false, true>(acc, n_base, mw, X, skip, lane, poff);
     __syncthreads();
     store_tile<NT>(a.dz[0], p0, a.P, X, tid);
