@@ -95,13 +95,19 @@ __global__ __launch_bounds__(256) void segment_stats_kernel(int64_t n_pix, int c
             const unsigned long long grp = __ballot(id == cur);
             const bool in = id == cur;
             if (cb == 0 && lane == leader) atomicAdd(&cnt[cur], (int)__popcll(grp));
+            const double ng = (double)__popcll(grp);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const float v = in ? xv[j] : 0.f;
+                // moments of the group about one of its OWN values (the leader's): the fp32 wave sums then carry the
+                // spread, not the mean, and the shift goes back in double -- sum x^2 - (sum x)^2 / n used to cancel in fp32
+                // rounding once a region's variance fell below ~1e-7 mean^2, which is where this loss drives it
+                const float sft = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv[j]), leader));
+                const float v = in ? xv[j] - sft : 0.f;
                 const float a = seg_wave_sum(v), b = seg_wave_sum(v * v);
                 if (lane == leader && cb + j < c) {
-                    atomicAdd(&s1[(size_t)cur * c + cb + j], (double)a);
-                    atomicAdd(&s2[(size_t)cur * c + cb + j], (double)b);
+                    const double sd = (double)sft, ad = (double)a;
+                    atomicAdd(&s1[(size_t)cur * c + cb + j], ad + ng * sd);
+                    atomicAdd(&s2[(size_t)cur * c + cb + j], (double)b + 2.0 * sd * ad + ng * sd * sd);
                 }
             }
             todo &= ~grp;

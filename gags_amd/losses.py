@@ -120,7 +120,9 @@ class _RegionVar(torch.autograd.Function):
         ok = cnt >= 2  # segments of 0 or 1 pixels are skipped (loss_utils.py:124-125)
         nn = torch.where(ok, n, torch.full_like(n, 2.0))
         mean = s1 / nn[:, None]
-        var = (s2 - nn[:, None] * mean * mean) / (nn[:, None] - 1.0)  # unbiased, as torch.var
+        # unbiased, as torch.var; the moments are accumulated in double about a member of each group (csrc/losses.hip), so the
+        # subtraction below is a double-precision one on accurately summed terms -- and a variance is never negative
+        var = ((s2 - nn[:, None] * mean * mean) / (nn[:, None] - 1.0)).clamp_min(0.0)
         per_seg = torch.where(ok, nn * var.mean(dim=1), torch.zeros_like(nn))
         loss = per_seg.sum() / (hh * ww)
         coef = torch.where(ok, 2.0 * nn / ((nn - 1.0) * c * hh * ww), torch.zeros_like(nn))
