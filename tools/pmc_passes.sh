@@ -20,6 +20,7 @@ SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_I
 FETCH_SIZE TCC_ATOMIC
 WRITE_SIZE TCC_HIT TCC_MISS
 TCC_EA0_RDREQ TCC_EA0_WRREQ TCC_EA0_ATOMIC TCC_REQ
+SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_F16
 LIST
 python "$R/tools/pmc_summary.py" "$OUT" "${PMC_KERNELS:-raster_|rs_|project|tile_|scan_|reduce_rows|gather_grec|make_grec|seg_|slot_rows|dot_}" "$OUT/traffic.json" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
