@@ -39,6 +39,18 @@ GRAD_ROWS_HOOK = None
 MAX_ISECTS = 1 << 27  # limit of the C ABI (int32 slot indices: 4 slots per intersection)
 
 
+ZERO_FILL_MIN_ELEMS = 1 << 24  # (below that the second stream's hand-over costs more than the zeros)
+OVERLAP_ZERO_FILL = True  # staged backward: zero-fill of the gradient on a second stream, sparse reduce (see _backward_staged)
+_SIDE = {}
+
+
+def _side_stream(dev):
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -365,6 +377,26 @@ def _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d,
               "gags_raster_bwd_colors_staged")
 
     hook = GRAD_RANGE_HOOK
+    if hook is None and OVERLAP_ZERO_FILL and rows > 0 and n * d >= ZERO_FILL_MIN_ELEMS:
+        # 73 % of the Gaussians blend nothing at C3: their rows of the gradient are zeros.  Fill the tensor on a second
+        # stream while the rows kernel (matrix / VALU-bound: the memory system has room) runs, and let the reduce stage
+        # write only the rows that exist: 3.07 GB -> 0.83 GB written by it.
+        side = _side_stream(dev)
+        ev0, ev1 = torch.cuda.Event(), torch.cuda.Event()
+        ev0.record()
+        with torch.cuda.stream(side):
+            side.wait_event(ev0)
+            v_colors.zero_()
+            ev1.record()
+        v_colors.record_stream(side)
+        for stage, name in ((1, "bwd_rows"), (2, "bwd_sort")):
+            with profiler.stage(name):
+                run(stage)
+        torch.cuda.current_stream().wait_event(ev1)
+        with profiler.stage("bwd_reduce"):
+            run(3 | 128)
+        profiler.note("bwd_rows", rows)
+        return v_colors
     if hook is not None and d % GRAD_RANGE_CHANNELS == 0 and d > GRAD_RANGE_CHANNELS:
         alias = v_colors.detach()  # own TensorImpl, same storage: autograd may still adopt v_colors without a copy
         for c0 in range(0, d, GRAD_RANGE_CHANNELS):

@@ -127,9 +127,10 @@ int gags_pack_isects(int n, int64_t n_isects, const int32_t *flatten_ids, const 
  * colors[N,D] / backgrounds[D] (gaussian_renderer/__init__.py:61,64).
  * backgrounds may be NULL.  Outputs render_colors[H,W,D], render_alphas[H,W],
  * last_ids[H,W] (sorted index of the last blended Gaussian per pixel).
- * Kernel choice: with `packed` given, D >= 16 and D % 4 == 0 runs on the matrix cores as the split
- * weights + feature passes when `scratch` (gags_raster_fwd_scratch_bytes) and `blk_rows`
- * ([tile_h*tile_w*4] int32, written: slots per 8x8 pixel block) are provided, else as one fused kernel; anything else runs the
+ * Kernel choice: with `packed` given, any D >= 16 runs on the matrix cores as the split weights + feature passes
+ * (128-channel slices, then 64, then 32-channel slices, the last one ragged; D = 513 is four wide slices and one lane of a
+ * narrow one) when `scratch` (gags_raster_fwd_scratch_bytes) and `blk_rows` ([tile_h*tile_w*4] int32, written: slots per
+ * 8x8 pixel block) are provided, else (D % 32 == 0) as one fused kernel; anything else runs the
  * VALU kernels.  The scratch and blk_rows of a split forward are what
  * gags_raster_bwd_colors_staged consumes, so keep them alive until the backward. */
 int64_t gags_raster_fwd_scratch_bytes(int64_t n_isects, int width, int height);
@@ -154,8 +155,8 @@ int gags_raster_bwd(int d, int width, int height, const float *means2d, const fl
                     float *v_colors, float *v_opacities, float *v_means2d, float *v_conics,
                     int flags, void *stream);
 
-/* K10, staged flavour: colours-only backward WITHOUT atomics (deterministic), 16 <= D <= 1024,
- * D % 4 == 0.  Consumes the scratch + blk_rows of a split gags_raster_fwd.
+/* K10, staged flavour: colours-only backward WITHOUT atomics (deterministic), 16 <= D <= 1024 (any such D).
+ * Consumes the scratch + blk_rows of a split gags_raster_fwd.
  *
  * gags_bwd_rowmap: numbers the (tile, Gaussian) pairs that blended into at least one pixel -- one partial
  * gradient row each -- in sorted order: rowmap[0 .. n_isects] = exclusive prefix sum of the hit flags the
@@ -166,11 +167,14 @@ int gags_raster_bwd(int d, int width, int height, const float *means2d, const fl
  * gags_raster_bwd_colors_staged: per tile the four pixel blocks' partial rows are merged on chip and stored
  * once per (tile, Gaussian), the rows are sorted by Gaussian and reduced; v_colors[N,D] is written in full
  * (no zero-fill needed).  scratch: gags_bwd_staged_scratch_bytes(rows, n, d) bytes.
- * stage: low 4 bits 0 = all, 1..3 = rows, sort, reduce (per-kernel timing); bit 5 (32), D % 128 == 0 only, opt-in: the
- * rows' contraction runs on the 16-bit matrix cores with both operands split into an fp16 head and tail (~2^-21
- * relative to a column's largest term instead of fp32 rounding; still atomic-free and bit-reproducible);
+ * stage: low 4 bits 0 = all, 1..3 = rows, sort, reduce (per-kernel timing, overlap of the zero-fill below).
+ * The rows' contraction (128-channel slices) runs on the 16-bit matrix cores with fp32-equivalent split operands: weights
+ * as three fp16 terms (exact), cotangent as two (one fp32 rounding), five MFMA terms per product, fp32 accumulation;
+ * atomic-free and bit-reproducible.  bit 5 (32): the fp32 matrix instructions instead (rounds 1-2's kernel).
  * bit 6 (64): v_colors points to an fp16 [N,D] tensor (the gradient of an fp16 feature table in the table's dtype;
  * sums are formed in fp32 and rounded once).
+ * bit 7 (128): v_colors arrives ZERO-FILLED and the reduce stage skips the Gaussians that blended nothing (73 % at C3)
+ * instead of writing their rows of zeros -- the caller fills it on a second stream while the rows stage runs.
  * Returns 1 when D is not eligible. */
 int64_t gags_bwd_rowmap_elems(int64_t n_isects, int width, int height);
 int64_t gags_bwd_rowmap_scratch_bytes(int64_t n_isects);

@@ -335,6 +335,33 @@ def test_backward_kernels_on_both_matrix_pipes_are_within_tolerance(oracle):
     assert np.median(rown) <= 1.5 * np.median(rowf) + 1e-9 and np.quantile(rown, 0.999) <= 2.0 * np.quantile(rowf, 0.999) + 1e-9
 
 
+def test_sparse_reduce_with_overlapped_zero_fill_is_bit_identical(oracle):
+    """The staged backward zero-fills the gradient on a second stream while the rows kernel runs and lets the reduce stage
+    skip the Gaussians that blended nothing (gags_raster_bwd_colors_staged stage bit 128): same bits as the dense reduce,
+    every culled / unblended row exactly zero, for fp32 and fp16 gradients and an odd width."""
+    from gags_amd import rasterization as R
+    for d, half in ((256, False), (513, False), (128, True)):
+        n, w, h = 5000, 176, 130
+        s = scene_arrays(n, d, w, h, seed=33, view=3, scale_mult=5.0)
+        v_out = np.random.default_rng(11).standard_normal((h, w, d)).astype(np.float32)
+        res = []
+        for overlap in (True, False):
+            R.OVERLAP_ZERO_FILL, old_min = overlap, R.ZERO_FILL_MIN_ELEMS
+            R.ZERO_FILL_MIN_ELEMS = 0
+            try:
+                cols = torch.from_numpy(s["colors"]).cuda()
+                cols = (cols.half() if half else cols).requires_grad_(True)
+                out, _, info = R.rasterization(to_dev(s["means"]), to_dev(s["quats"]), to_dev(s["scales"]), to_dev(s["opacities"]),
+                                               cols, to_dev(s["viewmat"])[None], to_dev(s["K"])[None], w, h)
+                (out[0] * to_dev(v_out)).sum().backward()
+                torch.cuda.synchronize()
+                res.append(cols.grad.clone())
+            finally:
+                R.OVERLAP_ZERO_FILL, R.ZERO_FILL_MIN_ELEMS = True, old_min
+        assert torch.equal(res[0], res[1]), (d, half)
+        assert bool((res[0][info["radii"][0] == 0] == 0).all())
+
+
 def test_backward_by_channel_ranges_is_bit_identical(oracle):
     """The by-view multi-GPU step asks the staged backward for the gradient one 128-channel range at a time
     (rasterization.GRAD_RANGE_HOOK, gags_amd/dist.py): same kernels on a sub-range, so the same bits as the one-shot
