@@ -40,7 +40,7 @@ MAX_ISECTS = 1 << 27  # limit of the C ABI (int32 slot indices: 4 slots per inte
 
 
 ZERO_FILL_MIN_ELEMS = 1 << 24  # (below that the second stream's hand-over costs more than the zeros)
-OVERLAP_ZERO_FILL = True  # staged backward: zero-fill of the gradient on a second stream, sparse reduce (see _backward_staged)
+OVERLAP_ZERO_FILL = True  # the colour gradient is zero-filled on a second stream during the forward's binning; sparse reduce
 _SIDE = {}
 
 
@@ -219,7 +219,7 @@ class _Rasterize(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, packed, width, height,
-                flags):
+                flags, prezero=None):
         lib = _lib.load()
         means2d, conics, opacities = _c(means2d), _c(conics), _c(opacities)
         # an fp16 feature table (BASELINE.json configs[4]) is read as it is by the matrix-core feature pass: widened
@@ -266,6 +266,7 @@ class _Rasterize(torch.autograd.Function):
                               last_ids, scratch if staged else None, blk_rows if staged else None)
         ctx.cfg = (width, height, flags)
         ctx.half = half
+        ctx.prezero = prezero if staged else None
         ctx.mark_non_differentiable(last_ids)
         return out, alphas, last_ids
 
@@ -289,8 +290,8 @@ class _Rasterize(torch.autograd.Function):
             # tensor + cast pass (autograd wants the table's dtype; an fp32 master sits behind a .half() cast)
             v_colors = _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height,
                                         (32 if (flags & _lib.GAGS_BWD_F32MFMA) else 0) | (64 if ctx.half else 0),
-                                        flatten_ids)
-            return None, None, v_colors, None, v_bg, None, None, None, None, None, None
+                                        flatten_ids, ctx.prezero)
+            return None, None, v_colors, None, v_bg, None, None, None, None, None, None, None
         if need_geom and blk_rows is not None and ctx.geom_mfma:
             # wide D: colours through the staged backward, geometry through the matrix-core dot pass + scalar pass
             v_colors = None
@@ -315,7 +316,7 @@ class _Rasterize(torch.autograd.Function):
                                                ptr(row_base), n_rows, _lib.GAGS_RECS_BY_GAUSSIAN, _stream()),
                       "gags_raster_bwd_geom")
             v_con, v_m2d, v_opac = v_geo[:, 0:3].contiguous(), v_geo[:, 3:5].contiguous(), v_geo[:, 5].contiguous()
-            return v_m2d, v_con, v_colors, v_opac, v_bg, None, None, None, None, None, None
+            return v_m2d, v_con, v_colors, v_opac, v_bg, None, None, None, None, None, None, None
         if ctx.half:  # VALU / atomic kernels read an fp32 table: widen the halves (exact); gradient returned in the table's dtype
             colors = colors.float()
         v_colors = torch.zeros(n, d, device=dev)
@@ -334,7 +335,7 @@ class _Rasterize(torch.autograd.Function):
                                       ptr(v_opac), ptr(v_m2d), ptr(v_con), bflags, _stream()), "gags_raster_bwd")
         if ctx.half:
             v_colors = v_colors.half()
-        return v_m2d, v_con, v_colors, v_opac, v_bg, None, None, None, None, None, None
+        return v_m2d, v_con, v_colors, v_opac, v_bg, None, None, None, None, None, None, None
 
 
 def _geom_mfma_width(d):
@@ -343,7 +344,7 @@ def _geom_mfma_width(d):
 
 
 def _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height, xflag=0,
-                     flatten_ids=None):
+                     flatten_ids=None, prezero=None):
     """Colours-only backward without atomics: hit flags of the forward -> prefix sum (one row per (tile, Gaussian)
     pair that blended anything) -> one 4-byte readback (total rows) -> merged partial rows -> sort by Gaussian ->
     segmented sum."""
@@ -377,26 +378,16 @@ def _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d,
               "gags_raster_bwd_colors_staged")
 
     hook = GRAD_RANGE_HOOK
-    if hook is None and OVERLAP_ZERO_FILL and rows > 0 and n * d >= ZERO_FILL_MIN_ELEMS:
-        # 73 % of the Gaussians blend nothing at C3: their rows of the gradient are zeros.  Fill the tensor on a second
-        # stream while the rows kernel (matrix / VALU-bound: the memory system has room) runs, and let the reduce stage
-        # write only the rows that exist: 3.07 GB -> 0.83 GB written by it.
-        side = _side_stream(dev)
-        ev0, ev1 = torch.cuda.Event(), torch.cuda.Event()
-        ev0.record()
-        with torch.cuda.stream(side):
-            side.wait_event(ev0)
-            v_colors.zero_()
-            ev1.record()
-        v_colors.record_stream(side)
-        for stage, name in ((1, "bwd_rows"), (2, "bwd_sort")):
-            with profiler.stage(name):
-                run(stage)
-        torch.cuda.current_stream().wait_event(ev1)
-        with profiler.stage("bwd_reduce"):
-            run(3 | 128)
-        profiler.note("bwd_rows", rows)
-        return v_colors
+    if prezero is not None and hook is None:
+        # the forward started a zero-fill of this tensor on a second stream while the binning kernels (small, latency-bound:
+        # the memory system idles) ran; the reduce stage then writes only the rows that exist -- 73 % of the Gaussians
+        # blend nothing at C3: 3.07 GB -> 0.83 GB written here.  (Filled under the rows kernel instead, the fill slowed
+        # that kernel by as much as the reduce stage gained.)
+        buf, ev = prezero
+        if buf.shape == v_colors.shape and buf.dtype == v_colors.dtype:
+            torch.cuda.current_stream().wait_event(ev)
+            v_colors = buf
+            xflag |= 128
     if hook is not None and d % GRAD_RANGE_CHANNELS == 0 and d > GRAD_RANGE_CHANNELS:
         alias = v_colors.detach()  # own TensorImpl, same storage: autograd may still adopt v_colors without a copy
         for c0 in range(0, d, GRAD_RANGE_CHANNELS):
@@ -467,6 +458,25 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
         cols = depths[:, None]
         bg = None if bg is None else torch.zeros(1, device=bg.device)
 
+    prezero = None
+    dz = cols.shape[-1]
+    if (OVERLAP_ZERO_FILL and GRAD_RANGE_HOOK is None and torch.is_grad_enabled() and cols.requires_grad and _mfma_width(dz)
+            and dz <= 1024 and n * dz >= ZERO_FILL_MIN_ELEMS and not (raster_flags & (_lib.GAGS_BWD_ATOMIC | _lib.GAGS_FWD_NO_MFMA
+                                                                                      | _lib.GAGS_FWD_FUSED))
+            and not (means.requires_grad or quats.requires_grad or scales.requires_grad or opacities.requires_grad)):
+        # colours-only (GAD) backward ahead: its gradient tensor is mostly rows of zeros.  Fill it now, on a second stream,
+        # under the binning kernels; the backward's reduce stage then writes only the rows that exist (_backward_staged)
+        vbuf = torch.empty(n, dz, device=cols.device, dtype=torch.float16 if cols.dtype == torch.float16 else torch.float32)
+        side = _side_stream(cols.device)
+        ev0, ev1 = torch.cuda.Event(), torch.cuda.Event()
+        ev0.record()
+        with torch.cuda.stream(side):
+            side.wait_event(ev0)
+            vbuf.zero_()
+            ev1.record()
+        vbuf.record_stream(side)
+        prezero = (vbuf, ev1)
+
     with torch.no_grad(), profiler.stage("binning"):
         dcols = cols.shape[-1]
         wide = _mfma_width(dcols)  # the matrix-core path wants packed records
@@ -476,7 +486,7 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
     # any width in ONE rasterization: 513 = 512 CLIP channels + 1 (BASELINE.json configs[4] "512-d feat + granularity") is
     # four 128-channel slices and one lane of a narrow slice on the same matrix-core kernels, into one output tensor
     out, alphas, last_ids = _Rasterize.apply(means2d, conics, cols, opacities, bg, isect_offsets, flatten_ids,
-                                             packed, width, height, int(raster_flags))
+                                             packed, width, height, int(raster_flags), prezero)
     if render_mode in ("ED", "RGB+ED"):
         if out.requires_grad:
             out = torch.cat([out[..., :-1], out[..., -1:] / alphas[..., None].clamp(min=1e-10)], dim=-1)
