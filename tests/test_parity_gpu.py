@@ -336,8 +336,8 @@ def test_backward_kernels_on_both_matrix_pipes_are_within_tolerance(oracle):
 
 
 def test_sparse_reduce_with_overlapped_zero_fill_is_bit_identical(oracle):
-    """The staged backward zero-fills the gradient on a second stream while the rows kernel runs and lets the reduce stage
-    skip the Gaussians that blended nothing (gags_raster_bwd_colors_staged stage bit 128): same bits as the dense reduce,
+    """Stage bit 128 of gags_raster_bwd_colors_staged (the gradient arrives zero-filled -- here by the opt-in overlap of
+    gags_amd.rasterization.OVERLAP_ZERO_FILL -- and the reduce stage skips the Gaussians that blended nothing): same bits as the dense reduce,
     every culled / unblended row exactly zero, for fp32 and fp16 gradients and an odd width."""
     from gags_amd import rasterization as R
     for d, half in ((256, False), (513, False), (128, True)):
@@ -357,7 +357,7 @@ def test_sparse_reduce_with_overlapped_zero_fill_is_bit_identical(oracle):
                 torch.cuda.synchronize()
                 res.append(cols.grad.clone())
             finally:
-                R.OVERLAP_ZERO_FILL, R.ZERO_FILL_MIN_ELEMS = True, old_min
+                R.OVERLAP_ZERO_FILL, R.ZERO_FILL_MIN_ELEMS = False, old_min
         assert torch.equal(res[0], res[1]), (d, half)
         assert bool((res[0][info["radii"][0] == 0] == 0).all())
 
