@@ -206,7 +206,7 @@ def test_fp16_table_on_the_16bit_matrix_cores(oracle):
     assert rel_l2(res[0][1], o_vf) <= 5e-4                # gradient returned in fp16
 
 
-@pytest.mark.parametrize("d", [17, 37, 130, 197, 513])
+@pytest.mark.parametrize("d", [17, 37, 72, 130, 197, 200, 513, 1000, 1024])
 def test_width_with_extra_channels(oracle, d):
     """Any D >= 16 is ONE rasterization on the matrix cores (513 = 512 CLIP channels + 1, BASELINE.json configs[4]): 128-
     channel slices, then 64, then 32-channel slices with a ragged last one; rows of an odd width are only 4-byte
