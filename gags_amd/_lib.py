@@ -33,6 +33,7 @@ SIGNATURES = {
     "gags_depth_order_scratch_bytes": (_i64, [_i32]),
     "gags_depth_order": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "gags_tile_emit": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "gags_tile_emit_cap": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),
     "gags_sort_scratch_bytes": (_i64, [_i64]),
     "gags_sort_pairs": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "gags_tile_offsets": (_i32, [_i64, _vp, _i32, _vp, _vp]),
@@ -54,6 +55,8 @@ SIGNATURES = {
                                              _i64, _vp, _i32, _vp]),
     "gags_raster_bwd_colors_staged_range": (_i32, [_i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
                                                    _i64, _vp, _i32, _i32, _i32, _vp]),
+    "gags_raster_bwd_colors_staged_cap": (_i32, [_i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
+                                                 _i64, _vp, _i32, _i32, _i32, _vp, _vp]),
     "gags_raster_stats": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "gags_project_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _vp, _vp]),

@@ -11,7 +11,7 @@ __global__ __launch_bounds__(256) void tile_emit_kernel(int n, const float *__re
                                                         const int32_t *__restrict__ cum,
                                                         const int32_t *__restrict__ order, int tile_w, int tile_h,
                                                         int64_t *__restrict__ isect_ids,
-                                                        int32_t *__restrict__ flatten_ids)
+                                                        int32_t *__restrict__ flatten_ids, int64_t cap)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;  // position in the emission order
     if (j >= n) return;
@@ -26,10 +26,23 @@ __global__ __launch_bounds__(256) void tile_emit_kernel(int n, const float *__re
     for (int ty = y0; ty < y1; ++ty)
         for (int tx = x0; tx < x1; ++tx) {
             const int64_t tile_id = (int64_t)ty * tile_w + tx;
-            isect_ids[cur] = (tile_id << 32) | dbits;
-            flatten_ids[cur] = i;
+            if (cur < cap) {  // (capacity-sized buffers: a count above the capacity is detected by the caller afterwards)
+                isect_ids[cur] = (tile_id << 32) | dbits;
+                flatten_ids[cur] = i;
+            }
             ++cur;
         }
+}
+
+// capacity-sized buffers: entries [total, cap) become sentinels of a tile past the last one (they sort to the end and
+// give isect_offsets its final entry = the true count) pointing at Gaussian 0 (never read: no tile's range holds them)
+__global__ __launch_bounds__(256) void isect_tail_kernel(int64_t cap, const int32_t *__restrict__ total, int n_tiles,
+                                                         int64_t *__restrict__ isect_ids, int32_t *__restrict__ flatten_ids)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= cap || i < (int64_t)total[0]) return;
+    isect_ids[i] = (int64_t)n_tiles << 32;
+    flatten_ids[i] = 0;
 }
 
 __global__ __launch_bounds__(256) void tile_offsets_kernel(int64_t n_isects, const int64_t *__restrict__ sorted_ids,
@@ -64,7 +77,7 @@ __global__ __launch_bounds__(256) void ed_normalize_kernel(int64_t n_pix, int d,
 
 }  // namespace
 
-extern "C" int gags_abi_version(void) { return 1; }
+extern "C" int gags_abi_version(void) { return 2; }  // 2: isect_offsets has n_tiles + 1 entries (the last one = n_isects)
 
 extern "C" const char *gags_strerror(int code)
 {
@@ -119,18 +132,32 @@ extern "C" int gags_read_i32(const int32_t *src, int32_t *dst_host, void *stream
     return GAGS_OK;
 }
 
+extern "C" int gags_tile_emit_cap(int n, const float *means2d, const int32_t *radii, const float *depths, const int32_t *cum,
+                                  const int32_t *order, int tile_w, int tile_h, int64_t *isect_ids, int32_t *flatten_ids,
+                                  int64_t cap, const int32_t *total, void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (n < 0 || tile_w <= 0 || tile_h <= 0 || cap < 0 || cap >= (1ll << 31)) return GAGS_EINVAL;
+    if (n == 0 && cap == 0) return GAGS_OK;
+    if (!isect_ids || !flatten_ids || (n > 0 && (!means2d || !radii || !depths || !cum))) return GAGS_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (n > 0)
+        hipLaunchKernelGGL(tile_emit_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, means2d, radii, depths, cum, order, tile_w,
+                           tile_h, isect_ids, flatten_ids, cap);
+    if (total && cap > 0)
+        hipLaunchKernelGGL(isect_tail_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, st, cap, total, tile_w * tile_h,
+                           isect_ids, flatten_ids);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
 extern "C" int gags_tile_emit(int n, const float *means2d, const int32_t *radii, const float *depths,
                               const int32_t *cum, const int32_t *order, int tile_w, int tile_h, int64_t *isect_ids,
                               int32_t *flatten_ids, void *stream)
 {
-    GAGS_CLEAR_ERR();
-    if (n < 0 || tile_w <= 0 || tile_h <= 0) return GAGS_EINVAL;
     if (n == 0) return GAGS_OK;
-    if (!means2d || !radii || !depths || !cum || !isect_ids || !flatten_ids) return GAGS_EINVAL;
-    hipLaunchKernelGGL(tile_emit_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, means2d,
-                       radii, depths, cum, order, tile_w, tile_h, isect_ids, flatten_ids);
-    GAGS_CHECK_LAUNCH();
-    return GAGS_OK;
+    return gags_tile_emit_cap(n, means2d, radii, depths, cum, order, tile_w, tile_h, isect_ids, flatten_ids, (1ll << 31) - 1, nullptr,
+                              stream);
 }
 
 extern "C" int gags_tile_offsets(int64_t n_isects, const int64_t *sorted_ids, int n_tiles, int32_t *isect_offsets,
@@ -139,14 +166,16 @@ extern "C" int gags_tile_offsets(int64_t n_isects, const int64_t *sorted_ids, in
     GAGS_CLEAR_ERR();
     if (n_isects < 0 || n_tiles <= 0 || !isect_offsets) return GAGS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    // n_tiles + 1 entries: [n_tiles] = the intersection count (with capacity-sized inputs: where the sentinel keys of
+    // tile `n_tiles` begin), so that no raster kernel needs the count from the host
     if (n_isects == 0) {
-        hipLaunchKernelGGL(fill_i32_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, st, n_tiles, 0, isect_offsets);
+        hipLaunchKernelGGL(fill_i32_kernel, dim3((n_tiles + 1 + 255) / 256), dim3(256), 0, st, n_tiles + 1, 0, isect_offsets);
         GAGS_CHECK_LAUNCH();
         return GAGS_OK;
     }
     if (!sorted_ids) return GAGS_EINVAL;
     hipLaunchKernelGGL(tile_offsets_kernel, dim3((unsigned)((n_isects + 255) / 256)), dim3(256), 0, st, n_isects,
-                       sorted_ids, n_tiles, isect_offsets);
+                       sorted_ids, n_tiles + 1, isect_offsets);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void rast
     const float *__restrict__ v_render_colors, const int32_t *__restrict__ offsets, int n_isects,
     const int32_t *__restrict__ blk_rows, const int32_t *__restrict__ trow, const float *__restrict__ wt,
     const int32_t *__restrict__ gid_s, const int32_t *__restrict__ trow_s, float *__restrict__ prow,
-    uint32_t *__restrict__ row_key, int32_t *__restrict__ row_idx)
+    uint32_t *__restrict__ row_key, int32_t *__restrict__ row_idx, int rows_cap)
 {
     constexpr int CW = 32 * NBR;  // channels per slice; this launch covers channels ch_base .. ch_base + n_slices * CW - 1 (clipped to d)
     constexpr int C4 = CW / 4;    // float4 columns per row of the slice
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void rast
     const int logical = gags_xcd_remap(blockIdx.x, n_tiles * n_slices);
     const int tile = gags_tile_of_order(logical / n_slices, tile_w, n_tiles / tile_w);
     const int start = offsets[tile];
-    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+    const int end = offsets[tile + 1]  /* n_tiles + 1 entries: the last one is the intersection count */;
     const int R0 = trow[start], R1 = trow[end];
     if (R1 == R0) return;  // nothing blended in this tile (uniform over the workgroup)
     const int blk = wave;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void rast
 #pragma unroll
                 for (int j = 0; j < NBR; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[t], V[t][j], acc[j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (mine && ch0 == 0) {  // row -> Gaussian map for the sort (every block of the row stores the same pair)
+            if (mine && ch0 == 0 && tr_c < rows_cap) {  // row -> Gaussian map for the sort (every block of the row stores the same pair)
                 row_key[tr_c] = (uint32_t)gid_c;
                 row_idx[tr_c] = tr_c;
             }
@@ -235,7 +235,10 @@ __global__ __launch_bounds__(256, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void rast
                 sum.x = ((v[0].x + v[1].x) + v[2].x) + v[3].x; sum.y = ((v[0].y + v[1].y) + v[2].y) + v[3].y;
                 sum.z = ((v[0].z + v[1].z) + v[2].z) + v[3].z; sum.w = ((v[0].w + v[1].w) + v[2].w) + v[3].w;
                 float *dst = prow + (size_t)(r0 + row) * d + ch0 + 4 * c4;
-                if (NBR != 1 || ch0 + 4 * c4 + 3 < d) {
+                if (r0 + row >= rows_cap) {
+                    // (capacity-sized scratch and more rows than it holds: nothing is stored; the caller sees the count
+                    // afterwards and runs the backward again with the right size)
+                } else if (NBR != 1 || ch0 + 4 * c4 + 3 < d) {
                     *reinterpret_cast<float4 *>(dst) = sum;
                 } else {  // ragged last slice (D % 32 != 0), possibly D % 4 != 0: never store past the row
                     const float sv[4] = {sum.x, sum.y, sum.z, sum.w};
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
     const float *__restrict__ v_render_colors, const int32_t *__restrict__ offsets, int n_isects,
     const int32_t *__restrict__ blk_rows, const int32_t *__restrict__ trow, const float *__restrict__ wt,
     const int32_t *__restrict__ gid_s, const int32_t *__restrict__ trow_s, float *__restrict__ prow,
-    uint32_t *__restrict__ row_key, int32_t *__restrict__ row_idx)
+    uint32_t *__restrict__ row_key, int32_t *__restrict__ row_idx, int rows_cap)
 {
     constexpr int NBR = 4, CW = 128, C4 = 32;
     __shared__ __attribute__((aligned(16))) float stage[4][32][CW];
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
     const int logical = gags_xcd_remap(blockIdx.x, n_tiles * n_slices);
     const int tile = gags_tile_of_order(logical / n_slices, tile_w, n_tiles / tile_w);
     const int start = offsets[tile];
-    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+    const int end = offsets[tile + 1]  /* n_tiles + 1 entries: the last one is the intersection count */;
     const int R0 = trow[start], R1 = trow[end];
     if (R1 == R0) return;
     const int blk = wave;
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
                 __builtin_amdgcn_sched_barrier(0);  // one K-step's terms at a time (hoisted together they spill)
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (mine && ch0 == 0) {
+            if (mine && ch0 == 0 && tr_c < rows_cap) {
                 row_key[tr_c] = (uint32_t)gid_c;
                 row_idx[tr_c] = tr_c;
             }
@@ -478,13 +481,24 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
                 float4 sum;
                 sum.x = ((v[0].x + v[1].x) + v[2].x) + v[3].x; sum.y = ((v[0].y + v[1].y) + v[2].y) + v[3].y;
                 sum.z = ((v[0].z + v[1].z) + v[2].z) + v[3].z; sum.w = ((v[0].w + v[1].w) + v[2].w) + v[3].w;
-                *reinterpret_cast<float4 *>(prow + (size_t)(r0 + row) * d + ch0 + 4 * c4) = sum;
+                if (r0 + row < rows_cap) *reinterpret_cast<float4 *>(prow + (size_t)(r0 + row) * d + ch0 + 4 * c4) = sum;
             }
             if (trip & 1) __builtin_amdgcn_sched_barrier(0);
         }
         pb = pbn;
         r0 = r1;
     }
+}
+
+// capacity-sized row buffers: keys [total, cap) become sentinels (key n_gauss: past every Gaussian), so that the sort and
+// the segment offsets can run over the capacity without the host knowing the row count
+__global__ __launch_bounds__(256) void row_tail_kernel(int64_t cap, const int32_t *__restrict__ total, int n_gauss,
+                                                       uint32_t *__restrict__ row_key, int32_t *__restrict__ row_idx)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= cap || i < (int64_t)total[0]) return;
+    row_key[i] = (uint32_t)n_gauss;
+    row_idx[i] = 0;
 }
 
 // trow_s[slot] = tile row of the slot's intersection (0x7fffffff for the pad slot of an odd count): one coalesced
@@ -497,7 +511,7 @@ __global__ __launch_bounds__(64) void slot_rows_kernel(int n_tiles, int n_isects
     const int tile = blockIdx.x >> 2, blk = blockIdx.x & 3;
     const int cnt = blk_rows[blockIdx.x];
     const int start = offsets[tile];
-    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+    const int end = offsets[tile + 1]  /* n_tiles + 1 entries: the last one is the intersection count */;
     const int sb = gags_slot_base(start, end, tile, blk);
     for (int j = threadIdx.x; j < cnt; j += 64) {
         const int sx = sidx_s[sb + j];
@@ -604,7 +618,7 @@ __global__ __launch_bounds__(64, 2) void raster_bwd_atomic(
     g.init(tile, blk, tile_w, width, height, lane);
     const int p = g.p, k = g.k;
     const int start = offsets[tile];
-    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+    const int end = offsets[tile + 1]  /* n_tiles + 1 entries: the last one is the intersection count */;
 
     float V[16][NBB];
     load_slab(V, v_render_colors, g, width, height, d, ch0);
@@ -729,7 +743,7 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
                                   const float *v_out, const int32_t *blk_rows, const int32_t *trow, int64_t rows,
                                   const float *wt, const int32_t *gid_s, const int32_t *trow_s, void *scratch,
                                   int64_t scratch_bytes, float *v_colors, int stage_flags, int ch_begin, int ch_count,
-                                  hipStream_t st)
+                                  const int32_t *rows_dev, hipStream_t st)
 {
     // stage: 0 = everything; 1 = rows, 2 = sort + segment offsets, 3 = reduce (per-kernel timing)
     GAGS_CLEAR_ERR();
@@ -754,7 +768,7 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
             // 128-channel slices, then 64, then 32-channel slices (the last one ragged when the range ends at an odd d)
 #define GAGS_ROWS_LAUNCH(KERNEL, CH0, NSL)                                                                           \
     hipLaunchKernelGGL(KERNEL, dim3(n_tiles * (NSL)), dim3(256), 0, st, d, width, height, tile_w, n_tiles, (CH0), (NSL), \
-                       v_out, offsets, n_isects, blk_rows, trow, wt, gid_s, trow_s, prow, key, idx)
+                       v_out, offsets, n_isects, blk_rows, trow, wt, gid_s, trow_s, prow, key, idx, (int)rows)
             int c = ch_begin;
             const int ce = ch_begin + ch_count;
             if (ce - c >= 128) {
@@ -771,6 +785,10 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
 #undef GAGS_ROWS_LAUNCH
         }
         if (sS) {
+            // rows is a CAPACITY when rows_dev is given (the true count lives on the device): sentinel keys past it
+            if (rows_dev)
+                hipLaunchKernelGGL(row_tail_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, rows, rows_dev, n_gauss, key,
+                                   idx);
             int nbits = 1;
             while ((1ll << nbits) <= n_gauss) ++nbits;  // keys in [0, n_gauss]
             const int rc = gags_sort_pairs_u32(rows, nbits, key, idx, key_s, idx_s, sb + L.sort, L.prow - L.sort, st);
@@ -835,7 +853,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_sdot(int d, int ch0, int dc
     const int cnt = blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk];
     if (cnt == 0) return;
     const int start = offsets[tile];
-    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+    const int end = offsets[tile + 1]  /* n_tiles + 1 entries: the last one is the intersection count */;
     const int sb = gags_slot_base(start, end, tile, blk);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pitch = dch + SD_PAD;
@@ -970,7 +988,7 @@ __global__ __launch_bounds__(64) void raster_bwd_geom(int width, int height, int
     const int cnt = blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk];
     if (cnt == 0) return;
     const int start = offsets[tile];
-    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+    const int end = offsets[tile + 1]  /* n_tiles + 1 entries: the last one is the intersection count */;
     const int sb = gags_slot_base(start, end, tile, blk);
     // row of slot j: compact numbering (row_base = exclusive prefix sum of blk_rows) or the sparse slot index itself
     const int rb = row_base ? row_base[tile * GAGS_BLOCKS_PER_TILE + blk] : sb;

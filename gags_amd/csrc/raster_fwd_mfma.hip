@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64, 2) void raster_fwd_feat(
     g.init(tile, blk, tile_w, width, height, lane);
     const int p = g.p, k = g.k;
     const int start = offsets[tile];
-    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+    const int end = offsets[tile + 1]  /* n_tiles + 1 entries: the last one is the intersection count */;
     const int sb = gags_slot_base(start, end, tile, blk);
     const int cnt = blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk];
     const int steps = cnt >> 1;
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(64, 2) void raster_fwd_feat_f16(
     g.init(tile, blk, tile_w, width, height, lane);
     const int p = g.p, k = g.k;  // A operand: pixel p of a half-block; B operand: channel group p; k: which 8 of the step's 16 slots
     const int start = offsets[tile];
-    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+    const int end = offsets[tile + 1]  /* n_tiles + 1 entries: the last one is the intersection count */;
     const int sb = gags_slot_base(start, end, tile, blk);
     const int cnt = blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk];
     const int steps = (cnt + 15) >> 4;
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(64, (NB >= 16 ? 1 : 2)) void raster_fwd_fused(
     g.init(tile, blk, tile_w, width, height, lane);
     const int p = g.p, k = g.k;
     const int start = offsets[tile];
-    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+    const int end = offsets[tile + 1]  /* n_tiles + 1 entries: the last one is the intersection count */;
 
     f32x16 acc[NB];
 #pragma unroll

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void raster_fwd_valu(
     const float px = (float)pj + 0.5f, py = (float)pi + 0.5f;
 
     const int start = offsets[tile];
-    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+    const int end = offsets[tile + 1]  /* n_tiles + 1 entries: the last one is the intersection count */;
 
     float acc[CDIM];
 #pragma unroll
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void raster_bwd_valu(
     const size_t pix = inside ? (size_t)pi * width + pj : 0;
 
     const int start = offsets[tile];
-    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+    const int end = offsets[tile + 1]  /* n_tiles + 1 entries: the last one is the intersection count */;
 
     const float T_final = inside ? 1.0f - render_alphas[pix] : 1.0f;
     float T = T_final;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void raster_stats_kernel(
     const bool inside = (pi < height) && (pj < width);
     const float px = (float)pj + 0.5f, py = (float)pi + 0.5f;
     const int start = offsets[tile];
-    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+    const int end = offsets[tile + 1]  /* n_tiles + 1 entries: the last one is the intersection count */;
     float T = 1.0f;
     bool done = !inside;
     unsigned n_eval = 0, n_blend = 0;

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64, 8) void raster_weights_kernel(
     const int p = g.p, k = g.k;
 
     const int start = offsets[tile];
-    const int end = (tile == n_tiles - 1) ? n_isects : offsets[tile + 1];
+    const int end = offsets[tile + 1]  /* n_tiles + 1 entries: the last one is the intersection count */;
     const int sb = gags_slot_base(start, end, tile, blk);
 
     PixState sA, sB;  // the lane's two pixels (upper / lower half of the 8x8 block)

@@ -56,6 +56,45 @@ def _side_stream(dev):
     return _SIDE[key]
 
 
+# Capacity mode (default): the two counts a view produces on the device -- tile intersections, partial gradient rows --
+# are NOT waited for before the kernels that need them are launched.  Buffers are sized by a capacity remembered from
+# earlier views of the same (N, width, height), the kernels take their ranges from device memory (isect_offsets' last
+# entry, sentinel keys), and the counts are read from a second stream once everything is enqueued: the host still learns
+# them (info["n_isects"] is exact, capacities are checked) but the queue never drains.  A count above its capacity --
+# nothing is written out of bounds -- re-runs that pass with exact sizes.  The first view of a shape runs the exact path.
+CAPACITY_MODE = True
+CAP_MARGIN = 1.25
+_CAP_ISECTS = {}
+_CAP_ROWS = {}
+_PINNED = {}
+
+
+class _DeferredCount:
+    """A device-side int32 read back without draining the launch stream: the copy runs on a second stream behind an
+    event recorded right after the kernel that produced the value."""
+
+    def __init__(self, scalar):
+        self.t = scalar
+        self.ev = torch.cuda.Event()
+        self.ev.record()
+
+    def get(self):
+        dev = self.t.device
+        side = _side_stream(dev)
+        key = dev.index
+        if key not in _PINNED:
+            _PINNED[key] = torch.empty(1, dtype=torch.int32).pin_memory()
+        host = _PINNED[key]
+        done = torch.cuda.Event()
+        with torch.cuda.stream(side):
+            side.wait_event(self.ev)
+            host.copy_(self.t, non_blocking=True)
+            done.record()
+        self.t.record_stream(side)
+        done.synchronize()
+        return int(host[0])
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -156,17 +195,19 @@ class _SH(torch.autograd.Function):
         return v_coeffs, v_means, None, None, None
 
 
-def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height, conics=None, opacities=None):
-    """K5-K8 (+K8b) on device.  One host readback (n_isects), as in gsplat.  Returns
-    (isect_ids sorted [I] int64, flatten_ids sorted [I] int32, isect_offsets [th,tw] int32, n_isects,
-    packed [I,8] f32 records in sorted order, or None when conics/opacities are not given)."""
+def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height, conics=None, opacities=None, cap=None):
+    """K5-K8 (+K8b) on device.  Returns (isect_ids sorted int64, flatten_ids sorted int32, isect_offsets [th,tw] int32 -- a
+    view of tile_h * tile_w + 1 entries whose last one is the count --, n_isects, packed [N,8] per-Gaussian records or None).
+    cap None: one host readback (n_isects), as in gsplat; the id arrays have exactly n_isects entries.
+    cap = capacity: nothing is read back here; the id arrays have `cap` entries (sentinels past the count) and n_isects is a
+    _DeferredCount the caller resolves after enqueuing what follows."""
     lib = _lib.load()
     st = _stream()
     dev = means2d.device
     n = radii.shape[0]
     tile_w, tile_h = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
     n_tiles = tile_w * tile_h
-    tile_bits = max(1, (n_tiles - 1).bit_length())
+    tile_bits = max(1, n_tiles.bit_length())  # (room for the sentinel tile id n_tiles of the capacity mode)
     cum = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     total = torch.empty(1, dtype=torch.int32, device=dev)
     # Gaussians in depth order first (N keys), intersections emitted in that order: the per-intersection sort
@@ -180,33 +221,42 @@ def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height, conics=
     sb = lib.gags_scan_scratch_bytes(n)
     scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
     check(lib.gags_cumsum_i32(n, ptr(tiles_ord), ptr(cum), ptr(total), ptr(scratch), sb, st), "gags_cumsum_i32")
-    host = ctypes.c_int32(0)
-    check(lib.gags_read_i32(ptr(total), ctypes.byref(host), st), "gags_read_i32")
-    n_isects = int(host.value)
-    if n_isects < 0 or n_isects >= MAX_ISECTS:  # the int32 prefix sum wrapped, or the slot space would
-        raise RuntimeError(f"gags_amd.rasterization: {n_isects if n_isects >= 0 else '> 2^31'} tile intersections in one "
-                           f"view; the kernels index at most 2^27 = {MAX_ISECTS} (INTEGRATION.md, memory model)")
-    offsets = torch.empty(tile_h, tile_w, dtype=torch.int32, device=dev)
-    ids = torch.empty(max(n_isects, 1), dtype=torch.int64, device=dev)
-    flat = torch.empty(max(n_isects, 1), dtype=torch.int32, device=dev)
+    if cap is None:
+        host = ctypes.c_int32(0)
+        check(lib.gags_read_i32(ptr(total), ctypes.byref(host), st), "gags_read_i32")
+        n_isects = int(host.value)
+        _check_isects(n_isects)
+        size, count = n_isects, n_isects
+    else:
+        size, count = int(cap), _DeferredCount(total)
+    offsets = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
+    ids = torch.empty(max(size, 1), dtype=torch.int64, device=dev)
+    flat = torch.empty(max(size, 1), dtype=torch.int32, device=dev)
     ids_s = torch.empty_like(ids)
     flat_s = torch.empty_like(flat)
-    if n_isects > 0:
-        check(lib.gags_tile_emit(n, ptr(means2d), ptr(radii), ptr(depths), ptr(cum), ptr(order), tile_w, tile_h,
-                                 ptr(ids), ptr(flat), st), "gags_tile_emit")
-        ssb = lib.gags_sort_scratch_bytes(n_isects)
+    if size > 0:
+        check(lib.gags_tile_emit_cap(n, ptr(means2d), ptr(radii), ptr(depths), ptr(cum), ptr(order), tile_w, tile_h,
+                                     ptr(ids), ptr(flat), size, ptr(total) if cap is not None else None, st),
+              "gags_tile_emit_cap")
+        ssb = lib.gags_sort_scratch_bytes(size)
         sscratch = torch.empty(ssb, dtype=torch.uint8, device=dev)
-        check(lib.gags_sort_pairs(n_isects, tile_bits, 1, ptr(ids), ptr(flat), ptr(ids_s), ptr(flat_s), ptr(sscratch),
+        check(lib.gags_sort_pairs(size, tile_bits, 1, ptr(ids), ptr(flat), ptr(ids_s), ptr(flat_s), ptr(sscratch),
                                   ssb, st), "gags_sort_pairs")
-    check(lib.gags_tile_offsets(n_isects, ptr(ids_s), n_tiles, ptr(offsets), st), "gags_tile_offsets")
+    check(lib.gags_tile_offsets(size, ptr(ids_s), n_tiles, ptr(offsets), st), "gags_tile_offsets")
     packed = None
     if conics is not None:
         # one 32-byte record per GAUSSIAN; the raster kernels gather it through flatten_ids themselves
         # (GAGS_RECS_BY_GAUSSIAN): no per-intersection copy of the records, no gather kernel
         packed = torch.empty(max(n, 1), 8, dtype=torch.float32, device=dev)
-        check(lib.gags_pack_isects(n, n_isects, ptr(flat_s), ptr(means2d), ptr(conics), ptr(opacities), ptr(radii),
+        check(lib.gags_pack_isects(n, max(size, 1), ptr(flat_s), ptr(means2d), ptr(conics), ptr(opacities), ptr(radii),
                                    ptr(packed), None, st), "gags_pack_isects")
-    return ids_s[:n_isects], flat_s[:n_isects], offsets, n_isects, packed
+    return ids_s[:size], flat_s[:size], offsets[:n_tiles].view(tile_h, tile_w), count, packed
+
+
+def _check_isects(n_isects):
+    if n_isects < 0 or n_isects >= MAX_ISECTS:  # the int32 prefix sum wrapped, or the slot space would
+        raise RuntimeError(f"gags_amd.rasterization: {n_isects if n_isects >= 0 else '> 2^31'} tile intersections in one "
+                           f"view; the kernels index at most 2^27 = {MAX_ISECTS} (INTEGRATION.md, memory model)")
 
 
 def _mfma_width(d):
@@ -349,7 +399,7 @@ def _geom_mfma_width(d):
 
 
 def _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height, xflag=0,
-                     flatten_ids=None, prezero=None):
+                     flatten_ids=None, prezero=None, exact_rows=False):
     """Colours-only backward without atomics: hit flags of the forward -> prefix sum (one row per (tile, Gaussian)
     pair that blended anything) -> one 4-byte readback (total rows) -> merged partial rows -> sort by Gaussian ->
     segmented sum."""
@@ -365,24 +415,32 @@ def _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d,
     total = torch.empty(1, dtype=torch.int32, device=dev)
     sb = lib.gags_bwd_rowmap_scratch_bytes(n_isects)
     stmp = torch.empty(max(sb, 4), dtype=torch.uint8, device=dev)
+    hook = GRAD_RANGE_HOOK
+    cap_key = (n, width, height, dev.index)
+    pending = None
     with profiler.stage("bwd_rowcount"):
         check(lib.gags_bwd_rowmap(n_isects, width, height, ptr(offsets), ptr(blk_rows), ptr(fwd_scratch),
                                   fwd_scratch.numel(), ptr(trow), ne, ptr(total), ptr(stmp), sb, st), "gags_bwd_rowmap")
-        host = ctypes.c_int32(0)
-        check(lib.gags_read_i32(ptr(total), ctypes.byref(host), st), "gags_read_i32")
-    rows = int(host.value)
+        if CAPACITY_MODE and hook is None and cap_key in _CAP_ROWS and not exact_rows:
+            # capacity mode (see CAPACITY_MODE): the row count stays on the device until the backward is enqueued
+            rows = min(max(n_isects, 1), int(_CAP_ROWS[cap_key] * CAP_MARGIN) + 1024)
+            pending = _DeferredCount(total)
+        else:
+            host = ctypes.c_int32(0)
+            check(lib.gags_read_i32(ptr(total), ctypes.byref(host), st), "gags_read_i32")
+            rows = int(host.value)
     nbytes = lib.gags_bwd_staged_scratch_bytes(rows, n, d)
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     v_colors = torch.empty(n, d, device=dev, dtype=torch.float16 if (xflag & 64) else torch.float32)
+    rows_dev = ptr(total) if pending is not None else None
 
     def run(stage):
         stage |= xflag
-        check(lib.gags_raster_bwd_colors_staged(d, n, width, height, ptr(offsets), n_isects, ptr(v_out), ptr(blk_rows),
-                                                ptr(trow), rows, ptr(fwd_scratch), fwd_scratch.numel(),
-                                                ptr(scratch), nbytes, ptr(v_colors), stage, st),
-              "gags_raster_bwd_colors_staged")
+        check(lib.gags_raster_bwd_colors_staged_cap(d, n, width, height, ptr(offsets), n_isects, ptr(v_out), ptr(blk_rows),
+                                                    ptr(trow), rows, ptr(fwd_scratch), fwd_scratch.numel(),
+                                                    ptr(scratch), nbytes, ptr(v_colors), stage, 0, d, rows_dev, st),
+              "gags_raster_bwd_colors_staged_cap")
 
-    hook = GRAD_RANGE_HOOK
     if prezero is not None and hook is None:
         # the forward started a zero-fill of this tensor on a second stream while the binning kernels (small, latency-bound:
         # the memory system idles) ran; the reduce stage then writes only the rows that exist -- 73 % of the Gaussians
@@ -411,6 +469,15 @@ def _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d,
         run(0)
         if hook is not None:
             hook(v_colors.detach(), 0, d)
+    if pending is not None:
+        true_rows = pending.get()
+        if true_rows > rows:  # more rows than the remembered capacity (none was stored out of bounds): again, exact
+            _CAP_ROWS[cap_key] = true_rows
+            return _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height, xflag & ~128,
+                                    flatten_ids, None, exact_rows=True)
+        rows = true_rows
+    if hook is None:
+        _CAP_ROWS[cap_key] = max(rows, int(0.97 * _CAP_ROWS.get(cap_key, 0)))
     profiler.note("bwd_rows", rows)
     return v_colors
 
@@ -482,16 +549,32 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
         vbuf.record_stream(side)
         prezero = (vbuf, ev1)
 
-    with torch.no_grad(), profiler.stage("binning"):
-        dcols = cols.shape[-1]
-        wide = _mfma_width(dcols)  # the matrix-core path wants packed records
-        isect_ids, flatten_ids, isect_offsets, n_isects, packed = tile_binning(
-            means2d, radii, depths, tiles, width, height, conics if wide else None, _c(opacities) if wide else None)
+    dcols = cols.shape[-1]
+    wide = _mfma_width(dcols)  # the matrix-core path wants packed records
+    cap_key = (n, width, height, means.device.index)
 
-    # any width in ONE rasterization: 513 = 512 CLIP channels + 1 (BASELINE.json configs[4] "512-d feat + granularity") is
-    # four 128-channel slices and one lane of a narrow slice on the same matrix-core kernels, into one output tensor
-    out, alphas, last_ids = _Rasterize.apply(means2d, conics, cols, opacities, bg, isect_offsets, flatten_ids,
-                                             packed, width, height, int(raster_flags), prezero)
+    def run(cap):
+        with torch.no_grad(), profiler.stage("binning"):
+            b = tile_binning(means2d, radii, depths, tiles, width, height, conics if wide else None,
+                             _c(opacities) if wide else None, cap)
+        # any width in ONE rasterization: 513 = 512 CLIP channels + 1 (BASELINE.json configs[4] "512-d feat + granularity")
+        # is four 128-channel slices and one lane of a narrow slice on the same matrix-core kernels, into one output tensor
+        r = _Rasterize.apply(means2d, conics, cols, opacities, bg, b[2], b[1], b[4], width, height, int(raster_flags), prezero)
+        return b, r
+
+    cap = None
+    if CAPACITY_MODE and cap_key in _CAP_ISECTS:
+        cap = min(MAX_ISECTS - 1, int(_CAP_ISECTS[cap_key] * CAP_MARGIN) + 4096)
+    (isect_ids, flatten_ids, isect_offsets, n_isects, packed), (out, alphas, last_ids) = run(cap)
+    if cap is not None:
+        n_true = n_isects.get()  # (the scan that produced it finished long ago: everything above is already enqueued)
+        _check_isects(n_true)
+        if n_true > cap:  # more intersections than the remembered capacity: nothing was written out of bounds; run again, exact
+            (isect_ids, flatten_ids, isect_offsets, n_isects, packed), (out, alphas, last_ids) = run(None)
+        else:
+            n_isects = n_true
+            isect_ids, flatten_ids = isect_ids[:n_true], flatten_ids[:n_true]
+    _CAP_ISECTS[cap_key] = max(n_isects, int(0.97 * _CAP_ISECTS.get(cap_key, 0)))
     if render_mode in ("ED", "RGB+ED"):
         if out.requires_grad:
             out = torch.cat([out[..., :-1], out[..., -1:] / alphas[..., None].clamp(min=1e-10)], dim=-1)

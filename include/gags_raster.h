@@ -16,7 +16,7 @@
  *    caller-visible memory, and there is no global mutable state (re-entrant per stream).
  *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls only
  *    enqueue work; they never synchronize, except gags_read_i32 which is the one
- *    explicit device->host readback (n_isects), mirroring gsplat's own sync.
+ *    explicit device->host readback (n_isects), mirroring gsplat's own sync -- avoidable: gags_tile_emit_cap.
  *  - return value: GAGS_OK (0) or a negative GAGS_E* code; gags_strerror() names it.
  *  - all floating point is fp32; indices are int32; intersection keys are int64
  *    (tile_id << 32 | float_bits(depth)), as in the reference's rasterizer.
@@ -95,6 +95,16 @@ int gags_tile_emit(int n, const float *means2d, const int32_t *radii, const floa
                    const int32_t *cum, const int32_t *order, int tile_w, int tile_h,
                    int64_t *isect_ids, int32_t *flatten_ids, void *stream);
 
+/* K6 into CAPACITY-sized buffers, so that the count need not reach the host before the launches: at most `cap` pairs
+ * are written, and entries [total[0], cap) become sentinel keys of a tile past the last one (they sort to the end;
+ * gags_sort_pairs needs tile_bits = bit length of n_tiles for them).  total = gags_cumsum_i32's device-side total.  Run
+ * sort / offsets / raster with `cap` as n_isects; read total afterwards (e.g. from a second stream, once everything is
+ * enqueued): if it exceeds cap the results are garbage -- nothing was written out of bounds -- and the view must be run
+ * again with a larger capacity. */
+int gags_tile_emit_cap(int n, const float *means2d, const int32_t *radii, const float *depths, const int32_t *cum,
+                       const int32_t *order, int tile_w, int tile_h, int64_t *isect_ids, int32_t *flatten_ids, int64_t cap,
+                       const int32_t *total, void *stream);
+
 /* K7: stable radix sort of the pairs on key bits [0, 32 + tile_bits); with depth_sorted != 0 the input
  * is already in depth order (K7a + ordered K6) and only bits [32, 32 + tile_bits) are sorted -- same
  * result (ties: depth, then Gaussian index), 2 passes instead of 6 at 1080p.
@@ -105,7 +115,10 @@ int gags_sort_pairs(int64_t n_isects, int tile_bits, int depth_sorted,
                     int64_t *keys_out, int32_t *vals_out,
                     void *scratch, int64_t scratch_bytes, void *stream);
 
-/* K8: isect_offsets[tile_h*tile_w] = first sorted index of each tile. */
+/* K8: isect_offsets[tile_h*tile_w + 1]: first sorted index of each tile, and in the LAST entry the intersection count
+ * (ABI version 2: every raster entry reads a tile's end from isect_offsets[tile + 1], none needs the count from the
+ * host).  With capacity-sized inputs (gags_tile_emit_cap) pass the capacity as n_isects: the last entry is where the
+ * sentinel keys begin = the true count. */
 int gags_tile_offsets(int64_t n_isects, const int64_t *sorted_ids, int n_tiles,
                       int32_t *isect_offsets, void *stream);
 
@@ -223,6 +236,14 @@ int gags_raster_bwd_colors_staged_range(int d, int n, int width, int height, con
                                         const void *fwd_scratch, int64_t fwd_scratch_bytes,
                                         void *scratch, int64_t scratch_bytes, float *v_colors, int stage,
                                         int ch_begin, int ch_count, void *stream);
+/* The same with `rows` as a CAPACITY and the true row count on the device (rows_dev = gags_bwd_rowmap's total; NULL:
+ * rows is exact): rows past the capacity are dropped, the keys between the count and the capacity become sentinels.  Read
+ * the count afterwards; if it exceeds the capacity run the backward again. */
+int gags_raster_bwd_colors_staged_cap(int d, int n, int width, int height, const int32_t *isect_offsets, int64_t n_isects,
+                                      const float *v_render_colors, const int32_t *blk_rows, const int32_t *rowmap,
+                                      int64_t rows, const void *fwd_scratch, int64_t fwd_scratch_bytes, void *scratch,
+                                      int64_t scratch_bytes, float *v_colors, int stage, int ch_begin, int ch_count,
+                                      const int32_t *rows_dev, void *stream);
 
 /* Diagnostics (roofline model): counts[0] += (pixel,Gaussian) pairs evaluated
  * before each pixel's stop, counts[1] += pairs blended.  counts[2] int64, zeroed by caller. */

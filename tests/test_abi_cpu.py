@@ -48,7 +48,7 @@ def test_library_exports_nothing_but_the_declared_c_abi(lib):
 
 
 def test_abi_version_and_error_strings(lib):
-    assert lib.gags_abi_version() == 1
+    assert lib.gags_abi_version() == 2
     assert lib.gags_strerror(0) == b"ok"
     for code in (-1, -2, -3, -4):
         assert lib.gags_strerror(code) not in (b"ok", b"unknown error")

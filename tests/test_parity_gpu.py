@@ -362,6 +362,56 @@ def test_sparse_reduce_with_overlapped_zero_fill_is_bit_identical(oracle):
         assert bool((res[0][info["radii"][0] == 0] == 0).all())
 
 
+def test_capacity_mode_keeps_the_counts_on_the_device_and_changes_nothing(oracle):
+    """Steady state (second view of a shape onwards): no gags_read_i32 at all -- buffers sized by remembered capacities,
+    sentinel keys, isect_offsets' last entry, counts read from a second stream after everything is enqueued -- and every
+    output identical to the exact path, including info["n_isects"] and the sliced id arrays.  A capacity that turns out
+    too small re-runs the pass and still returns the right answer."""
+    from gags_amd import _lib, rasterization as R
+    n, w, h, d = 6000, 208, 160, 128
+    s = scene_arrays(n, d, w, h, seed=77, view=4, scale_mult=6.0)
+    bg = np.full(d, 0.2, np.float32)
+    v_out = np.random.default_rng(13).standard_normal((h, w, d)).astype(np.float32)
+    lib = _lib.load()
+    calls = []
+    real = lib.gags_read_i32
+
+    def counting(*a):
+        calls.append(1)
+        return real(*a)
+
+    def once():
+        out, alpha, info, grads = _run_gpu(s, w, h, s["colors"], bg, v_out=v_out)
+        return out, alpha, info["n_isects"], info["isect_ids"].cpu().numpy(), info["flatten_ids"].cpu().numpy(), \
+            info["isect_offsets"][0].cpu().numpy(), info["last_ids"].cpu().numpy(), grads["colors"]
+
+    R.CAPACITY_MODE = False
+    try:
+        ref = once()
+    finally:
+        R.CAPACITY_MODE = True
+    R._CAP_ISECTS.clear(); R._CAP_ROWS.clear()
+    first = once()                      # learns the capacities (exact path)
+    lib.gags_read_i32 = counting
+    try:
+        steady = once()
+        assert calls == [], "the steady state must not read a count back synchronously"
+        # capacities far too small: both passes notice afterwards and run again
+        for k in list(R._CAP_ISECTS):
+            R._CAP_ISECTS[k] = 10
+        for k in list(R._CAP_ROWS):
+            R._CAP_ROWS[k] = 10
+        small = once()
+    finally:
+        lib.gags_read_i32 = real
+    for got in (first, steady, small):
+        assert got[2] == ref[2]
+        for a, b in zip(got, ref):
+            if isinstance(a, np.ndarray):
+                np.testing.assert_array_equal(a, b)
+    assert len(calls) >= 2   # the two overflows fell back to the exact path
+
+
 def test_backward_by_channel_ranges_is_bit_identical(oracle):
     """The by-view multi-GPU step asks the staged backward for the gradient one 128-channel range at a time
     (rasterization.GRAD_RANGE_HOOK, gags_amd/dist.py): same kernels on a sub-range, so the same bits as the one-shot
