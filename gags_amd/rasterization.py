@@ -18,6 +18,7 @@ backward launches the colours-only kernel and nothing else.
 PyTorch supplies device memory, streams and autograd plumbing; all arithmetic is in HIP.
 """
 import ctypes
+import os
 
 import torch
 
@@ -62,7 +63,7 @@ def _side_stream(dev):
 # entry, sentinel keys), and the counts are read from a second stream once everything is enqueued: the host still learns
 # them (info["n_isects"] is exact, capacities are checked) but the queue never drains.  A count above its capacity --
 # nothing is written out of bounds -- re-runs that pass with exact sizes.  The first view of a shape runs the exact path.
-CAPACITY_MODE = True
+CAPACITY_MODE = os.environ.get("GAGS_CAPACITY_MODE", "1") != "0"
 CAP_MARGIN = 1.25
 _CAP_ISECTS = {}
 _CAP_ROWS = {}
@@ -248,7 +249,7 @@ def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height, conics=
         # one 32-byte record per GAUSSIAN; the raster kernels gather it through flatten_ids themselves
         # (GAGS_RECS_BY_GAUSSIAN): no per-intersection copy of the records, no gather kernel
         packed = torch.empty(max(n, 1), 8, dtype=torch.float32, device=dev)
-        check(lib.gags_pack_isects(n, max(size, 1), ptr(flat_s), ptr(means2d), ptr(conics), ptr(opacities), ptr(radii),
+        check(lib.gags_pack_isects(n, size, ptr(flat_s), ptr(means2d), ptr(conics), ptr(opacities), ptr(radii),
                                    ptr(packed), None, st), "gags_pack_isects")
     return ids_s[:size], flat_s[:size], offsets[:n_tiles].view(tile_h, tile_w), count, packed
 
