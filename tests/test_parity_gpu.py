@@ -385,11 +385,10 @@ def test_capacity_mode_keeps_the_counts_on_the_device_and_changes_nothing(oracle
         return out, alpha, info["n_isects"], info["isect_ids"].cpu().numpy(), info["flatten_ids"].cpu().numpy(), \
             info["isect_offsets"][0].cpu().numpy(), info["last_ids"].cpu().numpy(), grads["colors"]
 
+    saved = R.CAPACITY_MODE
     R.CAPACITY_MODE = False
-    try:
-        ref = once()
-    finally:
-        R.CAPACITY_MODE = True
+    ref = once()
+    R.CAPACITY_MODE = True              # (opt-in: GAGS_CAPACITY_MODE=1)
     R._CAP_ISECTS.clear(); R._CAP_ROWS.clear()
     first = once()                      # learns the capacities (exact path)
     lib.gags_read_i32 = counting
@@ -404,6 +403,8 @@ def test_capacity_mode_keeps_the_counts_on_the_device_and_changes_nothing(oracle
         small = once()
     finally:
         lib.gags_read_i32 = real
+        R.CAPACITY_MODE = saved
+        R._CAP_ISECTS.clear(); R._CAP_ROWS.clear()
     for got in (first, steady, small):
         assert got[2] == ref[2]
         for a, b in zip(got, ref):
