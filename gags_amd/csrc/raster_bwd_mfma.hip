@@ -449,6 +449,10 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
             }
             if (pbn < cnt) load_A(pbn);
             __builtin_amdgcn_sched_barrier(0);
+            // this lane's four column unscales as two packed pairs: the row's inverse scale multiplies them with two
+            // v_pk_mul_f32, the accumulators with two more
+            typedef float pk2 __attribute__((ext_vector_type(2)));
+            const pk2 inv01 = {inv[0], inv[1]}, inv23 = {inv[2], inv[3]};
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 // accumulator row r of this lane = slot (r & 3) + 8 (r >> 2) + 4 k: that row's inverse scale sits in lane `slot`
@@ -456,10 +460,12 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
                 const unsigned i0 = __builtin_amdgcn_readlane(rinv, s0), i1 = __builtin_amdgcn_readlane(rinv, s0 + 4);
                 const float ri = __uint_as_float(k ? i1 : i0);
                 const int slot = s0 + 4 * k;
-                if (slot < run)
-                    *reinterpret_cast<float4 *>(&stage[wave][slot][NBR * p]) =
-                        make_float4(acc[0][r] * (inv[0] * ri), acc[1][r] * (inv[1] * ri), acc[2][r] * (inv[2] * ri),
-                                    acc[3][r] * (inv[3] * ri));
+                if (slot < run) {
+                    const pk2 rr = {ri, ri};
+                    const pk2 a01 = {acc[0][r], acc[1][r]}, a23 = {acc[2][r], acc[3][r]};
+                    const pk2 o01 = a01 * (inv01 * rr), o23 = a23 * (inv23 * rr);
+                    *reinterpret_cast<float4 *>(&stage[wave][slot][NBR * p]) = make_float4(o01[0], o01[1], o23[0], o23[1]);
+                }
             }
         }
         __syncthreads();
