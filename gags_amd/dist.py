@@ -82,7 +82,9 @@ def reduce_feature_grad(grad, mode="rs_ag", average=False, bucket_bytes=BUCKET_B
             w.wait()
     elif mode == "rs_ag":
         # bucket so that every bucket splits evenly into `ws` shards; the ragged tail is all-reduced
-        per = max(ws, (bucket_bytes // flat.element_size()) // ws * ws)
+        # (a tensor smaller than one bucket is ONE bucket: with per > numel everything used to fall through to the
+        # tail's plain all-reduce -- exactly the 228 MB union-row blocks of the C4 step)
+        per = max(ws, min(bucket_bytes // flat.element_size(), numel) // ws * ws)
         main = numel // per * per
         for o in range(0, main, per):
             b = flat[o:o + per]

@@ -27,6 +27,18 @@ def _worker(rank, world, port, mode, n, d, q):
     expect = sum(torch.randn(n, d, generator=torch.Generator().manual_seed(100 + r)) for r in range(world))
     reduce_feature_grad(grad, mode=mode, bucket_bytes=4096)
     ok = torch.allclose(grad, expect, rtol=1e-6, atol=1e-6)
+    # smaller than one bucket (the default 256 MB against the 228 MB union-row blocks of the C4 step): still
+    # reduce-scatter + all-gather over one bucket, only the < world-size tail is all-reduced
+    import gags_amd.dist as D
+    calls = []
+    real_rs = D._reduce_scatter
+    D._reduce_scatter = lambda shard, full: (calls.append(full.numel()), real_rs(shard, full))[1]
+    g2 = torch.randn(n, d, generator=torch.Generator().manual_seed(100 + rank))
+    reduce_feature_grad(g2, mode=mode)
+    D._reduce_scatter = real_rs
+    ok = ok and torch.allclose(g2, expect, rtol=1e-6, atol=1e-6)
+    if mode == "rs_ag":
+        ok = ok and calls == [n * d // world * world]
     views = shard_views(8)
     q.put((rank, bool(ok), views))
     dist.barrier()
