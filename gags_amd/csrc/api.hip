@@ -36,12 +36,13 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
                                   const float *wt, const int32_t *gid_s, const int32_t *trow_s, void *scratch,
                                   int64_t scratch_bytes, float *v_colors, int stage, int ch_begin, int ch_count,
                                   const int32_t *rows_dev, hipStream_t st);
-int64_t gags_raster_bwd_geom_scratch_bytes_impl(int64_t n_isects, int width, int height, int n_gauss, int64_t n_rows);
+int64_t gags_raster_bwd_geom_scratch_bytes_impl(int64_t n_isects, int width, int height, int n_gauss, int d, int64_t n_rows);
 int gags_raster_bwd_geom_launch(int d, int n_gauss, int width, int height, const float *colors, const float *backgrounds,
                                 const int32_t *offsets, int n_isects, const void *packed, const float *v_out,
                                 const float *v_alphas, const int32_t *blk_rows, const float *wt, const int32_t *gid_s,
                                 const int32_t *sidx_s, const float *Tbuf, void *scratch, int64_t scratch_bytes, float *v_geo,
-                                int by_gauss, const int32_t *row_base, int64_t n_rows, hipStream_t st);
+                                int by_gauss, const int32_t *row_base, int64_t n_rows, const int32_t *hit,
+                                const int32_t *flatten_ids, int f32mfma, hipStream_t st);
 int gags_blended_mask_launch(int n_isects, const int32_t *hit, const int32_t *flatten_ids, unsigned char *mask, hipStream_t st);
 int gags_bwd_slot_rows_launch(int width, int height, int n_isects, const int32_t *offsets, const int32_t *blk_rows,
                               const int32_t *sidx_s, const int32_t *trow, int32_t *trow_s, hipStream_t st);
@@ -204,10 +205,10 @@ extern "C" int gags_bwd_rowmap(int64_t n_isects, int width, int height, const in
                                      (const int32_t *)(fs + L.sidx), trow, rowmap + rowmap_slot_off(n_isects), st);
 }
 
-extern "C" int64_t gags_raster_bwd_geom_scratch_bytes(int64_t n_isects, int width, int height, int n, int64_t n_rows)
+extern "C" int64_t gags_raster_bwd_geom_scratch_bytes(int64_t n_isects, int width, int height, int n, int d, int64_t n_rows)
 {
-    if (n_isects < 0 || width <= 0 || height <= 0 || n < 0) return 0;
-    return gags_raster_bwd_geom_scratch_bytes_impl(n_isects, width, height, n, n_rows);
+    if (n_isects < 0 || width <= 0 || height <= 0 || n < 0 || d <= 0) return 0;
+    return gags_raster_bwd_geom_scratch_bytes_impl(n_isects, width, height, n, d, n_rows);
 }
 
 extern "C" int gags_raster_bwd_geom(int d, int n, int width, int height, const float *colors, const float *backgrounds,
@@ -217,7 +218,6 @@ extern "C" int gags_raster_bwd_geom(int d, int n, int width, int height, const f
                                     float *v_geo, const int32_t *flatten_ids, const int32_t *row_base, int64_t n_rows,
                                     int flags, void *stream)
 {
-    (void)flatten_ids;  // the slots carry their Gaussian ids (gid_s); kept in the signature for symmetry with the forward
     if (d <= 0 || width <= 0 || height <= 0 || n < 0 || n_isects < 0 || n_isects >= (1ll << 27)) return GAGS_EINVAL;
     if (n == 0) return GAGS_OK;
     if (!colors || !isect_offsets || !packed || !v_render_colors || !blk_rows || !fwd_scratch || !scratch || !v_geo)
@@ -229,7 +229,9 @@ extern "C" int gags_raster_bwd_geom(int d, int n, int width, int height, const f
                                        v_render_colors, v_render_alphas, blk_rows, (const float *)(fs + L.wt),
                                        (const int32_t *)(fs + L.gid), (const int32_t *)(fs + L.sidx),
                                        (const float *)(fs + L.tbuf), scratch, scratch_bytes, v_geo,
-                                       (flags & GAGS_RECS_BY_GAUSSIAN) ? 1 : 0, row_base, n_rows, (hipStream_t)stream);
+                                       (flags & GAGS_RECS_BY_GAUSSIAN) ? 1 : 0, row_base, n_rows,
+                                       (const int32_t *)(fs + L.hit), flatten_ids, (flags & 32) ? 1 : 0,
+                                       (hipStream_t)stream);
 }
 
 extern "C" int gags_blended_mask(int64_t n_isects, int width, int height, int n, const int32_t *flatten_ids,

@@ -852,6 +852,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_sdot(int d, int ch0, int dc
 {
     extern __shared__ __attribute__((aligned(16))) float slab[];  // [64 pixels in wt order e = 2 p + h][dch + SD_PAD]
     __shared__ float bred[4][64];
+    __shared__ __attribute__((aligned(16))) float bgs[SD_MAXCH];  // the pass's slice of the background
     const int dch = DCH ? DCH : dch_rt;
     const int logical = gags_xcd_remap(blockIdx.x, n_tiles * GAGS_BLOCKS_PER_TILE);
     const int blk = logical & 3;
@@ -891,11 +892,15 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_sdot(int d, int ch0, int dc
             }
         }
     }
+    if (backgrounds && tid < dch) bgs[tid] = backgrounds[ch0 + tid];
     __syncthreads();
-    if (backgrounds) {  // <bg, v_px> per pixel of the block, for the background term of v_alpha
-        const int e = tid & 63, part = tid >> 6, per = dch >> 2;
+    if (backgrounds) {  // <bg, v_px> per pixel of the block, for the background term of v_alpha (background slice from LDS)
+        const int e = tid & 63, part = tid >> 6;
         float acc = 0.f;
-        for (int c = part * per; c < (part + 1) * per; ++c) acc = fmaf(backgrounds[ch0 + c], slab[e * pitch + c], acc);
+        for (int c = 4 * part; c < dch; c += 16) {
+            const float4 x = *reinterpret_cast<const float4 *>(slab + e * pitch + c), b = *reinterpret_cast<const float4 *>(bgs + c);
+            acc = fmaf(b.x, x.x, acc); acc = fmaf(b.y, x.y, acc); acc = fmaf(b.z, x.z, acc); acc = fmaf(b.w, x.w, acc);
+        }
         bred[part][e] = acc;
         __syncthreads();
         if (tid < 64) {
@@ -965,6 +970,286 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_sdot(int d, int ch0, int dc
     }
 }
 
+// ---- the same dot pass on the fp16 matrix cores with split operands (round 3; the default) --------------------------------
+// S = <c_g, v_px> is a plain contraction over the channels, so the scheme of raster_bwd_rows_f16 applies with the roles
+// swapped: the FEATURE rows are the exact operand (three fp16 terms, one power-of-two scale per Gaussian row: largest
+// magnitude -> [2^14, 2^15)), the COTANGENT slab the rounded one (two terms, one scale per 8x8 block and pass -- the
+// geometry rows sum S over the block's 64 pixels, so an error relative to the block's largest cotangent is an error
+// relative to the row's largest term).  Five MFMA terms per product at the 16-bit rate instead of one at the fp32 rate.
+// What bounds this pass is not the arithmetic but the GATHER of the feature rows: every lane of an A operand reads
+// another Gaussian's row, and the vector L1 looks up one 128-byte line per cycle -- 32x32 tiles (two lanes per row, 32 B
+// per row and instruction) delivered 16-32 B/clk/CU and ran SLOWER with the 16-bit cores than the fp32 kernel (3.0 vs
+// 2.1 ms per pass at C3).  Hence v_mfma_f32_16x16x32_f16: FOUR lanes per row, 64 contiguous bytes of one row per
+// instruction, 16 lines per wave load.
+//   feat_split_kernel: once per pass, every BLENDED Gaussian's 256-channel slice -> three fp16 terms in operand order
+//     ([32-channel step][term][32 halves]) + 1 / scale per row; the split costs ~13 VALU instructions per two values and
+//     a row is read by ~16 units, so it is done once, not per unit;
+//   raster_bwd_sdot_f16: slab -> registers -> block maximum -> two fp16 planes in LDS (67.6 KB: two workgroups per CU);
+//     units of 16 slots x 64 pixels (four 16x16 accumulators), per 32-channel step 3 x 16 B from the table (four steps
+//     ahead), 8 x 16 B from LDS, 20 MFMAs, no VALU work in the loop; the accumulators leave scaled back by
+//     (row scale x block scale) -- S holds plain dot products, as before.
+constexpr int SF_PADH = 8;  // halves of padding per slab row (one 2-way conflict per ds_read_b128 lane group; 16 is conflict-free and measured the same)
+constexpr int SF_PF = 4;    // 32-channel steps of table rows in flight
+constexpr int SF_STAGE = 1024;  // slots of a block whose ids and scales are staged in LDS (8 KB; mean block: ~140 slots)
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void feat_split_kernel(int n_gauss, int d, int ch0, int ks, const float *__restrict__ colors,
+                                                         const unsigned char *__restrict__ mask, uint4 *__restrict__ table,
+                                                         float *__restrict__ rinv)
+{
+    const int row = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;  // half a wave per row, 8 channels per lane
+    if (row >= n_gauss || !mask[row]) return;
+    const int dch = min(32 * ks, d - ch0);
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = 0.f;
+    if (8 * l < dch) {
+        const float4 *src = reinterpret_cast<const float4 *>(colors + (size_t)row * d + ch0 + 8 * l);
+        const float4 u = src[0], v = src[1];
+        x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = v.x; x[5] = v.y; x[6] = v.z; x[7] = v.w;
+    }
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mx = fmaxf(mx, fabsf(x[i]));
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const int ebits = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+    const bool sane = ebits >= 16 && ebits <= 240;  // zero rows, denormals, non-finite values: scale 1
+    const float rs = sane ? __uint_as_float((unsigned)(268 - ebits) << 23) : 1.0f;  // 2^(14 - exponent)
+    if (l < 4 * ks) {
+        f16x8 t0, t1, t2;
+        split8x3(x, rs, t0, t1, t2);
+        uint4 *dst = table + (size_t)row * (12 * ks) + 12 * (l >> 2) + (l & 3);  // step l / 4, k quarter l % 4; term t: + 4 t
+        dst[0] = *reinterpret_cast<const uint4 *>(&t0);
+        dst[4] = *reinterpret_cast<const uint4 *>(&t1);
+        dst[8] = *reinterpret_cast<const uint4 *>(&t2);
+    }
+    if (l == 0) rinv[row] = sane ? __uint_as_float((unsigned)(ebits - 14) << 23) : 1.0f;
+}
+
+template <int KS>  // 32-channel steps of this pass: 8 = the full 256 channels, everything unrolled; 0 = `ks_rt`
+__global__ __launch_bounds__(256, 2) void raster_bwd_sdot_f16(int d, int ch0, int ks_rt, int width, int height, int tile_w, int n_tiles,
+                                                           int n_gauss, const float *__restrict__ v_out,
+                                                           const uint4 *__restrict__ table, const float *__restrict__ rinv,
+                                                           const float *__restrict__ backgrounds,
+                                                           const int32_t *__restrict__ offsets, int n_isects,
+                                                           const int32_t *__restrict__ blk_rows, const int32_t *__restrict__ gid_s,
+                                                           float *__restrict__ S, float *__restrict__ bgdot)
+{
+    extern __shared__ __attribute__((aligned(16))) _Float16 planes[];  // hi [64 pixels e = 2 p + h][pitch], then lo
+    __shared__ float bred[4][64];
+    __shared__ float wmax[4];
+    __shared__ __attribute__((aligned(16))) float bgs[SD_MAXCH];  // the pass's slice of the background
+    __shared__ int gids[SF_STAGE];                                 // the block's first SF_STAGE slots: Gaussian id, 1 / row scale
+    __shared__ float rinvs[SF_STAGE];
+    const int ks = KS ? KS : ks_rt;
+    const int dch = min(32 * ks, d - ch0);  // channels of the pass that exist (a multiple of 8); the rest of the last step is 0
+    const int pitch = 32 * ks + SF_PADH;
+    _Float16 *hi = planes, *lo = planes + 64 * pitch;
+    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * GAGS_BLOCKS_PER_TILE);
+    const int blk = logical & 3;
+    const int tile = gags_tile_of_order(logical >> 2, tile_w, n_tiles / tile_w);
+    const int cnt = blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk];
+    if (cnt == 0) return;
+    const int start = offsets[tile];
+    const int end = offsets[tile + 1]  /* n_tiles + 1 entries: the last one is the intersection count */;
+    const int sb = gags_slot_base(start, end, tile, blk);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ty = tile / tile_w, tx = tile - ty * tile_w;
+    const int bx0 = tx * GAGS_TILE + (blk & 1) * 8, by0 = ty * GAGS_TILE + (blk >> 1) * 8;
+    const int m = lane & 15, kq = lane >> 4;
+    // work units = 16 slots x the block's 64 pixels, dealt round-robin to the four waves (a block of ~150 slots: ten units)
+    const int n_units = (cnt + 15) >> 4;
+    // The (unit, step) pairs of a wave form ONE stream: the table rows are requested SF_PF steps ahead ACROSS unit
+    // boundaries.  NOTHING else is loaded from global memory inside that stream: loads return in order, so one HBM miss
+    // (an id, a scale, an earlier pass's sum) in front of a row request stalls the MFMAs for its whole latency -- the ids
+    // and scales of the block's slots are staged in LDS up front (requested before the slab, their latency passes under
+    // the slab's), and every pass writes its own S / bgdot buffer (raster_bwd_geom adds them up; no read-modify-write).
+    auto slot_gid = [&](int j) __attribute__((always_inline)) { return min(gid_s[sb + min(j, cnt - 1)], n_gauss - 1); };  // (pad slot: clamped, unused)
+    const int n_stage = min(cnt, SF_STAGE);
+    int sg[SF_STAGE / 256];
+#pragma unroll
+    for (int q = 0; q < SF_STAGE / 256; ++q) sg[q] = (q * 256 < n_stage) ? slot_gid(tid + q * 256) : 0;
+    int gid = 0;
+    // Row requests are made in QUAD order -- lane 4 r + q asks for quarter q (16 bytes) of row r's 64-byte step, four
+    // consecutive lanes one contiguous 64 bytes -- and the registers are then permuted into the MFMA's operand order
+    // (lane 16 q + r): the address coalescer works on neighbouring lanes, and in operand order (neighbours = different
+    // Gaussians) a 16-byte-per-lane gather went through at one lane per cycle, which bounded the whole pass.
+    const int lr = lane >> 2, lq = lane & 3;
+    const int perm_src = 4 * (4 * m + kq);  // ds_bpermute address: operand lane (m, kq) takes from request lane 4 m + kq
+    if (wave < n_units) gid = slot_gid(wave * 16 + lr);  // the wave's first unit: its rows are requested before the slab is waited for
+    uint4 a[SF_PF][3];
+    float ibs;  // 1 / block scale
+    {
+        // the whole slab in registers (<= 16 float4 per thread, all requested at once), its largest magnitude, then
+        // scaled and split into the two planes
+        const int q4 = 8 * ks;  // float4 per padded pixel row
+        const int total = 64 * q4;
+        float4 v[16];
+        float mx = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u * 256 < total) {  // (uniform)
+                const int i = min(tid + u * 256, total - 1);
+                const int e = i / q4, c4 = i - e * q4;
+                const int pp = e >> 1, h = e & 1;
+                const int pj = bx0 + (pp & 7), pi = by0 + (pp >> 3) + 4 * h;
+                const bool in = pi < height && pj < width && 4 * c4 < dch && tid + u * 256 < total;
+                v[u] = *reinterpret_cast<const float4 *>(v_out + ((size_t)min(pi, height - 1) * width + min(pj, width - 1)) * d +
+                                                         ch0 + min(4 * c4, dch - 4));
+                if (!in) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (wave < n_units) {  // (the ids were requested before the slab: they are here first)
+            const uint4 *arow = table + (size_t)gid * (12 * ks) + lq;
+#pragma unroll
+            for (int u = 0; u < SF_PF; ++u)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) a[u][t] = arow[12 * min(u, ks - 1) + 4 * t];
+        }
+        float sr[SF_STAGE / 256];
+#pragma unroll
+        for (int q = 0; q < SF_STAGE / 256; ++q) sr[q] = (q * 256 < n_stage) ? rinv[sg[q]] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if (lane == 0) wmax[wave] = mx;
+        if (backgrounds && tid < dch) bgs[tid] = backgrounds[ch0 + tid];
+#pragma unroll
+        for (int q = 0; q < SF_STAGE / 256; ++q)
+            if (q * 256 < n_stage) { gids[tid + q * 256] = sg[q]; rinvs[tid + q * 256] = sr[q]; }
+        __syncthreads();
+        mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        const int ebits = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+        const bool sane = ebits >= 16 && ebits <= 240;  // an all-zero (or non-finite) slab keeps scale 1
+        const float bs = sane ? __uint_as_float((unsigned)(268 - ebits) << 23) : 1.0f;  // largest magnitude -> [2^14, 2^15)
+        ibs = sane ? __uint_as_float((unsigned)(ebits - 14) << 23) : 1.0f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = tid + u * 256;
+            if (i < total) {
+                const int e = i / q4, c4 = i - e * q4;
+                const f32x2v_t a = {v[u].x * bs, v[u].y * bs}, b = {v[u].z * bs, v[u].w * bs};
+                const f16x2_t ah = __builtin_convertvector(a, f16x2_t), bh = __builtin_convertvector(b, f16x2_t);
+                const f16x2_t al = __builtin_convertvector(a - __builtin_convertvector(ah, f32x2v_t), f16x2_t);
+                const f16x2_t bl = __builtin_convertvector(b - __builtin_convertvector(bh, f32x2v_t), f16x2_t);
+                typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+                const f16x4_t h4 = {ah[0], ah[1], bh[0], bh[1]}, l4 = {al[0], al[1], bl[0], bl[1]};
+                *reinterpret_cast<f16x4_t *>(hi + e * pitch + 4 * c4) = h4;
+                *reinterpret_cast<f16x4_t *>(lo + e * pitch + 4 * c4) = l4;
+            }
+        }
+    }
+    __syncthreads();
+    if (backgrounds) {  // <bg, v_px> per pixel of the block, for the background term of v_alpha (from the two planes)
+        // eight channels at a time, the background slice from LDS (a global load per channel, waited for one by one,
+        // was 12.8 of this workgroup's 30 microseconds)
+        const int e = tid & 63, part = tid >> 6;
+        float acc = 0.f;
+        for (int c = 8 * part; c < dch; c += 32) {
+            const f16x8 h8 = *reinterpret_cast<const f16x8 *>(hi + e * pitch + c), l8 = *reinterpret_cast<const f16x8 *>(lo + e * pitch + c);
+            const float4 b0 = *reinterpret_cast<const float4 *>(bgs + c), b1 = *reinterpret_cast<const float4 *>(bgs + c + 4);
+            acc = fmaf(b0.x, (float)h8[0] + (float)l8[0], acc); acc = fmaf(b0.y, (float)h8[1] + (float)l8[1], acc);
+            acc = fmaf(b0.z, (float)h8[2] + (float)l8[2], acc); acc = fmaf(b0.w, (float)h8[3] + (float)l8[3], acc);
+            acc = fmaf(b1.x, (float)h8[4] + (float)l8[4], acc); acc = fmaf(b1.y, (float)h8[5] + (float)l8[5], acc);
+            acc = fmaf(b1.z, (float)h8[6] + (float)l8[6], acc); acc = fmaf(b1.w, (float)h8[7] + (float)l8[7], acc);
+        }
+        bred[part][e] = acc;
+        __syncthreads();
+        if (tid < 64) {
+            const int pp = tid >> 1, h = tid & 1;
+            const int pj = bx0 + (pp & 7), pi = by0 + (pp >> 3) + 4 * h;
+            if (pi < height && pj < width) {
+                const float t = ((bred[0][tid] + bred[1][tid]) + (bred[2][tid] + bred[3][tid])) * ibs;
+                bgdot[(size_t)pi * width + pj] = t;
+            }
+        }
+    }
+    auto unit_gid = [&](int unit) __attribute__((always_inline)) {  // staged; a block of more than SF_STAGE slots: the rest from memory
+        const int j = min(min(unit, n_units - 1) * 16 + lr, cnt - 1);
+        return j < SF_STAGE ? gids[j] : slot_gid(j);
+    };
+    int gid_n = unit_gid(wave + 4);
+    for (int unit = wave; unit < n_units; unit += 4) {
+        const int t0 = unit * 16;
+        const uint4 *arow = table + (size_t)gid * (12 * ks) + lq;      // step j, term t: + 12 j + 4 t
+        const uint4 *arow_n = table + (size_t)gid_n * (12 * ks) + lq;  // the wave's next unit (the last one: itself again)
+        const int jm = min(t0 + m, cnt - 1);
+        const float ri = (jm < SF_STAGE ? rinvs[jm] : rinv[slot_gid(jm)]) * ibs;
+        const int gid_nn = unit_gid(unit + 8);
+        const _Float16 *bh0 = hi + m * pitch + 8 * kq, *bl0 = lo + m * pitch + 8 * kq;  // pixel group pg: + 16 pg pitch
+        f32x4_t acc[4];
+#pragma unroll
+        for (int pg = 0; pg < 4; ++pg) acc[pg] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        auto step = [&](int j, int u) __attribute__((always_inline)) {
+            uint4 pa[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                pa[t].x = (unsigned)__builtin_amdgcn_ds_bpermute(perm_src, (int)a[u][t].x);
+                pa[t].y = (unsigned)__builtin_amdgcn_ds_bpermute(perm_src, (int)a[u][t].y);
+                pa[t].z = (unsigned)__builtin_amdgcn_ds_bpermute(perm_src, (int)a[u][t].z);
+                pa[t].w = (unsigned)__builtin_amdgcn_ds_bpermute(perm_src, (int)a[u][t].w);
+            }
+            const f16x8 a0 = *reinterpret_cast<const f16x8 *>(&pa[0]);
+            const f16x8 a1 = *reinterpret_cast<const f16x8 *>(&pa[1]);
+            const f16x8 a2 = *reinterpret_cast<const f16x8 *>(&pa[2]);
+            {   // slot u next holds step j + SF_PF of this unit, or -- past its end -- step u of the next one
+                const uint4 *src = (j + SF_PF < ks) ? arow + 12 * (j + SF_PF) : arow_n + 12 * min(u, ks - 1);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) a[u][t] = src[4 * t];
+            }
+            f16x8 bh[4], bl[4];
+#pragma unroll
+            for (int pg = 0; pg < 4; ++pg) {
+                bh[pg] = *reinterpret_cast<const f16x8 *>(bh0 + 16 * pg * pitch + 32 * j);
+                bl[pg] = *reinterpret_cast<const f16x8 *>(bl0 + 16 * pg * pitch + 32 * j);
+            }
+            // One scheduling fence per step, BETWEEN its reads and its MFMAs: the next step's permutes and LDS reads may
+            // rise into this step's MFMAs (and no further; without any fence every read of the unit went to the top: 96 spills).
+            __builtin_amdgcn_sched_barrier(0);
+            // smallest terms first; the four accumulators in turn (no MFMA waits for the one before it)
+#pragma unroll
+            for (int pg = 0; pg < 4; ++pg) acc[pg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, bh[pg], acc[pg], 0, 0, 0);
+#pragma unroll
+            for (int pg = 0; pg < 4; ++pg) acc[pg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bl[pg], acc[pg], 0, 0, 0);
+#pragma unroll
+            for (int pg = 0; pg < 4; ++pg) acc[pg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bh[pg], acc[pg], 0, 0, 0);
+#pragma unroll
+            for (int pg = 0; pg < 4; ++pg) acc[pg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bl[pg], acc[pg], 0, 0, 0);
+#pragma unroll
+            for (int pg = 0; pg < 4; ++pg) acc[pg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bh[pg], acc[pg], 0, 0, 0);
+        };
+        if constexpr (KS != 0) {
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                step(j, j % SF_PF);
+            }
+        } else {
+            for (int jb = 0; jb < ks; jb += SF_PF) {
+#pragma unroll
+                for (int u = 0; u < SF_PF; ++u)
+                    if (jb + u < ks) step(jb + u, u);
+            }
+        }
+        gid = gid_n;
+        gid_n = gid_nn;
+        // accumulator pg: column = pixel element 16 pg + m, rows = slots 4 kq + i; lane m holds the scale of slot m's row
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float sc = __shfl(ri, 4 * kq + i);
+            const int row = t0 + 4 * kq + i;
+            if (row < cnt) {
+#pragma unroll
+                for (int pg = 0; pg < 4; ++pg) S[(size_t)(sb + row) * 64 + 16 * pg + m] = acc[pg][i] * sc;
+            }
+        }
+    }
+}
+
 // wave64 sum on the VALU (DPP: quad swaps, row mirrors, row broadcasts; the total lands in lane 63), returned
 // wave-uniform -- __shfl_xor goes through the LDS crossbar, and six sums per slot made that the kernel's bound
 __device__ __forceinline__ float geom_wave_sum(float v)
@@ -986,8 +1271,9 @@ __global__ __launch_bounds__(64) void raster_bwd_geom(int width, int height, int
                                                       const float *__restrict__ Tbuf, const float *__restrict__ v_alphas,
                                                       const float *__restrict__ bgdot, float *__restrict__ grow,
                                                       uint32_t *__restrict__ key, int32_t *__restrict__ idx, int by_gauss,
-                                                      const int32_t *__restrict__ row_base)
-{
+                                                      const int32_t *__restrict__ row_base, int n_pass, size_t s_stride,
+                                                      size_t bg_stride)
+{   // n_pass > 1: the dot pass left one S / bgdot buffer per 256-channel pass (s_stride, bg_stride floats apart): summed here
     const int logical = gags_xcd_remap(blockIdx.x, n_tiles * GAGS_BLOCKS_PER_TILE);
     const int blk = logical & 3;
     const int tile = gags_tile_of_order(logical >> 2, tile_w, n_tiles / tile_w);
@@ -1007,7 +1293,12 @@ __global__ __launch_bounds__(64) void raster_bwd_geom(int width, int height, int
     const float px = (float)pj + 0.5f, py = (float)pi + 0.5f;
     const float T_final = inside ? Tbuf[pix] : 1.f;
     // T_f ra (v_a - <bg, v>): everything but ra is per pixel
-    const float k0 = inside ? T_final * ((v_alphas ? v_alphas[pix] : 0.f) - (bgdot ? bgdot[pix] : 0.f)) : 0.f;
+    float bgd = 0.f;
+    if (bgdot && inside) {
+        bgd = bgdot[pix];
+        for (int p = 1; p < n_pass; ++p) bgd += bgdot[p * bg_stride + pix];
+    }
+    const float k0 = inside ? T_final * ((v_alphas ? v_alphas[pix] : 0.f) - bgd) : 0.f;
     float behind = 0.f;  // SUM f S over the slots behind the current one
     // two-deep software pipeline over the slots (back to front): the slot's ids and rows are requested two slots ahead,
     // its packed record (addressed by the id) one slot ahead
@@ -1018,6 +1309,11 @@ __global__ __launch_bounds__(64) void raster_bwd_geom(int width, int height, int
         q.sx = sidx_s[slot]; q.g = gid_s[slot];
         q.f = wt[(size_t)slot * 64 + lane];
         q.sd = S[(size_t)slot * 64 + lane];
+        if (n_pass > 1) {  // (uniform; at most four passes: D <= 1024)
+            q.sd += S[s_stride + (size_t)slot * 64 + lane];
+            if (n_pass > 2) q.sd += S[2 * s_stride + (size_t)slot * 64 + lane];
+            if (n_pass > 3) q.sd += S[3 * s_stride + (size_t)slot * 64 + lane];
+        }
         return q;
     };
     auto fetch_rec = [&](const Ids &q) __attribute__((always_inline)) {  // (the pad slot's gid is n_gauss: clamped, unused)
@@ -1071,32 +1367,38 @@ __global__ __launch_bounds__(64) void raster_bwd_geom(int width, int height, int
 }
 
 struct GeomLayout {
-    int64_t S, bgdot, grow, key, idx, key_s, idx_s, seg, sort, total;
+    int64_t S, bgdot, grow, key, idx, key_s, idx_s, seg, table, rinv, mask, sort, total;
 };
 // n_rows < 0: one row per slot of the sparse slot space; else the compact row count (sum of blk_rows)
-inline GeomLayout geom_layout(int64_t n_isects, int width, int height, int n_gauss, int64_t n_rows)
+inline GeomLayout geom_layout(int64_t n_isects, int width, int height, int n_gauss, int d, int64_t n_rows)
 {
     const int64_t tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
     const int64_t slots = GAGS_BLOCKS_PER_TILE * (n_isects + tile_w * tile_h) + 64;
     const int64_t rows = n_rows < 0 ? slots : (n_rows > 0 ? n_rows : 1);
     GeomLayout L;
     int64_t o = 0;
-    L.S = o; o += al256(slots * 256);
-    L.bgdot = o; o += al256((int64_t)width * height * 4);
+    const int64_t n_pass = std::max(1, (d + SD_MAXCH - 1) / SD_MAXCH);  // the split-f16 dot pass: one S / bgdot buffer per pass
+    L.S = o; o += n_pass * al256(slots * 256);
+    L.bgdot = o; o += n_pass * al256((int64_t)width * height * 4);
     L.grow = o; o += al256(rows * 32);
     L.key = o; o += al256(rows * 4);
     L.idx = o; o += al256(rows * 4);
     L.key_s = o; o += al256(rows * 4);
     L.idx_s = o; o += al256(rows * 4);
     L.seg = o; o += al256(((int64_t)n_gauss + 2) * 4);
+    // split feature table of one pass (<= 256 channels: 6 bytes per channel), 1 / row scale, blended mask
+    const int64_t ks = (std::min(d, SD_MAXCH) + 31) / 32;  // 32-channel steps, 192 bytes each
+    L.table = o; o += al256((int64_t)n_gauss * ks * 192);
+    L.rinv = o; o += al256((int64_t)n_gauss * 4);
+    L.mask = o; o += al256((int64_t)n_gauss);
     L.sort = o; o += al256(gags_sort_u32_scratch_bytes(rows));
     L.total = o;
     return L;
 }
 
-int64_t gags_raster_bwd_geom_scratch_bytes_impl(int64_t n_isects, int width, int height, int n_gauss, int64_t n_rows)
+int64_t gags_raster_bwd_geom_scratch_bytes_impl(int64_t n_isects, int width, int height, int n_gauss, int d, int64_t n_rows)
 {
-    return geom_layout(n_isects, width, height, n_gauss, n_rows).total;
+    return geom_layout(n_isects, width, height, n_gauss, d, n_rows).total;
 }
 
 // 1 = width not eligible (d % 8 != 0 or d < 32)
@@ -1104,12 +1406,13 @@ int gags_raster_bwd_geom_launch(int d, int n_gauss, int width, int height, const
                                 const int32_t *offsets, int n_isects, const void *packed, const float *v_out,
                                 const float *v_alphas, const int32_t *blk_rows, const float *wt, const int32_t *gid_s,
                                 const int32_t *sidx_s, const float *Tbuf, void *scratch, int64_t scratch_bytes, float *v_geo,
-                                int by_gauss, const int32_t *row_base, int64_t n_rows, hipStream_t st)
+                                int by_gauss, const int32_t *row_base, int64_t n_rows, const int32_t *hit,
+                                const int32_t *flatten_ids, int f32mfma, hipStream_t st)
 {
     GAGS_CLEAR_ERR();
     if (d < 32 || d % 8 != 0) return 1;
     if (!row_base) n_rows = -1;
-    const GeomLayout L = geom_layout(n_isects, width, height, n_gauss, n_rows);
+    const GeomLayout L = geom_layout(n_isects, width, height, n_gauss, d, n_rows);
     if (scratch_bytes < L.total) return GAGS_ESCRATCH;
     const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
     const int n_tiles = tile_w * tile_h;
@@ -1128,7 +1431,43 @@ int gags_raster_bwd_geom_launch(int d, int n_gauss, int width, int height, const
             return GAGS_ELAUNCH;
         attr_set = true;
     }
-    for (int ch0 = 0; ch0 < d; ch0 += SD_MAXCH) {
+    const bool split16 = !f32mfma && hit && flatten_ids;
+    // the split-f16 dot pass writes one S / bgdot buffer per 256-channel pass (the fp32 one accumulates in the first)
+    const int64_t slots_all = GAGS_BLOCKS_PER_TILE * ((int64_t)n_isects + n_tiles) + 64;
+    const size_t s_stride = (size_t)al256(slots_all * 256) / 4, bg_stride = (size_t)al256((int64_t)width * height * 4) / 4;
+    const int n_pass = split16 ? (d + SD_MAXCH - 1) / SD_MAXCH : 1;
+    if (split16) {
+        static bool attr16_set = false;
+        const int lds16_max = 2 * 64 * (SD_MAXCH + SF_PADH) * 2;
+        if (!attr16_set) {
+            if (hipFuncSetAttribute((const void *)raster_bwd_sdot_f16<SD_MAXCH / 32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds16_max) != hipSuccess ||
+                hipFuncSetAttribute((const void *)raster_bwd_sdot_f16<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds16_max) != hipSuccess)
+                return GAGS_ELAUNCH;
+            attr16_set = true;
+        }
+        unsigned char *mask = (unsigned char *)(sb + L.mask);
+        uint4 *table = (uint4 *)(sb + L.table);
+        float *rinv = (float *)(sb + L.rinv);
+        if (hipMemsetAsync(mask, 0, (size_t)n_gauss, st) != hipSuccess) return GAGS_ELAUNCH;
+        if (n_isects > 0) {
+            const int rc = gags_blended_mask_launch(n_isects, hit, flatten_ids, mask, st);
+            if (rc != GAGS_OK) return rc;
+        }
+        for (int ch0 = 0; ch0 < d; ch0 += SD_MAXCH) {
+            const int ks = (min(SD_MAXCH, d - ch0) + 31) / 32;
+            float *S_p = S + (size_t)(ch0 / SD_MAXCH) * s_stride, *bg_p = bgdot ? bgdot + (size_t)(ch0 / SD_MAXCH) * bg_stride : nullptr;
+            hipLaunchKernelGGL(feat_split_kernel, dim3((n_gauss + 7) / 8), dim3(256), 0, st, n_gauss, d, ch0, ks, colors, mask, table, rinv);
+            const dim3 grid(n_tiles * GAGS_BLOCKS_PER_TILE);
+            const size_t lds = (size_t)2 * 64 * (32 * ks + SF_PADH) * 2;
+            if (ks == SD_MAXCH / 32)
+                hipLaunchKernelGGL(raster_bwd_sdot_f16<SD_MAXCH / 32>, grid, dim3(256), lds, st, d, ch0, ks, width, height, tile_w, n_tiles,
+                                   n_gauss, v_out, table, rinv, backgrounds, offsets, n_isects, blk_rows, gid_s, S_p, bg_p);
+            else
+                hipLaunchKernelGGL(raster_bwd_sdot_f16<0>, grid, dim3(256), lds, st, d, ch0, ks, width, height, tile_w, n_tiles,
+                                   n_gauss, v_out, table, rinv, backgrounds, offsets, n_isects, blk_rows, gid_s, S_p, bg_p);
+        }
+    }
+    for (int ch0 = 0; ch0 < d && !split16; ch0 += SD_MAXCH) {
         const int dch = min(SD_MAXCH, d - ch0);
         const dim3 grid(n_tiles * GAGS_BLOCKS_PER_TILE);
         const size_t lds = (size_t)64 * (dch + SD_PAD) * 4;
@@ -1141,7 +1480,7 @@ int gags_raster_bwd_geom_launch(int d, int n_gauss, int width, int height, const
     }
     hipLaunchKernelGGL(raster_bwd_geom, dim3(n_tiles * GAGS_BLOCKS_PER_TILE), dim3(64), 0, st, width, height, tile_w, n_tiles,
                        n_gauss, reinterpret_cast<const GRec *>(packed), offsets, n_isects, blk_rows, wt, gid_s, sidx_s, S, Tbuf,
-                       v_alphas, bgdot, grow, key, idx, by_gauss, row_base);
+                       v_alphas, bgdot, grow, key, idx, by_gauss, row_base, n_pass, s_stride, bg_stride);
     GAGS_CHECK_LAUNCH();
     int nbits = 1;
     while ((1ll << nbits) <= n_gauss) ++nbits;  // keys in [0, n_gauss]

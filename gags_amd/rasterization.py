@@ -366,14 +366,16 @@ class _Rasterize(torch.autograd.Function):
             incl = torch.cumsum(blk_rows, 0, dtype=torch.int32)
             row_base = (incl - blk_rows).contiguous()
             n_rows = int(incl[-1].item()) if incl.numel() else 0
-            nb = lib.gags_raster_bwd_geom_scratch_bytes(n_isects, width, height, n, n_rows)
+            nb = lib.gags_raster_bwd_geom_scratch_bytes(n_isects, width, height, n, d, n_rows)
             gscratch = torch.empty(nb, dtype=torch.uint8, device=dev)
             v_geo = torch.empty(n, 8, device=dev)
             with profiler.stage("raster_bwd_geom"):
                 check(lib.gags_raster_bwd_geom(d, n, width, height, ptr(colors), ptr(backgrounds), ptr(offsets), n_isects,
                                                ptr(packed), ptr(v_out), ptr(v_alphas), ptr(blk_rows), ptr(fwd_scratch),
                                                fwd_scratch.numel(), ptr(gscratch), nb, ptr(v_geo), ptr(flatten_ids),
-                                               ptr(row_base), n_rows, _lib.GAGS_RECS_BY_GAUSSIAN, _stream()),
+                                               ptr(row_base), n_rows,
+                                               _lib.GAGS_RECS_BY_GAUSSIAN | (32 if (flags & _lib.GAGS_BWD_F32MFMA) else 0),
+                                               _stream()),
                       "gags_raster_bwd_geom")
             v_con, v_m2d, v_opac = v_geo[:, 0:3].contiguous(), v_geo[:, 3:5].contiguous(), v_geo[:, 5].contiguous()
             return v_m2d, v_con, v_colors, v_opac, v_bg, None, None, None, None, None, None, None

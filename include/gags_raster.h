@@ -197,15 +197,19 @@ int gags_bwd_rowmap(int64_t n_isects, int width, int height, const int32_t *isec
 /* K10, geometry part at wide D (D >= 32, D % 8 == 0) after a split gags_raster_fwd: v_geo[N][8] =
  * (v_conics[3], v_means2d[2], v_opacities[1], 0, 0) per Gaussian, written in full, no atomics, deterministic.
  * The D-proportional work -- <colors[g], v_render_colors[px]> for every (slot, pixel) of the forward -- runs on the
- * fp32 matrix cores; the per-pair chain uses the forward's own weights (T = weight / alpha: front-to-back quantities,
+ * matrix cores: by default the 16-bit ones with split operands (feature rows as three fp16 terms, exact, one power-of-two
+ * scale per Gaussian; the cotangent as two, one scale per 8x8 block: fp32-equivalent), with
+ * flags bit 5 (32) the fp32 matrix instructions (rounds 1-2's kernel); the per-pair chain uses the forward's own weights (T = weight / alpha: front-to-back quantities,
  * not 1 - render_alpha rebuilt back to front).  Together with gags_raster_bwd_colors_staged this replaces
  * gags_raster_bwd when geometry needs grad at wide D (gsplat's rasterize_to_pixels backward [EXT]).
  * backgrounds / v_render_alphas may be NULL.  row_base (optional, [tile_h*tile_w*4] int32 = exclusive prefix sum of
  * blk_rows) with n_rows = sum of blk_rows numbers the per-slot rows compactly, so that only n_rows keys are sorted;
  * NULL / -1: one row per slot of the sparse slot space (no host-side count needed, ~6x more keys).
- * scratch: gags_raster_bwd_geom_scratch_bytes(n_isects, w, h, n, n_rows) (~1.1 KB per tile intersection).
+ * flatten_ids: the sorted intersections' Gaussian ids (names, with the forward's hit flags, the rows to split).
+ * scratch: gags_raster_bwd_geom_scratch_bytes(n_isects, w, h, n, d, n_rows) (~1.1 KB per tile intersection + 1.5 KB per
+ * Gaussian for the split table of one 256-channel pass).
  * Returns 1 when D is not eligible. */
-int64_t gags_raster_bwd_geom_scratch_bytes(int64_t n_isects, int width, int height, int n, int64_t n_rows);
+int64_t gags_raster_bwd_geom_scratch_bytes(int64_t n_isects, int width, int height, int n, int d, int64_t n_rows);
 int gags_raster_bwd_geom(int d, int n, int width, int height, const float *colors, const float *backgrounds,
                          const int32_t *isect_offsets, int64_t n_isects, const void *packed,
                          const float *v_render_colors, const float *v_render_alphas, const int32_t *blk_rows,

@@ -488,6 +488,33 @@ def test_wide_geometry_backward_matches_the_valu_kernel_and_is_deterministic():
             assert rel_l2(g_new[k], g_old[k]) <= 2e-5, k
 
 
+def test_wide_geometry_backward_on_both_matrix_pipes_and_under_rescaling():
+    """The dot pass of gags_raster_bwd_geom contracts on the 16-bit matrix cores with split operands (feature rows as
+    three fp16 terms, cotangent as two, power-of-two scales per Gaussian row and per 8x8 block); GAGS_BWD_F32MFMA keeps
+    rounds 1-2's fp32-MFMA kernel.  The two agree to fp32 rounding, and -- the scales being powers of two -- multiplying
+    the cotangent by 2^-30 (a mean-reduced loss) or the features by 2^12 multiplies every geometry gradient by exactly
+    that factor, bit for bit."""
+    from gags_amd import _lib
+    n, w, h, d = 2000, 112, 80, 328          # 256-channel pass + a ragged 72-channel pass (4.5 k-steps of 16)
+    s = scene_arrays(n, d, w, h, seed=33, view=4, scale_mult=5.0)
+    rng = np.random.default_rng(9)
+    v_out = rng.standard_normal((h, w, d)).astype(np.float32)
+    v_out[:, : w // 2] *= 1e-4               # blocks of very different magnitude
+    bg = np.full(d, 0.3, np.float32)
+    _, _, _, g16 = _run_gpu(s, w, h, s["colors"], bg, need_geom=True, v_out=v_out, v_alpha=None)
+    _, _, _, g32 = _run_gpu(s, w, h, s["colors"], bg, need_geom=True, v_out=v_out, v_alpha=None,
+                            flags=_lib.GAGS_BWD_F32MFMA)
+    for k in ("means", "quats", "scales", "opacities", "means2d"):
+        assert rel_l2(g16[k], g32[k]) <= 3e-6, k
+    _, _, _, gs = _run_gpu(s, w, h, s["colors"], bg, need_geom=True, v_out=v_out * np.float32(2.0 ** -30), v_alpha=None)
+    for k in ("opacities", "means2d"):
+        np.testing.assert_array_equal(gs[k], g16[k] * np.float32(2.0 ** -30))
+    _, _, _, gc = _run_gpu(s, w, h, s["colors"] * np.float32(4096.0), bg * np.float32(4096.0), need_geom=True, v_out=v_out,
+                           v_alpha=None)
+    for k in ("opacities", "means2d"):
+        np.testing.assert_array_equal(gc[k], g16[k] * np.float32(4096.0))
+
+
 def test_wide_geometry_backward_with_nothing_to_render():
     """Degenerate inputs through the matrix-core geometry path: every Gaussian behind the camera (no intersections at
     all), and a view that only a handful of Gaussians reach -- gradients are exact zeros where nothing blended."""

@@ -72,6 +72,7 @@ CASES = [
     ("C5 4M/1080p/D=513 (512+1) fp16 table -- BASELINE.json configs[4] as stated", C5 + (513,), dict(half=True, steps=4)),
     ("C5 4M/1080p/D=513 (512+1) fp16 table, 16-bit matrix cores forward too (opt-in)", C5 + (513,), dict(half=True, flags=128, steps=4)),
     ("C3 1.5M/1080p/D=512, ALL gradients (features + means, quats, scales, opacities)", C3 + (512,), dict(full_grad=True)),
+    ("C3 ALL gradients, fp32 matrix instructions (rounds 1-2's kernels)", C3 + (512,), dict(full_grad=True, flags=64)),
     ("C3 ALL gradients, VALU + atomics backward (what round 1 ran)", C3 + (512,), dict(full_grad=True, flags=4, steps=3)),
     ("C2 500k/1280x720/D=128, ALL gradients", (500_000, 1280, 720, 128), dict(full_grad=True)),
     ("C3 geometry D=16, ALL gradients (VALU kernels)", C3 + (16,), dict(full_grad=True)),
