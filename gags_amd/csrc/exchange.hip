@@ -19,21 +19,48 @@ template <> struct Elem<0> {
     using type = float;
     static __device__ __forceinline__ float ld(const void *p, size_t i) { return reinterpret_cast<const float *>(p)[i]; }
     static __device__ __forceinline__ void st(void *p, size_t i, float v) { reinterpret_cast<float *>(p)[i] = v; }
+    static __device__ __forceinline__ float4 ld4(const void *p, size_t i) { return *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(p) + i); }
+    static __device__ __forceinline__ void st4(void *p, size_t i, float4 v) { *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p) + i) = v; }
 };
 template <> struct Elem<1> {
     using type = __half;
     static __device__ __forceinline__ float ld(const void *p, size_t i) { return __half2float(reinterpret_cast<const __half *>(p)[i]); }
     static __device__ __forceinline__ void st(void *p, size_t i, float v) { reinterpret_cast<__half *>(p)[i] = __float2half_rn(v); }
+    static __device__ __forceinline__ float4 ld4(const void *p, size_t i)
+    {
+        const uint2 u = *reinterpret_cast<const uint2 *>(reinterpret_cast<const __half *>(p) + i);
+        const __half2 a = *reinterpret_cast<const __half2 *>(&u.x), b = *reinterpret_cast<const __half2 *>(&u.y);
+        return make_float4(__low2float(a), __high2float(a), __low2float(b), __high2float(b));
+    }
+    static __device__ __forceinline__ void st4(void *p, size_t i, float4 v)
+    {
+        const __half2 a = __floats2half2_rn(v.x, v.y), b = __floats2half2_rn(v.z, v.w);
+        uint2 u;
+        u.x = *reinterpret_cast<const unsigned *>(&a); u.y = *reinterpret_cast<const unsigned *>(&b);
+        *reinterpret_cast<uint2 *>(reinterpret_cast<__half *>(p) + i) = u;
+    }
 };
 template <> struct Elem<2> {
     using type = __hip_bfloat16;
     static __device__ __forceinline__ float ld(const void *p, size_t i) { return __bfloat162float(reinterpret_cast<const __hip_bfloat16 *>(p)[i]); }
     static __device__ __forceinline__ void st(void *p, size_t i, float v) { reinterpret_cast<__hip_bfloat16 *>(p)[i] = __float2bfloat16(v); }
+    static __device__ __forceinline__ float4 ld4(const void *p, size_t i)
+    {
+        const uint2 u = *reinterpret_cast<const uint2 *>(reinterpret_cast<const __hip_bfloat16 *>(p) + i);  // bf16 = the upper half of an fp32
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                           __uint_as_float(u.y & 0xffff0000u));
+    }
+    static __device__ __forceinline__ void st4(void *p, size_t i, float4 v)
+    {
+        __hip_bfloat16 h[4] = {__float2bfloat16(v.x), __float2bfloat16(v.y), __float2bfloat16(v.z), __float2bfloat16(v.w)};
+        *reinterpret_cast<uint2 *>(reinterpret_cast<__hip_bfloat16 *>(p) + i) = *reinterpret_cast<const uint2 *>(h);
+    }
 };
 
-// one thread per (row, 4 channels); the 4 channels are handled element-wise (rows of an odd width D are not
-// 16-byte aligned; the compiler still merges the accesses where the types allow)
-template <int TG, int TW>
+// one thread per (row, 4 channels).  V4: D, c0, cw multiples of 4 and 16-byte aligned bases -- one vector load and one
+// vector store per thread.  Otherwise element-wise, ALL loads before the first store (a load waited for inside the
+// per-element bound check is a vmcnt(0), and stores count in vmcnt: four serialized round trips per thread).
+template <int TG, int TW, bool V4>
 __global__ __launch_bounds__(256) void pack_rows_kernel(int64_t n_rows, const int64_t *__restrict__ idx,
                                                         const void *__restrict__ grad, int d, int c0, int cw,
                                                         void *__restrict__ wire)
@@ -44,12 +71,21 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(int64_t n_rows, const in
     const int64_t r = t / q;
     const int c = (int)(t - r * q) * 4;
     const int64_t g = idx ? idx[r] : r;
+    if constexpr (V4) {
+        Elem<TW>::st4(wire, (size_t)r * cw + c, Elem<TG>::ld4(grad, (size_t)g * d + c0 + c));
+    } else {
+        float v[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-        if (c + e < cw) Elem<TW>::st(wire, (size_t)r * cw + c + e, Elem<TG>::ld(grad, (size_t)g * d + c0 + c + e));
+        for (int e = 0; e < 4; ++e) v[e] = Elem<TG>::ld(grad, (size_t)g * d + c0 + min(c + e, cw - 1));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(v[e]));
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c + e < cw) Elem<TW>::st(wire, (size_t)r * cw + c + e, v[e]);
+    }
 }
 
-template <int TG, int TW, bool DELTA>
+template <int TG, int TW, bool DELTA, bool V4>
 __global__ __launch_bounds__(256) void unpack_rows_kernel(int64_t n_rows, const int64_t *__restrict__ idx,
                                                           const void *__restrict__ wire, const void *__restrict__ local,
                                                           void *__restrict__ grad, int d, int c0, int cw)
@@ -60,15 +96,31 @@ __global__ __launch_bounds__(256) void unpack_rows_kernel(int64_t n_rows, const 
     const int64_t r = t / q;
     const int c = (int)(t - r * q) * 4;
     const int64_t g = idx ? idx[r] : r;
+    if constexpr (V4) {
+        const size_t wi = (size_t)r * cw + c, gi = (size_t)g * d + c0 + c;
+        float4 v = Elem<TW>::ld4(wire, wi);
+        if constexpr (DELTA) {
+            const float4 o = Elem<TG>::ld4(grad, gi), l = Elem<TW>::ld4(local, wi);
+            v = make_float4(o.x + (v.x - l.x), o.y + (v.y - l.y), o.z + (v.z - l.z), o.w + (v.w - l.w));
+        }
+        Elem<TG>::st4(grad, gi, v);
+    } else {
+        float v[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if (c + e >= cw) continue;
-        const size_t wi = (size_t)r * cw + c + e, gi = (size_t)g * d + c0 + c + e;
-        float v = Elem<TW>::ld(wire, wi);
-        if constexpr (DELTA) v = Elem<TG>::ld(grad, gi) + (v - Elem<TW>::ld(local, wi));
-        Elem<TG>::st(grad, gi, v);
+        for (int e = 0; e < 4; ++e) {
+            const size_t wi = (size_t)r * cw + min(c + e, cw - 1), gi = (size_t)g * d + c0 + min(c + e, cw - 1);
+            v[e] = Elem<TW>::ld(wire, wi);
+            if constexpr (DELTA) v[e] = Elem<TG>::ld(grad, gi) + (v[e] - Elem<TW>::ld(local, wi));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(v[e]));
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c + e < cw) Elem<TG>::st(grad, (size_t)g * d + c0 + c + e, v[e]);
     }
 }
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 inline bool ok_types(int tg, int tw) { return (tg == 0 || tg == 1) && (tw == 0 || tw == 1 || tw == 2); }
 
@@ -84,7 +136,12 @@ extern "C" int gags_pack_rows(int64_t n_rows, const int64_t *idx, const void *gr
     const int64_t items = n_rows * ((cw + 3) >> 2);
     const dim3 grid((unsigned)((items + 255) / 256));
     hipStream_t st = (hipStream_t)stream;
-#define GO(TG, TW) hipLaunchKernelGGL((pack_rows_kernel<TG, TW>), grid, dim3(256), 0, st, n_rows, idx, grad, d, c0, cw, wire)
+    const bool v4 = ((d | c0 | cw) & 3) == 0 && aligned16(grad) && aligned16(wire);
+#define GO(TG, TW)                                                                                                         \
+    do {                                                                                                                   \
+        if (v4) hipLaunchKernelGGL((pack_rows_kernel<TG, TW, true>), grid, dim3(256), 0, st, n_rows, idx, grad, d, c0, cw, wire); \
+        else hipLaunchKernelGGL((pack_rows_kernel<TG, TW, false>), grid, dim3(256), 0, st, n_rows, idx, grad, d, c0, cw, wire);  \
+    } while (0)
     if (grad_type == 0) { if (wire_type == 0) GO(0, 0); else if (wire_type == 1) GO(0, 1); else GO(0, 2); }
     else { if (wire_type == 0) GO(1, 0); else if (wire_type == 1) GO(1, 1); else GO(1, 2); }
 #undef GO
@@ -102,14 +159,20 @@ extern "C" int gags_unpack_rows(int64_t n_rows, const int64_t *idx, const void *
     const int64_t items = n_rows * ((cw + 3) >> 2);
     const dim3 grid((unsigned)((items + 255) / 256));
     hipStream_t st = (hipStream_t)stream;
+    const bool v4 = ((d | c0 | cw) & 3) == 0 && aligned16(grad) && aligned16(wire) && (!local || aligned16(local));
+#define GO1(TG, TW, V)                                                                                                     \
+    do {                                                                                                                   \
+        if (local) hipLaunchKernelGGL((unpack_rows_kernel<TG, TW, true, V>), grid, dim3(256), 0, st, n_rows, idx, wire, local, grad, d, c0, cw); \
+        else hipLaunchKernelGGL((unpack_rows_kernel<TG, TW, false, V>), grid, dim3(256), 0, st, n_rows, idx, wire, local, grad, d, c0, cw);      \
+    } while (0)
 #define GO(TG, TW)                                                                                                         \
     do {                                                                                                                   \
-        if (local) hipLaunchKernelGGL((unpack_rows_kernel<TG, TW, true>), grid, dim3(256), 0, st, n_rows, idx, wire, local, grad, d, c0, cw); \
-        else hipLaunchKernelGGL((unpack_rows_kernel<TG, TW, false>), grid, dim3(256), 0, st, n_rows, idx, wire, local, grad, d, c0, cw);      \
+        if (v4) GO1(TG, TW, true); else GO1(TG, TW, false);                                                                \
     } while (0)
     if (grad_type == 0) { if (wire_type == 0) GO(0, 0); else if (wire_type == 1) GO(0, 1); else GO(0, 2); }
     else { if (wire_type == 0) GO(1, 0); else if (wire_type == 1) GO(1, 1); else GO(1, 2); }
 #undef GO
+#undef GO1
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }

@@ -80,22 +80,36 @@ __device__ __forceinline__ void mfma_step(f32x16 (&acc)[NB], float wgt, const fl
 // out[pix][ch] = acc (+ T*bg); accumulator row r of lane (p,k) <-> pixel q = (r&3) + 8(r>>2) + 4k of the block.
 // Tq[r] = final transmittance of that pixel (fetched by the caller BEFORE this loop, unconditionally:
 // a load inside the per-row in-image branch would cost one serialized L2 round trip per row).
+// The background slice of this lane's channels (zeros without a background).
 template <int NB>
-__device__ __forceinline__ void epilogue(const f32x16 (&acc)[NB], const BlockGeom &g, int width, int height, int d,
-                                         int ch0, const float *__restrict__ backgrounds,
-                                         float *__restrict__ render_colors, const float (&Tq)[16])
+__device__ __forceinline__ void fetch_bg(float (&bgv)[NB], const float *__restrict__ backgrounds, int ch0, int p, int d)
 {
     constexpr int VEC = FwdCfg<NB>::VEC, NG = FwdCfg<NB>::NG;
-    float bgv[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) bgv[j] = 0.f;
-    const bool has_bg = backgrounds != nullptr;  // wave-uniform
-    if (has_bg) {
+    if (backgrounds != nullptr) {  // wave-uniform
 #pragma unroll
         for (int gq = 0; gq < NG; ++gq)
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) bgv[gq * VEC + i] = backgrounds[min(ch0 + gq * 32 * VEC + VEC * g.p + i, d - 1)];
+            for (int i = 0; i < VEC; ++i) bgv[gq * VEC + i] = backgrounds[min(ch0 + gq * 32 * VEC + VEC * p + i, d - 1)];
     }
+}
+
+// Every load of the wave has to have LANDED before the first store: stores count in vmcnt too (gfx9), and a wait for a
+// pending load inside a row's in-image branch is a vmcnt(0) -- it also waits for the previous row's STORE to be
+// acknowledged.  The 16 stores of a half then went out one write latency apart: 9.5 us per half, 37 % of a feature
+// wave's life (timestamps, round 3).  The empty asm makes each value a use HERE, outside the branches.
+template <int NB>
+__device__ __forceinline__ void store_rows(const f32x16 (&acc)[NB], const BlockGeom &g, int width, int height, int d,
+                                           int ch0, bool has_bg, float *__restrict__ render_colors, float (&bgv)[NB],
+                                           const float (&Tq)[16])
+{
+    constexpr int VEC = FwdCfg<NB>::VEC, NG = FwdCfg<NB>::NG;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) asm volatile("" : "+v"(bgv[j]));
+    float tq[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { tq[r] = Tq[r]; asm volatile("" : "+v"(tq[r])); }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int q = (r & 3) + 8 * (r >> 2) + 4 * g.k;
@@ -108,13 +122,23 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[NB], const BlockGeo
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 const float a = acc[gq * VEC + i][r];
-                v[i] = has_bg ? __builtin_fmaf(Tq[r], bgv[gq * VEC + i], a) : a;
+                v[i] = has_bg ? __builtin_fmaf(tq[r], bgv[gq * VEC + i], a) : a;
             }
             if constexpr (VEC == 4) *reinterpret_cast<float4 *>(o + gq * 128) = make_float4(v[0], v[1], v[2], v[3]);
             else if constexpr (VEC == 2) *reinterpret_cast<float2 *>(o) = make_float2(v[0], v[1]);
             else if (ch0 + g.p < d) o[0] = v[0];
         }
     }
+}
+
+template <int NB>
+__device__ __forceinline__ void epilogue(const f32x16 (&acc)[NB], const BlockGeom &g, int width, int height, int d,
+                                         int ch0, const float *__restrict__ backgrounds,
+                                         float *__restrict__ render_colors, const float (&Tq)[16])
+{
+    float bgv[NB];
+    fetch_bg<NB>(bgv, backgrounds, ch0, g.p, d);
+    store_rows<NB>(acc, g, width, height, d, ch0, backgrounds != nullptr, render_colors, bgv, Tq);
 }
 
 // Feature pass over 8x8 pixel blocks: each lane owns two pixels (upper / lower half of the block), i.e. the
@@ -142,6 +166,20 @@ __global__ __launch_bounds__(64, 2) void raster_fwd_feat(
     const int sb = gags_slot_base(start, end, tile, blk);
     const int cnt = blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk];
     const int steps = cnt >> 1;
+
+    // The epilogue's inputs -- final transmittance of the lane's 2 x 16 pixels, background of its channels -- are
+    // requested FIRST: they are the oldest loads of the wave, long landed when the K loop ends (fetched after it they
+    // cost two exposed round trips, ~4 us of a 45 us wave).
+    const bool has_bg = backgrounds != nullptr;  // wave-uniform
+    float TqA[16], TqB[16], bgv[NB];
+    fetch_bg<NB>(bgv, backgrounds, ch0, p, d);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int q = (r & 3) + 8 * (r >> 2) + 4 * k;
+        const int qj = min(g.bx0 + (q & 7), width - 1);
+        TqA[r] = has_bg ? Tbuf[(size_t)min(g.by0 + (q >> 3), height - 1) * width + qj] : 0.f;
+        TqB[r] = has_bg ? Tbuf[(size_t)min(g.by0 + 4 + (q >> 3), height - 1) * width + qj] : 0.f;
+    }
 
     f32x16 accA[NB], accB[NB];
 #pragma unroll
@@ -202,20 +240,12 @@ __global__ __launch_bounds__(64, 2) void raster_fwd_feat(
         }
     }
     // accumulator row r of lane (p,k) <-> pixel q = (r&3) + 8(r>>2) + 4k of a 8x4 half
-    float Tq[16];
     BlockGeom half;
     half.p = p; half.k = k; half.bx0 = g.bx0;
-#pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {
-        half.by0 = g.by0 + 4 * hb;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int q = (r & 3) + 8 * (r >> 2) + 4 * k;
-            const int qj = min(half.bx0 + (q & 7), width - 1), qi = min(half.by0 + (q >> 3), height - 1);
-            Tq[r] = Tbuf[(size_t)qi * width + qj];
-        }
-        epilogue<NB>(hb ? accB : accA, half, width, height, d, ch0, backgrounds, render_colors, Tq);
-    }
+    half.by0 = g.by0;
+    store_rows<NB>(accA, half, width, height, d, ch0, has_bg, render_colors, bgv, TqA);
+    half.by0 = g.by0 + 4;
+    store_rows<NB>(accB, half, width, height, d, ch0, has_bg, render_colors, bgv, TqB);
 }
 
 // ---- feature pass on the 16-bit matrix cores (opt-in: GAGS_FWD_F16MFMA; fp16 feature table, D % 128 == 0) -------------

@@ -229,3 +229,41 @@ def test_bench_two_ranks_under_torch_distributed_run():
     assert 0 < ge["rows_exchanged_last_step"] <= 20000
     assert len(ge["range_exchange_ms_last_step"]) == 2  # two 128-channel ranges at D = 256
     assert "view-dp2" in line["config"]["parallelism"]
+
+
+@pytest.mark.parametrize("d,c0,c1", [(256, 128, 256), (37, 5, 30), (130, 2, 130), (64, 0, 64)])
+@pytest.mark.parametrize("gdt", [torch.float32, torch.float16])
+@pytest.mark.parametrize("wdt", [torch.float32, torch.float16, torch.bfloat16])
+def test_pack_and_unpack_rows_against_torch_indexing(d, c0, c1, gdt, wdt):
+    """gags_pack_rows / gags_unpack_rows (the row-compacted exchange's gather and scatter) against torch indexing:
+    vector path (D, c0, width multiples of 4) and element-wise path, every gradient / wire type, assign and delta."""
+    from gags_amd.dist import _pack_rows, _unpack_rows
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(d * 7 + c0)
+    n = 1000
+    grad = torch.randn(n, d, generator=g).to(gdt).to(dev)
+    idx = torch.randperm(n, generator=g)[:317].sort().values.to(dev)
+    for ix in (idx, None):
+        wire = _pack_rows(grad, ix, c0, c1, wdt)
+        want = (grad[:, c0:c1] if ix is None else grad[ix, c0:c1]).to(wdt)
+        assert torch.equal(wire, want)
+        # assign
+        new = torch.randn(wire.shape, generator=g).to(wdt).to(dev)
+        tgt = grad.clone()
+        _unpack_rows(tgt, ix, c0, c1, new)
+        ref = grad.clone()
+        if ix is None:
+            ref[:, c0:c1] = new.to(gdt)
+        else:
+            ref[ix, c0:c1] = new.to(gdt)
+        assert torch.equal(tgt, ref)
+        # delta: grad += wire - local, formed in fp32, rounded once
+        tgt = grad.clone()
+        _unpack_rows(tgt, ix, c0, c1, new, local=wire)
+        ref = grad.clone().float()
+        delta = new.float() - wire.float()
+        if ix is None:
+            ref[:, c0:c1] += delta
+        else:
+            ref[ix, c0:c1] += delta
+        assert torch.equal(tgt, ref.to(gdt))
