@@ -1401,7 +1401,7 @@ int64_t gags_raster_bwd_geom_scratch_bytes_impl(int64_t n_isects, int width, int
     return geom_layout(n_isects, width, height, n_gauss, d, n_rows).total;
 }
 
-// 1 = width not eligible (d % 8 != 0 or d < 32)
+// 1 = width not eligible (d % 8 != 0 or d < 16)
 int gags_raster_bwd_geom_launch(int d, int n_gauss, int width, int height, const float *colors, const float *backgrounds,
                                 const int32_t *offsets, int n_isects, const void *packed, const float *v_out,
                                 const float *v_alphas, const int32_t *blk_rows, const float *wt, const int32_t *gid_s,
@@ -1410,7 +1410,7 @@ int gags_raster_bwd_geom_launch(int d, int n_gauss, int width, int height, const
                                 const int32_t *flatten_ids, int f32mfma, hipStream_t st)
 {
     GAGS_CLEAR_ERR();
-    if (d < 32 || d % 8 != 0) return 1;
+    if (d < 16 || d % 8 != 0) return 1;
     if (!row_base) n_rows = -1;
     const GeomLayout L = geom_layout(n_isects, width, height, n_gauss, d, n_rows);
     if (scratch_bytes < L.total) return GAGS_ESCRATCH;

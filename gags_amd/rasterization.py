@@ -402,7 +402,7 @@ class _Rasterize(torch.autograd.Function):
 
 def _geom_mfma_width(d):
     """Widths whose geometry gradients run through gags_raster_bwd_geom (below that the VALU kernel is faster)."""
-    return d >= 32 and d % 8 == 0 and d <= 1024
+    return d >= 16 and d % 8 == 0 and d <= 1024
 
 
 def _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height, xflag=0,

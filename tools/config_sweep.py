@@ -75,7 +75,7 @@ CASES = [
     ("C3 ALL gradients, fp32 matrix instructions (rounds 1-2's kernels)", C3 + (512,), dict(full_grad=True, flags=64)),
     ("C3 ALL gradients, VALU + atomics backward (what round 1 ran)", C3 + (512,), dict(full_grad=True, flags=4, steps=3)),
     ("C2 500k/1280x720/D=128, ALL gradients", (500_000, 1280, 720, 128), dict(full_grad=True)),
-    ("C3 geometry D=16, ALL gradients (VALU kernels)", C3 + (16,), dict(full_grad=True)),
+    ("C3 geometry D=16, ALL gradients", C3 + (16,), dict(full_grad=True)),
 ]
 sel = sys.argv[1] if len(sys.argv) > 1 else ""   # substring filter
 out = dict(run(name, *shape, **kw) for name, shape, kw in CASES if sel in name)
