@@ -103,22 +103,34 @@ __device__ __forceinline__ void layer_main(f32x16 (&acc)[2][2], WFrag &f, const 
 __device__ __forceinline__ void epilogue_hidden(const f32x16 (&acc)[2][2], const float *__restrict__ bias, int n_base, Tile out,
                                                 int lane, unsigned *__restrict__ mask, int64_t p0, int64_t P, int poff)
 {
+    // 64 values per lane and layer: this epilogue costs more issue slots than the layer's MFMAs (timestamps, round 3), so
+    // it runs on packed instructions: v_pk_add_f32 (bias), v_cvt_pk_bf16_f32, then the ReLU on the PAIR -- v_pk_max_i16
+    // with 0 (a negative bf16 is a negative int16; rounding first and clamping second gives the same bits) -- and the
+    // ReLU decisions from v_pk_min_u16(pair, 1).  (Written as inline asm: the builtins' IEEE semantics expand to compares.)
     const int p = lane & 31, h = lane >> 5;
     unsigned bits[2][2] = {{0u, 0u}, {0u, 0u}};
+    const unsigned one2 = 0x00010001u;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int n = n_base + 32 * i + 8 * g + 4 * h;
             const float4 b = *reinterpret_cast<const float4 *>(bias + n);
+            const ff32x2_t b01 = {b.x, b.y}, b23 = {b.z, b.w};
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const float v0 = fmaxf(acc[i][j][4 * g] + b.x, 0.f), v1 = fmaxf(acc[i][j][4 * g + 1] + b.y, 0.f);
-                const float v2 = fmaxf(acc[i][j][4 * g + 2] + b.z, 0.f), v3 = fmaxf(acc[i][j][4 * g + 3] + b.w, 0.f);
-                const unsigned u0 = fpack(v0, v1), u1 = fpack(v2, v3);
+                const ff32x2_t a01 = {acc[i][j][4 * g], acc[i][j][4 * g + 1]}, a23 = {acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                const ff32x2_t v01 = a01 + b01, v23 = a23 + b23;
+                unsigned u0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v01, fbf16x2_t));
+                unsigned u1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v23, fbf16x2_t));
+                unsigned m0, m1;
+                asm("v_pk_max_i16 %0, %1, 0" : "=v"(u0) : "v"(u0));
+                asm("v_pk_max_i16 %0, %1, 0" : "=v"(u1) : "v"(u1));
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(m0) : "v"(u0), "v"(one2));
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(m1) : "v"(u1), "v"(one2));
                 *reinterpret_cast<uint2 *>(&out[poff + 32 * j + p][n]) = make_uint2(u0, u1);
-                const unsigned nib = ((u0 & 0x7fffu) ? 1u : 0u) | ((u0 & 0x7fff0000u) ? 2u : 0u) | ((u1 & 0x7fffu) ? 4u : 0u) |
-                                     ((u1 & 0x7fff0000u) ? 8u : 0u);
+                // m = bit 0 and bit 16 -> nibble bits 0..3
+                const unsigned nib = ((m0 | (m0 >> 15)) & 3u) | (((m1 | (m1 >> 15)) & 3u) << 2);
                 bits[i][j] |= nib << (8 * g);
             }
         }
@@ -182,37 +194,57 @@ __global__ __launch_bounds__(256 * PH, 2 / PH) void decoder_fwd_fused_kernel(Fwd
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, poff = FT * (tid >> 8);
     const int64_t p0 = (int64_t)blockIdx.x * TP;
     const int n_base = 64 * wave;
+    // the eight hidden layers' biases, staged once: read from global memory inside an epilogue they queue up BEHIND the
+    // next layer's prefetched weight fragments (loads return in order) and the epilogue stands still for that long
+    __shared__ __attribute__((aligned(16))) float bias_s[8][FH];
+    {
+        float bv[8 * FH / NT];
+#pragma unroll
+        for (int q = 0; q < 8 * FH / NT; ++q) { const int e = tid + NT * q; bv[q] = a.b[e >> 8][e & (FH - 1)]; }
+#pragma unroll
+        for (int q = 0; q < 8 * FH / NT; ++q) { const int e = tid + NT * q; bias_s[e >> 8][e & (FH - 1)] = bv[q]; }
+    }
     f32x16 acc[2][2];
     WFrag wf;
     wprefetch(wf, a.W[0], 2, 2 * wave, 0, 2, lane);
 
     // input tile -> bufB[p][0..31] bf16 (zero-padded), also kept as a0 for the first layer's weight gradient
-    for (int e = tid; e < TP * 32; e += NT) {
-        const int row = e >> 5, c = e & 31;
-        const int64_t p = p0 + row;
-        const float v = (p < a.P && c < a.c_in) ? a.x[p * a.c_in + c] : 0.f;
-        const unsigned short hv = (unsigned short)(fpack(v, 0.f) & 0xffffu);
-        bufB[row][c] = hv;
-        if (a.act[0] && p < a.P) a.act[0][p * 32 + c] = hv;
+    {   // (all eight requests first, addresses clamped: a load inside the bounds check is waited for on the spot, and the
+        // eight round trips of a thread queue up behind one another)
+        float xv[TP * 32 / NT];
+#pragma unroll
+        for (int q = 0; q < TP * 32 / NT; ++q) {
+            const int e = tid + NT * q, row = e >> 5, c = e & 31;
+            xv[q] = a.x[min(p0 + row, a.P - 1) * a.c_in + min(c, a.c_in - 1)];
+        }
+#pragma unroll
+        for (int q = 0; q < TP * 32 / NT; ++q) {
+            const int e = tid + NT * q, row = e >> 5, c = e & 31;
+            const int64_t p = p0 + row;
+            const float v = (p < a.P && c < a.c_in) ? xv[q] : 0.f;
+            const unsigned short hv = (unsigned short)(fpack(v, 0.f) & 0xffffu);
+            bufB[row][c] = hv;
+            if (a.act[0] && p < a.P) a.act[0][p * 32 + c] = hv;
+        }
     }
     __syncthreads();
     // L0: a0 (B) -> x1 (A)
     layer_main(acc, wf, a.W[0], 2, 2 * wave, 0, 2, bufB, lane, true, poff);
     wprefetch(wf, a.W[1], 16, 2 * wave, 0, 16, lane);
-    epilogue_hidden(acc, a.b[0], n_base, bufA, lane, a.mask[1], p0, a.P, poff);
+    epilogue_hidden(acc, bias_s[0], n_base, bufA, lane, a.mask[1], p0, a.P, poff);
     __syncthreads();
     store_tile<NT>(a.act[1], p0, a.P, bufA, tid);
     // L1: x1 (A) -> t1 (B)
     layer_main(acc, wf, a.W[1], 16, 2 * wave, 0, 16, bufA, lane, true, poff);
     wprefetch(wf, a.W[2], 16, 2 * wave, 0, 16, lane);
-    epilogue_hidden(acc, a.b[1], n_base, bufB, lane, a.mask[2], p0, a.P, poff);
+    epilogue_hidden(acc, bias_s[1], n_base, bufB, lane, a.mask[2], p0, a.P, poff);
     __syncthreads();
     store_tile<NT>(a.act[2], p0, a.P, bufB, tid);
     // L2: t1 (B) -> x2, written over t1 once every wave is done reading it; then A = x1 + x2
     layer_main(acc, wf, a.W[2], 16, 2 * wave, 0, 16, bufB, lane, true, poff);
     wprefetch(wf, a.W[3], 16, 2 * wave, 0, 16, lane);
     __syncthreads();
-    epilogue_hidden(acc, a.b[2], n_base, bufB, lane, a.mask[3], p0, a.P, poff);
+    epilogue_hidden(acc, bias_s[2], n_base, bufB, lane, a.mask[3], p0, a.P, poff);
     __syncthreads();
     store_tile<NT>(a.act[3], p0, a.P, bufB, tid);
     add_tile<NT>(bufA, bufB, tid);
@@ -220,20 +252,20 @@ __global__ __launch_bounds__(256 * PH, 2 / PH) void decoder_fwd_fused_kernel(Fwd
     // L3: x1 + x2 (A) -> x3 (B)
     layer_main(acc, wf, a.W[3], 16, 2 * wave, 0, 16, bufA, lane, true, poff);
     wprefetch(wf, a.W[4], 16, 2 * wave, 0, 16, lane);
-    epilogue_hidden(acc, a.b[3], n_base, bufB, lane, a.mask[4], p0, a.P, poff);
+    epilogue_hidden(acc, bias_s[3], n_base, bufB, lane, a.mask[4], p0, a.P, poff);
     __syncthreads();
     store_tile<NT>(a.act[4], p0, a.P, bufB, tid);
     // L4: x3 (B) -> t4 (A)
     layer_main(acc, wf, a.W[4], 16, 2 * wave, 0, 16, bufB, lane, true, poff);
     wprefetch(wf, a.W[5], 16, 2 * wave, 0, 16, lane);
-    epilogue_hidden(acc, a.b[4], n_base, bufA, lane, a.mask[5], p0, a.P, poff);
+    epilogue_hidden(acc, bias_s[4], n_base, bufA, lane, a.mask[5], p0, a.P, poff);
     __syncthreads();
     store_tile<NT>(a.act[5], p0, a.P, bufA, tid);
     // L5: t4 (A) -> x4 over t4; then B = x3 + x4
     layer_main(acc, wf, a.W[5], 16, 2 * wave, 0, 16, bufA, lane, true, poff);
     wprefetch(wf, a.W[6], 16, 2 * wave, 0, 16, lane);
     __syncthreads();
-    epilogue_hidden(acc, a.b[5], n_base, bufA, lane, a.mask[6], p0, a.P, poff);
+    epilogue_hidden(acc, bias_s[5], n_base, bufA, lane, a.mask[6], p0, a.P, poff);
     __syncthreads();
     store_tile<NT>(a.act[6], p0, a.P, bufA, tid);
     add_tile<NT>(bufB, bufA, tid);
@@ -241,12 +273,12 @@ __global__ __launch_bounds__(256 * PH, 2 / PH) void decoder_fwd_fused_kernel(Fwd
     // L6: x3 + x4 (B) -> t6 (A)
     layer_main(acc, wf, a.W[6], 16, 2 * wave, 0, 16, bufB, lane, true, poff);
     wprefetch(wf, a.W[7], 16, 2 * wave, 0, 16, lane);
-    epilogue_hidden(acc, a.b[6], n_base, bufA, lane, a.mask[7], p0, a.P, poff);
+    epilogue_hidden(acc, bias_s[6], n_base, bufA, lane, a.mask[7], p0, a.P, poff);
     __syncthreads();
     store_tile<NT>(a.act[7], p0, a.P, bufA, tid);
     // L7: t6 (A) -> t7 (B)
     layer_main(acc, wf, a.W[7], 16, 2 * wave, 0, 16, bufA, lane, true, poff);
-    epilogue_hidden(acc, a.b[7], n_base, bufB, lane, a.mask[8], p0, a.P, poff);
+    epilogue_hidden(acc, bias_s[7], n_base, bufB, lane, a.mask[8], p0, a.P, poff);
     __syncthreads();
     store_tile<NT>(a.act[8], p0, a.P, bufB, tid);
     // L8: t7 (B) -> fp32 logits [P, n_last], 256 channels per pass.  Stored straight from the accumulators every
@@ -374,7 +406,8 @@ __global__ __launch_bounds__(256 * PH, 2 / PH) void decoder_bwd_fused_kernel(Bwd
     const int n_base = 64 * wave;
     f32x16 acc[2][2];
     uint2 skip[2][4][2];  // the skip gradient in flight (g36, later g13): this lane's own 32 values, packed bf16
-    unsigned mw[2][2];
+    unsigned mw[2][2], mw2[2][2];  // ReLU masks of the layer in hand and of the next one down (requested one layer early:
+                                   // a load issued right before a layer's weight stream holds up every refill behind it)
     uint4 slab[8];
     WFrag wf;
 
@@ -389,55 +422,55 @@ __global__ __launch_bounds__(256 * PH, 2 / PH) void decoder_bwd_fused_kernel(Bwd
         layer_main(acc, wf, a.Wt[8], a.n_last / 16, 2 * wave, kb / 16, 16, X, lane, kb == 0, poff);
     }
     wprefetch(wf, a.Wt[7], 16, 2 * wave, 0, 16, lane);
+    fetch_mask(mw2, a.mask[7], p0, a.P, wave, lane, poff);
     epilogue_dgrad<false, false>(acc, n_base, mw, Y, skip, lane, poff);
     __syncthreads();
     store_tile<NT>(a.dz[7], p0, a.P, Y, tid);
     // L7: dz7 (Y) -> dz6 (X)
-    fetch_mask(mw, a.mask[7], p0, a.P, wave, lane, poff);
     layer_main(acc, wf, a.Wt[7], 16, 2 * wave, 0, 16, Y, lane, true, poff);
     wprefetch(wf, a.Wt[6], 16, 2 * wave, 0, 16, lane);
-    epilogue_dgrad<false, false>(acc, n_base, mw, X, skip, lane, poff);
+    fetch_mask(mw, a.mask[6], p0, a.P, wave, lane, poff);
+    epilogue_dgrad<false, false>(acc, n_base, mw2, X, skip, lane, poff);
     __syncthreads();
     store_tile<NT>(a.dz[6], p0, a.P, X, tid);
     // L6: dz6 (X) -> g36 (kept), dz5 = g36 * [x4 > 0] (Y)
-    fetch_mask(mw, a.mask[6], p0, a.P, wave, lane, poff);
     layer_main(acc, wf, a.Wt[6], 16, 2 * wave, 0, 16, X, lane, true, poff);
     wprefetch(wf, a.Wt[5], 16, 2 * wave, 0, 16, lane);
+    fetch_mask(mw2, a.mask[5], p0, a.P, wave, lane, poff);
     epilogue_dgrad<true, false>(acc, n_base, mw, Y, skip, lane, poff);
     __syncthreads();
     store_tile<NT>(a.dz[5], p0, a.P, Y, tid);
     // L5: dz5 (Y) -> dz4 (X)
-    fetch_mask(mw, a.mask[5], p0, a.P, wave, lane, poff);
     layer_main(acc, wf, a.Wt[5], 16, 2 * wave, 0, 16, Y, lane, true, poff);
     wprefetch(wf, a.Wt[4], 16, 2 * wave, 0, 16, lane);
-    epilogue_dgrad<false, false>(acc, n_base, mw, X, skip, lane, poff);
+    fetch_mask(mw, a.mask[4], p0, a.P, wave, lane, poff);
+    epilogue_dgrad<false, false>(acc, n_base, mw2, X, skip, lane, poff);
     __syncthreads();
     store_tile<NT>(a.dz[4], p0, a.P, X, tid);
     // L4: dz4 (X) + g36 -> dz3 (Y)
-    fetch_mask(mw, a.mask[4], p0, a.P, wave, lane, poff);
     layer_main(acc, wf, a.Wt[4], 16, 2 * wave, 0, 16, X, lane, true, poff);
     wprefetch(wf, a.Wt[3], 16, 2 * wave, 0, 16, lane);
+    fetch_mask(mw2, a.mask[3], p0, a.P, wave, lane, poff);
     epilogue_dgrad<false, true>(acc, n_base, mw, Y, skip, lane, poff);
     __syncthreads();
     store_tile<NT>(a.dz[3], p0, a.P, Y, tid);
     // L3: dz3 (Y) -> g13 (kept), dz2 = g13 * [x2 > 0] (X)
-    fetch_mask(mw, a.mask[3], p0, a.P, wave, lane, poff);
     layer_main(acc, wf, a.Wt[3], 16, 2 * wave, 0, 16, Y, lane, true, poff);
     wprefetch(wf, a.Wt[2], 16, 2 * wave, 0, 16, lane);
-    epilogue_dgrad<true, false>(acc, n_base, mw, X, skip, lane, poff);
+    fetch_mask(mw, a.mask[2], p0, a.P, wave, lane, poff);
+    epilogue_dgrad<true, false>(acc, n_base, mw2, X, skip, lane, poff);
     __syncthreads();
     store_tile<NT>(a.dz[2], p0, a.P, X, tid);
     // L2: dz2 (X) -> dz1 (Y)
-    fetch_mask(mw, a.mask[2], p0, a.P, wave, lane, poff);
     layer_main(acc, wf, a.Wt[2], 16, 2 * wave, 0, 16, X, lane, true, poff);
     wprefetch(wf, a.Wt[1], 16, 2 * wave, 0, 16, lane);
+    fetch_mask(mw2, a.mask[1], p0, a.P, wave, lane, poff);
     epilogue_dgrad<false, false>(acc, n_base, mw, Y, skip, lane, poff);
     __syncthreads();
     store_tile<NT>(a.dz[1], p0, a.P, Y, tid);
     // L1: dz1 (Y) + g13 -> dz0 (X)
-    fetch_mask(mw, a.mask[1], p0, a.P, wave, lane, poff);
     layer_main(acc, wf, a.Wt[1], 16, 2 * wave, 0, 16, Y, lane, true, poff);
-    epilogue_dgrad<false, true>(acc, n_base, mw, X, skip, lane, poff);
+    epilogue_dgrad<false, true>(acc, n_base, mw2, X, skip, lane, poff);
     __syncthreads();
     store_tile<NT>(a.dz[0], p0, a.P, X, tid);
     // L0: d x[p][c] = sum_n dz0[p][n] W0[n][c]: 32 (padded) channels x 64 pixels = two accumulator tiles, waves 0 and 1;
