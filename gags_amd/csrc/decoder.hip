@@ -1139,7 +1139,7 @@ inline bool narrow_shape(int n_out, int k_in)
     return (nb == 1 && (kb == 1 || kb == 2 || kb == 4 || kb == 8)) || (nb == 2 && (kb == 1 || kb == 2 || kb == 4)) ||
            (nb == 4 && (kb == 1 || kb == 2)) || (nb == 8 && kb == 1);
 }
-inline int64_t w256_chunk(int64_t n_pix) { return ((n_pix + 511) / 512 + W2P - 1) / W2P * W2P; }
+inline int64_t w256_chunk(int64_t n_pix) { return ((n_pix + 255) / 256 + W2P - 1) / W2P * W2P; }
 inline int wgrad_plan(int64_t n_pix, int n_out, int k_in, int64_t &parts)
 {
     if (narrow_shape(n_out, k_in)) { parts = narrow_parts(n_pix); return WG_NARROW; }
