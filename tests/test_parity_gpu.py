@@ -515,6 +515,46 @@ def test_wide_geometry_backward_on_both_matrix_pipes_and_under_rescaling():
         np.testing.assert_array_equal(gc[k], g16[k] * np.float32(4096.0))
 
 
+def test_full_backward_with_more_than_1024_slots_in_one_block(oracle):
+    """A block that blends more Gaussians than the dot pass stages in LDS (SF_STAGE = 1024 slot ids and scales per 8x8
+    block): the remaining slots take their ids and scales from memory.  1800 faint Gaussians (alpha ~ 1/170: the
+    transmittance never reaches the 1e-4 stop) piled onto a handful of pixels, D = 40 (one 32-channel step + a ragged one).
+    Reference: float64 autograd through the dense restatement -- the gsplat-order fp32 backward rebuilds T by 1800
+    successive divisions and is itself ~1e-4 off on such a pile (asserted: the HIP gradients are closer)."""
+    from oracle import dense_ref as dr
+    n, w, h, d = 1800, 64, 48, 40
+    s = scene_arrays(n, d, w, h, seed=41, view=None, scale_mult=1.0)
+    rng = np.random.default_rng(41)
+    s["means"] = np.tile(np.array([[0.02, 0.03, 6.0]], np.float32), (n, 1)) + rng.normal(0, 0.004, (n, 3)).astype(np.float32)
+    s["scales"] = np.full((n, 3), 0.012, np.float32) * rng.uniform(0.8, 1.25, (n, 3)).astype(np.float32)
+    s["opacities"] = np.full(n, 0.0065, np.float32) * rng.uniform(0.9, 1.1, n).astype(np.float32)
+    bg = np.full(d, 0.1, np.float32)
+    v_out = rng.standard_normal((h, w, d)).astype(np.float32)
+    v_alpha = rng.standard_normal((h, w)).astype(np.float32)
+    o_out, o_alpha, oi = oracle.rasterization(s["means"], s["quats"], s["scales"], s["opacities"], s["colors"],
+                                              s["viewmat"], s["K"], bg, w, h)
+    o_vc, o_vo, o_vm2, _ = oracle.raster_bwd(oi["means2d"], oi["conics"], s["opacities"], s["colors"], bg, w, h,
+                                             oi["isect_offsets"], oi["flatten_ids"], o_alpha, oi["last_ids"], v_out, v_alpha)
+    # the pile really is deeper than the staged part
+    counts = np.diff(np.asarray(oi["isect_offsets"]).reshape(-1))
+    assert counts.max() > 1200 and float(o_alpha.max()) > 0.99
+
+    def tm(a, rg=False):
+        return torch.tensor(np.asarray(a), dtype=torch.float64, requires_grad=rg)
+
+    C, M2, OP = tm(s["colors"], True), tm(oi["means2d"], True), tm(s["opacities"], True)
+    order = np.lexsort((np.arange(n), oi["depths"]))
+    o2, a2, _, ninc = dr.composite(M2, tm(oi["conics"]), OP, C, tm(bg), w, h, oi["radii"], order)
+    assert ninc == oi["n_blend"]
+    ((o2 * tm(v_out)).sum() + (a2 * tm(v_alpha)).sum()).backward()
+    out, alpha, info, g = _run_gpu(s, w, h, s["colors"], bg, need_geom=True, v_out=v_out, v_alpha=v_alpha)
+    np.testing.assert_array_equal(out, o_out)
+    for name, got, want, orc in (("colors", g["colors"], C.grad.numpy(), o_vc), ("opacities", g["opacities"], OP.grad.numpy(), o_vo),
+                                 ("means2d", g["means2d"], M2.grad.numpy(), o_vm2)):
+        e, e_orc = rel_l2(got, want), rel_l2(orc, want)
+        assert e <= 5e-6 and e <= e_orc, (name, e, e_orc)
+
+
 def test_wide_geometry_backward_with_nothing_to_render():
     """Degenerate inputs through the matrix-core geometry path: every Gaussian behind the camera (no intersections at
     all), and a view that only a handful of Gaussians reach -- gradients are exact zeros where nothing blended."""
