@@ -80,7 +80,20 @@ __global__ __launch_bounds__(256) void dot_partial_kernel(int64_t n, const float
     __shared__ double sm[4];
     const int64_t n4 = n >> 2, stride = (int64_t)DOT_BLOCKS * 256;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {  // eight 16-byte requests per thread in flight
+        float4 u[4], v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            u[q] = reinterpret_cast<const float4 *>(x)[i + q * stride];
+            v[q] = reinterpret_cast<const float4 *>(y)[i + q * stride];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            a0 = fmaf(u[q].x, v[q].x, a0); a1 = fmaf(u[q].y, v[q].y, a1); a2 = fmaf(u[q].z, v[q].z, a2); a3 = fmaf(u[q].w, v[q].w, a3);
+        }
+    }
+    for (; i < n4; i += stride) {
         const float4 u = reinterpret_cast<const float4 *>(x)[i], v = reinterpret_cast<const float4 *>(y)[i];
         a0 = fmaf(u.x, v.x, a0); a1 = fmaf(u.y, v.y, a1); a2 = fmaf(u.z, v.z, a2); a3 = fmaf(u.w, v.w, a3);
     }
