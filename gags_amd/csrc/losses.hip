@@ -68,49 +68,82 @@ __device__ __forceinline__ float seg_wave_sum(float v)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// FOUR consecutive pixels per lane (one 16-byte load per channel): on real segment maps (large regions) a wave of 256
+// pixels still meets one or two ids, so rounds, wave sums and double atomics are a quarter as many per pixel.  (The
+// synthetic map of tools/decoder_bench.py draws a random id per 8x8 block -- 32 ids per wave -- and is bound by the
+// rounds' wave sums either way: 0.5 ms per call at 1080p, c = 16.)
 __global__ __launch_bounds__(256) void segment_stats_kernel(int64_t n_pix, int c, const float *__restrict__ x,
                                                             const float *__restrict__ seg, int n_seg,
                                                             double *__restrict__ s1, double *__restrict__ s2,
-                                                            int32_t *__restrict__ cnt)
+                                                            int32_t *__restrict__ cnt, int vec)
 {
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     const int lane = threadIdx.x & 63;
-    int id = -1;
-    if (p < n_pix) {
-        const float f = seg[p];
-        id = (f >= 0.f && f < (float)n_seg) ? (int)f : -1;
-    }
-    const int64_t pc = min(p, n_pix - 1);
-    // one round per distinct segment id in the wave (neighbouring pixels mostly share one): the wave's 64 values of a
-    // channel are summed pairwise in fp32 on the VALU (the sums over many waves are the ones that need doubles) and
-    // the leader issues ONE double atomic per moment.  Channels in groups of 16 held in registers: read once.
-    for (int cb = 0; cb < c; cb += 16) {
-        float xv[16];
+    int id[4];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) xv[j] = x[(size_t)min(cb + j, c - 1) * n_pix + pc];
-        unsigned long long todo = __ballot(id >= 0);
+    for (int q = 0; q < 4; ++q) {
+        id[q] = -1;
+        if (p0 + q < n_pix) {
+            const float f = seg[p0 + q];
+            id[q] = (f >= 0.f && f < (float)n_seg) ? (int)f : -1;
+        }
+    }
+    // one round per distinct segment id in the wave: the group's values of a channel are summed in fp32 on the VALU (in
+    // the lane, then pairwise over the wave; the sums over many waves are the ones that need doubles) and the leader
+    // issues ONE double atomic per moment.  Channels in groups of 8 held in registers: read once.
+    for (int cb = 0; cb < c; cb += 8) {
+        float xv[8][4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float *row = x + (size_t)min(cb + j, c - 1) * n_pix;
+            if (vec) {  // n_pix % 4 == 0 and a 16-byte aligned base: every row is aligned (uniform)
+                const float4 t = *reinterpret_cast<const float4 *>(row + min(p0, n_pix - 4));
+                xv[j][0] = t.x; xv[j][1] = t.y; xv[j][2] = t.z; xv[j][3] = t.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xv[j][q] = row[min(p0 + q, n_pix - 1)];
+            }
+        }
+        unsigned pend = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pend |= (id[q] >= 0 ? 1u : 0u) << q;
+        unsigned long long todo = __ballot(pend != 0);
         while (todo) {
             const int leader = __ffsll((long long)todo) - 1;
-            const int cur = __builtin_amdgcn_readlane(id, leader);
-            const unsigned long long grp = __ballot(id == cur);
-            const bool in = id == cur;
-            if (cb == 0 && lane == leader) atomicAdd(&cnt[cur], (int)__popcll(grp));
-            const double ng = (double)__popcll(grp);
+            const int fq = __ffs((int)pend) - 1;  // this lane's first pending pixel (-1: none)
+            const int first_id = fq == 0 ? id[0] : fq == 1 ? id[1] : fq == 2 ? id[2] : id[3];
+            const int cur = __builtin_amdgcn_readlane(first_id, leader);
+            const int lq = __builtin_amdgcn_readlane(fq, leader);
+            unsigned in = 0;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                // moments of the group about one of its OWN values (the leader's): the fp32 wave sums then carry the
+            for (int q = 0; q < 4; ++q) in |= ((pend >> q & 1u) && id[q] == cur ? 1u : 0u) << q;
+            int n_in = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) n_in += (int)__popcll(__ballot((in >> q & 1u) != 0));
+            if (cb == 0 && lane == leader) atomicAdd(&cnt[cur], n_in);
+            const double ng = (double)n_in;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                // moments of the group about one of its OWN values (the leader's first pixel): the fp32 sums then carry the
                 // spread, not the mean, and the shift goes back in double -- sum x^2 - (sum x)^2 / n used to cancel in fp32
                 // rounding once a region's variance fell below ~1e-7 mean^2, which is where this loss drives it
-                const float sft = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv[j]), leader));
-                const float v = in ? xv[j] - sft : 0.f;
-                const float a = seg_wave_sum(v), b = seg_wave_sum(v * v);
+                const float mine = lq == 0 ? xv[j][0] : lq == 1 ? xv[j][1] : lq == 2 ? xv[j][2] : xv[j][3];
+                const float sft = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), leader));
+                float v = 0.f, vv = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float t = (in >> q & 1u) ? xv[j][q] - sft : 0.f;
+                    v += t; vv = fmaf(t, t, vv);
+                }
+                const float a = seg_wave_sum(v), b = seg_wave_sum(vv);
                 if (lane == leader && cb + j < c) {
                     const double sd = (double)sft, ad = (double)a;
                     atomicAdd(&s1[(size_t)cur * c + cb + j], ad + ng * sd);
                     atomicAdd(&s2[(size_t)cur * c + cb + j], (double)b + 2.0 * sd * ad + ng * sd * sd);
                 }
             }
-            todo &= ~grp;
+            pend &= ~in;
+            todo = __ballot(pend != 0);
         }
     }
 }
@@ -655,8 +688,9 @@ extern "C" int gags_segment_stats(int64_t n_pix, int c, const float *x, const fl
     GAGS_CLEAR_ERR();
     if (n_pix < 0 || c <= 0 || n_seg <= 0 || !s1 || !s2 || !cnt || (n_pix > 0 && (!x || !seg))) return GAGS_EINVAL;
     if (n_pix == 0) return GAGS_OK;
-    hipLaunchKernelGGL(segment_stats_kernel, dim3(nblk(n_pix)), dim3(256), 0, (hipStream_t)stream, n_pix, c, x, seg, n_seg,
-                       s1, s2, cnt);
+    const int vec = (n_pix % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(segment_stats_kernel, dim3(nblk((n_pix + 3) / 4)), dim3(256), 0, (hipStream_t)stream, n_pix, c, x, seg, n_seg,
+                       s1, s2, cnt, vec);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }
