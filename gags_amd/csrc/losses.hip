@@ -75,8 +75,14 @@ __device__ __forceinline__ float seg_wave_sum(float v)
 __global__ __launch_bounds__(256) void segment_stats_kernel(int64_t n_pix, int c, const float *__restrict__ x,
                                                             const float *__restrict__ seg, int n_seg,
                                                             double *__restrict__ s1, double *__restrict__ s2,
-                                                            int32_t *__restrict__ cnt, int vec)
+                                                            int32_t *__restrict__ cnt, int vec, int copies)
 {
+    // `copies` private sets of accumulators, picked by workgroup: the double atomics execute at the memory side and
+    // serialize per ADDRESS (~0.5 us each) -- with a few hundred segments in the image every address takes ~900 of them
+    {
+        const size_t cp = blockIdx.x % (unsigned)copies;
+        s1 += cp * (size_t)n_seg * c; s2 += cp * (size_t)n_seg * c; cnt += cp * (size_t)n_seg;
+    }
     const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     const int lane = threadIdx.x & 63;
     int id[4];
@@ -682,17 +688,23 @@ extern "C" int gags_entropy_bwd(int64_t n, const float *s, float v_over_n, float
     return GAGS_OK;
 }
 
-extern "C" int gags_segment_stats(int64_t n_pix, int c, const float *x, const float *seg, int n_seg, double *s1, double *s2,
-                                  int32_t *cnt, void *stream)
+extern "C" int gags_segment_stats_multi(int64_t n_pix, int c, const float *x, const float *seg, int n_seg, int copies,
+                                        double *s1, double *s2, int32_t *cnt, void *stream)
 {
     GAGS_CLEAR_ERR();
-    if (n_pix < 0 || c <= 0 || n_seg <= 0 || !s1 || !s2 || !cnt || (n_pix > 0 && (!x || !seg))) return GAGS_EINVAL;
+    if (n_pix < 0 || c <= 0 || n_seg <= 0 || copies <= 0 || !s1 || !s2 || !cnt || (n_pix > 0 && (!x || !seg))) return GAGS_EINVAL;
     if (n_pix == 0) return GAGS_OK;
     const int vec = (n_pix % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) ? 1 : 0;
     hipLaunchKernelGGL(segment_stats_kernel, dim3(nblk((n_pix + 3) / 4)), dim3(256), 0, (hipStream_t)stream, n_pix, c, x, seg, n_seg,
-                       s1, s2, cnt, vec);
+                       s1, s2, cnt, vec, copies);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
+}
+
+extern "C" int gags_segment_stats(int64_t n_pix, int c, const float *x, const float *seg, int n_seg, double *s1, double *s2,
+                                  int32_t *cnt, void *stream)
+{
+    return gags_segment_stats_multi(n_pix, c, x, seg, n_seg, 1, s1, s2, cnt, stream);
 }
 
 extern "C" int gags_region_var_bwd(int64_t n_pix, int c, const float *x, const float *seg, int n_seg, const float *mean,

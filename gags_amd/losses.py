@@ -69,14 +69,18 @@ def scale_regulation_loss(scale_map):
     return _Entropy.apply(scale_map)
 
 
+_STAT_COPIES = 16  # private accumulator sets of gags_segment_stats_multi (the double atomics serialize per address)
+
+
 def _segment_stats(x, seg_map, n_seg):
     c, n_pix = x.shape[0], seg_map.numel()
-    s1 = torch.zeros(n_seg, c, dtype=torch.float64, device=x.device)
+    k = _STAT_COPIES if n_seg * c * _STAT_COPIES <= (1 << 22) else 1
+    s1 = torch.zeros(k, n_seg, c, dtype=torch.float64, device=x.device)
     s2 = torch.zeros_like(s1)
-    cnt = torch.zeros(n_seg, dtype=torch.int32, device=x.device)
-    check(_lib.load().gags_segment_stats(n_pix, c, ptr(x), ptr(seg_map), n_seg, ptr(s1), ptr(s2), ptr(cnt), _st()),
-          "gags_segment_stats")
-    return s1, s2, cnt
+    cnt = torch.zeros(k, n_seg, dtype=torch.int32, device=x.device)
+    check(_lib.load().gags_segment_stats_multi(n_pix, c, ptr(x), ptr(seg_map), n_seg, k, ptr(s1), ptr(s2), ptr(cnt), _st()),
+          "gags_segment_stats_multi")
+    return s1.sum(0), s2.sum(0), cnt.sum(0, dtype=torch.int32)
 
 
 class _ScaleBalance(torch.autograd.Function):

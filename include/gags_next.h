@@ -36,6 +36,11 @@ int gags_entropy_bwd(int64_t n, const float *s, float v_over_n, float *v_s, void
  * :117-133 scale_region_regulation_loss with c = the feature width). */
 int gags_segment_stats(int64_t n_pix, int c, const float *x, const float *seg, int n_seg, double *s1, double *s2,
                        int32_t *cnt, void *stream);
+/* The same with `copies` private accumulator sets s1 / s2 [copies, n_seg, c], cnt [copies, n_seg] (zero-filled by the
+ * caller, summed by the caller): a workgroup adds into set (block index mod copies).  The double atomics serialize per
+ * address at the memory side; with a few hundred segments per image that, not bandwidth, bounds the one-set kernel. */
+int gags_segment_stats_multi(int64_t n_pix, int c, const float *x, const float *seg, int n_seg, int copies, double *s1,
+                             double *s2, int32_t *cnt, void *stream);
 /* Backward of the region-variance loss: v_x[c, p] = coef[seg(p)] * (x[c, p] - mean[seg(p), c]), 0 outside segments. */
 int gags_region_var_bwd(int64_t n_pix, int c, const float *x, const float *seg, int n_seg, const float *mean,
                         const float *coef, float *v_x, void *stream);
