@@ -75,8 +75,9 @@ __device__ __forceinline__ float seg_wave_sum(float v)
 __global__ __launch_bounds__(256) void segment_stats_kernel(int64_t n_pix, int c, const float *__restrict__ x,
                                                             const float *__restrict__ seg, int n_seg,
                                                             double *__restrict__ s1, double *__restrict__ s2,
-                                                            int32_t *__restrict__ cnt, int vec, int copies)
-{
+                                                            int32_t *__restrict__ cnt, int vec, int copies, int pm)
+{   // pm: x is PIXEL-major [n_pix, c] (the rasterizer's own layout: the [C,H,W] map a loss receives is a permuted view of
+    // it, and `.contiguous()` on that view is a 132 MB copy per iteration at 1080p, c = 16); else channel-major [c, n_pix]
     // `copies` private sets of accumulators, picked by workgroup: the double atomics execute at the memory side and
     // serialize per ADDRESS (~0.5 us each) -- with a few hundred segments in the image every address takes ~900 of them
     {
@@ -101,8 +102,12 @@ __global__ __launch_bounds__(256) void segment_stats_kernel(int64_t n_pix, int c
         float xv[8][4];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float *row = x + (size_t)min(cb + j, c - 1) * n_pix;
-            if (vec) {  // n_pix % 4 == 0 and a 16-byte aligned base: every row is aligned (uniform)
+            const int ch = min(cb + j, c - 1);
+            const float *row = x + (size_t)ch * n_pix;
+            if (pm) {  // (a lane walks its pixels' rows channel by channel: every 64-byte line is used up over j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xv[j][q] = x[(size_t)min(p0 + q, n_pix - 1) * c + ch];
+            } else if (vec) {  // n_pix % 4 == 0 and a 16-byte aligned base: every row is aligned (uniform)
                 const float4 t = *reinterpret_cast<const float4 *>(row + min(p0, n_pix - 4));
                 xv[j][0] = t.x; xv[j][1] = t.y; xv[j][2] = t.z; xv[j][3] = t.w;
             } else {
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(256) void segment_stats_kernel(int64_t n_pix, int c
 __global__ __launch_bounds__(256) void region_var_bwd_kernel(int64_t n_pix, int c, const float *__restrict__ x,
                                                              const float *__restrict__ seg, int n_seg,
                                                              const float *__restrict__ mean, const float *__restrict__ coef,
-                                                             float *__restrict__ vx)
+                                                             float *__restrict__ vx, int pm)
 {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= n_pix) return;
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(256) void region_var_bwd_kernel(int64_t n_pix, int 
     const int id = (f >= 0.f && f < (float)n_seg) ? (int)f : -1;
     const float k = id >= 0 ? coef[id] : 0.f;
     for (int ch = 0; ch < c; ++ch) {
-        const size_t o = (size_t)ch * n_pix + p;
+        const size_t o = pm ? (size_t)p * c + ch : (size_t)ch * n_pix + p;  // pixel-major [n_pix, c] or channel-major
         vx[o] = id >= 0 ? k * (x[o] - mean[(size_t)id * c + ch]) : 0.f;
     }
 }
@@ -689,14 +694,16 @@ extern "C" int gags_entropy_bwd(int64_t n, const float *s, float v_over_n, float
 }
 
 extern "C" int gags_segment_stats_multi(int64_t n_pix, int c, const float *x, const float *seg, int n_seg, int copies,
-                                        double *s1, double *s2, int32_t *cnt, void *stream)
+                                        double *s1, double *s2, int32_t *cnt, int layout, void *stream)
 {
     GAGS_CLEAR_ERR();
-    if (n_pix < 0 || c <= 0 || n_seg <= 0 || copies <= 0 || !s1 || !s2 || !cnt || (n_pix > 0 && (!x || !seg))) return GAGS_EINVAL;
+    if (n_pix < 0 || c <= 0 || n_seg <= 0 || copies <= 0 || !s1 || !s2 || !cnt || (n_pix > 0 && (!x || !seg)) ||
+        (layout != 0 && layout != 1))
+        return GAGS_EINVAL;
     if (n_pix == 0) return GAGS_OK;
     const int vec = (n_pix % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) ? 1 : 0;
     hipLaunchKernelGGL(segment_stats_kernel, dim3(nblk((n_pix + 3) / 4)), dim3(256), 0, (hipStream_t)stream, n_pix, c, x, seg, n_seg,
-                       s1, s2, cnt, vec, copies);
+                       s1, s2, cnt, vec, copies, layout);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }
@@ -704,19 +711,26 @@ extern "C" int gags_segment_stats_multi(int64_t n_pix, int c, const float *x, co
 extern "C" int gags_segment_stats(int64_t n_pix, int c, const float *x, const float *seg, int n_seg, double *s1, double *s2,
                                   int32_t *cnt, void *stream)
 {
-    return gags_segment_stats_multi(n_pix, c, x, seg, n_seg, 1, s1, s2, cnt, stream);
+    return gags_segment_stats_multi(n_pix, c, x, seg, n_seg, 1, s1, s2, cnt, 0, stream);
+}
+
+extern "C" int gags_region_var_bwd_layout(int64_t n_pix, int c, const float *x, const float *seg, int n_seg, const float *mean,
+                                          const float *coef, float *v_x, int layout, void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (n_pix < 0 || c <= 0 || n_seg <= 0 || (n_pix > 0 && (!x || !seg || !mean || !coef || !v_x)) || (layout != 0 && layout != 1))
+        return GAGS_EINVAL;
+    if (n_pix == 0) return GAGS_OK;
+    hipLaunchKernelGGL(region_var_bwd_kernel, dim3(nblk(n_pix)), dim3(256), 0, (hipStream_t)stream, n_pix, c, x, seg, n_seg,
+                       mean, coef, v_x, layout);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
 }
 
 extern "C" int gags_region_var_bwd(int64_t n_pix, int c, const float *x, const float *seg, int n_seg, const float *mean,
                                    const float *coef, float *v_x, void *stream)
 {
-    GAGS_CLEAR_ERR();
-    if (n_pix < 0 || c <= 0 || n_seg <= 0 || (n_pix > 0 && (!x || !seg || !mean || !coef || !v_x))) return GAGS_EINVAL;
-    if (n_pix == 0) return GAGS_OK;
-    hipLaunchKernelGGL(region_var_bwd_kernel, dim3(nblk(n_pix)), dim3(256), 0, (hipStream_t)stream, n_pix, c, x, seg, n_seg,
-                       mean, coef, v_x);
-    GAGS_CHECK_LAUNCH();
-    return GAGS_OK;
+    return gags_region_var_bwd_layout(n_pix, c, x, seg, n_seg, mean, coef, v_x, 0, stream);
 }
 
 extern "C" int gags_gather_seg_coef(int64_t n_pix, const float *seg, int n_seg, const float *coef, float *out, void *stream)

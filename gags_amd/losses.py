@@ -72,14 +72,16 @@ def scale_regulation_loss(scale_map):
 _STAT_COPIES = 16  # private accumulator sets of gags_segment_stats_multi (the double atomics serialize per address)
 
 
-def _segment_stats(x, seg_map, n_seg):
-    c, n_pix = x.shape[0], seg_map.numel()
+def _segment_stats(x, seg_map, n_seg, pixel_major=False):
+    """x: [c, n_pix], or [n_pix, c] with pixel_major."""
+    n_pix = seg_map.numel()
+    c = x.shape[1] if pixel_major else x.shape[0]
     k = _STAT_COPIES if n_seg * c * _STAT_COPIES <= (1 << 22) else 1
     s1 = torch.zeros(k, n_seg, c, dtype=torch.float64, device=x.device)
     s2 = torch.zeros_like(s1)
     cnt = torch.zeros(k, n_seg, dtype=torch.int32, device=x.device)
-    check(_lib.load().gags_segment_stats_multi(n_pix, c, ptr(x), ptr(seg_map), n_seg, k, ptr(s1), ptr(s2), ptr(cnt), _st()),
-          "gags_segment_stats_multi")
+    check(_lib.load().gags_segment_stats_multi(n_pix, c, ptr(x), ptr(seg_map), n_seg, k, ptr(s1), ptr(s2), ptr(cnt),
+                                               1 if pixel_major else 0, _st()), "gags_segment_stats_multi")
     return s1.sum(0), s2.sum(0), cnt.sum(0, dtype=torch.int32)
 
 
@@ -116,10 +118,14 @@ def Scale_balance_loss(loss_map, seg_map, mask, scale_select_idx=1, mix_seg=Fals
 class _RegionVar(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, seg_map):
-        x, seg = _f(x), _f(seg_map)
+        seg = _f(seg_map)
         c, hh, ww = x.shape
+        # the rasterizer hands its [H,W,C] memory over as a [C,H,W] view: read it as it lies (pixel-major) instead of
+        # copying 132 MB into channel-major order every iteration
+        pm = x.is_cuda and x.dtype == torch.float32 and not x.is_contiguous() and x.permute(1, 2, 0).is_contiguous()
+        x = x.permute(1, 2, 0) if pm else _f(x)
         n_seg = _n_seg(seg)
-        s1, s2, cnt = _segment_stats(x.reshape(c, -1), seg.reshape(-1), n_seg)
+        s1, s2, cnt = _segment_stats(x.reshape(-1, c) if pm else x.reshape(c, -1), seg.reshape(-1), n_seg, pixel_major=pm)
         n = cnt.double()
         ok = cnt >= 2  # segments of 0 or 1 pixels are skipped (loss_utils.py:124-125)
         nn = torch.where(ok, n, torch.full_like(n, 2.0))
@@ -131,16 +137,17 @@ class _RegionVar(torch.autograd.Function):
         loss = per_seg.sum() / (hh * ww)
         coef = torch.where(ok, 2.0 * nn / ((nn - 1.0) * c * hh * ww), torch.zeros_like(nn))
         ctx.save_for_backward(x, seg, mean.float().contiguous(), coef.float())
-        ctx.n_seg = n_seg
+        ctx.n_seg, ctx.pm, ctx.c = n_seg, pm, c
         return loss.float()
 
     @staticmethod
     def backward(ctx, v):
         x, seg, mean, coef = ctx.saved_tensors
-        vx = torch.empty_like(x)
-        check(_lib.load().gags_region_var_bwd(seg.numel(), x.shape[0], ptr(x), ptr(seg), ctx.n_seg, ptr(mean),
-                                              ptr((coef * v).contiguous()), ptr(vx), _st()), "gags_region_var_bwd")
-        return vx, None
+        vx = torch.empty_like(x)  # (pixel-major input: [H,W,C] memory, returned as the [C,H,W] view of it)
+        check(_lib.load().gags_region_var_bwd_layout(seg.numel(), ctx.c, ptr(x), ptr(seg), ctx.n_seg, ptr(mean),
+                                                     ptr((coef * v).contiguous()), ptr(vx), 1 if ctx.pm else 0, _st()),
+              "gags_region_var_bwd_layout")
+        return (vx.permute(2, 0, 1) if ctx.pm else vx), None
 
 
 def scale_region_regulation_loss(scale_map, seg_map, scale_bal_idx=1, mix_seg=False):

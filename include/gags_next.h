@@ -38,12 +38,16 @@ int gags_segment_stats(int64_t n_pix, int c, const float *x, const float *seg, i
                        int32_t *cnt, void *stream);
 /* The same with `copies` private accumulator sets s1 / s2 [copies, n_seg, c], cnt [copies, n_seg] (zero-filled by the
  * caller, summed by the caller): a workgroup adds into set (block index mod copies).  The double atomics serialize per
- * address at the memory side; with a few hundred segments per image that, not bandwidth, bounds the one-set kernel. */
+ * address at the memory side; with a few hundred segments per image that, not bandwidth, bounds the one-set kernel.
+ * layout 1: x is pixel-major [n_pix, c] (the rasterizer's own memory under the [C,H,W] view: no `.contiguous()` copy). */
 int gags_segment_stats_multi(int64_t n_pix, int c, const float *x, const float *seg, int n_seg, int copies, double *s1,
-                             double *s2, int32_t *cnt, void *stream);
+                             double *s2, int32_t *cnt, int layout, void *stream);
 /* Backward of the region-variance loss: v_x[c, p] = coef[seg(p)] * (x[c, p] - mean[seg(p), c]), 0 outside segments. */
 int gags_region_var_bwd(int64_t n_pix, int c, const float *x, const float *seg, int n_seg, const float *mean,
                         const float *coef, float *v_x, void *stream);
+/* ... with x and v_x pixel-major [n_pix, c] when layout = 1. */
+int gags_region_var_bwd_layout(int64_t n_pix, int c, const float *x, const float *seg, int n_seg, const float *mean,
+                               const float *coef, float *v_x, int layout, void *stream);
 /* Backward of the segment-balanced mean: out[p] = coef[seg(p)], 0 outside segments. */
 int gags_gather_seg_coef(int64_t n_pix, const float *seg, int n_seg, const float *coef, float *out, void *stream);
 
