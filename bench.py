@@ -510,7 +510,7 @@ def main():
                 q.grad = None
             line["all_gradients"] = {
                 "note": "same workload, gradients of features AND means, quats, scales, opacities (SURVEY A9 + K2): geometry "
-                        "dot products on the fp32 matrix cores (gags_raster_bwd_geom), no atomics",
+                        "dot products on the 16-bit matrix cores with fp32-equivalent split operands (gags_raster_bwd_geom), no atomics",
                 "value": gsteps / gdt, "unit": "views/s", "ms_per_step": 1e3 * gdt / gsteps, "steps": gsteps}
         if world == 1 and args.config == "C3" and not (args.no_heavy or args.n or args.d):
             # second reading of SURVEY 8d (gags_amd/synthetic.py): same N / resolution / D, ~4.4x larger splats
