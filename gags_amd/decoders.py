@@ -221,6 +221,14 @@ def _fusable(wb, c_in):
             and shapes[8][1] == 256 and shapes[8][0] % 256 == 0)
 
 
+_SCALE_SHAPES = [(64, 32), (128, 64), (64, 128), (32, 64), (32, 32), (32, 32)]  # CNN_scale_decoder, padded to 32s
+
+
+def _scale_fusable(wb, c_in):
+    """The reference's CNN_scale_decoder shape (16 -> 64 -> 128 -> 64 -> 32 -> 16 -> 3): csrc/decoder_scale.hip."""
+    return c_in <= 32 and [tuple(w.shape) for w, _ in wb] == _SCALE_SHAPES
+
+
 def _chain_forward(x, kind, params):
     """The GEMM chain of a decoder up to its fp32 logits.  Returns (logits [P, ld], activations, packed weights, h, w,
     c_in)."""
@@ -229,6 +237,18 @@ def _chain_forward(x, kind, params):
     xp, h, w = _pixel_major(x)
     p = h * w
     a0 = torch.empty(p, wb[0][0].shape[1], dtype=torch.bfloat16, device=x.device)
+    if kind == "scale" and FUSED and _scale_fusable(wb, xp.shape[1]):
+        # the six layers in one kernel, a wave per 32-pixel tile (csrc/decoder_scale.hip): bit-identical to the chain below
+        dev = x.device
+        acts = [a0] + [torch.empty(p, wgt.shape[0], dtype=torch.bfloat16, device=dev) for wgt, _ in wb[:5]]
+        logits = torch.empty(p, 32, device=dev)
+        arr = ctypes.c_void_p * 6
+        wf = [_frag_layout(wgt) for wgt, _ in wb]
+        masks = torch.empty(p, 11, dtype=torch.int32, device=dev)  # the ReLU decisions as bits, for the fused backward
+        check(_lib.load().gags_scale_decoder_fwd_fused(p, xp.shape[1], ptr(xp), arr(*[t.data_ptr() for t in wf]),
+                                                       arr(*[b.data_ptr() for _, b in wb]), arr(*[t.data_ptr() for t in acts]),
+                                                       ptr(masks), ptr(logits), _st()), "gags_scale_decoder_fwd_fused")
+        return logits, acts + [masks], wb, h, w, xp.shape[1]
     fused = kind == "decoder" and FUSED and _fusable(wb, xp.shape[1])
     if not fused:  # (the fused kernel converts its input tile itself and keeps it as a0)
         check(_lib.load().gags_decoder_pack_input(p, xp.shape[1], a0.shape[1], ptr(xp), ptr(a0), _st()), "gags_decoder_pack_input")
@@ -321,6 +341,7 @@ def _chain_backward(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, need_w=
         wg(0, dz0, a0)
         gin = dx(0, dz0) if need_x else None
     else:
+        smask = acts[len(wb)] if len(acts) == len(wb) + 1 else None  # the fused forward's ReLU bit masks (csrc/decoder_scale.hip)
         cur = dz
         for i in range(len(wb) - 1, -1, -1):
             wg(i, cur, acts[i])

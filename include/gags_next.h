@@ -144,6 +144,15 @@ int gags_decoder_fwd_fused(int64_t n_pix, int c_in, int n_last, const float *x, 
 int gags_decoder_bwd_fused(int64_t n_pix, int c_in, int n_last, const void *dz_last_bf16, const void *const *wt_bf16,
                            const void *masks, void *const *dz_bf16, float *gin, void *stream);
 
+/* CNN_scale_decoder (models/networks.py:220-248: 16 -> 64 -> 128 -> 64 -> 32 -> 16 -> 3) as one kernel, bf16 mode: x
+ * [n_pix, c_in <= 32] fp32; w_bf16[6]: the padded matrices [64,32] [128,64] [64,128] [32,64] [32,32] [32,32] in MFMA-
+ * fragment order ([N / 32][K / 16][64][8]); bias[6] fp32 [N_pad]; acts_bf16[6] (optional): a0 [n_pix, 32] and the five
+ * hidden activations [n_pix, 64 / 128 / 64 / 32 / 32] kept for the weight gradients; masks (optional): uint32 [n_pix, 11],
+ * the ReLU decisions of the five hidden activations as bits (words 0-1, 2-5, 6-7, 8, 9 + one spare); logits [n_pix, 32]
+ * fp32 (3 real columns).  Bit-identical to the same chain run through gags_decoder_layer. */
+int gags_scale_decoder_fwd_fused(int64_t n_pix, int c_in, const float *x, const void *const *w_bf16,
+                                 const float *const *bias, void *const *acts_bf16, void *masks, float *logits, void *stream);
+
 /* ---- N1 at the reference's precision (models/networks.py:109-248 are fp32 Conv2d stacks) ------------------------- */
 
 /* The same layer as gags_decoder_layer with fp32 tensors and fp32-equivalent arithmetic: every operand enters the 16-bit

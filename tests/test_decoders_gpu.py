@@ -443,3 +443,49 @@ def test_fused_decoder_kernels_are_bit_identical_to_the_layer_by_layer_chain():
     assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
     for u, v in zip(a[4] + a[5], b[4] + b[5]):
         assert torch.equal(u, v)
+
+
+def test_fused_scale_decoder_kernels_are_bit_identical_to_the_layer_by_layer_chain():
+    """bf16 mode: CNN_scale_decoder's six layers as ONE kernel, a wave per 32-pixel tile (csrc/decoder_scale.hip), against
+    the same chain run layer by layer: logits, every kept activation, the softmax output, the input gradient and every
+    weight / bias gradient IDENTICAL; ragged pixel count (not a multiple of the tile), and the ReLU bit masks the fused
+    forward leaves behind equal [activation > 0]."""
+    from gags_amd import decoders as D
+    from make_golden_next import decoder_weights
+    _, ws = decoder_weights(0)
+    sdec = _load(D.CNN_scale_decoder(16, 3, "bf16"), ws)
+    g = torch.Generator(device="cuda").manual_seed(22)
+    H, W = 61, 97
+    x = torch.randn(H, W, 16, device="cuda", generator=g).permute(2, 0, 1)
+    G = torch.randn(3, H, W, device="cuda", generator=g)
+    res = []
+    for fused in (True, False):
+        D.FUSED = fused
+        try:
+            xi = x.clone().requires_grad_(True)
+            sdec.zero_grad(set_to_none=True)
+            params = [t for m in sdec.convs() for t in (m.weight, m.bias)]
+            logits, acts, wb, h, w, c_in = D._chain_forward(xi.detach(), "scale", params)
+            y = sdec(xi)
+            (y * G).sum().backward()
+            res.append((logits.clone(), [a.clone() for a in acts], y.detach().clone(), xi.grad.clone(),
+                        [c.weight.grad.clone() for c in sdec.convs()], [c.bias.grad.clone() for c in sdec.convs()]))
+        finally:
+            D.FUSED = True
+    a, b = res
+    assert len(a[1]) == 7 and len(b[1]) == 6                       # the fused forward also keeps the masks
+    assert torch.equal(a[0][:, :3], b[0][:, :3]), "logits"
+    for i, (u, v) in enumerate(zip(a[1][:6], b[1])):
+        assert torch.equal(u, v), f"activation {i}"
+    masks = a[1][6]
+    off = 0
+    for act in b[1][1:]:                                           # words of a1 .. a5: bit n % 32 of word n / 32 = [a > 0]
+        n = act.shape[1]
+        bits = (act.float() > 0).view(-1, n // 32, 32).long()
+        want = (bits << torch.arange(32, device="cuda")).sum(-1)
+        got = masks[:, off:off + n // 32].long() & 0xffffffff
+        assert torch.equal(got, want), f"mask words at {off}"
+        off += n // 32
+    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    for u, v in zip(a[4] + a[5], b[4] + b[5]):
+        assert torch.equal(u, v)
