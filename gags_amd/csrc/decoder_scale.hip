@@ -193,7 +193,94 @@ __global__ __launch_bounds__(256, 2) void sdec_fwd_fused_kernel(SFwdArgs a)
     }
 }
 
+// input-gradient epilogue: out[p][n] = bf16(acc) where the activation's ReLU bit is set, else 0 (no bias)
+template <int NT>
+__device__ __forceinline__ void sepilogue_dgrad(const f32x16 (&acc)[4], const unsigned (&mw)[4], STile out, int lane)
+{
+    const int p = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = 32 * t + 8 * g + 4 * h;
+            const unsigned nib = mw[t] >> (8 * g + 4 * h);
+            const float v0 = (nib & 1u) ? acc[t][4 * g] : 0.f, v1 = (nib & 2u) ? acc[t][4 * g + 1] : 0.f;
+            const float v2 = (nib & 4u) ? acc[t][4 * g + 2] : 0.f, v3 = (nib & 8u) ? acc[t][4 * g + 3] : 0.f;
+            const unsigned u0 = __builtin_bit_cast(unsigned, __builtin_convertvector(sf32x2_t{v0, v1}, sbf16x2_t));
+            const unsigned u1 = __builtin_bit_cast(unsigned, __builtin_convertvector(sf32x2_t{v2, v3}, sbf16x2_t));
+            *reinterpret_cast<uint2 *>(&out[p][n]) = make_uint2(u0, u1);
+        }
+}
+
+// The five input-gradient GEMMs dz5 -> dz4 -> ... -> dz0 (dz_{i-1} = (dz_i W_i) . [a_i > 0]), same tiling as the forward;
+// layer i's "weight" is the transposed matrix Wt_i [K_i, N_i]: output width SK[i], contraction over SN[i].
+__global__ __launch_bounds__(256, 2) void sdec_bwd_fused_kernel(SBwdArgs a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short buf[4][2][SP][SLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    STile A = buf[wave][0], B = buf[wave][1];
+    const int64_t n_tiles = (a.P + SP - 1) / SP;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t p0 = tile * SP;
+        const int64_t pg = min(p0 + (lane & 31), a.P - 1);
+        // this lane's pixel's ReLU words (a1: 0-1, a2: 2-5, a3: 6-7, a4: 8, a5: 9) and the dz5 tile: all requested at once
+        unsigned mk[10];
+#pragma unroll
+        for (int q = 0; q < 10; ++q) mk[q] = a.mask[pg * 11 + q];
+        uint4 d5[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int id = lane + 64 * q, row = id >> 2, c = (id & 3) * 8;
+            d5[q] = *reinterpret_cast<const uint4 *>(a.dz5 + (size_t)min(p0 + row, a.P - 1) * 32 + c);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int id = lane + 64 * q, row = id >> 2, c = (id & 3) * 8;
+            *reinterpret_cast<uint4 *>(&A[row][c]) = d5[q];
+        }
+        __builtin_amdgcn_wave_barrier();
+        f32x16 acc[4];
+        unsigned mw[4];
+        // (L = the forward layer whose transposed matrix is applied; output = dz[L - 1], width SK[L], mask = a_L's words at SMW[L - 1])
+#define GAGS_SDGRAD(L, IN, OUT)                                                                                             \
+        slayer_mma<SN[L], SK[L] / 32>(acc, a.Wt[L], IN, lane);                                                              \
+        _Pragma("unroll") for (int t = 0; t < SK[L] / 32; ++t) mw[t] = mk[SMW[L - 1] + t];                                  \
+        sepilogue_dgrad<SK[L] / 32>(acc, mw, OUT, lane);                                                                    \
+        __builtin_amdgcn_wave_barrier();                                                                                    \
+        stile_store<SK[L]>(a.dz[L - 1], p0, a.P, OUT, lane);
+        GAGS_SDGRAD(5, A, B)
+        GAGS_SDGRAD(4, B, A)
+        GAGS_SDGRAD(3, A, B)
+        GAGS_SDGRAD(2, B, A)
+        GAGS_SDGRAD(1, A, B)
+#undef GAGS_SDGRAD
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace
+
+extern "C" int gags_scale_decoder_bwd_fused(int64_t n_pix, const void *dz_last_bf16, const void *const *wt_bf16, const void *masks,
+                                            void *const *dz_bf16, void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (n_pix < 0 || !dz_last_bf16 || !wt_bf16 || !masks || !dz_bf16) return GAGS_EINVAL;
+    if (n_pix == 0) return GAGS_OK;
+    SBwdArgs a;
+    a.dz5 = (const unsigned short *)dz_last_bf16; a.mask = (const unsigned *)masks; a.P = n_pix;
+    a.Wt[0] = nullptr; a.dz[5] = nullptr;
+    for (int i = 1; i < SNL; ++i) {
+        if (!wt_bf16[i] || !dz_bf16[i - 1]) return GAGS_EINVAL;
+        a.Wt[i] = (const unsigned short *)wt_bf16[i];
+        a.dz[i - 1] = (unsigned short *)dz_bf16[i - 1];
+    }
+    const int64_t n_tiles = (n_pix + SP - 1) / SP;
+    const int64_t want = (n_tiles + 3) / 4;
+    const unsigned grid = (unsigned)(want < 256 * 2 * 8 ? want : 256 * 2 * 8);
+    hipLaunchKernelGGL(sdec_bwd_fused_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
 
 extern "C" int gags_scale_decoder_fwd_fused(int64_t n_pix, int c_in, const float *x, const void *const *w_bf16,
                                             const float *const *bias, void *const *acts_bf16, void *masks, float *logits,

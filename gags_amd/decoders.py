@@ -342,12 +342,24 @@ def _chain_backward(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, need_w=
         gin = dx(0, dz0) if need_x else None
     else:
         smask = acts[len(wb)] if len(acts) == len(wb) + 1 else None  # the fused forward's ReLU bit masks (csrc/decoder_scale.hip)
-        cur = dz
-        for i in range(len(wb) - 1, -1, -1):
-            wg(i, cur, acts[i])
-            if i > 0 or need_x:
-                cur = dx(i, cur, mask_src=acts[i] if i > 0 else None)
-        gin = cur if need_x else None
+        if smask is not None and FUSED and dz.shape[1] == 32:
+            # the five input-gradient GEMMs in one kernel (bit-identical to the loop below), then the weight gradients
+            dzs = [torch.empty(p, wgt.shape[0], dtype=torch.bfloat16, device=dz.device) for wgt, _ in wb[:5]]
+            arr6, arr5 = ctypes.c_void_p * 6, ctypes.c_void_p * 5
+            wtf = [None] + [_frag_layout(t) for t in wt[1:]]
+            check(_lib.load().gags_scale_decoder_bwd_fused(p, ptr(dz), arr6(*[None if t is None else t.data_ptr() for t in wtf]),
+                                                           ptr(smask), arr5(*[t.data_ptr() for t in dzs]), _st()),
+                  "gags_scale_decoder_bwd_fused")
+            for i in range(len(wb) - 1, -1, -1):
+                wg(i, dz if i == 5 else dzs[i], acts[i])
+            gin = dx(0, dzs[0]) if need_x else None
+        else:
+            cur = dz
+            for i in range(len(wb) - 1, -1, -1):
+                wg(i, cur, acts[i])
+                if i > 0 or need_x:
+                    cur = dx(i, cur, mask_src=acts[i] if i > 0 else None)
+            gin = cur if need_x else None
     gx = None
     if gin is not None:
         gx = torch.empty(h, w, c_in, device=dz.device)

@@ -153,6 +153,14 @@ int gags_decoder_bwd_fused(int64_t n_pix, int c_in, int n_last, const void *dz_l
 int gags_scale_decoder_fwd_fused(int64_t n_pix, int c_in, const float *x, const void *const *w_bf16,
                                  const float *const *bias, void *const *acts_bf16, void *masks, float *logits, void *stream);
 
+/* ... and the five input-gradient GEMMs of its backward in one kernel: dz_last [n_pix, 32] bf16 (from the head's backward)
+ * -> dz_bf16[0..4] = the gradients at the outputs of layers 0..4 ([n_pix, 64 / 128 / 64 / 32 / 32] bf16: what the weight
+ * gradients contract).  wt_bf16[1..5]: the TRANSPOSED padded matrices ([64,128]... = W_i^T [K_i, N_i]) in fragment order
+ * (entry 0 unused); masks: what gags_scale_decoder_fwd_fused kept.  Bit-identical to the chain of gags_decoder_layer calls
+ * with mask_src. */
+int gags_scale_decoder_bwd_fused(int64_t n_pix, const void *dz_last_bf16, const void *const *wt_bf16, const void *masks,
+                                 void *const *dz_bf16, void *stream);
+
 /* ---- N1 at the reference's precision (models/networks.py:109-248 are fp32 Conv2d stacks) ------------------------- */
 
 /* The same layer as gags_decoder_layer with fp32 tensors and fp32-equivalent arithmetic: every operand enters the 16-bit
