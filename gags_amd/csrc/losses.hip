@@ -475,11 +475,6 @@ constexpr int FHJ = 16;  // float4 per lane (ld <= 512)
 
 typedef __bf16 l_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float l_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned l_pack_bf16(float lo, float hi)
-{
-    const l_f32x2 v = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, l_bf16x2));
-}
 
 // c = ld = 512 (CNN_decoder(16, 512), the reference's configuration): 16 float4 per lane, straight-line code.
 // ONE_TAP: the segmentation map has the render's resolution (identity resize: every pixel has exactly one source
@@ -534,6 +529,7 @@ __global__ __launch_bounds__(256, 3) void head_distill_kernel(int H, int W, int 
 #pragma unroll
         for (int k = 0; k < (ONE_TAP ? 1 : 4); ++k) er[l][k] = img_embed + (size_t)t.id[l][k] * c + c0;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, dot = 0.f;
+    l_f32x2 a02 = {0.f, 0.f}, a12 = {0.f, 0.f}, a22 = {0.f, 0.f}, dot2 = {0.f, 0.f};  // BWD: packed partial sums
     unsigned sgn_pos[2] = {0u, 0u}, sgn_neg[2] = {0u, 0u};  // BWD: sign of diff per element (64 per lane)
     float4 en[3];
     if (ONE_TAP) {
@@ -563,28 +559,39 @@ __global__ __launch_bounds__(256, 3) void head_distill_kernel(int H, int W, int 
             }
         }
         const float xe[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+        // the element-wise part on PACKED fp32 instructions (v_pk_mul_f32 / v_pk_add_f32, two elements each: this kernel is
+        // bound by its VALU issue slots, ~100 per step and lane, not by its 4.25 GB of logits); same operations, same order
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float y = xe[q] * inv;  // (x * (1 / n): within an ulp of F.normalize's x / n)
-            const float gt = (f[0][q] * s0 + f[1][q] * s1) + f[2][q] * s2;
-            const float diff = y * m - gt * m;
+        for (int q = 0; q < 4; q += 2) {
+            const l_f32x2 x2 = {xe[q], xe[q + 1]}, f0 = {f[0][q], f[0][q + 1]}, f1 = {f[1][q], f[1][q + 1]}, f2 = {f[2][q], f[2][q + 1]};
+            const l_f32x2 y2 = x2 * inv;  // (x * (1 / n): within an ulp of F.normalize's x / n)
+            const l_f32x2 gt2 = (f0 * s0 + f1 * s1) + f2 * s2;
+            const l_f32x2 d2 = y2 * m - gt2 * m;
             if (!BWD) {
-                a0 += fabsf(diff);
+                a0 += fabsf(d2[0]);
+                a0 += fabsf(d2[1]);
             } else {
                 // sign(diff) in {-1, 0, +1} by integer arithmetic on the bits (a float compare per element keeps a lane
                 // mask in an SGPR pair alive until the bit sets are assembled: 128 pairs, spilled)
-                const unsigned u = __float_as_uint(diff);
-                const unsigned neg = u >> 31, mag = min(u & 0x7fffffffu, 1u);
-                const int bit = 4 * j + q;
-                sgn_neg[bit >> 5] |= (mag & neg) << (bit & 31);
-                sgn_pos[bit >> 5] |= (mag & (neg ^ 1u)) << (bit & 31);
-                const float gg = __uint_as_float((u & 0x80000000u) | 0x3f800000u) * (float)mag * vm;  // d l1 / d y = sign(diff) v m
-                dot = fmaf(xe[q], gg, dot);
-                a0 = fmaf(-gg, f[0][q], a0); a1 = fmaf(-gg, f[1][q], a1); a2 = fmaf(-gg, f[2][q], a2);
+                l_f32x2 sg2;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const unsigned u = __float_as_uint(d2[e]);
+                    const unsigned neg = u >> 31, mag = min(u & 0x7fffffffu, 1u);
+                    const int bit = 4 * j + q + e;
+                    sgn_neg[bit >> 5] |= (mag & neg) << (bit & 31);
+                    sgn_pos[bit >> 5] |= (mag & (neg ^ 1u)) << (bit & 31);
+                    sg2[e] = __uint_as_float((u & 0x80000000u) | 0x3f800000u) * (float)mag;  // sign(diff)
+                }
+                const l_f32x2 gg2 = sg2 * vm;  // d l1 / d y = sign(diff) v m
+                dot2 = __builtin_elementwise_fma(x2, gg2, dot2);  // (even / odd elements in the two halves, added at the end)
+                a02 = __builtin_elementwise_fma(-gg2, f0, a02); a12 = __builtin_elementwise_fma(-gg2, f1, a12);
+                a22 = __builtin_elementwise_fma(-gg2, f2, a22);
             }
         }
         __builtin_amdgcn_sched_barrier(0);  // one step at a time (unfenced, every gather of the pixel is hoisted: 256 VGPRs)
     }
+    if (BWD) { a0 = a02[0] + a02[1]; a1 = a12[0] + a12[1]; a2 = a22[0] + a22[1]; dot = dot2[0] + dot2[1]; }
     a0 += __shfl_xor(a0, 1); a0 += __shfl_xor(a0, 2); a0 += __shfl_xor(a0, 4);
     if (!BWD) {
         if ((tid & 7) == 0 && pr < HW) {
@@ -605,14 +612,20 @@ __global__ __launch_bounds__(256, 3) void head_distill_kernel(int H, int W, int 
 #pragma unroll
     for (int j = 0; j < FHJ; ++j) {
         const float xe[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
-        float dq[4];
+        unsigned pk[2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int bit = 4 * j + q;
-            const float sg = (float)((int)((sgn_pos[bit >> 5] >> (bit & 31)) & 1u) - (int)((sgn_neg[bit >> 5] >> (bit & 31)) & 1u)) * gmag;
-            dq[q] = fmaf(-xe[q], k1, sg);
+        for (int q = 0; q < 4; q += 2) {
+            l_f32x2 sg2;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int bit = 4 * j + q + e;
+                sg2[e] = (float)((int)((sgn_pos[bit >> 5] >> (bit & 31)) & 1u) - (int)((sgn_neg[bit >> 5] >> (bit & 31)) & 1u));
+            }
+            const l_f32x2 x2 = {xe[q], xe[q + 1]};
+            const l_f32x2 dq2 = __builtin_elementwise_fma(-x2, l_f32x2{k1, k1}, sg2 * gmag);
+            pk[q >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(dq2, l_bf16x2));
         }
-        *reinterpret_cast<uint2 *>(dz + (size_t)pr * c + c0 + 32 * j) = make_uint2(l_pack_bf16(dq[0], dq[1]), l_pack_bf16(dq[2], dq[3]));
+        *reinterpret_cast<uint2 *>(dz + (size_t)pr * c + c0 + 32 * j) = make_uint2(pk[0], pk[1]);
     }
 }
 
