@@ -100,6 +100,15 @@ __global__ __launch_bounds__(256) void segment_stats_kernel(int64_t n_pix, int c
     // issues ONE double atomic per moment.  Channels in groups of 8 held in registers: read once.
     for (int cb = 0; cb < c; cb += 8) {
         float xv[8][4];
+        if (pm && (c & 7) == 0) {  // (uniform) pixel-major rows of whole 8-channel groups: two 16-byte loads per pixel
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float *px = x + (size_t)min(p0 + q, n_pix - 1) * c + cb;
+                const float4 t0 = *reinterpret_cast<const float4 *>(px), t1 = *reinterpret_cast<const float4 *>(px + 4);
+                xv[0][q] = t0.x; xv[1][q] = t0.y; xv[2][q] = t0.z; xv[3][q] = t0.w;
+                xv[4][q] = t1.x; xv[5][q] = t1.y; xv[6][q] = t1.z; xv[7][q] = t1.w;
+            }
+        } else
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int ch = min(cb + j, c - 1);
@@ -157,6 +166,29 @@ __global__ __launch_bounds__(256) void segment_stats_kernel(int64_t n_pix, int c
             todo = __ballot(pend != 0);
         }
     }
+}
+
+// pixel-major [n_pix, c], c % 4 == 0: one lane per float4, consecutive lanes on consecutive 16 bytes of the tensor
+__global__ __launch_bounds__(256) void region_var_bwd_pm_kernel(int64_t n_pix, int c, const float *__restrict__ x,
+                                                                const float *__restrict__ seg, int n_seg,
+                                                                const float *__restrict__ mean, const float *__restrict__ coef,
+                                                                float *__restrict__ vx)
+{
+    const int q4 = c >> 2;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_pix * q4) return;
+    const int64_t p = t / q4;
+    const int ch = (int)(t - p * q4) * 4;
+    const float f = seg[p];
+    const int id = (f >= 0.f && f < (float)n_seg) ? (int)f : -1;
+    const float4 xv = *reinterpret_cast<const float4 *>(x + (size_t)p * c + ch);
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (id >= 0) {
+        const float k = coef[id];
+        const float4 mv = *reinterpret_cast<const float4 *>(mean + (size_t)id * c + ch);
+        o = make_float4(k * (xv.x - mv.x), k * (xv.y - mv.y), k * (xv.z - mv.z), k * (xv.w - mv.w));
+    }
+    *reinterpret_cast<float4 *>(vx + (size_t)p * c + ch) = o;
 }
 
 __global__ __launch_bounds__(256) void region_var_bwd_kernel(int64_t n_pix, int c, const float *__restrict__ x,
@@ -734,8 +766,12 @@ extern "C" int gags_region_var_bwd_layout(int64_t n_pix, int c, const float *x, 
     if (n_pix < 0 || c <= 0 || n_seg <= 0 || (n_pix > 0 && (!x || !seg || !mean || !coef || !v_x)) || (layout != 0 && layout != 1))
         return GAGS_EINVAL;
     if (n_pix == 0) return GAGS_OK;
-    hipLaunchKernelGGL(region_var_bwd_kernel, dim3(nblk(n_pix)), dim3(256), 0, (hipStream_t)stream, n_pix, c, x, seg, n_seg,
-                       mean, coef, v_x, layout);
+    if (layout == 1 && (c & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(v_x) | reinterpret_cast<uintptr_t>(mean)) & 15) == 0)
+        hipLaunchKernelGGL(region_var_bwd_pm_kernel, dim3(nblk(n_pix * (c >> 2))), dim3(256), 0, (hipStream_t)stream, n_pix, c, x, seg,
+                           n_seg, mean, coef, v_x);
+    else
+        hipLaunchKernelGGL(region_var_bwd_kernel, dim3(nblk(n_pix)), dim3(256), 0, (hipStream_t)stream, n_pix, c, x, seg, n_seg,
+                           mean, coef, v_x, layout);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }
