@@ -753,23 +753,35 @@ void launch_wgrad_narrow(int64_t n_pix, const void *dz, const void *a1, const vo
                            (const unsigned short *)a1, (const unsigned short *)a2, d_w, d_b, chunk);
 }
 
-// out[e] = sum of the partial results over the pixel chunks, in chunk order (fixed => reproducible)
-__global__ __launch_bounds__(256) void sum_wparts_kernel(int n_parts, int64_t elems, const float *__restrict__ part,
-                                                         float *__restrict__ out)
+// out[e] = sum of the partial results over the pixel chunks, in a FIXED order (=> reproducible): sixteen groups of a
+// workgroup take the chunks g, g + 16, ... of 64 consecutive elements (up to 16 loads in flight each), their sums are
+// added in group order.  (One thread per element walking all 768 chunks of a narrow layer was a chain of 48 round trips:
+// 17-28 us for a 4 KB matrix, 0.5 ms per iteration over the thirty sums.)
+__global__ __launch_bounds__(1024) void sum_wparts_kernel(int n_parts, int64_t elems, const float *__restrict__ part,
+                                                          float *__restrict__ out)
 {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= elems) return;
+    __shared__ float sm[16][64];
+    const int g = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int64_t e = (int64_t)blockIdx.x * 64 + l;
+    const int64_t ec = min(e, elems - 1);
     float t = 0.f;
-    int c = 0;
-    for (; c + 16 <= n_parts; c += 16) {  // 16 loads in flight, adds in chunk order (a plain loop waits one latency per chunk)
+    int c = g;
+    for (; c + 16 * 15 < n_parts; c += 16 * 16) {
         float v[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = part[(size_t)(c + i) * elems + e];
+        for (int i = 0; i < 16; ++i) v[i] = part[(size_t)(c + 16 * i) * elems + ec];
 #pragma unroll
         for (int i = 0; i < 16; ++i) t += v[i];
     }
-    for (; c < n_parts; ++c) t += part[(size_t)c * elems + e];
-    out[e] = t;
+    for (; c < n_parts; c += 16) t += part[(size_t)c * elems + ec];
+    sm[g][l] = t;
+    __syncthreads();
+    if (g == 0 && e < elems) {
+        float r = sm[0][l];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) r += sm[i][l];
+        out[e] = r;
+    }
 }
 
 // backward of the output heads: channel-major cotangent G[C, P] and the saved pixel-major logits x[P, ld] ->
@@ -1198,9 +1210,9 @@ extern "C" int gags_decoder_wgrad(int64_t n_pix, int n_out, int k_in, const void
                            (const unsigned short *)a2, pw, pb);
     }
     const int64_t elems = (int64_t)n_out * k_in;
-    hipLaunchKernelGGL(sum_wparts_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, (int)parts, elems, pw, d_w);
+    hipLaunchKernelGGL(sum_wparts_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(1024), 0, st, (int)parts, elems, pw, d_w);
     if (d_b)
-        hipLaunchKernelGGL(sum_wparts_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, (int)parts, (int64_t)n_out, pb,
+        hipLaunchKernelGGL(sum_wparts_kernel, dim3((unsigned)((n_out + 63) / 64)), dim3(1024), 0, st, (int)parts, (int64_t)n_out, pb,
                            d_b);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
