@@ -85,6 +85,7 @@ SIGNATURES = {
     "gags_decoder_head_distill_fwd": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_decoder_head_distill_bwd": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_decoder_pack_input": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp]),
+    "gags_decoder_pack_layer": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_decoder_layer": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_decoder_wgrad_scratch_bytes": (_i64, [_i64, _i32, _i32]),
     "gags_decoder_wgrad": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),

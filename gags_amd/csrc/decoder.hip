@@ -1079,6 +1079,43 @@ __global__ __launch_bounds__(256) void unpack_f32_kernel(int64_t P, int C, int l
 
 }  // namespace
 
+namespace {
+// one layer's parameters in every form the kernels read, in ONE launch (torch: zeros + slice copy + cast + transpose +
+// two permuted copies + the bias pair = ~10 tiny kernels per layer, ~150 per iteration for the two decoders)
+__global__ __launch_bounds__(256) void pack_layer_kernel(int co, int ci, int np, int kp, const float *__restrict__ w,
+                                                         const float *__restrict__ b, unsigned short *__restrict__ wr,
+                                                         unsigned short *__restrict__ wtr, unsigned short *__restrict__ wf,
+                                                         unsigned short *__restrict__ wtf, float *__restrict__ bp)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < np) bp[e] = e < co ? b[e] : 0.f;
+    if (e >= np * kp) return;
+    const int n = e / kp, k = e - n * kp;
+    const float v = (n < co && k < ci) ? w[(size_t)n * ci + k] : 0.f;
+    typedef __bf16 pbf2 __attribute__((ext_vector_type(2)));
+    typedef float pf2 __attribute__((ext_vector_type(2)));
+    const pf2 pr = {v, 0.f};
+    const unsigned short h = (unsigned short)(__builtin_bit_cast(unsigned, __builtin_convertvector(pr, pbf2)) & 0xffffu);  // RN-even, as torch
+    wr[(size_t)n * kp + k] = h;
+    wtr[(size_t)k * np + n] = h;
+    // fragment order of a [R, C] matrix: [R / 32][C / 16][2][32][8] (gags_amd/decoders.py: _frag_layout)
+    wf[((((size_t)(n >> 5) * (kp >> 4) + (k >> 4)) * 2 + ((k >> 3) & 1)) * 32 + (n & 31)) * 8 + (k & 7)] = h;
+    wtf[((((size_t)(k >> 5) * (np >> 4) + (n >> 4)) * 2 + ((n >> 3) & 1)) * 32 + (k & 31)) * 8 + (n & 7)] = h;
+}
+}  // namespace
+
+extern "C" int gags_decoder_pack_layer(int co, int ci, const float *w, const float *b, void *w_bf16, void *wt_bf16, void *w_frag,
+                                       void *wt_frag, float *bias_pad, void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (co <= 0 || ci <= 0 || !w || !b || !w_bf16 || !wt_bf16 || !w_frag || !wt_frag || !bias_pad) return GAGS_EINVAL;
+    const int np = (co + 31) / 32 * 32, kp = (ci + 31) / 32 * 32;
+    hipLaunchKernelGGL(pack_layer_kernel, dim3((unsigned)((np * kp + 255) / 256)), dim3(256), 0, (hipStream_t)stream, co, ci, np, kp, w, b,
+                       (unsigned short *)w_bf16, (unsigned short *)wt_bf16, (unsigned short *)w_frag, (unsigned short *)wt_frag, bias_pad);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
 extern "C" int gags_decoder_pack_input(int64_t n_pix, int c, int c_pad, const float *x, void *y_bf16, void *stream)
 {
     GAGS_CLEAR_ERR();

@@ -74,18 +74,55 @@ def _wgrad(n_pix, dz, a1, a2, n, k):
     return dw, db
 
 
+_PACK_CACHE = {}  # (id of the first weight) -> (versions, packed): decoders whose parameters did not change are not repacked
+
+
 def _pack_weights(weights, biases):
-    """bf16 [N_pad, K_pad] weights + their transposes (for the input-gradient GEMMs) and fp32 [N_pad] biases; every
-    dimension zero-padded to a multiple of 32."""
+    """bf16 [N_pad, K_pad] weights and fp32 [N_pad] biases, every dimension zero-padded to a multiple of 32; each packed
+    weight also carries its transpose (for the input-gradient GEMMs) and both in MFMA-fragment order (for the fused
+    kernels) as attributes -- one gags_decoder_pack_layer launch per layer, and none while the parameters' version
+    counters stand still (frozen decoders, the second use within one iteration's backward)."""
+    key = id(weights[0])
+    vers = tuple((t.data_ptr(), t._version) for t in list(weights) + list(biases))
+    hit = _PACK_CACHE.get(key)
+    if hit is not None and hit[0] == vers:
+        return hit[1]
+    lib = _lib.load()
     out = []
     for wt, bs in zip(weights, biases):
         co, ci = wt.shape[:2]
-        w = torch.zeros(_pad32(co), _pad32(ci), device=wt.device, dtype=torch.bfloat16)
-        w[:co, :ci] = wt.detach()[:, :, 0, 0].to(torch.bfloat16)
-        b = torch.zeros(_pad32(co), device=wt.device)
-        b[:co] = bs.detach()
+        n, k = _pad32(co), _pad32(ci)
+        dev = wt.device
+        w = torch.empty(n, k, device=dev, dtype=torch.bfloat16)
+        w_t = torch.empty(k, n, device=dev, dtype=torch.bfloat16)
+        wf = torch.empty(n // 32, k // 16, 2, 32, 8, device=dev, dtype=torch.bfloat16)
+        wtf = torch.empty(k // 32, n // 16, 2, 32, 8, device=dev, dtype=torch.bfloat16)
+        b = torch.empty(n, device=dev)
+        src = wt.detach().reshape(co, ci)
+        src = src if (src.is_contiguous() and src.dtype == torch.float32) else src.contiguous().float()
+        bsrc = bs.detach()
+        bsrc = bsrc if (bsrc.is_contiguous() and bsrc.dtype == torch.float32) else bsrc.contiguous().float()
+        check(lib.gags_decoder_pack_layer(co, ci, ptr(src), ptr(bsrc), ptr(w), ptr(w_t), ptr(wf), ptr(wtf), ptr(b), _st()),
+              "gags_decoder_pack_layer")
+        w._gags_frag, w._gags_t = wf, w_t
+        w_t._gags_frag = wtf
         out.append((w, b))
+    if len(_PACK_CACHE) > 16:
+        _PACK_CACHE.clear()
+    _PACK_CACHE[key] = (vers, out)
     return out
+
+
+def invalidate_packed():
+    """Forget every packed weight set.  Needed only after a parameter was written through `.data` (which does not move its
+    version counter); optimizers, load_state_dict and in-place ops under no_grad all do."""
+    _PACK_CACHE.clear()
+
+
+def _transposed(w):
+    """[K_pad, N_pad] of a packed weight (contracts over N in the input-gradient GEMMs)."""
+    t = getattr(w, "_gags_t", None)
+    return t if t is not None else w.t().contiguous()
 
 
 def _xlayer(n_pix, w, b, a1, a2=None, relu=True, mask_src=None, residual=None, premask=False, ldy=None):
@@ -210,6 +247,9 @@ FUSED = True  # bf16 mode: CNN_decoder's forward (and input-gradient) chain as o
 def _frag_layout(w):
     """bf16 [N, K] (N % 32 == 0, K % 16 == 0) -> [N / 32, K / 16, 64, 8]: the A operand of one v_mfma_f32_32x32x16_bf16 (lane
     32 kh + n holds k = 16 s + 8 kh .. + 7 of row 32 t + n) as one contiguous kilobyte (csrc/decoder_fused.hip: layer_mma)."""
+    f = getattr(w, "_gags_frag", None)  # packed by gags_decoder_pack_layer
+    if f is not None:
+        return f
     n, k = w.shape
     return w.view(n // 32, 32, k // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
 
@@ -292,7 +332,7 @@ def _chain_backward(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, need_w=
     [H,W,C_in] memory, weight / bias gradients in parameter order).  need_x / need_w: what autograd asked for."""
     p = h * w
     need_w = need_w or [True] * len(wb)
-    wt = [wgt.t().contiguous() for wgt, _ in wb]  # [K_pad, N_pad]: the input-gradient GEMM contracts over N
+    wt = [_transposed(wgt) for wgt, _ in wb]  # [K_pad, N_pad]: the input-gradient GEMM contracts over N
     dws = [None] * len(wb)
 
     def wg(i, dz_i, a1, a2=None):

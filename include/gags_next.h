@@ -90,6 +90,12 @@ int gags_decoder_head_distill_bwd(int c, int ld, int H, int W, int h, int w, int
 /* fp32 pixel-major x[n_pix, c] (the rasterizer's own [H, W, D] output) -> bf16 y[n_pix, c_pad], zero-padded
  * (c_pad % 32 == 0). */
 int gags_decoder_pack_input(int64_t n_pix, int c, int c_pad, const float *x, void *y_bf16, void *stream);
+/* One 1x1-conv layer's parameters (w [co, ci] fp32 = Conv2d.weight[:, :, 0, 0], b [co]) in every form the bf16 kernels read,
+ * dimensions zero-padded to multiples of 32 (Np, Kp): w_bf16 [Np, Kp] and its transpose wt_bf16 [Kp, Np] row-major, both
+ * again in MFMA-fragment order ([R / 32][C / 16][2][32][8]: the A operand of one v_mfma_f32_32x32x16_bf16 as one
+ * contiguous kilobyte) for the fused kernels, and the padded fp32 bias.  Round-to-nearest-even, as torch's cast. */
+int gags_decoder_pack_layer(int co, int ci, const float *w, const float *b, void *w_bf16, void *wt_bf16, void *w_frag,
+                            void *wt_frag, float *bias_pad, void *stream);
 
 /* One 1x1-convolution layer as a GEMM on the 16-bit matrix cores (bf16 operands, fp32 accumulate):
  *     y[p, n] = act( sum_k (a1[p, k] + a2[p, k]) * w[n, k] + bias[n] ) * (mask_src[p, n] > 0) + residual[p, n]

@@ -489,3 +489,36 @@ def test_fused_scale_decoder_kernels_are_bit_identical_to_the_layer_by_layer_cha
     assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
     for u, v in zip(a[4] + a[5], b[4] + b[5]):
         assert torch.equal(u, v)
+
+
+def test_packed_weights_follow_in_place_updates():
+    """The packed (padded bf16 / transposed / fragment-order) weights are cached on the parameters' version counters: an
+    in-place update under no_grad (what every optimizer does) repacks them, an unchanged module does not launch the pack
+    kernel again, and the packed forms equal torch's own cast / transpose / permute."""
+    from gags_amd import decoders as D
+    from make_golden_next import decoder_weights
+    _, ws = decoder_weights(0)
+    sdec = _load(D.CNN_scale_decoder(16, 3, "bf16"), ws)
+    x = torch.randn(16, 40, 50, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    params = [t for m in sdec.convs() for t in (m.weight, m.bias)]
+    wb1 = D._pack_weights(params[0::2], params[1::2])
+    assert D._pack_weights(params[0::2], params[1::2]) is wb1                       # cached
+    for (w, b), conv in zip(wb1, sdec.convs()):
+        co, ci = conv.weight.shape[:2]
+        ref = torch.zeros_like(w)
+        ref[:co, :ci] = conv.weight.detach()[:, :, 0, 0].to(torch.bfloat16)
+        assert torch.equal(w, ref) and torch.equal(D._transposed(w), ref.t().contiguous())
+        n, k = ref.shape
+        assert torch.equal(D._frag_layout(w), ref.view(n // 32, 32, k // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous())
+        rt = ref.t().contiguous()
+        assert torch.equal(D._frag_layout(D._transposed(w)), rt.view(k // 32, 32, n // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous())
+        assert torch.equal(b[:co], conv.bias.detach()) and float(b[co:].abs().sum()) == 0.0
+    y1 = sdec(x).clone()
+    with torch.no_grad():
+        sdec.convs()[2].weight.mul_(1.5)
+    wb2 = D._pack_weights(params[0::2], params[1::2])
+    assert wb2 is not wb1
+    y2 = sdec(x)
+    assert not torch.equal(y1, y2)
+    D.invalidate_packed()
+    assert torch.equal(sdec(x), y2)

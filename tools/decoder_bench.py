@@ -39,6 +39,8 @@ def ev():
 
 
 def iteration(times=None):
+    from gags_amd import decoders as _D
+    _D.invalidate_packed()  # as after an optimizer step: the decoders' weights are repacked every iteration
     marks = [ev()]
     pkg = render(cam, pc, None, bg, feature_mode=True)
     fmap = pkg["render"]; marks.append(ev())
