@@ -161,6 +161,22 @@ __device__ __forceinline__ void store_tile(unsigned short *__restrict__ dst, int
 }
 
 // dst[p][:] = bf16(dst + add) element-wise (fp32 add, one rounding: what gags_decoder_layer does with two sources)
+// dst += add in LDS, and the sum's tile to its place in a pixel-major [P, 256] tensor: the residual sums x1 + x2 and
+// x3 + x4 are what layers 3 and 6 read AND what their weight gradients contract -- kept instead of x2 / x4 (whose ReLU
+// decisions travel as bit masks), those weight gradients read one tensor, not two
+template <int NT>
+__device__ __forceinline__ void add_store_tile(Tile dst, Tile add, unsigned short *__restrict__ keep, int64_t p0, int64_t P, int tid)
+{
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int id = tid + NT * q, row = id >> 5, c = (id & 31) * 8;
+        const uint4 x = *reinterpret_cast<const uint4 *>(&dst[row][c]), y = *reinterpret_cast<const uint4 *>(&add[row][c]);
+        const uint4 sum = make_uint4(fpack(flo(x.x) + flo(y.x), fhi(x.x) + fhi(y.x)), fpack(flo(x.y) + flo(y.y), fhi(x.y) + fhi(y.y)),
+                                     fpack(flo(x.z) + flo(y.z), fhi(x.z) + fhi(y.z)), fpack(flo(x.w) + flo(y.w), fhi(x.w) + fhi(y.w)));
+        *reinterpret_cast<uint4 *>(&dst[row][c]) = sum;
+        if (keep && p0 + row < P) *reinterpret_cast<uint4 *>(keep + (size_t)(p0 + row) * FH + c) = sum;
+    }
+}
 template <int NT>
 __device__ __forceinline__ void add_tile(Tile dst, Tile add, int tid)
 {
@@ -246,8 +262,7 @@ __global__ __launch_bounds__(256 * PH, 2 / PH) void decoder_fwd_fused_kernel(Fwd
     __syncthreads();
     epilogue_hidden(acc, bias_s[2], n_base, bufB, lane, a.mask[3], p0, a.P, poff);
     __syncthreads();
-    store_tile<NT>(a.act[3], p0, a.P, bufB, tid);
-    add_tile<NT>(bufA, bufB, tid);
+    add_store_tile<NT>(bufA, bufB, a.act[3], p0, a.P, tid);  // kept: x1 + x2, the input of layer 3 (what its weight gradient contracts)
     __syncthreads();
     // L3: x1 + x2 (A) -> x3 (B)
     layer_main(acc, wf, a.W[3], 16, 2 * wave, 0, 16, bufA, lane, true, poff);
@@ -267,8 +282,7 @@ __global__ __launch_bounds__(256 * PH, 2 / PH) void decoder_fwd_fused_kernel(Fwd
     __syncthreads();
     epilogue_hidden(acc, bias_s[5], n_base, bufA, lane, a.mask[6], p0, a.P, poff);
     __syncthreads();
-    store_tile<NT>(a.act[6], p0, a.P, bufA, tid);
-    add_tile<NT>(bufB, bufA, tid);
+    add_store_tile<NT>(bufB, bufA, a.act[6], p0, a.P, tid);  // kept: x3 + x4, the input of layer 6
     __syncthreads();
     // L6: x3 + x4 (B) -> t6 (A)
     layer_main(acc, wf, a.W[6], 16, 2 * wave, 0, 16, bufB, lane, true, poff);

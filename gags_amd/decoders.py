@@ -344,7 +344,7 @@ def _chain_backward(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, need_w=
 
     if kind == "decoder" and len(acts) == 10:  # the fused forward ran (its bit masks ride along as the tenth entry)
         # the nine input-gradient GEMMs in one kernel (csrc/decoder_fused.hip), then the weight gradients
-        a0, x1, t1, x2, x3, t4, x4, t6, t7, masks = acts
+        a0, x1, t1, s12, x3, t4, s34, t6, t7, masks = acts  # (the fused forward keeps x1 + x2 and x3 + x4 in place of x2 / x4)
         dev = dz.device
         dzs = [torch.empty(p, 256, dtype=torch.bfloat16, device=dev) for _ in range(8)]
         gx = torch.empty(h, w, c_in, device=dev) if need_x else None
@@ -353,8 +353,8 @@ def _chain_backward(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, need_w=
         wtf = [_frag_layout(t) for t in wt]
         check(_lib.load().gags_decoder_bwd_fused(p, c_in, dz.shape[1], ptr(dz), arr(*[t.data_ptr() for t in wtf]), ptr(masks),
                                                  arr8(*[t.data_ptr() for t in dzs]), ptr(gx), _st()), "gags_decoder_bwd_fused")
-        wg(8, dz, t7); wg(7, dzs[7], t6); wg(6, dzs[6], x3, x4); wg(5, dzs[5], t4); wg(4, dzs[4], x3)
-        wg(3, dzs[3], x1, x2); wg(2, dzs[2], t1); wg(1, dzs[1], x1); wg(0, dzs[0], a0)
+        wg(8, dz, t7); wg(7, dzs[7], t6); wg(6, dzs[6], s34); wg(5, dzs[5], t4); wg(4, dzs[4], x3)
+        wg(3, dzs[3], s12); wg(2, dzs[2], t1); wg(1, dzs[1], x1); wg(0, dzs[0], a0)
         grads = []
         for pair, shp in zip(dws, shapes):
             co, ci = shp[:2]

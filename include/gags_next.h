@@ -136,8 +136,9 @@ int gags_decoder_head(int64_t n_pix, int c, int ld, int mode, const float *x, fl
  * x5 = conv(x3 + x4)) in ONE kernel, bf16 mode: 64-pixel tiles, activations resident in LDS, weights streamed from L2.
  * x [n_pix, c_in] fp32 (c_in <= 32); w_bf16[9]: the padded bf16 matrices gags_decoder_layer takes ([256, 32], 7 x [256,
  * 256], [n_last, 256]) re-ordered into MFMA fragments: [N / 32][K / 16][lane = 32 kh + n][8 values k = 16 s + 8 kh ..]; bias[9] fp32; acts_bf16[9] (or NULL, or NULL entries): a0 [n_pix, 32] and the eight hidden
- * activations [n_pix, 256] kept for the backward; logits [n_pix, n_last] fp32, n_last % 256 == 0.  Bit-identical to the
- * same chain run through gags_decoder_layer. */
+ * activations [n_pix, 256] kept for the backward -- entries 3 and 6 hold the residual SUMS x1 + x2 and x3 + x4 (the inputs
+ * of layers 3 and 6: what their weight gradients contract), not x2 / x4 --; logits [n_pix, n_last] fp32, n_last % 256 == 0.
+ * Bit-identical to the same chain run through gags_decoder_layer. */
 int gags_decoder_fwd_fused(int64_t n_pix, int c_in, int n_last, const float *x, const void *const *w_bf16,
                            const float *const *bias, void *const *acts_bf16, void *masks, float *logits, void *stream);
 /* (masks, optional: uint32 [8, n_pix, 8] -- the ReLU decisions of the eight hidden activations as bits, word n / 32 bit

@@ -439,6 +439,8 @@ def test_fused_decoder_kernels_are_bit_identical_to_the_layer_by_layer_chain():
     a, b = res
     assert torch.equal(a[0], b[0]), "logits"
     for i, (u, v) in enumerate(zip(a[1], b[1])):
+        if i in (3, 6):  # the fused forward keeps the residual sums x1 + x2 / x3 + x4 (what layers 3 / 6 read) in place of x2 / x4
+            v = (b[1][i - 2].float() + v.float()).to(torch.bfloat16)
         assert torch.equal(u, v), f"activation {i}"
     assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
     for u, v in zip(a[4] + a[5], b[4] + b[5]):
