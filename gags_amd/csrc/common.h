@@ -52,6 +52,15 @@ __device__ __forceinline__ void gags_tile_aabb(float mx, float my, int radius, i
     y1 = (int)fminf(fmaxf(ceilf(ty + tr), 0.f), (float)tile_h);
 }
 
+// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() is `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`: it also
+// waits for every global load in flight -- i.e. it lands the prefetch a double-buffered loop has just issued, once per
+// step (round 3: wgrad256_kernel spent a full HBM round trip per 32-pixel step at its barrier).  Use where the waves
+// exchange data through LDS only; loads still in flight are waited for where their registers are used.
+__device__ __forceinline__ void gags_lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // XCD-aware tile remap: the dispatcher places workgroup b on XCD b % 8 (speed only, never
 // correctness).  Give each XCD a contiguous run of tiles so neighbouring tiles -- which
 // share Gaussians, hence feature rows -- hit the same 4 MiB L2.  Bijective for any count.

@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256, 2) void wgrad256_kernel(int64_t P, int N, cons
         if (s + 1 < steps) commit(buf ^ 1, pa + (s + 1) * W2P);
         if (s + 2 < steps) fetch(pa + (s + 2) * W2P);
         compute(buf);
-        __syncthreads();
+        gags_lds_barrier();  // (not __syncthreads(): that would land the fetch above before every step)
     }
     // accumulator: column = lane & 31 -> k, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -> n; 32 lanes = 128 contiguous bytes
 #pragma unroll
