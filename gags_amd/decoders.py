@@ -24,6 +24,7 @@ input gradient comes back in the rasterizer's [H,W,C] layout; gradients nobody a
 parameters) are not computed.
 """
 import ctypes
+import weakref
 
 import torch
 from torch import nn
@@ -85,7 +86,8 @@ def _pack_weights(weights, biases):
     key = id(weights[0])
     vers = tuple((t.data_ptr(), t._version) for t in list(weights) + list(biases))
     hit = _PACK_CACHE.get(key)
-    if hit is not None and hit[0] == vers:
+    # (the weak references tell a parameter from a later one that got the same id, address and version counter)
+    if hit is not None and hit[0] == vers and all(r() is t for r, t in zip(hit[2], list(weights) + list(biases))):
         return hit[1]
     lib = _lib.load()
     out = []
@@ -109,7 +111,7 @@ def _pack_weights(weights, biases):
         out.append((w, b))
     if len(_PACK_CACHE) > 16:
         _PACK_CACHE.clear()
-    _PACK_CACHE[key] = (vers, out)
+    _PACK_CACHE[key] = (vers, out, [weakref.ref(t) for t in list(weights) + list(biases)])
     return out
 
 
