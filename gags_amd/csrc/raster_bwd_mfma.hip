@@ -848,7 +848,8 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_sdot(int d, int ch0, int dc
                                                        const float *__restrict__ colors, const float *__restrict__ backgrounds,
                                                        const int32_t *__restrict__ offsets, int n_isects,
                                                        const int32_t *__restrict__ blk_rows, const int32_t *__restrict__ gid_s,
-                                                       float *__restrict__ S, float *__restrict__ bgdot, int accumulate)
+                                                       float *__restrict__ S, float *__restrict__ bgdot, int accumulate,
+                                                       const int32_t *__restrict__ row_base)
 {
     extern __shared__ __attribute__((aligned(16))) float slab[];  // [64 pixels in wt order e = 2 p + h][dch + SD_PAD]
     __shared__ float bred[4][64];
@@ -862,6 +863,8 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_sdot(int d, int ch0, int dc
     const int start = offsets[tile];
     const int end = offsets[tile + 1]  /* n_tiles + 1 entries: the last one is the intersection count */;
     const int sb = gags_slot_base(start, end, tile, blk);
+    // S rows: compact numbering (row_base = exclusive prefix sum of blk_rows: S is n_rows x 256 B) or the sparse slot index
+    const int srb = row_base ? row_base[tile * GAGS_BLOCKS_PER_TILE + blk] : sb;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pitch = dch + SD_PAD;
     const int ty = tile / tile_w, tx = tile - ty * tile_w;
@@ -930,7 +933,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_sdot(int d, int ch0, int dc
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = min(t0 + (r & 3) + 8 * (r >> 2) + 4 * kh, cnt - 1);
-                acc0[r] = S[(size_t)(sb + row) * 64 + 32 * hh + m];
+                acc0[r] = S[(size_t)(srb + row) * 64 + 32 * hh + m];
             }
         } else {
 #pragma unroll
@@ -965,7 +968,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_sdot(int d, int ch0, int dc
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = t0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (row < cnt) S[(size_t)(sb + row) * 64 + 32 * hh + m] = acc0[r];
+            if (row < cnt) S[(size_t)(srb + row) * 64 + 32 * hh + m] = acc0[r];
         }
     }
 }
@@ -1034,7 +1037,8 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_sdot_f16(int d, int ch0, in
                                                            const float *__restrict__ backgrounds,
                                                            const int32_t *__restrict__ offsets, int n_isects,
                                                            const int32_t *__restrict__ blk_rows, const int32_t *__restrict__ gid_s,
-                                                           float *__restrict__ S, float *__restrict__ bgdot)
+                                                           float *__restrict__ S, float *__restrict__ bgdot,
+                                                           const int32_t *__restrict__ row_base)
 {
     extern __shared__ __attribute__((aligned(16))) _Float16 planes[];  // hi [64 pixels e = 2 p + h][pitch], then lo
     __shared__ float bred[4][64];
@@ -1054,6 +1058,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_sdot_f16(int d, int ch0, in
     const int start = offsets[tile];
     const int end = offsets[tile + 1]  /* n_tiles + 1 entries: the last one is the intersection count */;
     const int sb = gags_slot_base(start, end, tile, blk);
+    const int srb = row_base ? row_base[tile * GAGS_BLOCKS_PER_TILE + blk] : sb;  // S rows: compact or sparse numbering
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ty = tile / tile_w, tx = tile - ty * tile_w;
     const int bx0 = tx * GAGS_TILE + (blk & 1) * 8, by0 = ty * GAGS_TILE + (blk >> 1) * 8;
@@ -1244,7 +1249,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_sdot_f16(int d, int ch0, in
             const int row = t0 + 4 * kq + i;
             if (row < cnt) {
 #pragma unroll
-                for (int pg = 0; pg < 4; ++pg) S[(size_t)(sb + row) * 64 + 16 * pg + m] = acc[pg][i] * sc;
+                for (int pg = 0; pg < 4; ++pg) S[(size_t)(srb + row) * 64 + 16 * pg + m] = acc[pg][i] * sc;
             }
         }
     }
@@ -1308,11 +1313,12 @@ __global__ __launch_bounds__(64) void raster_bwd_geom(int width, int height, int
         const int slot = sb + max(j, 0);
         q.sx = sidx_s[slot]; q.g = gid_s[slot];
         q.f = wt[(size_t)slot * 64 + lane];
-        q.sd = S[(size_t)slot * 64 + lane];
+        const size_t so = (size_t)(rb + max(j, 0)) * 64 + lane;  // S is numbered like the per-slot rows (compact or sparse)
+        q.sd = S[so];
         if (n_pass > 1) {  // (uniform; at most four passes: D <= 1024)
-            q.sd += S[s_stride + (size_t)slot * 64 + lane];
-            if (n_pass > 2) q.sd += S[2 * s_stride + (size_t)slot * 64 + lane];
-            if (n_pass > 3) q.sd += S[3 * s_stride + (size_t)slot * 64 + lane];
+            q.sd += S[s_stride + so];
+            if (n_pass > 2) q.sd += S[2 * s_stride + so];
+            if (n_pass > 3) q.sd += S[3 * s_stride + so];
         }
         return q;
     };
@@ -1378,7 +1384,7 @@ inline GeomLayout geom_layout(int64_t n_isects, int width, int height, int n_gau
     GeomLayout L;
     int64_t o = 0;
     const int64_t n_pass = std::max(1, (d + SD_MAXCH - 1) / SD_MAXCH);  // the split-f16 dot pass: one S / bgdot buffer per pass
-    L.S = o; o += n_pass * al256(slots * 256);
+    L.S = o; o += n_pass * al256((rows + 64) * 256);  // numbered like the per-slot rows: compact (n_rows) or the sparse slot space
     L.bgdot = o; o += n_pass * al256((int64_t)width * height * 4);
     L.grow = o; o += al256(rows * 32);
     L.key = o; o += al256(rows * 4);
@@ -1433,8 +1439,8 @@ int gags_raster_bwd_geom_launch(int d, int n_gauss, int width, int height, const
     }
     const bool split16 = !f32mfma && hit && flatten_ids;
     // the split-f16 dot pass writes one S / bgdot buffer per 256-channel pass (the fp32 one accumulates in the first)
-    const int64_t slots_all = GAGS_BLOCKS_PER_TILE * ((int64_t)n_isects + n_tiles) + 64;
-    const size_t s_stride = (size_t)al256(slots_all * 256) / 4, bg_stride = (size_t)al256((int64_t)width * height * 4) / 4;
+    const int64_t s_rows = (n_rows < 0 ? GAGS_BLOCKS_PER_TILE * ((int64_t)n_isects + n_tiles) + 64 : (n_rows > 0 ? n_rows : 1)) + 64;
+    const size_t s_stride = (size_t)al256(s_rows * 256) / 4, bg_stride = (size_t)al256((int64_t)width * height * 4) / 4;
     const int n_pass = split16 ? (d + SD_MAXCH - 1) / SD_MAXCH : 1;
     if (split16) {
         static bool attr16_set = false;
@@ -1461,10 +1467,10 @@ int gags_raster_bwd_geom_launch(int d, int n_gauss, int width, int height, const
             const size_t lds = (size_t)2 * 64 * (32 * ks + SF_PADH) * 2;
             if (ks == SD_MAXCH / 32)
                 hipLaunchKernelGGL(raster_bwd_sdot_f16<SD_MAXCH / 32>, grid, dim3(256), lds, st, d, ch0, ks, width, height, tile_w, n_tiles,
-                                   n_gauss, v_out, table, rinv, backgrounds, offsets, n_isects, blk_rows, gid_s, S_p, bg_p);
+                                   n_gauss, v_out, table, rinv, backgrounds, offsets, n_isects, blk_rows, gid_s, S_p, bg_p, row_base);
             else
                 hipLaunchKernelGGL(raster_bwd_sdot_f16<0>, grid, dim3(256), lds, st, d, ch0, ks, width, height, tile_w, n_tiles,
-                                   n_gauss, v_out, table, rinv, backgrounds, offsets, n_isects, blk_rows, gid_s, S_p, bg_p);
+                                   n_gauss, v_out, table, rinv, backgrounds, offsets, n_isects, blk_rows, gid_s, S_p, bg_p, row_base);
         }
     }
     for (int ch0 = 0; ch0 < d && !split16; ch0 += SD_MAXCH) {
@@ -1473,10 +1479,10 @@ int gags_raster_bwd_geom_launch(int d, int n_gauss, int width, int height, const
         const size_t lds = (size_t)64 * (dch + SD_PAD) * 4;
         if (dch == SD_MAXCH)
             hipLaunchKernelGGL(raster_bwd_sdot<SD_MAXCH>, grid, dim3(256), lds, st, d, ch0, dch, width, height, tile_w, n_tiles, n_gauss,
-                               v_out, colors, backgrounds, offsets, n_isects, blk_rows, gid_s, S, bgdot, ch0 > 0 ? 1 : 0);
+                               v_out, colors, backgrounds, offsets, n_isects, blk_rows, gid_s, S, bgdot, ch0 > 0 ? 1 : 0, row_base);
         else
             hipLaunchKernelGGL(raster_bwd_sdot<0>, grid, dim3(256), lds, st, d, ch0, dch, width, height, tile_w, n_tiles, n_gauss,
-                               v_out, colors, backgrounds, offsets, n_isects, blk_rows, gid_s, S, bgdot, ch0 > 0 ? 1 : 0);
+                               v_out, colors, backgrounds, offsets, n_isects, blk_rows, gid_s, S, bgdot, ch0 > 0 ? 1 : 0, row_base);
     }
     hipLaunchKernelGGL(raster_bwd_geom, dim3(n_tiles * GAGS_BLOCKS_PER_TILE), dim3(64), 0, st, width, height, tile_w, n_tiles,
                        n_gauss, reinterpret_cast<const GRec *>(packed), offsets, n_isects, blk_rows, wt, gid_s, sidx_s, S, Tbuf,

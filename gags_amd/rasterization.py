@@ -46,6 +46,7 @@ ZERO_FILL_MIN_ELEMS = 1 << 24  # (below that the second stream's hand-over costs
 # 1.27 -> 0.95 ms, but the fill kernel takes the CUs from whatever it runs beside -- under the rows kernel that kernel
 # slowed by 0.38 ms, under the binning kernels the step grew by 1.7 ms.  The C-ABI flag stays for callers that own a zeroed
 # buffer anyway.
+GEOM_COMPACT_ROWS = True   # gags_raster_bwd_geom: per-slot rows numbered compactly (one prefix sum + a 4-byte readback)
 OVERLAP_ZERO_FILL = False
 _SIDE = {}
 
@@ -363,9 +364,12 @@ class _Rasterize(torch.autograd.Function):
                 colors = colors.float()
             # compact numbering of the per-slot rows: one small prefix sum and a 4-byte readback instead of sorting the
             # whole sparse slot space (6x the keys)
-            incl = torch.cumsum(blk_rows, 0, dtype=torch.int32)
-            row_base = (incl - blk_rows).contiguous()
-            n_rows = int(incl[-1].item()) if incl.numel() else 0
+            if GEOM_COMPACT_ROWS:
+                incl = torch.cumsum(blk_rows, 0, dtype=torch.int32)
+                row_base = (incl - blk_rows).contiguous()
+                n_rows = int(incl[-1].item()) if incl.numel() else 0
+            else:  # the C ABI's other numbering: rows (and the dot products) in the sparse slot space, no count needed
+                row_base, n_rows = None, -1
             nb = lib.gags_raster_bwd_geom_scratch_bytes(n_isects, width, height, n, d, n_rows)
             gscratch = torch.empty(nb, dtype=torch.uint8, device=dev)
             v_geo = torch.empty(n, 8, device=dev)

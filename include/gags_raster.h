@@ -206,8 +206,9 @@ int gags_bwd_rowmap(int64_t n_isects, int width, int height, const int32_t *isec
  * blk_rows) with n_rows = sum of blk_rows numbers the per-slot rows compactly, so that only n_rows keys are sorted;
  * NULL / -1: one row per slot of the sparse slot space (no host-side count needed, ~6x more keys).
  * flatten_ids: the sorted intersections' Gaussian ids (names, with the forward's hit flags, the rows to split).
- * scratch: gags_raster_bwd_geom_scratch_bytes(n_isects, w, h, n, d, n_rows) (~1.1 KB per tile intersection + 1.5 KB per
- * Gaussian for the split table of one 256-channel pass).
+ * scratch: gags_raster_bwd_geom_scratch_bytes(n_isects, w, h, n, d, n_rows): with row_base the dot products are numbered
+ * like the rows (256 B per blended slot and 256-channel pass: 2.3 GB at C3, D = 512), without it they live in a copy of
+ * the forward's sparse slot space (~1.1 KB per tile intersection and pass); + 1.5 KB per Gaussian for the split table.
  * Returns 1 when D is not eligible. */
 int64_t gags_raster_bwd_geom_scratch_bytes(int64_t n_isects, int width, int height, int n, int d, int64_t n_rows);
 int gags_raster_bwd_geom(int d, int n, int width, int height, const float *colors, const float *backgrounds,

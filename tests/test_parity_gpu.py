@@ -555,6 +555,27 @@ def test_full_backward_with_more_than_1024_slots_in_one_block(oracle):
         assert e <= 5e-6 and e <= e_orc, (name, e, e_orc)
 
 
+def test_wide_geometry_backward_in_the_sparse_slot_numbering():
+    """gags_raster_bwd_geom with row_base = NULL (rows and dot products live in the forward's sparse slot space: no prefix
+    sum, no readback, ~6x the keys to sort) gives the same gradients, bit for bit, as the compact numbering the wrapper
+    uses -- the sums run over the same rows in the same order."""
+    from gags_amd import rasterization as R
+    n, w, h, d = 2000, 112, 80, 328
+    s = scene_arrays(n, d, w, h, seed=34, view=2, scale_mult=5.0)
+    rng = np.random.default_rng(10)
+    v_out = rng.standard_normal((h, w, d)).astype(np.float32)
+    v_alpha = rng.standard_normal((h, w)).astype(np.float32)
+    bg = np.full(d, 0.2, np.float32)
+    _, _, _, g_c = _run_gpu(s, w, h, s["colors"], bg, need_geom=True, v_out=v_out, v_alpha=v_alpha)
+    R.GEOM_COMPACT_ROWS = False
+    try:
+        _, _, _, g_s = _run_gpu(s, w, h, s["colors"], bg, need_geom=True, v_out=v_out, v_alpha=v_alpha)
+    finally:
+        R.GEOM_COMPACT_ROWS = True
+    for k in ("means", "quats", "scales", "opacities", "means2d", "colors"):
+        np.testing.assert_array_equal(g_c[k], g_s[k])
+
+
 def test_wide_geometry_backward_with_nothing_to_render():
     """Degenerate inputs through the matrix-core geometry path: every Gaussian behind the camera (no intersections at
     all), and a view that only a handful of Gaussians reach -- gradients are exact zeros where nothing blended."""
