@@ -57,6 +57,7 @@ struct XArgs {
     float *part;            // TN: partial outputs [n_chunks][Mo * No]
     unsigned m_tiles, n_tiles;  // NT: tile counts (the workgroup index is decoded XCD-aware)
     float *bias_part;       // TN: partial column sums of A1 (the bias gradient) [n_chunks][Mo], or null
+    int vout;               // NT: the epilogue may move float4 pieces of rows (N % 4 == 0, ldy % 4 == 0, aligned outputs)
 };
 
 // Staging is split in two so that the global loads of step s + 1 are in flight while step s multiplies:
@@ -176,11 +177,16 @@ __device__ __forceinline__ void tile_step(f32x16 (&acc)[2][2], unsigned short (*
     }
 }
 
+constexpr int XOP = XN + 4;  // output tile pitch in floats (528 B rows: 16-byte aligned)
 template <bool TWO, bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_x3_nt_kernel(XArgs g)
 {
-    __shared__ __attribute__((aligned(16))) unsigned short Xs[NTERM][XM][XLD];
-    __shared__ __attribute__((aligned(16))) unsigned short Ys[NTERM][XN][XLD];
+    // one buffer: the operand images during the K loop (2 x 3 x 128 x 40 bf16 = 60 KB), then the fp32 output tile of the
+    // epilogue (128 x 132 floats = 66 KB); two workgroups per CU either way
+    constexpr int OPER = 2 * NTERM * XM * XLD * 2, OUTB = XM * XOP * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[OPER > OUTB ? OPER : OUTB];
+    unsigned short (*Xs)[XM][XLD] = reinterpret_cast<unsigned short (*)[XM][XLD]>(smem);
+    unsigned short (*Ys)[XN][XLD] = reinterpret_cast<unsigned short (*)[XN][XLD]>(smem + NTERM * XM * XLD * 2);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wy = wave >> 1, wx = wave & 1;
     // the column tiles of one pixel tile run back to back on the SAME XCD (workgroups are dealt round-robin over the 8
     // XCDs, each with its own L2): the second one finds the activation rows in that L2 instead of re-reading HBM
@@ -209,6 +215,70 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_nt_kernel(XArgs g)
         __builtin_amdgcn_sched_barrier(0);  // (the scheduler would sink the loads to their use after the MFMAs)
         tile_step(acc, Xs, Ys, wy, wx, lane);
         __syncthreads();
+    }
+    if (g.vout) {  // (uniform)
+        // Epilogue through LDS (N % 4 == 0, ldy % 4 == 0, 16-byte aligned outputs): the accumulators (+ bias, ReLU) go to a fp32 tile in the buffer the operand
+        // images no longer need, then every thread handles whole float4 pieces of rows -- residual, pre-mask copy, mask and
+        // the result move as 16-byte accesses of full lines.  (Straight from the accumulators every access is 4 bytes per
+        // lane, 64 stores and up to 128 loads per lane: 38 % of this kernel's time, timestamps of round 3.)
+        float (*T)[XOP] = reinterpret_cast<float (*)[XOP]>(smem);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int nl = wx * 64 + j * 32 + (lane & 31);
+                const float bv = g.bias ? g.bias[min(n0 + nl, g.N - 1)] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pl = wy * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    float v = acc[i][j][r] + bv;
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    T[pl][nl] = v;
+                }
+            }
+        __syncthreads();
+#pragma unroll
+        for (int q0 = 0; q0 < 16; q0 += 8) {  // two batches of eight pieces: every load of a batch before its first store
+            float4 ev[8], mv[8];
+            size_t o[8];
+            bool in[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int id = tid + 256 * (q0 + q), row = id >> 5, c = (id & 31) * 4;
+                const int64_t p = m0 + row;
+                in[q] = p < g.M && n0 + c < g.N;  // (N % 4 == 0: a piece is inside or outside as a whole)
+                o[q] = (size_t)min(p, g.M - 1) * g.ldy + min(n0 + c, g.N - 4);
+            }
+            if (g.E) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ev[q] = *reinterpret_cast<const float4 *>(g.E + o[q]);
+            }
+            if (g.mask_src) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) mv[q] = *reinterpret_cast<const float4 *>(g.mask_src + o[q]);
+            }
+            if (g.E) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { asm volatile("" : "+v"(ev[q].x)); asm volatile("" : "+v"(ev[q].y)); asm volatile("" : "+v"(ev[q].z)); asm volatile("" : "+v"(ev[q].w)); }
+            }
+            if (g.mask_src) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { asm volatile("" : "+v"(mv[q].x)); asm volatile("" : "+v"(mv[q].y)); asm volatile("" : "+v"(mv[q].z)); asm volatile("" : "+v"(mv[q].w)); }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int id = tid + 256 * (q0 + q), row = id >> 5, c = (id & 31) * 4;
+                float4 v = *reinterpret_cast<const float4 *>(&T[row][c]);
+                if (g.E) { v.x += ev[q].x; v.y += ev[q].y; v.z += ev[q].z; v.w += ev[q].w; }
+                if (g.Ypre && in[q]) *reinterpret_cast<float4 *>(g.Ypre + o[q]) = v;
+                if (g.mask_src) {
+                    v.x = mv[q].x > 0.f ? v.x : 0.f; v.y = mv[q].y > 0.f ? v.y : 0.f;
+                    v.z = mv[q].z > 0.f ? v.z : 0.f; v.w = mv[q].w > 0.f ? v.w : 0.f;
+                }
+                if (g.Y && in[q]) *reinterpret_cast<float4 *>(g.Y + o[q]) = v;
+            }
+        }
+        return;
     }
     // accumulator of tile (i, j): column = lane & 31 -> n, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -> pixel.
     // The residual / mask rows of a tile are requested together, unconditionally (clamped addresses), before any of
@@ -397,6 +467,9 @@ extern "C" int gags_decoder_layer_exact(int64_t n_pix, int n_out, int k_in, cons
     const dim3 grid((g.m_tiles + 7) / 8 * 8 * g.n_tiles);
     const bool vec = k_in % 4 == 0 && lda % 4 == 0 && ((reinterpret_cast<uintptr_t>(a1) | reinterpret_cast<uintptr_t>(a2) |
                                                           reinterpret_cast<uintptr_t>(w)) & 15) == 0;
+    g.vout = (n_out % 4 == 0 && ldy % 4 == 0 &&
+              ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(y_premask) | reinterpret_cast<uintptr_t>(mask_src) |
+                reinterpret_cast<uintptr_t>(residual)) & 15) == 0) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     if (a2) {
         if (vec) hipLaunchKernelGGL((gemm_x3_nt_kernel<true, true>), grid, dim3(256), 0, st, g);
