@@ -100,6 +100,42 @@ def reduce_feature_grad(grad, mode="rs_ag", average=False, bucket_bytes=BUCKET_B
     return grad
 
 
+GEOMETRY_PARAMS = ("_xyz", "_rotation", "_scaling", "_opacity")  # [N,3] [N,4] [N,3] [N,1]: SURVEY 8e's [N, 3+4+3+1]
+
+
+def reduce_geometry_grads(pc, mode="rs_ag", average=False, names=GEOMETRY_PARAMS):
+    """By-view step with trainable geometry (north_star: "all-reduce of feature / GEOMETRY gradients"): sum over the ranks
+    of d loss / d (_xyz, _rotation, _scaling, _opacity) as ONE packed [N, 11] fp32 block -- one bucket through the same
+    reduce-scatter + all-gather as the feature gradient (66 MB at C3, against 3 GB of features) -- written back into each
+    parameter's .grad.  Parameters that do not require grad are skipped (the reference's GAD stage freezes them all,
+    scene/gaussian_model.py:183-208: then this is a no-op); a trainable parameter whose .grad is None on this rank (its
+    view blended nothing) contributes zeros and receives the sum.  Every rank must call it with the same set of trainable
+    parameters.  Returns the list of reduced parameter names."""
+    params = [(k, getattr(pc, k)) for k in names if getattr(pc, k, None) is not None and getattr(pc, k).requires_grad]
+    if not params or world() == 1:
+        return [k for k, _ in params]
+    n = params[0][1].shape[0]
+    cols = [p.numel() // max(n, 1) for _, p in params]
+    block = torch.empty(n, sum(cols), dtype=torch.float32, device=params[0][1].device)
+    c = 0
+    for (_, p), w in zip(params, cols):
+        if p.grad is None:
+            block[:, c:c + w].zero_()
+        else:
+            block[:, c:c + w].copy_(p.grad.reshape(n, w))
+        c += w
+    reduce_feature_grad(block, mode=mode, average=average)
+    c = 0
+    for (_, p), w in zip(params, cols):
+        part = block[:, c:c + w].reshape(p.shape)
+        if p.grad is None:
+            p.grad = part.to(p.dtype).contiguous()
+        else:
+            p.grad.copy_(part)
+        c += w
+    return [k for k, _ in params]
+
+
 _TYPE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
 
@@ -150,11 +186,14 @@ class OverlappedGradReducer:
         red.finish(pc._semantic_feature.grad)     # compute stream waits for the exchange; exact fp32 sum
 
     The tensor autograd consumes is never written by the exchange stream (the hook only READS it); the reduced ranges
-    live in the reducer until finish().  finish() then either assigns them -- when the parameter's gradient is this
-    backward's local gradient and nothing else: `param.grad` was None on entry (known when `param` is given), or the
-    gradient tensor is the very tensor the hook saw -- or, when the gradient already holds other terms (accumulation
-    over several views, a clone with unknown history), adds `sum over ranks - local` from the packed local rows it kept.
-    A gradient that has been reduced once is never reduced again.
+    live in the reducer until finish().  finish() ASSIGNS them only when the gradient tensor is the very tensor the
+    hook saw (autograd adopted it: same storage) AND nobody wrote to it in place since (its version counter is the one
+    the hook saw).  In every other case -- the parameter has a second consumer in the graph (a regulariser on
+    `_semantic_feature`: autograd sums the terms into a fresh tensor, or adds in place), accumulation over several views,
+    a clone or a cast with unknown history -- the gradient holds terms that are not this backward's local rows, so
+    finish() adds `sum over ranks - local` from the packed local rows it always keeps; terms from other graph paths stay
+    rank-local and are the caller's to reduce (reduce_feature_grad).  A gradient that has been reduced once is never
+    reduced again.
 
     wire="bf16" (opt-in) halves the bytes on xGMI: the range is rounded to bfloat16, summed in bfloat16 by the
     collective and widened again; the result differs from the fp32 sum by ~1e-2 relative (tests/test_dist_cpu.py
@@ -181,13 +220,11 @@ class OverlappedGradReducer:
     def _reset(self):
         self._alias, self._covered, self._entries = None, 0, []
         self._mask, self._idx = None, None
-        self._keep_local = True
+        self._alias_version = None
 
     def __enter__(self):
         from . import rasterization
         self._reset()
-        # the parameter's gradient will be exactly this backward's local gradient iff it does not exist yet
-        self._keep_local = not (self.param is not None and self.param.grad is None)
         self._prev = (rasterization.GRAD_RANGE_HOOK, rasterization.GRAD_ROWS_HOOK)
         rasterization.GRAD_RANGE_HOOK = self.on_range
         rasterization.GRAD_ROWS_HOOK = self.on_rows if (self.rows == "union" and world() > 1) else None
@@ -225,7 +262,7 @@ class OverlappedGradReducer:
         if idx is None:
             self.rows_exchanged = None
         wire = _pack_rows(grad, idx, c0, c1, torch.bfloat16 if self.wire == "bf16" else torch.float32)
-        local = wire.clone() if self._keep_local else None
+        local = wire.clone()  # always: whether autograd adopts the hook's tensor is only known in finish()
         reduce_feature_grad(wire, mode=self.mode, bucket_bytes=self.bucket_bytes)
         return dict(c0=c0, c1=c1, wire=wire, local=local, idx=idx)
 
@@ -233,6 +270,8 @@ class OverlappedGradReducer:
         if any(e["c0"] < c1 and c0 < e["c1"] for e in self._entries) or (
                 self._alias is not None and self._alias.data_ptr() != grad.data_ptr()):
             raise RuntimeError("OverlappedGradReducer: one backward per `with` block (call finish() between views)")
+        if self._alias is None:
+            self._alias_version = grad._version  # kernels write through raw pointers: only torch in-place ops bump it
         self._alias = grad
         self._covered += c1 - c0
         if world() == 1:
@@ -269,9 +308,14 @@ class OverlappedGradReducer:
             raise RuntimeError(f"OverlappedGradReducer: the backward delivered {self._covered} of "
                                f"{param_grad.shape[1]} channels")
         if used:
-            adopted = self._alias is not None and self._alias.data_ptr() == param_grad.data_ptr()
+            # adopted: the parameter's gradient IS the tensor the hook saw (same storage, same shape) and no in-place op
+            # touched it since (the alias shares its version counter) => it holds exactly this backward's local rows
+            adopted = (self._alias is not None and self._alias.data_ptr() == param_grad.data_ptr()
+                       and self._alias.shape == param_grad.shape and param_grad.dtype == self._alias.dtype
+                       and param_grad._version == self._alias_version == self._alias._version)
+            self.assigned = bool(adopted)
             for e in self._entries:
-                assign = (not self._keep_local) or adopted
+                assign = adopted
                 _unpack_rows(param_grad, e["idx"], e["c0"], e["c1"], e["wire"], None if assign else e["local"])
                 if cuda:
                     e["wire"].record_stream(torch.cuda.current_stream())
@@ -299,7 +343,8 @@ def distributed_step(render_fn, cams, pc, bg, cotangents, mode="rs_ag"):
     <render, G_v> for each, then reduce the feature gradient over ranks.  mode "channel": `pc` holds this
     rank's channel shard of the features ([N, c1-c0], see channel_shard) and `cotangents[v]` the matching
     channels of G_v; every view is rendered, the gradient of the shard accumulates locally, nothing is
-    exchanged.  Returns the local sum of losses."""
+    exchanged.  Trainable geometry (any of GEOMETRY_PARAMS requiring grad) is reduced too, as one packed [N,11] block.
+    Returns the local sum of losses."""
     if mode == "channel":
         pc._semantic_feature.grad = None
         total = None
@@ -320,4 +365,5 @@ def distributed_step(render_fn, cams, pc, bg, cotangents, mode="rs_ag"):
     if pc._semantic_feature.grad is None:
         pc._semantic_feature.grad = torch.zeros_like(pc._semantic_feature)
     reduce_feature_grad(pc._semantic_feature.grad, mode=mode)
+    reduce_geometry_grads(pc, mode=mode)
     return total

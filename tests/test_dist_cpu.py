@@ -157,7 +157,7 @@ def _overlap_worker(rank, world, port, wire, q):
     grad = grads[rank].clone()
     red = OverlappedGradReducer(mode=mode, wire=wire, bucket_bytes=8192)
     feed(red, grad)
-    out["adopted"] = (red.finish(grad), rel(grad, expect))
+    out["adopted"] = (red.finish(grad), rel(grad, expect), red.assigned)
     # 2. copied: another consumer forced a clone (param unknown: the reducer falls back on local + (sum - local))
     local = grads[rank].clone()
     feed(red, local)
@@ -170,13 +170,23 @@ def _overlap_worker(rank, world, port, wire, q):
     feed(red, local)
     acc = old + local
     out["accumulated"] = (red.finish(acc), rel(acc, old + expect))
-    # 4. param known and its gradient None on entry: assignment even when autograd cloned (bit-identical to case 1)
+    # 4. param known, its gradient None on entry, but the parameter has a SECOND consumer in the graph (a regulariser on
+    #    the features): autograd sums both terms into a fresh tensor.  The other term must survive, un-reduced (ADVICE r3:
+    #    an assignment on "grad was None on entry" silently dropped it on the union rows)
     prm = torch.nn.Parameter(torch.zeros(n, d))
     red_p = OverlappedGradReducer(mode=mode, wire=wire, bucket_bytes=8192, param=prm)
     local = grads[rank].clone()
     feed(red_p, local)
-    prm.grad = local.clone()
-    out["param_fresh"] = (red_p.finish(prm.grad), rel(prm.grad, expect), bool(torch.equal(prm.grad, grad)))
+    other_term = torch.randn(n, d, generator=torch.Generator().manual_seed(500 + rank))
+    prm.grad = local + other_term
+    out["param_fresh"] = (red_p.finish(prm.grad), rel(prm.grad, expect + other_term), not red_p.assigned)
+    # 4a. ... or adds the second term IN PLACE into the adopted tensor (same storage; its version counter moved)
+    prm.grad = None
+    local = grads[rank].clone()
+    feed(red_p, local)
+    local += other_term
+    out["param_inplace"] = (red_p.finish(local), rel(local, expect + other_term), not red_p.assigned)
+    prm.grad = local
     # 4b. the same parameter with a gradient already there: the next block accumulates
     local = grads[rank].clone()
     feed(red_p, local)
@@ -224,9 +234,9 @@ def test_overlapped_reducer_two_ranks(wire, tol):
         p.join(timeout=60)
         assert p.exitcode == 0
     for _, out in res:
-        for case in ("adopted", "copied", "accumulated", "param_fresh", "param_accumulate"):
+        for case in ("adopted", "copied", "accumulated", "param_fresh", "param_inplace", "param_accumulate"):
             assert out[case][0] and out[case][1] <= tol, (case, out[case])
-        assert out["param_fresh"][2]
+        assert out["adopted"][2] and out["param_fresh"][2] and out["param_inplace"][2]
         if wire is None:
             assert out["cast"][0] and out["cast"][1] <= 1e-6, out["cast"]
         assert not out["unseen"][0] and out["unseen"][1] <= 1e-6  # the plain path is always the exact fp32 reduction
@@ -276,3 +286,59 @@ def test_overlapped_reducer_exchanges_only_the_union_of_nonzero_rows(world):
     for _, used, exact, rows, union in res:
         assert used and exact           # (three ranks: every rank adds the same shards in the same order)
         assert rows == union and union < 1001
+
+
+def _geometry_worker(rank, world, port, q):
+    """reduce_geometry_grads: the four geometry gradients travel as ONE packed [N,11] block and come back as
+    the exact sum; frozen parameters are left alone; a rank whose view produced no gradient contributes zeros."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import gags_amd.dist as D
+    n = 517
+    shapes = {"_xyz": (n, 3), "_rotation": (n, 4), "_scaling": (n, 3), "_opacity": (n, 1)}
+
+    class PC:
+        pass
+
+    def grads_of(r):
+        g = torch.Generator().manual_seed(900 + r)
+        return {k: torch.randn(*s, generator=g) for k, s in shapes.items()}
+
+    pc = PC()
+    for k, s in shapes.items():
+        setattr(pc, k, torch.nn.Parameter(torch.zeros(*s)))
+    mine = grads_of(rank)
+    for k in shapes:
+        getattr(pc, k).grad = mine[k].clone()
+    pc._scaling.requires_grad_(False)          # frozen: must not be touched
+    if rank == 1:
+        pc._opacity.grad = None                # this rank's view blended nothing
+    calls = []
+    real = D.reduce_feature_grad
+    D.reduce_feature_grad = lambda g, **kw: (calls.append(tuple(g.shape)), real(g, **kw))[1]
+    done = D.reduce_geometry_grads(pc, mode="rs_ag")
+    D.reduce_feature_grad = real
+    expect = {k: sum(grads_of(r)[k] for r in range(world)) for k in shapes}
+    expect["_opacity"] = sum(grads_of(r)["_opacity"] for r in range(world) if r != 1)
+    ok = done == ["_xyz", "_rotation", "_opacity"] and calls == [(n, 8)]
+    for k in done:
+        ok = ok and torch.equal(getattr(pc, k).grad, expect[k])
+    ok = ok and torch.equal(pc._scaling.grad, mine["_scaling"])
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_geometry_gradients_reduce_as_one_packed_block_two_ranks():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_geometry_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
