@@ -142,6 +142,16 @@ def cpu_baseline(pc, cam, d, width, height, target_s):
     }
 
 
+def rccl_info():
+    """What decides the collective's algorithm on this stack: library version and the NCCL_* / RCCL_* environment."""
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        ver = None
+    env = {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_")) or k == "HSA_ENABLE_IPC_MODE_LEGACY"}
+    return {"version": ver, "NCCL_ALGO": os.environ.get("NCCL_ALGO"), "NCCL_PROTO": os.environ.get("NCCL_PROTO"), "env": env}
+
+
 def host_cpu():
     """Sockets x cores x threads and the model name of the host (cpu_baseline.cores = OpenMP threads used)."""
     try:
@@ -166,15 +176,21 @@ def host_cpu():
 # kernels behind each bracketed stage, by their short rocprofv3 names (tools/pmc_summary.py)
 # (matched as prefixes: template arguments differ between rounds, e.g. "raster_fwd_feat<4, false>")
 STAGE_KERNELS = {
-    "raster_fwd": ("raster_weights_kernel", "raster_fwd_feat<4"),
-    "bwd_rows": ("raster_bwd_rows_f16",),
+    "raster_weights": ("raster_weights_kernel",),
+    "raster_fwd_feat": ("raster_fwd_feat<4",),
+    "bwd_rows": ("raster_bwd_rows",),
     "bwd_reduce": ("reduce_rows_kernel",),
 }
+# flops one matrix instruction of each kernel issues (SQ_INSTS_MFMA x this = issued matrix work per launch)
+MFMA_FLOP = {"raster_fwd_feat": 2 * 32 * 32 * 2,    # v_mfma_f32_32x32x2_f32
+             "bwd_rows": 2 * 32 * 32 * 16}           # v_mfma_f32_32x32x16_f16
+F16_MATRIX_PEAK_TFLOPS = 2516.6   # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak
 
 
-def _traffic_of(traffic, prefix):
-    """HBM bytes per launch of the kernel whose short rocprofv3 name starts with `prefix` (None when absent or ambiguous)."""
-    hits = [v["hbm_bytes"] for k, v in traffic.items() if k.startswith(prefix)]
+def _traffic_of(traffic, prefix, key="hbm_bytes"):
+    """Per-launch counter (default: HBM bytes) of the kernel whose short rocprofv3 name starts with `prefix` (None when
+    absent or ambiguous)."""
+    hits = [v.get(key) for k, v in traffic.items() if k.startswith(prefix)]
     return hits[0] if len(hits) == 1 else None
 
 
@@ -210,7 +226,7 @@ def main():
 
     from gags_amd import _lib, profiler, synthetic as syn
     from gags_amd.gaussian_renderer import render
-    from gags_amd.dist import OverlappedGradReducer, reduce_feature_grad
+    from gags_amd.dist import OverlappedGradReducer, reduce_feature_grad, reduce_geometry_grads
     _lib.load()
     exposed = []  # per step: ms the compute stream waited for the gradient exchange after the backward (by-view, N>1)
 
@@ -228,7 +244,7 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
-    def build(mode, grad_reduce=None, scale0=scale0):
+    def build(mode, grad_reduce=None, scale0=scale0, cache=False, share=None):
         """(step function, model, camera of the last view, local feature width) of one decomposition (gags_amd/dist.py).
         view   : Gaussians + features replicated (same seed on every rank), one yawed view per rank (C4's cameras),
                  reduce-scatter + all-gather (or all-reduce) of the feature gradient at step end.
@@ -242,18 +258,34 @@ def main():
         else:
             dl = d
             views = [first + rank] if world > 1 else [None]
-        pc_ = syn.make_model(n, dl, width, height, seed=0, device=dev, gen_device=dev, scale0=scale0)
+        if share is None:
+            pc_ = syn.make_model(n, dl, width, height, seed=0, device=dev, gen_device=dev, scale0=scale0)
+        else:  # (probe of another decomposition: the same geometry tensors, a feature table of this mode's width)
+            from gags_amd.scene import GaussianModel
+            pc_ = GaussianModel.from_tensors(share._xyz.data, share._scaling.data, share._rotation.data, share._opacity.data,
+                                             share._features_dc.data, share._features_rest.data,
+                                             share._semantic_feature.data[:, :dl].contiguous())
         pc_.training_setup()
-        pc_.cache_activations(True)  # geometry frozen for the whole run (GAD stage, train.py:62-75): getters evaluated once
+        # the getters (exp / normalize / sigmoid of the frozen geometry) are evaluated on EVERY render, inside the timed
+        # region, as the reference does (scene/gaussian_model.py:116-139); the library's opt-in activation cache is
+        # measured separately and reported as `activation_cache_on`
+        pc_.cache_activations(cache)
         cams = [syn.make_camera(width, height, view=(v % 8) if v is not None else None, device=dev) for v in views]
         G_ = syn.make_cotangent(dl, height, width, seed=1, device=dev)  # [D,H,W] view of [H,W,D] memory
 
         exchange = mode == "view" and world > 1 and not args.no_allreduce
         overlap = exchange and not args.no_overlap
-        red = (OverlappedGradReducer(mode=grad_reduce, wire=args.wire, rows=args.rows, param=pc_._semantic_feature)
-               if overlap else None)
+        ex = {"mode": grad_reduce, "red": None}
+
+        def set_collective(name):
+            """Switch the by-view step's collective (same model, same cameras): rs_ag | allreduce."""
+            ex["mode"] = name
+            ex["red"] = (OverlappedGradReducer(mode=name, wire=args.wire, rows=args.rows, param=pc_._semantic_feature)
+                         if overlap else None)
+        set_collective(grad_reduce)
 
         def step_():
+            red = ex["red"]
             pc_._semantic_feature.grad = None
             for cam_ in cams:
                 pkg_ = render(cam_, pc_, None, bg, feature_mode=True, raster_flags=args.raster_flags)
@@ -268,11 +300,14 @@ def main():
             if exchange and red is None:
                 if args.wire == "bf16":
                     g16 = pc_._semantic_feature.grad.to(torch.bfloat16)
-                    reduce_feature_grad(g16, mode=grad_reduce)
+                    reduce_feature_grad(g16, mode=ex["mode"])
                     pc_._semantic_feature.grad.copy_(g16)
                 else:
-                    reduce_feature_grad(pc_._semantic_feature.grad, mode=grad_reduce)
+                    reduce_feature_grad(pc_._semantic_feature.grad, mode=ex["mode"])
+            if exchange:  # trainable geometry (not the GAD stage): its gradients travel as one packed [N,11] block
+                reduce_geometry_grads(pc_, mode=ex["mode"])
             return pkg_
+        step_.set_collective = set_collective
         return step_, pc_, cams[-1], dl
 
     bg = torch.zeros(3, device=dev)
@@ -289,8 +324,13 @@ def main():
         elif channel_ok:  # auto: two probe steps of each candidate, same decision on every rank (MAX over ranks)
             probe = {}
             cands = {"view": ("view", "rs_ag"), "view/allreduce": ("view", "allreduce"), "channel": ("channel", None)}
+            base_fn, base_pc, _, _ = build("view", "rs_ag")  # ONE model: the collectives switch on it, the channel probe shares its geometry
             for name, (m, gr) in cands.items():
-                fn, pc_, _, _ = build(m, gr)
+                if m == "view":
+                    fn, pc_ = base_fn, base_pc
+                    fn.set_collective(gr)
+                else:
+                    fn, pc_, _, _ = build(m, gr, share=base_pc)
                 try:  # a collective flavour the backend refuses costs its candidate, not the run
                     fn()
                     torch.cuda.synchronize(); barrier()
@@ -305,7 +345,8 @@ def main():
                 torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
                 probe[name] = 1e3 * float(tt.item()) / 2 if tt.item() != float("inf") else None
                 del fn, pc_
-                torch.cuda.empty_cache()
+            del base_fn, base_pc
+            torch.cuda.empty_cache()
             best = min((k_ for k_ in probe if probe[k_] is not None), key=probe.get, default="channel")
             mode, chosen_reduce = cands[best]
             if chosen_reduce:
@@ -379,6 +420,31 @@ def main():
 
     exposed_ms = exposed[-1].exposed_ms() if exposed else None
     range_ms = exposed[-1].range_ms if exposed else None
+    # "verify RCCL picks the direct/mesh algorithm": the same step with the OTHER collective, a few steps, so
+    # that one N-GPU run yields the rs_ag / allreduce comparison (MAX over ranks; outside `value`)
+    collective_ms = None
+    if world > 1 and mode == "view" and not args.no_allreduce:
+        collective_ms = {args.grad_reduce: 1e3 * dt / args.steps}
+        other = "allreduce" if args.grad_reduce == "rs_ag" else "rs_ag"
+        if os.environ.get("GAGS_DIST_BACKEND", "nccl") == "nccl":
+            ok = 1
+            try:
+                step.set_collective(other)
+                step()
+                torch.cuda.synchronize(); barrier()
+                osteps = max(2, min(args.steps, 5))
+                t1 = time.perf_counter()
+                for _ in range(osteps):
+                    step()
+                torch.cuda.synchronize(); barrier()
+                odt = time.perf_counter() - t1
+            except RuntimeError as e:
+                print(f"[bench] rank {rank}: collective '{other}' failed: {e}", file=sys.stderr, flush=True)
+                ok, odt, osteps = 0, 0.0, 1
+            tt = torch.tensor([odt if ok else float("inf")], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            collective_ms[other] = 1e3 * float(tt.item()) / osteps if tt.item() != float("inf") else None
+            step.set_collective(args.grad_reduce)
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -395,9 +461,16 @@ def main():
         #                 (HBM bound; the kernel actually reads one row per touched (tile, Gaussian))
         #   raster_bwd  : 14*Q_eval + 2*D*Q_blend flops              (single-kernel atomic backward, if used)
         rows = profiler.notes().get("bwd_rows", 0)
+        blk = profiler.notes().get("fwd_blk_rows")
+        slots = int(blk.sum().item()) if blk is not None else 0  # (block, Gaussian) pairs that blended: one weight row each
         dl = d_local  # feature width of one launch on this rank (D, or the rank's channel shard)
+        pix = width * height
+        #   raster_weights : HBM bytes = 40 I (ids, records, hit flags) + 264 slots (weight row, ids) + 12 P (alpha, last id, T)
+        #                    (reported against HBM; the kernel is VALU-bound -- 14 flops per evaluated pair -- and says so)
+        #   raster_fwd_feat: 2*D*Q_blend flops  (fp32 matrix instructions)
         work = {
-            "raster_fwd": ("mfma", 14.0 * q_eval + 2.0 * dl * q_blend),
+            "raster_weights": ("hbm", 40.0 * n_isects + 264.0 * slots + 12.0 * pix),
+            "raster_fwd_feat": ("mfma", 2.0 * dl * q_blend),
             "bwd_rows": ("mfma", 2.0 * dl * q_blend),
             "bwd_reduce": ("hbm", 4.0 * dl * (n_visible + n)),
             "raster_bwd": ("mfma", 14.0 * q_eval + 2.0 * dl * q_blend),
@@ -419,11 +492,25 @@ def main():
             if name in kernels:
                 tb = [_traffic_of(traffic, m) for m in members]
                 kernels[name]["traffic"] = sum(tb) if all(t is not None for t in tb) else None
+                # matrix work the kernel ISSUES per launch (SQ_INSTS_MFMA x flops per instruction, same PMC passes) next
+                # to the algorithmic flops: the ratio is the padding (zero halves, ragged 32-row tiles, split terms)
+                mi = _traffic_of(traffic, members[0], "mfma_insts")
+                if name in MFMA_FLOP and mi:
+                    ms = kernels[name]["avg_launch_ms"]
+                    issued = mi * MFMA_FLOP[name]
+                    pipe_peak = F16_MATRIX_PEAK_TFLOPS if name == "bwd_rows" and not (args.raster_flags & _lib.GAGS_BWD_F32MFMA) else FP32_MATRIX_PEAK_TFLOPS
+                    kernels[name]["issued_flops"] = issued
+                    kernels[name]["mfma_issue_frac"] = issued / (ms * 1e-3) / 1e12 / pipe_peak
+                    kernels[name]["mfma_busy_cycles"] = _traffic_of(traffic, members[0], "mfma_busy_cycles")
+                    kernels[name]["busy_cu_cycles"] = _traffic_of(traffic, members[0], "busy_cu_cycles")
+        if "raster_weights" in kernels:
+            kernels["raster_weights"]["note"] = ("VALU-bound (14 flops per evaluated pair: 14*Q_eval = %.1f GFLOP per launch); priced "
+                                                 "against HBM by the bytes it has to move" % (14.0 * q_eval / 1e9))
         if "bwd_rows" in kernels and not (args.raster_flags & _lib.GAGS_BWD_F32MFMA):
             kernels["bwd_rows"]["note"] = ("algorithmic fp32 flops (2 D Q_blend) against the fp32 matrix peak; the kernel issues them as "
                                            "5 v_mfma_f32_32x32x16_f16 terms per product on split operands (fp32-equivalent, DESIGN.md 4)")
         dom = max(kernels, key=lambda k_: kernels[k_]["avg_launch_ms"])
-        roof = dict(kernels[dom], kernel=dom, traffic_source=traffic_src)
+        roof = dict(kernels[dom], kernel=dom, rocprof_name=STAGE_KERNELS.get(dom, (dom,))[0], traffic_source=traffic_src)
         line = {
             "metric": "feature-raster fwd+bwd views/s",
             "value": value, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -451,9 +538,12 @@ def main():
                                           "collective": args.grad_reduce, "exposed_ms_last_step": exposed_ms,
                                           "range_exchange_ms_last_step": range_ms,
                                           "rows": args.rows if not args.no_overlap else "all",
-                                          "rows_exchanged_last_step": (exposed[-1].rows_exchanged if exposed else None)})},
+                                          "rows_exchanged_last_step": (exposed[-1].rows_exchanged if exposed else None),
+                                          "collective_ms_per_step": collective_ms,
+                                          "rccl": rccl_info()})},
             "roofline": roof,
             "kernels": kernels,
+            "activation_getters": "evaluated on every render inside the timed region (scene/gaussian_model.py:116-139), cache off",
             "stages_ms": {k: round(v[0], 4) for k, v in sorted(stages.items())},
             "step_ms": {"median": per_step[len(per_step) // 2], "p10": per_step[int(0.1 * (len(per_step) - 1))],
                         "p90": per_step[int(round(0.9 * (len(per_step) - 1)))]},
@@ -461,7 +551,6 @@ def main():
         }
         # whole-step view of the metric's "HBM-roofline %": compulsory traffic of one view, every tensor once
         # (SURVEY.md 8d):  72 N + 36 I + 2 V D s_f + 2 P (D s_o + 8) + 4 V D   bytes, s_f = s_o = 4
-        pix = width * height
         b_view = 72.0 * n + 36.0 * n_isects + 2.0 * n_visible * dl * 4 + 2.0 * pix * (dl * 4 + 8) + 4.0 * n_visible * dl
         views_per_gpu_step = world if mode == "channel" else 1
         gbs = b_view * views_per_gpu_step / (ms_per_step * 1e-3) / 1e9
@@ -469,6 +558,22 @@ def main():
                                      "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pc, cam, d, width, height, args.cpu_seconds)
+        if world == 1 and not (args.no_heavy or args.raster_flags):
+            # the library's opt-in activation cache (frozen geometry: getters evaluated once, gags_amd/scene.py); OFF in `value`
+            pc.cache_activations(True)
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            csteps = max(3, min(args.steps, 10))
+            t0 = time.perf_counter()
+            for _ in range(csteps):
+                step()
+            torch.cuda.synchronize()
+            cdt = time.perf_counter() - t0
+            pc.cache_activations(False)
+            line["activation_cache_on"] = {"note": "same workload with GaussianModel.cache_activations(True): exp / normalize / sigmoid "
+                                                   "of the frozen geometry evaluated once instead of on every render",
+                                           "value": csteps / cdt, "unit": "views/s", "ms_per_step": 1e3 * cdt / csteps, "steps": csteps}
         if world == 1 and d % 128 == 0 and not (args.no_heavy or args.raster_flags):
             # the same workload with the backward's contraction on the fp32 matrix instructions (rounds 1-2's default,
             # gags_amd._lib.GAGS_BWD_F32MFMA), reported next to `value` for comparison; DESIGN.md section 4

@@ -67,6 +67,8 @@ SIGNATURES = {
     "gags_adam_step": (_i32, [_i64, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _f64, _i32, _vp]),
     "gags_pack_rows": (_i32, [_i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
     "gags_unpack_rows": (_i32, [_i64, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "gags_compact_mask_scratch_bytes": (_i64, [_i32]),
+    "gags_compact_mask": (_i32, [_i32, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "gags_dot_scratch_bytes": (_i64, []),
     "gags_dot_f32": (_i32, [_i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     # include/gags_next.h
@@ -107,6 +109,7 @@ SIGNATURES = {
 
 GAGS_BWD_COLORS_ONLY = 1
 GAGS_FWD_NO_MFMA = 2
+GAGS_FWD_ONLY_WEIGHTS, GAGS_FWD_ONLY_FEATURES = 512, 1024  # C flags: one kernel of the split forward per call (per-kernel timing)
 GAGS_RECS_BY_GAUSSIAN = 256  # C flag: `packed` is the per-Gaussian record table (gags_pack_isects with packed = NULL)
 GAGS_BWD_ATOMIC = 4  # python-side: use the atomic colours-only backward instead of the staged one
 GAGS_FEAT_F16 = 32  # forward: colors is an fp16 table (include/gags_raster.h)

@@ -112,10 +112,12 @@ extern "C" int gags_raster_fwd(int d, int n, int width, int height, const float 
             float *wt = (float *)(sb + L.wt);
             int32_t *gid_s = (int32_t *)(sb + L.gid);
             float *tbuf = (float *)(sb + L.tbuf);
-            int rc = gags_raster_weights_launch(width, height, n, packed, (flags & GAGS_RECS_BY_GAUSSIAN) ? 1 : 0, isect_offsets, flatten_ids, (int)n_isects, wt,
+            int rc = GAGS_OK;
+            if (!(flags & GAGS_FWD_ONLY_FEATURES))
+                rc = gags_raster_weights_launch(width, height, n, packed, (flags & GAGS_RECS_BY_GAUSSIAN) ? 1 : 0, isect_offsets, flatten_ids, (int)n_isects, wt,
                                                 gid_s, (int32_t *)(sb + L.sidx), (int32_t *)(sb + L.hit), blk_rows, tbuf,
                                                 render_alphas, last_ids, st);
-            if (rc != GAGS_OK) return rc;
+            if (rc != GAGS_OK || (flags & GAGS_FWD_ONLY_WEIGHTS)) return rc;
             return gags_raster_fwd_feat_launch(d, width, height, n, colors, (flags & GAGS_FEAT_F16) ? ((flags & GAGS_FWD_F16MFMA) ? 2 : 1) : 0, backgrounds, isect_offsets, (int)n_isects,
                                                blk_rows, wt, gid_s, tbuf, render_colors, st);
         }

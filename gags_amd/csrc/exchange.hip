@@ -11,6 +11,7 @@
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 #include "common.h"
+#include "scan.h"
 
 namespace {
 
@@ -70,13 +71,20 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(int64_t n_rows, const in
     if (t >= n_rows * q) return;
     const int64_t r = t / q;
     const int c = (int)(t - r * q) * 4;
-    const int64_t g = idx ? idx[r] : r;
+    const int64_t gi = idx ? idx[r] : r;
+    const bool pad = gi < 0;  // a padding row of a capacity-sized block (gags_compact_mask): zeros on the wire
+    const int64_t g = pad ? 0 : gi;
     if constexpr (V4) {
-        Elem<TW>::st4(wire, (size_t)r * cw + c, Elem<TG>::ld4(grad, (size_t)g * d + c0 + c));
+        float4 v = Elem<TG>::ld4(grad, (size_t)g * d + c0 + c);
+        if (pad) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        Elem<TW>::st4(wire, (size_t)r * cw + c, v);
     } else {
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = Elem<TG>::ld(grad, (size_t)g * d + c0 + min(c + e, cw - 1));
+        for (int e = 0; e < 4; ++e) {
+            v[e] = Elem<TG>::ld(grad, (size_t)g * d + c0 + min(c + e, cw - 1));
+            if (pad) v[e] = 0.f;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(v[e]));
 #pragma unroll
@@ -96,6 +104,7 @@ __global__ __launch_bounds__(256) void unpack_rows_kernel(int64_t n_rows, const 
     const int64_t r = t / q;
     const int c = (int)(t - r * q) * 4;
     const int64_t g = idx ? idx[r] : r;
+    if (g < 0) return;  // padding row of a capacity-sized block
     if constexpr (V4) {
         const size_t wi = (size_t)r * cw + c, gi = (size_t)g * d + c0 + c;
         float4 v = Elem<TW>::ld4(wire, wi);
@@ -118,6 +127,52 @@ __global__ __launch_bounds__(256) void unpack_rows_kernel(int64_t n_rows, const 
         for (int e = 0; e < 4; ++e)
             if (c + e < cw) Elem<TG>::st(grad, (size_t)g * d + c0 + c + e, v[e]);
     }
+}
+
+// ---- row mask -> ascending list of row numbers, on the device (the union of the ranks' blended Gaussians) ------------
+// Three small launches: per-block counts (2048 mask bytes per block), the spine (scan.h), scatter.  Ascending order is part
+// of the contract: row r of the wire block must be the same Gaussian on every rank.
+constexpr int CM_PER_THREAD = 8, CM_TILE = 256 * CM_PER_THREAD;
+
+__device__ __forceinline__ int cm_load(const uint8_t *__restrict__ mask, int n, int base, unsigned &bits)
+{
+    bits = 0;
+#pragma unroll
+    for (int e = 0; e < CM_PER_THREAD; ++e)
+        if (base + e < n && mask[base + e]) bits |= 1u << e;
+    return __popc(bits);
+}
+
+__global__ __launch_bounds__(256) void cm_count_kernel(int n, const uint8_t *__restrict__ mask, int32_t *__restrict__ block_sums)
+{
+    __shared__ int smem[4];
+    unsigned bits;
+    const int c = cm_load(mask, n, blockIdx.x * CM_TILE + threadIdx.x * CM_PER_THREAD, bits);
+    int total;
+    gags_scan::block_incl_scan(c, total, smem);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void cm_scatter_kernel(int n, const uint8_t *__restrict__ mask, const int32_t *__restrict__ block_offs,
+                                                         const int32_t *__restrict__ total, int64_t cap, int64_t *__restrict__ idx)
+{
+    __shared__ int smem[4];
+    unsigned bits;
+    const int base = blockIdx.x * CM_TILE + threadIdx.x * CM_PER_THREAD;
+    const int c = cm_load(mask, n, base, bits);
+    int tot;
+    const int incl = gags_scan::block_incl_scan(c, tot, smem);
+    int64_t pos = (int64_t)block_offs[blockIdx.x] + incl - c;
+#pragma unroll
+    for (int e = 0; e < CM_PER_THREAD; ++e)
+        if (bits & (1u << e)) {
+            if (pos < cap) idx[pos] = base + e;
+            ++pos;
+        }
+    // padding behind the count: -1 (gags_pack_rows writes zeros for it, gags_unpack_rows skips it)
+    const int64_t cnt = total[0];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cap; i += (int64_t)gridDim.x * 256)
+        if (i >= cnt) idx[i] = -1;
 }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -173,6 +228,35 @@ extern "C" int gags_unpack_rows(int64_t n_rows, const int64_t *idx, const void *
     else { if (wire_type == 0) GO(1, 0); else if (wire_type == 1) GO(1, 1); else GO(1, 2); }
 #undef GO
 #undef GO1
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+extern "C" int64_t gags_compact_mask_scratch_bytes(int n)
+{
+    const int64_t nb = ((int64_t)(n > 0 ? n : 0) + CM_TILE - 1) / CM_TILE;
+    return (nb > 0 ? nb : 1) * (int64_t)sizeof(int32_t);
+}
+
+extern "C" int gags_compact_mask(int n, const uint8_t *mask, int64_t cap, int64_t *idx, int32_t *count, void *scratch,
+                                 int64_t scratch_bytes, void *stream)
+{
+    if (n < 0 || cap < 0 || !count || (cap > 0 && !idx)) return GAGS_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    GAGS_CLEAR_ERR();
+    if (n == 0) {
+        (void)hipMemsetAsync(count, 0, sizeof(int32_t), st);
+        if (cap > 0) (void)hipMemsetAsync(idx, 0xff, (size_t)cap * sizeof(int64_t), st);
+        GAGS_CHECK_LAUNCH();
+        return GAGS_OK;
+    }
+    if (!mask || !scratch) return GAGS_EINVAL;
+    if (scratch_bytes < gags_compact_mask_scratch_bytes(n)) return GAGS_ESCRATCH;
+    const int nb = (n + CM_TILE - 1) / CM_TILE;
+    int32_t *bs = (int32_t *)scratch;
+    hipLaunchKernelGGL(cm_count_kernel, dim3(nb), dim3(256), 0, st, n, mask, bs);
+    hipLaunchKernelGGL(gags_scan::scan_spine, dim3(1), dim3(gags_scan::SCAN_THREADS), 0, st, nb, bs, count);
+    hipLaunchKernelGGL(cm_scatter_kernel, dim3(nb), dim3(256), 0, st, n, mask, bs, count, cap, idx);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }

@@ -162,7 +162,14 @@ def _chain_forward_exact(x, kind, params):
     """The fp32 chain of a decoder up to its logits (precision="exact").  Same return tuple as _chain_forward; `wb` holds
     the fp32 [out, in] weight matrices and biases."""
     weights, biases = params[0::2], params[1::2]
-    wb = [(wt.detach()[:, :, 0, 0].contiguous().float(), bs.detach().contiguous().float()) for wt, bs in zip(weights, biases)]
+    # private copies (2.4 MB for CNN_decoder), with the transposes the input-gradient GEMMs contract made NOW: for fp32
+    # [co, ci, 1, 1] weights `[:, :, 0, 0].contiguous().float()` is a VIEW of the live parameter, and a backward that runs
+    # after an in-place optimizer step would silently differentiate the new weights (ADVICE r3)
+    wb = []
+    for wt, bs in zip(weights, biases):
+        wm = wt.detach()[:, :, 0, 0].float().clone()
+        wm._gags_t = wm.t().contiguous()
+        wb.append((wm, bs.detach().float().clone()))
     xp, h, w = _pixel_major(x)
     p = h * w
     a0 = xp
@@ -194,7 +201,7 @@ def _chain_backward_exact(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, n
     """fp32 backward of the chain from dz [P, c_out] (precision="exact")."""
     p = h * w
     need_w = need_w or [True] * len(wb)
-    wt = [wgt.t().contiguous() for wgt, _ in wb]  # [k_in, n_out]: the input-gradient GEMM contracts over n_out
+    wt = [_transposed(wgt) for wgt, _ in wb]  # [k_in, n_out] (made in the forward): the input-gradient GEMM contracts over n_out
     dws = [None] * len(wb)
 
     def wg(i, dz_i, a1, a2=None):

@@ -206,12 +206,15 @@ class OverlappedGradReducer:
     If the backward never called the hook (narrow D, atomic kernels), finish() runs the plain reduction of the
     untouched gradient.  `exposed_ms()` = time the compute stream spent on the exchange after the backward had finished."""
 
-    def __init__(self, mode="rs_ag", wire=None, bucket_bytes=BUCKET_BYTES, rows="union", param=None):
+    def __init__(self, mode="rs_ag", wire=None, bucket_bytes=BUCKET_BYTES, rows="union", param=None, sync_free=False,
+                 cap_margin=1.1):
         if rows not in ("union", "all"):
             raise ValueError(rows)
         if wire not in (None, "fp32", "bf16"):
             raise ValueError(wire)
         self.mode, self.wire, self.bucket_bytes, self.rows, self.param = mode, wire, bucket_bytes, rows, param
+        self.sync_free, self.cap_margin = bool(sync_free), float(cap_margin)
+        self._cap_hint, self._pinned = {}, {}
         self.comm = torch.cuda.Stream() if torch.cuda.is_available() else None
         self.rows_exchanged = None  # |union| of the last step (None: all rows)
         self.range_ms = None        # per range of the last step: ms of pack + collective on the exchange stream
@@ -220,6 +223,7 @@ class OverlappedGradReducer:
     def _reset(self):
         self._alias, self._covered, self._entries = None, 0, []
         self._mask, self._idx = None, None
+        self._count, self._padded = None, None
         self._alias_version = None
 
     def __enter__(self):
@@ -252,10 +256,61 @@ class OverlappedGradReducer:
         self._mask = mask
 
     def _union_rows(self):
-        if self._idx is None and self._mask is not None:
-            self._idx = torch.nonzero(self._mask).squeeze(1)  # one host sync, on the exchange stream's past work only
+        """Row list of the union (ascending; identical on every rank).  Device tensors: gags_compact_mask -- prefix sum +
+        scatter on the exchange stream, no torch.nonzero.  What the host needs is the COUNT (it sizes the collective):
+        * default: a 4-byte copy to pinned memory behind an event, waited for right here -- the host waits for the mask's
+          all-reduce + three tiny kernels only (the compute stream keeps the whole first range queued meanwhile; the
+          backward's own row-count readback has already passed this point);
+        * sync_free=True: the block is sized by a capacity remembered from earlier steps (identical on every rank, because
+          the union is), padded with rows of zeros (idx = -1), and the true count is read in finish(); a union larger than
+          the capacity -- nothing was written out of bounds -- is exchanged again in finish() with all N rows."""
+        if self._idx is not None or self._mask is None:
+            return self._idx
+        mask = self._mask
+        if not mask.is_cuda:
+            self._idx = torch.nonzero(mask).squeeze(1)
             self.rows_exchanged = int(self._idx.numel())
+            return self._idx
+        from . import _lib
+        lib = _lib.load()
+        n = mask.numel()
+        dev = mask.device
+        cap = n
+        if self.sync_free and self._cap_hint.get(n):
+            cap = min(n, int(self._cap_hint[n] * self.cap_margin) + 1024)
+        idx = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
+        count = torch.empty(1, dtype=torch.int32, device=dev)
+        sb = lib.gags_compact_mask_scratch_bytes(n)
+        scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
+        _lib.check(lib.gags_compact_mask(n, _lib.ptr(mask), cap, _lib.ptr(idx), _lib.ptr(count), _lib.ptr(scratch), sb,
+                                         torch.cuda.current_stream().cuda_stream), "gags_compact_mask")
+        host = self._pinned.setdefault(dev.index, torch.empty(1, dtype=torch.int32).pin_memory())
+        host.copy_(count, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._count = (host, ev, count)
+        if cap == n:  # exact: wait for the count now (see above) and cut the list to it
+            ev.synchronize()
+            c = int(host[0])
+            self._cap_hint[n] = max(c, int(0.97 * self._cap_hint.get(n, 0)))
+            self._idx, self.rows_exchanged, self._count = idx[:c], c, None
+        else:
+            self._idx, self.rows_exchanged, self._padded = idx[:cap], cap, cap
         return self._idx
+
+    def _resolve_count(self):
+        """sync_free: the union's true size, known by now; True when it exceeded the capacity the block was sized with."""
+        if self._count is None:
+            return False
+        host, ev, _ = self._count
+        ev.synchronize()
+        c = int(host[0])
+        n = self._mask.numel() if self._mask is not None else 0
+        self._cap_hint[n] = max(c, int(0.97 * self._cap_hint.get(n, 0)))
+        self._count = None
+        over = c > self._padded
+        self.rows_exchanged = c
+        return over
 
     def _exchange(self, grad, c0, c1):
         idx = self._union_rows()
@@ -307,6 +362,13 @@ class OverlappedGradReducer:
         if self._entries and not used:
             raise RuntimeError(f"OverlappedGradReducer: the backward delivered {self._covered} of "
                                f"{param_grad.shape[1]} channels")
+        if used and self._resolve_count():
+            # sync_free: this step's union outgrew the remembered capacity; the surplus rows were never packed.  Same
+            # decision on every rank (the union is identical): exchange every range again with all N rows, here
+            for e in self._entries:
+                wire = _pack_rows(self._alias, None, e["c0"], e["c1"], e["wire"].dtype)
+                e.update(idx=None, local=wire.clone(), wire=wire)
+                reduce_feature_grad(wire, mode=self.mode, bucket_bytes=self.bucket_bytes)
         if used:
             # adopted: the parameter's gradient IS the tensor the hook saw (same storage, same shape) and no in-place op
             # touched it since (the alias shares its version counter) => it holds exactly this backward's local rows

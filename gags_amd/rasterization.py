@@ -256,7 +256,9 @@ def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height, conics=
         packed = torch.empty(max(n, 1), 8, dtype=torch.float32, device=dev)
         check(lib.gags_pack_isects(n, size, ptr(flat_s), ptr(means2d), ptr(conics), ptr(opacities), ptr(radii),
                                    ptr(packed), None, st), "gags_pack_isects")
-    return ids_s[:size], flat_s[:size], offsets[:n_tiles].view(tile_h, tile_w), count, packed
+    off_view = offsets[:n_tiles].view(tile_h, tile_w)
+    off_view._gags_count_attached = True  # (entry n_tiles, written by gags_tile_offsets, sits behind the view: see _offsets_with_count)
+    return ids_s[:size], flat_s[:size], off_view, count, packed
 
 
 def _check_isects(n_isects):
@@ -292,6 +294,7 @@ class _Rasterize(torch.autograd.Function):
         n, d = colors.shape
         dev = colors.device
         n_isects = flatten_ids.shape[0]
+        offsets = _offsets_with_count(offsets, n_isects)
         out = torch.empty(height, width, d, device=dev)
         alphas = torch.empty(height, width, device=dev)
         last_ids = torch.empty(height, width, dtype=torch.int32, device=dev)
@@ -310,13 +313,25 @@ class _Rasterize(torch.autograd.Function):
                     half, colors = False, colors.float()
         if split:
             blk_rows = torch.empty(offsets.numel() * 4, dtype=torch.int32, device=dev)  # per 8x8 pixel block
-        with profiler.stage("raster_fwd"):
+        cflags = ((flags & 3) | _lib.GAGS_RECS_BY_GAUSSIAN | (_lib.GAGS_FEAT_F16 if half else 0)
+                  | (64 if (half and d >= 128 and (flags & _lib.GAGS_FWD_F16MFMA)) else 0))
+
+        def launch(extra=0):
             check(lib.gags_raster_fwd(d, n, width, height, ptr(means2d), ptr(conics), ptr(opacities), ptr(colors),
                                       ptr(backgrounds), ptr(offsets), ptr(flatten_ids), n_isects, ptr(packed),
                                       ptr(out), ptr(alphas), ptr(last_ids), ptr(scratch), nbytes, ptr(blk_rows),
-                                      (flags & 3) | _lib.GAGS_RECS_BY_GAUSSIAN | (_lib.GAGS_FEAT_F16 if half else 0)
-                                      | (64 if (half and d >= 128 and (flags & _lib.GAGS_FWD_F16MFMA)) else 0),
-                                      _stream()), "gags_raster_fwd")
+                                      cflags | extra, _stream()), "gags_raster_fwd")
+
+        with profiler.stage("raster_fwd"):
+            if profiler.ENABLED and split and n_isects > 0:  # one event pair per kernel, for bench.py's roofline line
+                with profiler.stage("raster_weights"):
+                    launch(_lib.GAGS_FWD_ONLY_WEIGHTS)
+                with profiler.stage("raster_fwd_feat"):
+                    launch(_lib.GAGS_FWD_ONLY_FEATURES)
+            else:
+                launch()
+        if split:
+            profiler.note("fwd_blk_rows", blk_rows)
         need_geom = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[3]
         # wide-D geometry gradients on the matrix cores (gags_raster_bwd_geom) also consume the forward's scratch
         geom_mfma = split and need_geom and _geom_mfma_width(d) and not (flags & _lib.GAGS_BWD_ATOMIC)
@@ -404,6 +419,24 @@ class _Rasterize(torch.autograd.Function):
         return v_m2d, v_con, v_colors, v_opac, v_bg, None, None, None, None, None, None, None
 
 
+def _offsets_with_count(offsets, n_isects):
+    """ABI v2: every raster kernel reads `isect_offsets[tile + 1]` as a tile's end, so the buffer must hold n_tiles + 1
+    entries, the last one = the intersection count (include/gags_raster.h).  tile_binning hands out a [tile_h, tile_w] view
+    of such a buffer; a tensor that was cloned, re-created in gsplat's [tile_h, tile_w] layout or sliced elsewhere has no
+    entry behind its last tile -- re-attach the count here instead of letting the kernels read out of bounds."""
+    n_tiles = offsets.numel()
+    if (offsets.is_contiguous() and offsets.dtype == torch.int32
+            and offsets.untyped_storage().nbytes() // 4 - offsets.storage_offset() >= n_tiles + 1
+            and getattr(offsets, "_gags_count_attached", False)):
+        return offsets
+    full = torch.empty(n_tiles + 1, dtype=torch.int32, device=offsets.device)
+    full[:n_tiles] = offsets.reshape(-1)
+    full[n_tiles] = n_isects
+    out = full[:n_tiles].view(offsets.shape)
+    out._gags_count_attached = True
+    return out
+
+
 def _geom_mfma_width(d):
     """Widths whose geometry gradients run through gags_raster_bwd_geom (below that the VALU kernel is faster)."""
     return d >= 16 and d % 8 == 0 and d <= 1024
@@ -487,7 +520,7 @@ def _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d,
             return _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height, xflag & ~128,
                                     flatten_ids, None, exact_rows=True)
         rows = true_rows
-    if hook is None:
+    if hook is None and CAPACITY_MODE:
         _CAP_ROWS[cap_key] = max(rows, int(0.97 * _CAP_ROWS.get(cap_key, 0)))
     profiler.note("bwd_rows", rows)
     return v_colors
@@ -585,7 +618,8 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
         else:
             n_isects = n_true
             isect_ids, flatten_ids = isect_ids[:n_true], flatten_ids[:n_true]
-    _CAP_ISECTS[cap_key] = max(n_isects, int(0.97 * _CAP_ISECTS.get(cap_key, 0)))
+    if CAPACITY_MODE:
+        _CAP_ISECTS[cap_key] = max(n_isects, int(0.97 * _CAP_ISECTS.get(cap_key, 0)))
     if render_mode in ("ED", "RGB+ED"):
         if out.requires_grad:
             out = torch.cat([out[..., :-1], out[..., -1:] / alphas[..., None].clamp(min=1e-10)], dim=-1)

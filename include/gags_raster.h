@@ -49,6 +49,10 @@ extern "C" {
 #define GAGS_FWD_F16MFMA 64    /* with GAGS_FEAT_F16 and D % 128 == 0, opt-in: the feature pass contracts on the 16-bit matrix
                                   cores (features exact, weights as fp16 head + tail: ~2^-22 per term, not bit-identical) */
 
+#define GAGS_FWD_ONLY_WEIGHTS 512   /* split forward: launch the weights pass only (alphas, last_ids, scratch) ... */
+#define GAGS_FWD_ONLY_FEATURES 1024 /* ... or the feature pass only, on the scratch a GAGS_FWD_ONLY_WEIGHTS call left: lets a
+                                  caller bracket the two kernels with its own events (bench.py's per-kernel roofline) */
+
 #define GAGS_RECS_BY_GAUSSIAN 256 /* `packed` holds one record per GAUSSIAN (gags_pack_isects with packed = NULL) and the raster
                                   kernels gather it through flatten_ids themselves: no per-intersection copy (32 B x n_isects
                                   written and read back) and no gather kernel */
@@ -297,9 +301,16 @@ int gags_adam_step(int64_t numel, float *param, const float *grad, float *exp_av
  * torch.distributed over RCCL; these two kernels move the rows that can be non-zero between the gradient [N, d] and
  * the dense wire block [n_rows, cw] of one channel range [c0, c0 + cw).  idx: int64 row numbers (device; NULL = all rows,
  * n_rows = N).  Element types: 0 fp32, 1 fp16, 2 bf16 (wire only).
- *   gags_pack_rows  : wire[r, :] = grad[idx[r], c0 : c0 + cw]
+ *   gags_pack_rows  : wire[r, :] = grad[idx[r], c0 : c0 + cw]                     (idx[r] < 0: a padding row, zeros)
  *   gags_unpack_rows: local == NULL: grad[idx[r], c0 : c0 + cw]  = wire[r, :]
- *                     local != NULL: grad[idx[r], c0 : c0 + cw] += wire[r, :] - local[r, :]   (local: same type as wire) */
+ *                     local != NULL: grad[idx[r], c0 : c0 + cw] += wire[r, :] - local[r, :]   (local: same type as wire)
+ *                     (idx[r] < 0: skipped)
+ *   gags_compact_mask: the row list itself, on the device: idx[0 .. count) = ascending r with mask[r] != 0 (the union of
+ *                     the ranks' blended-Gaussian masks, gags_blended_mask), idx[count .. cap) = -1, count[0] = number of
+ *                     set rows (may exceed cap: the surplus is not stored).  Replaces a host-synchronising torch.nonzero. */
+int64_t gags_compact_mask_scratch_bytes(int n);
+int gags_compact_mask(int n, const uint8_t *mask, int64_t cap, int64_t *idx, int32_t *count, void *scratch,
+                      int64_t scratch_bytes, void *stream);
 int gags_pack_rows(int64_t n_rows, const int64_t *idx, const void *grad, int grad_type, int d, int c0, int cw,
                    void *wire, int wire_type, void *stream);
 int gags_unpack_rows(int64_t n_rows, const int64_t *idx, const void *wire, int wire_type, const void *local,

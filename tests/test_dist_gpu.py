@@ -108,14 +108,28 @@ def _overlap_step_worker(rank, world, port, out_dir):
     cam = syn.make_camera(W, H, view=rank + 2, device=dev)
     G = syn.make_cotangent(d, H, W, seed=10 + rank, device=dev)
     bg = torch.zeros(3, device=dev)
-    red = OverlappedGradReducer(mode="allreduce", rows="union")
-    loss = (render(cam, pc, None, bg, feature_mode=True)["render"] * G).sum()
-    with red:
-        loss.backward()
-    used = red.finish(pc._semantic_feature.grad)
-    torch.cuda.synchronize()
-    np.save(os.path.join(out_dir, f"ogr_{rank}.npy"), pc._semantic_feature.grad.detach().cpu().numpy())
-    np.save(os.path.join(out_dir, f"ogr_meta_{rank}.npy"), np.array([int(used), red.rows_exchanged or -1]))
+    red = OverlappedGradReducer(mode="allreduce", rows="union", sync_free=True)
+
+    def one_step():
+        pc._semantic_feature.grad = None
+        loss = (render(cam, pc, None, bg, feature_mode=True)["render"] * G).sum()
+        with red:
+            loss.backward()
+        used = red.finish(pc._semantic_feature.grad)
+        torch.cuda.synchronize()
+        return used, pc._semantic_feature.grad.detach().cpu().numpy()
+
+    used, g_first = one_step()          # first step of a shape: the exact count is waited for (no capacity yet)
+    rows_first = red.rows_exchanged
+    used2, g_cap = one_step()           # second step: capacity-sized block, padding rows, count read in finish()
+    padded = red._padded
+    red._cap_hint = {k: 8 for k in red._cap_hint}   # a union far above the remembered capacity: all-rows fallback
+    used3, g_over = one_step()
+    np.save(os.path.join(out_dir, f"ogr_{rank}.npy"), g_first)
+    np.save(os.path.join(out_dir, f"ogr_cap_{rank}.npy"), g_cap)
+    np.save(os.path.join(out_dir, f"ogr_over_{rank}.npy"), g_over)
+    np.save(os.path.join(out_dir, f"ogr_meta_{rank}.npy"),
+            np.array([int(used and used2 and used3), rows_first or -1, padded or -1, red.rows_exchanged or -1]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -146,10 +160,36 @@ def test_overlapped_union_row_exchange_with_the_real_backward(tmp_path):
         p.join(timeout=300)
         assert p.exitcode == 0
     for r in range(world):
-        g = np.load(tmp_path / f"ogr_{r}.npy")
-        used, rows = np.load(tmp_path / f"ogr_meta_{r}.npy")
-        np.testing.assert_array_equal(g, ref)   # two addends per element: exact
+        used, rows, padded, rows_last = np.load(tmp_path / f"ogr_meta_{r}.npy")
+        for tag in ("ogr", "ogr_cap", "ogr_over"):   # exact count / capacity-sized padded block / over-capacity fallback
+            np.testing.assert_array_equal(np.load(tmp_path / f"{tag}_{r}.npy"), ref)   # two addends per element: exact
         assert used == 1 and rows == union and 0 < union < N
+        assert union <= padded <= N and rows_last == union
+
+
+@pytest.mark.parametrize("n,p", [(1, 1.0), (7, 0.5), (2048, 0.3), (2049, 0.01), (100_003, 0.27), (1_500_000, 0.3), (5000, 0.0)])
+def test_compact_mask_is_the_ascending_nonzero_list(n, p):
+    """gags_compact_mask against torch.nonzero: ascending row numbers, -1 padding behind the count, a capacity below the
+    count drops the surplus without writing out of bounds."""
+    from gags_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(n)
+    mask = (torch.rand(n, generator=g) < p).to(torch.uint8).to(dev) * 3   # any non-zero byte counts
+    want = torch.nonzero(mask).squeeze(1)
+    sb = lib.gags_compact_mask_scratch_bytes(n)
+    scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
+    for cap in (n, max(int(want.numel()) // 2, 0), int(want.numel()) + 5):
+        idx = torch.full((cap + 4,), 12345, dtype=torch.int64, device=dev)
+        count = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(lib.gags_compact_mask(n, _lib.ptr(mask), cap, _lib.ptr(idx), _lib.ptr(count), _lib.ptr(scratch), sb, None),
+                   "gags_compact_mask")
+        torch.cuda.synchronize()
+        c = int(count.item())
+        assert c == want.numel()
+        k = min(c, cap)
+        assert torch.equal(idx[:k], want[:k])
+        assert bool((idx[k:cap] == -1).all()) and bool((idx[cap:] == 12345).all())
 
 
 def _nccl_worker(rank, world, port, q):
@@ -229,6 +269,7 @@ def test_bench_two_ranks_under_torch_distributed_run():
     assert 0 < ge["rows_exchanged_last_step"] <= 20000
     assert len(ge["range_exchange_ms_last_step"]) == 2  # two 128-channel ranges at D = 256
     assert "view-dp2" in line["config"]["parallelism"]
+    assert ge["collective_ms_per_step"]["allreduce"] > 0 and "version" in ge["rccl"]
 
 
 @pytest.mark.parametrize("d,c0,c1", [(256, 128, 256), (37, 5, 30), (130, 2, 130), (64, 0, 64)])
@@ -243,6 +284,15 @@ def test_pack_and_unpack_rows_against_torch_indexing(d, c0, c1, gdt, wdt):
     n = 1000
     grad = torch.randn(n, d, generator=g).to(gdt).to(dev)
     idx = torch.randperm(n, generator=g)[:317].sort().values.to(dev)
+    # padding rows (idx = -1, gags_compact_mask's capacity-sized lists): zeros on the wire, skipped on the way back
+    padded = torch.cat([idx, torch.full((9,), -1, dtype=idx.dtype, device=dev)])
+    wire_p = _pack_rows(grad, padded, c0, c1, wdt)
+    assert torch.equal(wire_p[:317], grad[idx, c0:c1].to(wdt)) and bool((wire_p[317:] == 0).all())
+    before = grad.clone()
+    _unpack_rows(grad, padded, c0, c1, wire_p)
+    assert torch.equal(grad[:, c0:c1].float(), before[:, c0:c1].to(wdt).to(gdt).float().where(
+        torch.zeros(n, 1, dtype=torch.bool, device=dev).index_fill_(0, idx, True), before[:, c0:c1].float()))
+    grad.copy_(before)
     for ix in (idx, None):
         wire = _pack_rows(grad, ix, c0, c1, wdt)
         want = (grad[:, c0:c1] if ix is None else grad[ix, c0:c1]).to(wdt)

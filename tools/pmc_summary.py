@@ -43,6 +43,12 @@ def main():
                 f = sum(acc[k]["FETCH_SIZE"]) / len(acc[k]["FETCH_SIZE"]) * 1024.0 * 2.0
                 w = sum(acc[k]["WRITE_SIZE"]) / len(acc[k]["WRITE_SIZE"]) * 1024.0
                 traffic[k] = {"fetch_bytes": f, "write_bytes": w, "hbm_bytes": f + w}
+                for key, ctr in (("mfma_insts", "SQ_INSTS_MFMA"), ("mfma_busy_cycles", "SQ_VALU_MFMA_BUSY_CYCLES"),
+                                 ("busy_cu_cycles", "SQ_BUSY_CU_CYCLES"), ("valu_insts", "SQ_INSTS_VALU"),
+                                 ("lds_bank_conflict", "SQ_LDS_BANK_CONFLICT"), ("wave_cycles", "SQ_WAVE_CYCLES"),
+                                 ("wait_inst_any", "SQ_WAIT_INST_ANY")):
+                    if ctr in acc[k]:
+                        traffic[k][key] = sum(acc[k][ctr]) / len(acc[k][ctr])
         json.dump(traffic, open(sys.argv[3], "w"), indent=1, sort_keys=True)
     for k in sorted(acc):
         print(k)
