@@ -207,13 +207,13 @@ class OverlappedGradReducer:
     untouched gradient.  `exposed_ms()` = time the compute stream spent on the exchange after the backward had finished."""
 
     def __init__(self, mode="rs_ag", wire=None, bucket_bytes=BUCKET_BYTES, rows="union", param=None, sync_free=False,
-                 cap_margin=1.1):
+                 cap_margin=1.1, cap_slack=1024):
         if rows not in ("union", "all"):
             raise ValueError(rows)
         if wire not in (None, "fp32", "bf16"):
             raise ValueError(wire)
         self.mode, self.wire, self.bucket_bytes, self.rows, self.param = mode, wire, bucket_bytes, rows, param
-        self.sync_free, self.cap_margin = bool(sync_free), float(cap_margin)
+        self.sync_free, self.cap_margin, self.cap_slack = bool(sync_free), float(cap_margin), int(cap_slack)
         self._cap_hint, self._pinned = {}, {}
         self.comm = torch.cuda.Stream() if torch.cuda.is_available() else None
         self.rows_exchanged = None  # |union| of the last step (None: all rows)
@@ -277,7 +277,7 @@ class OverlappedGradReducer:
         dev = mask.device
         cap = n
         if self.sync_free and self._cap_hint.get(n):
-            cap = min(n, int(self._cap_hint[n] * self.cap_margin) + 1024)
+            cap = min(n, int(self._cap_hint[n] * self.cap_margin) + self.cap_slack)
         idx = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
         count = torch.empty(1, dtype=torch.int32, device=dev)
         sb = lib.gags_compact_mask_scratch_bytes(n)

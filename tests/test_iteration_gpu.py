@@ -1,0 +1,100 @@
+"""The COMPOSED distillation iteration (train.py:149-172) against the reference's own functions chained on one input
+(tests/golden/make_golden_iteration.py imports models/networks.py, utils/loss_utils.py and scene/dataset_readers.py in
+the build container): gags_amd.distill.distillation_loss -- the composition tools/decoder_bench.py times -- must give the
+same loss, the same d loss / d feature_map and the same gradient for every parameter of both decoders, before and after
+iteration 15001 (the loss weights change there, and the region-variance term starts to send gradient into the map)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+Z = np.load(os.path.join(HERE, "golden", "iteration_vectors.npz"))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+
+def _models(precision):
+    from gags_amd.decoders import CNN_decoder, CNN_scale_decoder
+    from make_golden_next import decoder_weights
+    wd, ws = decoder_weights(0)
+    dec, sdec = CNN_decoder(16, 512, precision), CNN_scale_decoder(16, 3, precision)
+    with torch.no_grad():
+        for model, weights in ((dec, wd), (sdec, ws)):
+            for m, (W, b) in zip(model.convs(), weights):
+                m.weight.copy_(W[:, :, None, None])
+                m.bias.copy_(b)
+    return dec.cuda(), sdec.cuda()
+
+
+def _run(precision, iteration, fused_head=None, layout="pixel_major"):
+    from gags_amd.distill import distillation_loss
+    dec, sdec = _models(precision)
+    fmap = torch.from_numpy(Z["fmap"]).cuda()
+    if layout == "pixel_major":  # what render() hands over: [H,W,C] memory behind a [C,H,W] view
+        fmap = fmap.permute(1, 2, 0).contiguous().permute(2, 0, 1)
+    fmap.requires_grad_(True)
+    seg, emb = torch.from_numpy(Z["seg_map"]).cuda(), torch.from_numpy(Z["img_embed"]).cuda()
+    loss, terms = distillation_loss(fmap, seg, emb, dec, sdec, iteration, fused_head=fused_head)
+    loss.backward()
+    return loss, terms, fmap.grad, dec, sdec
+
+
+@pytest.mark.parametrize("layout", ["pixel_major", "channel_major"])
+@pytest.mark.parametrize("tag,iteration", [("early", 7000), ("late", 20000)])
+def test_composed_iteration_matches_the_reference_chain(tag, iteration, layout):
+    """Default precision (fp32-equivalent): loss 1e-5, d loss / d feature_map and every decoder gradient 1e-3 rel-L2 of the
+    reference's fp32 autograd (the bound of test_decoders_gpu.py's per-module test; measured ~1e-6)."""
+    loss, terms, vf, dec, sdec = _run("exact", iteration, layout=layout)
+    assert abs(loss.item() - float(Z[f"{tag}_loss"])) <= 1e-5 * abs(float(Z[f"{tag}_loss"]))
+    l1, ce, rv = (float(v) for v in Z[f"{tag}_terms"])
+    assert abs(terms["l1"].item() - l1) <= 1e-5 * l1 and abs(terms["ce"].item() - ce) <= 1e-5 * ce
+    if tag == "late":
+        assert abs(terms["regionvar"].item() - rv) <= 1e-5 * rv
+    else:
+        assert terms["regionvar"] is None  # computed by the reference, dropped from its loss before 15001
+    assert rel_l2(terms["scale_map"].detach().cpu().numpy(), Z["scale_map"]) <= 1e-5
+    np.testing.assert_array_equal(terms["seg_map_trained"].cpu().numpy(), Z["seg_map_trained"])
+    assert vf.shape == Z[f"{tag}_vfmap"].shape
+    assert rel_l2(vf.cpu().numpy(), Z[f"{tag}_vfmap"]) <= 1e-3
+    for i, m in enumerate(dec.convs()):
+        gw = m.weight.grad[:, :, 0, 0]
+        want = Z[f"{tag}_dec_vw{i}"]
+        assert rel_l2(gw[:want.shape[0]].cpu().numpy(), want) <= 1e-3, i
+        assert abs(gw.double().norm().item() - float(Z[f"{tag}_dec_vw{i}_norm"])) <= 1e-3 * float(Z[f"{tag}_dec_vw{i}_norm"])
+        assert rel_l2(m.bias.grad.cpu().numpy(), Z[f"{tag}_dec_vb{i}"]) <= 1e-3, i
+    for i, m in enumerate(sdec.convs()):  # the scale decoder learns from CE and through the ground-truth blend only
+        assert rel_l2(m.weight.grad[:, :, 0, 0].cpu().numpy(), Z[f"{tag}_sdec_vw{i}"]) <= 1e-3, i
+        assert rel_l2(m.bias.grad.cpu().numpy(), Z[f"{tag}_sdec_vb{i}"]) <= 1e-3, i
+
+
+def test_the_scale_decoder_does_not_backpropagate_into_the_feature_map():
+    """train.py:149's .detach(): before iteration 15001 the map's gradient comes through cnn_decoder alone -- it must equal
+    the gradient of the L1 term by itself (the CE term reaches only the scale decoder)."""
+    from gags_amd import losses as L
+    _, _, vf, _, _ = _run("exact", 7000)
+    dec, sdec = _models("exact")
+    fmap = torch.from_numpy(Z["fmap"]).cuda().permute(1, 2, 0).contiguous().permute(2, 0, 1).requires_grad_(True)
+    seg, emb = torch.from_numpy(Z["seg_map"]).cuda(), torch.from_numpy(Z["img_embed"]).cuda()
+    with torch.no_grad():
+        scale_map = sdec(fmap.detach())
+    l1m, mask = L.distill_l1_map(dec(fmap), emb, seg, scale_map)
+    L.Scale_balance_loss(l1m, L.get_trained_seg(seg, scale_map), mask.squeeze(0), mix_seg=True).backward()
+    assert torch.equal(vf, fmap.grad)
+
+
+@pytest.mark.parametrize("tag,iteration", [("early", 7000), ("late", 20000)])
+@pytest.mark.parametrize("fused_head", [True, False])
+def test_composed_iteration_in_the_bf16_mode_stays_within_its_stated_bound(tag, iteration, fused_head):
+    """precision="bf16" (fast opt-in; fused head + loss or the two-step route): loss within 2e-3, gradient direction of
+    the feature map >= 0.98 cosine of the reference's (a low-precision forward flips the ReLUs of units within rounding of
+    zero: DESIGN.md section 7)."""
+    loss, _, vf, _, _ = _run("bf16", iteration, fused_head=fused_head)
+    want = float(Z[f"{tag}_loss"])
+    assert abs(loss.item() - want) <= 2e-3 * abs(want)
+    a, b = vf.double().flatten().cpu(), torch.from_numpy(Z[f"{tag}_vfmap"]).double().flatten()
+    assert float((a @ b) / (a.norm() * b.norm())) >= 0.98

@@ -12,6 +12,7 @@ sys.path.insert(0, ROOT)
 import torch
 from gags_amd import losses as L, synthetic as syn
 from gags_amd.decoders import CNN_decoder, CNN_scale_decoder
+from gags_amd.distill import distillation_loss
 from gags_amd.gaussian_renderer import render
 
 dev = torch.device("cuda", 0)
@@ -19,7 +20,7 @@ cfg = syn.CONFIGS["C3"]
 n, w, h, d = cfg["n"], cfg["width"], cfg["height"], 16
 pc = syn.make_model(n, d, w, h, seed=0, device=dev, gen_device=dev)
 pc.training_setup()
-pc.cache_activations(True)  # geometry frozen for the whole run (GAD stage, train.py:62-75): getters evaluated once
+pc.cache_activations("--cache-activations" in sys.argv)  # default: getters evaluated on every render, as the reference does
 cam = syn.make_camera(w, h, device=dev)
 bg = torch.zeros(3, device=dev)
 PRECISION = "bf16" if "--bf16" in sys.argv else "exact"   # default: the reference's precision; --bf16: the fast opt-in mode
@@ -44,24 +45,16 @@ def iteration(times=None):
     marks = [ev()]
     pkg = render(cam, pc, None, bg, feature_mode=True)
     fmap = pkg["render"]; marks.append(ev())
-    scale_map = sdec(fmap.detach()); marks.append(ev())
-    seg_tr = L.get_trained_seg(seg, scale_map)
-    reg = L.scale_region_regulation_loss(fmap, seg_tr, mix_seg=True)
-    ce = L.scale_regulation_loss(scale_map); marks.append(ev())
-    if FUSED:  # the decoder's head fused into the distillation L1 (CNN_decoder.distill_l1): one call for train.py:159-166
-        l1m, mask = dec.distill_l1(fmap, img_embed, seg, scale_map); marks.append(ev())
-    else:
-        f512 = dec(fmap); marks.append(ev())
-        l1m, mask = L.distill_l1_map(f512, img_embed, seg, scale_map)
-    l1 = L.Scale_balance_loss(l1m, seg_tr, mask.squeeze(0), mix_seg=True)
-    loss = 1.0 * l1 + 0.002 * ce + 0.1 * reg; marks.append(ev())
+    # train.py:149-172 after iteration 15001 (all three loss terms): gags_amd/distill.py, the composition that
+    # tests/test_iteration_gpu.py checks against the reference's own functions chained on one input
+    loss, _ = distillation_loss(fmap, seg, img_embed, dec, sdec, iteration=20000, fused_head=FUSED); marks.append(ev())
     for m in (dec, sdec):
         m.zero_grad(set_to_none=True)
     pc._semantic_feature.grad = None
     loss.backward(); marks.append(ev())
     if times is not None:
         torch.cuda.synchronize()
-        for k, (a, b) in zip(("render16", "scale_decoder", "seg_losses", "decoder_fwd", "distill_loss", "backward"), zip(marks, marks[1:])):
+        for k, (a, b) in zip(("render16", "decoders_and_losses_fwd", "backward"), zip(marks, marks[1:])):
             times.setdefault(k, []).append(a.elapsed_time(b))
     return loss
 
