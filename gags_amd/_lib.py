@@ -27,6 +27,10 @@ SIGNATURES = {
     "gags_device_count": (_i32, []),
     "gags_project_fwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _f32,
                                 _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gags_project_fwd_raw": (_i32, [_i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _f32,
+                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gags_project_bwd_raw": (_i32, [_i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp,
+                                    _vp, _vp, _vp, _vp, _vp]),
     "gags_scan_scratch_bytes": (_i64, [_i32]),
     "gags_cumsum_i32": (_i32, [_i32, _vp, _vp, _vp, _vp, _i64, _vp]),
     "gags_read_i32": (_i32, [_vp, _vp, _vp]),

@@ -22,16 +22,42 @@ __device__ __forceinline__ Cam load_cam(const float *__restrict__ vm, const floa
     return c;
 }
 
+// The activations of scene/gaussian_model.py:116-139 as torch evaluates them on this stack, bit for bit
+// (tools/micro/actprobe.py: 0 of 4 M values differ): get_scaling = exp(_scaling) (* scaling_modifier in render()),
+// get_rotation = F.normalize(_rotation) = q / max(|q|, 1e-12) with |q|^2 summed pairwise, get_opacity = sigmoid(_opacity).
+__device__ __forceinline__ float4 gags_act_rotation(float4 q)
+{
+    const float nrm = fmaxf(sqrtf((q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w)), 1e-12f);
+    return make_float4(q.x / nrm, q.y / nrm, q.z / nrm, q.w / nrm);
+}
+__device__ __forceinline__ float gags_act_scaling(float s, float modifier) { return expf(s) * modifier; }
+__device__ __forceinline__ float gags_act_opacity(float o) { return 1.0f / (1.0f + expf(-o)); }
+
+// RAW: quats / scales are the stored parameters (_rotation un-normalised, _scaling in log space) and the kernel applies
+// the getters itself (gags_project_fwd_raw); the activated opacity -- and, for a later backward, the activated quats and
+// scales when asked for -- are written on the way.
+template <bool RAW>
 __global__ __launch_bounds__(256) void project_fwd_kernel(
     int n, const float *__restrict__ means, const float *__restrict__ quats,
     const float *__restrict__ scales, const float *__restrict__ viewmat, const float *__restrict__ Kmat,
     int width, int height, float eps2d, float near_plane, float far_plane, float radius_clip,
     int tile_w, int tile_h,
     int32_t *__restrict__ radii, float *__restrict__ means2d, float *__restrict__ depths,
-    float *__restrict__ conics, int32_t *__restrict__ tiles_per_gauss)
+    float *__restrict__ conics, int32_t *__restrict__ tiles_per_gauss,
+    const float *__restrict__ opacity_logits, float scaling_modifier, float *__restrict__ opacities_out,
+    float *__restrict__ quats_out, float *__restrict__ scales_out)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    float4 q = reinterpret_cast<const float4 *>(quats)[i];
+    float s0 = scales[3 * i], s1 = scales[3 * i + 1], s2 = scales[3 * i + 2];
+    if constexpr (RAW) {
+        q = gags_act_rotation(q);
+        s0 = gags_act_scaling(s0, scaling_modifier); s1 = gags_act_scaling(s1, scaling_modifier); s2 = gags_act_scaling(s2, scaling_modifier);
+        opacities_out[i] = gags_act_opacity(opacity_logits[i]);
+        if (quats_out) reinterpret_cast<float4 *>(quats_out)[i] = q;
+        if (scales_out) { scales_out[3 * i] = s0; scales_out[3 * i + 1] = s1; scales_out[3 * i + 2] = s2; }
+    }
     const Cam c = load_cam(viewmat, Kmat);
     const float fw = (float)width, fh = (float)height;
     const float tan_fovx = 0.5f * fw / c.fx;
@@ -49,7 +75,6 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     const float y = ((c.R10 * px + c.R11 * py) + c.R12 * pz) + c.t1;
     const float z = ((c.R20 * px + c.R21 * py) + c.R22 * pz) + c.t2;
     if (!(z < near_plane || z > far_plane)) {
-        const float4 q = reinterpret_cast<const float4 *>(quats)[i];
         float qw = q.x, qx = q.y, qy = q.z, qz = q.w;
         const float inv_norm = 1.0f / sqrtf(((qx * qx + qy * qy) + qz * qz) + qw * qw);
         qw *= inv_norm; qx *= inv_norm; qy *= inv_norm; qz *= inv_norm;
@@ -59,7 +84,6 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
         const float r00 = 1.f - 2.f * (y2 + z2), r01 = 2.f * (xy - wz), r02 = 2.f * (xz + wy);
         const float r10 = 2.f * (xy + wz), r11 = 1.f - 2.f * (x2 + z2), r12 = 2.f * (yz - wx);
         const float r20 = 2.f * (xz - wy), r21 = 2.f * (yz + wx), r22 = 1.f - 2.f * (x2 + y2);
-        const float s0 = scales[3 * i], s1 = scales[3 * i + 1], s2 = scales[3 * i + 2];
         const float m00 = r00 * s0, m01 = r01 * s1, m02 = r02 * s2;
         const float m10 = r10 * s0, m11 = r11 * s1, m12 = r12 * s2;
         const float m20 = r20 * s0, m21 = r21 * s1, m22 = r22 * s2;
@@ -143,9 +167,31 @@ extern "C" int gags_project_fwd(int n, const float *means, const float *quats, c
         !tiles_per_gauss)
         return GAGS_EINVAL;
     const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
-    hipLaunchKernelGGL(project_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, means,
+    hipLaunchKernelGGL(project_fwd_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, means,
                        quats, scales, viewmat, K, width, height, eps2d, near_plane, far_plane, radius_clip,
-                       tile_w, tile_h, radii, means2d, depths, conics, tiles_per_gauss);
+                       tile_w, tile_h, radii, means2d, depths, conics, tiles_per_gauss, nullptr, 1.0f, nullptr, nullptr, nullptr);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+extern "C" int gags_project_fwd_raw(int n, const float *means, const float *rotation, const float *scaling_log,
+                                    const float *opacity_logit, float scaling_modifier, const float *viewmat, const float *K,
+                                    int width, int height, float eps2d, float near_plane, float far_plane,
+                                    float radius_clip, int32_t *radii, float *means2d, float *depths, float *conics,
+                                    int32_t *tiles_per_gauss, float *opacities, float *quats_act, float *scales_act,
+                                    void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (n < 0 || width <= 0 || height <= 0) return GAGS_EINVAL;
+    if (n == 0) return GAGS_OK;
+    if (!means || !rotation || !scaling_log || !opacity_logit || !viewmat || !K || !radii || !means2d || !depths ||
+        !conics || !tiles_per_gauss || !opacities)
+        return GAGS_EINVAL;
+    const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
+    hipLaunchKernelGGL(project_fwd_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, means,
+                       rotation, scaling_log, viewmat, K, width, height, eps2d, near_plane, far_plane, radius_clip,
+                       tile_w, tile_h, radii, means2d, depths, conics, tiles_per_gauss, opacity_logit, scaling_modifier,
+                       opacities, quats_act, scales_act);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }
@@ -153,15 +199,27 @@ extern "C" int gags_project_fwd(int n, const float *means, const float *quats, c
 namespace {
 
 // K2: projection backward, one lane per Gaussian (same operation order as the forward).
+// RAW (gags_project_bwd_raw): quats / scales are the stored parameters; the getters are re-applied (bit for bit the
+// forward's), and the gradients are taken one step further, to the stored parameters: d/d _scaling = v_s * exp(_scaling) *
+// modifier, d/d _rotation through q / max(|q|, 1e-12), d/d _opacity = v_o * o (1 - o) for EVERY Gaussian (the opacity's
+// gradient comes from the rasterizer, not from the projection, so it is not gated by radii).
+template <bool RAW>
 __global__ __launch_bounds__(256) void project_bwd_kernel(
     int N, const float *__restrict__ means, const float *__restrict__ quats, const float *__restrict__ scales,
     const float *__restrict__ viewmat, const float *__restrict__ Kmat, int width, int height, float eps2d,
     const int32_t *__restrict__ radii, const float *__restrict__ v_means2d, const float *__restrict__ v_depths,
     const float *__restrict__ v_conics, float *__restrict__ v_means, float *__restrict__ v_quats,
-    float *__restrict__ v_scales)
+    float *__restrict__ v_scales, const float *__restrict__ opacity_logits, float scaling_modifier,
+    const float *__restrict__ v_opacities, float *__restrict__ v_opacity_logits)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
+    if constexpr (RAW) {
+        if (v_opacity_logits) {
+            const float o = gags_act_opacity(opacity_logits[i]);
+            v_opacity_logits[i] = v_opacities ? (v_opacities[i] * (1.0f - o)) * o : 0.f;  // (torch: grad * (1 - y) * y)
+        }
+    }
     _Pragma("unroll") for (int k = 0; k < 3; ++k) { v_means[3 * i + k] = 0.f; v_scales[3 * i + k] = 0.f; }
     _Pragma("unroll") for (int k = 0; k < 4; ++k) v_quats[4 * i + k] = 0.f;
     if (radii[i] <= 0) return;
@@ -179,14 +237,21 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
         float p[3];
         _Pragma("unroll") for (int r = 0; r < 3; ++r) p[r] = ((Rc[r][0] * mu[0] + Rc[r][1] * mu[1]) + Rc[r][2] * mu[2]) + tc[r];
         const float x = p[0], y = p[1], z = p[2];
-        const float q0 = quats[4 * i], q1 = quats[4 * i + 1], q2 = quats[4 * i + 2], q3 = quats[4 * i + 3];
+        float q0 = quats[4 * i], q1 = quats[4 * i + 1], q2 = quats[4 * i + 2], q3 = quats[4 * i + 3];
+        float raw_nrm = 1.f;
+        if constexpr (RAW) {
+            raw_nrm = fmaxf(sqrtf((q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3)), 1e-12f);
+            const float4 qa = gags_act_rotation(make_float4(q0, q1, q2, q3));
+            q0 = qa.x; q1 = qa.y; q2 = qa.z; q3 = qa.w;
+        }
         const float inv_norm = 1.0f / sqrtf(((q1 * q1 + q2 * q2) + q3 * q3) + q0 * q0);
         const float qw = q0 * inv_norm, qx = q1 * inv_norm, qy = q2 * inv_norm, qz = q3 * inv_norm;
         float R[3][3];
         R[0][0] = 1.f - 2.f * (qy * qy + qz * qz); R[0][1] = 2.f * (qx * qy - qw * qz); R[0][2] = 2.f * (qx * qz + qw * qy);
         R[1][0] = 2.f * (qx * qy + qw * qz); R[1][1] = 1.f - 2.f * (qx * qx + qz * qz); R[1][2] = 2.f * (qy * qz - qw * qx);
         R[2][0] = 2.f * (qx * qz - qw * qy); R[2][1] = 2.f * (qy * qz + qw * qx); R[2][2] = 1.f - 2.f * (qx * qx + qy * qy);
-        const float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+        float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+        if constexpr (RAW) { _Pragma("unroll") for (int k = 0; k < 3; ++k) s[k] = gags_act_scaling(s[k], scaling_modifier); }
         float M[3][3], S3[3][3], A[3][3], Sc[3][3];
         _Pragma("unroll") for (int r = 0; r < 3; ++r) _Pragma("unroll") for (int c = 0; c < 3; ++c) M[r][c] = R[r][c] * s[c];
         _Pragma("unroll") for (int r = 0; r < 3; ++r) _Pragma("unroll") for (int c = 0; c < 3; ++c)
@@ -254,7 +319,8 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
         /* ---- 6. M = R diag(s) ---- */
         float GR[3][3];
         _Pragma("unroll") for (int c = 0; c < 3; ++c) {
-            v_scales[3 * i + c] = (R[0][c] * GM[0][c] + R[1][c] * GM[1][c]) + R[2][c] * GM[2][c];
+            const float vs = (R[0][c] * GM[0][c] + R[1][c] * GM[1][c]) + R[2][c] * GM[2][c];
+            v_scales[3 * i + c] = RAW ? vs * s[c] : vs;  // RAW: d/d log-scale (torch: grad * modifier, then * exp(_scaling))
             _Pragma("unroll") for (int r = 0; r < 3; ++r) GR[r][c] = GM[r][c] * s[c];
         }
         /* ---- 7. R(q^) -> q^ ---- */
@@ -267,10 +333,15 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
                                  qy * GR[1][2] + qx * GR[2][0] + qy * GR[2][1]);
         /* ---- 8. normalisation q^ = q/|q| ---- */
         const float dotp = ((qw * vqw + qx * vqx) + qy * vqy) + qz * vqz;
-        v_quats[4 * i] = (vqw - qw * dotp) * inv_norm;
-        v_quats[4 * i + 1] = (vqx - qx * dotp) * inv_norm;
-        v_quats[4 * i + 2] = (vqy - qy * dotp) * inv_norm;
-        v_quats[4 * i + 3] = (vqz - qz * dotp) * inv_norm;
+        float g0 = (vqw - qw * dotp) * inv_norm, g1 = (vqx - qx * dotp) * inv_norm;
+        float g2 = (vqy - qy * dotp) * inv_norm, g3 = (vqz - qz * dotp) * inv_norm;
+        if constexpr (RAW) {
+            // through the getter q_a = q / n, n = max(|q|, 1e-12):  v_q = (g - q_a <q_a, g>) / n  (q_a = (q0..q3) here)
+            const float d2 = ((q0 * g0 + q1 * g1) + q2 * g2) + q3 * g3;
+            g0 = (g0 - q0 * d2) / raw_nrm; g1 = (g1 - q1 * d2) / raw_nrm;
+            g2 = (g2 - q2 * d2) / raw_nrm; g3 = (g3 - q3 * d2) / raw_nrm;
+        }
+        v_quats[4 * i] = g0; v_quats[4 * i + 1] = g1; v_quats[4 * i + 2] = g2; v_quats[4 * i + 3] = g3;
 }
 
 }  // namespace
@@ -288,9 +359,28 @@ extern "C" int gags_project_bwd(int n, const float *means, const float *quats, c
     if (!means || !quats || !scales || !viewmat || !K || !radii || !v_means2d || !v_conics || !v_means ||
         !v_quats || !v_scales)
         return GAGS_EINVAL;
-    hipLaunchKernelGGL(project_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, means, quats,
+    hipLaunchKernelGGL(project_bwd_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, means, quats,
                        scales, viewmat, K, width, height, eps2d, radii, v_means2d, v_depths, v_conics, v_means,
-                       v_quats, v_scales);
+                       v_quats, v_scales, nullptr, 1.0f, nullptr, nullptr);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+extern "C" int gags_project_bwd_raw(int n, const float *means, const float *rotation, const float *scaling_log,
+                                    const float *opacity_logit, float scaling_modifier, const float *viewmat, const float *K,
+                                    int width, int height, float eps2d, const int32_t *radii, const float *v_means2d,
+                                    const float *v_depths, const float *v_conics, const float *v_opacities, float *v_means,
+                                    float *v_rotation, float *v_scaling_log, float *v_opacity_logit, void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (n < 0 || width <= 0 || height <= 0) return GAGS_EINVAL;
+    if (n == 0) return GAGS_OK;
+    if (!means || !rotation || !scaling_log || !viewmat || !K || !radii || !v_means2d || !v_conics || !v_means ||
+        !v_rotation || !v_scaling_log || (v_opacity_logit && !opacity_logit))
+        return GAGS_EINVAL;
+    hipLaunchKernelGGL(project_bwd_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, means, rotation,
+                       scaling_log, viewmat, K, width, height, eps2d, radii, v_means2d, v_depths, v_conics, v_means,
+                       v_rotation, v_scaling_log, opacity_logit, scaling_modifier, v_opacities, v_opacity_logit);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }

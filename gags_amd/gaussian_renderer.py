@@ -39,14 +39,48 @@ def _intrinsics(viewpoint_camera, device):
     return K
 
 
+# R2 folded into R4 (the getters are "4 elementwise kernels/iter over N (fusable into projection)"): when `pc`
+# stores its parameters the way scene/gaussian_model.py:48-61 does and activates them the way :36-42 does (exp, sigmoid,
+# F.normalize), render() hands the STORED tensors to the projection kernel, which applies those getters itself -- bit for
+# bit what torch computes (tools/micro/actprobe.py; tests/test_parity_gpu.py::test_raw_parameter_projection_*).  Any other
+# `pc` goes through its getters, as in the reference.  False: always the getters.
+RAW_PARAMS = True
+
+
+def _stored_parameters(pc):
+    """(rotation, scaling_log, opacity_logit) when `pc` is a GaussianModel in the reference's layout with the reference's
+    activations, else None."""
+    if not RAW_PARAMS:
+        return None
+    try:
+        rot, scal, opac = pc._rotation, pc._scaling, pc._opacity
+    except AttributeError:
+        return None
+    F = torch.nn.functional
+    if (getattr(pc, "scaling_activation", torch.exp) is not torch.exp
+            or getattr(pc, "opacity_activation", torch.sigmoid) is not torch.sigmoid
+            or getattr(pc, "rotation_activation", F.normalize) is not F.normalize):
+        return None
+    n = pc.get_xyz.shape[0]
+    if not all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 for t in (rot, scal, opac)):
+        return None
+    if tuple(rot.shape) != (n, 4) or tuple(scal.shape) != (n, 3) or tuple(opac.shape) != (n, 1):
+        return None
+    return rot, scal, opac
+
+
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, feature_mode=True, scaling_modifier=1.0,
            override_color=None, render_mode="RGB", raster_flags=0):
     """Render the scene.  Background tensor (bg_color) must be on GPU!"""
     means3D = pc.get_xyz
     K = _intrinsics(viewpoint_camera, means3D.device)
-    opacity = pc.get_opacity
-    scales = pc.get_scaling * scaling_modifier
-    rotations = pc.get_rotation
+    stored = _stored_parameters(pc)
+    if stored is not None:
+        rotations, scales, opacity = stored
+    else:
+        opacity = pc.get_opacity
+        scales = pc.get_scaling * scaling_modifier
+        rotations = pc.get_rotation
     if feature_mode:
         colors = pc.get_semantic_feature  # [N, D]
         sh_degree = None
@@ -63,7 +97,8 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, feature_mode=True
         means=means3D, quats=rotations, scales=scales, opacities=opacity.squeeze(-1), colors=colors,
         viewmats=viewmat[None], Ks=K[None], backgrounds=bg_color[None],
         width=int(viewpoint_camera.image_width), height=int(viewpoint_camera.image_height),
-        packed=False, sh_degree=sh_degree, render_mode=render_mode, raster_flags=raster_flags)
+        packed=False, sh_degree=sh_degree, render_mode=render_mode, raster_flags=raster_flags,
+        raw_params=stored is not None, scaling_modifier=float(scaling_modifier))
 
     # squeeze (not [0]): its backward is a view, [0]'s is a zero-fill + copy of the whole map
     rendered_image = render_colors.squeeze(0).permute(2, 0, 1)  # [1,H,W,D'] -> [D',H,W]

@@ -166,6 +166,58 @@ class _Project(torch.autograd.Function):
         return v_means, v_quats, v_scales, None, None, None, None, None, None, None, None
 
 
+class _ProjectRaw(torch.autograd.Function):
+    """K1 + K4 on the STORED parameters (gags_project_fwd_raw / gags_project_bwd_raw): the getters of
+    scene/gaussian_model.py:116-139 -- exp, F.normalize, sigmoid -- and render()'s `* scaling_modifier` run inside the
+    projection kernel, bit for bit as torch evaluates them; the backward returns gradients of the stored parameters."""
+
+    @staticmethod
+    def forward(ctx, means, rotation, scaling_log, opacity_logit, viewmat, K, width, height, eps2d, near, far, radius_clip,
+                scaling_modifier):
+        lib = _lib.load()
+        means, rotation, scaling_log, viewmat, K = _c(means), _c(rotation), _c(scaling_log), _c(viewmat), _c(K)
+        logit = _c(opacity_logit.reshape(-1))
+        n = means.shape[0]
+        dev = means.device
+        radii = torch.empty(n, dtype=torch.int32, device=dev)
+        means2d = torch.empty(n, 2, dtype=torch.float32, device=dev)
+        depths = torch.empty(n, dtype=torch.float32, device=dev)
+        conics = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        tiles = torch.empty(n, dtype=torch.int32, device=dev)
+        opac = torch.empty(n, dtype=torch.float32, device=dev)
+        with profiler.stage("project_fwd"):
+            check(lib.gags_project_fwd_raw(n, ptr(means), ptr(rotation), ptr(scaling_log), ptr(logit), scaling_modifier,
+                                           ptr(viewmat), ptr(K), width, height, eps2d, near, far, radius_clip, ptr(radii),
+                                           ptr(means2d), ptr(depths), ptr(conics), ptr(tiles), ptr(opac), None, None,
+                                           _stream()), "gags_project_fwd_raw")
+        ctx.save_for_backward(means, rotation, scaling_log, logit, viewmat, K, radii)
+        ctx.cfg = (width, height, eps2d, scaling_modifier, tuple(opacity_logit.shape))
+        ctx.mark_non_differentiable(radii, tiles)
+        return radii, means2d, depths, conics, tiles, opac
+
+    @staticmethod
+    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, _v_tiles, v_opac):
+        lib = _lib.load()
+        means, rotation, scaling_log, logit, viewmat, K, radii = ctx.saved_tensors
+        width, height, eps2d, modifier, oshape = ctx.cfg
+        n = means.shape[0]
+        dev = means.device
+        v_means2d = torch.zeros(n, 2, device=dev) if v_means2d is None else _c(v_means2d)
+        v_conics = torch.zeros(n, 3, device=dev) if v_conics is None else _c(v_conics)
+        v_depths = None if v_depths is None else _c(v_depths)
+        v_opac = None if v_opac is None else _c(v_opac)
+        v_means = torch.empty(n, 3, device=dev)
+        v_rot = torch.empty(n, 4, device=dev)
+        v_scal = torch.empty(n, 3, device=dev)
+        v_logit = torch.empty(n, device=dev) if ctx.needs_input_grad[3] else None
+        check(lib.gags_project_bwd_raw(n, ptr(means), ptr(rotation), ptr(scaling_log), ptr(logit), modifier, ptr(viewmat),
+                                       ptr(K), width, height, eps2d, ptr(radii), ptr(v_means2d), ptr(v_depths),
+                                       ptr(v_conics), ptr(v_opac), ptr(v_means), ptr(v_rot), ptr(v_scal), ptr(v_logit),
+                                       _stream()), "gags_project_bwd_raw")
+        return (v_means, v_rot, v_scal, None if v_logit is None else v_logit.reshape(oshape), None, None, None, None, None,
+                None, None, None, None)
+
+
 class _SH(torch.autograd.Function):
     """K3: SH colour and its backward: coefficients, and -- when positions are trainable -- the view direction
     (d colour / d means through normalize(mean - campos), as gsplat propagates it)."""
@@ -530,9 +582,14 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
                   near_plane=0.01, far_plane=1e10, radius_clip=0.0, eps2d=0.3, sh_degree=None, packed=False,
                   tile_size=16, backgrounds=None, render_mode="RGB", sparse_grad=False, absgrad=False,
                   rasterize_mode="classic", channel_chunk=32, distributed=False, camera_model="pinhole",
-                  covars=None, raster_flags=0):
+                  covars=None, raster_flags=0, raw_params=False, scaling_modifier=1.0):
     """See module docstring.  `channel_chunk` is accepted and ignored: any D is composited in a
-    single pass over the sorted lists (SURVEY A12 shows this is identical per channel)."""
+    single pass over the sorted lists (SURVEY A12 shows this is identical per channel).
+    raw_params=True (not part of gsplat's signature): `quats`, `scales`, `opacities` are the STORED parameters of
+    scene/gaussian_model.py:48-61 -- `_rotation` [N,4] un-normalised, `_scaling` [N,3] log-space, `_opacity` [N] or [N,1]
+    logits -- and the getters of :116-139 together with `* scaling_modifier` run inside the projection kernel
+    (gags_project_fwd_raw; bit-identical to torch's exp / F.normalize / sigmoid): no elementwise launches, no extra passes
+    over N, and the backward returns the gradients of the stored parameters."""
     if tile_size != TILE:
         raise NotImplementedError("tile_size must be 16 (the gsplat default the reference relies on)")
     if rasterize_mode != "classic" or camera_model != "pinhole" or covars is not None or distributed or absgrad:
@@ -543,15 +600,22 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
     if viewmats.dim() != 3 or viewmats.shape[0] != 1 or Ks.shape[0] != 1:
         raise NotImplementedError("one camera per call (the reference renders one view per iteration, train.py:134-142)")
     n = means.shape[0]
-    if quats.shape != (n, 4) or scales.shape != (n, 3) or opacities.shape != (n,):
+    if raw_params and opacities.shape == (n, 1):
+        pass
+    elif quats.shape != (n, 4) or scales.shape != (n, 3) or opacities.shape != (n,):
         raise ValueError("means [N,3], quats [N,4], scales [N,3], opacities [N] expected")
     _need_cuda(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds)
     width, height = int(width), int(height)
     viewmat, K = viewmats[0], Ks[0]
 
-    radii, means2d, depths, conics, tiles = _Project.apply(means, quats, scales, viewmat, K, width, height,
-                                                           float(eps2d), float(near_plane), float(far_plane),
-                                                           float(radius_clip))
+    if raw_params:
+        radii, means2d, depths, conics, tiles, opacities = _ProjectRaw.apply(
+            means, quats, scales, opacities, viewmat, K, width, height, float(eps2d), float(near_plane), float(far_plane),
+            float(radius_clip), float(scaling_modifier))
+    else:
+        radii, means2d, depths, conics, tiles = _Project.apply(means, quats, scales, viewmat, K, width, height,
+                                                               float(eps2d), float(near_plane), float(far_plane),
+                                                               float(radius_clip))
     # [1,N,2] node callers may retain_grad() on (gaussian_renderer/__init__.py:75-78); the
     # rasterizer consumes a view of it so its .grad receives d loss / d means2d.
     means2d_c = means2d[None]

@@ -260,6 +260,24 @@ int gags_raster_stats(int width, int height, const float *means2d, const float *
                       const float *opacities, const int32_t *isect_offsets, const int32_t *flatten_ids,
                       int64_t n_isects, int64_t *counts, void *stream);
 
+/* K1 + K4 on the STORED parameters (R2 folded into R4; SURVEY 8a R2: "4 elementwise kernels/iter over N (fusable into
+ * projection)"): rotation[N,4] un-normalised, scaling_log[N,3], opacity_logit[N] exactly as scene/gaussian_model.py:48-61
+ * holds them; the kernel applies the getters of :116-139 -- exp (* scaling_modifier, gaussian_renderer/__init__.py:41),
+ * F.normalize, sigmoid -- bit for bit as torch evaluates them (tools/micro/actprobe.py), then projects as gags_project_fwd.
+ * Extra outputs: opacities[N] (activated: what the raster kernels read); quats_act[N,4] / scales_act[N,3] (activated; NULL
+ * = not wanted).  The backward takes the gradients back to the stored parameters, v_opacities[N] (from the rasterizer;
+ * NULL = zeros) included; v_opacity_logit may be NULL. */
+int gags_project_fwd_raw(int n, const float *means, const float *rotation, const float *scaling_log,
+                         const float *opacity_logit, float scaling_modifier, const float *viewmat, const float *K,
+                         int width, int height, float eps2d, float near_plane, float far_plane, float radius_clip,
+                         int32_t *radii, float *means2d, float *depths, float *conics, int32_t *tiles_per_gauss,
+                         float *opacities, float *quats_act, float *scales_act, void *stream);
+int gags_project_bwd_raw(int n, const float *means, const float *rotation, const float *scaling_log,
+                         const float *opacity_logit, float scaling_modifier, const float *viewmat, const float *K,
+                         int width, int height, float eps2d, const int32_t *radii, const float *v_means2d,
+                         const float *v_depths, const float *v_conics, const float *v_opacities, float *v_means,
+                         float *v_rotation, float *v_scaling_log, float *v_opacity_logit, void *stream);
+
 /* K2: projection backward: chain rule of gags_project_fwd for Gaussians with radii>0.
  * Inputs v_means2d[N,2], v_depths[N] (may be NULL), v_conics[N,3];
  * outputs (overwritten) v_means[N,3], v_quats[N,4], v_scales[N,3]. */

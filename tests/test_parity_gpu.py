@@ -909,3 +909,74 @@ def test_harness_dot_matches_float64():
     ref = torch.dot(x.double(), y.double()).item()
     assert outs[0] == outs[1]
     assert abs(outs[0] - ref) <= 1e-5 * (x.double().norm() * y.double().norm()).item()
+
+
+@pytest.mark.parametrize("modifier", [1.0, 0.7])
+def test_raw_parameter_projection_is_bit_identical_to_the_getters(oracle, modifier):
+    """gags_project_fwd_raw (R2 folded into R4): fed the STORED parameters (_rotation un-normalised, _scaling in log space,
+    _opacity logits, scene/gaussian_model.py:48-61) it must produce, bit for bit, what gags_project_fwd -- and the oracle --
+    produce from torch's own getters (exp, F.normalize, sigmoid, render()'s `* scaling_modifier`), the activated opacity and
+    the optional activated quats / scales included."""
+    from gags_amd import _lib, synthetic as syn
+    from gags_amd.rasterization import _Project, _ProjectRaw
+    w, h, n = 300, 200, 50_000
+    p = syn.make_gaussians(n, 0, w, h, seed=31, scale0=syn.SCALE0 * 4)
+    p["rotation"][:4] *= 1e-20                    # |q| < 1e-12: F.normalize's eps clamp decides the activated value
+    cam = syn.make_camera(w, h, view=2, device="cuda")
+    vm, K = syn.camera_matrices(cam)
+    Kd = torch.from_numpy(K).cuda()
+    xyz, rot, slog, logit = (p[k].cuda() for k in ("xyz", "rotation", "scaling_log", "opacity_logit"))
+    q_act, s_act, o_act = torch.nn.functional.normalize(rot), torch.exp(slog) * modifier, torch.sigmoid(logit)
+    cfg = (w, h, 0.3, 0.01, 1e10, 0.0)
+    want = _Project.apply(xyz, q_act, s_act, vm, Kd, *cfg)
+    got = _ProjectRaw.apply(xyz, rot, slog, logit, vm, Kd, *cfg, modifier)
+    for a, b, name in zip(got[:5], want, ("radii", "means2d", "depths", "conics", "tiles_per_gauss")):
+        assert torch.equal(a, b), name
+    assert torch.equal(got[5], o_act.reshape(-1))
+    assert int((want[0] > 0).sum()) > n // 2
+    o_radii, o_m2d, o_depths, o_conics = oracle.project_fwd(xyz.cpu().numpy(), q_act.cpu().numpy(), s_act.cpu().numpy(),
+                                                            vm.cpu().numpy(), K, w, h)
+    np.testing.assert_array_equal(got[0].cpu().numpy(), o_radii)
+    np.testing.assert_array_equal(got[1].cpu().numpy(), o_m2d)
+    np.testing.assert_array_equal(got[3].cpu().numpy(), o_conics)
+    # the optional activated copies (for callers that keep them)
+    lib = _lib.load()
+    outs = [torch.empty(n, dtype=torch.int32, device="cuda"), torch.empty(n, 2, device="cuda"), torch.empty(n, device="cuda"),
+            torch.empty(n, 3, device="cuda"), torch.empty(n, dtype=torch.int32, device="cuda"), torch.empty(n, device="cuda"),
+            torch.empty(n, 4, device="cuda"), torch.empty(n, 3, device="cuda")]
+    _lib.check(lib.gags_project_fwd_raw(n, _lib.ptr(xyz), _lib.ptr(rot), _lib.ptr(slog), _lib.ptr(logit.reshape(-1).contiguous()),
+                                        modifier, _lib.ptr(vm.contiguous()), _lib.ptr(Kd), w, h, 0.3, 0.01, 1e10, 0.0,
+                                        *[_lib.ptr(t) for t in outs], None), "gags_project_fwd_raw")
+    assert torch.equal(outs[6], q_act) and torch.equal(outs[7], s_act)
+
+
+def test_raw_parameter_projection_gradients_match_autograd_through_the_getters():
+    """render() with every parameter trainable: the raw-parameter path (getters and their backward inside the projection
+    kernels) against the getter path (torch's exp / normalize / sigmoid and their autograd): same render bit for bit, same
+    feature gradient bit for bit, geometry gradients of the STORED parameters to fp32 rounding."""
+    import gags_amd.gaussian_renderer as gr
+    from gags_amd import synthetic as syn
+    w, h, n, d = 176, 130, 6000, 32
+    cam = syn.make_camera(w, h, view=5, device="cuda")
+    bg = torch.tensor([0.5, 0.5, 0.5], device="cuda")
+    G = syn.make_cotangent(d, h, w, seed=4).cuda()
+    res = {}
+    for raw in (True, False):
+        pc = syn.make_model(n, d, w, h, seed=33, device="cuda", scale0=syn.SCALE0 * 5)
+        pc.training_setup()
+        geo = [pc._xyz, pc._rotation, pc._scaling, pc._opacity]
+        for q in geo:
+            q.requires_grad_(True)
+        gr.RAW_PARAMS = raw
+        try:
+            pkg = gr.render(cam, pc, None, bg, feature_mode=True, scaling_modifier=0.9)
+            (pkg["render"] * G).sum().backward()
+        finally:
+            gr.RAW_PARAMS = True
+        res[raw] = (pkg["render"].detach().clone(), pc._semantic_feature.grad.clone(), [q.grad.clone() for q in geo],
+                    pkg["viewspace_points"].grad.clone())
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    assert torch.equal(res[True][3], res[False][3])  # d loss / d means2d (densification statistics) is untouched
+    for a, b, name in zip(res[True][2], res[False][2], ("xyz", "rotation", "scaling", "opacity")):
+        assert a.shape == b.shape and float(b.abs().max()) > 0, name
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) <= 1e-6, name
