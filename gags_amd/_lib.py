@@ -103,6 +103,8 @@ SIGNATURES = {
     "gags_scale_decoder_fwd_fused": (_i32, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_scale_decoder_bwd_fused": (_i32, [_i64, _vp, _vp, _vp, _vp, _vp]),
     "gags_decoder_layer_exact": (_i32, [_i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "gags_decoder_layer_split": (_i32, [_i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "gags_decoder_wgrad_split": (_i32, [_i64, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp]),
     "gags_decoder_wgrad_exact_scratch_bytes": (_i64, [_i64, _i32, _i32]),
     "gags_decoder_wgrad_exact": (_i32, [_i64, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp]),
     "gags_decoder_head_bwd_exact": (_i32, [_i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp]),

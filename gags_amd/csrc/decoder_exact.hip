@@ -12,6 +12,13 @@
 //                              the loader transposes; pixel chunks -> partial matrices -> summed in chunk order: NO atomics,
 //                              bit-reproducible)
 // plus the bias gradient (column sums, same two deterministic stages) and the output heads' backward in fp32.
+//
+// A second tier, NT = 2 (gags_decoder_layer_split / gags_decoder_wgrad_split with terms = 2; round 4): every operand as TWO
+// bfloat16 terms, a = h + m + O(2^-17 |a|) (16 significand bits), a product as its three terms of order <= 1,
+//     a b ~ h h' + h m' + m h'                                                    (dropped: m m' <= 2^-18 |a b|)
+// i.e. a relative error <= ~2^-16 per product -- 32x tighter than the TF32 arithmetic (10-bit significands) torch runs the
+// reference's nn.Conv2d stacks in by default on the GPU its README names -- at half the matrix work and two thirds of the
+// split / LDS work of the exact tier.  fp32 tensors in memory, fp32 accumulation, the same deterministic reductions.
 #include "common.h"
 #include "gags_next.h"
 
@@ -22,7 +29,7 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int XM = 128, XN = 128, XK = 32;  // workgroup tile: 128 x 128 outputs, 32 contraction elements per step
 constexpr int XLD = XK + 8;                 // LDS row pitch in bf16 (80 B: 16-byte aligned rows, banks spread)
-constexpr int NTERM = 3;
+// (the kernels are templates over the number of bf16 terms per operand, NT in {3: exact, 2: bf16x2})
 
 // two floats -> packed bf16 pair, round to nearest even, in one instruction (v_cvt_pk_bf16_f32, new on gfx950)
 typedef __bf16 xbf16x2_t __attribute__((ext_vector_type(2)));
@@ -33,14 +40,17 @@ __device__ __forceinline__ unsigned xpack(float lo, float hi)
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, xbf16x2_t));
 }
 
-// (a, b) -> three packed bf16 pairs t[s] = (term s of a) | (term s of b) << 16 with  x = h + m + l  exactly
-__device__ __forceinline__ void split3x2(float a, float b, unsigned (&t)[NTERM])
+// (a, b) -> NT packed bf16 pairs t[s] = (term s of a) | (term s of b) << 16; NT = 3: x = h + m + l exactly; NT = 2: h + m
+template <int NT>
+__device__ __forceinline__ void split3x2(float a, float b, unsigned (&t)[NT])
 {
     t[0] = xpack(a, b);
     float ra = a - __uint_as_float(t[0] << 16), rb = b - __uint_as_float(t[0] & 0xffff0000u);
     t[1] = xpack(ra, rb);
-    ra -= __uint_as_float(t[1] << 16); rb -= __uint_as_float(t[1] & 0xffff0000u);
-    t[2] = xpack(ra, rb);
+    if constexpr (NT == 3) {
+        ra -= __uint_as_float(t[1] << 16); rb -= __uint_as_float(t[1] & 0xffff0000u);
+        t[2] = xpack(ra, rb);
+    }
 }
 
 struct XArgs {
@@ -99,17 +109,18 @@ __device__ __forceinline__ void fetch_rows(float (&v)[4][4], const float *__rest
     }
 }
 
+template <int NT>
 __device__ __forceinline__ void commit_rows(unsigned short (*S)[XM][XLD], const float (&v)[4][4], int tid)
 {
     const int kc = (tid & 7) * 4;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int r = (tid >> 3) + 32 * q;
-        unsigned t01[NTERM], t23[NTERM];
-        split3x2(v[q][0], v[q][1], t01);
-        split3x2(v[q][2], v[q][3], t23);
+        unsigned t01[NT], t23[NT];
+        split3x2<NT>(v[q][0], v[q][1], t01);
+        split3x2<NT>(v[q][2], v[q][3], t23);
 #pragma unroll
-        for (int s = 0; s < NTERM; ++s) *reinterpret_cast<uint2 *>(&S[s][r][kc]) = make_uint2(t01[s], t23[s]);
+        for (int s = 0; s < NT; ++s) *reinterpret_cast<uint2 *>(&S[s][r][kc]) = make_uint2(t01[s], t23[s]);
     }
 }
 
@@ -135,30 +146,32 @@ __device__ __forceinline__ void fetch_cols(float (&v)[16], const float *__restri
 }
 
 // ... -> S[term][column][pixel]: four 8-byte stores per term (four consecutive pixels each: the transposition)
+template <int NT>
 __device__ __forceinline__ void commit_cols(unsigned short (*S)[XM][XLD], const float (&v)[16], int tid)
 {
     const int c = tid & 127, sp = 16 * (tid >> 7);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        unsigned t01[NTERM], t23[NTERM];
-        split3x2(v[4 * j], v[4 * j + 1], t01);
-        split3x2(v[4 * j + 2], v[4 * j + 3], t23);
+        unsigned t01[NT], t23[NT];
+        split3x2<NT>(v[4 * j], v[4 * j + 1], t01);
+        split3x2<NT>(v[4 * j + 2], v[4 * j + 3], t23);
 #pragma unroll
-        for (int s = 0; s < NTERM; ++s) *reinterpret_cast<uint2 *>(&S[s][c][sp + 4 * j]) = make_uint2(t01[s], t23[s]);
+        for (int s = 0; s < NT; ++s) *reinterpret_cast<uint2 *>(&S[s][c][sp + 4 * j]) = make_uint2(t01[s], t23[s]);
     }
 }
 
 // one 32-wide contraction step from LDS: each wave owns 64 x 64 outputs (2 x 2 MFMA tiles)
+template <int NT>
 __device__ __forceinline__ void tile_step(f32x16 (&acc)[2][2], unsigned short (*Xs)[XM][XLD], unsigned short (*Ys)[XN][XLD], int wy,
                                           int wx, int lane)
 {
 #pragma unroll
     for (int ks = 0; ks < XK; ks += 16) {
-        bf16x8 a[2][NTERM], b[2][NTERM];
+        bf16x8 a[2][NT], b[2][NT];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int s = 0; s < NTERM; ++s) {
+            for (int s = 0; s < NT; ++s) {
                 a[i][s] = *reinterpret_cast<const bf16x8 *>(&Xs[s][wy * 64 + i * 32 + (lane & 31)][ks + 8 * (lane >> 5)]);
                 b[i][s] = *reinterpret_cast<const bf16x8 *>(&Ys[s][wx * 64 + i * 32 + (lane & 31)][ks + 8 * (lane >> 5)]);
             }
@@ -167,9 +180,11 @@ __device__ __forceinline__ void tile_step(f32x16 (&acc)[2][2], unsigned short (*
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 // smallest terms first
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
+                if constexpr (NT == 3) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
+                }
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
@@ -178,15 +193,17 @@ __device__ __forceinline__ void tile_step(f32x16 (&acc)[2][2], unsigned short (*
 }
 
 constexpr int XOP = XN + 4;  // output tile pitch in floats (528 B rows: 16-byte aligned)
-template <bool TWO, bool VEC>
+// (NT = 2 with three workgroups per CU, its 40 KB of operand images would allow it: measured 1.46 -> 2.28 ms per 256 x 256
+// layer -- the 170-register budget spills the accumulators -- and no change for the weight-gradient kernel; two it stays)
+template <bool TWO, bool VEC, int NT>
 __global__ __launch_bounds__(256, 2) void gemm_x3_nt_kernel(XArgs g)
 {
     // one buffer: the operand images during the K loop (2 x 3 x 128 x 40 bf16 = 60 KB), then the fp32 output tile of the
     // epilogue (128 x 132 floats = 66 KB); two workgroups per CU either way
-    constexpr int OPER = 2 * NTERM * XM * XLD * 2, OUTB = XM * XOP * 4;
+    constexpr int OPER = 2 * NT * XM * XLD * 2, OUTB = XM * XOP * 4;
     __shared__ __attribute__((aligned(16))) unsigned char smem[OPER > OUTB ? OPER : OUTB];
     unsigned short (*Xs)[XM][XLD] = reinterpret_cast<unsigned short (*)[XM][XLD]>(smem);
-    unsigned short (*Ys)[XN][XLD] = reinterpret_cast<unsigned short (*)[XN][XLD]>(smem + NTERM * XM * XLD * 2);
+    unsigned short (*Ys)[XN][XLD] = reinterpret_cast<unsigned short (*)[XN][XLD]>(smem + NT * XM * XLD * 2);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wy = wave >> 1, wx = wave & 1;
     // the column tiles of one pixel tile run back to back on the SAME XCD (workgroups are dealt round-robin over the 8
     // XCDs, each with its own L2): the second one finds the activation rows in that L2 instead of re-reading HBM
@@ -206,14 +223,14 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_nt_kernel(XArgs g)
     fetch_rows<TWO, VEC>(va, g.A1, g.A2, g.lda, m0, g.M, 0, g.K, tid);
     fetch_rows<false, VEC>(vb, g.B, nullptr, g.ldb, n0, g.N, 0, g.K, tid);
     for (int k0 = 0; k0 < g.K; k0 += XK) {
-        commit_rows(Xs, va, tid);
-        commit_rows(Ys, vb, tid);
+        commit_rows<NT>(Xs, va, tid);
+        commit_rows<NT>(Ys, vb, tid);
         __syncthreads();
         // next step's operands: in flight while this one multiplies (past the end: clamped re-reads, never committed)
         fetch_rows<TWO, VEC>(va, g.A1, g.A2, g.lda, m0, g.M, k0 + XK, g.K, tid);
         fetch_rows<false, VEC>(vb, g.B, nullptr, g.ldb, n0, g.N, k0 + XK, g.K, tid);
         __builtin_amdgcn_sched_barrier(0);  // (the scheduler would sink the loads to their use after the MFMAs)
-        tile_step(acc, Xs, Ys, wy, wx, lane);
+        tile_step<NT>(acc, Xs, Ys, wy, wx, lane);
         __syncthreads();
     }
     if (g.vout) {  // (uniform)
@@ -319,11 +336,11 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_nt_kernel(XArgs g)
         }
 }
 
-template <bool TWO>
+template <bool TWO, int NT>
 __global__ __launch_bounds__(256, 2) void gemm_x3_tn_kernel(XArgs g)
 {
-    __shared__ __attribute__((aligned(16))) unsigned short Xs[NTERM][XM][XLD];
-    __shared__ __attribute__((aligned(16))) unsigned short Ys[NTERM][XN][XLD];
+    __shared__ __attribute__((aligned(16))) unsigned short Xs[NT][XM][XLD];
+    __shared__ __attribute__((aligned(16))) unsigned short Ys[NT][XN][XLD];
     __shared__ float bsh[2][XM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wy = wave >> 1, wx = wave & 1;
     const int64_t pa = (int64_t)blockIdx.x * g.chunk, pb = min(pa + g.chunk, g.P);
@@ -342,8 +359,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_tn_kernel(XArgs g)
     fetch_cols<false>(va, g.A1, nullptr, g.lda, pa, pb, m0, g.Mo, tid);
     fetch_cols<TWO>(vb, g.B, g.B2, g.ldb, pa, pb, n0, g.No, tid);
     for (int64_t p0 = pa; p0 < pb; p0 += XK) {
-        commit_cols(Xs, va, tid);
-        commit_cols(Ys, vb, tid);
+        commit_cols<NT>(Xs, va, tid);
+        commit_cols<NT>(Ys, vb, tid);
         if (do_bias) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) bsum += va[i];
@@ -353,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_tn_kernel(XArgs g)
         fetch_cols<false>(va, g.A1, nullptr, g.lda, p0 + XK, pb, m0, g.Mo, tid);
         fetch_cols<TWO>(vb, g.B, g.B2, g.ldb, p0 + XK, pb, n0, g.No, tid);
         __builtin_amdgcn_sched_barrier(0);
-        tile_step(acc, Xs, Ys, wy, wx, lane);
+        tile_step<NT>(acc, Xs, Ys, wy, wx, lane);
         __syncthreads();
     }
     float *out = g.part + (size_t)blockIdx.x * g.Mo * g.No;
@@ -452,11 +469,12 @@ inline int64_t wgrad_chunk(int64_t n_pix)
 
 }  // namespace
 
-extern "C" int gags_decoder_layer_exact(int64_t n_pix, int n_out, int k_in, const float *a1, const float *a2, int lda,
+extern "C" int gags_decoder_layer_split(int64_t n_pix, int n_out, int k_in, const float *a1, const float *a2, int lda,
                                         const float *w, const float *bias, int relu, const float *mask_src,
-                                        const float *residual, float *y, float *y_premask, int ldy, void *stream)
+                                        const float *residual, float *y, float *y_premask, int ldy, int terms, void *stream)
 {
     GAGS_CLEAR_ERR();
+    if (terms != 2 && terms != 3) return GAGS_EINVAL;
     if (n_pix < 0 || n_out <= 0 || k_in <= 0 || lda < k_in || ldy < n_out || !a1 || !w || (!y && !y_premask)) return GAGS_EINVAL;
     if (n_pix == 0) return GAGS_OK;
     XArgs g = {};
@@ -471,15 +489,28 @@ extern "C" int gags_decoder_layer_exact(int64_t n_pix, int n_out, int k_in, cons
               ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(y_premask) | reinterpret_cast<uintptr_t>(mask_src) |
                 reinterpret_cast<uintptr_t>(residual)) & 15) == 0) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
-    if (a2) {
-        if (vec) hipLaunchKernelGGL((gemm_x3_nt_kernel<true, true>), grid, dim3(256), 0, st, g);
-        else hipLaunchKernelGGL((gemm_x3_nt_kernel<true, false>), grid, dim3(256), 0, st, g);
-    } else {
-        if (vec) hipLaunchKernelGGL((gemm_x3_nt_kernel<false, true>), grid, dim3(256), 0, st, g);
-        else hipLaunchKernelGGL((gemm_x3_nt_kernel<false, false>), grid, dim3(256), 0, st, g);
-    }
+#define GO(NT)                                                                                              \
+    do {                                                                                                    \
+        if (a2) {                                                                                           \
+            if (vec) hipLaunchKernelGGL((gemm_x3_nt_kernel<true, true, NT>), grid, dim3(256), 0, st, g);    \
+            else hipLaunchKernelGGL((gemm_x3_nt_kernel<true, false, NT>), grid, dim3(256), 0, st, g);       \
+        } else {                                                                                            \
+            if (vec) hipLaunchKernelGGL((gemm_x3_nt_kernel<false, true, NT>), grid, dim3(256), 0, st, g);   \
+            else hipLaunchKernelGGL((gemm_x3_nt_kernel<false, false, NT>), grid, dim3(256), 0, st, g);      \
+        }                                                                                                   \
+    } while (0)
+    if (terms == 3) GO(3); else GO(2);
+#undef GO
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
+}
+
+extern "C" int gags_decoder_layer_exact(int64_t n_pix, int n_out, int k_in, const float *a1, const float *a2, int lda,
+                                        const float *w, const float *bias, int relu, const float *mask_src,
+                                        const float *residual, float *y, float *y_premask, int ldy, void *stream)
+{
+    return gags_decoder_layer_split(n_pix, n_out, k_in, a1, a2, lda, w, bias, relu, mask_src, residual, y, y_premask, ldy, 3,
+                                    stream);
 }
 
 extern "C" int64_t gags_decoder_wgrad_exact_scratch_bytes(int64_t n_pix, int n_out, int k_in)
@@ -489,11 +520,12 @@ extern "C" int64_t gags_decoder_wgrad_exact_scratch_bytes(int64_t n_pix, int n_o
     return al256(n_chunks * ((int64_t)n_out * k_in + n_out) * 4);
 }
 
-extern "C" int gags_decoder_wgrad_exact(int64_t n_pix, int n_out, int k_in, const float *dz, int lddz, const float *a1,
+extern "C" int gags_decoder_wgrad_split(int64_t n_pix, int n_out, int k_in, const float *dz, int lddz, const float *a1,
                                         const float *a2, int lda, float *d_w, float *d_b, void *scratch,
-                                        int64_t scratch_bytes, void *stream)
+                                        int64_t scratch_bytes, int terms, void *stream)
 {
     GAGS_CLEAR_ERR();
+    if (terms != 2 && terms != 3) return GAGS_EINVAL;
     if (n_pix < 0 || n_out <= 0 || k_in <= 0 || lddz < n_out || lda < k_in || !dz || !a1 || !d_w) return GAGS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (n_pix == 0) {
@@ -509,8 +541,13 @@ extern "C" int gags_decoder_wgrad_exact(int64_t n_pix, int n_out, int k_in, cons
     g.A1 = dz; g.lda = lddz; g.B = a1; g.B2 = a2; g.ldb = lda; g.Mo = n_out; g.No = k_in; g.P = n_pix; g.chunk = chunk; g.part = part;
     g.bias_part = d_b ? part_b : nullptr;
     const dim3 grid((unsigned)n_chunks, (unsigned)((n_out + XM - 1) / XM), (unsigned)((k_in + XN - 1) / XN));
-    if (a2) hipLaunchKernelGGL(gemm_x3_tn_kernel<true>, grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL(gemm_x3_tn_kernel<false>, grid, dim3(256), 0, st, g);
+    if (terms == 3) {
+        if (a2) hipLaunchKernelGGL((gemm_x3_tn_kernel<true, 3>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((gemm_x3_tn_kernel<false, 3>), grid, dim3(256), 0, st, g);
+    } else {
+        if (a2) hipLaunchKernelGGL((gemm_x3_tn_kernel<true, 2>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((gemm_x3_tn_kernel<false, 2>), grid, dim3(256), 0, st, g);
+    }
     const int64_t elems = (int64_t)n_out * k_in;
     hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, n_chunks, elems, part, d_w);
     if (d_b)
@@ -518,6 +555,13 @@ extern "C" int gags_decoder_wgrad_exact(int64_t n_pix, int n_out, int k_in, cons
                            d_b);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
+}
+
+extern "C" int gags_decoder_wgrad_exact(int64_t n_pix, int n_out, int k_in, const float *dz, int lddz, const float *a1,
+                                        const float *a2, int lda, float *d_w, float *d_b, void *scratch,
+                                        int64_t scratch_bytes, void *stream)
+{
+    return gags_decoder_wgrad_split(n_pix, n_out, k_in, dz, lddz, a1, a2, lda, d_w, d_b, scratch, scratch_bytes, 3, stream);
 }
 
 extern "C" int gags_decoder_head_bwd_exact(int64_t n_pix, int c, int ldx, int mode, const float *x, const float *g, int layout,

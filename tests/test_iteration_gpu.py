@@ -44,32 +44,39 @@ def _run(precision, iteration, fused_head=None, layout="pixel_major"):
     return loss, terms, fmap.grad, dec, sdec
 
 
+@pytest.mark.parametrize("precision,ftol", [("exact", 1e-5), ("bf16x2", 1e-4)])
 @pytest.mark.parametrize("layout", ["pixel_major", "channel_major"])
 @pytest.mark.parametrize("tag,iteration", [("early", 7000), ("late", 20000)])
-def test_composed_iteration_matches_the_reference_chain(tag, iteration, layout):
-    """Default precision (fp32-equivalent): loss 1e-5, d loss / d feature_map and every decoder gradient 1e-3 rel-L2 of the
-    reference's fp32 autograd (the bound of test_decoders_gpu.py's per-module test; measured ~1e-6)."""
-    loss, terms, vf, dec, sdec = _run("exact", iteration, layout=layout)
-    assert abs(loss.item() - float(Z[f"{tag}_loss"])) <= 1e-5 * abs(float(Z[f"{tag}_loss"]))
+def test_composed_iteration_matches_the_reference_chain(tag, iteration, layout, precision, ftol):
+    """Default precision (fp32-equivalent) and the two-term tier: loss 1e-5 / 1e-4, d loss / d feature_map and every decoder
+    gradient 1e-3 rel-L2 of the reference's fp32 autograd (the bounds of test_decoders_gpu.py's per-module test)."""
+    loss, terms, vf, dec, sdec = _run(precision, iteration, layout=layout)
+    assert abs(loss.item() - float(Z[f"{tag}_loss"])) <= ftol * abs(float(Z[f"{tag}_loss"]))
     l1, ce, rv = (float(v) for v in Z[f"{tag}_terms"])
-    assert abs(terms["l1"].item() - l1) <= 1e-5 * l1 and abs(terms["ce"].item() - ce) <= 1e-5 * ce
+    assert abs(terms["l1"].item() - l1) <= ftol * l1 and abs(terms["ce"].item() - ce) <= ftol * ce
     if tag == "late":
-        assert abs(terms["regionvar"].item() - rv) <= 1e-5 * rv
+        assert abs(terms["regionvar"].item() - rv) <= ftol * rv
     else:
         assert terms["regionvar"] is None  # computed by the reference, dropped from its loss before 15001
-    assert rel_l2(terms["scale_map"].detach().cpu().numpy(), Z["scale_map"]) <= 1e-5
+    assert rel_l2(terms["scale_map"].detach().cpu().numpy(), Z["scale_map"]) <= ftol
     np.testing.assert_array_equal(terms["seg_map_trained"].cpu().numpy(), Z["seg_map_trained"])
+    # The L1 map's gradient is sign(pred - gt) / C per element: ONE of the 393 216 differences changing sign moves
+    # d loss / d prediction by 2 / sqrt(393 216) = 3.2e-3 in rel-L2, whatever the precision of everything else.  At 1e-6
+    # (exact) no difference is that close to zero on this fixture; at 2^-16 per product (bf16x2) a handful are: its
+    # gradients through the composed, non-smooth loss are bounded at 1e-2 here, and at 1e-3 -- the bound VERDICT r3 item 4
+    # asks for -- through the smooth per-module fixture (tests/test_decoders_gpu.py: measured 1.5e-5).
+    gtol = 1e-3 if precision == "exact" else 1e-2
     assert vf.shape == Z[f"{tag}_vfmap"].shape
-    assert rel_l2(vf.cpu().numpy(), Z[f"{tag}_vfmap"]) <= 1e-3
+    assert rel_l2(vf.cpu().numpy(), Z[f"{tag}_vfmap"]) <= gtol
     for i, m in enumerate(dec.convs()):
         gw = m.weight.grad[:, :, 0, 0]
         want = Z[f"{tag}_dec_vw{i}"]
-        assert rel_l2(gw[:want.shape[0]].cpu().numpy(), want) <= 1e-3, i
-        assert abs(gw.double().norm().item() - float(Z[f"{tag}_dec_vw{i}_norm"])) <= 1e-3 * float(Z[f"{tag}_dec_vw{i}_norm"])
-        assert rel_l2(m.bias.grad.cpu().numpy(), Z[f"{tag}_dec_vb{i}"]) <= 1e-3, i
+        assert rel_l2(gw[:want.shape[0]].cpu().numpy(), want) <= gtol, i
+        assert abs(gw.double().norm().item() - float(Z[f"{tag}_dec_vw{i}_norm"])) <= gtol * float(Z[f"{tag}_dec_vw{i}_norm"])
+        assert rel_l2(m.bias.grad.cpu().numpy(), Z[f"{tag}_dec_vb{i}"]) <= gtol, i
     for i, m in enumerate(sdec.convs()):  # the scale decoder learns from CE and through the ground-truth blend only
-        assert rel_l2(m.weight.grad[:, :, 0, 0].cpu().numpy(), Z[f"{tag}_sdec_vw{i}"]) <= 1e-3, i
-        assert rel_l2(m.bias.grad.cpu().numpy(), Z[f"{tag}_sdec_vb{i}"]) <= 1e-3, i
+        assert rel_l2(m.weight.grad[:, :, 0, 0].cpu().numpy(), Z[f"{tag}_sdec_vw{i}"]) <= gtol, i
+        assert rel_l2(m.bias.grad.cpu().numpy(), Z[f"{tag}_sdec_vb{i}"]) <= gtol, i
 
 
 def test_the_scale_decoder_does_not_backpropagate_into_the_feature_map():

@@ -51,7 +51,20 @@ cases = {
     "wgrad_256x256": (lambda: D._wgrad(P, a, a2, None, 256, 256), 2 * P * 256 * 256, P * 256 * 4),
     "wgrad_256x256_two_sources": (lambda: D._wgrad(P, a, a2, m, 256, 256), 2 * P * 256 * 256, P * 256 * 6),
 }
-only = sys.argv[1:] or list(cases)
+# the fp32-tensor tiers (csrc/decoder_exact.hip): operands split into 3 ("exact") or 2 ("bf16x2") bf16 terms
+af, af2, mf = a.float(), a2.float(), m.float()
+wf256, wf512 = w256.float(), w512.float()
+for terms, tag in ((3, "exact"), (2, "bf16x2")):
+    cases.update({
+        f"{tag}_layer_256x256": (lambda t=terms: D._xlayer(P, wf256, b256, af, terms=t), 2 * P * 256 * 256, P * 256 * 8),
+        f"{tag}_layer_256x256_two_sources": (lambda t=terms: D._xlayer(P, wf256, b256, af, af2, terms=t), 2 * P * 256 * 256, P * 256 * 12),
+        f"{tag}_layer_512x256": (lambda t=terms: D._xlayer(P, wf512, b512, af, relu=False, terms=t), 2 * P * 512 * 256, P * (1024 + 2048)),
+        f"{tag}_dgrad_256x256_mask_residual": (lambda t=terms: D._xlayer(P, wf256, None, af, relu=False, mask_src=mf, residual=af2, terms=t),
+                                               2 * P * 256 * 256, P * 256 * 16),
+        f"{tag}_wgrad_256x256": (lambda t=terms: D._xwgrad(P, af, af2, None, 256, 256, terms=t), 2 * P * 256 * 256, P * 256 * 8),
+        f"{tag}_wgrad_256x256_two_sources": (lambda t=terms: D._xwgrad(P, af, af2, mf, 256, 256, terms=t), 2 * P * 256 * 256, P * 256 * 12),
+    })
+only = [k for k in cases if any(f in k for f in sys.argv[1:])] if sys.argv[1:] else list(cases)
 out = {}
 for k in only:
     fn, fl, by = cases[k]
