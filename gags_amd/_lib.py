@@ -33,6 +33,7 @@ SIGNATURES = {
                                     _vp, _vp, _vp, _vp, _vp]),
     "gags_scan_scratch_bytes": (_i64, [_i32]),
     "gags_cumsum_i32": (_i32, [_i32, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "gags_cumsum_gather_i32": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "gags_read_i32": (_i32, [_vp, _vp, _vp]),
     "gags_depth_order_scratch_bytes": (_i64, [_i32]),
     "gags_depth_order": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),

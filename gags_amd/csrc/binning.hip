@@ -5,6 +5,12 @@
 
 namespace {
 
+// One wave emits the intersections of 64 consecutive Gaussians of the emission order.  Their output positions are ONE
+// contiguous range [cum[first - 1], cum[last]) -- so the wave writes that range with consecutive lanes on consecutive
+// entries (8-byte keys, 4-byte values: whole cache lines) and finds, per entry, the Gaussian it belongs to by a 6-step
+// search over the wave's 64 start offsets in LDS.  (One lane per Gaussian writing its own run of ~5 entries put every
+// 12 bytes on a cache line of its own: 0.8 TB/s, 107 us at C3.)  Same entries, same order: tile rows top to bottom,
+// left to right inside the Gaussian's tile rectangle.
 __global__ __launch_bounds__(256) void tile_emit_kernel(int n, const float *__restrict__ means2d,
                                                         const int32_t *__restrict__ radii,
                                                         const float *__restrict__ depths,
@@ -13,25 +19,45 @@ __global__ __launch_bounds__(256) void tile_emit_kernel(int n, const float *__re
                                                         int64_t *__restrict__ isect_ids,
                                                         int32_t *__restrict__ flatten_ids, int64_t cap)
 {
+    __shared__ int s_rel[4][64], s_x0[4][64], s_y0[4][64], s_w[4][64], s_gid[4][64];
+    __shared__ uint32_t s_dbits[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int j = blockIdx.x * 256 + threadIdx.x;  // position in the emission order
-    if (j >= n) return;
-    const int i = order ? order[j] : j;            // Gaussian
-    const int rad = radii[i];
-    if (rad <= 0) return;
-    const float2 m = reinterpret_cast<const float2 *>(means2d)[i];
-    int x0, x1, y0, y1;
-    gags_tile_aabb(m.x, m.y, rad, tile_w, tile_h, x0, x1, y0, y1);
-    int cur = (j == 0) ? 0 : cum[j - 1];
-    const int64_t dbits = (int64_t)(uint32_t)__float_as_int(depths[i]);
-    for (int ty = y0; ty < y1; ++ty)
-        for (int tx = x0; tx < x1; ++tx) {
-            const int64_t tile_id = (int64_t)ty * tile_w + tx;
-            if (cur < cap) {  // (capacity-sized buffers: a count above the capacity is detected by the caller afterwards)
-                isect_ids[cur] = (tile_id << 32) | dbits;
-                flatten_ids[cur] = i;
-            }
-            ++cur;
+    const int jw = j - lane;                       // the wave's first position
+    if (jw >= n) return;                           // (whole wave)
+    const bool live = j < n;
+    const int i = live ? (order ? order[j] : j) : 0;  // Gaussian
+    const int rad = live ? radii[i] : 0;
+    int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+    uint32_t dbits = 0;
+    if (rad > 0) {
+        const float2 m = reinterpret_cast<const float2 *>(means2d)[i];
+        gags_tile_aabb(m.x, m.y, rad, tile_w, tile_h, x0, x1, y0, y1);
+        dbits = (uint32_t)__float_as_int(depths[i]);
+    }
+    const int base = (jw == 0) ? 0 : cum[jw - 1];
+    const int start = live ? ((j == 0) ? 0 : cum[j - 1]) : 0x7fffffff;
+    const int jl = min(jw + 63, n - 1);
+    const int total = cum[jl] - base;
+    s_rel[w][lane] = live ? start - base : 0x7fffffff;
+    s_x0[w][lane] = x0; s_y0[w][lane] = y0; s_w[w][lane] = max(x1 - x0, 1); s_gid[w][lane] = i; s_dbits[w][lane] = dbits;
+    __builtin_amdgcn_wave_barrier();  // (LDS traffic of one wave is in order; the barrier keeps the compiler from reordering)
+    for (int t = lane; t < total; t += 64) {
+        // largest l with s_rel[l] <= t (start offsets are non-decreasing; Gaussians without tiles share their successor's)
+        int l = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1)
+            if (s_rel[w][l + step] <= t) l += step;
+        const int r = t - s_rel[w][l];
+        const int ww = s_w[w][l];
+        const int dy = r / ww;
+        const int64_t tile_id = (int64_t)(s_y0[w][l] + dy) * tile_w + (s_x0[w][l] + (r - dy * ww));
+        const int64_t pos = (int64_t)base + t;
+        if (pos < cap) {  // (capacity-sized buffers: a count above the capacity is detected by the caller afterwards)
+            isect_ids[pos] = (tile_id << 32) | (int64_t)s_dbits[w][l];
+            flatten_ids[pos] = s_gid[w][l];
         }
+    }
 }
 
 // capacity-sized buffers: entries [total, cap) become sentinels of a tile past the last one (they sort to the end and
@@ -118,6 +144,24 @@ extern "C" int gags_cumsum_i32(int n, const int32_t *in, int32_t *cum, int32_t *
     if (!in || !cum || !scratch) return GAGS_EINVAL;
     if (scratch_bytes < gags_scan_scratch_bytes(n)) return GAGS_ESCRATCH;
     gags_scan::launch<false>(n, in, cum, total, (int32_t *)scratch, st);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+extern "C" int gags_cumsum_gather_i32(int n, const int32_t *in, const int32_t *idx, int32_t *cum, int32_t *total, void *scratch,
+                                      int64_t scratch_bytes, void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (n < 0) return GAGS_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) {
+        if (total) hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(256), 0, st, 1, 0, total);
+        GAGS_CHECK_LAUNCH();
+        return GAGS_OK;
+    }
+    if (!in || !idx || !cum || !scratch || in == cum) return GAGS_EINVAL;  // (a permuted read cannot run in place)
+    if (scratch_bytes < gags_scan_scratch_bytes(n)) return GAGS_ESCRATCH;
+    gags_scan::launch<false>(n, in, cum, total, (int32_t *)scratch, st, idx);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }

@@ -41,7 +41,10 @@ __device__ __forceinline__ int block_incl_scan(int v, int &total, int *smem /*>=
     return s + off;
 }
 
+// idx (optional): the scan runs over in[idx[i]] -- a permuted view of `in` (the tile counts in depth order) without
+// a gather kernel and a permuted copy in between
 __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums(int n, const int32_t *__restrict__ in,
+                                                                 const int32_t *__restrict__ idx,
                                                                  int32_t *__restrict__ block_sums)
 {
     __shared__ int smem[4];
@@ -50,7 +53,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums(int n, const int
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         const int i = base + k * SCAN_THREADS + threadIdx.x;
-        s += (i < n) ? in[i] : 0;
+        s += (i < n) ? in[idx ? idx[i] : i] : 0;
     }
     int total;
     block_incl_scan(s, total, smem);
@@ -85,6 +88,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_spine(int nb, int32_t *__re
 
 template <bool EXCLUSIVE>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_final(int n, const int32_t *in /* may alias out */,
+                                                            const int32_t *__restrict__ idx,
                                                             const int32_t *__restrict__ block_offs,
                                                             int32_t *out)
 {
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_final(int n, const int32_t 
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         const int i = base + k;
-        v[k] = (i < n) ? in[i] : 0;
+        v[k] = (i < n) ? in[idx ? idx[i] : i] : 0;
         s += v[k];
     }
     int total;
@@ -126,12 +130,13 @@ inline int64_t scratch_bytes(int64_t n)
 
 // in-place allowed (in == out).  total may be NULL.
 template <bool EXCLUSIVE>
-inline void launch(int n, const int32_t *in, int32_t *out, int32_t *total, int32_t *block_scratch, hipStream_t st)
+inline void launch(int n, const int32_t *in, int32_t *out, int32_t *total, int32_t *block_scratch, hipStream_t st,
+                   const int32_t *idx = nullptr)
 {
     const int nb = (n + SCAN_TILE - 1) / SCAN_TILE;
-    hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(SCAN_THREADS), 0, st, n, in, block_scratch);
+    hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(SCAN_THREADS), 0, st, n, in, idx, block_scratch);
     hipLaunchKernelGGL(scan_spine, dim3(1), dim3(SCAN_THREADS), 0, st, nb, block_scratch, total);
-    hipLaunchKernelGGL(scan_final<EXCLUSIVE>, dim3(nb), dim3(SCAN_THREADS), 0, st, n, in, block_scratch, out);
+    hipLaunchKernelGGL(scan_final<EXCLUSIVE>, dim3(nb), dim3(SCAN_THREADS), 0, st, n, in, idx, block_scratch, out);
 }
 
 }  // namespace gags_scan

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(int64_t n, int shift, c
         const int64_t i = wbase + k * 64 + lane;
         const bool ok = i < n;
         key[k] = ok ? keys_in[i] : (K)~(K)0;
-        val[k] = ok ? vals_in[i] : 0;
+        val[k] = ok ? (vals_in ? vals_in[i] : (int32_t)i) : 0;  // vals_in == NULL: the values are the input positions (an argsort)
         const uint32_t dgt = ok ? (uint32_t)((key[k] >> shift) & 0xff) : 0xffffffffu;
         // match-any over the wave: mask of lanes holding the same digit (8 ballots)
         uint64_t m = __ballot(ok);
@@ -85,7 +85,10 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(int64_t n, int shift, c
         rank[k] = prev + before;
     }
     __syncthreads();
-    // per-digit exclusive scan across the 4 waves -> base of (wave, digit) inside the digit run
+    // per-digit exclusive scan across the 4 waves -> base of (wave, digit) inside the digit run; and the digit runs' starts
+    // inside the block (exclusive scan of the block's digit totals over the 256 digits)
+    __shared__ int scan_tmp[4];
+    __shared__ uint32_t dstart[RS_RADIX];
     {
         const int d = threadIdx.x;
         uint32_t run = 0;
@@ -95,16 +98,38 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(int64_t n, int shift, c
             cnt[k][d] = run;
             run += c;
         }
+        int total;
+        const int incl = gags_scan::block_incl_scan((int)run, total, scan_tmp);  // (two barriers inside)
+        dstart[d] = (uint32_t)incl - run;
     }
     __syncthreads();
+    // Stage the block's pairs in LDS in their sorted order, then write them out with consecutive threads on consecutive
+    // addresses of a digit run.  (Written straight from the ranking registers, neighbouring lanes hold keys of different
+    // digits: every 8- / 4-byte store was its own partial cache line -- rs_scatter<u64> ran at 1.8 TB/s.)
+    __shared__ K keys_l[RS_TILE];
+    __shared__ int32_t vals_l[RS_TILE];
 #pragma unroll
     for (int k = 0; k < RS_ITEMS; ++k) {
         const int64_t i = wbase + k * 64 + lane;
         if (i < n) {
             const uint32_t dgt = (uint32_t)((key[k] >> shift) & 0xff);
-            const uint32_t pos = gbase[dgt] + cnt[w][dgt] + rank[k];
-            keys_out[pos] = key[k];
-            vals_out[pos] = val[k];
+            const uint32_t lp = dstart[dgt] + cnt[w][dgt] + rank[k];
+            keys_l[lp] = key[k];
+            vals_l[lp] = val[k];
+        }
+    }
+    __syncthreads();
+    const int64_t bbase = (int64_t)blockIdx.x * RS_TILE;
+    const int nvalid = (int)((n - bbase) < (int64_t)RS_TILE ? (n - bbase) : (int64_t)RS_TILE);
+#pragma unroll
+    for (int k = 0; k < RS_ITEMS; ++k) {
+        const int i = k * RS_THREADS + threadIdx.x;
+        if (i < nvalid) {
+            const K kk = keys_l[i];
+            const uint32_t dgt = (uint32_t)((kk >> shift) & 0xff);
+            const uint32_t pos = gbase[dgt] + ((uint32_t)i - dstart[dgt]);
+            keys_out[pos] = kk;
+            vals_out[pos] = vals_l[i];
         }
     }
 }
@@ -128,7 +153,7 @@ int sort_pairs_t(int64_t n, int first_bit, int nbits, const K *keys_in, const in
     if (n == 0) return GAGS_OK;
     if (n < 0 || n >= (1ll << 31) || nbits <= 0 || first_bit < 0 || first_bit + nbits > (int)(8 * sizeof(K)))
         return GAGS_EINVAL;
-    if (!keys_in || !vals_in || !keys_out || !vals_out || !scratch) return GAGS_EINVAL;
+    if (!keys_in || !keys_out || !vals_out || !scratch) return GAGS_EINVAL;  // (vals_in may be NULL: argsort)
     if (scratch_bytes < sort_scratch_bytes_t<K>(n)) return GAGS_ESCRATCH;
     const int nblocks = (int)((n + RS_TILE - 1) / RS_TILE);
     const int64_t keys_b = ((n * (int64_t)sizeof(K) + 255) / 256) * 256, vals_b = ((n * 4 + 255) / 256) * 256;
@@ -182,11 +207,6 @@ extern "C" int gags_sort_pairs(int64_t n, int tile_bits, int depth_sorted, const
 }
 
 namespace {
-__global__ __launch_bounds__(256) void iota_kernel(int n, int32_t *__restrict__ out)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = i;
-}
 __global__ __launch_bounds__(256) void gather_i32_kernel(int n, const int32_t *__restrict__ idx,
                                                          const int32_t *__restrict__ src, int32_t *__restrict__ dst)
 {
@@ -211,19 +231,19 @@ extern "C" int gags_depth_order(int n, const float *depths, const int32_t *tiles
     GAGS_CLEAR_ERR();
     if (n < 0) return GAGS_EINVAL;
     if (n == 0) return GAGS_OK;
-    if (!depths || !tiles_per_gauss || !order || !tiles_ordered || !scratch) return GAGS_EINVAL;
+    if (!depths || !order || !scratch || (tiles_ordered && !tiles_per_gauss)) return GAGS_EINVAL;
     if (scratch_bytes < gags_depth_order_scratch_bytes(n)) return GAGS_ESCRATCH;
     hipStream_t st = (hipStream_t)stream;
     char *sb = (char *)scratch;
-    int32_t *iota = (int32_t *)sb;
     uint32_t *keys_sorted = (uint32_t *)(sb + al256s((int64_t)n * 4));
     void *sort_scratch = sb + 2 * al256s((int64_t)n * 4);
-    hipLaunchKernelGGL(iota_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, iota);
-    const int rc = sort_pairs_t<uint32_t>(n, 0, 32, reinterpret_cast<const uint32_t *>(depths), iota, keys_sorted, order,
+    // argsort: the first pass numbers the inputs itself (no iota kernel, no index array read)
+    const int rc = sort_pairs_t<uint32_t>(n, 0, 32, reinterpret_cast<const uint32_t *>(depths), nullptr, keys_sorted, order,
                                           sort_scratch, sort_scratch_bytes_t<uint32_t>(n), st);
     if (rc != GAGS_OK) return rc;
-    hipLaunchKernelGGL(gather_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, order, tiles_per_gauss,
-                       tiles_ordered);
+    if (tiles_ordered)  // (optional: gags_cumsum_gather_i32 scans tiles_per_gauss[order[.]] without this copy)
+        hipLaunchKernelGGL(gather_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, order, tiles_per_gauss,
+                           tiles_ordered);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }

@@ -271,14 +271,14 @@ def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height, conics=
     # Gaussians in depth order first (N keys), intersections emitted in that order: the per-intersection sort
     # (n_isects ~ 5 N keys) then only groups by tile -- 2 radix passes instead of 6, same sorted result
     order = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-    tiles_ord = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     dsb = lib.gags_depth_order_scratch_bytes(n)
     dscratch = torch.empty(dsb, dtype=torch.uint8, device=dev)
-    check(lib.gags_depth_order(n, ptr(depths), ptr(tiles_per_gauss), ptr(order), ptr(tiles_ord), ptr(dscratch), dsb, st),
-          "gags_depth_order")
+    check(lib.gags_depth_order(n, ptr(depths), None, ptr(order), None, ptr(dscratch), dsb, st), "gags_depth_order")
     sb = lib.gags_scan_scratch_bytes(n)
     scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
-    check(lib.gags_cumsum_i32(n, ptr(tiles_ord), ptr(cum), ptr(total), ptr(scratch), sb, st), "gags_cumsum_i32")
+    # prefix sum of the tile counts IN DEPTH ORDER, read through `order` (no permuted copy)
+    check(lib.gags_cumsum_gather_i32(n, ptr(tiles_per_gauss), ptr(order), ptr(cum), ptr(total), ptr(scratch), sb, st),
+          "gags_cumsum_gather_i32")
     if cap is None:
         host = ctypes.c_int32(0)
         check(lib.gags_read_i32(ptr(total), ctypes.byref(host), st), "gags_read_i32")

@@ -82,12 +82,18 @@ int64_t gags_scan_scratch_bytes(int n);
 int gags_cumsum_i32(int n, const int32_t *in, int32_t *cum, int32_t *total,
                     void *scratch, int64_t scratch_bytes, void *stream);
 
+/* K5 over a permuted view: cum[i] = sum_{j <= i} in[idx[j]] (the tile counts in depth order, idx = gags_depth_order's
+ * `order`): no gather kernel, no permuted copy.  in != cum. */
+int gags_cumsum_gather_i32(int n, const int32_t *in, const int32_t *idx, int32_t *cum, int32_t *total,
+                           void *scratch, int64_t scratch_bytes, void *stream);
+
 /* the single device->host readback of the path (n_isects); synchronizes `stream`. */
 int gags_read_i32(const int32_t *src, int32_t *dst_host, void *stream);
 
-/* K7a (optional, faster binning): order[N] = stable argsort of the Gaussians by depth bits, and
- * tiles_ordered[i] = tiles_per_gauss[order[i]] (prefix-sum THAT, emit in that order, and K7 only has to
- * group by tile).  scratch: gags_depth_order_scratch_bytes(n) bytes. */
+/* K7a (optional, faster binning): order[N] = stable argsort of the Gaussians by depth bits, and -- when tiles_ordered is
+ * not NULL -- tiles_ordered[i] = tiles_per_gauss[order[i]] (prefix-sum THAT, or call gags_cumsum_gather_i32 on
+ * tiles_per_gauss and order; emit in that order, and K7 only has to group by tile).
+ * scratch: gags_depth_order_scratch_bytes(n) bytes. */
 int64_t gags_depth_order_scratch_bytes(int n);
 int gags_depth_order(int n, const float *depths, const int32_t *tiles_per_gauss, int32_t *order,
                      int32_t *tiles_ordered, void *scratch, int64_t scratch_bytes, void *stream);
