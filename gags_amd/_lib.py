@@ -28,7 +28,7 @@ SIGNATURES = {
     "gags_project_fwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _f32,
                                 _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_project_fwd_raw": (_i32, [_i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _f32,
-                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_project_bwd_raw": (_i32, [_i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp, _vp, _vp]),
     "gags_scan_scratch_bytes": (_i64, [_i32]),

@@ -4,6 +4,7 @@
 // of the numerical contract (bit-exact radii / tile counts against the oracle), so this
 // translation unit must be built with -ffp-contract=off.
 #include "common.h"
+#include "raster_mfma_common.h"
 
 namespace {
 
@@ -45,16 +46,18 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     int32_t *__restrict__ radii, float *__restrict__ means2d, float *__restrict__ depths,
     float *__restrict__ conics, int32_t *__restrict__ tiles_per_gauss,
     const float *__restrict__ opacity_logits, float scaling_modifier, float *__restrict__ opacities_out,
-    float *__restrict__ quats_out, float *__restrict__ scales_out)
+    float *__restrict__ quats_out, float *__restrict__ scales_out, gags_mfma::GRec *__restrict__ grec_out)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float4 q = reinterpret_cast<const float4 *>(quats)[i];
     float s0 = scales[3 * i], s1 = scales[3 * i + 1], s2 = scales[3 * i + 2];
+    float opac = 0.f;
     if constexpr (RAW) {
         q = gags_act_rotation(q);
         s0 = gags_act_scaling(s0, scaling_modifier); s1 = gags_act_scaling(s1, scaling_modifier); s2 = gags_act_scaling(s2, scaling_modifier);
-        opacities_out[i] = gags_act_opacity(opacity_logits[i]);
+        opac = gags_act_opacity(opacity_logits[i]);
+        opacities_out[i] = opac;
         if (quats_out) reinterpret_cast<float4 *>(quats_out)[i] = q;
         if (scales_out) { scales_out[3 * i] = s0; scales_out[3 * i + 1] = s1; scales_out[3 * i + 2] = s2; }
     }
@@ -150,6 +153,11 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     depths[i] = o_z;
     conics[3 * i] = o_a; conics[3 * i + 1] = o_b; conics[3 * i + 2] = o_c;
     tiles_per_gauss[i] = o_tiles;
+    // K8b on the way (the activated opacity is at hand here): the per-Gaussian record of the matrix-core raster kernels
+    // (gags_pack_isects with packed = NULL writes the same bytes from the arrays above)
+    if constexpr (RAW) {
+        if (grec_out && o_rad > 0) grec_out[i] = gags_mfma::make_grec_from(o_mx, o_my, o_a, o_b, o_c, opac);
+    }
 }
 
 }  // namespace
@@ -169,7 +177,7 @@ extern "C" int gags_project_fwd(int n, const float *means, const float *quats, c
     const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
     hipLaunchKernelGGL(project_fwd_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, means,
                        quats, scales, viewmat, K, width, height, eps2d, near_plane, far_plane, radius_clip,
-                       tile_w, tile_h, radii, means2d, depths, conics, tiles_per_gauss, nullptr, 1.0f, nullptr, nullptr, nullptr);
+                       tile_w, tile_h, radii, means2d, depths, conics, tiles_per_gauss, nullptr, 1.0f, nullptr, nullptr, nullptr, nullptr);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }
@@ -179,7 +187,7 @@ extern "C" int gags_project_fwd_raw(int n, const float *means, const float *rota
                                     int width, int height, float eps2d, float near_plane, float far_plane,
                                     float radius_clip, int32_t *radii, float *means2d, float *depths, float *conics,
                                     int32_t *tiles_per_gauss, float *opacities, float *quats_act, float *scales_act,
-                                    void *stream)
+                                    void *grec, void *stream)
 {
     GAGS_CLEAR_ERR();
     if (n < 0 || width <= 0 || height <= 0) return GAGS_EINVAL;
@@ -191,7 +199,7 @@ extern "C" int gags_project_fwd_raw(int n, const float *means, const float *rota
     hipLaunchKernelGGL(project_fwd_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, means,
                        rotation, scaling_log, viewmat, K, width, height, eps2d, near_plane, far_plane, radius_clip,
                        tile_w, tile_h, radii, means2d, depths, conics, tiles_per_gauss, opacity_logit, scaling_modifier,
-                       opacities, quats_act, scales_act);
+                       opacities, quats_act, scales_act, reinterpret_cast<gags_mfma::GRec *>(grec));
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }

@@ -33,14 +33,12 @@ struct HRec {
 constexpr int RING = 128;      // per-wave ring of compacted hits (4 KB; at most 5 + 64 are ever queued)
 constexpr int WT_STRIDE = 36;  // dwords per slot row of an LDS weight tile (conflict-free b32 write / b128 read)
 
-__device__ __forceinline__ GRec make_grec(const float *__restrict__ means2d, const float *__restrict__ conics,
-                                          const float *__restrict__ opacities, int g)
+__device__ __forceinline__ GRec make_grec_from(float x, float y, float ca, float cb, float cc, float o)
 {
     GRec r;
-    const float2 m = reinterpret_cast<const float2 *>(means2d)[g];
-    r.x = m.x; r.y = m.y;
-    r.a = conics[3 * g]; r.b = conics[3 * g + 1]; r.c = conics[3 * g + 2];
-    r.o = opacities[g];
+    r.x = x; r.y = y;
+    r.a = ca; r.b = cb; r.c = cc;
+    r.o = o;
     // conservative half-extent of {alpha >= 1/255}: sigma <= tau = ln(255 o); |dx| <= sqrt(2 tau Sxx)
     const float det = r.a * r.c - r.b * r.b;
     const float tau = __logf(255.0f * r.o) + 0.02f;
@@ -54,6 +52,13 @@ __device__ __forceinline__ GRec make_grec(const float *__restrict__ means2d, con
         r.ey = sqrtf(s * r.a) * 1.001f + 0.01f;
     }
     return r;
+}
+
+__device__ __forceinline__ GRec make_grec(const float *__restrict__ means2d, const float *__restrict__ conics,
+                                          const float *__restrict__ opacities, int g)
+{
+    const float2 m = reinterpret_cast<const float2 *>(means2d)[g];
+    return make_grec_from(m.x, m.y, conics[3 * g], conics[3 * g + 1], conics[3 * g + 2], opacities[g]);
 }
 
 // Per-pixel compositing state, replicated in both half-waves (lane p and lane p+32).

@@ -173,7 +173,7 @@ class _ProjectRaw(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means, rotation, scaling_log, opacity_logit, viewmat, K, width, height, eps2d, near, far, radius_clip,
-                scaling_modifier):
+                scaling_modifier, want_records):
         lib = _lib.load()
         means, rotation, scaling_log, viewmat, K = _c(means), _c(rotation), _c(scaling_log), _c(viewmat), _c(K)
         logit = _c(opacity_logit.reshape(-1))
@@ -185,18 +185,20 @@ class _ProjectRaw(torch.autograd.Function):
         conics = torch.empty(n, 3, dtype=torch.float32, device=dev)
         tiles = torch.empty(n, dtype=torch.int32, device=dev)
         opac = torch.empty(n, dtype=torch.float32, device=dev)
+        # the per-Gaussian records of the matrix-core raster kernels (K8b), written on the way: no record kernel in the binning
+        grec = torch.empty(max(n, 1), 8, dtype=torch.float32, device=dev) if want_records else torch.empty(0, device=dev)
         with profiler.stage("project_fwd"):
             check(lib.gags_project_fwd_raw(n, ptr(means), ptr(rotation), ptr(scaling_log), ptr(logit), scaling_modifier,
                                            ptr(viewmat), ptr(K), width, height, eps2d, near, far, radius_clip, ptr(radii),
                                            ptr(means2d), ptr(depths), ptr(conics), ptr(tiles), ptr(opac), None, None,
-                                           _stream()), "gags_project_fwd_raw")
+                                           ptr(grec) if want_records else None, _stream()), "gags_project_fwd_raw")
         ctx.save_for_backward(means, rotation, scaling_log, logit, viewmat, K, radii)
         ctx.cfg = (width, height, eps2d, scaling_modifier, tuple(opacity_logit.shape))
-        ctx.mark_non_differentiable(radii, tiles)
-        return radii, means2d, depths, conics, tiles, opac
+        ctx.mark_non_differentiable(radii, tiles, grec)
+        return radii, means2d, depths, conics, tiles, opac, grec
 
     @staticmethod
-    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, _v_tiles, v_opac):
+    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, _v_tiles, v_opac, _v_grec):
         lib = _lib.load()
         means, rotation, scaling_log, logit, viewmat, K, radii = ctx.saved_tensors
         width, height, eps2d, modifier, oshape = ctx.cfg
@@ -215,7 +217,7 @@ class _ProjectRaw(torch.autograd.Function):
                                        ptr(v_conics), ptr(v_opac), ptr(v_means), ptr(v_rot), ptr(v_scal), ptr(v_logit),
                                        _stream()), "gags_project_bwd_raw")
         return (v_means, v_rot, v_scal, None if v_logit is None else v_logit.reshape(oshape), None, None, None, None, None,
-                None, None, None, None)
+                None, None, None, None, None)
 
 
 class _SH(torch.autograd.Function):
@@ -253,7 +255,7 @@ class _SH(torch.autograd.Function):
         return v_coeffs, v_means, None, None, None
 
 
-def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height, conics=None, opacities=None, cap=None):
+def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height, conics=None, opacities=None, cap=None, records=None):
     """K5-K8 (+K8b) on device.  Returns (isect_ids sorted int64, flatten_ids sorted int32, isect_offsets [th,tw] int32 -- a
     view of tile_h * tile_w + 1 entries whose last one is the count --, n_isects, packed [N,8] per-Gaussian records or None).
     cap None: one host readback (n_isects), as in gsplat; the id arrays have exactly n_isects entries.
@@ -301,8 +303,8 @@ def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height, conics=
         check(lib.gags_sort_pairs(size, tile_bits, 1, ptr(ids), ptr(flat), ptr(ids_s), ptr(flat_s), ptr(sscratch),
                                   ssb, st), "gags_sort_pairs")
     check(lib.gags_tile_offsets(size, ptr(ids_s), n_tiles, ptr(offsets), st), "gags_tile_offsets")
-    packed = None
-    if conics is not None:
+    packed = records  # (gags_project_fwd_raw already wrote the per-Gaussian table)
+    if conics is not None and packed is None:
         # one 32-byte record per GAUSSIAN; the raster kernels gather it through flatten_ids themselves
         # (GAGS_RECS_BY_GAUSSIAN): no per-intersection copy of the records, no gather kernel
         packed = torch.empty(max(n, 1), 8, dtype=torch.float32, device=dev)
@@ -608,10 +610,17 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
     width, height = int(width), int(height)
     viewmat, K = viewmats[0], Ks[0]
 
+    records = None
     if raw_params:
-        radii, means2d, depths, conics, tiles, opacities = _ProjectRaw.apply(
+        # (the record table is only read by the matrix-core path: D >= 16 after the depth channel of RGB+D / RGB+ED is appended)
+        dfinal = (3 if sh_degree is not None else colors.shape[-1]) + (1 if render_mode in ("RGB+D", "RGB+ED") else 0)
+        if render_mode in ("D", "ED"):
+            dfinal = 1
+        radii, means2d, depths, conics, tiles, opacities, records = _ProjectRaw.apply(
             means, quats, scales, opacities, viewmat, K, width, height, float(eps2d), float(near_plane), float(far_plane),
-            float(radius_clip), float(scaling_modifier))
+            float(radius_clip), float(scaling_modifier), bool(_mfma_width(dfinal) and n > 0))
+        if records.numel() == 0:
+            records = None
     else:
         radii, means2d, depths, conics, tiles = _Project.apply(means, quats, scales, viewmat, K, width, height,
                                                                float(eps2d), float(near_plane), float(far_plane),
@@ -664,7 +673,7 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
     def run(cap):
         with torch.no_grad(), profiler.stage("binning"):
             b = tile_binning(means2d, radii, depths, tiles, width, height, conics if wide else None,
-                             _c(opacities) if wide else None, cap)
+                             _c(opacities) if wide else None, cap, records=records if wide else None)
         # any width in ONE rasterization: 513 = 512 CLIP channels + 1 (BASELINE.json configs[4] "512-d feat + granularity")
         # is four 128-channel slices and one lane of a narrow slice on the same matrix-core kernels, into one output tensor
         r = _Rasterize.apply(means2d, conics, cols, opacities, bg, b[2], b[1], b[4], width, height, int(raster_flags), prezero)

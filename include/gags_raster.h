@@ -271,13 +271,14 @@ int gags_raster_stats(int width, int height, const float *means2d, const float *
  * holds them; the kernel applies the getters of :116-139 -- exp (* scaling_modifier, gaussian_renderer/__init__.py:41),
  * F.normalize, sigmoid -- bit for bit as torch evaluates them (tools/micro/actprobe.py), then projects as gags_project_fwd.
  * Extra outputs: opacities[N] (activated: what the raster kernels read); quats_act[N,4] / scales_act[N,3] (activated; NULL
- * = not wanted).  The backward takes the gradients back to the stored parameters, v_opacities[N] (from the rasterizer;
+ * = not wanted); grec (N * GAGS_PACKED_BYTES bytes, or NULL): the per-Gaussian record table of K8b for every Gaussian with
+ * radii > 0 -- the bytes gags_pack_isects(packed = NULL) would write -- so that the binning needs no record kernel.  The backward takes the gradients back to the stored parameters, v_opacities[N] (from the rasterizer;
  * NULL = zeros) included; v_opacity_logit may be NULL. */
 int gags_project_fwd_raw(int n, const float *means, const float *rotation, const float *scaling_log,
                          const float *opacity_logit, float scaling_modifier, const float *viewmat, const float *K,
                          int width, int height, float eps2d, float near_plane, float far_plane, float radius_clip,
                          int32_t *radii, float *means2d, float *depths, float *conics, int32_t *tiles_per_gauss,
-                         float *opacities, float *quats_act, float *scales_act, void *stream);
+                         float *opacities, float *quats_act, float *scales_act, void *grec, void *stream);
 int gags_project_bwd_raw(int n, const float *means, const float *rotation, const float *scaling_log,
                          const float *opacity_logit, float scaling_modifier, const float *viewmat, const float *K,
                          int width, int height, float eps2d, const int32_t *radii, const float *v_means2d,

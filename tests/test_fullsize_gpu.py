@@ -179,6 +179,48 @@ def test_c3_heavy_splats_forward_and_gradient(oracle):
     assert st["n_isects"] > 10 * st["visible"] > 0
 
 
+def test_c3_heavy_splats_at_the_full_width_on_a_tile_sample(oracle):
+    """C3H as bench.py's `heavy_workload` runs it: 1.5 M Gaussians, 1080p, D = 512, SURVEY 8d's literal splat scale (63 M
+    intersections).  The oracle's compositing is bounded to every 16th tile (510 of 8160; projection, binning and sorting
+    are checked in full): the render of those tiles bit-exact, and -- with a cotangent that is zero outside them, so
+    that the gradient is exactly the sampled tiles' contribution -- the colours gradient within GRAD_TOL."""
+    from gags_amd import synthetic as syn
+    from gags_amd.rasterization import rasterization
+    c = syn.CONFIGS["C3"]
+    n, w, h, d, step = c["n"], c["width"], c["height"], 512, 16
+    dev = torch.device("cuda", 0)
+    t, vm, K, _, _ = _activated(n, d, w, h, 0, syn.SCALE0_SURVEY)
+    cols = t["colors"].clone().requires_grad_(True)
+    bg = torch.full((d,), 0.25, device=dev)
+    out, alphas, info = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], cols, vm[None], K[None], w, h,
+                                      backgrounds=bg[None])
+    hv = {k: v.cpu().numpy() for k, v in t.items()}
+    o_out, o_alpha, oi = oracle.rasterization(hv["means"], hv["quats"], hv["scales"], hv["opacities"], hv["colors"],
+                                              vm.cpu().numpy(), K.cpu().numpy(), bg.cpu().numpy(), w, h, tile_begin=0, tile_step=step)
+    assert info["n_isects"] == oi["n_isects"] > 10 * int((oi["radii"] > 0).sum())
+    np.testing.assert_array_equal(info["radii"][0].cpu().numpy(), oi["radii"])
+    np.testing.assert_array_equal(info["isect_ids"].cpu().numpy(), oi["isect_ids"])
+    np.testing.assert_array_equal(info["flatten_ids"].cpu().numpy(), oi["flatten_ids"])
+    np.testing.assert_array_equal(info["isect_offsets"][0].cpu().numpy(), oi["isect_offsets"])
+    tw, th = (w + 15) // 16, (h + 15) // 16
+    sampled = (torch.arange(th * tw, device=dev) % step == 0).view(th, tw)
+    pix = sampled.repeat_interleave(16, 0).repeat_interleave(16, 1)[:h, :w]   # [H,W] bool: pixels of the sampled tiles
+    assert int(pix.sum()) > 100_000
+    ph = pix.cpu().numpy()
+    np.testing.assert_array_equal(alphas[0, ..., 0].detach().cpu().numpy()[ph], o_alpha[ph])
+    np.testing.assert_array_equal(info["last_ids"].cpu().numpy()[ph], oi["last_ids"][ph])
+    assert torch.equal(out[0].detach()[pix], torch.from_numpy(o_out[ph]).to(dev)), "render differs on the sampled tiles"
+    del o_out
+    gen = torch.Generator(device=dev).manual_seed(100)
+    v_out = torch.randn(h, w, d, device=dev, generator=gen) * pix[..., None]
+    (out[0] * v_out).sum().backward()
+    del out
+    o_vf = oracle.raster_bwd_colors_fwdorder(oi["means2d"], oi["conics"], hv["opacities"], d, w, h, oi["isect_offsets"],
+                                             oi["flatten_ids"], v_out.cpu().numpy(), n, tile_begin=0, tile_step=step)
+    e = _big_rel_l2(cols.grad, o_vf)
+    assert e <= GRAD_TOL, e
+
+
 @pytest.mark.parametrize("d", [512, 513])
 def test_c5_as_stated_fp16_table(oracle, d):
     """BASELINE.json configs[4] as it is stated: 4 M Gaussians, 1080p, 512-d features (+ the granularity channel:

@@ -929,10 +929,17 @@ def test_raw_parameter_projection_is_bit_identical_to_the_getters(oracle, modifi
     q_act, s_act, o_act = torch.nn.functional.normalize(rot), torch.exp(slog) * modifier, torch.sigmoid(logit)
     cfg = (w, h, 0.3, 0.01, 1e10, 0.0)
     want = _Project.apply(xyz, q_act, s_act, vm, Kd, *cfg)
-    got = _ProjectRaw.apply(xyz, rot, slog, logit, vm, Kd, *cfg, modifier)
+    got = _ProjectRaw.apply(xyz, rot, slog, logit, vm, Kd, *cfg, modifier, True)
     for a, b, name in zip(got[:5], want, ("radii", "means2d", "depths", "conics", "tiles_per_gauss")):
         assert torch.equal(a, b), name
     assert torch.equal(got[5], o_act.reshape(-1))
+    # the per-Gaussian record table written on the way == what gags_pack_isects builds from the arrays (visible Gaussians)
+    rec = torch.zeros(n, 8, device="cuda")
+    _lib.check(_lib.load().gags_pack_isects(n, 1, _lib.ptr(torch.zeros(1, dtype=torch.int32, device="cuda")), _lib.ptr(want[1]),
+                                            _lib.ptr(want[3]), _lib.ptr(o_act.reshape(-1).contiguous()), _lib.ptr(want[0]),
+                                            _lib.ptr(rec), None, None), "gags_pack_isects")
+    vis = want[0] > 0
+    assert torch.equal(got[6][vis], rec[vis])
     assert int((want[0] > 0).sum()) > n // 2
     o_radii, o_m2d, o_depths, o_conics = oracle.project_fwd(xyz.cpu().numpy(), q_act.cpu().numpy(), s_act.cpu().numpy(),
                                                             vm.cpu().numpy(), K, w, h)
@@ -946,7 +953,7 @@ def test_raw_parameter_projection_is_bit_identical_to_the_getters(oracle, modifi
             torch.empty(n, 4, device="cuda"), torch.empty(n, 3, device="cuda")]
     _lib.check(lib.gags_project_fwd_raw(n, _lib.ptr(xyz), _lib.ptr(rot), _lib.ptr(slog), _lib.ptr(logit.reshape(-1).contiguous()),
                                         modifier, _lib.ptr(vm.contiguous()), _lib.ptr(Kd), w, h, 0.3, 0.01, 1e10, 0.0,
-                                        *[_lib.ptr(t) for t in outs], None), "gags_project_fwd_raw")
+                                        *[_lib.ptr(t) for t in outs], None, None), "gags_project_fwd_raw")
     assert torch.equal(outs[6], q_act) and torch.equal(outs[7], s_act)
 
 

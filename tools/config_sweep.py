@@ -20,7 +20,7 @@ dev = torch.device("cuda", 0)
 def run(name, n, w, h, d, half=False, steps=8, flags=0, full_grad=False):
     pc = syn.make_model(n, d, w, h, seed=0, device=dev, gen_device=dev)
     pc.training_setup()
-    pc.cache_activations(True)  # geometry frozen for the whole run (GAD stage, train.py:62-75): getters evaluated once
+    # (render() hands the stored parameters to the projection kernel: the getters run inside it, every view)
     geo = [pc._xyz, pc._scaling, pc._rotation, pc._opacity]
     if full_grad:  # joint training: every geometry parameter gets its gradient too (SURVEY A9 in full)
         for q in geo:
