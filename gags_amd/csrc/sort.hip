@@ -2,9 +2,10 @@
 //
 // Hand-written for gfx950 wave64 (no library): 8-bit digits, three kernels per pass
 //   1. histogram   : per-block digit counts (LDS atomics), written digit-major
-//   2. scan        : device-wide exclusive scan over [digit][block] -> global scatter bases
+//   2. row scan    : one workgroup per digit: exclusive prefix of its row over the blocks + the row total
 //   3. scatter     : each block re-reads its tile, ranks keys STABLY (wave-level match via
-//                    per-digit ballots, wave-ordered LDS counters) and writes pairs out
+//                    per-digit ballots, wave-ordered LDS counters), stages the pairs in LDS in sorted order and writes
+//                    whole digit runs out (digit bases: an exclusive scan of the 256 row totals in the prologue)
 // Traffic per pass: read 12 B + write 12 B per pair + one extra 8 B key read for the
 // histogram = 32 B/pair; 45-bit keys at 1080p (13 tile bits) need 6 passes.
 // HBM-bound integer work: nothing here is reshaped into a GEMM.
@@ -36,6 +37,37 @@ __global__ __launch_bounds__(RS_THREADS) void rs_histogram(int64_t n, int shift,
     hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
+// Scan of the [digit][block] histogram, one workgroup per DIGIT: row d becomes its own exclusive prefix over the blocks
+// and totals[d] the row's sum; the scatter kernel adds the digits' bases (an exclusive scan of the 256 totals, done by
+// each workgroup in its prologue).  One fully parallel launch instead of the generic three-kernel scan with its
+// single-workgroup spine over the flattened matrix.
+__global__ __launch_bounds__(RS_THREADS) void rs_rowscan(int nblocks, uint32_t *__restrict__ hist, uint32_t *__restrict__ totals)
+{
+    __shared__ int smem[4];
+    uint32_t *row = hist + (size_t)blockIdx.x * nblocks;
+    uint32_t carry = 0;
+    for (int base = 0; base < nblocks; base += RS_TILE) {
+        const int i0 = base + threadIdx.x * RS_ITEMS;
+        uint32_t v[RS_ITEMS];
+        uint32_t s = 0;
+#pragma unroll
+        for (int k = 0; k < RS_ITEMS; ++k) {
+            v[k] = (i0 + k < nblocks) ? row[i0 + k] : 0u;
+            s += v[k];
+        }
+        int total;
+        const int incl = gags_scan::block_incl_scan((int)s, total, smem);
+        uint32_t run = carry + (uint32_t)incl - s;
+#pragma unroll
+        for (int k = 0; k < RS_ITEMS; ++k) {
+            if (i0 + k < nblocks) row[i0 + k] = run;
+            run += v[k];
+        }
+        carry += (uint32_t)total;
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
 // Stable scatter.  Items are laid out blocked-by-wave so that (wave, item, lane) order is the
 // input order: wave w owns [w*512, (w+1)*512) of the tile, item k covers 64 consecutive keys.
 template <typename K>
@@ -43,15 +75,24 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(int64_t n, int shift, c
                                                          const int32_t *__restrict__ vals_in,
                                                          K *__restrict__ keys_out,
                                                          int32_t *__restrict__ vals_out,
-                                                         const uint32_t *__restrict__ hist, int nblocks)
+                                                         const uint32_t *__restrict__ hist, int nblocks,
+                                                         const uint32_t *__restrict__ totals)
 {
     __shared__ uint32_t cnt_s[4][RS_RADIX];  // per-wave digit counts, then per-wave bases
     volatile uint32_t(*cnt)[RS_RADIX] = cnt_s;
     __shared__ uint32_t gbase[RS_RADIX];    // global base of each digit for this block
+    __shared__ int scan_tmp[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 4; ++k) cnt[k][threadIdx.x] = 0;
-    gbase[threadIdx.x] = hist[(size_t)threadIdx.x * nblocks + blockIdx.x];
+    {
+        // base of digit d = keys with a smaller digit (exclusive scan of the 256 row totals) + this digit's keys in
+        // earlier blocks (rs_rowscan)
+        const uint32_t tot = totals[threadIdx.x];
+        int all;
+        const int incl = gags_scan::block_incl_scan((int)tot, all, scan_tmp);
+        gbase[threadIdx.x] = ((uint32_t)incl - tot) + hist[(size_t)threadIdx.x * nblocks + blockIdx.x];
+    }
     __syncthreads();
 
     const int64_t wbase = (int64_t)blockIdx.x * RS_TILE + (int64_t)w * (64 * RS_ITEMS);
@@ -87,7 +128,6 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter(int64_t n, int shift, c
     __syncthreads();
     // per-digit exclusive scan across the 4 waves -> base of (wave, digit) inside the digit run; and the digit runs' starts
     // inside the block (exclusive scan of the block's digit totals over the 256 digits)
-    __shared__ int scan_tmp[4];
     __shared__ uint32_t dstart[RS_RADIX];
     {
         const int d = threadIdx.x;
@@ -141,7 +181,7 @@ int64_t sort_scratch_bytes_t(int64_t n_in)
     const int64_t nblocks = (n + RS_TILE - 1) / RS_TILE;
     const int64_t keys = ((n * (int64_t)sizeof(K) + 255) / 256) * 256, vals = ((n * 4 + 255) / 256) * 256;
     const int64_t hist = ((nblocks * RS_RADIX * 4 + 255) / 256) * 256;
-    return keys + vals + hist + gags_scan::scratch_bytes(nblocks * RS_RADIX);
+    return keys + vals + hist + RS_RADIX * 4;  // + the 256 digit totals
 }
 
 // stable LSD sort of (key, value) pairs on key bits [first_bit, first_bit + nbits); ping-pongs through
@@ -161,7 +201,7 @@ int sort_pairs_t(int64_t n, int first_bit, int nbits, const K *keys_in, const in
     int32_t *vtmp = (int32_t *)((char *)scratch + keys_b);
     uint32_t *hist = (uint32_t *)((char *)scratch + keys_b + vals_b);
     const int64_t hist_b = (((int64_t)nblocks * RS_RADIX * 4 + 255) / 256) * 256;
-    int32_t *scan_tmp = (int32_t *)((char *)scratch + keys_b + vals_b + hist_b);
+    uint32_t *totals = (uint32_t *)((char *)scratch + keys_b + vals_b + hist_b);
     const int passes = (nbits + 7) / 8;
     const K *src_k = keys_in;
     const int32_t *src_v = vals_in;
@@ -170,9 +210,9 @@ int sort_pairs_t(int64_t n, int first_bit, int nbits, const K *keys_in, const in
         K *dst_k = to_out ? keys_out : ktmp;
         int32_t *dst_v = to_out ? vals_out : vtmp;
         hipLaunchKernelGGL(rs_histogram<K>, dim3(nblocks), dim3(RS_THREADS), 0, st, n, first_bit + p * 8, src_k, hist, nblocks);
-        gags_scan::launch<true>(RS_RADIX * nblocks, (const int32_t *)hist, (int32_t *)hist, nullptr, scan_tmp, st);
+        hipLaunchKernelGGL(rs_rowscan, dim3(RS_RADIX), dim3(RS_THREADS), 0, st, nblocks, hist, totals);
         hipLaunchKernelGGL(rs_scatter<K>, dim3(nblocks), dim3(RS_THREADS), 0, st, n, first_bit + p * 8, src_k, src_v, dst_k, dst_v,
-                           hist, nblocks);
+                           hist, nblocks, totals);
         src_k = dst_k;
         src_v = dst_v;
     }
