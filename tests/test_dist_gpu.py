@@ -270,6 +270,7 @@ def test_bench_two_ranks_under_torch_distributed_run():
     assert len(ge["range_exchange_ms_last_step"]) == 2  # two 128-channel ranges at D = 256
     assert "view-dp2" in line["config"]["parallelism"]
     assert ge["collective_ms_per_step"]["allreduce"] > 0 and "version" in ge["rccl"]
+    assert "rs_ag" in ge["collective_ms_per_step"]  # the other collective was attempted (gloo refuses it on device tensors: null)
 
 
 @pytest.mark.parametrize("d,c0,c1", [(256, 128, 256), (37, 5, 30), (130, 2, 130), (64, 0, 64)])

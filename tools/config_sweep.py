@@ -77,6 +77,7 @@ CASES = [
     ("C2 500k/1280x720/D=128, ALL gradients", (500_000, 1280, 720, 128), dict(full_grad=True)),
     ("C3 geometry D=16, ALL gradients", C3 + (16,), dict(full_grad=True)),
 ]
-sel = sys.argv[1] if len(sys.argv) > 1 else ""   # substring filter
-out = dict(run(name, *shape, **kw) for name, shape, kw in CASES if sel in name)
+sel = sys.argv[1] if len(sys.argv) > 1 else ""   # substring filter; a trailing "$" asks for the exact name
+match = (lambda name: name == sel[:-1]) if sel.endswith("$") else (lambda name: sel in name)
+out = dict(run(name, *shape, **kw) for name, shape, kw in CASES if match(name))
 print(json.dumps(out))

@@ -21,7 +21,12 @@ timeout 900 python bench.py --steps 20 --warmup 3 > "$O/${TAG}_c3_bench.json" 2>
 timeout 300 python tools/chunk_stats.py C3 > "$O/${TAG}_c3_chunk_stats.txt" 2>&1
 timeout 300 python tools/slot_support.py C3 > "$O/${TAG}_c3_slot_support.txt" 2>&1
 timeout 300 python tools/decoder_bench.py > "$O/${TAG}_d16_iteration_exact.json" 2>/dev/null
+timeout 300 python tools/decoder_bench.py --bf16x2 > "$O/${TAG}_d16_iteration_bf16x2.json" 2>/dev/null
 timeout 300 python tools/decoder_bench.py --bf16 > "$O/${TAG}_d16_iteration.json" 2>/dev/null
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$O/d16rstats" -o d16r --output-format csv -- \
+    python "$R/tools/config_sweep.py" 'C3 geometry D=16$' > /dev/null 2>&1 )
+S=$(find "$O/d16rstats" -name '*kernel_stats.csv' | head -1)
+[ -n "$S" ] && python "$R/tools/trim_stats.py" "$S" "$O/${TAG}_d16_raster_kernel_stats.csv" 45
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$O/d16stats" -o d16 --output-format csv -- \
     python "$R/tools/decoder_bench.py" --bf16 > /dev/null 2>&1 )
 S=$(find "$O/d16stats" -name '*kernel_stats.csv' | head -1)
