@@ -556,8 +556,6 @@ def main():
         gbs = b_view * views_per_gpu_step / (ms_per_step * 1e-3) / 1e9
         line["hbm_roofline_step"] = {"algorithmic_bytes_per_view": b_view, "achieved": gbs, "peak": HBM_PEAK_GBS,
                                      "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(pc, cam, d, width, height, args.cpu_seconds)
         if world == 1 and not (args.no_heavy or args.raster_flags):
             # the library's opt-in activation cache (frozen geometry: getters evaluated once, gags_amd/scene.py); OFF in `value`
             pc.cache_activations(True)
@@ -574,6 +572,8 @@ def main():
             line["activation_cache_on"] = {"note": "same workload with GaussianModel.cache_activations(True): exp / normalize / sigmoid "
                                                    "of the frozen geometry evaluated once instead of on every render",
                                            "value": csteps / cdt, "unit": "views/s", "ms_per_step": 1e3 * cdt / csteps, "steps": csteps}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(pc, cam, d, width, height, args.cpu_seconds)
         if world == 1 and d % 128 == 0 and not (args.no_heavy or args.raster_flags):
             # the same workload with the backward's contraction on the fp32 matrix instructions (rounds 1-2's default,
             # gags_amd._lib.GAGS_BWD_F32MFMA), reported next to `value` for comparison; DESIGN.md section 4
