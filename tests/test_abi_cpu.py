@@ -67,6 +67,17 @@ def test_argument_validation_returns_codes_without_launching(lib):
     assert lib.gags_scan_scratch_bytes(100000) >= 4
     assert lib.gags_cumsum_i32(-5, None, None, None, None, 0, None) == -1
     assert lib.gags_sh_fwd(4, 16, 7, None, None, None, None, None, None) == -1
+    # round 4's entries: the stored-parameter projection, the permuted prefix sum, the row-list compaction, the split tiers
+    assert lib.gags_project_fwd_raw(-1, *([None] * 4), 1.0, None, None, 16, 16, 0.3, 0.01, 1e10, 0.0, *([None] * 9), None) == -1
+    assert lib.gags_project_fwd_raw(8, *([None] * 4), 1.0, None, None, 16, 16, 0.3, 0.01, 1e10, 0.0, *([None] * 9), None) == -1
+    assert lib.gags_project_bwd_raw(8, *([None] * 4), 1.0, None, None, 16, 16, 0.3, *([None] * 9), None) == -1
+    assert lib.gags_cumsum_gather_i32(-1, None, None, None, None, None, 0, None) == -1
+    assert lib.gags_cumsum_gather_i32(8, None, None, None, None, None, 0, None) == -1
+    assert lib.gags_compact_mask(-1, None, 0, None, None, None, 0, None) == -1
+    assert lib.gags_compact_mask(8, None, 8, None, None, None, 0, None) == -1
+    assert lib.gags_compact_mask_scratch_bytes(100000) >= 4 * 49
+    assert lib.gags_decoder_layer_split(8, 4, 4, *([None] * 2), 4, *([None] * 2), 1, *([None] * 4), 4, 5, None) == -1   # terms = 5
+    assert lib.gags_decoder_wgrad_split(8, 4, 4, None, 4, None, None, 4, None, None, None, 0, 1, None) == -1            # terms = 1
 
 
 def test_missing_library_raises_loudly(monkeypatch, tmp_path):
