@@ -17,6 +17,21 @@
 
 using namespace gags_mfma;
 
+// Phase stamps of a wave (tools/probe/: a SEPARATE probe build, -DGAGS_PROBE; the shipped library has none of this).
+#ifdef GAGS_PROBE
+__device__ unsigned long long *gags_probe_buf = nullptr;
+extern "C" __attribute__((visibility("default"))) int gags_probe_set(void *p)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(gags_probe_buf), &p, sizeof(p)) == hipSuccess ? 0 : -2;
+}
+#define GAGS_STAMP(i)                                                                                       \
+    do {                                                                                                    \
+        if (gags_probe_buf && threadIdx.x == 0) gags_probe_buf[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define GAGS_STAMP(i) ((void)0)
+#endif
+
 namespace {
 
 template <int NB>
@@ -166,6 +181,15 @@ __global__ __launch_bounds__(64, 2) void raster_fwd_feat(
     const int sb = gags_slot_base(start, end, tile, blk);
     const int cnt = blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk];
     const int steps = cnt >> 1;
+    GAGS_STAMP(0);
+#ifdef GAGS_PROBE
+    if (gags_probe_buf && threadIdx.x == 0) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        gags_probe_buf[(size_t)blockIdx.x * 8 + 6] = hw;
+        gags_probe_buf[(size_t)blockIdx.x * 8 + 7] = (unsigned)steps;
+    }
+#endif
 
     // The epilogue's inputs -- final transmittance of the lane's 2 x 16 pixels, background of its channels -- are
     // requested FIRST: they are the oldest loads of the wave, long landed when the K loop ends (fetched after it they
@@ -222,8 +246,12 @@ __global__ __launch_bounds__(64, 2) void raster_fwd_feat(
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        GAGS_STAMP(1);
         for (int s = 0; s < steps; s += PD) {
             const int gv_use = gv;
+#ifdef GAGS_PROBE
+            if (s == PD) GAGS_STAMP(2);  // the first group's MFMAs are through: its operands had landed
+#endif
 #pragma unroll
             for (int i = 0; i < PD; ++i) {
                 const bool live = s + i < steps;
@@ -239,13 +267,16 @@ __global__ __launch_bounds__(64, 2) void raster_fwd_feat(
             }
         }
     }
+    GAGS_STAMP(3);
     // accumulator row r of lane (p,k) <-> pixel q = (r&3) + 8(r>>2) + 4k of a 8x4 half
     BlockGeom half;
     half.p = p; half.k = k; half.bx0 = g.bx0;
     half.by0 = g.by0;
     store_rows<NB>(accA, half, width, height, d, ch0, has_bg, render_colors, bgv, TqA);
+    GAGS_STAMP(4);
     half.by0 = g.by0 + 4;
     store_rows<NB>(accB, half, width, height, d, ch0, has_bg, render_colors, bgv, TqB);
+    GAGS_STAMP(5);
 }
 
 // ---- feature pass on the 16-bit matrix cores (opt-in: GAGS_FWD_F16MFMA; fp16 feature table, D % 128 == 0) -------------
