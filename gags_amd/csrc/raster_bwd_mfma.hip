@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void rast
         if (threadIdx.x < CMAX) reinterpret_cast<uint32_t *>(&pos[par][0][0])[threadIdx.x] = 0xffffffffu;
         const int tr32 = __builtin_amdgcn_readlane(tr, 32);
         if (lane == 0) cand[par][wave] = tr32;
-        __syncthreads();
+        gags_lds_barrier();  // LDS traffic only: __syncthreads() would also wait for the loads in flight (next chunk's weight tile) and the row stores
         const int r1 = min(min(min(cand[par][0], cand[par][1]), min(cand[par][2], cand[par][3])), min(r0 + CMAX, R1));
         const bool mine = lane < 32 && tr < r1;
         const int run = __popcll(__ballot(mine));  // this block's slots pb .. pb+run-1 fall into [r0, r1)
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void rast
                 }
             }
         }
-        __syncthreads();
+        gags_lds_barrier();  // LDS traffic only: __syncthreads() would also wait for the loads in flight (next chunk's weight tile) and the row stores
         // merged rows of the chunk: sum over the blocks that hold the row, in block order; one float4 per thread and item
         const int items = (r1 - r0) * C4;
         // branch-free, fully unrolled (at most CMAX * C4 / 256 trips): see raster_bwd_rows_pair
@@ -273,6 +273,28 @@ __global__ __launch_bounds__(256, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void rast
 // order: bit-reproducible.  A burst is 80 MFMAs of 32 cycles instead of 128 of 64.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+// Phase clocks of the rows kernel's waves (tools/probe/: a SEPARATE probe build, -DGAGS_PROBE; never the shipped library)
+#ifdef GAGS_PROBE
+}  // namespace
+__device__ unsigned long long *gags_probe_buf_bwd = nullptr;
+extern "C" __attribute__((visibility("default"))) int gags_probe_set_bwd(void *p)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(gags_probe_buf_bwd), &p, sizeof(p)) == hipSuccess ? 0 : -2;
+}
+namespace {
+#define GAGS_PH_DECL unsigned long long pt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tl_ = __builtin_readcyclecounter()
+#define GAGS_PH(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); pt_[i] += now_ - tl_; tl_ = now_; } while (0)
+#define GAGS_PH_WRITE()                                                                                                  \
+    do {                                                                                                                 \
+        if (gags_probe_buf_bwd && lane == 0)                                                                             \
+            for (int i_ = 0; i_ < 8; ++i_) gags_probe_buf_bwd[((size_t)blockIdx.x * 4 + wave) * 8 + i_] = pt_[i_];        \
+    } while (0)
+#else
+#define GAGS_PH_DECL ((void)0)
+#define GAGS_PH(i) ((void)0)
+#define GAGS_PH_WRITE() ((void)0)
+#endif
+
 __device__ __forceinline__ void split8(const float (&x)[8], float scale, f16x8 &hi, f16x8 &lo)
 {
 #pragma unroll
@@ -317,6 +339,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
     __shared__ __attribute__((aligned(16))) float zrow[CW];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    GAGS_PH_DECL;
     if (threadIdx.x < CW) zrow[threadIdx.x] = 0.f;
     const int logical = gags_xcd_remap(blockIdx.x, n_tiles * n_slices);
     const int tile = gags_tile_of_order(logical / n_slices, tile_w, n_tiles / tile_w);
@@ -370,6 +393,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
         }
     }
 
+    GAGS_PH(0);  // prologue: metadata, cotangent slab loaded, scaled and split
     int pb = 0;
     int r0 = R0;
     int tr = 0x7fffffff, gid = 0;
@@ -394,7 +418,8 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
         if (threadIdx.x < CMAX) reinterpret_cast<uint32_t *>(&pos[par][0][0])[threadIdx.x] = 0xffffffffu;
         const int tr32 = __builtin_amdgcn_readlane(tr, 32);
         if (lane == 0) cand[par][wave] = tr32;
-        __syncthreads();
+        gags_lds_barrier();  // LDS traffic only: __syncthreads() would also wait for the loads in flight (next chunk's weight tile) and the row stores
+        GAGS_PH(1);  // chunk bookkeeping + first barrier
         const int r1 = min(min(min(cand[par][0], cand[par][1]), min(cand[par][2], cand[par][3])), min(r0 + CMAX, R1));
         const bool mine = lane < 32 && tr < r1;
         const int run = __popcll(__ballot(mine));
@@ -405,6 +430,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            GAGS_PH(2);  // wait for the weight tile (and everything else in flight: the previous chunk's row stores)
             // power-of-two scale of this lane's slot row: its largest weight (weights are >= 0) -> [2^14, 2^15); exponent
             // arithmetic on the bits.  A row of zeros (pad slot, rows past the run: never stored) keeps scale 1.
             float wmx = 0.f;
@@ -438,6 +464,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
                 __builtin_amdgcn_sched_barrier(0);  // one K-step's terms at a time (hoisted together they spill)
             }
             __builtin_amdgcn_sched_barrier(0);
+            GAGS_PH(3);  // row scale, split, 80 MFMAs
             if (mine && ch0 == 0 && tr_c < rows_cap) {
                 row_key[tr_c] = (uint32_t)gid_c;
                 row_idx[tr_c] = tr_c;
@@ -449,6 +476,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
             }
             if (pbn < cnt) load_A(pbn);
             __builtin_amdgcn_sched_barrier(0);
+            GAGS_PH(4);  // keys, next chunk's loads issued
             // this lane's four column unscales as two packed pairs: the row's inverse scale multiplies them with two
             // v_pk_mul_f32, the accumulators with two more
             typedef float pk2 __attribute__((ext_vector_type(2)));
@@ -468,7 +496,9 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
                 }
             }
         }
-        __syncthreads();
+        GAGS_PH(5);  // unscale + park in LDS
+        gags_lds_barrier();  // LDS traffic only: __syncthreads() would also wait for the loads in flight (next chunk's weight tile) and the row stores
+        GAGS_PH(6);  // second barrier
         const int items = (r1 - r0) * C4;
         int gt = threadIdx.x;
         asm volatile("" : "+v"(gt));
@@ -491,9 +521,11 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
             }
             if (trip & 1) __builtin_amdgcn_sched_barrier(0);
         }
+        GAGS_PH(7);  // merge: LDS reads, adds, row stores
         pb = pbn;
         r0 = r1;
     }
+    GAGS_PH_WRITE();
 }
 
 // capacity-sized row buffers: keys [total, cap) become sentinels (key n_gauss: past every Gaussian), so that the sort and
