@@ -91,6 +91,7 @@ SIGNATURES = {
     "gags_distill_l1_map_bwd": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "gags_decoder_head_distill_fwd": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_decoder_head_distill_bwd": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gags_decoder_head_distill_bwd_f32": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_decoder_pack_input": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp]),
     "gags_decoder_pack_layer": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_decoder_layer": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),

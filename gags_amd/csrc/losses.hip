@@ -511,7 +511,8 @@ typedef float l_f32x2 __attribute__((ext_vector_type(2)));
 // c = ld = 512 (CNN_decoder(16, 512), the reference's configuration): 16 float4 per lane, straight-line code.
 // ONE_TAP: the segmentation map has the render's resolution (identity resize: every pixel has exactly one source
 // pixel), the common case -- one gather per level, the gathers of step j + 1 in flight during step j.
-template <bool BWD, bool ONE_TAP>
+// DZ32 (BWD): the logits' gradient leaves as fp32 (the fp32-tensor decoder tiers) instead of bf16.
+template <bool BWD, bool ONE_TAP, bool DZ32 = false>
 __global__ __launch_bounds__(256, 3) void head_distill_kernel(int H, int W, int h, int w, int n_emb,
                                                               const float *__restrict__ x, const float *__restrict__ img_embed,
                                                               const float *__restrict__ seg_map, const float *__restrict__ scale_map,
@@ -645,6 +646,7 @@ __global__ __launch_bounds__(256, 3) void head_distill_kernel(int H, int W, int 
     for (int j = 0; j < FHJ; ++j) {
         const float xe[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
         unsigned pk[2];
+        float df[4];
 #pragma unroll
         for (int q = 0; q < 4; q += 2) {
             l_f32x2 sg2;
@@ -656,8 +658,12 @@ __global__ __launch_bounds__(256, 3) void head_distill_kernel(int H, int W, int 
             const l_f32x2 x2 = {xe[q], xe[q + 1]};
             const l_f32x2 dq2 = __builtin_elementwise_fma(-x2, l_f32x2{k1, k1}, sg2 * gmag);
             pk[q >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(dq2, l_bf16x2));
+            df[q] = dq2[0]; df[q + 1] = dq2[1];
         }
-        *reinterpret_cast<uint2 *>(dz + (size_t)pr * c + c0 + 32 * j) = make_uint2(pk[0], pk[1]);
+        if constexpr (DZ32)
+            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(dz) + (size_t)pr * c + c0 + 32 * j) = make_float4(df[0], df[1], df[2], df[3]);
+        else
+            *reinterpret_cast<uint2 *>(dz + (size_t)pr * c + c0 + 32 * j) = make_uint2(pk[0], pk[1]);
     }
 }
 
@@ -899,6 +905,26 @@ extern "C" int gags_decoder_head_distill_bwd(int c, int ld, int H, int W, int h,
         hipLaunchKernelGGL((head_distill_kernel<true, false>), dim3((H * W + TPM - 1) / TPM), dim3(256), 0, (hipStream_t)stream, H, W,
                            h, w, n_emb, x, img_embed, seg_map, scale_map, v_map, (float *)nullptr, (float *)nullptr,
                            (unsigned short *)dz_bf16, v_scale);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+extern "C" int gags_decoder_head_distill_bwd_f32(int c, int ld, int H, int W, int h, int w, int n_emb, const float *x,
+                                                 const float *img_embed, const float *seg_map, const float *scale_map,
+                                                 const float *v_map, float *dz, float *v_scale, void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (!sam_args_ok(c, H, W, h, w, n_emb) || c != 512 || ld != 512 || !x || !img_embed || !seg_map || !scale_map || !v_map ||
+        !dz || !v_scale)
+        return GAGS_EINVAL;
+    if (H == h && W == w)
+        hipLaunchKernelGGL((head_distill_kernel<true, true, true>), dim3((H * W + TPM - 1) / TPM), dim3(256), 0, (hipStream_t)stream, H,
+                           W, h, w, n_emb, x, img_embed, seg_map, scale_map, v_map, (float *)nullptr, (float *)nullptr,
+                           (unsigned short *)dz, v_scale);
+    else
+        hipLaunchKernelGGL((head_distill_kernel<true, false, true>), dim3((H * W + TPM - 1) / TPM), dim3(256), 0, (hipStream_t)stream, H,
+                           W, h, w, n_emb, x, img_embed, seg_map, scale_map, v_map, (float *)nullptr, (float *)nullptr,
+                           (unsigned short *)dz, v_scale);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }

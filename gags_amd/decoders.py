@@ -497,9 +497,11 @@ class _DecoderDistillFn(torch.autograd.Function):
     gradient -- the normalised [512,H,W] map and its gradient are never written or read (21 GB per iteration at 1080p)."""
 
     @staticmethod
-    def forward(ctx, x, img_embed, seg_map, scale_map, c_out, *params):
+    def forward(ctx, x, img_embed, seg_map, scale_map, c_out, precision, *params):
         from .losses import _f
-        logits, acts, wb, h, w, c_in = _chain_forward(x, "decoder", params)
+        ctx.terms = {"exact": 3, "bf16x2": 2}.get(precision, 0)  # 0: the bf16 mode
+        logits, acts, wb, h, w, c_in = (_chain_forward_exact(x, "decoder", params, ctx.terms) if ctx.terms
+                                        else _chain_forward(x, "decoder", params))
         e, seg, sc = _f(img_embed), _f(seg_map), _f(scale_map)
         if e.shape[1] != c_out or tuple(sc.shape) != (3, h, w) or seg.dim() != 3 or seg.shape[0] != 4:
             raise ValueError(f"embeddings {tuple(e.shape)}, seg_map {tuple(seg.shape)}, scale_map {tuple(sc.shape)} "
@@ -520,14 +522,21 @@ class _DecoderDistillFn(torch.autograd.Function):
         from .losses import _f
         logits, e, seg, sc, *acts = ctx.saved_tensors
         (h, w), c = ctx.hw, ctx.c_out
-        dz = torch.empty(h * w, logits.shape[1], dtype=torch.bfloat16, device=logits.device)
         vs = torch.empty(3, h, w, device=logits.device)
-        check(_lib.load().gags_decoder_head_distill_bwd(c, logits.shape[1], h, w, seg.shape[1], seg.shape[2], e.shape[0],
-                                                        ptr(logits), ptr(e), ptr(seg), ptr(sc), ptr(_f(v_map)), ptr(dz), ptr(vs),
-                                                        _st()), "gags_decoder_head_distill_bwd")
-        need_x, need_w = _needs(ctx, 5)
-        gx, grads = _chain_backward(dz, acts, ctx.wb, "decoder", h, w, ctx.c_in, ctx.shapes, need_x, need_w)
-        return (gx, None, None, vs, None, *grads)
+        need_x, need_w = _needs(ctx, 6)
+        if ctx.terms:  # fp32-tensor tiers: the logits' gradient stays fp32
+            dz = torch.empty(h * w, logits.shape[1], device=logits.device)
+            check(_lib.load().gags_decoder_head_distill_bwd_f32(c, logits.shape[1], h, w, seg.shape[1], seg.shape[2], e.shape[0],
+                                                                ptr(logits), ptr(e), ptr(seg), ptr(sc), ptr(_f(v_map)), ptr(dz),
+                                                                ptr(vs), _st()), "gags_decoder_head_distill_bwd_f32")
+            gx, grads = _chain_backward_exact(dz, acts, ctx.wb, "decoder", h, w, ctx.c_in, ctx.shapes, need_x, need_w, ctx.terms)
+        else:
+            dz = torch.empty(h * w, logits.shape[1], dtype=torch.bfloat16, device=logits.device)
+            check(_lib.load().gags_decoder_head_distill_bwd(c, logits.shape[1], h, w, seg.shape[1], seg.shape[2], e.shape[0],
+                                                            ptr(logits), ptr(e), ptr(seg), ptr(sc), ptr(_f(v_map)), ptr(dz), ptr(vs),
+                                                            _st()), "gags_decoder_head_distill_bwd")
+            gx, grads = _chain_backward(dz, acts, ctx.wb, "decoder", h, w, ctx.c_in, ctx.shapes, need_x, need_w)
+        return (gx, None, None, vs, None, None, *grads)
 
 
 class _Stack(nn.Module):
@@ -571,15 +580,16 @@ class CNN_decoder(_Stack):
             l1_loss_map(feature_map * mask, gt * mask), mask
         with the decoder's normalising head fused into the loss (the [512,H,W] map is never materialised).  Returns
         (l1_map [H,W], mask [1,H,W] bool); gradients reach x, the decoder's parameters and scale_map.  Not part of the
-        reference's module: an optional fast path."""
+        reference's module: an optional fast path (every precision tier: the fp32-tensor tiers keep the logits' gradient
+        in fp32, the bf16 mode rounds it to bf16)."""
         if not x.is_cuda:
             raise RuntimeError("gags_amd.decoders: tensors must live on the GPU (there is no CPU path)")
-        if self.output_dim != 512 or self.precision != "bf16":
-            # fp32-equivalent precision: the decoder, then the fused ground-truth assembly + L1 map (both fp32)
+        if self.output_dim != 512:
+            # other widths: the decoder, then the fused ground-truth assembly + L1 map
             l1, mask = __import__("gags_amd.losses", fromlist=["distill_l1_map"]).distill_l1_map(self(x), img_embed, seg_map, scale_map)
             return l1, mask
         params = [t for m in self.convs() for t in (m.weight, m.bias)]
-        l1, mask = _DecoderDistillFn.apply(x, img_embed, seg_map, scale_map, self.output_dim, *params)
+        l1, mask = _DecoderDistillFn.apply(x, img_embed, seg_map, scale_map, self.output_dim, self.precision, *params)
         return l1, (mask != 0)[None]
 
 

@@ -84,6 +84,10 @@ int gags_decoder_head_distill_fwd(int c, int ld, int H, int W, int h, int w, int
 int gags_decoder_head_distill_bwd(int c, int ld, int H, int W, int h, int w, int n_emb, const float *x,
                                   const float *img_embed, const float *seg_map, const float *scale_map,
                                   const float *v_map, void *dz_bf16, float *v_scale, void *stream);
+/* ... with the logits' gradient in fp32 (dz[H*W, ld] float): the fp32-tensor decoder tiers ("exact", "bf16x2"). */
+int gags_decoder_head_distill_bwd_f32(int c, int ld, int H, int W, int h, int w, int n_emb, const float *x,
+                                      const float *img_embed, const float *seg_map, const float *scale_map,
+                                      const float *v_map, float *dz, float *v_scale, void *stream);
 
 /* ---- N1: the per-pixel decoders (models/networks.py:109-248: stacks of 1x1 convolutions) ---------------------- */
 

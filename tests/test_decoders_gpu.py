@@ -319,8 +319,9 @@ def test_decoder_output_is_pixel_major_and_its_gradient_flows_without_transposes
     assert ((gw_a - gw_b).double().norm() / gw_b.double().norm()).item() <= tol
 
 
+@pytest.mark.parametrize("precision,gtol", [("bf16", 2e-2), ("exact", 5e-3), ("bf16x2", 5e-3)])
 @pytest.mark.parametrize("H,W,h,w", [(96, 130, 96, 130), (60, 77, 30, 40)])
-def test_fused_head_and_distillation_loss_equals_the_two_step_route(H, W, h, w):
+def test_fused_head_and_distillation_loss_equals_the_two_step_route(H, W, h, w, precision, gtol):
     """CNN_decoder.distill_l1 (head fused into the loss: gags_decoder_head_distill_fwd / _bwd) against
     distill_l1_map(decoder(x), ...): the loss map, the mask, and every gradient (input, all decoder parameters, scale
     map), with an identity-size and a resized (bilinear, four taps) segmentation map."""
@@ -328,7 +329,10 @@ def test_fused_head_and_distillation_loss_equals_the_two_step_route(H, W, h, w):
     from gags_amd.decoders import CNN_decoder
     from make_golden_next import decoder_weights
     wd, _ = decoder_weights(0)
-    dec = _load(CNN_decoder(16, 512, "bf16"), wd)  # the fused head + loss is the bf16 mode's fast path
+    # every tier has the fused head + loss (the fp32-tensor tiers keep the logits' gradient in fp32).  Gradient bounds: the
+    # bf16 mode rounds the logits' gradient to bf16; in the fp32 tiers the two routes differ by an ulp in y = x / |x|, and the
+    # L1's sign(y m - gt m) flips for the one or two of the ~6 M differences that are that close to zero (each flip: 8e-4)
+    dec = _load(CNN_decoder(16, 512, precision), wd)
     g = torch.Generator(device="cuda").manual_seed(12)
     n_emb = 40
     x = torch.randn(H, W, 16, device="cuda", generator=g).permute(2, 0, 1)
@@ -356,9 +360,9 @@ def test_fused_head_and_distillation_loss_equals_the_two_step_route(H, W, h, w):
     assert torch.equal(a[1], b[1]) and a[1].shape == (1, H, W)
     assert rel(b[0], a[0]) <= 1e-6
     assert rel(b[3], a[3]) <= 1e-5                       # scale-map gradient: fp32 on both routes
-    assert rel(b[2], a[2]) <= 2e-2                       # behind bf16 layers (the logits' gradient is rounded to bf16)
+    assert rel(b[2], a[2]) <= gtol
     for u, v in zip(b[4] + b[5], a[4] + a[5]):
-        assert rel(u, v) <= 2e-2
+        assert rel(u, v) <= gtol
 
 
 @pytest.mark.parametrize("n,k,two,p", [(256, 256, True, 20011), (512, 256, False, 9001), (3, 16, False, 5003), (16, 3, False, 5003),

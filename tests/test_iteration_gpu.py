@@ -90,7 +90,7 @@ def test_the_scale_decoder_does_not_backpropagate_into_the_feature_map():
     seg, emb = torch.from_numpy(Z["seg_map"]).cuda(), torch.from_numpy(Z["img_embed"]).cuda()
     with torch.no_grad():
         scale_map = sdec(fmap.detach())
-    l1m, mask = L.distill_l1_map(dec(fmap), emb, seg, scale_map)
+    l1m, mask = dec.distill_l1(fmap, emb, seg, scale_map)  # (the route distillation_loss takes: head fused into the loss)
     L.Scale_balance_loss(l1m, L.get_trained_seg(seg, scale_map), mask.squeeze(0), mix_seg=True).backward()
     assert torch.equal(vf, fmap.grad)
 

@@ -71,7 +71,7 @@ for _ in range(K):
     iteration(times)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
-print(json.dumps({"fused_head_loss": FUSED and PRECISION == "bf16", "decoder_precision": PRECISION,
+print(json.dumps({"fused_head_loss": FUSED, "decoder_precision": PRECISION,
                   "workload": "train.py:142-174 iteration, 1.5M Gaussians, 1920x1080, D=16 -> CNN decoders -> losses",
                   "ms_per_iteration": 1e3 * dt, "iterations_per_s": 1 / dt,
                   "stages_ms": {k: sum(v) / len(v) for k, v in times.items()}}))
