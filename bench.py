@@ -426,25 +426,25 @@ def main():
     if world > 1 and mode == "view" and not args.no_allreduce:
         collective_ms = {args.grad_reduce: 1e3 * dt / args.steps}
         other = "allreduce" if args.grad_reduce == "rs_ag" else "rs_ag"
-        if True:  # (under the gloo debug transport rs_ag on device tensors is refused: recorded as null, same code path)
-            ok = 1
-            try:
-                step.set_collective(other)
+        # (under the gloo debug transport rs_ag on device tensors is slow or refused: recorded as measured / null, same code path)
+        ok = 1
+        try:
+            step.set_collective(other)
+            step()
+            torch.cuda.synchronize(); barrier()
+            osteps = max(2, min(args.steps, 5))
+            t1 = time.perf_counter()
+            for _ in range(osteps):
                 step()
-                torch.cuda.synchronize(); barrier()
-                osteps = max(2, min(args.steps, 5))
-                t1 = time.perf_counter()
-                for _ in range(osteps):
-                    step()
-                torch.cuda.synchronize(); barrier()
-                odt = time.perf_counter() - t1
-            except RuntimeError as e:
-                print(f"[bench] rank {rank}: collective '{other}' failed: {e}", file=sys.stderr, flush=True)
-                ok, odt, osteps = 0, 0.0, 1
-            tt = torch.tensor([odt if ok else float("inf")], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-            collective_ms[other] = 1e3 * float(tt.item()) / osteps if tt.item() != float("inf") else None
-            step.set_collective(args.grad_reduce)
+            torch.cuda.synchronize(); barrier()
+            odt = time.perf_counter() - t1
+        except RuntimeError as e:
+            print(f"[bench] rank {rank}: collective '{other}' failed: {e}", file=sys.stderr, flush=True)
+            ok, odt, osteps = 0, 0.0, 1
+        tt = torch.tensor([odt if ok else float("inf")], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        collective_ms[other] = 1e3 * float(tt.item()) / osteps if tt.item() != float("inf") else None
+        step.set_collective(args.grad_reduce)
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

@@ -284,7 +284,9 @@ class OverlappedGradReducer:
         scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
         _lib.check(lib.gags_compact_mask(n, _lib.ptr(mask), cap, _lib.ptr(idx), _lib.ptr(count), _lib.ptr(scratch), sb,
                                          torch.cuda.current_stream().cuda_stream), "gags_compact_mask")
-        host = self._pinned.setdefault(dev.index, torch.empty(1, dtype=torch.int32).pin_memory())
+        if dev.index not in self._pinned:
+            self._pinned[dev.index] = torch.empty(1, dtype=torch.int32).pin_memory()
+        host = self._pinned[dev.index]
         host.copy_(count, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
