@@ -125,6 +125,8 @@ GAGS_BWD_F32MFMA = 64  # python-side: staged backward contracts with v_mfma_f32_
 #                        default fp32-equivalent split operands on the 16-bit matrix cores (csrc/raster_bwd_mfma.hip)
 GAGS_BWD_F16SPLIT = 0   # (round 2's opt-in flag: that kernel, made exact, is the default now)
 GAGS_FWD_F16MFMA = 128  # python-side: fp16 feature table + D % 128 == 0: feature pass on the 16-bit matrix cores (opt-in; C flag 64)
+GAGS_FWD_EXACT = 2048  # fp32 table, D >= 128: feature pass on v_mfma_f32_32x32x2_f32, bit-identical to the sequential fmaf chain (the
+#                        oracle); default: 16-bit matrix cores on operands split into three bf16 terms (include/gags_raster.h)
 GAGS_FWD_FUSED = 8  # python-side: single-kernel matrix-core forward (no scratch) instead of weights + features
 
 _lib = None

@@ -22,7 +22,7 @@ int gags_raster_weights_launch(int width, int height, int n_gauss, const void *p
                                int32_t *hit, int32_t *blk_rows, float *Tbuf, float *alphas, int32_t *last_ids,
                                hipStream_t st);
 // raster_fwd_mfma.hip
-int gags_raster_fwd_feat_launch(int d, int width, int height, int n_gauss, const float *colors, int colors_f16,
+int gags_raster_fwd_feat_launch(int d, int width, int height, int n_gauss, const float *colors, int colors_f16, int exact,
                                 const float *backgrounds, const int32_t *offsets, int n_isects,
                                 const int32_t *blk_rows, const float *wt, const int32_t *gid_s, const float *Tbuf,
                                 float *out, hipStream_t st);
@@ -55,12 +55,11 @@ inline int64_t al256(int64_t x) { return (x + 255) / 256 * 256; }
 struct FwdScratch {
     int64_t wt, gid, sidx, hit, tbuf, total;
 };
-// slot space: GAGS_BLOCKS_PER_TILE * (n_isects + n_tiles) slots of 64 weights (+ slack so that the backward may
-// read a whole 32-slot tile)
+// slot space: gags_slot_count() slots of 64 weights (common.h)
 inline FwdScratch fwd_layout(int64_t n_isects, int width, int height)
 {
     const int64_t tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
-    const int64_t slots = GAGS_BLOCKS_PER_TILE * (n_isects + tile_w * tile_h) + 64;
+    const int64_t slots = gags_slot_count(n_isects, tile_w * tile_h);
     FwdScratch L;
     int64_t o = 0;
     L.wt = o; o += al256(slots * 256);
@@ -118,7 +117,8 @@ extern "C" int gags_raster_fwd(int d, int n, int width, int height, const float 
                                                 gid_s, (int32_t *)(sb + L.sidx), (int32_t *)(sb + L.hit), blk_rows, tbuf,
                                                 render_alphas, last_ids, st);
             if (rc != GAGS_OK || (flags & GAGS_FWD_ONLY_WEIGHTS)) return rc;
-            return gags_raster_fwd_feat_launch(d, width, height, n, colors, (flags & GAGS_FEAT_F16) ? ((flags & GAGS_FWD_F16MFMA) ? 2 : 1) : 0, backgrounds, isect_offsets, (int)n_isects,
+            return gags_raster_fwd_feat_launch(d, width, height, n, colors, (flags & GAGS_FEAT_F16) ? ((flags & GAGS_FWD_F16MFMA) ? 2 : 1) : 0,
+                                               (flags & GAGS_FWD_EXACT) ? 1 : 0, backgrounds, isect_offsets, (int)n_isects,
                                                blk_rows, wt, gid_s, tbuf, render_colors, st);
         }
         return gags_raster_fwd_fused_launch(d, width, height, packed, colors, backgrounds, isect_offsets, flatten_ids,
@@ -168,7 +168,7 @@ inline int64_t rowmap_slot_off(int64_t n_isects) { return al256((n_isects + 1) *
 inline int64_t slot_count(int64_t n_isects, int width, int height)
 {
     const int64_t tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
-    return GAGS_BLOCKS_PER_TILE * (n_isects + tile_w * tile_h) + 64;
+    return gags_slot_count(n_isects, tile_w * tile_h);
 }
 }  // namespace
 

@@ -96,11 +96,18 @@ __host__ __device__ __forceinline__ bool gags_mfma_width(int d) { return d >= 16
 
 // Slot space of the matrix-core rasterizer (raster_weights.hip): every (tile, 8x8 block) owns a fixed
 // region of K-step slots sized by the tile's list length, so no counting pass is needed.
-//   base(tile, blk) = 4*(start + tile) + blk * even(L),  capacity even(L),  L = end - start,  blk in 0..3
-// Total slot count for a view: 4 * (n_isects + n_tiles).  A slot holds 64 weights (256 B).
+//   base(tile, blk) = 4*start + 64*tile + blk * r16(L),  capacity r16(L) = L rounded up to 16,  L = end - start,  blk in 0..3
+// (4 r16(L) <= 4 L + 60: the regions of a tile fit its 4 L + 64 slots.)  A region holds the block's `blk_rows` slots
+// (an even count) followed by ZERO slots (weights 0, Gaussian id N) up to the next multiple of 16: kernels that consume
+// slots sixteen at a time (the 16-bit matrix-core feature pass) need neither a clamp nor a mask in their last step.
+// Total slot count for a view: gags_slot_count().  A slot holds 64 weights (256 B).
 #define GAGS_BLOCKS_PER_TILE 4
 __host__ __device__ __forceinline__ int gags_slot_base(int start, int end, int tile, int blk)
 {
-    const int lp = (end - start + 1) & ~1;
-    return GAGS_BLOCKS_PER_TILE * (start + tile) + blk * lp;
+    const int lp = (end - start + 15) & ~15;
+    return GAGS_BLOCKS_PER_TILE * start + 64 * tile + blk * lp;
+}
+__host__ __device__ __forceinline__ int64_t gags_slot_count(int64_t n_isects, int64_t n_tiles)
+{
+    return GAGS_BLOCKS_PER_TILE * n_isects + 64 * n_tiles + 64;  // (+ slack so that a kernel may read a whole 32-slot tile behind the last region)
 }

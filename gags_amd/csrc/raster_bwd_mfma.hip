@@ -1411,7 +1411,7 @@ struct GeomLayout {
 inline GeomLayout geom_layout(int64_t n_isects, int width, int height, int n_gauss, int d, int64_t n_rows)
 {
     const int64_t tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
-    const int64_t slots = GAGS_BLOCKS_PER_TILE * (n_isects + tile_w * tile_h) + 64;
+    const int64_t slots = gags_slot_count(n_isects, tile_w * tile_h);
     const int64_t rows = n_rows < 0 ? slots : (n_rows > 0 ? n_rows : 1);
     GeomLayout L;
     int64_t o = 0;
@@ -1454,7 +1454,7 @@ int gags_raster_bwd_geom_launch(int d, int n_gauss, int width, int height, const
     if (scratch_bytes < L.total) return GAGS_ESCRATCH;
     const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
     const int n_tiles = tile_w * tile_h;
-    const int64_t slots = n_rows < 0 ? GAGS_BLOCKS_PER_TILE * ((int64_t)n_isects + n_tiles) + 64 : n_rows;  // rows to sort
+    const int64_t slots = n_rows < 0 ? gags_slot_count(n_isects, n_tiles) : n_rows;  // rows to sort
     char *sb = (char *)scratch;
     float *S = (float *)(sb + L.S), *bgdot = backgrounds ? (float *)(sb + L.bgdot) : nullptr, *grow = (float *)(sb + L.grow);
     uint32_t *key = (uint32_t *)(sb + L.key), *key_s = (uint32_t *)(sb + L.key_s);
@@ -1471,7 +1471,7 @@ int gags_raster_bwd_geom_launch(int d, int n_gauss, int width, int height, const
     }
     const bool split16 = !f32mfma && hit && flatten_ids;
     // the split-f16 dot pass writes one S / bgdot buffer per 256-channel pass (the fp32 one accumulates in the first)
-    const int64_t s_rows = (n_rows < 0 ? GAGS_BLOCKS_PER_TILE * ((int64_t)n_isects + n_tiles) + 64 : (n_rows > 0 ? n_rows : 1)) + 64;
+    const int64_t s_rows = (n_rows < 0 ? gags_slot_count(n_isects, n_tiles) : (n_rows > 0 ? n_rows : 1)) + 64;
     const size_t s_stride = (size_t)al256(s_rows * 256) / 4, bg_stride = (size_t)al256((int64_t)width * height * 4) / 4;
     const int n_pass = split16 ? (d + SD_MAXCH - 1) / SD_MAXCH : 1;
     if (split16) {

@@ -13,6 +13,8 @@
 // epilogue stores 16 B per lane.  All D channels of a slice are composited in ONE walk of the list
 // (gsplat re-walks it ceil(D/32) times).
 #include <hip/hip_fp16.h>
+#include <cstdlib>
+#include <type_traits>
 #include "raster_mfma_common.h"
 
 using namespace gags_mfma;
@@ -402,6 +404,431 @@ __global__ __launch_bounds__(64, 2) void raster_fwd_feat_f16(
     }
 }
 
+// ---- feature pass of an fp32 table on the 16-bit matrix cores, fp32-equivalent (the DEFAULT for D >= 128) -----------------
+// v_mfma_f32_32x32x16_bf16 runs at 16x the rate of v_mfma_f32_32x32x2_f32.  Both operands are written as THREE bfloat16
+// terms obtained by truncation -- t0 = the top 16 bits of x, t1 = the top 16 bits of x - t0, t2 = x - t0 - t1: every
+// subtraction is exact and 3 x 8 significand bits hold fp32's 24, so  x = t0 + t1 + t2  EXACTLY, with fp32's own exponent
+// range (no scales, nothing to overflow or flush: the reason bf16 and not fp16 here -- in the forward K runs over SLOTS, so
+// a per-Gaussian scale of the feature rows could not be factored out of the accumulator).  A product is issued as its six
+// terms of order <= 2 in 2^-8:   w f ~ a2 b0 + a1 b1 + a0 b2 + a1 b0 + a0 b1 + a0 b0   (dropped: a1 b2, a2 b1, a2 b2 <=
+// 2^-23 |w f|); every partial product of two bf16 numbers is exact in the fp32 accumulator.  So each product enters the
+// sum with a relative error below one fp32 rounding and the sum is accumulated in fp32 by the matrix core: as close to the
+// float64 statement as the fp32 matrix instructions (tests/test_parity_gpu.py::test_forward_x16_*), but NOT bit-identical
+// to the sequential fmaf chain of the oracle -- GAGS_FWD_EXACT selects raster_fwd_feat above, which is.
+// 48 MFMAs of 32 cycles per 16 slots x 64 pixels x 128 channels instead of 64 of 64 cycles.
+// One wave per (tile, 8x8 block, 128-channel slice), K-steps of 16 slots: lane (p, kg) holds, as A operand, the weights of
+// pixel p (upper / lower half of the block) for slots 8 kg .. 8 kg + 7 of the step, and as B operand channel 4 p + j of
+// the same eight slots (tile j = channels ch0 + 4 n + j: the strided tiles of the fp32 kernel, same float4 epilogue).
+// The split is done in registers on the way (9 VALU instructions per pair of values and three terms), in the shadow of the
+// wave's own MFMAs; feature rows are gathered as two float2 halves per slot so that each half's registers are refilled
+// for the next step as soon as its two channel tiles have been split.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3_pair(float x, float y, unsigned &t0, unsigned &t1, unsigned &t2)
+{
+    // {bf16 term of x | bf16 term of y << 16}: v_perm_b32 picks bytes 2, 3 of both
+    const unsigned ux = __float_as_uint(x), uy = __float_as_uint(y);
+    t0 = __builtin_amdgcn_perm(uy, ux, 0x07060302u);
+    const float rx = x - __uint_as_float(ux & 0xffff0000u), ry = y - __uint_as_float(uy & 0xffff0000u);
+    const unsigned vx = __float_as_uint(rx), vy = __float_as_uint(ry);
+    t1 = __builtin_amdgcn_perm(vy, vx, 0x07060302u);
+    const float qx = rx - __uint_as_float(vx & 0xffff0000u), qy = ry - __uint_as_float(vy & 0xffff0000u);
+    t2 = __builtin_amdgcn_perm(__float_as_uint(qy), __float_as_uint(qx), 0x07060302u);
+}
+
+struct Op3 {  // the three bf16 terms of one MFMA operand (8 K elements per lane)
+    bf16x8 t[3];
+};
+
+__device__ __forceinline__ Op3 split_op(const float (&v)[8])
+{
+    union { bf16x8 v; unsigned u[4]; } o[3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) split3_pair(v[2 * q], v[2 * q + 1], o[0].u[q], o[1].u[q], o[2].u[q]);
+    Op3 r;
+    r.t[0] = o[0].v; r.t[1] = o[1].v; r.t[2] = o[2].v;
+    return r;
+}
+
+__device__ __forceinline__ void mfma6(f32x16 &acc, const Op3 &a, const Op3 &b)
+{
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[2], b.t[0], acc, 0, 0, 0);  // smallest terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[1], b.t[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[0], b.t[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[1], b.t[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[0], b.t[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[0], b.t[0], acc, 0, 0, 0);
+}
+
+// id of slot I (0..7) of the lane's half of the step, from a vector whose every 16-lane row holds the eight ids of its
+// half-wave twice (lane l: slot 8 (l >> 5) + (l & 7)): DPP row broadcast, fused by the compiler into the consuming add
+template <int I>
+__device__ __forceinline__ unsigned row_bcast_add(unsigned v, unsigned add)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + I, 0xf, 0xf, false) + add;
+}
+
+// BIG: the table does not fit 32-bit byte offsets (N D 4 >= 2^32): offsets in floats, widened per gather
+template <bool BIG>
+__global__ __launch_bounds__(64, 2) void raster_fwd_feat_x16(
+    int d, int width, int height, int tile_w, int n_tiles, int n_slices, int n_gauss,
+    const float *__restrict__ colors, const float *__restrict__ backgrounds, const int32_t *__restrict__ offsets,
+    int n_isects, const int32_t *__restrict__ blk_rows, const float *__restrict__ wt,
+    const int32_t *__restrict__ gid_s, const float *__restrict__ Tbuf, float *__restrict__ render_colors)
+{
+    constexpr int NB = 4, CS = 128;
+    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * GAGS_BLOCKS_PER_TILE * n_slices);
+    const int slice = logical % n_slices, rest = logical / n_slices;
+    const int blk = rest & 3;
+    const int tile = gags_tile_of_order(rest >> 2, tile_w, n_tiles / tile_w);
+    const int ch0 = slice * CS;
+    const int lane = threadIdx.x;
+    BlockGeom64 g;
+    g.init(tile, blk, tile_w, width, height, lane);
+    const int p = g.p, k = g.k;
+    const int start = offsets[tile];
+    const int end = offsets[tile + 1]  /* n_tiles + 1 entries: the last one is the intersection count */;
+    const int sb = gags_slot_base(start, end, tile, blk);
+    const int cnt = blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk];  // even
+    const int steps = (cnt + 15) >> 4;
+
+    // The epilogue's inputs are requested first (see raster_fwd_feat) -- the final transmittance of the lane's OWN two
+    // pixels and the background of its channels -- and parked in LDS for the duration of the K loop, which needs every
+    // register (the epilogue then fetches the pixels of its accumulator rows from the lanes that own them: ds_bpermute).
+    __shared__ __attribute__((aligned(16))) float park[6 * 64];
+    const bool has_bg = backgrounds != nullptr;  // wave-uniform
+    {
+        float bgv0[NB];
+        fetch_bg<NB>(bgv0, backgrounds, ch0, p, d);
+        const int pjc = min(g.pj, width - 1);
+        const float tA = has_bg ? Tbuf[(size_t)min(g.piA, height - 1) * width + pjc] : 0.f;
+        const float tB = has_bg ? Tbuf[(size_t)min(g.piB, height - 1) * width + pjc] : 0.f;
+        *reinterpret_cast<float4 *>(park + 4 * lane) = make_float4(bgv0[0], bgv0[1], bgv0[2], bgv0[3]);
+        *reinterpret_cast<float2 *>(park + 256 + 2 * lane) = make_float2(tA, tB);
+    }
+
+    f32x16 accA[NB], accB[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accA[j][r] = 0.f; accB[j][r] = 0.f; }
+
+    if (steps > 0) {
+        const unsigned gmax = (unsigned)(n_gauss - 1);
+        // The lane's eight slots of step s are sb + 16 s + 8 k + i.  Behind the block's count its region holds ZERO slots
+        // up to the next multiple of 16 (raster_weights.hip): weight 0, id N (clamped into the table: a finite row).
+        const unsigned id_off = (unsigned)(sb + 8 * k + (lane & 7)) * 4u;  // (slot indices stay below 2^29)
+        auto load_ids = [&](int s) {
+            return *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(gid_s) + (id_off + 64u * (unsigned)s));
+        };
+        const float *wp = wt + (size_t)(sb + 8 * k) * 64 + 2 * p;
+        auto load_w = [&](int s, float2 (&w)[8]) {
+            const float *src = wp + (size_t)s * (16 * 64);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[i] = *reinterpret_cast<const float2 *>(src + i * 64);
+        };
+        const unsigned lane_off = BIG ? (unsigned)(ch0 + 4 * p) : (unsigned)(ch0 + 4 * p) * 4u;
+        const unsigned row_pitch = BIG ? (unsigned)d : (unsigned)d * 4u;
+        auto load_f = [&](unsigned idv, float4 (&f)[8]) {  // channels ch0 + 4 p .. + 3 of the eight rows
+            const unsigned ro = min(idv, gmax) * row_pitch;  // (the zero slots carry id N)
+            const unsigned o[8] = {row_bcast_add<0>(ro, lane_off), row_bcast_add<1>(ro, lane_off), row_bcast_add<2>(ro, lane_off),
+                                   row_bcast_add<3>(ro, lane_off), row_bcast_add<4>(ro, lane_off), row_bcast_add<5>(ro, lane_off),
+                                   row_bcast_add<6>(ro, lane_off), row_bcast_add<7>(ro, lane_off)};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if constexpr (BIG) f[i] = *reinterpret_cast<const float4 *>(colors + (size_t)o[i]);
+                else f[i] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(colors) + o[i]);
+            }
+        };
+        // software pipeline: rows and weights of step s + 1 are requested during step s, the ids two steps further ahead
+        // (loads return in order: an id requested late would be waited for together with the rows issued before it)
+        float4 F[8];
+        float2 W[8];
+        unsigned id1, id2;
+        load_w(0, W);
+        load_f(load_ids(0), F);
+        id1 = load_ids(min(1, steps - 1));
+        id2 = load_ids(min(2, steps - 1));
+        auto step = [&](int s) {
+            // A operands: the weights of the lane's pixel pair for its eight slots
+            Op3 aA, aB;
+            {
+                float wa[8], wb[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { wa[i] = W[i].x; wb[i] = W[i].y; }
+                aA = split_op(wa);
+                aB = split_op(wb);
+            }
+            // B operands of the four channel tiles; then the rows' registers are free for the next step's
+            Op3 b[NB];
+            {
+                float x[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] = F[i].x;
+                b[0] = split_op(x);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] = F[i].y;
+                b[1] = split_op(x);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] = F[i].z;
+                b[2] = split_op(x);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] = F[i].w;
+                b[3] = split_op(x);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_f(id1, F);
+            id1 = id2;
+            id2 = load_ids(min(s + 3, steps - 1));
+            __builtin_amdgcn_sched_barrier(0);
+            mfma6(accA[0], aA, b[0]); mfma6(accB[0], aB, b[0]);
+            mfma6(accA[1], aA, b[1]); mfma6(accB[1], aB, b[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(min(s + 1, steps - 1), W);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma6(accA[2], aA, b[2]); mfma6(accB[2], aB, b[2]);
+            mfma6(accA[3], aA, b[3]); mfma6(accB[3], aB, b[3]);
+        };
+        for (int s = 0; s < steps; ++s) step(s);
+    }
+    // accumulator row r of lane (p, k) is pixel q = (r & 3) + 8 (r >> 2) + 4 k of a 8x4 half; its transmittance was parked by lane q
+    float TqA[16], TqB[16], bgv[NB];
+    {
+        const float4 b4 = *reinterpret_cast<const float4 *>(park + 4 * lane);
+        bgv[0] = b4.x; bgv[1] = b4.y; bgv[2] = b4.z; bgv[3] = b4.w;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = (r & 3) + 8 * (r >> 2) + 4 * k;
+            const float2 t = *reinterpret_cast<const float2 *>(park + 256 + 2 * q);
+            TqA[r] = t.x; TqB[r] = t.y;
+        }
+    }
+    BlockGeom half;
+    half.p = p; half.k = k; half.bx0 = g.bx0;
+    half.by0 = g.by0;
+    store_rows<NB>(accA, half, width, height, d, ch0, has_bg, render_colors, bgv, TqA);
+    half.by0 = g.by0 + 4;
+    store_rows<NB>(accB, half, width, height, d, ch0, has_bg, render_colors, bgv, TqB);
+}
+
+// ---- the same arithmetic as a stream: ONE wave per SIMD, every split in the shadow of the wave's own MFMAs (the default) ----
+// Measured on raster_fwd_feat_x16 (C3, ablations of its phases): its 264 splitting instructions per 16 slots cost 0.8 ms, its
+// MFMAs 0.55 ms, its output stores 0.55 ms -- and the three ADD UP: while one wave of a SIMD streams MFMAs its partner is issued
+// one instruction per MFMA (hardware finding of round 2), so two waves per SIMD take turns instead of overlapping,
+// and VALU instructions between two MFMAs on the SAME accumulator cost the result-forwarding path (+43 cycles each).  So this
+// kernel gives one wave the SIMD's whole register file (512: accumulators in the AGPRs) and
+//   * walks ALL 128-channel slices of its 8x8 block as one stream of steps (a block's prologue and its exposed first loads
+//     are paid once per block, not once per slice; output stores happen three times inside the stream, once at its end);
+//   * issues the 48 MFMAs of a step as two halves of 24 that rotate over FOUR accumulators (tiles 0, 1 then 2, 3; upper and
+//     lower pixel half): consecutive MFMAs never touch the same accumulator, the same one returns after 128 cycles;
+//   * fills the gaps between them with the splits of the operands that come NEXT -- half 1: this step's tiles 2, 3 and the
+//     next step's upper-half weights; half 2: the next step's tiles 0, 1 and lower-half weights -- and with the requests of
+//     the rows and weights two to three steps ahead (double-buffered raw registers; loads return in order and every wait
+//     is for the oldest request).
+// Bit-identical to raster_fwd_feat_x16 (same terms, same order per accumulator).
+template <bool BIG>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void raster_fwd_feat_x16s(
+    int d, int width, int height, int tile_w, int n_tiles, int n_slices, int n_gauss,
+    const float *__restrict__ colors, const float *__restrict__ backgrounds, const int32_t *__restrict__ offsets,
+    int n_isects, const int32_t *__restrict__ blk_rows, const float *__restrict__ wt,
+    const int32_t *__restrict__ gid_s, const float *__restrict__ Tbuf, float *__restrict__ render_colors)
+{
+    constexpr int NB = 4, CS = 128;
+    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * GAGS_BLOCKS_PER_TILE);
+    const int blk = logical & 3;
+    const int tile = gags_tile_of_order(logical >> 2, tile_w, n_tiles / tile_w);
+    const int lane = threadIdx.x;
+    BlockGeom64 g;
+    g.init(tile, blk, tile_w, width, height, lane);
+    const int p = g.p, k = g.k;
+    const int start = offsets[tile];
+    const int end = offsets[tile + 1]  /* n_tiles + 1 entries: the last one is the intersection count */;
+    const int sb = gags_slot_base(start, end, tile, blk);
+    const int cnt = blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk];  // even
+    const int steps = (cnt + 15) >> 4;
+
+    // final transmittance of the lane's own two pixels, parked in LDS: the stores fetch the pixels of their accumulator rows
+    // from the lanes that own them
+    __shared__ __attribute__((aligned(16))) float park[2 * 64];
+    const bool has_bg = backgrounds != nullptr;  // wave-uniform
+    {
+        const int pjc = min(g.pj, width - 1);
+        const float tA = has_bg ? Tbuf[(size_t)min(g.piA, height - 1) * width + pjc] : 0.f;
+        const float tB = has_bg ? Tbuf[(size_t)min(g.piB, height - 1) * width + pjc] : 0.f;
+        *reinterpret_cast<float2 *>(park + 2 * lane) = make_float2(tA, tB);
+    }
+    float bgv[NB];
+    fetch_bg<NB>(bgv, backgrounds, 0, p, d);
+
+    f32x16 accA[NB], accB[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accA[j][r] = 0.f; accB[j][r] = 0.f; }
+
+    // a slice's accumulators -> render_colors (+ T * background), then zeros for the next slice
+    auto flush = [&](int slice) __attribute__((always_inline)) {
+        float TqA[16], TqB[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = (r & 3) + 8 * (r >> 2) + 4 * k;
+            const float2 t = *reinterpret_cast<const float2 *>(park + 2 * q);
+            TqA[r] = t.x; TqB[r] = t.y;
+        }
+        BlockGeom half;
+        half.p = p; half.k = k; half.bx0 = g.bx0;
+        half.by0 = g.by0;
+        store_rows<NB>(accA, half, width, height, d, slice * CS, has_bg, render_colors, bgv, TqA);
+        half.by0 = g.by0 + 4;
+        store_rows<NB>(accB, half, width, height, d, slice * CS, has_bg, render_colors, bgv, TqB);
+        if (slice + 1 < n_slices) fetch_bg<NB>(bgv, backgrounds, (slice + 1) * CS, p, d);
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accA[j][r] = 0.f; accB[j][r] = 0.f; }
+    };
+
+    if (steps == 0) {  // nothing blended into this block: background only
+        for (int slice = 0; slice < n_slices; ++slice) flush(slice);
+        return;
+    }
+
+    const unsigned gmax = (unsigned)(n_gauss - 1);
+    const unsigned id_off = (unsigned)(sb + 8 * k + (lane & 7)) * 4u;  // (slot indices stay below 2^29)
+    auto load_ids = [&](int s) __attribute__((always_inline)) {
+        return *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(gid_s) + (id_off + 64u * (unsigned)s));
+    };
+    const float *wp = wt + (size_t)(sb + 8 * k) * 64 + 2 * p;
+    auto load_w = [&](int s, float2 (&w)[8]) __attribute__((always_inline)) {
+        const float *src = wp + (size_t)s * (16 * 64);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = *reinterpret_cast<const float2 *>(src + i * 64);
+    };
+    const unsigned lane_off = BIG ? (unsigned)(4 * p) : (unsigned)(4 * p) * 4u;
+    const unsigned slice_pitch = BIG ? (unsigned)CS : (unsigned)CS * 4u;
+    const unsigned row_pitch = BIG ? (unsigned)d : (unsigned)d * 4u;
+    const unsigned half_off = BIG ? 2u : 8u;
+    // rows whose ids are `idv`, slice `sl`: channels 128 sl + 4 p + 2 h + {0, 1} of the eight rows of this lane's half
+    auto load_f = [&](unsigned idv, int sl, unsigned h, float2 (&f)[8]) __attribute__((always_inline)) {
+        const unsigned ro = min(idv, gmax) * row_pitch;  // (the zero slots carry id N)
+        unsigned base = lane_off + (unsigned)sl * slice_pitch + h * half_off;
+        asm volatile("" : "+v"(base));  // (keeps the two halves' requests apart: merged into one 16-byte load they could not be refilled separately)
+        const unsigned o[8] = {row_bcast_add<0>(ro, base), row_bcast_add<1>(ro, base), row_bcast_add<2>(ro, base),
+                               row_bcast_add<3>(ro, base), row_bcast_add<4>(ro, base), row_bcast_add<5>(ro, base),
+                               row_bcast_add<6>(ro, base), row_bcast_add<7>(ro, base)};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if constexpr (BIG) f[i] = *reinterpret_cast<const float2 *>(colors + (size_t)o[i]);
+            else f[i] = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(colors) + o[i]);
+        }
+    };
+    auto split_x = [&](const float2 (&f)[8]) __attribute__((always_inline)) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = f[i].x;
+        return split_op(v);
+    };
+    auto split_y = [&](const float2 (&f)[8]) __attribute__((always_inline)) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = f[i].y;
+        return split_op(v);
+    };
+
+    // position of a flattened step: step s of slice sl (past the end: the last slice again, harmless re-reads)
+    struct Cur { int s, sl; };
+    auto adv = [&](Cur c) __attribute__((always_inline)) {
+        Cur r;
+        const bool wrap = c.s + 1 == steps;
+        r.s = wrap ? 0 : c.s + 1;
+        r.sl = wrap ? min(c.sl + 1, n_slices - 1) : c.sl;
+        return r;
+    };
+    const int total = n_slices * steps;
+
+    // raw registers (double-buffered by step parity) and operands
+    float2 F0[2][8], F1[2][8], W[2][8];
+    Op3 aA[2], aB[2], b[NB];
+    Cur c0{0, 0};
+    Cur c1 = adv(c0), c2 = adv(c1), c3 = adv(c2);
+    unsigned idX, idY;  // ids of the steps at c2, c3
+    {
+        // requests in the order of the steady state, so that the counted waits agree on both edges into the loop
+        const unsigned i0 = load_ids(c0.s), i1 = load_ids(c1.s);
+        idX = load_ids(c2.s);
+        idY = load_ids(c3.s);
+        load_w(c0.s, W[0]);
+        load_f(i0, c0.sl, 0, F0[0]);
+        load_f(i0, c0.sl, 1, F1[0]);
+        load_w(c1.s, W[1]);
+        load_f(i1, c1.sl, 0, F0[1]);
+        load_f(i1, c1.sl, 1, F1[1]);
+        aA[0] = split_x(W[0]);
+        aB[0] = split_y(W[0]);
+        b[0] = split_x(F0[0]);
+        b[1] = split_y(F0[0]);
+        load_f(idX, c2.sl, 0, F0[0]);
+        load_w(c2.s, W[0]);
+    }
+
+    // 24 MFMAs on four accumulators in rotation; term pairs smallest first (the order of mfma6 per accumulator)
+#define GAGS_HALF_MFMA(T0, T1, AP)                                                                                   \
+    do {                                                                                                             \
+        constexpr int ta_[6] = {2, 1, 0, 1, 0, 0}, tb_[6] = {0, 1, 2, 0, 1, 0};                                      \
+        _Pragma("unroll") for (int t_ = 0; t_ < 6; ++t_) {                                                           \
+            accA[T0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA[AP].t[ta_[t_]], b[T0].t[tb_[t_]], accA[T0], 0, 0, 0); \
+            accB[T0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aB[AP].t[ta_[t_]], b[T0].t[tb_[t_]], accB[T0], 0, 0, 0); \
+            accA[T1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA[AP].t[ta_[t_]], b[T1].t[tb_[t_]], accA[T1], 0, 0, 0); \
+            accB[T1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aB[AP].t[ta_[t_]], b[T1].t[tb_[t_]], accB[T1], 0, 0, 0); \
+        }                                                                                                            \
+    } while (0)
+    // interleave: one MFMA, then up to six VALU instructions of the splits (and a request now and then)
+#define GAGS_HALF_SCHED(NLOADS)                                                      \
+    do {                                                                             \
+        _Pragma("unroll") for (int q_ = 0; q_ < 24; ++q_) {                          \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       \
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                       \
+            if (q_ >= 24 - (NLOADS)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
+        }                                                                            \
+    } while (0)
+
+    auto step = [&](auto par_) __attribute__((always_inline)) {
+        constexpr int P = decltype(par_)::value, Q = P ^ 1;
+        const Cur c4 = adv(c3);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- half 1: tiles 0, 1 of this step | tiles 2, 3 of this step and the next step's upper-half weights ----
+        const unsigned idZ = load_ids(c4.s);  // (this iteration's oldest request)
+        b[2] = split_x(F1[P]);
+        b[3] = split_y(F1[P]);
+        aA[Q] = split_x(W[Q]);
+        load_f(idX, c2.sl, 1, F1[P]);
+        GAGS_HALF_MFMA(0, 1, P);
+        GAGS_HALF_SCHED(9);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- half 2: tiles 2, 3 | the next step's tiles 0, 1 and lower-half weights ----
+        b[0] = split_x(F0[Q]);
+        b[1] = split_y(F0[Q]);
+        aB[Q] = split_y(W[Q]);
+        load_f(idY, c3.sl, 0, F0[Q]);
+        load_w(c3.s, W[Q]);
+        GAGS_HALF_MFMA(2, 3, P);
+        GAGS_HALF_SCHED(16);
+        __builtin_amdgcn_sched_barrier(0);
+        idX = idY;
+        idY = idZ;
+        const bool slice_done = c0.s + 1 == steps;
+        const int slice = c0.sl;
+        c0 = c1; c1 = c2; c2 = c3; c3 = c4;
+        if (slice_done) flush(slice);
+    };
+    for (int n = 0; n < total; n += 2) {
+        step(std::integral_constant<int, 0>{});
+        if (n + 1 < total) step(std::integral_constant<int, 1>{});
+    }
+#undef GAGS_HALF_MFMA
+#undef GAGS_HALF_SCHED
+}
+
 template <int NB>
 __global__ __launch_bounds__(64, (NB >= 16 ? 1 : 2)) void raster_fwd_fused(
     int d, int width, int height, int tile_w, int n_tiles, int n_slices, const GRec *__restrict__ packed,
@@ -506,7 +933,7 @@ int launch_feat(int d, int ch_base, int ch_count, int width, int height, int n_g
 // narrow one, all on the matrix cores and into ONE output tensor.  Rows of an odd width are only 4-byte (fp16 table:
 // 2-byte) aligned; vector loads / stores of global memory tolerate that on this part (unaligned access mode).
 template <bool HALF>
-int launch_feat_any(int d, int width, int height, int n_gauss, const float *colors, int f16_mfma,
+int launch_feat_any(int d, int width, int height, int n_gauss, const float *colors, int f16_mfma, int exact,
                     const float *backgrounds, const int32_t *offsets, int n_isects, const int32_t *blk_rows,
                     const float *wt, const int32_t *gid_s, const float *Tbuf, float *out, hipStream_t st)
 {
@@ -525,6 +952,29 @@ int launch_feat_any(int d, int width, int height, int n_gauss, const float *colo
             } else {
                 rc = launch_feat<4, true>(d, 0, done, ARGS);
             }
+        } else if (!exact) {  // the default: 16-bit matrix cores on fp32-equivalent split operands
+            const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
+            const int n_tiles = tile_w * tile_h, n_slices = done / 128;
+            const bool small = (int64_t)n_gauss * d * 4 + 4096 < (1ll << 32);
+            const char *var = getenv("GAGS_X16_VARIANT");  // (experiment switch; removed once the stream kernel is settled)
+            if (!(var && var[0] == '5')) {
+                if (small)
+                    hipLaunchKernelGGL(raster_fwd_feat_x16<false>, dim3(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices), dim3(64), 0, st, d,
+                                       width, height, tile_w, n_tiles, n_slices, n_gauss, colors, backgrounds, offsets, n_isects,
+                                       blk_rows, wt, gid_s, Tbuf, out);
+                else
+                    hipLaunchKernelGGL(raster_fwd_feat_x16<true>, dim3(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices), dim3(64), 0, st, d,
+                                       width, height, tile_w, n_tiles, n_slices, n_gauss, colors, backgrounds, offsets, n_isects,
+                                       blk_rows, wt, gid_s, Tbuf, out);
+            } else if (small)
+                hipLaunchKernelGGL(raster_fwd_feat_x16s<false>, dim3(n_tiles * GAGS_BLOCKS_PER_TILE), dim3(64), 0, st, d, width, height,
+                                   tile_w, n_tiles, n_slices, n_gauss, colors, backgrounds, offsets, n_isects, blk_rows, wt, gid_s,
+                                   Tbuf, out);
+            else
+                hipLaunchKernelGGL(raster_fwd_feat_x16s<true>, dim3(n_tiles * GAGS_BLOCKS_PER_TILE), dim3(64), 0, st, d, width, height,
+                                   tile_w, n_tiles, n_slices, n_gauss, colors, backgrounds, offsets, n_isects, blk_rows, wt, gid_s,
+                                   Tbuf, out);
+            GAGS_CHECK_LAUNCH();
         } else {
             rc = launch_feat<4, HALF>(d, 0, done, ARGS);
         }
@@ -556,15 +1006,15 @@ int launch_fused(int d, int width, int height, const GRec *packed, const float *
 }  // namespace
 
 // feature pass of the split forward (after gags_raster_weights_launch)
-int gags_raster_fwd_feat_launch(int d, int width, int height, int n_gauss, const float *colors, int colors_f16,
+int gags_raster_fwd_feat_launch(int d, int width, int height, int n_gauss, const float *colors, int colors_f16, int exact,
                                 const float *backgrounds, const int32_t *offsets, int n_isects,
                                 const int32_t *blk_rows, const float *wt, const int32_t *gid_s, const float *Tbuf,
                                 float *out, hipStream_t st)
 {
     GAGS_CLEAR_ERR();
 #define ARGS backgrounds, offsets, n_isects, blk_rows, wt, gid_s, Tbuf, out, st
-    if (colors_f16) return launch_feat_any<true>(d, width, height, n_gauss, colors, colors_f16 == 2, ARGS);
-    return launch_feat_any<false>(d, width, height, n_gauss, colors, 0, ARGS);
+    if (colors_f16) return launch_feat_any<true>(d, width, height, n_gauss, colors, colors_f16 == 2, exact, ARGS);
+    return launch_feat_any<false>(d, width, height, n_gauss, colors, 0, exact, ARGS);
 #undef ARGS
 }
 

@@ -16,7 +16,8 @@
 //   blk_rows[blk]  : number of slots of the block (even);
 //   Tbuf / render_alphas / last_ids : per-pixel results of the chain.
 // Slots of a block live in a fixed, sparse region of the slot space (no counting pre-pass):
-//   region(tile, blk) = 4*(offsets[tile] + tile) + blk * even(L_tile), capacity even(L_tile).
+//   region(tile, blk) = 4*offsets[tile] + 64*tile + blk * r16(L_tile), capacity r16(L_tile) = L_tile rounded up to 16
+//   (gags_slot_base); the slots behind the block's count, up to the next multiple of 16, are zero slots.
 // 8x8 rather than 8x4 blocks: a Gaussian then leaves ~36 % fewer (block, slot) rows, and those rows are the
 // backward's HBM traffic; the price is ~30 % more zero weights inside the MFMA tiles.
 #include "raster_mfma_common.h"
@@ -133,13 +134,15 @@ __global__ __launch_bounds__(64, 8) void raster_weights_kernel(
         };
         while (kstep()) {}
     }
-    if ((row - sb) & 1) {  // consumers take slots in pairs: pad with one zero slot that belongs to no Gaussian
-        if (k == 0) {
-            *reinterpret_cast<float2 *>(wt + (size_t)row * 64 + 2 * p) = make_float2(0.f, 0.f);
-            if (p == 0) { gid_s[row] = n_gauss; sidx_s[row] = -1; }
-        }
-        row += 1;
+    const int used = row - sb;
+    const int cnt = (used + 1) & ~1;  // consumers take slots in pairs: an odd count is padded with one zero slot that belongs to no Gaussian
+    // ... and the region is filled with zero slots up to the next multiple of 16 (its capacity is one: gags_slot_base), so
+    // that the 16-slot steps of the 16-bit matrix-core feature pass need neither a clamp nor a mask
+    for (int r = used + k; r < ((used + 15) & ~15); r += 2) {
+        *reinterpret_cast<float2 *>(wt + (size_t)(sb + r) * 64 + 2 * p) = make_float2(0.f, 0.f);
+        if (p == 0) { gid_s[sb + r] = n_gauss; sidx_s[sb + r] = -1; }
     }
+    row = sb + cnt;
     if (lane == 0) blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk] = row - sb;
     {
         const auto cA = __builtin_amdgcn_permlane32_swap((unsigned)sA.cur, (unsigned)sA.cur, false, false);

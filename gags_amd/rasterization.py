@@ -367,7 +367,7 @@ class _Rasterize(torch.autograd.Function):
                     half, colors = False, colors.float()
         if split:
             blk_rows = torch.empty(offsets.numel() * 4, dtype=torch.int32, device=dev)  # per 8x8 pixel block
-        cflags = ((flags & 3) | _lib.GAGS_RECS_BY_GAUSSIAN | (_lib.GAGS_FEAT_F16 if half else 0)
+        cflags = ((flags & 3) | (flags & _lib.GAGS_FWD_EXACT) | _lib.GAGS_RECS_BY_GAUSSIAN | (_lib.GAGS_FEAT_F16 if half else 0)
                   | (64 if (half and d >= 128 and (flags & _lib.GAGS_FWD_F16MFMA)) else 0))
 
         def launch(extra=0):

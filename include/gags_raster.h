@@ -49,6 +49,11 @@ extern "C" {
 #define GAGS_FWD_F16MFMA 64    /* with GAGS_FEAT_F16 and D % 128 == 0, opt-in: the feature pass contracts on the 16-bit matrix
                                   cores (features exact, weights as fp16 head + tail: ~2^-22 per term, not bit-identical) */
 
+#define GAGS_FWD_EXACT 2048    /* fp32 table, D >= 128: contract the feature pass with v_mfma_f32_32x32x2_f32 -- bit-for-bit the
+                                  sequential fmaf chain of the algorithm (what the oracle computes) -- instead of the default
+                                  16-bit matrix cores on operands split into three bf16 terms (exact operands, products to
+                                  2^-23: as close to the float64 statement, 3x faster, not bit-identical to the chain) */
+
 #define GAGS_FWD_ONLY_WEIGHTS 512   /* split forward: launch the weights pass only (alphas, last_ids, scratch) ... */
 #define GAGS_FWD_ONLY_FEATURES 1024 /* ... or the feature pass only, on the scratch a GAGS_FWD_ONLY_WEIGHTS call left: lets a
                                   caller bracket the two kernels with its own events (bench.py's per-kernel roofline) */

@@ -344,6 +344,55 @@ void orc_raster_fwd(int D, int width, int height, int tile_w, int tile_h,
 }
 
 /* ------------------------------------------------------------------------------------
+ * K9 with the COLOUR SUMS in double: the same fp32 alpha / transmittance chain, skip and stop
+ * decisions as orc_raster_fwd (so the same weights, bit for bit), but every product c * (alpha T)
+ * is formed and accumulated in float64 and the result is returned in float64.  This is the
+ * yardstick for contraction kernels that are fp32-equivalent without being bit-identical to the
+ * sequential fmaf chain (the 16-bit matrix-core feature pass): "how far is each kernel from the
+ * exact sum of these fp32 products".  Writes render_colors64 only (tile subset as above).
+ * ---------------------------------------------------------------------------------- */
+void orc_raster_fwd_acc64(int D, int width, int height, int tile_w, int tile_h,
+                          const float *means2d, const float *conics, const float *opacities,
+                          const float *colors, const float *backgrounds,
+                          const int32_t *tile_offsets, const int32_t *flatten_ids, int64_t n_isects,
+                          int tile_begin, int tile_step, double *render_colors64)
+{
+    const int n_tiles = tile_w * tile_h;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int tile = tile_begin; tile < n_tiles; tile += tile_step) {
+        const int ty = tile / tile_w, tx = tile % tile_w;
+        const int64_t start = tile_offsets[tile];
+        const int64_t end = (tile == n_tiles - 1) ? n_isects : tile_offsets[tile + 1];
+        double *acc = (double *)malloc(sizeof(double) * (size_t)D);
+        for (int ly = 0; ly < ORC_TILE; ++ly)
+            for (int lx = 0; lx < ORC_TILE; ++lx) {
+                const int i = ty * ORC_TILE + ly, j = tx * ORC_TILE + lx;
+                if (i >= height || j >= width) continue;
+                const float px = (float)j + 0.5f, py = (float)i + 0.5f;
+                float T = 1.0f;
+                for (int k = 0; k < D; ++k) acc[k] = 0.0;
+                for (int64_t s = start; s < end; ++s) {
+                    const int32_t g = flatten_ids[s];
+                    const float dx = means2d[2 * g] - px, dy = means2d[2 * g + 1] - py;
+                    const float ca = conics[3 * g], cb = conics[3 * g + 1], cc = conics[3 * g + 2];
+                    const float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
+                    const float alpha = fminf(ORC_ALPHA_MAX, opacities[g] * orc_exp_neg(sigma));
+                    if (sigma < 0.f || alpha < ORC_ALPHA_MIN) continue;
+                    const float next_T = T * (1.0f - alpha);
+                    if (next_T <= ORC_T_STOP) break;
+                    const double vis = (double)(alpha * T);
+                    const float *c = colors + (size_t)g * D;
+                    for (int k = 0; k < D; ++k) acc[k] += (double)c[k] * vis;
+                    T = next_T;
+                }
+                double *o = render_colors64 + ((size_t)i * width + j) * D;
+                for (int k = 0; k < D; ++k) o[k] = acc[k] + (backgrounds ? (double)T * (double)backgrounds[k] : 0.0);
+            }
+        free(acc);
+    }
+}
+
+/* ------------------------------------------------------------------------------------
  * K10  rasterize backward, back-to-front replay from last_ids.
  * v_colors [N,D], v_opacities [N], v_means2d [N,2], v_conics [N,3] must be zeroed by the
  * caller; any of the three geometry outputs may be NULL together (colours-only mode,

@@ -126,6 +126,26 @@ def raster_fwd(means2d, conics, opacities, colors, backgrounds, width, height, i
     return out, alphas, last, dict(n_eval=n_eval.value, n_blend=n_blend.value)
 
 
+def raster_fwd_acc64(means2d, conics, opacities, colors, backgrounds, width, height, isect_offsets, flatten_ids,
+                     tile_begin=0, tile_step=1):
+    """The forward with its colour sums formed in float64 on the SAME fp32 weights (orc_raster_fwd_acc64): the yardstick
+    for fp32-equivalent contraction kernels.  Returns render_colors [H,W,D] float64 (tiles outside the subset: zeros)."""
+    colors = _f32(colors)
+    D = colors.shape[1]
+    tile_h, tile_w = isect_offsets.shape
+    out = np.zeros((height, width, D), np.float64)
+    flat = np.ascontiguousarray(flatten_ids, dtype=np.int32)
+    if flat.size == 0:
+        flat = np.zeros(1, np.int32)
+    bg = None if backgrounds is None else _f32(backgrounds)
+    lib().orc_raster_fwd_acc64(ctypes.c_int(D), ctypes.c_int(width), ctypes.c_int(height), ctypes.c_int(tile_w),
+                               ctypes.c_int(tile_h), _p(_f32(means2d)), _p(_f32(conics)), _p(_f32(opacities)),
+                               _p(colors), _p(bg), _p(np.ascontiguousarray(isect_offsets, dtype=np.int32)), _p(flat),
+                               ctypes.c_int64(len(flatten_ids)), ctypes.c_int(tile_begin), ctypes.c_int(tile_step),
+                               _p(out))
+    return out
+
+
 def raster_bwd(means2d, conics, opacities, colors, backgrounds, width, height, isect_offsets, flatten_ids,
                render_alphas, last_ids, v_render_colors, v_render_alphas=None, colors_only=False,
                tile_begin=0, tile_step=1):

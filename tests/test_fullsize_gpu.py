@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import rel_l2, scene_arrays, to_dev
+from helpers import FWD_SPLIT_TOL, rel_l2, scene_arrays, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -41,6 +41,19 @@ def _big_rel_l2(gpu_t, host_np, chunk=1 << 27):
         num += float(((flat[o:o + chunk].double() - r) ** 2).sum())
         den += float((r ** 2).sum())
     return (num / max(den, 1e-300)) ** 0.5
+
+
+def _check_big_forward(out_t, o_out, rerender_exact):
+    """The default render (D >= 128: 16-bit matrix cores on split operands) within FWD_SPLIT_TOL of the oracle's fmaf chain,
+    and the GAGS_FWD_EXACT render of the same inputs bit-identical to it."""
+    if o_out.shape[-1] < 128:
+        assert _big_equal(out_t, o_out), "forward render differs from the oracle"
+        return
+    e = _big_rel_l2(out_t, o_out)
+    assert e <= FWD_SPLIT_TOL, e
+    with torch.no_grad():
+        ex = rerender_exact()
+    assert _big_equal(ex, o_out), "exact forward render differs from the oracle"
 
 
 def _activated(n, d, w, h, seed, scale0=None):
@@ -80,7 +93,10 @@ def _full_size_case(oracle, n, w, h, d, seed, backward=True, scale0=None, bgv=0.
     np.testing.assert_array_equal(info["depths"][0].detach().cpu().numpy(), oi["depths"])
     np.testing.assert_array_equal(info["last_ids"].cpu().numpy(), oi["last_ids"])
     np.testing.assert_array_equal(alphas[0, ..., 0].detach().cpu().numpy(), o_alpha)
-    assert _big_equal(out[0].detach(), o_out), "forward render differs from the oracle"  # bit-exact forward
+    from gags_amd import _lib
+    _check_big_forward(out[0].detach(), o_out, lambda: rasterization(
+        t["means"], t["quats"], t["scales"], t["opacities"], cols.detach(), vm[None], K[None], w, h,
+        backgrounds=None if bg is None else bg[None], raster_flags=_lib.GAGS_FWD_EXACT)[0][0])  # bit-exact forward
     stats = dict(n_isects=oi["n_isects"], visible=int((oi["radii"] > 0).sum()), n_blend=oi["n_blend"])
     if not backward:
         return stats
@@ -209,8 +225,15 @@ def test_c3_heavy_splats_at_the_full_width_on_a_tile_sample(oracle):
     ph = pix.cpu().numpy()
     np.testing.assert_array_equal(alphas[0, ..., 0].detach().cpu().numpy()[ph], o_alpha[ph])
     np.testing.assert_array_equal(info["last_ids"].cpu().numpy()[ph], oi["last_ids"][ph])
-    assert torch.equal(out[0].detach()[pix], torch.from_numpy(o_out[ph]).to(dev)), "render differs on the sampled tiles"
-    del o_out
+    from gags_amd import _lib
+    ref_px = torch.from_numpy(o_out[ph]).to(dev)
+    e = ((out[0].detach()[pix].double() - ref_px.double()).norm() / ref_px.double().norm()).item()
+    assert e <= FWD_SPLIT_TOL, e
+    with torch.no_grad():
+        ex = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], cols.detach(), vm[None], K[None], w, h,
+                           backgrounds=bg[None], raster_flags=_lib.GAGS_FWD_EXACT)[0][0]
+    assert torch.equal(ex[pix], ref_px), "exact render differs on the sampled tiles"
+    del o_out, ex, ref_px
     gen = torch.Generator(device=dev).manual_seed(100)
     v_out = torch.randn(h, w, d, device=dev, generator=gen) * pix[..., None]
     (out[0] * v_out).sum().backward()
@@ -262,6 +285,48 @@ def test_c5_as_stated_fp16_table(oracle, d):
         assert rel_l2(g, o_vf[:, 512]) <= 5e-4
 
 
+def test_default_forward_is_as_close_to_float64_as_the_exact_kernel(oracle):
+    """What makes the 16-bit matrix-core forward the default: against the float64 sum of the SAME fp32 products (the oracle's
+    alpha / transmittance chain, colour sums in double: orc_raster_fwd_acc64) on every 64th tile of the C3 view it is as
+    close as the kernel that is the sequential fp32 fmaf chain -- measured 1.98e-7 against 1.99e-7 on bench.py's very inputs,
+    1.94e-7 against 1.70e-7 here (rows of mixed magnitude, background 0.5): asserted within 25 % of it and below 3e-7.  And with the features rescaled by 2^60 / 2^-60 and every third row by another 2^-20 (rows of very different
+    magnitude in one step) the relative error does not move: bf16 terms keep fp32's exponent range, nothing is scaled."""
+    from gags_amd import _lib, synthetic as syn
+    from gags_amd.rasterization import rasterization
+    c = syn.CONFIGS["C3"]
+    n, w, h, d, step = c["n"], c["width"], c["height"], c["d"], 64
+    dev = torch.device("cuda", 0)
+    t, vm, K, _, _ = _activated(n, d, w, h, 0)
+    bg = torch.full((d,), 0.5, device=dev)
+    tw, th = (w + 15) // 16, (h + 15) // 16
+    pix = (torch.arange(th * tw, device=dev) % step == 0).view(th, tw).repeat_interleave(16, 0).repeat_interleave(16, 1)[:h, :w]
+    ph = pix.cpu().numpy()
+    hv = {k: v.cpu().numpy() for k, v in t.items()}
+    errs = {}
+    with torch.no_grad():
+        for scale in (1.0, 2.0 ** 60, 2.0 ** -60):
+            feat = t["colors"] * scale
+            feat[::3] *= 2.0 ** -20
+            _, _, oi = oracle.rasterization(hv["means"], hv["quats"], hv["scales"], hv["opacities"], feat[:, :4].cpu().numpy(),
+                                            vm.cpu().numpy(), K.cpu().numpy(), None, w, h, tile_begin=0, tile_step=1 << 20)
+            ref = oracle.raster_fwd_acc64(oi["means2d"], oi["conics"], hv["opacities"], feat.cpu().numpy(),
+                                          (bg * scale).cpu().numpy(), w, h, oi["isect_offsets"], oi["flatten_ids"],
+                                          tile_begin=0, tile_step=step)[ph]
+            for name, fl in (("default", 0), ("exact", _lib.GAGS_FWD_EXACT)):
+                out = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], feat, vm[None], K[None], w, h,
+                                    backgrounds=(bg * scale)[None], raster_flags=fl)[0][0]
+                got = out[pix].double().cpu().numpy()
+                errs[(name, scale)] = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+                del out, got
+            del ref
+    print("forward vs the float64 sum of the same products:", errs)
+    for scale in (1.0, 2.0 ** 60, 2.0 ** -60):
+        assert errs[("default", scale)] <= 1.25 * errs[("exact", scale)] + 1e-9, errs
+        assert errs[("default", scale)] <= 3e-7, errs
+    assert abs(errs[("default", 2.0 ** 60)] - errs[("default", 1.0)]) <= 1e-9 and \
+        abs(errs[("default", 2.0 ** -60)] - errs[("default", 1.0)]) <= 1e-9, errs
+
+
 def test_colour_gradient_accuracy_against_float64(oracle):
     """DESIGN.md section 2's deviation as a test.  gsplat rebuilds T in the backward from 1 - render_alpha, which
     cancels on nearly saturated pixels; the HIP colours-only backward uses the forward's own alpha*T.  Against the
@@ -293,7 +358,7 @@ def test_colour_gradient_accuracy_against_float64(oracle):
     cols = to_dev(s["colors"]).requires_grad_(True)
     out, _, info = rasterization(to_dev(s["means"]), to_dev(s["quats"]), to_dev(s["scales"]), to_dev(opac), cols,
                                  to_dev(s["viewmat"])[None], to_dev(s["K"])[None], w, h, backgrounds=to_dev(bg)[None])
-    np.testing.assert_array_equal(out[0].detach().cpu().numpy(), o_out)
+    assert rel_l2(out[0].detach().cpu().numpy(), o_out) <= FWD_SPLIT_TOL
     (out[0] * to_dev(v_out)).sum().backward()
     e_hip = rel_l2(cols.grad.cpu().numpy(), ref)
     e_gsplat = rel_l2(o_vc, ref)
@@ -342,7 +407,7 @@ def test_c2_all_gradients_against_the_oracle(oracle):
     vmh, Kh, bgh = vm.cpu().numpy(), K.cpu().numpy(), bg.cpu().numpy()
     o_out, o_alpha, oi = oracle.rasterization(hv["means"], hv["quats"], hv["scales"], hv["opacities"], hv["colors"], vmh, Kh,
                                               bgh, w, h)
-    assert _big_equal(out[0].detach(), o_out)
+    assert _big_rel_l2(out[0].detach(), o_out) <= FWD_SPLIT_TOL
     o_vc, o_vo, o_vm2, o_vcon = oracle.raster_bwd(oi["means2d"], oi["conics"], hv["opacities"], hv["colors"], bgh, w, h,
                                                   oi["isect_offsets"], oi["flatten_ids"], o_alpha, oi["last_ids"],
                                                   v_out.cpu().numpy(), v_alpha.cpu().numpy())

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import rel_l2, scene_arrays, to_dev
+from helpers import FWD_SPLIT_TOL, check_forward, rel_l2, scene_arrays, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -49,6 +49,15 @@ def _run_gpu(s, width, height, colors, bg, render_mode="RGB", sh_degree=None, ne
                          means2d=info["means2d"].grad[0].cpu().numpy())
     torch.cuda.synchronize()
     return out[0].detach().cpu().numpy(), alphas[0, ..., 0].detach().cpu().numpy(), info, grads
+
+
+def _exact_forward(s, width, height, colors, bg, **kw):
+    """The same render through the kernel that is the oracle's fmaf chain (GAGS_FWD_EXACT), for widths whose default is the
+    16-bit matrix-core forward; None below 128 channels (the default IS exact there)."""
+    from gags_amd import _lib
+    if colors.shape[-1] < 128:
+        return None
+    return _run_gpu(s, width, height, colors, bg, flags=_lib.GAGS_FWD_EXACT, **kw)[0]
 
 
 def _check_indices(info, oinfo):
@@ -92,7 +101,7 @@ def test_forward_and_colour_grad(oracle, n, w, h, d, seed, view, mult, bgv):
     out, alpha, info, grads = _run_gpu(s, w, h, s["colors"], bg, v_out=v_out)
     _check_indices(info, oinfo)
     np.testing.assert_array_equal(alpha, o_alpha)
-    np.testing.assert_array_equal(out, o_out)  # bit-exact forward
+    check_forward(out, o_out, _exact_forward(s, w, h, s["colors"], bg))  # bit-exact forward (D >= 128: through GAGS_FWD_EXACT; default within FWD_SPLIT_TOL)
     # gsplat-order oracle (T rebuilt back to front from 1 - render_alpha: cancellation-prone on saturated
     # pixels) and forward-order oracle (same sum, alpha*T recomputed front to back).  The VALU kernels follow
     # the former, the MFMA colours-only kernel the latter; either way the looser gsplat-order bound holds.
@@ -112,7 +121,7 @@ def test_mfma_and_valu_paths_agree_bitwise(oracle):
     n, w, h, d = 4000, 192, 144, 128
     s = scene_arrays(n, d, w, h, seed=12, view=2, scale_mult=5.0)
     bg = np.full(d, 0.7, np.float32)
-    a, aa, ia, _ = _run_gpu(s, w, h, s["colors"], bg)
+    a, aa, ia, _ = _run_gpu(s, w, h, s["colors"], bg, flags=_lib.GAGS_FWD_EXACT)
     for flags in (_lib.GAGS_FWD_NO_MFMA, _lib.GAGS_FWD_FUSED):
         b, ab, ib, _ = _run_gpu(s, w, h, s["colors"], bg, flags=flags)
         np.testing.assert_array_equal(a, b)
@@ -220,7 +229,7 @@ def test_width_with_extra_channels(oracle, d):
                                                  s["K"], bg, w, h)
     out, alpha, info, grads = _run_gpu(s, w, h, s["colors"], bg, v_out=v_out)
     _check_indices(info, oinfo)
-    np.testing.assert_array_equal(out, o_out)
+    check_forward(out, o_out, _exact_forward(s, w, h, s["colors"], bg))
     o_vf = oracle.raster_bwd_colors_fwdorder(oinfo["means2d"], oinfo["conics"], s["opacities"], d, w, h, oinfo["isect_offsets"],
                                              oinfo["flatten_ids"], v_out, n)
     assert rel_l2(grads["colors"], o_vf) <= GRAD_TOL
@@ -316,8 +325,8 @@ def test_backward_kernels_on_both_matrix_pipes_are_within_tolerance(oracle):
     _, _, _, g_def2 = _run_gpu(s, w, h, s["colors"], bg, v_out=v_out)
     out2, _, _, g_f32 = _run_gpu(s, w, h, s["colors"], bg, v_out=v_out, flags=_lib.GAGS_BWD_F32MFMA)
     _, _, _, g_f32b = _run_gpu(s, w, h, s["colors"], bg, v_out=v_out, flags=_lib.GAGS_BWD_F32MFMA)
-    np.testing.assert_array_equal(out, o_out)
-    np.testing.assert_array_equal(out2, o_out)
+    check_forward(out, o_out, _exact_forward(s, w, h, s["colors"], bg))
+    np.testing.assert_array_equal(out2, out)
     np.testing.assert_array_equal(g_def["colors"], g_def2["colors"])
     np.testing.assert_array_equal(g_f32["colors"], g_f32b["colors"])
     # per channel (the scales differ by 12 orders of magnitude: a global rel-L2 would only see the largest columns)
@@ -459,7 +468,7 @@ def test_full_backward(oracle, n, w, h, d, seed, view):
     o_vmeans, o_vq, o_vs = oracle.project_bwd(s["means"], s["quats"], s["scales"], s["viewmat"], s["K"], w, h,
                                               oinfo["radii"], o_vm2, None, o_vcon)
     out, alpha, info, g = _run_gpu(s, w, h, s["colors"], bg, need_geom=True, v_out=v_out, v_alpha=v_alpha)
-    np.testing.assert_array_equal(out, o_out)
+    check_forward(out, o_out, _exact_forward(s, w, h, s["colors"], bg))
     assert rel_l2(g["colors"], o_vc) <= GRAD_TOL
     assert rel_l2(g["opacities"], o_vo) <= 1e-4
     assert rel_l2(g["means2d"], o_vm2) <= 1e-4
@@ -858,11 +867,15 @@ def test_full_size_properties_c3():
     out = pkg["render"].detach()
     radii = pkg["radii"]
     assert out.shape == (d, h, w) and torch.isfinite(out).all()
-    # (1) the matrix-core split forward and the VALU kernel are the same fmaf chain: identical bits at full size
+    # (1) the exact matrix-core forward (GAGS_FWD_EXACT) and the VALU kernel are the same fmaf chain: identical bits at full
+    # size; the default forward (16-bit matrix cores, split operands) is the same sum within FWD_SPLIT_TOL
     pkv = fwd(_lib.GAGS_FWD_NO_MFMA)
-    assert torch.equal(out, pkv["render"].detach())
+    pke = fwd(_lib.GAGS_FWD_EXACT)
+    assert torch.equal(pke["render"].detach(), pkv["render"].detach())
     assert torch.equal(pkg["alphas"], pkv["alphas"]) and torch.equal(pkg["info"]["last_ids"], pkv["info"]["last_ids"])
-    del pkv
+    e = ((out.double() - pkv["render"].detach().double()).norm() / pkv["render"].detach().double().norm()).item()
+    assert e <= FWD_SPLIT_TOL, e
+    del pkv, pke
     # (2) determinism and (3) homogeneity (scaling by 2 is exact in fp32)
     g1 = grad_of(pkg, G).clone()
     g1b = grad_of(fwd(), G).clone()

@@ -54,11 +54,11 @@ rows_per_chunk, runs, bursts, chunks_tile, old_tiles = [], [], 0, [], 0
 rng = np.random.default_rng(0)
 for t in rng.choice(nt, size=min(nt, 1500), replace=False):
     s, e = off[t], (I if t == nt - 1 else off[t + 1])
-    lp = (e - s + 1) & ~1
+    lp = (e - s + 15) & ~15  # gags_slot_base (csrc/common.h)
     lists = []
     for b in range(4):
         c = blk[4 * t + b]
-        sb = 4 * (s + t) + b * lp
+        sb = 4 * s + 64 * t + b * lp
         lists.append(trs[sb:sb + c])
         old_tiles += (c + 31) // 32
     r0, R1 = trow[s], trow[e]

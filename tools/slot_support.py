@@ -28,11 +28,11 @@ pkg["render"].sum().backward()
 off, I, br = cap["offsets"], cap["n_isects"], cap["blk_rows"]
 nt = off.numel()
 L = torch.diff(torch.cat([off, torch.tensor([I], device=dev)]))
-evenL = (L + 1) // 2 * 2
+padL = (L + 15) // 16 * 16  # gags_slot_base (csrc/common.h): regions padded to 16 slots
 tile = torch.arange(nt, device=dev)
-base = (4 * (off + tile))[:, None] + torch.arange(4, device=dev)[None, :] * evenL[:, None]   # [tiles, 4]
+base = (4 * off + 64 * tile)[:, None] + torch.arange(4, device=dev)[None, :] * padL[:, None]   # [tiles, 4]
 base = base.reshape(-1); cnt = br.reshape(-1)
-slots_total = 4 * (I + nt) + 64
+slots_total = 4 * I + 64 * nt + 64  # gags_slot_count (csrc/common.h)
 wt = cap["scratch"][: slots_total * 256].view(torch.float32).view(slots_total, 64)
 mark = torch.zeros(slots_total + 1, dtype=torch.int32, device=dev)
 mark.index_add_(0, base, torch.ones_like(base, dtype=torch.int32))
