@@ -13,8 +13,6 @@
 // epilogue stores 16 B per lane.  All D channels of a slice are composited in ONE walk of the list
 // (gsplat re-walks it ceil(D/32) times).
 #include <hip/hip_fp16.h>
-#include <cstdlib>
-#include <type_traits>
 #include "raster_mfma_common.h"
 
 using namespace gags_mfma;
@@ -419,9 +417,10 @@ __global__ __launch_bounds__(64, 2) void raster_fwd_feat_f16(
 // One wave per (tile, 8x8 block, 128-channel slice), K-steps of 16 slots: lane (p, kg) holds, as A operand, the weights of
 // pixel p (upper / lower half of the block) for slots 8 kg .. 8 kg + 7 of the step, and as B operand channel 4 p + j of
 // the same eight slots (tile j = channels ch0 + 4 n + j: the strided tiles of the fp32 kernel, same float4 epilogue).
-// The split is done in registers on the way (9 VALU instructions per pair of values and three terms), in the shadow of the
-// wave's own MFMAs; feature rows are gathered as two float2 halves per slot so that each half's registers are refilled
-// for the next step as soon as its two channel tiles have been split.
+// The split is done in registers on the way (11 VALU instructions per pair of values and three terms: 264 per step), then the
+// next step's rows are requested into the registers the split has freed, then the 48 MFMAs run (four accumulators in
+// rotation).  The ids of a step's slots arrive as ONE vector load (each 16-lane row holds its half-wave's eight ids) and
+// reach the address arithmetic through DPP row broadcasts: one VALU instruction per gathered row.
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void split3_pair(float x, float y, unsigned &t0, unsigned &t1, unsigned &t2)
@@ -611,224 +610,6 @@ __global__ __launch_bounds__(64, 2) void raster_fwd_feat_x16(
     store_rows<NB>(accB, half, width, height, d, ch0, has_bg, render_colors, bgv, TqB);
 }
 
-// ---- the same arithmetic as a stream: ONE wave per SIMD, every split in the shadow of the wave's own MFMAs (the default) ----
-// Measured on raster_fwd_feat_x16 (C3, ablations of its phases): its 264 splitting instructions per 16 slots cost 0.8 ms, its
-// MFMAs 0.55 ms, its output stores 0.55 ms -- and the three ADD UP: while one wave of a SIMD streams MFMAs its partner is issued
-// one instruction per MFMA (hardware finding of round 2), so two waves per SIMD take turns instead of overlapping,
-// and VALU instructions between two MFMAs on the SAME accumulator cost the result-forwarding path (+43 cycles each).  So this
-// kernel gives one wave the SIMD's whole register file (512: accumulators in the AGPRs) and
-//   * walks ALL 128-channel slices of its 8x8 block as one stream of steps (a block's prologue and its exposed first loads
-//     are paid once per block, not once per slice; output stores happen three times inside the stream, once at its end);
-//   * issues the 48 MFMAs of a step as two halves of 24 that rotate over FOUR accumulators (tiles 0, 1 then 2, 3; upper and
-//     lower pixel half): consecutive MFMAs never touch the same accumulator, the same one returns after 128 cycles;
-//   * fills the gaps between them with the splits of the operands that come NEXT -- half 1: this step's tiles 2, 3 and the
-//     next step's upper-half weights; half 2: the next step's tiles 0, 1 and lower-half weights -- and with the requests of
-//     the rows and weights two to three steps ahead (double-buffered raw registers; loads return in order and every wait
-//     is for the oldest request).
-// Bit-identical to raster_fwd_feat_x16 (same terms, same order per accumulator).
-template <bool BIG>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void raster_fwd_feat_x16s(
-    int d, int width, int height, int tile_w, int n_tiles, int n_slices, int n_gauss,
-    const float *__restrict__ colors, const float *__restrict__ backgrounds, const int32_t *__restrict__ offsets,
-    int n_isects, const int32_t *__restrict__ blk_rows, const float *__restrict__ wt,
-    const int32_t *__restrict__ gid_s, const float *__restrict__ Tbuf, float *__restrict__ render_colors)
-{
-    constexpr int NB = 4, CS = 128;
-    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * GAGS_BLOCKS_PER_TILE);
-    const int blk = logical & 3;
-    const int tile = gags_tile_of_order(logical >> 2, tile_w, n_tiles / tile_w);
-    const int lane = threadIdx.x;
-    BlockGeom64 g;
-    g.init(tile, blk, tile_w, width, height, lane);
-    const int p = g.p, k = g.k;
-    const int start = offsets[tile];
-    const int end = offsets[tile + 1]  /* n_tiles + 1 entries: the last one is the intersection count */;
-    const int sb = gags_slot_base(start, end, tile, blk);
-    const int cnt = blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk];  // even
-    const int steps = (cnt + 15) >> 4;
-
-    // final transmittance of the lane's own two pixels, parked in LDS: the stores fetch the pixels of their accumulator rows
-    // from the lanes that own them
-    __shared__ __attribute__((aligned(16))) float park[2 * 64];
-    const bool has_bg = backgrounds != nullptr;  // wave-uniform
-    {
-        const int pjc = min(g.pj, width - 1);
-        const float tA = has_bg ? Tbuf[(size_t)min(g.piA, height - 1) * width + pjc] : 0.f;
-        const float tB = has_bg ? Tbuf[(size_t)min(g.piB, height - 1) * width + pjc] : 0.f;
-        *reinterpret_cast<float2 *>(park + 2 * lane) = make_float2(tA, tB);
-    }
-    float bgv[NB];
-    fetch_bg<NB>(bgv, backgrounds, 0, p, d);
-
-    f32x16 accA[NB], accB[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { accA[j][r] = 0.f; accB[j][r] = 0.f; }
-
-    // a slice's accumulators -> render_colors (+ T * background), then zeros for the next slice
-    auto flush = [&](int slice) __attribute__((always_inline)) {
-        float TqA[16], TqB[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int q = (r & 3) + 8 * (r >> 2) + 4 * k;
-            const float2 t = *reinterpret_cast<const float2 *>(park + 2 * q);
-            TqA[r] = t.x; TqB[r] = t.y;
-        }
-        BlockGeom half;
-        half.p = p; half.k = k; half.bx0 = g.bx0;
-        half.by0 = g.by0;
-        store_rows<NB>(accA, half, width, height, d, slice * CS, has_bg, render_colors, bgv, TqA);
-        half.by0 = g.by0 + 4;
-        store_rows<NB>(accB, half, width, height, d, slice * CS, has_bg, render_colors, bgv, TqB);
-        if (slice + 1 < n_slices) fetch_bg<NB>(bgv, backgrounds, (slice + 1) * CS, p, d);
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { accA[j][r] = 0.f; accB[j][r] = 0.f; }
-    };
-
-    if (steps == 0) {  // nothing blended into this block: background only
-        for (int slice = 0; slice < n_slices; ++slice) flush(slice);
-        return;
-    }
-
-    const unsigned gmax = (unsigned)(n_gauss - 1);
-    const unsigned id_off = (unsigned)(sb + 8 * k + (lane & 7)) * 4u;  // (slot indices stay below 2^29)
-    auto load_ids = [&](int s) __attribute__((always_inline)) {
-        return *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(gid_s) + (id_off + 64u * (unsigned)s));
-    };
-    const float *wp = wt + (size_t)(sb + 8 * k) * 64 + 2 * p;
-    auto load_w = [&](int s, float2 (&w)[8]) __attribute__((always_inline)) {
-        const float *src = wp + (size_t)s * (16 * 64);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) w[i] = *reinterpret_cast<const float2 *>(src + i * 64);
-    };
-    const unsigned lane_off = BIG ? (unsigned)(4 * p) : (unsigned)(4 * p) * 4u;
-    const unsigned slice_pitch = BIG ? (unsigned)CS : (unsigned)CS * 4u;
-    const unsigned row_pitch = BIG ? (unsigned)d : (unsigned)d * 4u;
-    const unsigned half_off = BIG ? 2u : 8u;
-    // rows whose ids are `idv`, slice `sl`: channels 128 sl + 4 p + 2 h + {0, 1} of the eight rows of this lane's half
-    auto load_f = [&](unsigned idv, int sl, unsigned h, float2 (&f)[8]) __attribute__((always_inline)) {
-        const unsigned ro = min(idv, gmax) * row_pitch;  // (the zero slots carry id N)
-        unsigned base = lane_off + (unsigned)sl * slice_pitch + h * half_off;
-        asm volatile("" : "+v"(base));  // (keeps the two halves' requests apart: merged into one 16-byte load they could not be refilled separately)
-        const unsigned o[8] = {row_bcast_add<0>(ro, base), row_bcast_add<1>(ro, base), row_bcast_add<2>(ro, base),
-                               row_bcast_add<3>(ro, base), row_bcast_add<4>(ro, base), row_bcast_add<5>(ro, base),
-                               row_bcast_add<6>(ro, base), row_bcast_add<7>(ro, base)};
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if constexpr (BIG) f[i] = *reinterpret_cast<const float2 *>(colors + (size_t)o[i]);
-            else f[i] = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(colors) + o[i]);
-        }
-    };
-    auto split_x = [&](const float2 (&f)[8]) __attribute__((always_inline)) {
-        float v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = f[i].x;
-        return split_op(v);
-    };
-    auto split_y = [&](const float2 (&f)[8]) __attribute__((always_inline)) {
-        float v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = f[i].y;
-        return split_op(v);
-    };
-
-    // position of a flattened step: step s of slice sl (past the end: the last slice again, harmless re-reads)
-    struct Cur { int s, sl; };
-    auto adv = [&](Cur c) __attribute__((always_inline)) {
-        Cur r;
-        const bool wrap = c.s + 1 == steps;
-        r.s = wrap ? 0 : c.s + 1;
-        r.sl = wrap ? min(c.sl + 1, n_slices - 1) : c.sl;
-        return r;
-    };
-    const int total = n_slices * steps;
-
-    // raw registers (double-buffered by step parity) and operands
-    float2 F0[2][8], F1[2][8], W[2][8];
-    Op3 aA[2], aB[2], b[NB];
-    Cur c0{0, 0};
-    Cur c1 = adv(c0), c2 = adv(c1), c3 = adv(c2);
-    unsigned idX, idY;  // ids of the steps at c2, c3
-    {
-        // requests in the order of the steady state, so that the counted waits agree on both edges into the loop
-        const unsigned i0 = load_ids(c0.s), i1 = load_ids(c1.s);
-        idX = load_ids(c2.s);
-        idY = load_ids(c3.s);
-        load_w(c0.s, W[0]);
-        load_f(i0, c0.sl, 0, F0[0]);
-        load_f(i0, c0.sl, 1, F1[0]);
-        load_w(c1.s, W[1]);
-        load_f(i1, c1.sl, 0, F0[1]);
-        load_f(i1, c1.sl, 1, F1[1]);
-        aA[0] = split_x(W[0]);
-        aB[0] = split_y(W[0]);
-        b[0] = split_x(F0[0]);
-        b[1] = split_y(F0[0]);
-        load_f(idX, c2.sl, 0, F0[0]);
-        load_w(c2.s, W[0]);
-    }
-
-    // 24 MFMAs on four accumulators in rotation; term pairs smallest first (the order of mfma6 per accumulator)
-#define GAGS_HALF_MFMA(T0, T1, AP)                                                                                   \
-    do {                                                                                                             \
-        constexpr int ta_[6] = {2, 1, 0, 1, 0, 0}, tb_[6] = {0, 1, 2, 0, 1, 0};                                      \
-        _Pragma("unroll") for (int t_ = 0; t_ < 6; ++t_) {                                                           \
-            accA[T0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA[AP].t[ta_[t_]], b[T0].t[tb_[t_]], accA[T0], 0, 0, 0); \
-            accB[T0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aB[AP].t[ta_[t_]], b[T0].t[tb_[t_]], accB[T0], 0, 0, 0); \
-            accA[T1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA[AP].t[ta_[t_]], b[T1].t[tb_[t_]], accA[T1], 0, 0, 0); \
-            accB[T1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aB[AP].t[ta_[t_]], b[T1].t[tb_[t_]], accB[T1], 0, 0, 0); \
-        }                                                                                                            \
-    } while (0)
-    // interleave: one MFMA, then up to six VALU instructions of the splits (and a request now and then)
-#define GAGS_HALF_SCHED(NLOADS)                                                      \
-    do {                                                                             \
-        _Pragma("unroll") for (int q_ = 0; q_ < 24; ++q_) {                          \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       \
-            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                       \
-            if (q_ >= 24 - (NLOADS)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
-        }                                                                            \
-    } while (0)
-
-    auto step = [&](auto par_) __attribute__((always_inline)) {
-        constexpr int P = decltype(par_)::value, Q = P ^ 1;
-        const Cur c4 = adv(c3);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- half 1: tiles 0, 1 of this step | tiles 2, 3 of this step and the next step's upper-half weights ----
-        const unsigned idZ = load_ids(c4.s);  // (this iteration's oldest request)
-        b[2] = split_x(F1[P]);
-        b[3] = split_y(F1[P]);
-        aA[Q] = split_x(W[Q]);
-        load_f(idX, c2.sl, 1, F1[P]);
-        GAGS_HALF_MFMA(0, 1, P);
-        GAGS_HALF_SCHED(9);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- half 2: tiles 2, 3 | the next step's tiles 0, 1 and lower-half weights ----
-        b[0] = split_x(F0[Q]);
-        b[1] = split_y(F0[Q]);
-        aB[Q] = split_y(W[Q]);
-        load_f(idY, c3.sl, 0, F0[Q]);
-        load_w(c3.s, W[Q]);
-        GAGS_HALF_MFMA(2, 3, P);
-        GAGS_HALF_SCHED(16);
-        __builtin_amdgcn_sched_barrier(0);
-        idX = idY;
-        idY = idZ;
-        const bool slice_done = c0.s + 1 == steps;
-        const int slice = c0.sl;
-        c0 = c1; c1 = c2; c2 = c3; c3 = c4;
-        if (slice_done) flush(slice);
-    };
-    for (int n = 0; n < total; n += 2) {
-        step(std::integral_constant<int, 0>{});
-        if (n + 1 < total) step(std::integral_constant<int, 1>{});
-    }
-#undef GAGS_HALF_MFMA
-#undef GAGS_HALF_SCHED
-}
-
 template <int NB>
 __global__ __launch_bounds__(64, (NB >= 16 ? 1 : 2)) void raster_fwd_fused(
     int d, int width, int height, int tile_w, int n_tiles, int n_slices, const GRec *__restrict__ packed,
@@ -955,25 +736,14 @@ int launch_feat_any(int d, int width, int height, int n_gauss, const float *colo
         } else if (!exact) {  // the default: 16-bit matrix cores on fp32-equivalent split operands
             const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
             const int n_tiles = tile_w * tile_h, n_slices = done / 128;
-            const bool small = (int64_t)n_gauss * d * 4 + 4096 < (1ll << 32);
-            const char *var = getenv("GAGS_X16_VARIANT");  // (experiment switch; removed once the stream kernel is settled)
-            if (!(var && var[0] == '5')) {
-                if (small)
-                    hipLaunchKernelGGL(raster_fwd_feat_x16<false>, dim3(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices), dim3(64), 0, st, d,
-                                       width, height, tile_w, n_tiles, n_slices, n_gauss, colors, backgrounds, offsets, n_isects,
-                                       blk_rows, wt, gid_s, Tbuf, out);
-                else
-                    hipLaunchKernelGGL(raster_fwd_feat_x16<true>, dim3(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices), dim3(64), 0, st, d,
-                                       width, height, tile_w, n_tiles, n_slices, n_gauss, colors, backgrounds, offsets, n_isects,
-                                       blk_rows, wt, gid_s, Tbuf, out);
-            } else if (small)
-                hipLaunchKernelGGL(raster_fwd_feat_x16s<false>, dim3(n_tiles * GAGS_BLOCKS_PER_TILE), dim3(64), 0, st, d, width, height,
-                                   tile_w, n_tiles, n_slices, n_gauss, colors, backgrounds, offsets, n_isects, blk_rows, wt, gid_s,
-                                   Tbuf, out);
+            if ((int64_t)n_gauss * d * 4 + 4096 < (1ll << 32))
+                hipLaunchKernelGGL(raster_fwd_feat_x16<false>, dim3(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices), dim3(64), 0, st, d,
+                                   width, height, tile_w, n_tiles, n_slices, n_gauss, colors, backgrounds, offsets, n_isects,
+                                   blk_rows, wt, gid_s, Tbuf, out);
             else
-                hipLaunchKernelGGL(raster_fwd_feat_x16s<true>, dim3(n_tiles * GAGS_BLOCKS_PER_TILE), dim3(64), 0, st, d, width, height,
-                                   tile_w, n_tiles, n_slices, n_gauss, colors, backgrounds, offsets, n_isects, blk_rows, wt, gid_s,
-                                   Tbuf, out);
+                hipLaunchKernelGGL(raster_fwd_feat_x16<true>, dim3(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices), dim3(64), 0, st, d,
+                                   width, height, tile_w, n_tiles, n_slices, n_gauss, colors, backgrounds, offsets, n_isects,
+                                   blk_rows, wt, gid_s, Tbuf, out);
             GAGS_CHECK_LAUNCH();
         } else {
             rc = launch_feat<4, HALF>(d, 0, done, ARGS);

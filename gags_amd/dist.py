@@ -176,14 +176,14 @@ def _unpack_rows(grad, idx, c0, c1, wire, local=None):
 class OverlappedGradReducer:
     """By-view step with the gradient exchange overlapped with the backward (SURVEY 8e "overlapped with the tail of
     bwd").  Used as a context manager around ONE `loss.backward()`: the staged backward then produces the feature
-    gradient one 128-channel range at a time (gags_amd.rasterization.GRAD_RANGE_HOOK) and every finished range is
+    gradient one 128-channel range at a time (RasterContext.grad_range_hook) and every finished range is
     packed into a private buffer, summed over the ranks on a second stream while the next range is still being computed,
     and written into the parameter's gradient by finish():
 
         red = OverlappedGradReducer(mode="rs_ag", param=pc._semantic_feature)
         with red:
             loss.backward()
-        red.finish(pc._semantic_feature.grad)     # compute stream waits for the exchange; exact fp32 sum
+        red.finish(pc._semantic_feature.grad)     # compute stream waits for the exchange; the fp32 sum (exact when adopted)
 
     The tensor autograd consumes is never written by the exchange stream (the hook only READS it); the reduced ranges
     live in the reducer until finish().  finish() ASSIGNS them only when the gradient tensor is the very tensor the
@@ -191,15 +191,18 @@ class OverlappedGradReducer:
     the hook saw).  In every other case -- the parameter has a second consumer in the graph (a regulariser on
     `_semantic_feature`: autograd sums the terms into a fresh tensor, or adds in place), accumulation over several views,
     a clone or a cast with unknown history -- the gradient holds terms that are not this backward's local rows, so
-    finish() adds `sum over ranks - local` from the packed local rows it always keeps; terms from other graph paths stay
-    rank-local and are the caller's to reduce (reduce_feature_grad).  A gradient that has been reduced once is never
+    finish() adds `sum over ranks - local` from the packed local rows it always keeps (one more fp32 rounding per element
+    than the assigned sum: grad + (sum - local) is not bit-identical to the sum; the copy costs a second [|union|, 128] block
+    per range until finish() -- whether autograd adopts the hook's tensor, and whether anybody writes to it in place
+    afterwards, is only known then); terms from other graph paths stay rank-local and are the caller's to reduce
+    (reduce_feature_grad).  A gradient that has been reduced once is never
     reduced again.
 
     wire="bf16" (opt-in) halves the bytes on xGMI: the range is rounded to bfloat16, summed in bfloat16 by the
     collective and widened again; the result differs from the fp32 sum by ~1e-2 relative (tests/test_dist_cpu.py
     states and checks the bound), so it is never the default.
     rows="union" (the default): a view's gradient is non-zero only in the rows of the Gaussians that blended into one
-    of its pixels (27 % of N at C3).  The backward hands over that mask first (GRAD_ROWS_HOOK); the ranks take its
+    of its pixels (27 % of N at C3).  The backward hands over that mask first (RasterContext.grad_rows_hook); the ranks take its
     union (a max-all-reduce of N bytes) and every range is exchanged as the [|union|, 128] block of those rows -- the
     same collectives on fewer bytes, the same exact fp32 sum (rows outside the union are zero on every rank).
     rows="all" exchanges all N rows.
@@ -207,13 +210,14 @@ class OverlappedGradReducer:
     untouched gradient.  `exposed_ms()` = time the compute stream spent on the exchange after the backward had finished."""
 
     def __init__(self, mode="rs_ag", wire=None, bucket_bytes=BUCKET_BYTES, rows="union", param=None, sync_free=False,
-                 cap_margin=1.1, cap_slack=1024):
+                 cap_margin=1.1, cap_slack=1024, context=None):
         if rows not in ("union", "all"):
             raise ValueError(rows)
         if wire not in (None, "fp32", "bf16"):
             raise ValueError(wire)
         self.mode, self.wire, self.bucket_bytes, self.rows, self.param = mode, wire, bucket_bytes, rows, param
         self.sync_free, self.cap_margin, self.cap_slack = bool(sync_free), float(cap_margin), int(cap_slack)
+        self.context = context  # the RasterContext whose backward feeds this reducer (None: the entering thread's default)
         self._cap_hint, self._pinned = {}, {}
         self.comm = torch.cuda.Stream() if torch.cuda.is_available() else None
         self.rows_exchanged = None  # |union| of the last step (None: all rows)
@@ -229,14 +233,16 @@ class OverlappedGradReducer:
     def __enter__(self):
         from . import rasterization
         self._reset()
-        self._prev = (rasterization.GRAD_RANGE_HOOK, rasterization.GRAD_ROWS_HOOK)
-        rasterization.GRAD_RANGE_HOOK = self.on_range
-        rasterization.GRAD_ROWS_HOOK = self.on_rows if (self.rows == "union" and world() > 1) else None
+        # the hooks go into ONE RasterContext (the one given, else this thread's default): renders through any other context
+        # -- an evaluation view, another thread -- are not touched
+        self._ctx = self.context if self.context is not None else rasterization.default_context()
+        self._prev = (self._ctx.grad_range_hook, self._ctx.grad_rows_hook)
+        self._ctx.grad_range_hook = self.on_range
+        self._ctx.grad_rows_hook = self.on_rows if (self.rows == "union" and world() > 1) else None
         return self
 
     def __exit__(self, *exc):
-        from . import rasterization
-        rasterization.GRAD_RANGE_HOOK, rasterization.GRAD_ROWS_HOOK = self._prev
+        self._ctx.grad_range_hook, self._ctx.grad_rows_hook = self._prev
         return False
 
     def on_rows(self, mask):
@@ -371,6 +377,7 @@ class OverlappedGradReducer:
                 wire = _pack_rows(self._alias, None, e["c0"], e["c1"], e["wire"].dtype)
                 e.update(idx=None, local=wire.clone(), wire=wire)
                 reduce_feature_grad(wire, mode=self.mode, bucket_bytes=self.bucket_bytes)
+            self.rows_exchanged = None  # (all N rows went over the wire in the end)
         if used:
             # adopted: the parameter's gradient IS the tensor the hook saw (same storage, same shape) and no in-place op
             # touched it since (the alias shares its version counter) => it holds exactly this backward's local rows

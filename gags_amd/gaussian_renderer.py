@@ -12,18 +12,16 @@ import math
 
 import torch
 
-from .rasterization import rasterization
+from .rasterization import default_context, rasterization
+from .scene import GaussianModel
 
 # The reference re-uploads K with torch.tensor(..., device="cuda") on every call
-# (gaussian_renderer/__init__.py:31-38).  K depends only on (FoVx, FoVy, W, H); keep the
-# device copy resident instead of paying a pageable H2D copy per iteration.
-_K_CACHE = {}
-
-
-def _intrinsics(viewpoint_camera, device):
+# (gaussian_renderer/__init__.py:31-38).  K depends only on (FoVx, FoVy, W, H); the device copy stays resident in the
+# caller's RasterContext instead of paying a pageable H2D copy per iteration.
+def _intrinsics(viewpoint_camera, device, cache):
     key = (float(viewpoint_camera.FoVx), float(viewpoint_camera.FoVy), int(viewpoint_camera.image_width),
            int(viewpoint_camera.image_height), str(device))
-    K = _K_CACHE.get(key)
+    K = cache.get(key)
     if K is None:
         tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
         tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
@@ -33,9 +31,9 @@ def _intrinsics(viewpoint_camera, device):
             [[focal_length_x, 0, viewpoint_camera.image_width / 2.0],
              [0, focal_length_y, viewpoint_camera.image_height / 2.0],
              [0, 0, 1]], device=device)
-        if len(_K_CACHE) > 4096:
-            _K_CACHE.clear()
-        _K_CACHE[key] = K
+        if len(cache) > 4096:
+            cache.clear()
+        cache[key] = K
     return K
 
 
@@ -48,8 +46,13 @@ RAW_PARAMS = True
 
 
 def _stored_parameters(pc):
-    """(rotation, scaling_log, opacity_logit) when `pc` is a GaussianModel in the reference's layout with the reference's
-    activations, else None."""
+    """(rotation, scaling_log, opacity_logit) when `pc` provably activates its parameters the way
+    scene/gaussian_model.py:36-42,116-139 does, else None (the getters are called, as in the reference).
+
+    "Provably": `pc` is this package's GaussianModel with its getters NOT overridden (a subclass that clamps, masks or
+    re-activates in get_scaling / get_opacity / get_rotation goes through its getters), or any other model that carries the
+    reference's three activation attributes and they ARE torch.exp / torch.sigmoid / F.normalize (the reference's
+    GaussianModel.setup_functions).  A duck-typed model without those attributes is never assumed to use them."""
     if not RAW_PARAMS:
         return None
     try:
@@ -57,10 +60,18 @@ def _stored_parameters(pc):
     except AttributeError:
         return None
     F = torch.nn.functional
-    if (getattr(pc, "scaling_activation", torch.exp) is not torch.exp
-            or getattr(pc, "opacity_activation", torch.sigmoid) is not torch.sigmoid
-            or getattr(pc, "rotation_activation", F.normalize) is not F.normalize):
-        return None
+    cls = type(pc)
+    own = isinstance(pc, GaussianModel) and all(
+        getattr(cls, name, None) is getattr(GaussianModel, name) for name in ("get_scaling", "get_rotation", "get_opacity"))
+    if not own:
+        try:
+            if (pc.scaling_activation is not torch.exp or pc.opacity_activation is not torch.sigmoid
+                    or pc.rotation_activation is not F.normalize):
+                return None
+        except AttributeError:
+            return None
+        if isinstance(pc, GaussianModel):  # (a subclass of ours with overridden getters: the attributes do not describe them)
+            return None
     n = pc.get_xyz.shape[0]
     if not all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 for t in (rot, scal, opac)):
         return None
@@ -70,10 +81,13 @@ def _stored_parameters(pc):
 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, feature_mode=True, scaling_modifier=1.0,
-           override_color=None, render_mode="RGB", raster_flags=0):
-    """Render the scene.  Background tensor (bg_color) must be on GPU!"""
+           override_color=None, render_mode="RGB", raster_flags=0, context=None):
+    """Render the scene.  Background tensor (bg_color) must be on GPU!
+    raster_flags / context are this package's additions to the reference's signature (kernel selection; the RasterContext
+    holding this caller's hooks, capacities and caches -- None = the calling thread's default)."""
+    rctx = context if context is not None else default_context()
     means3D = pc.get_xyz
-    K = _intrinsics(viewpoint_camera, means3D.device)
+    K = _intrinsics(viewpoint_camera, means3D.device, rctx.k_cache)
     stored = _stored_parameters(pc)
     if stored is not None:
         rotations, scales, opacity = stored
@@ -98,7 +112,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, feature_mode=True
         viewmats=viewmat[None], Ks=K[None], backgrounds=bg_color[None],
         width=int(viewpoint_camera.image_width), height=int(viewpoint_camera.image_height),
         packed=False, sh_degree=sh_degree, render_mode=render_mode, raster_flags=raster_flags,
-        raw_params=stored is not None, scaling_modifier=float(scaling_modifier))
+        raw_params=stored is not None, scaling_modifier=float(scaling_modifier), context=rctx)
 
     # squeeze (not [0]): its backward is a view, [0]'s is a zero-fill + copy of the whole map
     rendered_image = render_colors.squeeze(0).permute(2, 0, 1)  # [1,H,W,D'] -> [D',H,W]

@@ -19,6 +19,7 @@ PyTorch supplies device memory, streams and autograd plumbing; all arithmetic is
 """
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -26,71 +27,99 @@ from . import _lib, profiler
 from ._lib import check, ptr
 
 TILE = 16
-# Multi-GPU by-view step (gags_amd/dist.py: OverlappedGradReducer): when set, the staged colours-only backward
-# produces the feature gradient one channel range at a time and calls
-#     GRAD_RANGE_HOOK(v_colors_alias [N,D], ch_begin, ch_end)
-# right after the kernels of each range were enqueued, so that the exchange of one range overlaps the computation
-# of the next.  The alias shares storage with the tensor handed to autograd.
-GRAD_RANGE_HOOK = None
-GRAD_RANGE_CHANNELS = 128
-# When set together with GRAD_RANGE_HOOK, the backward first calls GRAD_ROWS_HOOK(mask uint8 [N]): mask[g] = 1 for every
-# Gaussian that blended into a pixel of this view, i.e. the only rows of the gradient that can be non-zero (SURVEY 8e:
-# "gradients are sparse in rows"); the exchange then moves the union of these rows over the ranks instead of all N.
-GRAD_ROWS_HOOK = None
 MAX_ISECTS = 1 << 27  # limit of the C ABI (int32 slot indices: 4 slots per intersection)
-
-
 ZERO_FILL_MIN_ELEMS = 1 << 24  # (below that the second stream's hand-over costs more than the zeros)
-# Experiment, OFF: zero-fill the colour gradient on a second stream during the forward's binning and let the reduce stage
-# write only the rows that exist (stage bit 128; 73 % of the Gaussians blend nothing at C3).  Measured at C3: reduce
-# 1.27 -> 0.95 ms, but the fill kernel takes the CUs from whatever it runs beside -- under the rows kernel that kernel
-# slowed by 0.38 ms, under the binning kernels the step grew by 1.7 ms.  The C-ABI flag stays for callers that own a zeroed
-# buffer anyway.
 GEOM_COMPACT_ROWS = True   # gags_raster_bwd_geom: per-slot rows numbered compactly (one prefix sum + a 4-byte readback)
-OVERLAP_ZERO_FILL = False
-_SIDE = {}
-
-
-def _side_stream(dev):
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
-    if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=dev)
-    return _SIDE[key]
-
-
-# Capacity mode (GAGS_CAPACITY_MODE=1; OFF by default): the two counts a view produces on the device -- tile intersections,
-# partial gradient rows -- are NOT waited for before the kernels that need them are launched.  Buffers are sized by a
-# capacity remembered from earlier views of the same (N, width, height), the kernels take their ranges from device memory
-# (isect_offsets' last entry, sentinel keys), and the counts are read from a second stream once everything is enqueued: the
-# host still learns them (info["n_isects"] is exact, capacities are checked) but the queue never drains.  A count above
-# its capacity -- nothing is written out of bounds -- re-runs that pass with exact sizes.  The first view of a shape runs
-# the exact path.  Measured A/B on one box (C3, D = 512 / D = 16): 10.76-10.94 ms against 10.62-10.68 ms, 2.59 against
-# 2.51-2.54 ms with a 25 % margin -- the two readbacks cost the GPU ~40 us of idle queue per step (the host is far
-# ahead of the device), the sentinel keys cost more in the two sorts.  Kept as a switch for callers whose host is the
-# bottleneck; the margin below is what a training loop over similar views can afford.
-CAPACITY_MODE = os.environ.get("GAGS_CAPACITY_MODE", "0") == "1"
 CAP_MARGIN = 1.05
-_CAP_ISECTS = {}
-_CAP_ROWS = {}
-_PINNED = {}
+# Default of RasterContext.capacity_mode (GAGS_CAPACITY_MODE=1; OFF otherwise): see RasterContext.
+CAPACITY_MODE = os.environ.get("GAGS_CAPACITY_MODE", "0") == "1"
+
+
+class RasterContext:
+    """Everything `rasterization(...)` remembers or is told between calls -- SURVEY 8b asks for a boundary that is
+    "re-entrant per stream, no global state": the C library has none, and the Python layer keeps its own in an object the
+    caller may own.  `rasterization(..., context=ctx)` / `render(..., context=ctx)` use `ctx`; without one, the calling
+    THREAD's default context (default_context()) is used, so two renderers in one process -- a training view inside a
+    gradient-exchange block and an evaluation view, two threads -- never see each other's hooks or capacities.
+
+    grad_range_hook / grad_rows_hook / grad_range_channels
+        Multi-GPU by-view step (gags_amd/dist.py: OverlappedGradReducer): when grad_range_hook is set, the staged
+        colours-only backward produces the feature gradient one channel range at a time and calls
+            grad_range_hook(v_colors_alias [N,D], ch_begin, ch_end)
+        right after the kernels of each range were enqueued, so that the exchange of one range overlaps the computation of
+        the next (the alias shares storage with the tensor handed to autograd).  With grad_rows_hook also set, the backward
+        first calls grad_rows_hook(mask uint8 [N]): mask[g] = 1 for every Gaussian that blended into a pixel of this view,
+        i.e. the only rows of the gradient that can be non-zero ("gradients are sparse in rows").
+    capacity_mode, cap_isects, cap_rows
+        Capacity mode (OFF by default): the two counts a view produces on the device -- tile intersections, partial
+        gradient rows -- are NOT waited for before the kernels that need them are launched.  Buffers are sized by a capacity
+        remembered from earlier views of the same (N, width, height), the kernels take their ranges from device memory
+        (isect_offsets' last entry, sentinel keys), and the counts are read from a second stream once everything is
+        enqueued: the host still learns them (info["n_isects"] is exact, capacities are checked) but the queue never
+        drains.  A count above its capacity -- nothing is written out of bounds -- re-runs that pass with exact sizes; the
+        first view of a shape runs the exact path.  Measured A/B on one box (C3, D = 512 / D = 16): 10.76-10.94 ms
+        against 10.62-10.68 ms, 2.59 against 2.51-2.54 ms with a 25 % margin -- the two readbacks cost the GPU ~40 us of
+        idle queue per step (the host is far ahead of the device), the sentinel keys cost more in the two sorts.  Kept as a
+        switch for callers whose host is the bottleneck.
+    overlap_zero_fill
+        Experiment, OFF: zero-fill the colour gradient on a second stream during the forward's binning and let the reduce
+        stage write only the rows that exist (stage bit 128; 73 % of the Gaussians blend nothing at C3).  Measured at C3:
+        reduce 1.27 -> 0.95 ms, but the fill kernel takes the CUs from whatever it runs beside -- under the rows kernel that
+        kernel slowed by 0.38 ms, under the binning kernels the step grew by 1.7 ms.  The C-ABI flag stays for callers
+        that own a zeroed buffer anyway.
+    Also here: the pinned 4-byte buffers of the deferred count readbacks, the side streams, and render()'s cache of the
+    intrinsics matrix."""
+
+    def __init__(self, capacity_mode=None, overlap_zero_fill=False):
+        self.grad_range_hook = None
+        self.grad_rows_hook = None
+        self.grad_range_channels = 128
+        self.capacity_mode = CAPACITY_MODE if capacity_mode is None else bool(capacity_mode)
+        self.cap_isects = {}
+        self.cap_rows = {}
+        self.overlap_zero_fill = bool(overlap_zero_fill)
+        self.k_cache = {}
+        self._pinned = {}
+        self._side = {}
+
+    def side_stream(self, dev):
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        if key not in self._side:
+            self._side[key] = torch.cuda.Stream(device=dev)
+        return self._side[key]
+
+    def pinned_i32(self, dev):
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        if key not in self._pinned:
+            self._pinned[key] = torch.empty(1, dtype=torch.int32).pin_memory()
+        return self._pinned[key]
+
+
+_TLS = threading.local()
+
+
+def default_context():
+    """The calling thread's own RasterContext (created on first use)."""
+    ctx = getattr(_TLS, "ctx", None)
+    if ctx is None:
+        ctx = _TLS.ctx = RasterContext()
+    return ctx
 
 
 class _DeferredCount:
     """A device-side int32 read back without draining the launch stream: the copy runs on a second stream behind an
     event recorded right after the kernel that produced the value."""
 
-    def __init__(self, scalar):
+    def __init__(self, scalar, rctx):
         self.t = scalar
+        self.rctx = rctx
         self.ev = torch.cuda.Event()
         self.ev.record()
 
     def get(self):
         dev = self.t.device
-        side = _side_stream(dev)
-        key = dev.index
-        if key not in _PINNED:
-            _PINNED[key] = torch.empty(1, dtype=torch.int32).pin_memory()
-        host = _PINNED[key]
+        side = self.rctx.side_stream(dev)
+        host = self.rctx.pinned_i32(dev)
         done = torch.cuda.Event()
         with torch.cuda.stream(side):
             side.wait_event(self.ev)
@@ -255,9 +284,11 @@ class _SH(torch.autograd.Function):
         return v_coeffs, v_means, None, None, None
 
 
-def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height, conics=None, opacities=None, cap=None, records=None):
-    """K5-K8 (+K8b) on device.  Returns (isect_ids sorted int64, flatten_ids sorted int32, isect_offsets [th,tw] int32 -- a
-    view of tile_h * tile_w + 1 entries whose last one is the count --, n_isects, packed [N,8] per-Gaussian records or None).
+def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height, conics=None, opacities=None, cap=None, records=None,
+                 context=None):
+    """K5-K8 (+K8b) on device.  Returns (isect_ids sorted int64, flatten_ids sorted int32, isect_offsets [th,tw] int32,
+    n_isects, packed [N,8] per-Gaussian records or None, offsets_full = the buffer behind isect_offsets: th * tw + 1 entries
+    whose last one is the count).
     cap None: one host readback (n_isects), as in gsplat; the id arrays have exactly n_isects entries.
     cap = capacity: nothing is read back here; the id arrays have `cap` entries (sentinels past the count) and n_isects is a
     _DeferredCount the caller resolves after enqueuing what follows."""
@@ -288,7 +319,7 @@ def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height, conics=
         _check_isects(n_isects)
         size, count = n_isects, n_isects
     else:
-        size, count = int(cap), _DeferredCount(total)
+        size, count = int(cap), _DeferredCount(total, context or default_context())
     offsets = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
     ids = torch.empty(max(size, 1), dtype=torch.int64, device=dev)
     flat = torch.empty(max(size, 1), dtype=torch.int32, device=dev)
@@ -310,9 +341,10 @@ def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height, conics=
         packed = torch.empty(max(n, 1), 8, dtype=torch.float32, device=dev)
         check(lib.gags_pack_isects(n, size, ptr(flat_s), ptr(means2d), ptr(conics), ptr(opacities), ptr(radii),
                                    ptr(packed), None, st), "gags_pack_isects")
+    # `offsets` has n_tiles + 1 entries, the last one = the intersection count (gags_tile_offsets): the raster kernels read
+    # isect_offsets[tile + 1] as a tile's end.  Callers get gsplat's [tile_h, tile_w] view AND the buffer itself.
     off_view = offsets[:n_tiles].view(tile_h, tile_w)
-    off_view._gags_count_attached = True  # (entry n_tiles, written by gags_tile_offsets, sits behind the view: see _offsets_with_count)
-    return ids_s[:size], flat_s[:size], off_view, count, packed
+    return ids_s[:size], flat_s[:size], off_view, count, packed, offsets
 
 
 def _check_isects(n_isects):
@@ -336,7 +368,10 @@ class _Rasterize(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, packed, width, height,
-                flags, prezero=None):
+                flags, prezero=None, rctx=None, n_isects=None):
+        """offsets: the buffer of n_tiles + 1 int32 entries tile_binning returns as `offsets_full` (last entry = the
+        intersection count), or a gsplat-style [tile_h, tile_w] tensor together with `n_isects` (the count is then attached
+        here).  rctx: the RasterContext of the call."""
         lib = _lib.load()
         means2d, conics, opacities = _c(means2d), _c(conics), _c(opacities)
         # an fp16 feature table (BASELINE.json configs[4]) is read as it is by the matrix-core feature pass: widened
@@ -347,8 +382,9 @@ class _Rasterize(torch.autograd.Function):
         backgrounds = None if backgrounds is None else _c(backgrounds)
         n, d = colors.shape
         dev = colors.device
-        n_isects = flatten_ids.shape[0]
-        offsets = _offsets_with_count(offsets, n_isects)
+        n_tiles = ((width + TILE - 1) // TILE) * ((height + TILE - 1) // TILE)
+        offsets = _offsets_with_count(offsets, n_tiles, flatten_ids.shape[0] if n_isects is None else n_isects)
+        n_isects = flatten_ids.shape[0]  # (capacity mode: the buffers' size; the kernels take the count from `offsets`)
         out = torch.empty(height, width, d, device=dev)
         alphas = torch.empty(height, width, device=dev)
         last_ids = torch.empty(height, width, dtype=torch.int32, device=dev)
@@ -366,7 +402,7 @@ class _Rasterize(torch.autograd.Function):
                 if half:
                     half, colors = False, colors.float()
         if split:
-            blk_rows = torch.empty(offsets.numel() * 4, dtype=torch.int32, device=dev)  # per 8x8 pixel block
+            blk_rows = torch.empty(n_tiles * 4, dtype=torch.int32, device=dev)  # per 8x8 pixel block
         cflags = ((flags & 3) | (flags & _lib.GAGS_FWD_EXACT) | _lib.GAGS_RECS_BY_GAUSSIAN | (_lib.GAGS_FEAT_F16 if half else 0)
                   | (64 if (half and d >= 128 and (flags & _lib.GAGS_FWD_F16MFMA)) else 0))
 
@@ -396,6 +432,7 @@ class _Rasterize(torch.autograd.Function):
                               last_ids, scratch if staged else None, blk_rows if staged else None)
         ctx.cfg = (width, height, flags)
         ctx.half = half
+        ctx.rctx = rctx if rctx is not None else default_context()
         ctx.prezero = prezero if staged else None
         ctx.mark_non_differentiable(last_ids)
         return out, alphas, last_ids
@@ -418,15 +455,15 @@ class _Rasterize(torch.autograd.Function):
         if not need_geom and blk_rows is not None:
             # an fp16 table gets its gradient in fp16 straight from the reduce kernel (fp32 sums, rounded once): no fp32
             # tensor + cast pass (autograd wants the table's dtype; an fp32 master sits behind a .half() cast)
-            v_colors = _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height,
+            v_colors = _backward_staged(lib, ctx.rctx, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height,
                                         (32 if (flags & _lib.GAGS_BWD_F32MFMA) else 0) | (64 if ctx.half else 0),
                                         flatten_ids, ctx.prezero)
-            return None, None, v_colors, None, v_bg, None, None, None, None, None, None, None
+            return None, None, v_colors, None, v_bg, None, None, None, None, None, None, None, None, None
         if need_geom and blk_rows is not None and ctx.geom_mfma:
             # wide D: colours through the staged backward, geometry through the matrix-core dot pass + scalar pass
             v_colors = None
             if ctx.needs_input_grad[2]:
-                v_colors = _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height,
+                v_colors = _backward_staged(lib, ctx.rctx, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height,
                                             (32 if (flags & _lib.GAGS_BWD_F32MFMA) else 0) | (64 if ctx.half else 0),
                                             flatten_ids)
             if ctx.half:  # the geometry kernels read an fp32 table: widen the halves (exact) for this backward
@@ -451,7 +488,7 @@ class _Rasterize(torch.autograd.Function):
                                                _stream()),
                       "gags_raster_bwd_geom")
             v_con, v_m2d, v_opac = v_geo[:, 0:3].contiguous(), v_geo[:, 3:5].contiguous(), v_geo[:, 5].contiguous()
-            return v_m2d, v_con, v_colors, v_opac, v_bg, None, None, None, None, None, None, None
+            return v_m2d, v_con, v_colors, v_opac, v_bg, None, None, None, None, None, None, None, None, None
         if ctx.half:  # VALU / atomic kernels read an fp32 table: widen the halves (exact); gradient returned in the table's dtype
             colors = colors.float()
         v_colors = torch.zeros(n, d, device=dev)
@@ -470,25 +507,22 @@ class _Rasterize(torch.autograd.Function):
                                       ptr(v_opac), ptr(v_m2d), ptr(v_con), bflags, _stream()), "gags_raster_bwd")
         if ctx.half:
             v_colors = v_colors.half()
-        return v_m2d, v_con, v_colors, v_opac, v_bg, None, None, None, None, None, None, None
+        return v_m2d, v_con, v_colors, v_opac, v_bg, None, None, None, None, None, None, None, None, None
 
 
-def _offsets_with_count(offsets, n_isects):
+def _offsets_with_count(offsets, n_tiles, n_isects):
     """ABI v2: every raster kernel reads `isect_offsets[tile + 1]` as a tile's end, so the buffer must hold n_tiles + 1
-    entries, the last one = the intersection count (include/gags_raster.h).  tile_binning hands out a [tile_h, tile_w] view
-    of such a buffer; a tensor that was cloned, re-created in gsplat's [tile_h, tile_w] layout or sliced elsewhere has no
-    entry behind its last tile -- re-attach the count here instead of letting the kernels read out of bounds."""
-    n_tiles = offsets.numel()
-    if (offsets.is_contiguous() and offsets.dtype == torch.int32
-            and offsets.untyped_storage().nbytes() // 4 - offsets.storage_offset() >= n_tiles + 1
-            and getattr(offsets, "_gags_count_attached", False)):
+    entries, the last one = the intersection count (include/gags_raster.h).  tile_binning's `offsets_full` is such a buffer
+    and passes through; a gsplat-style [tile_h, tile_w] tensor (no entry behind its last tile) is copied into one with the
+    TRUE count `n_isects` the caller states -- never a buffer size."""
+    if offsets.dim() == 1 and offsets.numel() == n_tiles + 1 and offsets.is_contiguous() and offsets.dtype == torch.int32:
         return offsets
+    if offsets.numel() != n_tiles:
+        raise ValueError(f"isect_offsets must have {n_tiles} (= tile_h * tile_w) entries, or {n_tiles + 1} with the count")
     full = torch.empty(n_tiles + 1, dtype=torch.int32, device=offsets.device)
     full[:n_tiles] = offsets.reshape(-1)
-    full[n_tiles] = n_isects
-    out = full[:n_tiles].view(offsets.shape)
-    out._gags_count_attached = True
-    return out
+    full[n_tiles] = int(n_isects)
+    return full
 
 
 def _geom_mfma_width(d):
@@ -496,33 +530,34 @@ def _geom_mfma_width(d):
     return d >= 16 and d % 8 == 0 and d <= 1024
 
 
-def _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height, xflag=0,
+def _backward_staged(lib, rctx, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height, xflag=0,
                      flatten_ids=None, prezero=None, exact_rows=False):
     """Colours-only backward without atomics: hit flags of the forward -> prefix sum (one row per (tile, Gaussian)
     pair that blended anything) -> one 4-byte readback (total rows) -> merged partial rows -> sort by Gaussian ->
     segmented sum."""
     dev = v_out.device
     st = _stream()
-    if GRAD_ROWS_HOOK is not None and GRAD_RANGE_HOOK is not None and flatten_ids is not None:
+    if rctx.grad_rows_hook is not None and rctx.grad_range_hook is not None and flatten_ids is not None:
         mask = torch.empty(n, dtype=torch.uint8, device=dev)
         check(lib.gags_blended_mask(n_isects, width, height, n, ptr(flatten_ids), ptr(fwd_scratch), fwd_scratch.numel(),
                                     ptr(mask), st), "gags_blended_mask")
-        GRAD_ROWS_HOOK(mask)  # before the readback below: the ranks agree on the union while the backward starts
+        rctx.grad_rows_hook(mask)  # before the readback below: the ranks agree on the union while the backward starts
     ne = lib.gags_bwd_rowmap_elems(n_isects, width, height)
     trow = torch.empty(ne, dtype=torch.int32, device=dev)
     total = torch.empty(1, dtype=torch.int32, device=dev)
     sb = lib.gags_bwd_rowmap_scratch_bytes(n_isects)
     stmp = torch.empty(max(sb, 4), dtype=torch.uint8, device=dev)
-    hook = GRAD_RANGE_HOOK
+    hook = rctx.grad_range_hook
+    rng = rctx.grad_range_channels
     cap_key = (n, width, height, dev.index)
     pending = None
     with profiler.stage("bwd_rowcount"):
         check(lib.gags_bwd_rowmap(n_isects, width, height, ptr(offsets), ptr(blk_rows), ptr(fwd_scratch),
                                   fwd_scratch.numel(), ptr(trow), ne, ptr(total), ptr(stmp), sb, st), "gags_bwd_rowmap")
-        if CAPACITY_MODE and hook is None and cap_key in _CAP_ROWS and not exact_rows:
-            # capacity mode (see CAPACITY_MODE): the row count stays on the device until the backward is enqueued
-            rows = min(max(n_isects, 1), int(_CAP_ROWS[cap_key] * CAP_MARGIN) + 1024)
-            pending = _DeferredCount(total)
+        if rctx.capacity_mode and hook is None and cap_key in rctx.cap_rows and not exact_rows:
+            # capacity mode (see RasterContext): the row count stays on the device until the backward is enqueued
+            rows = min(max(n_isects, 1), int(rctx.cap_rows[cap_key] * CAP_MARGIN) + 1024)
+            pending = _DeferredCount(total, rctx)
         else:
             host = ctypes.c_int32(0)
             check(lib.gags_read_i32(ptr(total), ctypes.byref(host), st), "gags_read_i32")
@@ -549,16 +584,16 @@ def _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d,
             torch.cuda.current_stream().wait_event(ev)
             v_colors = buf
             xflag |= 128
-    if hook is not None and d % GRAD_RANGE_CHANNELS == 0 and d > GRAD_RANGE_CHANNELS:
+    if hook is not None and d % rng == 0 and d > rng:
         alias = v_colors.detach()  # own TensorImpl, same storage: autograd may still adopt v_colors without a copy
-        for c0 in range(0, d, GRAD_RANGE_CHANNELS):
+        for c0 in range(0, d, rng):
             for stage in ((1, 2, 3) if c0 == 0 else (1, 3)):
                 with profiler.stage(("bwd_rows", "bwd_sort", "bwd_reduce")[stage - 1]):
                     check(lib.gags_raster_bwd_colors_staged_range(
                         d, n, width, height, ptr(offsets), n_isects, ptr(v_out), ptr(blk_rows), ptr(trow), rows,
                         ptr(fwd_scratch), fwd_scratch.numel(), ptr(scratch), nbytes, ptr(v_colors), stage | xflag, c0,
-                        GRAD_RANGE_CHANNELS, st), "gags_raster_bwd_colors_staged_range")
-            hook(alias, c0, c0 + GRAD_RANGE_CHANNELS)
+                        rng, st), "gags_raster_bwd_colors_staged_range")
+            hook(alias, c0, c0 + rng)
     elif profiler.ENABLED:  # one event pair per kernel (group), for the roofline line of bench.py
         for stage, name in enumerate(("bwd_rows", "bwd_sort", "bwd_reduce"), start=1):
             with profiler.stage(name):
@@ -570,12 +605,12 @@ def _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d,
     if pending is not None:
         true_rows = pending.get()
         if true_rows > rows:  # more rows than the remembered capacity (none was stored out of bounds): again, exact
-            _CAP_ROWS[cap_key] = true_rows
-            return _backward_staged(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height, xflag & ~128,
+            rctx.cap_rows[cap_key] = true_rows
+            return _backward_staged(lib, rctx, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height, xflag & ~128,
                                     flatten_ids, None, exact_rows=True)
         rows = true_rows
-    if hook is None and CAPACITY_MODE:
-        _CAP_ROWS[cap_key] = max(rows, int(0.97 * _CAP_ROWS.get(cap_key, 0)))
+    if hook is None and rctx.capacity_mode:
+        rctx.cap_rows[cap_key] = max(rows, int(0.97 * rctx.cap_rows.get(cap_key, 0)))
     profiler.note("bwd_rows", rows)
     return v_colors
 
@@ -584,14 +619,17 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
                   near_plane=0.01, far_plane=1e10, radius_clip=0.0, eps2d=0.3, sh_degree=None, packed=False,
                   tile_size=16, backgrounds=None, render_mode="RGB", sparse_grad=False, absgrad=False,
                   rasterize_mode="classic", channel_chunk=32, distributed=False, camera_model="pinhole",
-                  covars=None, raster_flags=0, raw_params=False, scaling_modifier=1.0):
+                  covars=None, raster_flags=0, raw_params=False, scaling_modifier=1.0, context=None):
     """See module docstring.  `channel_chunk` is accepted and ignored: any D is composited in a
     single pass over the sorted lists (SURVEY A12 shows this is identical per channel).
     raw_params=True (not part of gsplat's signature): `quats`, `scales`, `opacities` are the STORED parameters of
     scene/gaussian_model.py:48-61 -- `_rotation` [N,4] un-normalised, `_scaling` [N,3] log-space, `_opacity` [N] or [N,1]
     logits -- and the getters of :116-139 together with `* scaling_modifier` run inside the projection kernel
     (gags_project_fwd_raw; bit-identical to torch's exp / F.normalize / sigmoid): no elementwise launches, no extra passes
-    over N, and the backward returns the gradients of the stored parameters."""
+    over N, and the backward returns the gradients of the stored parameters.
+    context (not part of gsplat's signature): the RasterContext that carries this caller's hooks and capacities; None = the
+    calling thread's default_context()."""
+    rctx = context if context is not None else default_context()
     if tile_size != TILE:
         raise NotImplementedError("tile_size must be 16 (the gsplat default the reference relies on)")
     if rasterize_mode != "classic" or camera_model != "pinhole" or covars is not None or distributed or absgrad:
@@ -602,10 +640,10 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
     if viewmats.dim() != 3 or viewmats.shape[0] != 1 or Ks.shape[0] != 1:
         raise NotImplementedError("one camera per call (the reference renders one view per iteration, train.py:134-142)")
     n = means.shape[0]
-    if raw_params and opacities.shape == (n, 1):
-        pass
-    elif quats.shape != (n, 4) or scales.shape != (n, 3) or opacities.shape != (n,):
-        raise ValueError("means [N,3], quats [N,4], scales [N,3], opacities [N] expected")
+    if means.shape != (n, 3) or quats.shape != (n, 4) or scales.shape != (n, 3):
+        raise ValueError("means [N,3], quats [N,4], scales [N,3] expected")
+    if opacities.shape != (n,) and not (raw_params and opacities.shape == (n, 1)):  # (the stored logits are [N,1])
+        raise ValueError("opacities [N] expected" + (" (or the stored [N,1] logits with raw_params)" if raw_params else ""))
     _need_cuda(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds)
     width, height = int(width), int(height)
     viewmat, K = viewmats[0], Ks[0]
@@ -649,14 +687,14 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
 
     prezero = None
     dz = cols.shape[-1]
-    if (OVERLAP_ZERO_FILL and GRAD_RANGE_HOOK is None and torch.is_grad_enabled() and cols.requires_grad and _mfma_width(dz)
+    if (rctx.overlap_zero_fill and rctx.grad_range_hook is None and torch.is_grad_enabled() and cols.requires_grad and _mfma_width(dz)
             and dz <= 1024 and n * dz >= ZERO_FILL_MIN_ELEMS and not (raster_flags & (_lib.GAGS_BWD_ATOMIC | _lib.GAGS_FWD_NO_MFMA
                                                                                       | _lib.GAGS_FWD_FUSED))
             and not (means.requires_grad or quats.requires_grad or scales.requires_grad or opacities.requires_grad)):
         # colours-only (GAD) backward ahead: its gradient tensor is mostly rows of zeros.  Fill it now, on a second stream,
         # under the binning kernels; the backward's reduce stage then writes only the rows that exist (_backward_staged)
         vbuf = torch.empty(n, dz, device=cols.device, dtype=torch.float16 if cols.dtype == torch.float16 else torch.float32)
-        side = _side_stream(cols.device)
+        side = rctx.side_stream(cols.device)
         ev0, ev1 = torch.cuda.Event(), torch.cuda.Event()
         ev0.record()
         with torch.cuda.stream(side):
@@ -673,15 +711,16 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
     def run(cap):
         with torch.no_grad(), profiler.stage("binning"):
             b = tile_binning(means2d, radii, depths, tiles, width, height, conics if wide else None,
-                             _c(opacities) if wide else None, cap, records=records if wide else None)
+                             _c(opacities) if wide else None, cap, records=records if wide else None, context=rctx)
         # any width in ONE rasterization: 513 = 512 CLIP channels + 1 (BASELINE.json configs[4] "512-d feat + granularity")
         # is four 128-channel slices and one lane of a narrow slice on the same matrix-core kernels, into one output tensor
-        r = _Rasterize.apply(means2d, conics, cols, opacities, bg, b[2], b[1], b[4], width, height, int(raster_flags), prezero)
-        return b, r
+        r = _Rasterize.apply(means2d, conics, cols, opacities, bg, b[5], b[1], b[4], width, height, int(raster_flags), prezero,
+                             rctx, None)
+        return b[:5], r
 
     cap = None
-    if CAPACITY_MODE and cap_key in _CAP_ISECTS:
-        cap = min(MAX_ISECTS - 1, int(_CAP_ISECTS[cap_key] * CAP_MARGIN) + 4096)
+    if rctx.capacity_mode and cap_key in rctx.cap_isects:
+        cap = min(MAX_ISECTS - 1, int(rctx.cap_isects[cap_key] * CAP_MARGIN) + 4096)
     (isect_ids, flatten_ids, isect_offsets, n_isects, packed), (out, alphas, last_ids) = run(cap)
     if cap is not None:
         n_true = n_isects.get()  # (the scan that produced it finished long ago: everything above is already enqueued)
@@ -691,8 +730,8 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
         else:
             n_isects = n_true
             isect_ids, flatten_ids = isect_ids[:n_true], flatten_ids[:n_true]
-    if CAPACITY_MODE:
-        _CAP_ISECTS[cap_key] = max(n_isects, int(0.97 * _CAP_ISECTS.get(cap_key, 0)))
+    if rctx.capacity_mode:
+        rctx.cap_isects[cap_key] = max(n_isects, int(0.97 * rctx.cap_isects.get(cap_key, 0)))
     if render_mode in ("ED", "RGB+ED"):
         if out.requires_grad:
             out = torch.cat([out[..., :-1], out[..., -1:] / alphas[..., None].clamp(min=1e-10)], dim=-1)

@@ -146,10 +146,10 @@ def _overlap_worker(rank, world, port, wire, q):
 
     def feed(red, local):
         with red:
-            assert rasterization.GRAD_RANGE_HOOK is not None
+            assert rasterization.default_context().grad_range_hook is not None
             for c0 in range(0, d, 128):
-                rasterization.GRAD_RANGE_HOOK(local.detach(), c0, c0 + 128)  # alias with its own TensorImpl
-        assert rasterization.GRAD_RANGE_HOOK is None
+                rasterization.default_context().grad_range_hook(local.detach(), c0, c0 + 128)  # alias with its own TensorImpl
+        assert rasterization.default_context().grad_range_hook is None
 
     out = {}
     mode = "allreduce" if wire == "bf16" else "rs_ag"
@@ -209,7 +209,7 @@ def _overlap_worker(rank, world, port, wire, q):
     try:
         with red:
             for _ in range(2):
-                rasterization.GRAD_RANGE_HOOK(grads[rank].clone().detach(), 0, 128)
+                rasterization.default_context().grad_range_hook(grads[rank].clone().detach(), 0, 128)
         out["second_refused"] = False
     except RuntimeError:
         out["second_refused"] = True
@@ -245,7 +245,7 @@ def test_overlapped_reducer_two_ranks(wire, tol):
 
 def _union_worker(rank, world, port, q):
     """rows="union": every rank's gradient is non-zero in its own subset of rows; the reducer is handed the row mask
-    first (GRAD_ROWS_HOOK), exchanges only the union's rows and must reproduce the plain sum exactly."""
+    first (RasterContext.grad_rows_hook), exchanges only the union's rows and must reproduce the plain sum exactly."""
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -259,11 +259,11 @@ def _union_worker(rank, world, port, q):
     grad = grads[rank].clone()
     red = OverlappedGradReducer(mode="rs_ag", bucket_bytes=8192)
     with red:
-        assert rasterization.GRAD_ROWS_HOOK is not None
-        rasterization.GRAD_ROWS_HOOK(masks[rank].to(torch.uint8))
+        assert rasterization.default_context().grad_rows_hook is not None
+        rasterization.default_context().grad_rows_hook(masks[rank].to(torch.uint8))
         for c0 in range(0, d, 128):
-            rasterization.GRAD_RANGE_HOOK(grad.detach(), c0, c0 + 128)
-    assert rasterization.GRAD_ROWS_HOOK is None
+            rasterization.default_context().grad_range_hook(grad.detach(), c0, c0 + 128)
+    assert rasterization.default_context().grad_rows_hook is None
     used = red.finish(grad)
     ok = torch.equal(grad, expect) if world == 2 else bool(((grad - expect).abs() <= 1e-6 * expect.abs().max()).all())
     q.put((rank, used, bool(ok), red.rows_exchanged, union))

@@ -318,3 +318,49 @@ def test_pack_and_unpack_rows_against_torch_indexing(d, c0, c1, gdt, wdt):
         else:
             ref[ix, c0:c1] += delta
         assert torch.equal(tgt, ref.to(gdt))
+
+
+def test_two_renderers_in_one_process_do_not_share_hooks():
+    """"re-entrant per stream, no global state".  One model trains inside an OverlappedGradReducer block (its
+    backward is asked for the gradient range by range), a second one is rendered and differentiated in between through its
+    own RasterContext: the reducer sees only the first model's ranges, the second model's gradient is the plain one-shot
+    gradient, and both equal what each gives alone."""
+    import torch
+    from gags_amd import synthetic as syn
+    from gags_amd.dist import OverlappedGradReducer
+    from gags_amd.gaussian_renderer import render
+    from gags_amd.rasterization import RasterContext
+    dev = torch.device("cuda", 0)
+    w, h, d = 160, 112, 256
+    cam = syn.make_camera(w, h, view=3, device=dev)
+    bg = torch.zeros(3, device=dev)
+    G = syn.make_cotangent(d, h, w, seed=1).to(dev)
+    pcs = [syn.make_model(3000, d, w, h, seed=sd, device=dev, scale0=syn.SCALE0 * 4) for sd in (5, 6)]
+    for pc in pcs:
+        pc.training_setup()
+
+    def alone(pc):
+        pc._semantic_feature.grad = None
+        (render(cam, pc, None, bg, feature_mode=True, context=RasterContext())["render"] * G).sum().backward()
+        return pc._semantic_feature.grad.clone()
+
+    ref = [alone(pc) for pc in pcs]
+    for pc in pcs:
+        pc._semantic_feature.grad = None
+    train_ctx, eval_ctx = RasterContext(), RasterContext()
+    red = OverlappedGradReducer(mode="allreduce", rows="all", context=train_ctx)
+    seen = []
+    with red:
+        inner = train_ctx.grad_range_hook
+        train_ctx.grad_range_hook = lambda g, c0, c1: (seen.append((g.shape[0], c0, c1)), inner(g, c0, c1))[1]
+        pk_train = render(cam, pcs[0], None, bg, feature_mode=True, context=train_ctx)
+        pk_eval = render(cam, pcs[1], None, bg, feature_mode=True, context=eval_ctx)   # the other renderer, in between
+        (pk_eval["render"] * G).sum().backward()
+        (pk_train["render"] * G).sum().backward()
+        assert eval_ctx.grad_range_hook is None
+    red.finish(pcs[0]._semantic_feature.grad)
+    torch.cuda.synchronize()
+    assert [(c0, c1) for _, c0, c1 in seen] == [(0, 128), (128, 256)]            # only the training model's backward
+    assert train_ctx.grad_range_hook is None                                       # restored on exit
+    assert torch.equal(pcs[1]._semantic_feature.grad, ref[1])
+    assert torch.equal(pcs[0]._semantic_feature.grad, ref[0])                      # world size 1: the sum is the local gradient

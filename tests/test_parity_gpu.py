@@ -21,7 +21,7 @@ GSPLAT_ORDER_TOL_SATURATED = 4e-4
 
 
 def _run_gpu(s, width, height, colors, bg, render_mode="RGB", sh_degree=None, need_geom=False, flags=0,
-             v_out=None, v_alpha=None):
+             v_out=None, v_alpha=None, context=None):
     from gags_amd.rasterization import rasterization
     means, quats, scales = to_dev(s["means"]), to_dev(s["quats"]), to_dev(s["scales"])
     opac, cols = to_dev(s["opacities"]), to_dev(colors)
@@ -33,7 +33,7 @@ def _run_gpu(s, width, height, colors, bg, render_mode="RGB", sh_degree=None, ne
     out, alphas, info = rasterization(means, quats, scales, opac, cols, to_dev(s["viewmat"])[None],
                                       to_dev(s["K"])[None], width, height,
                                       backgrounds=None if bg is None else to_dev(bg)[None],
-                                      sh_degree=sh_degree, render_mode=render_mode, raster_flags=flags)
+                                      sh_degree=sh_degree, render_mode=render_mode, raster_flags=flags, context=context)
     grads = None
     if v_out is not None:
         loss = (out[0] * to_dev(v_out)).sum()
@@ -346,7 +346,7 @@ def test_backward_kernels_on_both_matrix_pipes_are_within_tolerance(oracle):
 
 def test_sparse_reduce_with_overlapped_zero_fill_is_bit_identical(oracle):
     """Stage bit 128 of gags_raster_bwd_colors_staged (the gradient arrives zero-filled -- here by the opt-in overlap of
-    gags_amd.rasterization.OVERLAP_ZERO_FILL -- and the reduce stage skips the Gaussians that blended nothing): same bits as the dense reduce,
+    RasterContext.overlap_zero_fill -- and the reduce stage skips the Gaussians that blended nothing): same bits as the dense reduce,
     every culled / unblended row exactly zero, for fp32 and fp16 gradients and an odd width."""
     from gags_amd import rasterization as R
     for d, half in ((256, False), (513, False), (128, True)):
@@ -355,18 +355,18 @@ def test_sparse_reduce_with_overlapped_zero_fill_is_bit_identical(oracle):
         v_out = np.random.default_rng(11).standard_normal((h, w, d)).astype(np.float32)
         res = []
         for overlap in (True, False):
-            R.OVERLAP_ZERO_FILL, old_min = overlap, R.ZERO_FILL_MIN_ELEMS
+            rctx, old_min = R.RasterContext(overlap_zero_fill=overlap), R.ZERO_FILL_MIN_ELEMS
             R.ZERO_FILL_MIN_ELEMS = 0
             try:
                 cols = torch.from_numpy(s["colors"]).cuda()
                 cols = (cols.half() if half else cols).requires_grad_(True)
                 out, _, info = R.rasterization(to_dev(s["means"]), to_dev(s["quats"]), to_dev(s["scales"]), to_dev(s["opacities"]),
-                                               cols, to_dev(s["viewmat"])[None], to_dev(s["K"])[None], w, h)
+                                               cols, to_dev(s["viewmat"])[None], to_dev(s["K"])[None], w, h, context=rctx)
                 (out[0] * to_dev(v_out)).sum().backward()
                 torch.cuda.synchronize()
                 res.append(cols.grad.clone())
             finally:
-                R.OVERLAP_ZERO_FILL, R.ZERO_FILL_MIN_ELEMS = False, old_min
+                R.ZERO_FILL_MIN_ELEMS = old_min
         assert torch.equal(res[0], res[1]), (d, half)
         assert bool((res[0][info["radii"][0] == 0] == 0).all())
 
@@ -389,31 +389,26 @@ def test_capacity_mode_keeps_the_counts_on_the_device_and_changes_nothing(oracle
         calls.append(1)
         return real(*a)
 
-    def once():
-        out, alpha, info, grads = _run_gpu(s, w, h, s["colors"], bg, v_out=v_out)
+    def once(rctx):
+        out, alpha, info, grads = _run_gpu(s, w, h, s["colors"], bg, v_out=v_out, context=rctx)
         return out, alpha, info["n_isects"], info["isect_ids"].cpu().numpy(), info["flatten_ids"].cpu().numpy(), \
             info["isect_offsets"][0].cpu().numpy(), info["last_ids"].cpu().numpy(), grads["colors"]
 
-    saved = R.CAPACITY_MODE
-    R.CAPACITY_MODE = False
-    ref = once()
-    R.CAPACITY_MODE = True              # (opt-in: GAGS_CAPACITY_MODE=1)
-    R._CAP_ISECTS.clear(); R._CAP_ROWS.clear()
-    first = once()                      # learns the capacities (exact path)
+    ref = once(R.RasterContext(capacity_mode=False))
+    cap = R.RasterContext(capacity_mode=True)   # (opt-in; GAGS_CAPACITY_MODE=1 makes it the default of new contexts)
+    first = once(cap)                   # learns the capacities (exact path)
     lib.gags_read_i32 = counting
     try:
-        steady = once()
+        steady = once(cap)
         assert calls == [], "the steady state must not read a count back synchronously"
         # capacities far too small: both passes notice afterwards and run again
-        for k in list(R._CAP_ISECTS):
-            R._CAP_ISECTS[k] = 10
-        for k in list(R._CAP_ROWS):
-            R._CAP_ROWS[k] = 10
-        small = once()
+        for k in list(cap.cap_isects):
+            cap.cap_isects[k] = 10
+        for k in list(cap.cap_rows):
+            cap.cap_rows[k] = 10
+        small = once(cap)
     finally:
         lib.gags_read_i32 = real
-        R.CAPACITY_MODE = saved
-        R._CAP_ISECTS.clear(); R._CAP_ROWS.clear()
     for got in (first, steady, small):
         assert got[2] == ref[2]
         for a, b in zip(got, ref):
@@ -424,7 +419,7 @@ def test_capacity_mode_keeps_the_counts_on_the_device_and_changes_nothing(oracle
 
 def test_backward_by_channel_ranges_is_bit_identical(oracle):
     """The by-view multi-GPU step asks the staged backward for the gradient one 128-channel range at a time
-    (rasterization.GRAD_RANGE_HOOK, gags_amd/dist.py): same kernels on a sub-range, so the same bits as the one-shot
+    (RasterContext.grad_range_hook, gags_amd/dist.py): same kernels on a sub-range, so the same bits as the one-shot
     backward, and the hook sees the ranges in order on an alias of the tensor autograd receives."""
     from gags_amd import rasterization as R
     n, w, h, d = 5000, 192, 144, 384
@@ -432,11 +427,13 @@ def test_backward_by_channel_ranges_is_bit_identical(oracle):
     v_out = np.random.default_rng(9).standard_normal((h, w, d)).astype(np.float32)
     _, _, _, g_full = _run_gpu(s, w, h, s["colors"], None, v_out=v_out)
     seen = []
-    R.GRAD_RANGE_HOOK = lambda grad, c0, c1: seen.append((grad.data_ptr(), c0, c1))
-    try:
-        _, _, _, g_rng = _run_gpu(s, w, h, s["colors"], None, v_out=v_out)
-    finally:
-        R.GRAD_RANGE_HOOK = None
+    rctx = R.RasterContext()
+    rctx.grad_range_hook = lambda grad, c0, c1: seen.append((grad.data_ptr(), c0, c1))
+    _, _, _, g_rng = _run_gpu(s, w, h, s["colors"], None, v_out=v_out, context=rctx)
+    # ... and a render through another context in between never sees the hook (no global state)
+    _, _, _, g_other = _run_gpu(s, w, h, s["colors"], None, v_out=v_out)
+    np.testing.assert_array_equal(g_other["colors"], g_full["colors"])
+    assert len(seen) == 3
     assert [(c0, c1) for _, c0, c1 in seen] == [(0, 128), (128, 256), (256, 384)]
     assert len({p for p, _, _ in seen}) == 1
     np.testing.assert_array_equal(g_rng["colors"], g_full["colors"])

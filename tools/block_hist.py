@@ -14,9 +14,9 @@ pc = syn.make_model(n, d, w, h, seed=0, device=dev, gen_device=dev)
 cam = syn.make_camera(w, h, device=dev)
 captured = {}
 orig = R._backward_staged
-def spy(lib, offsets, n_isects, blk_rows, *a, **k):
-    captured["blk_rows"] = blk_rows.clone(); captured["offsets"] = offsets.clone(); captured["n_isects"] = n_isects
-    return orig(lib, offsets, n_isects, blk_rows, *a, **k)
+def spy(lib, rctx, offsets, n_isects, blk_rows, *a, **k):
+    captured["blk_rows"] = blk_rows.clone(); captured["offsets"] = offsets[:-1].clone(); captured["n_isects"] = n_isects
+    return orig(lib, rctx, offsets, n_isects, blk_rows, *a, **k)
 R._backward_staged = spy
 pc.training_setup()
 pkg = render(cam, pc, None, torch.zeros(3, device=dev), feature_mode=True)

@@ -22,7 +22,7 @@ cap = {}
 orig = R._backward_staged
 
 
-def spy(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n_, d_, width, height, *extra, **kw):
+def spy(lib, rctx, offsets, n_isects, blk_rows, fwd_scratch, v_out, n_, d_, width, height, *extra, **kw):
     # (*extra: whatever _backward_staged grew since -- flags, flatten_ids; passed through untouched)
     ne = lib.gags_bwd_rowmap_elems(n_isects, width, height)
     rm = torch.empty(ne, dtype=torch.int32, device=v_out.device)
@@ -32,8 +32,8 @@ def spy(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n_, d_, width, hei
     R.check(lib.gags_bwd_rowmap(n_isects, width, height, R.ptr(offsets), R.ptr(blk_rows), R.ptr(fwd_scratch), fwd_scratch.numel(),
                                 R.ptr(rm), ne, R.ptr(tot), R.ptr(tmp), sb, None), "rowmap")
     torch.cuda.synchronize()
-    cap.update(offsets=offsets.cpu().numpy().reshape(-1), blk=blk_rows.cpu().numpy(), rm=rm.cpu().numpy(), I=n_isects)
-    return orig(lib, offsets, n_isects, blk_rows, fwd_scratch, v_out, n_, d_, width, height, *extra, **kw)
+    cap.update(offsets=offsets.cpu().numpy().reshape(-1)[:-1], blk=blk_rows.cpu().numpy(), rm=rm.cpu().numpy(), I=n_isects)
+    return orig(lib, rctx, offsets, n_isects, blk_rows, fwd_scratch, v_out, n_, d_, width, height, *extra, **kw)
 
 
 R._backward_staged = spy

@@ -24,9 +24,9 @@ def spy(*a, **k):
     return out
 R.tile_binning = spy
 orig_b = R._backward_staged
-def spy_b(lib, offsets, n_isects, blk_rows, *a, **k):
+def spy_b(lib, rctx, offsets, n_isects, blk_rows, *a, **k):
     cap["blk_rows"] = blk_rows.clone()
-    return orig_b(lib, offsets, n_isects, blk_rows, *a, **k)
+    return orig_b(lib, rctx, offsets, n_isects, blk_rows, *a, **k)
 R._backward_staged = spy_b
 pkg = render(cam, pc, None, torch.zeros(3, device=dev), feature_mode=True)
 pkg["render"].sum().backward()

@@ -18,10 +18,10 @@ pc.training_setup()
 cam = syn.make_camera(w, h, device=dev)
 cap = {}
 orig = R._backward_staged
-def spy(lib, offsets, n_isects, blk_rows, fwd_scratch, *a, **k):
-    cap.update(offsets=offsets.clone().reshape(-1).long(), n_isects=n_isects, blk_rows=blk_rows.clone().long(),
+def spy(lib, rctx, offsets, n_isects, blk_rows, fwd_scratch, *a, **k):
+    cap.update(offsets=offsets[:-1].clone().reshape(-1).long(), n_isects=n_isects, blk_rows=blk_rows.clone().long(),
                scratch=fwd_scratch)
-    return orig(lib, offsets, n_isects, blk_rows, fwd_scratch, *a, **k)
+    return orig(lib, rctx, offsets, n_isects, blk_rows, fwd_scratch, *a, **k)
 R._backward_staged = spy
 pkg = render(cam, pc, None, torch.zeros(3, device=dev), feature_mode=True)
 pkg["render"].sum().backward()
