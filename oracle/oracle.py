@@ -23,8 +23,8 @@ TILE = 16
 
 def build(force=False):
     """Compile libgags_oracle.so with gcc (oracle/Makefile)."""
-    src = os.path.join(_HERE, "gags_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("gags_oracle.c", "gags_cpu.c")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libgags_oracle.so"])
     return _LIB_PATH
 

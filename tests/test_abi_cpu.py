@@ -14,6 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     names = set()
     for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        if os.path.basename(h) == "gags_cpu.h":  # the CPU twins live in oracle/libgags_oracle.so (test infrastructure)
+            continue
         src = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
         names |= set(re.findall(r"\b(gags_\w+)\s*\(", src))
     return names
@@ -102,3 +104,80 @@ def test_cpu_tensors_are_rejected_not_rerouted():
     with pytest.raises(RuntimeError, match="no CPU path"):
         rasterization(torch.zeros(4, 3), torch.zeros(4, 4), torch.zeros(4, 3), torch.zeros(4), torch.zeros(4, 3),
                       torch.eye(4)[None], torch.eye(3)[None], 16, 16)
+
+
+def test_cpu_twins_share_the_c_abi_signatures(oracle):
+    """"CPU twins with identical signatures".  oracle/libgags_oracle.so exports gags_cpu_<name> for the core
+    entry points (include/gags_cpu.h); each is typed here with the ctypes signature _lib.SIGNATURES holds for gags_<name>
+    -- the very table the product binds the GPU library with -- and the whole operator is driven through them on host
+    pointers: projection, prefix sum, emit, sort, offsets, forward, backward.  Result == the oracle's own front-end."""
+    import ctypes
+    import re
+    import numpy as np
+    from gags_amd import _lib
+    from helpers import scene_arrays
+    here = os.path.dirname(os.path.abspath(__file__))
+    strip = lambda txt: re.sub(r"/\*.*?\*/", "", txt, flags=re.S)  # noqa: E731
+    header = strip(open(os.path.join(here, "..", "include", "gags_cpu.h")).read())
+    gh = strip(open(os.path.join(here, "..", "include", "gags_raster.h")).read())
+    names = sorted(set(re.findall(r"\b(gags_cpu_\w+)\s*\(", header)))
+    assert len(names) >= 14
+    cpu = ctypes.CDLL(os.path.join(here, "..", "oracle", "libgags_oracle.so"))
+    fn = {}
+    for name in names:
+        gpu_name = name.replace("gags_cpu_", "gags_")
+        assert gpu_name in _lib.SIGNATURES, f"{name} has no GPU counterpart in the C ABI"
+        f = getattr(cpu, name)  # exported
+        f.restype, f.argtypes = _lib.SIGNATURES[gpu_name]
+        fn[gpu_name] = f
+        # ... and the header declares the twin with the GPU entry's parameter list, token for token
+        norm = lambda txt: re.sub(r"\s+", "", txt)  # noqa: E731
+        decl_cpu = re.search(re.escape(name) + r"\s*\((.*?)\)\s*;", header, re.S).group(1)
+        decl_gpu = re.search(r"\b" + re.escape(gpu_name) + r"\s*\((.*?)\)\s*;", gh, re.S).group(1)
+        assert norm(decl_cpu) == norm(decl_gpu), name
+
+    def P(a):
+        return None if a is None else ctypes.c_void_p(a.ctypes.data)
+
+    n, w, h, d = 1500, 96, 64, 16
+    s = scene_arrays(n, d, w, h, seed=3, view=2, scale_mult=6.0)
+    bg = np.full(d, 0.25, np.float32)
+    tw, th = (w + 15) // 16, (h + 15) // 16
+    radii, tiles = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    m2d, depths, conics = np.zeros((n, 2), np.float32), np.zeros(n, np.float32), np.zeros((n, 3), np.float32)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)  # noqa: E731
+    means, quats, scales, opac, cols = (f32(s[k]) for k in ("means", "quats", "scales", "opacities", "colors"))
+    vm, K = f32(s["viewmat"]), f32(s["K"])
+    assert fn["gags_project_fwd"](n, P(means), P(quats), P(scales), P(vm), P(K), w, h, 0.3, 0.01, 1e10, 0.0, P(radii), P(m2d),
+                                  P(depths), P(conics), P(tiles), None) == 0
+    cum, total = np.zeros(n, np.int32), np.zeros(1, np.int32)
+    assert fn["gags_cumsum_i32"](n, P(tiles), P(cum), P(total), None, 0, None) == 0
+    ni = int(total[0])
+    ids, flat = np.zeros(ni, np.int64), np.zeros(ni, np.int32)
+    assert fn["gags_tile_emit"](n, P(m2d), P(radii), P(depths), P(cum), None, tw, th, P(ids), P(flat), None) == 0
+    ids_s, flat_s = np.zeros_like(ids), np.zeros_like(flat)
+    assert fn["gags_sort_pairs"](ni, max(1, (tw * th).bit_length()), 0, P(ids), P(flat), P(ids_s), P(flat_s), None, 0, None) == 0
+    offsets = np.zeros(tw * th + 1, np.int32)
+    assert fn["gags_tile_offsets"](ni, P(ids_s), tw * th, P(offsets), None) == 0
+    assert offsets[-1] == ni
+    out, alphas, last = np.zeros((h, w, d), np.float32), np.zeros((h, w), np.float32), np.zeros((h, w), np.int32)
+    assert fn["gags_raster_fwd"](d, n, w, h, P(m2d), P(conics), P(opac), P(cols), P(bg), P(offsets), P(flat_s), ni, None, P(out),
+                                 P(alphas), P(last), None, 0, None, 0, None) == 0
+    v_out = np.random.default_rng(5).standard_normal((h, w, d)).astype(np.float32)
+    v_cols = np.zeros((n, d), np.float32)
+    assert fn["gags_raster_bwd"](d, w, h, P(m2d), P(conics), P(opac), P(cols), P(bg), P(offsets), P(flat_s), ni, None, P(alphas),
+                                 P(last), P(v_out), None, P(v_cols), None, None, None, _lib.GAGS_BWD_COLORS_ONLY, None) == 0
+    o_out, o_alpha, oi = oracle.rasterization(s["means"], s["quats"], s["scales"], s["opacities"], s["colors"], s["viewmat"],
+                                              s["K"], bg, w, h)
+    np.testing.assert_array_equal(radii, oi["radii"])
+    np.testing.assert_array_equal(ids_s, oi["isect_ids"])
+    np.testing.assert_array_equal(flat_s, oi["flatten_ids"])
+    np.testing.assert_array_equal(offsets[:-1].reshape(th, tw), oi["isect_offsets"])
+    np.testing.assert_array_equal(out, o_out)
+    np.testing.assert_array_equal(last, oi["last_ids"])
+    o_vc, _, _, _ = oracle.raster_bwd(oi["means2d"], oi["conics"], s["opacities"], s["colors"], bg, w, h, oi["isect_offsets"],
+                                      oi["flatten_ids"], o_alpha, oi["last_ids"], v_out, None, colors_only=True)
+    np.testing.assert_allclose(v_cols, o_vc, rtol=0, atol=1e-5 * float(np.abs(o_vc).max()))  # (per-tile sums added in thread order)
+    # error convention of the ABI: a bad argument is a code, not a crash
+    assert fn["gags_raster_fwd"](0, n, w, h, None, None, None, None, None, None, None, 0, None, None, None, None, None, 0, None, 0,
+                                 None) == -1
