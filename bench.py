@@ -142,6 +142,68 @@ def cpu_baseline(pc, cam, d, width, height, target_s):
     }
 
 
+def iteration_d16(dev, n, width, height, steps):
+    """One train.py:142-174 iteration at D = 16 (tools/decoder_bench.py's loop, inside bench.py): ms per iteration with the
+    decoders in the tier matched to the reference's arithmetic (bf16x2: operands as two bf16 terms, 16 significand bits --
+    the reference's convolutions run in TF32, 11 bits, by PyTorch's default) and, labelled as NARROWER than the reference,
+    in plain bf16."""
+    from gags_amd import decoders as D, synthetic as syn
+    from gags_amd.decoders import CNN_decoder, CNN_scale_decoder
+    from gags_amd.distill import distillation_loss
+    from gags_amd.gaussian_renderer import render
+    d = 16
+    pc = syn.make_model(n, d, width, height, seed=0, device=dev, gen_device=dev)
+    pc.training_setup()
+    cam = syn.make_camera(width, height, device=dev)
+    bg = torch.zeros(3, device=dev)
+    g = torch.Generator(device=dev).manual_seed(0)
+    n_emb = 300
+    img_embed = torch.nn.functional.normalize(torch.randn(n_emb, 512, device=dev, generator=g), dim=-1)
+    seg = torch.randint(-1, n_emb, (4, height // 8 + 1, width // 8 + 1), device=dev, generator=g).float()
+    seg = seg.repeat_interleave(8, 1).repeat_interleave(8, 2)[:, :height, :width].contiguous()
+    out = {"workload": f"train.py:142-174 iteration: {n} Gaussians, {width}x{height}, D=16 -> CNN_scale_decoder + CNN_decoder "
+                       "(16 -> 512) -> distillation losses (all three terms) -> backward through decoders and rasterizer"}
+    k = max(3, min(steps, 8))
+    for precision in ("bf16x2", "bf16"):
+        dec, sdec = CNN_decoder(16, 512, precision).to(dev), CNN_scale_decoder(16, 3, precision).to(dev)
+
+        def iteration(marks=None):
+            D.invalidate_packed()  # as after an optimizer step: the decoders' weights are repacked every iteration
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
+            fmap = render(cam, pc, None, bg, feature_mode=True)["render"]
+            ev[1].record()
+            loss, _ = distillation_loss(fmap, seg, img_embed, dec, sdec, iteration=20000, fused_head=True)
+            ev[2].record()
+            for m in (dec, sdec):
+                m.zero_grad(set_to_none=True)
+            pc._semantic_feature.grad = None
+            loss.backward()
+            ev[3].record()
+            if marks is not None:
+                marks.append(ev)
+
+        for _ in range(2):
+            iteration()
+        torch.cuda.synchronize()
+        marks = []
+        t0 = time.perf_counter()
+        for _ in range(k):
+            iteration(marks)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / k
+        st = {nm: sum(e[i].elapsed_time(e[i + 1]) for e in marks) / k
+              for i, nm in enumerate(("render16", "decoders_and_losses_fwd", "backward"))}
+        out[precision] = {"ms_per_iteration": ms, "iterations_per_s": 1e3 / ms, "steps": k, "stages_ms": st,
+                          "precision_note": ("operands as two bf16 terms (16 significand bits), three matrix terms per product, fp32 "
+                                             "accumulation: at or above the TF32 (11-bit) convolutions the reference runs" if precision == "bf16x2"
+                                             else "plain bf16 operands (8 significand bits): NARROWER than the reference's TF32 -- reported "
+                                                  "for comparison, not a creditable number")}
+        del dec, sdec
+        torch.cuda.empty_cache()
+    return out
+
+
 def rccl_info():
     """What decides the collective's algorithm on this stack: library version and the NCCL_* / RCCL_* environment."""
     try:
@@ -177,12 +239,12 @@ def host_cpu():
 # (matched as prefixes: template arguments differ between rounds, e.g. "raster_fwd_feat<4, false>")
 STAGE_KERNELS = {
     "raster_weights": ("raster_weights_kernel",),
-    "raster_fwd_feat": ("raster_fwd_feat<4",),
+    "raster_fwd_feat": ("raster_fwd_feat_x16",),   # (GAGS_FWD_EXACT: "raster_fwd_feat<4")
     "bwd_rows": ("raster_bwd_rows",),
     "bwd_reduce": ("reduce_rows_kernel",),
 }
 # flops one matrix instruction of each kernel issues (SQ_INSTS_MFMA x this = issued matrix work per launch)
-MFMA_FLOP = {"raster_fwd_feat": 2 * 32 * 32 * 2,    # v_mfma_f32_32x32x2_f32
+MFMA_FLOP = {"raster_fwd_feat": 2 * 32 * 32 * 16,   # v_mfma_f32_32x32x16_bf16 (six terms per product)
              "bwd_rows": 2 * 32 * 32 * 16}           # v_mfma_f32_32x32x16_f16
 F16_MATRIX_PEAK_TFLOPS = 2516.6   # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak
 
@@ -267,8 +329,7 @@ def main():
                                              share._semantic_feature.data[:, :dl].contiguous())
         pc_.training_setup()
         # the getters (exp / normalize / sigmoid of the frozen geometry) are evaluated on EVERY render, inside the timed
-        # region, as the reference does (scene/gaussian_model.py:116-139); the library's opt-in activation cache is
-        # measured separately and reported as `activation_cache_on`
+        # region, as the reference does (scene/gaussian_model.py:116-139) -- fused into the projection kernel
         pc_.cache_activations(cache)
         cams = [syn.make_camera(width, height, view=(v % 8) if v is not None else None, device=dev) for v in views]
         G_ = syn.make_cotangent(dl, height, width, seed=1, device=dev)  # [D,H,W] view of [H,W,D] memory
@@ -467,7 +528,8 @@ def main():
         pix = width * height
         #   raster_weights : HBM bytes = 40 I (ids, records, hit flags) + 264 slots (weight row, ids) + 12 P (alpha, last id, T)
         #                    (reported against HBM; the kernel is VALU-bound -- 14 flops per evaluated pair -- and says so)
-        #   raster_fwd_feat: 2*D*Q_blend flops  (fp32 matrix instructions)
+        #   raster_fwd_feat: 2*D*Q_blend flops  (priced against the fp32 matrix peak: the arithmetic it replaces; issued as six
+        #                    v_mfma_f32_32x32x16_bf16 terms per product on operands split into three bf16 terms)
         work = {
             "raster_weights": ("hbm", 40.0 * n_isects + 264.0 * slots + 12.0 * pix),
             "raster_fwd_feat": ("mfma", 2.0 * dl * q_blend),
@@ -498,7 +560,8 @@ def main():
                 if name in MFMA_FLOP and mi:
                     ms = kernels[name]["avg_launch_ms"]
                     issued = mi * MFMA_FLOP[name]
-                    pipe_peak = F16_MATRIX_PEAK_TFLOPS if name == "bwd_rows" and not (args.raster_flags & _lib.GAGS_BWD_F32MFMA) else FP32_MATRIX_PEAK_TFLOPS
+                    pipe_peak = (FP32_MATRIX_PEAK_TFLOPS if (name == "bwd_rows" and (args.raster_flags & _lib.GAGS_BWD_F32MFMA))
+                                 or (name == "raster_fwd_feat" and (args.raster_flags & _lib.GAGS_FWD_EXACT)) else F16_MATRIX_PEAK_TFLOPS)
                     kernels[name]["issued_flops"] = issued
                     kernels[name]["mfma_issue_frac"] = issued / (ms * 1e-3) / 1e12 / pipe_peak
                     kernels[name]["mfma_busy_cycles"] = _traffic_of(traffic, members[0], "mfma_busy_cycles")
@@ -506,6 +569,10 @@ def main():
         if "raster_weights" in kernels:
             kernels["raster_weights"]["note"] = ("VALU-bound (14 flops per evaluated pair: 14*Q_eval = %.1f GFLOP per launch); priced "
                                                  "against HBM by the bytes it has to move" % (14.0 * q_eval / 1e9))
+        if "raster_fwd_feat" in kernels and not (args.raster_flags & _lib.GAGS_FWD_EXACT):
+            kernels["raster_fwd_feat"]["note"] = ("algorithmic fp32 flops (2 D Q_blend) against the fp32 matrix peak; issued as 6 "
+                                                  "v_mfma_f32_32x32x16_bf16 terms per product, both operands split into three bf16 terms "
+                                                  "in registers (exact operands; fp32-equivalent, DESIGN.md 4)")
         if "bwd_rows" in kernels and not (args.raster_flags & _lib.GAGS_BWD_F32MFMA):
             kernels["bwd_rows"]["note"] = ("algorithmic fp32 flops (2 D Q_blend) against the fp32 matrix peak; the kernel issues them as "
                                            "5 v_mfma_f32_32x32x16_f16 terms per product on split operands (fp32-equivalent, DESIGN.md 4)")
@@ -516,8 +583,10 @@ def main():
             "value": value, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "dtype_note": "fp32 tensors and fp32(-equivalent) arithmetic: forward on v_mfma_f32_32x32x2_f32 (bit-identical to the oracle); "
-                          "backward contraction on v_mfma_f32_32x32x16_f16 with fp32-equivalent split operands, fp32 accumulation",
+            "dtype_note": "fp32 tensors and fp32(-equivalent) arithmetic: forward contraction on v_mfma_f32_32x32x16_bf16 with both operands "
+                          "split into three bf16 terms (exact operands, six terms per product: as close to float64 as the fp32 chain; "
+                          "GAGS_FWD_EXACT = v_mfma_f32_32x32x2_f32, bit-identical to the oracle); backward contraction on "
+                          "v_mfma_f32_32x32x16_f16 with fp32-equivalent split operands; fp32 accumulation in both",
             "config": {"workload": f"{args.config}: {n} Gaussians, {width}x{height}, D={d}, {world} view(s)/step"
                                    + (f", every GPU renders all {world} views for its {d_local} channels"
                                       if mode == "channel" else ", 1 view/GPU/step"),
@@ -543,7 +612,9 @@ def main():
                                           "rccl": rccl_info()})},
             "roofline": roof,
             "kernels": kernels,
-            "activation_getters": "evaluated on every render inside the timed region (scene/gaussian_model.py:116-139), cache off",
+            "activation_getters": "fused: exp / normalize / sigmoid of scene/gaussian_model.py:116-139 run inside the projection kernel "
+                                  "(gags_project_fwd_raw, bit-identical to torch's) on every render, inside the timed region; no getter "
+                                  "kernels are launched, so the activation cache of gags_amd/scene.py has nothing left to save here",
             "stages_ms": {k: round(v[0], 4) for k, v in sorted(stages.items())},
             "step_ms": {"median": per_step[len(per_step) // 2], "p10": per_step[int(0.1 * (len(per_step) - 1))],
                         "p90": per_step[int(round(0.9 * (len(per_step) - 1)))]},
@@ -556,22 +627,6 @@ def main():
         gbs = b_view * views_per_gpu_step / (ms_per_step * 1e-3) / 1e9
         line["hbm_roofline_step"] = {"algorithmic_bytes_per_view": b_view, "achieved": gbs, "peak": HBM_PEAK_GBS,
                                      "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
-        if world == 1 and not (args.no_heavy or args.raster_flags):
-            # the library's opt-in activation cache (frozen geometry: getters evaluated once, gags_amd/scene.py); OFF in `value`
-            pc.cache_activations(True)
-            for _ in range(2):
-                step()
-            torch.cuda.synchronize()
-            csteps = max(3, min(args.steps, 10))
-            t0 = time.perf_counter()
-            for _ in range(csteps):
-                step()
-            torch.cuda.synchronize()
-            cdt = time.perf_counter() - t0
-            pc.cache_activations(False)
-            line["activation_cache_on"] = {"note": "same workload with GaussianModel.cache_activations(True): exp / normalize / sigmoid "
-                                                   "of the frozen geometry evaluated once instead of on every render",
-                                           "value": csteps / cdt, "unit": "views/s", "ms_per_step": 1e3 * cdt / csteps, "steps": csteps}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(pc, cam, d, width, height, args.cpu_seconds)
         if world == 1 and d % 128 == 0 and not (args.no_heavy or args.raster_flags):
@@ -617,6 +672,45 @@ def main():
                 "note": "same workload, gradients of features AND means, quats, scales, opacities (SURVEY A9 + K2): geometry "
                         "dot products on the 16-bit matrix cores with fp32-equivalent split operands (gags_raster_bwd_geom), no atomics",
                 "value": gsteps / gdt, "unit": "views/s", "ms_per_step": 1e3 * gdt / gsteps, "steps": gsteps}
+        if world == 1 and d % 128 == 0 and d > 128 and not (args.no_heavy or args.raster_flags):
+            # The N > 1 code path priced on ONE GPU (no multi-GPU box is reachable from the build): the by-view step exactly as
+            # rank 0 of 8 runs it, with every collective replaced by two device copies of the block it would exchange
+            # (OverlappedGradReducer(loopback=...)): range-staged backward, gags_blended_mask, gags_compact_mask, pack and unpack
+            # of C4's union block (446 525 rows = 29.8 % of N at C3: tools/union_rows.py), on the exchange stream under the
+            # backward.  What it does NOT contain is the wire time of RCCL over xGMI (DESIGN.md section 6 prices that).
+            union_rows = int(round(0.2977 * n))
+            red = OverlappedGradReducer(mode="rs_ag", rows="union", param=pc._semantic_feature, loopback=(8, union_rows))
+
+            def dp_step():
+                pc._semantic_feature.grad = None
+                pkg_ = render(cam, pc, None, bg, feature_mode=True)
+                loss = _CotangentLoss.apply(pkg_["render"].permute(1, 2, 0), G_dp.permute(1, 2, 0))
+                with red:
+                    loss.backward()
+                red.finish(pc._semantic_feature.grad)
+
+            G_dp = syn.make_cotangent(d, height, width, seed=1, device=dev)
+            for _ in range(2):
+                dp_step()
+            torch.cuda.synchronize()
+            vsteps = max(3, min(args.steps, 10))
+            t0 = time.perf_counter()
+            for _ in range(vsteps):
+                dp_step()
+            torch.cuda.synchronize()
+            vdt = 1e3 * (time.perf_counter() - t0) / vsteps
+            t0 = time.perf_counter()
+            for _ in range(vsteps):
+                step()
+            torch.cuda.synchronize()
+            pdt = 1e3 * (time.perf_counter() - t0) / vsteps
+            line["view_dp_overhead_ms"] = {
+                "note": "by-view step as rank 0 of 8 runs it, loop-back exchange (two device copies per 128-channel block instead of "
+                        "the collective): range-staged backward + gags_blended_mask + gags_compact_mask + pack / unpack of the "
+                        "union block, overlapped with the backward on a second stream; xGMI wire time not included",
+                "plain_step_ms": pdt, "view_dp_step_ms": vdt, "overhead_ms": vdt - pdt, "union_rows": red.rows_exchanged,
+                "exposed_ms_last_step": red.exposed_ms(), "range_exchange_ms_last_step": red.range_ms, "steps": vsteps}
+            del red, G_dp
         if world == 1 and args.config == "C3" and not (args.no_heavy or args.n or args.d):
             # second reading of SURVEY 8d (gags_amd/synthetic.py): same N / resolution / D, ~4.4x larger splats
             del step, pc
@@ -638,6 +732,14 @@ def main():
                 "workload": f"C3H: {n} Gaussians, {width}x{height}, D={d}, splat scale 0.004 z_mean (SURVEY 8d literal)",
                 "value": hsteps / hdt, "unit": "views/s", "ms_per_step": 1e3 * hdt / hsteps, "steps": hsteps,
                 "n_isects": hi, "visible": hv, "isects_per_visible": hi / max(hv, 1)}
+        if world == 1 and args.config == "C3" and not (args.no_heavy or args.n or args.d or args.raster_flags):
+            # BASELINE.json configs[2] says "full GAD.sh distillation loop": one train.py:142-174 iteration at the width the
+            # reference really rasterizes (D = 16, train.py:68) -- render -> CNN_scale_decoder / CNN_decoder -> losses ->
+            # backward through decoders and rasterizer -- through gags_amd.distill.distillation_loss, the composition
+            # tests/test_iteration_gpu.py pins against the reference's own functions.  Not `value` (the metric is the
+            # feature rasterizer); on the driver's clock so that it is not a builder-only number.
+            torch.cuda.empty_cache()
+            line["iteration_d16"] = iteration_d16(dev, n, width, height, args.steps)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

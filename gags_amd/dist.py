@@ -210,7 +210,7 @@ class OverlappedGradReducer:
     untouched gradient.  `exposed_ms()` = time the compute stream spent on the exchange after the backward had finished."""
 
     def __init__(self, mode="rs_ag", wire=None, bucket_bytes=BUCKET_BYTES, rows="union", param=None, sync_free=False,
-                 cap_margin=1.1, cap_slack=1024, context=None):
+                 cap_margin=1.1, cap_slack=1024, context=None, loopback=None):
         if rows not in ("union", "all"):
             raise ValueError(rows)
         if wire not in (None, "fp32", "bf16"):
@@ -218,6 +218,12 @@ class OverlappedGradReducer:
         self.mode, self.wire, self.bucket_bytes, self.rows, self.param = mode, wire, bucket_bytes, rows, param
         self.sync_free, self.cap_margin, self.cap_slack = bool(sync_free), float(cap_margin), int(cap_slack)
         self.context = context  # the RasterContext whose backward feeds this reducer (None: the entering thread's default)
+        # loopback = (world_size, union_rows): ONE process runs the step exactly as rank 0 of `world_size` would -- the
+        # range-staged backward, gags_blended_mask, gags_compact_mask, pack and unpack of a block of `union_rows` rows (this
+        # view's own rows, topped up to that count) -- with each collective replaced by two device copies of the block (the
+        # bytes a reduce-scatter + all-gather move through this GPU's memory).  bench.py prices the N > 1 code path on one
+        # GPU with it (`view_dp_overhead_ms`); the "sum" it returns is this rank's own gradient.
+        self.loopback = loopback
         self._cap_hint, self._pinned = {}, {}
         self.comm = torch.cuda.Stream() if torch.cuda.is_available() else None
         self.rows_exchanged = None  # |union| of the last step (None: all rows)
@@ -238,12 +244,34 @@ class OverlappedGradReducer:
         self._ctx = self.context if self.context is not None else rasterization.default_context()
         self._prev = (self._ctx.grad_range_hook, self._ctx.grad_rows_hook)
         self._ctx.grad_range_hook = self.on_range
-        self._ctx.grad_rows_hook = self.on_rows if (self.rows == "union" and world() > 1) else None
+        self._ctx.grad_rows_hook = self.on_rows if (self.rows == "union" and self._world() > 1) else None
         return self
 
     def __exit__(self, *exc):
         self._ctx.grad_range_hook, self._ctx.grad_rows_hook = self._prev
         return False
+
+    def _world(self):
+        return self.loopback[0] if self.loopback else world()
+
+    def _collective(self, wire):
+        if self.loopback:  # two passes over the block, like the shard exchange of a reduce-scatter + all-gather
+            tmp = torch.empty_like(wire)
+            tmp.copy_(wire)
+            wire.copy_(tmp)
+        else:
+            reduce_feature_grad(wire, mode=self.mode, bucket_bytes=self.bucket_bytes)
+
+    def _union_mask(self, mask):
+        if not self.loopback:
+            dist.all_reduce(mask, op=dist.ReduceOp.MAX)
+            return
+        # loop-back: rows of other ranks' views are emulated by marking further rows until the union has `union_rows`
+        want = int(self.loopback[1])
+        have = int(mask.sum().item()) if want else 0
+        if have < want:
+            free = torch.nonzero(mask == 0).squeeze(1)
+            mask[free[:want - have]] = 1
 
     def on_rows(self, mask):
         """mask uint8 [N] of this rank's view; the union over the ranks is formed on the exchange stream right away
@@ -255,10 +283,10 @@ class OverlappedGradReducer:
             ev.record()
             with torch.cuda.stream(self.comm):
                 self.comm.wait_event(ev)
-                dist.all_reduce(mask, op=dist.ReduceOp.MAX)
+                self._union_mask(mask)
             mask.record_stream(self.comm)
         else:
-            dist.all_reduce(mask, op=dist.ReduceOp.MAX)
+            self._union_mask(mask)
         self._mask = mask
 
     def _union_rows(self):
@@ -326,7 +354,7 @@ class OverlappedGradReducer:
             self.rows_exchanged = None
         wire = _pack_rows(grad, idx, c0, c1, torch.bfloat16 if self.wire == "bf16" else torch.float32)
         local = wire.clone()  # always: whether autograd adopts the hook's tensor is only known in finish()
-        reduce_feature_grad(wire, mode=self.mode, bucket_bytes=self.bucket_bytes)
+        self._collective(wire)
         return dict(c0=c0, c1=c1, wire=wire, local=local, idx=idx)
 
     def on_range(self, grad, c0, c1):
@@ -337,7 +365,7 @@ class OverlappedGradReducer:
             self._alias_version = grad._version  # kernels write through raw pointers: only torch in-place ops bump it
         self._alias = grad
         self._covered += c1 - c0
-        if world() == 1:
+        if self._world() == 1:
             return
         if grad.is_cuda and self.comm is not None:
             ev = torch.cuda.Event()
@@ -365,7 +393,7 @@ class OverlappedGradReducer:
             self._bwd_done = torch.cuda.Event(enable_timing=True)
             self._bwd_done.record()
             torch.cuda.current_stream().wait_stream(self.comm)
-        ws = world()
+        ws = self._world()
         used = ws > 1 and bool(self._entries) and self._covered == param_grad.shape[1]
         if self._entries and not used:
             raise RuntimeError(f"OverlappedGradReducer: the backward delivered {self._covered} of "
@@ -376,7 +404,7 @@ class OverlappedGradReducer:
             for e in self._entries:
                 wire = _pack_rows(self._alias, None, e["c0"], e["c1"], e["wire"].dtype)
                 e.update(idx=None, local=wire.clone(), wire=wire)
-                reduce_feature_grad(wire, mode=self.mode, bucket_bytes=self.bucket_bytes)
+                self._collective(wire)
             self.rows_exchanged = None  # (all N rows went over the wire in the end)
         if used:
             # adopted: the parameter's gradient IS the tensor the hook saw (same storage, same shape) and no in-place op
@@ -392,7 +420,7 @@ class OverlappedGradReducer:
                     e["wire"].record_stream(torch.cuda.current_stream())
                     if e["local"] is not None:
                         e["local"].record_stream(torch.cuda.current_stream())
-        elif ws > 1:
+        elif ws > 1 and not self.loopback:
             reduce_feature_grad(param_grad, mode=self.mode, bucket_bytes=self.bucket_bytes)
         if cuda:
             self._all_done = torch.cuda.Event(enable_timing=True)
