@@ -96,7 +96,7 @@ extern "C" int gags_raster_fwd(int d, int n, int width, int height, const float 
                                const void *packed, float *render_colors, float *render_alphas, int32_t *last_ids,
                                void *scratch, int64_t scratch_bytes, int32_t *blk_rows, int flags, void *stream)
 {
-    if (d <= 0 || n < 0 || width <= 0 || height <= 0 || n_isects < 0 || n_isects >= (1ll << 27)) return GAGS_EINVAL;
+    if (d <= 0 || n < 0 || width <= 0 || height <= 0 || n_isects < 0 || n_isects >= GAGS_MAX_ISECTS) return GAGS_EINVAL;
     if (!isect_offsets || !render_colors || !render_alphas || !last_ids) return GAGS_EINVAL;
     if (n_isects > 0 && (!means2d || !conics || !opacities || !colors || !flatten_ids)) return GAGS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -136,7 +136,7 @@ extern "C" int gags_raster_bwd(int d, int width, int height, const float *means2
                                const float *v_render_colors, const float *v_render_alphas, float *v_colors,
                                float *v_opacities, float *v_means2d, float *v_conics, int flags, void *stream)
 {
-    if (d <= 0 || width <= 0 || height <= 0 || n_isects < 0 || n_isects >= (1ll << 27)) return GAGS_EINVAL;
+    if (d <= 0 || width <= 0 || height <= 0 || n_isects < 0 || n_isects >= GAGS_MAX_ISECTS) return GAGS_EINVAL;
     if (n_isects == 0) return GAGS_OK;
     if (!means2d || !conics || !opacities || !colors || !isect_offsets || !flatten_ids || !render_alphas ||
         !last_ids || !v_render_colors || !v_colors)
@@ -189,7 +189,7 @@ extern "C" int gags_bwd_rowmap(int64_t n_isects, int width, int height, const in
                                int64_t scratch_bytes, void *stream)
 {
     GAGS_CLEAR_ERR();
-    if (n_isects < 0 || n_isects >= (1ll << 27) || width <= 0 || height <= 0 || !fwd_scratch || !rowmap || !total ||
+    if (n_isects < 0 || n_isects >= GAGS_MAX_ISECTS || width <= 0 || height <= 0 || !fwd_scratch || !rowmap || !total ||
         !isect_offsets || !blk_rows)
         return GAGS_EINVAL;
     if (rowmap_elems < gags_bwd_rowmap_elems(n_isects, width, height)) return GAGS_ESCRATCH;
@@ -220,7 +220,7 @@ extern "C" int gags_raster_bwd_geom(int d, int n, int width, int height, const f
                                     float *v_geo, const int32_t *flatten_ids, const int32_t *row_base, int64_t n_rows,
                                     int flags, void *stream)
 {
-    if (d <= 0 || width <= 0 || height <= 0 || n < 0 || n_isects < 0 || n_isects >= (1ll << 27)) return GAGS_EINVAL;
+    if (d <= 0 || width <= 0 || height <= 0 || n < 0 || n_isects < 0 || n_isects >= GAGS_MAX_ISECTS) return GAGS_EINVAL;
     if (n == 0) return GAGS_OK;
     if (!colors || !isect_offsets || !packed || !v_render_colors || !blk_rows || !fwd_scratch || !scratch || !v_geo)
         return GAGS_EINVAL;
@@ -239,7 +239,7 @@ extern "C" int gags_raster_bwd_geom(int d, int n, int width, int height, const f
 extern "C" int gags_blended_mask(int64_t n_isects, int width, int height, int n, const int32_t *flatten_ids,
                                  const void *fwd_scratch, int64_t fwd_scratch_bytes, unsigned char *mask, void *stream)
 {
-    if (n_isects < 0 || n_isects >= (1ll << 27) || width <= 0 || height <= 0 || n < 0) return GAGS_EINVAL;
+    if (n_isects < 0 || n_isects >= GAGS_MAX_ISECTS || width <= 0 || height <= 0 || n < 0) return GAGS_EINVAL;
     if (n == 0) return GAGS_OK;
     if (!mask) return GAGS_EINVAL;
     if (hipMemsetAsync(mask, 0, (size_t)n, (hipStream_t)stream) != hipSuccess) return GAGS_ELAUNCH;
@@ -258,7 +258,7 @@ extern "C" int gags_raster_bwd_colors_staged_cap(int d, int n, int width, int he
                                                  float *v_colors, int stage, int ch_begin, int ch_count,
                                                  const int32_t *rows_dev, void *stream)
 {
-    if (d <= 0 || width <= 0 || height <= 0 || n < 0 || n_isects < 0 || n_isects >= (1ll << 27) || rows < 0 ||
+    if (d <= 0 || width <= 0 || height <= 0 || n < 0 || n_isects < 0 || n_isects >= GAGS_MAX_ISECTS || rows < 0 ||
         rows >= (1ll << 31) || stage < 0 || (stage & 15) > 3)
         return GAGS_EINVAL;
     if (n == 0) return GAGS_OK;

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void rast
     int d, int width, int height, int tile_w, int n_tiles, int ch_base, int n_slices,
     const float *__restrict__ v_render_colors, const int32_t *__restrict__ offsets, int n_isects,
     const int32_t *__restrict__ blk_rows, const int32_t *__restrict__ trow, const float *__restrict__ wt,
-    const int32_t *__restrict__ gid_s, const int32_t *__restrict__ trow_s, float *__restrict__ prow,
+    const int32_t *__restrict__ gid_s, const int32_t *__restrict__ trow_s, float *__restrict__ prow, int prow_pitch,
     uint32_t *__restrict__ row_key, int32_t *__restrict__ row_idx, int rows_cap)
 {
     constexpr int CW = 32 * NBR;  // channels per slice; this launch covers channels ch_base .. ch_base + n_slices * CW - 1 (clipped to d)
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void rast
 #pragma unroll
                 for (int j = 0; j < NBR; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[t], V[t][j], acc[j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (mine && ch0 == 0 && tr_c < rows_cap) {  // row -> Gaussian map for the sort (every block of the row stores the same pair)
+            if (mine && ch0 == 0 && tr_c < rows_cap) {  // row -> Gaussian map for the sort (every block of the row stores the same pair; the call that covers channel 0 writes it)
                 row_key[tr_c] = (uint32_t)gid_c;
                 row_idx[tr_c] = tr_c;
             }
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256, (NBR == 4 ? 2 : (NBR == 2 ? 3 : 4))) void rast
                 float4 sum;
                 sum.x = ((v[0].x + v[1].x) + v[2].x) + v[3].x; sum.y = ((v[0].y + v[1].y) + v[2].y) + v[3].y;
                 sum.z = ((v[0].z + v[1].z) + v[2].z) + v[3].z; sum.w = ((v[0].w + v[1].w) + v[2].w) + v[3].w;
-                float *dst = prow + (size_t)(r0 + row) * d + ch0 + 4 * c4;
+                float *dst = prow + (size_t)(r0 + row) * prow_pitch + ch0 + 4 * c4;
                 if (r0 + row >= rows_cap) {
                     // (capacity-sized scratch and more rows than it holds: nothing is stored; the caller sees the count
                     // afterwards and runs the backward again with the right size)
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
     int d, int width, int height, int tile_w, int n_tiles, int ch_base, int n_slices,
     const float *__restrict__ v_render_colors, const int32_t *__restrict__ offsets, int n_isects,
     const int32_t *__restrict__ blk_rows, const int32_t *__restrict__ trow, const float *__restrict__ wt,
-    const int32_t *__restrict__ gid_s, const int32_t *__restrict__ trow_s, float *__restrict__ prow,
+    const int32_t *__restrict__ gid_s, const int32_t *__restrict__ trow_s, float *__restrict__ prow, int prow_pitch,
     uint32_t *__restrict__ row_key, int32_t *__restrict__ row_idx, int rows_cap)
 {
     constexpr int NBR = 4, CW = 128, C4 = 32;
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
                 float4 sum;
                 sum.x = ((v[0].x + v[1].x) + v[2].x) + v[3].x; sum.y = ((v[0].y + v[1].y) + v[2].y) + v[3].y;
                 sum.z = ((v[0].z + v[1].z) + v[2].z) + v[3].z; sum.w = ((v[0].w + v[1].w) + v[2].w) + v[3].w;
-                if (r0 + row < rows_cap) *reinterpret_cast<float4 *>(prow + (size_t)(r0 + row) * d + ch0 + 4 * c4) = sum;
+                if (r0 + row < rows_cap) *reinterpret_cast<float4 *>(prow + (size_t)(r0 + row) * prow_pitch + ch0 + 4 * c4) = sum;
             }
             if (trip & 1) __builtin_amdgcn_sched_barrier(0);
         }
@@ -588,8 +588,8 @@ template <bool HALF, int VW>
 __global__ __launch_bounds__(256) void reduce_rows_kernel(int n_gauss, int d, int ch_begin, int ch_count,
                                                           const int32_t *__restrict__ seg,
                                                           const int32_t *__restrict__ sorted_rows,
-                                                          const float *__restrict__ prow, void *__restrict__ v_colors_,
-                                                          int sparse)
+                                                          const float *__restrict__ prow, int prow_pitch,
+                                                          void *__restrict__ v_colors_, int sparse)
 {
     const int lpg = ch_count / VW;  // lanes per Gaussian (channels ch_begin .. ch_begin + ch_count - 1 of its row)
     const int gpb = 256 / lpg;
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(int n_gauss, int d, in
     if (sparse && b == e) return;
     if constexpr (VW == 1) {
         float acc = 0.f;
-        for (int i = b; i < e; ++i) acc += prow[(size_t)sorted_rows[i] * d + cl];
+        for (int i = b; i < e; ++i) acc += prow[(size_t)sorted_rows[i] * prow_pitch + cl];
         if constexpr (HALF) reinterpret_cast<__half *>(v_colors_)[(size_t)g * d + cl] = __float2half_rn(acc);
         else reinterpret_cast<float *>(v_colors_)[(size_t)g * d + cl] = acc;
     } else {
@@ -611,17 +611,17 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(int n_gauss, int d, in
         int i = b;
         for (; i + 3 < e; i += 4) {
             const int r0 = sorted_rows[i], r1 = sorted_rows[i + 1], r2 = sorted_rows[i + 2], r3 = sorted_rows[i + 3];
-            const float4 v0 = *reinterpret_cast<const float4 *>(prow + (size_t)r0 * d + cl);
-            const float4 v1 = *reinterpret_cast<const float4 *>(prow + (size_t)r1 * d + cl);
-            const float4 v2 = *reinterpret_cast<const float4 *>(prow + (size_t)r2 * d + cl);
-            const float4 v3 = *reinterpret_cast<const float4 *>(prow + (size_t)r3 * d + cl);
+            const float4 v0 = *reinterpret_cast<const float4 *>(prow + (size_t)r0 * prow_pitch + cl);
+            const float4 v1 = *reinterpret_cast<const float4 *>(prow + (size_t)r1 * prow_pitch + cl);
+            const float4 v2 = *reinterpret_cast<const float4 *>(prow + (size_t)r2 * prow_pitch + cl);
+            const float4 v3 = *reinterpret_cast<const float4 *>(prow + (size_t)r3 * prow_pitch + cl);
             acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
             acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
             acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
             acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
         }
         for (; i < e; ++i) {
-            const float4 v0 = *reinterpret_cast<const float4 *>(prow + (size_t)sorted_rows[i] * d + cl);
+            const float4 v0 = *reinterpret_cast<const float4 *>(prow + (size_t)sorted_rows[i] * prow_pitch + cl);
             acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
         }
         if constexpr (HALF) {
@@ -795,18 +795,23 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
     if (ch_count <= 0 || ch_begin < 0 || ch_begin + ch_count > d || ch_begin % 32 != 0 ||
         (ch_count % 32 != 0 && ch_begin + ch_count != d))
         return GAGS_EINVAL;
-    const StagedLayout L = staged_layout(rows > 0 ? rows : 1, n_gauss, d);
+    // stage bit 256: the scratch holds partial rows of THIS call's channel range only ([rows, ch_count rounded up to 4]
+    // instead of [rows, d]; sized with gags_bwd_staged_scratch_bytes(rows, n, that width)): a wide gradient is then produced
+    // range by range through a scratch a quarter (an eighth ...) the size -- what lets heavy views fit (C5H: 80 M rows)
+    const bool narrow = (stage_flags & 256) != 0;
+    const int pp = narrow ? ((ch_count + 3) & ~3) : d;
+    const StagedLayout L = staged_layout(rows > 0 ? rows : 1, n_gauss, pp);
     if (scratch_bytes < L.total) return GAGS_ESCRATCH;
     char *sb = (char *)scratch;
     uint32_t *key = (uint32_t *)(sb + L.key), *key_s = (uint32_t *)(sb + L.key_s);
     int32_t *idx = (int32_t *)(sb + L.idx), *idx_s = (int32_t *)(sb + L.idx_s), *seg = (int32_t *)(sb + L.seg);
-    float *prow = (float *)(sb + L.prow);
+    float *prow = (float *)(sb + L.prow) - (narrow ? ch_begin : 0);  // (indexed by absolute channel)
     if (rows > 0) {
         if (sA) {
             // 128-channel slices, then 64, then 32-channel slices (the last one ragged when the range ends at an odd d)
 #define GAGS_ROWS_LAUNCH(KERNEL, CH0, NSL)                                                                           \
     hipLaunchKernelGGL(KERNEL, dim3(n_tiles * (NSL)), dim3(256), 0, st, d, width, height, tile_w, n_tiles, (CH0), (NSL), \
-                       v_out, offsets, n_isects, blk_rows, trow, wt, gid_s, trow_s, prow, key, idx, (int)rows)
+                       v_out, offsets, n_isects, blk_rows, trow, wt, gid_s, trow_s, prow, pp, key, idx, (int)rows)
             int c = ch_begin;
             const int ce = ch_begin + ch_count;
             if (ce - c >= 128) {
@@ -844,14 +849,14 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
         if (c4 > 0) {
             const int gpb = 256 / (c4 >> 2);
             const dim3 grid((n_gauss + gpb - 1) / gpb);
-            if (half) hipLaunchKernelGGL((reduce_rows_kernel<true, 4>), grid, dim3(256), 0, st, n_gauss, d, ch_begin, c4, seg, idx_s, prow, (void *)v_colors, sparse);
-            else hipLaunchKernelGGL((reduce_rows_kernel<false, 4>), grid, dim3(256), 0, st, n_gauss, d, ch_begin, c4, seg, idx_s, prow, (void *)v_colors, sparse);
+            if (half) hipLaunchKernelGGL((reduce_rows_kernel<true, 4>), grid, dim3(256), 0, st, n_gauss, d, ch_begin, c4, seg, idx_s, prow, pp, (void *)v_colors, sparse);
+            else hipLaunchKernelGGL((reduce_rows_kernel<false, 4>), grid, dim3(256), 0, st, n_gauss, d, ch_begin, c4, seg, idx_s, prow, pp, (void *)v_colors, sparse);
         }
         if (c1 > 0) {
             const int gpb = 256 / c1;
             const dim3 grid((n_gauss + gpb - 1) / gpb);
-            if (half) hipLaunchKernelGGL((reduce_rows_kernel<true, 1>), grid, dim3(256), 0, st, n_gauss, d, ch_begin + c4, c1, seg, idx_s, prow, (void *)v_colors, sparse);
-            else hipLaunchKernelGGL((reduce_rows_kernel<false, 1>), grid, dim3(256), 0, st, n_gauss, d, ch_begin + c4, c1, seg, idx_s, prow, (void *)v_colors, sparse);
+            if (half) hipLaunchKernelGGL((reduce_rows_kernel<true, 1>), grid, dim3(256), 0, st, n_gauss, d, ch_begin + c4, c1, seg, idx_s, prow, pp, (void *)v_colors, sparse);
+            else hipLaunchKernelGGL((reduce_rows_kernel<false, 1>), grid, dim3(256), 0, st, n_gauss, d, ch_begin + c4, c1, seg, idx_s, prow, pp, (void *)v_colors, sparse);
         }
     }
     GAGS_CHECK_LAUNCH();
@@ -1529,7 +1534,7 @@ int gags_raster_bwd_geom_launch(int d, int n_gauss, int width, int height, const
     } else {
         hipLaunchKernelGGL(seg_fill_kernel, dim3((n_gauss + 1 + 255) / 256), dim3(256), 0, st, n_gauss, seg);
     }
-    hipLaunchKernelGGL((reduce_rows_kernel<false, 4>), dim3((n_gauss + 127) / 128), dim3(256), 0, st, n_gauss, 8, 0, 8, seg, idx_s, grow,
+    hipLaunchKernelGGL((reduce_rows_kernel<false, 4>), dim3((n_gauss + 127) / 128), dim3(256), 0, st, n_gauss, 8, 0, 8, seg, idx_s, grow, 8,
                        (void *)v_geo, 0);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;

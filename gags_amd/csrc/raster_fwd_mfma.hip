@@ -516,7 +516,7 @@ __global__ __launch_bounds__(64, 2) void raster_fwd_feat_x16(
         const unsigned gmax = (unsigned)(n_gauss - 1);
         // The lane's eight slots of step s are sb + 16 s + 8 k + i.  Behind the block's count its region holds ZERO slots
         // up to the next multiple of 16 (raster_weights.hip): weight 0, id N (clamped into the table: a finite row).
-        const unsigned id_off = (unsigned)(sb + 8 * k + (lane & 7)) * 4u;  // (slot indices stay below 2^29)
+        const unsigned id_off = (unsigned)(sb + 8 * k + (lane & 7)) * 4u;  // (slot indices stay below 2^30: GAGS_MAX_ISECTS)
         auto load_ids = [&](int s) {
             return *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(gid_s) + (id_off + 64u * (unsigned)s));
         };

@@ -27,10 +27,11 @@ from . import _lib, profiler
 from ._lib import check, ptr
 
 TILE = 16
-MAX_ISECTS = 1 << 27  # limit of the C ABI (int32 slot indices: 4 slots per intersection)
+MAX_ISECTS = 1 << 28  # GAGS_MAX_ISECTS of the C ABI (include/gags_raster.h: 32-bit offsets into the slot tables)
 ZERO_FILL_MIN_ELEMS = 1 << 24  # (below that the second stream's hand-over costs more than the zeros)
 GEOM_COMPACT_ROWS = True   # gags_raster_bwd_geom: per-slot rows numbered compactly (one prefix sum + a 4-byte readback)
 CAP_MARGIN = 1.05
+PROW_MAX_BYTES = 24 << 30  # staged backward: partial rows beyond this are produced per 128-channel range (see _backward_staged)
 # Default of RasterContext.capacity_mode (GAGS_CAPACITY_MODE=1; OFF otherwise): see RasterContext.
 CAPACITY_MODE = os.environ.get("GAGS_CAPACITY_MODE", "0") == "1"
 
@@ -350,7 +351,7 @@ def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height, conics=
 def _check_isects(n_isects):
     if n_isects < 0 or n_isects >= MAX_ISECTS:  # the int32 prefix sum wrapped, or the slot space would
         raise RuntimeError(f"gags_amd.rasterization: {n_isects if n_isects >= 0 else '> 2^31'} tile intersections in one "
-                           f"view; the kernels index at most 2^27 = {MAX_ISECTS} (INTEGRATION.md, memory model)")
+                           f"view; the kernels index at most 2^28 = {MAX_ISECTS} (INTEGRATION.md, memory model)")
 
 
 def _mfma_width(d):
@@ -562,7 +563,10 @@ def _backward_staged(lib, rctx, offsets, n_isects, blk_rows, fwd_scratch, v_out,
             host = ctypes.c_int32(0)
             check(lib.gags_read_i32(ptr(total), ctypes.byref(host), st), "gags_read_i32")
             rows = int(host.value)
-    nbytes = lib.gags_bwd_staged_scratch_bytes(rows, n, d)
+    # a heavy view's partial rows ([rows, D] fp32) can outgrow the device (C5H: 80 M rows x 2 KB): beyond PROW_MAX_BYTES the
+    # gradient is produced one 128-channel range at a time through a [rows, 128] scratch (stage bit 256)
+    narrow = (hook is None and pending is None and d % 128 == 0 and d > 128 and rows * d * 4 > PROW_MAX_BYTES)
+    nbytes = lib.gags_bwd_staged_scratch_bytes(rows, n, 128 if narrow else d)
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     v_colors = torch.empty(n, d, device=dev, dtype=torch.float16 if (xflag & 64) else torch.float32)
     rows_dev = ptr(total) if pending is not None else None
@@ -584,7 +588,15 @@ def _backward_staged(lib, rctx, offsets, n_isects, blk_rows, fwd_scratch, v_out,
             torch.cuda.current_stream().wait_event(ev)
             v_colors = buf
             xflag |= 128
-    if hook is not None and d % rng == 0 and d > rng:
+    if narrow:
+        for c0 in range(0, d, 128):
+            for stage in ((1, 2, 3) if c0 == 0 else (1, 3)):
+                with profiler.stage(("bwd_rows", "bwd_sort", "bwd_reduce")[stage - 1]):
+                    check(lib.gags_raster_bwd_colors_staged_range(
+                        d, n, width, height, ptr(offsets), n_isects, ptr(v_out), ptr(blk_rows), ptr(trow), rows,
+                        ptr(fwd_scratch), fwd_scratch.numel(), ptr(scratch), nbytes, ptr(v_colors), stage | xflag | 256, c0,
+                        128, st), "gags_raster_bwd_colors_staged_range")
+    elif hook is not None and d % rng == 0 and d > rng:
         alias = v_colors.detach()  # own TensorImpl, same storage: autograd may still adopt v_colors without a copy
         for c0 in range(0, d, rng):
             for stage in ((1, 2, 3) if c0 == 0 else (1, 3)):

@@ -34,6 +34,10 @@ extern "C" {
 #pragma GCC visibility push(default)
 
 #define GAGS_TILE 16
+/* tile intersections of one view: the raster entries refuse more (GAGS_EINVAL).  4 K-step slots per intersection plus 64 per
+ * tile must stay below 2^30 (32-bit byte offsets into the slot tables); 2^28 = 268 M covers a 4 M-Gaussian scene at 40+ tiles
+ * per Gaussian.  The slot space is ~1 KB per intersection: the caller's memory is the practical limit. */
+#define GAGS_MAX_ISECTS (1ll << 28)
 
 #define GAGS_OK 0
 #define GAGS_EINVAL (-1)   /* bad argument (null pointer, non-positive size, unsupported D) */
@@ -203,6 +207,10 @@ int gags_raster_bwd(int d, int width, int height, const float *means2d, const fl
  * sums are formed in fp32 and rounded once).
  * bit 7 (128): v_colors arrives ZERO-FILLED and the reduce stage skips the Gaussians that blended nothing (73 % at C3)
  * instead of writing their rows of zeros -- the caller fills it on a second stream while the rows stage runs.
+ * bit 8 (256), with gags_raster_bwd_colors_staged_range / _cap: the scratch holds the partial rows of THIS call's channel
+ * range only -- [rows, ch_count] instead of [rows, D]; size it with gags_bwd_staged_scratch_bytes(rows, n, ch_count) -- so
+ * that a wide gradient can be produced range by range (stages 1, 2, 3 for the first range, 1 and 3 for the others)
+ * through a quarter of the memory: a heavy view's rows (80 M x 2 KB at D = 512) need not exist at once.
  * Returns 1 when D is not eligible. */
 int64_t gags_bwd_rowmap_elems(int64_t n_isects, int width, int height);
 int64_t gags_bwd_rowmap_scratch_bytes(int64_t n_isects);

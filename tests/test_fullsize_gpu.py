@@ -195,25 +195,27 @@ def test_c3_heavy_splats_forward_and_gradient(oracle):
     assert st["n_isects"] > 10 * st["visible"] > 0
 
 
-def test_c3_heavy_splats_at_the_full_width_on_a_tile_sample(oracle):
-    """C3H as bench.py's `heavy_workload` runs it: 1.5 M Gaussians, 1080p, D = 512, SURVEY 8d's literal splat scale (63 M
-    intersections).  The oracle's compositing is bounded to every 16th tile (510 of 8160; projection, binning and sorting
-    are checked in full): the render of those tiles bit-exact, and -- with a cotangent that is zero outside them, so
-    that the gradient is exactly the sampled tiles' contribution -- the colours gradient within GRAD_TOL."""
-    from gags_amd import synthetic as syn
+def _heavy_tile_sample(oracle, n, w, h, d, step, fp16_table=False, min_isects_per_visible=10):
+    """A heavy-splat view whose compositing the oracle can only afford on every `step`-th tile: projection, binning and
+    sorting are checked in full; on the sampled tiles the exact render is bit-identical, the default render within
+    FWD_SPLIT_TOL, and -- with a cotangent that is zero outside them, so that the gradient is exactly the sampled tiles'
+    contribution -- the colours gradient within GRAD_TOL (5e-4 when it is returned in fp16)."""
+    from gags_amd import _lib, synthetic as syn
     from gags_amd.rasterization import rasterization
-    c = syn.CONFIGS["C3"]
-    n, w, h, d, step = c["n"], c["width"], c["height"], 512, 16
     dev = torch.device("cuda", 0)
+    torch.cuda.reset_peak_memory_stats()
     t, vm, K, _, _ = _activated(n, d, w, h, 0, syn.SCALE0_SURVEY)
-    cols = t["colors"].clone().requires_grad_(True)
+    table = t["colors"].half() if fp16_table else t["colors"]
+    cols = table.clone().requires_grad_(True)
     bg = torch.full((d,), 0.25, device=dev)
     out, alphas, info = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], cols, vm[None], K[None], w, h,
                                       backgrounds=bg[None])
-    hv = {k: v.cpu().numpy() for k, v in t.items()}
-    o_out, o_alpha, oi = oracle.rasterization(hv["means"], hv["quats"], hv["scales"], hv["opacities"], hv["colors"],
+    hv = {k: v.cpu().numpy() for k, v in t.items() if k != "colors"}
+    host_cols = table.float().cpu().numpy()
+    o_out, o_alpha, oi = oracle.rasterization(hv["means"], hv["quats"], hv["scales"], hv["opacities"], host_cols,
                                               vm.cpu().numpy(), K.cpu().numpy(), bg.cpu().numpy(), w, h, tile_begin=0, tile_step=step)
-    assert info["n_isects"] == oi["n_isects"] > 10 * int((oi["radii"] > 0).sum())
+    del host_cols
+    assert info["n_isects"] == oi["n_isects"] > min_isects_per_visible * int((oi["radii"] > 0).sum())
     np.testing.assert_array_equal(info["radii"][0].cpu().numpy(), oi["radii"])
     np.testing.assert_array_equal(info["isect_ids"].cpu().numpy(), oi["isect_ids"])
     np.testing.assert_array_equal(info["flatten_ids"].cpu().numpy(), oi["flatten_ids"])
@@ -221,19 +223,22 @@ def test_c3_heavy_splats_at_the_full_width_on_a_tile_sample(oracle):
     tw, th = (w + 15) // 16, (h + 15) // 16
     sampled = (torch.arange(th * tw, device=dev) % step == 0).view(th, tw)
     pix = sampled.repeat_interleave(16, 0).repeat_interleave(16, 1)[:h, :w]   # [H,W] bool: pixels of the sampled tiles
-    assert int(pix.sum()) > 100_000
+    assert int(pix.sum()) > 50_000
     ph = pix.cpu().numpy()
     np.testing.assert_array_equal(alphas[0, ..., 0].detach().cpu().numpy()[ph], o_alpha[ph])
     np.testing.assert_array_equal(info["last_ids"].cpu().numpy()[ph], oi["last_ids"][ph])
-    from gags_amd import _lib
     ref_px = torch.from_numpy(o_out[ph]).to(dev)
-    e = ((out[0].detach()[pix].double() - ref_px.double()).norm() / ref_px.double().norm()).item()
-    assert e <= FWD_SPLIT_TOL, e
-    with torch.no_grad():
-        ex = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], cols.detach(), vm[None], K[None], w, h,
-                           backgrounds=bg[None], raster_flags=_lib.GAGS_FWD_EXACT)[0][0]
-    assert torch.equal(ex[pix], ref_px), "exact render differs on the sampled tiles"
-    del o_out, ex, ref_px
+    if fp16_table:   # (an fp16 table's default forward widens the halves exactly: the fp32 chain, bit for bit)
+        assert torch.equal(out[0].detach()[pix], ref_px), "render differs on the sampled tiles"
+    else:
+        e = ((out[0].detach()[pix].double() - ref_px.double()).norm() / ref_px.double().norm()).item()
+        assert e <= FWD_SPLIT_TOL, e
+        with torch.no_grad():
+            ex = rasterization(t["means"], t["quats"], t["scales"], t["opacities"], cols.detach(), vm[None], K[None], w, h,
+                               backgrounds=bg[None], raster_flags=_lib.GAGS_FWD_EXACT)[0][0]
+        assert torch.equal(ex[pix], ref_px), "exact render differs on the sampled tiles"
+        del ex
+    del o_out, ref_px
     gen = torch.Generator(device=dev).manual_seed(100)
     v_out = torch.randn(h, w, d, device=dev, generator=gen) * pix[..., None]
     (out[0] * v_out).sum().backward()
@@ -241,7 +246,35 @@ def test_c3_heavy_splats_at_the_full_width_on_a_tile_sample(oracle):
     o_vf = oracle.raster_bwd_colors_fwdorder(oi["means2d"], oi["conics"], hv["opacities"], d, w, h, oi["isect_offsets"],
                                              oi["flatten_ids"], v_out.cpu().numpy(), n, tile_begin=0, tile_step=step)
     e = _big_rel_l2(cols.grad, o_vf)
-    assert e <= GRAD_TOL, e
+    assert e <= (5e-4 if fp16_table else GRAD_TOL), e
+    return dict(n_isects=int(oi["n_isects"]), peak_gib=torch.cuda.max_memory_allocated() / 2 ** 30)
+
+
+def test_c3_heavy_splats_at_the_full_width_on_a_tile_sample(oracle):
+    """C3H as bench.py's `heavy_workload` runs it: 1.5 M Gaussians, 1080p, D = 512, SURVEY 8d's literal splat scale (63 M
+    intersections), compositing checked on every 16th tile (510 of 8160)."""
+    from gags_amd import synthetic as syn
+    c = syn.CONFIGS["C3"]
+    st = _heavy_tile_sample(oracle, c["n"], c["width"], c["height"], 512, step=16)
+    print("C3H:", st)
+
+
+def test_c5_heavy_splats_on_a_tile_sample(oracle):
+    """C5H: BASELINE.json configs[4]'s scene size -- 4 M Gaussians, 1080p, 512-d, fp16 feature table -- with SURVEY 8d's
+    literal splat scale, i.e. a Mip-NeRF360-like ~42 tiles per Gaussian: ~170 M intersections, above the 2^27 the C ABI
+    indexed until round 4 (GAGS_MAX_ISECTS is 2^28 now; the slot space is ~180 GB of the 288).  Index tensors in full,
+    compositing on every 32nd tile; forward + colours-only backward."""
+    from gags_amd import synthetic as syn
+    c = syn.CONFIGS["C5"]
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 250 * 2 ** 30:
+        pytest.skip(f"needs ~230 GiB of device memory (free: {free / 2 ** 30:.0f} GiB)")
+    st = _heavy_tile_sample(oracle, c["n"], c["width"], c["height"], 512, step=32, fp16_table=True, min_isects_per_visible=30)
+    print("C5H:", st)
+    assert st["n_isects"] > (1 << 27)
 
 
 @pytest.mark.parametrize("d", [512, 513])

@@ -439,6 +439,32 @@ def test_backward_by_channel_ranges_is_bit_identical(oracle):
     np.testing.assert_array_equal(g_rng["colors"], g_full["colors"])
 
 
+def test_backward_through_a_range_sized_scratch_is_bit_identical(oracle):
+    """Stage bit 256 of the staged backward (heavy views: the partial rows of ONE 128-channel range at a time through a
+    [rows, 128] scratch instead of [rows, D]; rasterization.PROW_MAX_BYTES decides): same kernels, same order of summation,
+    so the same bits as the one-shot backward -- fp32 and fp16 gradients."""
+    from gags_amd import rasterization as R
+    n, w, h = 5000, 192, 144
+    for d, half in ((384, False), (256, True)):
+        s = scene_arrays(n, d, w, h, seed=43, view=3, scale_mult=5.0)
+        v_out = np.random.default_rng(9).standard_normal((h, w, d)).astype(np.float32)
+        res = []
+        saved = R.PROW_MAX_BYTES
+        for limit in (saved, 0):
+            R.PROW_MAX_BYTES = limit
+            try:
+                cols = torch.from_numpy(s["colors"]).cuda()
+                cols = (cols.half() if half else cols).requires_grad_(True)
+                out, _, _ = R.rasterization(to_dev(s["means"]), to_dev(s["quats"]), to_dev(s["scales"]), to_dev(s["opacities"]), cols,
+                                            to_dev(s["viewmat"])[None], to_dev(s["K"])[None], w, h)
+                (out[0] * to_dev(v_out)).sum().backward()
+                torch.cuda.synchronize()
+                res.append(cols.grad.clone())
+            finally:
+                R.PROW_MAX_BYTES = saved
+        assert torch.equal(res[0], res[1]), (d, half)
+
+
 @pytest.mark.parametrize("n,w,h,d,seed,view", [
     (2500, 128, 96, 16, 7, 3), (2000, 100, 70, 3, 8, None),
     (2000, 112, 80, 48, 9, 5),    # two channel chunks, the second one ragged: per-chunk bg dot, v_alpha on chunk 0 only
