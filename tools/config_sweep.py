@@ -17,8 +17,8 @@ from bench import _CotangentLoss  # loss = <render, G> whose backward hands G it
 dev = torch.device("cuda", 0)
 
 
-def run(name, n, w, h, d, half=False, steps=8, flags=0, full_grad=False):
-    pc = syn.make_model(n, d, w, h, seed=0, device=dev, gen_device=dev)
+def run(name, n, w, h, d, half=False, steps=8, flags=0, full_grad=False, scale0=syn.SCALE0):
+    pc = syn.make_model(n, d, w, h, seed=0, device=dev, gen_device=dev, scale0=scale0)
     pc.training_setup()
     # (render() hands the stored parameters to the projection kernel: the getters run inside it, every view)
     geo = [pc._xyz, pc._scaling, pc._rotation, pc._opacity]
@@ -67,7 +67,11 @@ CASES = [
     ("C5 4M/1080p/D=512 fp16 table", C5 + (512,), dict(half=True)),
     ("C5 4M/1080p/D=512 fp16 table, 16-bit matrix cores forward too (opt-in)", C5 + (512,), dict(half=True, flags=128)),
     ("C3 1.5M/1080p/D=512 fp16 table, 16-bit matrix cores forward too (opt-in)", C3 + (512,), dict(half=True, flags=128)),
+    ("C3 1.5M/1080p/D=512 fp32 table (the bench line's workload)", C3 + (512,), {}),
+    ("C3 1.5M/1080p/D=512 fp32 table, exact forward (GAGS_FWD_EXACT: fp32 matrix instructions, bit-identical to the oracle)", C3 + (512,), dict(flags=2048)),
     ("C3 1.5M/1080p/D=512 fp32 table, backward on the fp32 matrix instructions (GAGS_BWD_F32MFMA)", C3 + (512,), dict(flags=64)),
+    ("C3H 1.5M/1080p/D=512, SURVEY-literal splats (63 M intersections)", C3 + (512,), dict(scale0=syn.SCALE0_SURVEY, steps=4)),
+    ("C5H 4M/1080p/D=512 fp16 table, SURVEY-literal splats (169 M intersections)", C5 + (512,), dict(half=True, scale0=syn.SCALE0_SURVEY, steps=3)),
     ("C5 4M/1080p/D=513 (512+1) fp32", C5 + (513,), dict(steps=4)),
     ("C5 4M/1080p/D=513 (512+1) fp16 table -- BASELINE.json configs[4] as stated", C5 + (513,), dict(half=True, steps=4)),
     ("C5 4M/1080p/D=513 (512+1) fp16 table, 16-bit matrix cores forward too (opt-in)", C5 + (513,), dict(half=True, flags=128, steps=4)),
