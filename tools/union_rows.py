@@ -19,8 +19,8 @@ pc = syn.make_model(n, d, w, h, seed=0, device=dev, gen_device=dev)
 pc.training_setup()
 bg = torch.zeros(3, device=dev)
 masks = []
-rasterization.GRAD_RANGE_HOOK = lambda g, c0, c1: None
-rasterization.GRAD_ROWS_HOOK = lambda m: masks.append(m.clone())
+rasterization.default_context().grad_range_hook = lambda g, c0, c1: None
+rasterization.default_context().grad_rows_hook = lambda m: masks.append(m.clone())
 for v in range(8):
     pc._semantic_feature.grad = None
     out = render(syn.make_camera(w, h, view=v, device=dev), pc, None, bg, feature_mode=True)
