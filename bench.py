@@ -164,7 +164,7 @@ def iteration_d16(dev, n, width, height, steps):
     out = {"workload": f"train.py:142-174 iteration: {n} Gaussians, {width}x{height}, D=16 -> CNN_scale_decoder + CNN_decoder "
                        "(16 -> 512) -> distillation losses (all three terms) -> backward through decoders and rasterizer"}
     k = max(3, min(steps, 8))
-    for precision in ("bf16x2", "bf16"):
+    for precision in ("bf16x2", "f16", "bf16"):
         dec, sdec = CNN_decoder(16, 512, precision).to(dev), CNN_scale_decoder(16, 3, precision).to(dev)
 
         def iteration(marks=None):
@@ -195,10 +195,14 @@ def iteration_d16(dev, n, width, height, steps):
         st = {nm: sum(e[i].elapsed_time(e[i + 1]) for e in marks) / k
               for i, nm in enumerate(("render16", "decoders_and_losses_fwd", "backward"))}
         out[precision] = {"ms_per_iteration": ms, "iterations_per_s": 1e3 / ms, "steps": k, "stages_ms": st,
-                          "precision_note": ("operands as two bf16 terms (16 significand bits), three matrix terms per product, fp32 "
-                                             "accumulation: at or above the TF32 (11-bit) convolutions the reference runs" if precision == "bf16x2"
-                                             else "plain bf16 operands (8 significand bits): NARROWER than the reference's TF32 -- reported "
-                                                  "for comparison, not a creditable number")}
+                          "precision_note": {
+                              "bf16x2": "operands as two bf16 terms (16 significand bits), three matrix terms per product, fp32 "
+                                        "accumulation: at or above the TF32 (11-bit) convolutions the reference runs",
+                              "f16": "IEEE-half operands: TF32's own 11-bit significand, fp32 accumulation, activations stored as "
+                                     "half, gradients scaled by a device-chosen power of two (half has 5 exponent bits); within 2x of "
+                                     "an emulated TF32 chain's distance to fp32 at every tensor (tests/test_decoders_gpu.py)",
+                              "bf16": "plain bf16 operands (8 significand bits): NARROWER than the reference's TF32 -- reported "
+                                      "for comparison, not a creditable number"}[precision]}
         del dec, sdec
         torch.cuda.empty_cache()
     return out

@@ -110,10 +110,19 @@ SIGNATURES = {
     "gags_decoder_wgrad_exact_scratch_bytes": (_i64, [_i64, _i32, _i32]),
     "gags_decoder_wgrad_exact": (_i32, [_i64, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp]),
     "gags_decoder_head_bwd_exact": (_i32, [_i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp]),
+    # the "f16" decoder tier: the same kernels with IEEE half operands (include/gags_next.h), same signatures
+    **{name + "_h16": None for name in ("gags_decoder_pack_layer", "gags_decoder_pack_input", "gags_decoder_layer", "gags_decoder_head",
+                                        "gags_decoder_wgrad_scratch_bytes", "gags_decoder_wgrad", "gags_decoder_head_bwd",
+                                        "gags_decoder_unpack_grad", "gags_decoder_fwd_fused", "gags_decoder_bwd_fused",
+                                        "gags_scale_decoder_fwd_fused", "gags_scale_decoder_bwd_fused")},
+    "gags_decoder_head_distill_bwd_h16": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_relevancy": (_i32, [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "gags_relevancy_activate_scratch_bytes": (_i64, [_i32, _i32, _i32]),
     "gags_relevancy_activate": (_i32, [_i32, _i32, _i32, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
 }
+
+for _name in [k for k, v in SIGNATURES.items() if v is None]:  # (a twin's signature is its bf16 counterpart's)
+    SIGNATURES[_name] = SIGNATURES[_name[:-4]]
 
 GAGS_BWD_COLORS_ONLY = 1
 GAGS_FWD_NO_MFMA = 2

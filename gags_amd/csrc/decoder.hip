@@ -10,6 +10,7 @@
 // with the second source for the residual sums (x1 + x2, x3 + x4 of CNN_decoder.forward) and, in the backward, the
 // ReLU mask of the layer below and the residual's gradient in the epilogue.
 #include "common.h"
+#include "half16.h"
 #include "gags_next.h"
 
 namespace {
@@ -17,24 +18,13 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ unsigned short f2bf(float f)
-{
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even
-    return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
-// two floats -> packed bf16 pair, round to nearest even, in one instruction (v_cvt_pk_bf16_f32, new on gfx950)
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
-{
-    const f32x2_t v = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
-}
-__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
-__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+// the 16-bit operand type (bfloat16, or IEEE half when compiled with -DGAGS_H16): csrc/half16.h
+using gags_h16::h16_mfma;
+__device__ __forceinline__ unsigned short f2bf(float f) { return gags_h16::h16_from(f); }  // (NaN stays NaN, round to nearest even)
+__device__ __forceinline__ float bf2f(unsigned short h) { return gags_h16::h16_to(h); }
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) { return gags_h16::h16_pack(lo, hi); }
+__device__ __forceinline__ float bf_lo(unsigned u) { return gags_h16::h16_lo(u); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return gags_h16::h16_hi(u); }
 
 constexpr int TM = 128, TK = 64;             // workgroup tile: 128 pixels x (64 NJ) outputs, K step 64
 constexpr int LDK = TK + 8;                  // LDS row pitch in bf16 (144 B: 16-byte aligned, spreads the banks)
@@ -146,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a, int n_til
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = h16_mfma(bf[j], af[i], acc[i][j]);
         }
         __syncthreads();
     }
@@ -433,7 +423,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(int64_t P, int N, int K
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = h16_mfma(af[i], bf[j], acc[i][j]);
         }
         __syncthreads();
     }
@@ -568,7 +558,7 @@ __global__ __launch_bounds__(256, 2) void wgrad256_kernel(int64_t P, int N, cons
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[i][j] = h16_mfma(af[i], bf[j], acc[i][j]);
         }
     };
     const int64_t steps = (pb - pa + W2P - 1) / W2P;
@@ -698,7 +688,7 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(int64_t P, const unsi
 #pragma unroll
             for (int i = 0; i < NB; ++i)
 #pragma unroll
-                for (int j = 0; j < KB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < KB; ++j) acc[i][j] = h16_mfma(af[i], bf[j], acc[i][j]);
         }
     }
     // sum the four waves in LDS (the patches are done with) -- one wave at a time, in wave order, plain read-modify-
@@ -1092,10 +1082,7 @@ __global__ __launch_bounds__(256) void pack_layer_kernel(int co, int ci, int np,
     if (e >= np * kp) return;
     const int n = e / kp, k = e - n * kp;
     const float v = (n < co && k < ci) ? w[(size_t)n * ci + k] : 0.f;
-    typedef __bf16 pbf2 __attribute__((ext_vector_type(2)));
-    typedef float pf2 __attribute__((ext_vector_type(2)));
-    const pf2 pr = {v, 0.f};
-    const unsigned short h = (unsigned short)(__builtin_bit_cast(unsigned, __builtin_convertvector(pr, pbf2)) & 0xffffu);  // RN-even, as torch
+    const unsigned short h = gags_h16::h16_from(v);  // RN-even, as torch
     wr[(size_t)n * kp + k] = h;
     wtr[(size_t)k * np + n] = h;
     // fragment order of a [R, C] matrix: [R / 32][C / 16][2][32][8] (gags_amd/decoders.py: _frag_layout)
@@ -1104,7 +1091,7 @@ __global__ __launch_bounds__(256) void pack_layer_kernel(int co, int ci, int np,
 }
 }  // namespace
 
-extern "C" int gags_decoder_pack_layer(int co, int ci, const float *w, const float *b, void *w_bf16, void *wt_bf16, void *w_frag,
+extern "C" int GAGS_DEC(gags_decoder_pack_layer)(int co, int ci, const float *w, const float *b, void *w_bf16, void *wt_bf16, void *w_frag,
                                        void *wt_frag, float *bias_pad, void *stream)
 {
     GAGS_CLEAR_ERR();
@@ -1116,7 +1103,7 @@ extern "C" int gags_decoder_pack_layer(int co, int ci, const float *w, const flo
     return GAGS_OK;
 }
 
-extern "C" int gags_decoder_pack_input(int64_t n_pix, int c, int c_pad, const float *x, void *y_bf16, void *stream)
+extern "C" int GAGS_DEC(gags_decoder_pack_input)(int64_t n_pix, int c, int c_pad, const float *x, void *y_bf16, void *stream)
 {
     GAGS_CLEAR_ERR();
     if (n_pix < 0 || c <= 0 || c_pad < c || c_pad % 32 != 0 || (n_pix > 0 && (!x || !y_bf16))) return GAGS_EINVAL;
@@ -1127,7 +1114,7 @@ extern "C" int gags_decoder_pack_input(int64_t n_pix, int c, int c_pad, const fl
     return GAGS_OK;
 }
 
-extern "C" int gags_decoder_layer(int64_t n_pix, int n_out, int k_in, const void *a1, const void *a2, const void *w,
+extern "C" int GAGS_DEC(gags_decoder_layer)(int64_t n_pix, int n_out, int k_in, const void *a1, const void *a2, const void *w,
                                   const float *bias, int relu, const void *mask_src, const void *residual, void *y_bf16,
                                   void *y_premask_bf16, float *y_f32, void *stream)
 {
@@ -1154,7 +1141,7 @@ extern "C" int gags_decoder_layer(int64_t n_pix, int n_out, int k_in, const void
     return GAGS_OK;
 }
 
-extern "C" int gags_decoder_head(int64_t n_pix, int c, int ld, int mode, const float *x, float *out, int layout, void *stream)
+extern "C" int GAGS_DEC(gags_decoder_head)(int64_t n_pix, int c, int ld, int mode, const float *x, float *out, int layout, void *stream)
 {
     GAGS_CLEAR_ERR();
     if (n_pix < 0 || c <= 0 || ld < c || (mode != 0 && mode != 1) || (n_pix > 0 && (!x || !out))) return GAGS_EINVAL;
@@ -1198,7 +1185,7 @@ inline int wgrad_plan(int64_t n_pix, int n_out, int k_in, int64_t &parts)
 }
 }  // namespace
 
-extern "C" int64_t gags_decoder_wgrad_scratch_bytes(int64_t n_pix, int n_out, int k_in)
+extern "C" int64_t GAGS_DEC(gags_decoder_wgrad_scratch_bytes)(int64_t n_pix, int n_out, int k_in)
 {
     if (n_pix <= 0 || n_out <= 0 || k_in <= 0) return 0;
     int64_t parts;
@@ -1206,7 +1193,7 @@ extern "C" int64_t gags_decoder_wgrad_scratch_bytes(int64_t n_pix, int n_out, in
     return (parts * ((int64_t)n_out * k_in + n_out) * 4 + 255) / 256 * 256;
 }
 
-extern "C" int gags_decoder_wgrad(int64_t n_pix, int n_out, int k_in, const void *dz, const void *a1, const void *a2,
+extern "C" int GAGS_DEC(gags_decoder_wgrad)(int64_t n_pix, int n_out, int k_in, const void *dz, const void *a1, const void *a2,
                                   float *d_w, float *d_b, void *scratch, int64_t scratch_bytes, void *stream)
 {
     GAGS_CLEAR_ERR();
@@ -1255,7 +1242,7 @@ extern "C" int gags_decoder_wgrad(int64_t n_pix, int n_out, int k_in, const void
     return GAGS_OK;
 }
 
-extern "C" int gags_decoder_head_bwd(int64_t n_pix, int c, int ld, int mode, const float *x, const float *g, void *dz_bf16,
+extern "C" int GAGS_DEC(gags_decoder_head_bwd)(int64_t n_pix, int c, int ld, int mode, const float *x, const float *g, void *dz_bf16,
                                      int layout, void *stream)
 {
     GAGS_CLEAR_ERR();
@@ -1281,7 +1268,7 @@ extern "C" int gags_decoder_head_bwd(int64_t n_pix, int c, int ld, int mode, con
     return GAGS_OK;
 }
 
-extern "C" int gags_decoder_unpack_grad(int64_t n_pix, int c, int ld, const void *x_bf16, float *y, void *stream)
+extern "C" int GAGS_DEC(gags_decoder_unpack_grad)(int64_t n_pix, int c, int ld, const void *x_bf16, float *y, void *stream)
 {
     GAGS_CLEAR_ERR();
     if (n_pix < 0 || c <= 0 || ld < c || (n_pix > 0 && (!x_bf16 || !y))) return GAGS_EINVAL;

@@ -13,22 +13,18 @@
 // rounding to bf16): the results are BIT-IDENTICAL to the layer-by-layer path (tests/test_decoders_gpu.py).
 #include <stdlib.h>
 #include "common.h"
+#include "half16.h"
 #include "gags_next.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 fbf16x2_t __attribute__((ext_vector_type(2)));
 typedef float ff32x2_t __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ unsigned fpack(float lo, float hi)
-{
-    const ff32x2_t v = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, fbf16x2_t));
-}
-__device__ __forceinline__ float flo(unsigned u) { return __uint_as_float(u << 16); }
-__device__ __forceinline__ float fhi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+using gags_h16::h16_mfma;
+__device__ __forceinline__ unsigned fpack(float lo, float hi) { return gags_h16::h16_pack(lo, hi); }
+__device__ __forceinline__ float flo(unsigned u) { return gags_h16::h16_lo(u); }
+__device__ __forceinline__ float fhi(unsigned u) { return gags_h16::h16_hi(u); }
 
 constexpr int FT = 64;        // pixels per tile and group of four waves; a workgroup holds PH such groups (tile = 64 PH pixels)
 constexpr int FH = 256;       // hidden width
@@ -86,10 +82,10 @@ __device__ __forceinline__ void layer_main(f32x16 (&acc)[2][2], WFrag &f, const 
             if (ks < ksteps) {  // (uniform)
                 const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(&in[poff + (lane & 31)][16 * ks + 8 * (lane >> 5)]);
                 const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(&in[poff + 32 + (lane & 31)][16 * ks + 8 * (lane >> 5)]);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1, b1, acc[1][1], 0, 0, 0);
+                acc[0][0] = h16_mfma(c0, b0, acc[0][0]);
+                acc[0][1] = h16_mfma(c0, b1, acc[0][1]);
+                acc[1][0] = h16_mfma(c1, b0, acc[1][0]);
+                acc[1][1] = h16_mfma(c1, b1, acc[1][1]);
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetch FPD steps ahead (the scheduler sinks loads to their use)
         }
@@ -121,8 +117,8 @@ __device__ __forceinline__ void epilogue_hidden(const f32x16 (&acc)[2][2], const
             for (int j = 0; j < 2; ++j) {
                 const ff32x2_t a01 = {acc[i][j][4 * g], acc[i][j][4 * g + 1]}, a23 = {acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                 const ff32x2_t v01 = a01 + b01, v23 = a23 + b23;
-                unsigned u0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v01, fbf16x2_t));
-                unsigned u1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v23, fbf16x2_t));
+                unsigned u0 = gags_h16::h16_clamp_hi(gags_h16::h16_pack_raw(v01[0], v01[1]));  // (the ReLU below removes the negative side)
+                unsigned u1 = gags_h16::h16_clamp_hi(gags_h16::h16_pack_raw(v23[0], v23[1]));
                 unsigned m0, m1;
                 asm("v_pk_max_i16 %0, %1, 0" : "=v"(u0) : "v"(u0));
                 asm("v_pk_max_i16 %0, %1, 0" : "=v"(u1) : "v"(u1));
@@ -504,7 +500,7 @@ __global__ __launch_bounds__(256 * PH, 2 / PH) void decoder_bwd_fused_kernel(Bwd
         for (int ks = 0; ks < 16; ++ks) {
             const bf16x8 wf = *reinterpret_cast<const bf16x8 *>(w0 + 512 * ks);
             const bf16x8 bf = *reinterpret_cast<const bf16x8 *>(&X[poff + 32 * wave + (lane & 31)][16 * ks + 8 * (lane >> 5)]);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, bf, c, 0, 0, 0);
+            c = h16_mfma(wf, bf, c);
         }
         const int64_t pg = p0 + poff + 32 * wave + (lane & 31);
         if (pg < a.P) {
@@ -528,7 +524,7 @@ inline int fused_ph()
 
 }  // namespace
 
-extern "C" int gags_decoder_fwd_fused(int64_t n_pix, int c_in, int n_last, const float *x, const void *const *w_bf16,
+extern "C" int GAGS_DEC(gags_decoder_fwd_fused)(int64_t n_pix, int c_in, int n_last, const float *x, const void *const *w_bf16,
                                       const float *const *bias, void *const *acts_bf16, void *masks, float *logits,
                                       void *stream)
 {
@@ -553,7 +549,7 @@ extern "C" int gags_decoder_fwd_fused(int64_t n_pix, int c_in, int n_last, const
     return GAGS_OK;
 }
 
-extern "C" int gags_decoder_bwd_fused(int64_t n_pix, int c_in, int n_last, const void *dz_last_bf16, const void *const *wt_bf16,
+extern "C" int GAGS_DEC(gags_decoder_bwd_fused)(int64_t n_pix, int c_in, int n_last, const void *dz_last_bf16, const void *const *wt_bf16,
                                       const void *masks, void *const *dz_bf16, float *gin, void *stream)
 {
     GAGS_CLEAR_ERR();

@@ -11,13 +11,14 @@
 // Padded widths (gags_amd/decoders.py: _pack_weights, every dimension to a multiple of 32):
 //   K = 32, 64, 128, 64, 32, 32   N = 64, 128, 64, 32, 32, 32   (real: 16 -> 64 -> 128 -> 64 -> 32 -> 16 -> 3)
 #include "common.h"
+#include "half16.h"
 #include "gags_next.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 sbf16x2_t __attribute__((ext_vector_type(2)));
+using gags_h16::h16_mfma;
 typedef float sf32x2_t __attribute__((ext_vector_type(2)));
 
 constexpr int SP = 32;          // pixels per tile = per wave
@@ -65,7 +66,7 @@ __device__ __forceinline__ void slayer_mma(f32x16 (&acc)[4], const unsigned shor
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const bf16x8 a = *reinterpret_cast<const bf16x8 *>(Wf + ((size_t)(t * KS + ks) * 64 + lane) * 8);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+            acc[t] = h16_mfma(a, b, acc[t]);
         }
     }
 }
@@ -101,8 +102,8 @@ __device__ __forceinline__ void sepilogue(const f32x16 (&acc)[4], const float *_
             const float4 b = *reinterpret_cast<const float4 *>(bias + n);
             const sf32x2_t v01 = sf32x2_t{acc[t][4 * g], acc[t][4 * g + 1]} + sf32x2_t{b.x, b.y};
             const sf32x2_t v23 = sf32x2_t{acc[t][4 * g + 2], acc[t][4 * g + 3]} + sf32x2_t{b.z, b.w};
-            unsigned u0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v01, sbf16x2_t));
-            unsigned u1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v23, sbf16x2_t));
+            unsigned u0 = gags_h16::h16_clamp_hi(gags_h16::h16_pack_raw(v01[0], v01[1]));
+            unsigned u1 = gags_h16::h16_clamp_hi(gags_h16::h16_pack_raw(v23[0], v23[1]));
             unsigned m0, m1;
             asm("v_pk_max_i16 %0, %1, 0" : "=v"(u0) : "v"(u0));
             asm("v_pk_max_i16 %0, %1, 0" : "=v"(u1) : "v"(u1));
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void sdec_fwd_fused_kernel(SFwdArgs a)
                 const int e = lane + 64 * q, row = e >> 5, c = e & 31;
                 const float v = (p0 + row < a.P && c < a.c_in) ? xv[q] : 0.f;
                 const sf32x2_t pr = {v, 0.f};
-                A[row][c] = (unsigned short)(__builtin_bit_cast(unsigned, __builtin_convertvector(pr, sbf16x2_t)) & 0xffffu);
+                A[row][c] = (unsigned short)(gags_h16::h16_pack(pr[0], pr[1]) & 0xffffu);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -206,8 +207,8 @@ __device__ __forceinline__ void sepilogue_dgrad(const f32x16 (&acc)[4], const un
             const unsigned nib = mw[t] >> (8 * g + 4 * h);
             const float v0 = (nib & 1u) ? acc[t][4 * g] : 0.f, v1 = (nib & 2u) ? acc[t][4 * g + 1] : 0.f;
             const float v2 = (nib & 4u) ? acc[t][4 * g + 2] : 0.f, v3 = (nib & 8u) ? acc[t][4 * g + 3] : 0.f;
-            const unsigned u0 = __builtin_bit_cast(unsigned, __builtin_convertvector(sf32x2_t{v0, v1}, sbf16x2_t));
-            const unsigned u1 = __builtin_bit_cast(unsigned, __builtin_convertvector(sf32x2_t{v2, v3}, sbf16x2_t));
+            const unsigned u0 = gags_h16::h16_pack(v0, v1);
+            const unsigned u1 = gags_h16::h16_pack(v2, v3);
             *reinterpret_cast<uint2 *>(&out[p][n]) = make_uint2(u0, u1);
         }
 }
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void sdec_bwd_fused_kernel(SBwdArgs a)
 
 }  // namespace
 
-extern "C" int gags_scale_decoder_bwd_fused(int64_t n_pix, const void *dz_last_bf16, const void *const *wt_bf16, const void *masks,
+extern "C" int GAGS_DEC(gags_scale_decoder_bwd_fused)(int64_t n_pix, const void *dz_last_bf16, const void *const *wt_bf16, const void *masks,
                                             void *const *dz_bf16, void *stream)
 {
     GAGS_CLEAR_ERR();
@@ -282,7 +283,7 @@ extern "C" int gags_scale_decoder_bwd_fused(int64_t n_pix, const void *dz_last_b
     return GAGS_OK;
 }
 
-extern "C" int gags_scale_decoder_fwd_fused(int64_t n_pix, int c_in, const float *x, const void *const *w_bf16,
+extern "C" int GAGS_DEC(gags_scale_decoder_fwd_fused)(int64_t n_pix, int c_in, const float *x, const void *const *w_bf16,
                                             const float *const *bias, void *const *acts_bf16, void *masks, float *logits,
                                             void *stream)
 {

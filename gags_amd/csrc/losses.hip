@@ -511,14 +511,15 @@ typedef float l_f32x2 __attribute__((ext_vector_type(2)));
 // c = ld = 512 (CNN_decoder(16, 512), the reference's configuration): 16 float4 per lane, straight-line code.
 // ONE_TAP: the segmentation map has the render's resolution (identity resize: every pixel has exactly one source
 // pixel), the common case -- one gather per level, the gathers of step j + 1 in flight during step j.
-// DZ32 (BWD): the logits' gradient leaves as fp32 (the fp32-tensor decoder tiers) instead of bf16.
-template <bool BWD, bool ONE_TAP, bool DZ32 = false>
+// DZM (BWD): the logits' gradient leaves as 0 = bf16 (the bf16 mode), 1 = fp32 (the fp32-tensor decoder tiers), 2 = IEEE half
+// multiplied by the power of two dz_scale[0] and saturated at +-65504 (the f16 tier: csrc/half16.h).
+template <bool BWD, bool ONE_TAP, int DZM = 0>
 __global__ __launch_bounds__(256, 3) void head_distill_kernel(int H, int W, int h, int w, int n_emb,
                                                               const float *__restrict__ x, const float *__restrict__ img_embed,
                                                               const float *__restrict__ seg_map, const float *__restrict__ scale_map,
                                                               const float *__restrict__ v_map, float *__restrict__ l1_map,
                                                               float *__restrict__ mask_out, unsigned short *__restrict__ dz,
-                                                              float *__restrict__ v_scale)
+                                                              float *__restrict__ v_scale, const float *__restrict__ dz_scale = nullptr)
 {
     constexpr int c = 512;
     __shared__ TapsLds tl[TPM];
@@ -641,7 +642,8 @@ __global__ __launch_bounds__(256, 3) void head_distill_kernel(int H, int W, int 
         v_scale[pr] = a0; v_scale[(size_t)HW + pr] = a1; v_scale[2 * (size_t)HW + pr] = a2;
     }
     // y = x / n:  dz = (g - y <y, g>) / n = g / n - x <x, g> / n^3;  g = sign(diff) v m, the signs kept as two bit sets
-    const float k1 = dot * inv * inv * inv, gmag = vm * inv;
+    float k1 = dot * inv * inv * inv, gmag = vm * inv;
+    if constexpr (DZM == 2) { const float sc = dz_scale[0]; k1 *= sc; gmag *= sc; }  // (a power of two: exact)
 #pragma unroll
     for (int j = 0; j < FHJ; ++j) {
         const float xe[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
@@ -657,10 +659,17 @@ __global__ __launch_bounds__(256, 3) void head_distill_kernel(int H, int W, int 
             }
             const l_f32x2 x2 = {xe[q], xe[q + 1]};
             const l_f32x2 dq2 = __builtin_elementwise_fma(-x2, l_f32x2{k1, k1}, sg2 * gmag);
+            if constexpr (DZM == 2) {
+                typedef _Float16 l_f16x2 __attribute__((ext_vector_type(2)));
+                unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(dq2, l_f16x2));
+                asm("v_pk_min_f16 %0, %1, %2" : "=v"(u) : "v"(u), "v"(0x7bff7bffu));
+                asm("v_pk_max_f16 %0, %1, %2" : "=v"(u) : "v"(u), "v"(0xfbfffbffu));
+                pk[q >> 1] = u;
+            } else
             pk[q >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(dq2, l_bf16x2));
             df[q] = dq2[0]; df[q + 1] = dq2[1];
         }
-        if constexpr (DZ32)
+        if constexpr (DZM == 1)
             *reinterpret_cast<float4 *>(reinterpret_cast<float *>(dz) + (size_t)pr * c + c0 + 32 * j) = make_float4(df[0], df[1], df[2], df[3]);
         else
             *reinterpret_cast<uint2 *>(dz + (size_t)pr * c + c0 + 32 * j) = make_uint2(pk[0], pk[1]);
@@ -909,6 +918,27 @@ extern "C" int gags_decoder_head_distill_bwd(int c, int ld, int H, int W, int h,
     return GAGS_OK;
 }
 
+extern "C" int gags_decoder_head_distill_bwd_h16(int c, int ld, int H, int W, int h, int w, int n_emb, const float *x,
+                                                 const float *img_embed, const float *seg_map, const float *scale_map,
+                                                 const float *v_map, void *dz_f16, const float *dz_scale, float *v_scale,
+                                                 void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (!sam_args_ok(c, H, W, h, w, n_emb) || c != 512 || ld != 512 || !x || !img_embed || !seg_map || !scale_map || !v_map ||
+        !dz_f16 || !dz_scale || !v_scale)
+        return GAGS_EINVAL;
+    if (H == h && W == w)
+        hipLaunchKernelGGL((head_distill_kernel<true, true, 2>), dim3((H * W + TPM - 1) / TPM), dim3(256), 0, (hipStream_t)stream, H,
+                           W, h, w, n_emb, x, img_embed, seg_map, scale_map, v_map, (float *)nullptr, (float *)nullptr,
+                           (unsigned short *)dz_f16, v_scale, dz_scale);
+    else
+        hipLaunchKernelGGL((head_distill_kernel<true, false, 2>), dim3((H * W + TPM - 1) / TPM), dim3(256), 0, (hipStream_t)stream, H,
+                           W, h, w, n_emb, x, img_embed, seg_map, scale_map, v_map, (float *)nullptr, (float *)nullptr,
+                           (unsigned short *)dz_f16, v_scale, dz_scale);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
 extern "C" int gags_decoder_head_distill_bwd_f32(int c, int ld, int H, int W, int h, int w, int n_emb, const float *x,
                                                  const float *img_embed, const float *seg_map, const float *scale_map,
                                                  const float *v_map, float *dz, float *v_scale, void *stream)
@@ -918,11 +948,11 @@ extern "C" int gags_decoder_head_distill_bwd_f32(int c, int ld, int H, int W, in
         !dz || !v_scale)
         return GAGS_EINVAL;
     if (H == h && W == w)
-        hipLaunchKernelGGL((head_distill_kernel<true, true, true>), dim3((H * W + TPM - 1) / TPM), dim3(256), 0, (hipStream_t)stream, H,
+        hipLaunchKernelGGL((head_distill_kernel<true, true, 1>), dim3((H * W + TPM - 1) / TPM), dim3(256), 0, (hipStream_t)stream, H,
                            W, h, w, n_emb, x, img_embed, seg_map, scale_map, v_map, (float *)nullptr, (float *)nullptr,
                            (unsigned short *)dz, v_scale);
     else
-        hipLaunchKernelGGL((head_distill_kernel<true, false, true>), dim3((H * W + TPM - 1) / TPM), dim3(256), 0, (hipStream_t)stream, H,
+        hipLaunchKernelGGL((head_distill_kernel<true, false, 1>), dim3((H * W + TPM - 1) / TPM), dim3(256), 0, (hipStream_t)stream, H,
                            W, h, w, n_emb, x, img_embed, seg_map, scale_map, v_map, (float *)nullptr, (float *)nullptr,
                            (unsigned short *)dz, v_scale);
     GAGS_CHECK_LAUNCH();

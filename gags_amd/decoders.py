@@ -22,6 +22,16 @@ rounded to 10-bit significands.  gfx950 has no TF32; this tier splits every oper
 bits) and multiplies three matrix terms per product (h h' + h m' + m h'), fp32 tensors and accumulation, the same
 deterministic reductions: relative error <= ~2^-16 per product, 32x tighter than TF32, half the matrix work of "exact".
 Against the reference modules' own fp32 results: outputs <= 1e-4, every gradient <= 1e-3 (tests/test_decoders_gpu.py).
+`precision="f16"` (round 5) is the tier of EQUAL width to the reference's arithmetic: IEEE-half operands carry TF32's own
+11-bit significand, products accumulate in fp32 (v_mfma_f32_32x32x16_f16, the rate of the bf16 instruction), activations
+and their gradients are stored as half between layers.  It runs the bf16 mode's kernels compiled a second time for the
+other operand type (csrc/half16.h: entry points ..._h16), including the fused chains.  What half lacks is exponent range:
+conversions saturate at +-65504 instead of producing inf, and the backward multiplies the cotangent by a power of two
+chosen on the device from its magnitude (no host sync; `_pow2_scale`) and divides the results by it -- exact, so a
+cotangent scaled by 2^k gives gradients scaled by exactly 2^k.  Measured against the reference modules' fp32 autograd:
+4.5e-2 worst gradient rel-L2, the same chain with TF32-rounded operands (what the reference's cuDNN convolutions do): 4.6e-2
+(tests/test_decoders_gpu.py::test_f16_tier_is_as_close_to_fp32_as_the_tf32_arithmetic_the_reference_runs); one 1080p
+iteration 20.4 ms against bf16x2's 62 ms (profiles/r05_d16_iterations.txt).
 `precision="bf16"` is the fast opt-in (`dec.precision = "bf16"` or the constructor argument): bf16 operands, fp32
 accumulation, activations and their gradients kept in bf16 between layers -- outputs ~5e-3, gradients ~2e-2 of the fp32
 results (a low-precision forward flips the ReLU of units within rounding of zero).  Its weight gradients are
@@ -44,6 +54,33 @@ def _st():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class _H16Mode:
+    """The 16-bit operand type of the fast kernels: which instantiation of the library's entry points (suffix) and which
+    torch dtype their 16-bit tensors have.  bf16: the "bf16" mode; f16: IEEE half, the "f16" tier (csrc/half16.h)."""
+
+    def __init__(self, name, sfx, dtype):
+        self.name, self.sfx, self.dtype = name, sfx, dtype
+
+    def fn(self, base):
+        return getattr(_lib.load(), base + self.sfx)
+
+
+_BF16 = _H16Mode("bf16", "", torch.bfloat16)
+_F16 = _H16Mode("f16", "_h16", torch.float16)
+# f16 tier: the gradient entering a backward chain is multiplied by a power of two S such that S * max|cotangent proxy| is
+# 2^F16_TARGET_LOG2 (half has 5 exponent bits: unscaled, the 1e-9 .. 1e-6 gradients of a mean-reduced loss at 1080p would be
+# flushed; conversions saturate at 65504, so a proxy that underestimates costs accuracy on the largest elements, never an inf)
+F16_TARGET_LOG2 = 8.0
+
+
+def _pow2_scale(amax, target_log2=F16_TARGET_LOG2):
+    """Device scalars (S, 1 / S), S = 2^floor(target - log2(amax)) (1 when amax is 0 or not finite); no host sync."""
+    ok = torch.isfinite(amax) & (amax > 0)
+    e = torch.floor(target_log2 - torch.log2(torch.where(ok, amax, torch.ones_like(amax)))).clamp(-100.0, 100.0)
+    s = torch.where(ok, torch.exp2(e), torch.ones_like(amax)).float().reshape(1)
+    return s, 1.0 / s
+
+
 def _pad32(n):
     return (n + 31) // 32 * 32
 
@@ -57,27 +94,26 @@ def _pixel_major(x):
     return xp.reshape(h * w, c), h, w
 
 
-def _layer(n_pix, w, b, a1, a2=None, relu=True, f32=False, mask_src=None, residual=None, premask=False):
-    """One GEMM layer (gags_decoder_layer).  Returns y (bf16, or fp32 with f32=True) and, with premask=True, also the
-    bf16 value before the mask."""
+def _layer(n_pix, w, b, a1, a2=None, relu=True, f32=False, mask_src=None, residual=None, premask=False, mode=_BF16):
+    """One GEMM layer (gags_decoder_layer).  Returns y (16-bit, or fp32 with f32=True) and, with premask=True, also the
+    16-bit value before the mask."""
     n, k = w.shape
     dev = w.device
-    y = None if f32 else torch.empty(n_pix, n, dtype=torch.bfloat16, device=dev)
+    y = None if f32 else torch.empty(n_pix, n, dtype=mode.dtype, device=dev)
     yf = torch.empty(n_pix, n, device=dev) if f32 else None
-    ypre = torch.empty(n_pix, n, dtype=torch.bfloat16, device=dev) if premask else None
-    check(_lib.load().gags_decoder_layer(n_pix, n, k, ptr(a1), ptr(a2), ptr(w), ptr(b), int(relu), ptr(mask_src),
-                                         ptr(residual), ptr(y), ptr(ypre), ptr(yf), _st()), "gags_decoder_layer")
+    ypre = torch.empty(n_pix, n, dtype=mode.dtype, device=dev) if premask else None
+    check(mode.fn("gags_decoder_layer")(n_pix, n, k, ptr(a1), ptr(a2), ptr(w), ptr(b), int(relu), ptr(mask_src),
+                                        ptr(residual), ptr(y), ptr(ypre), ptr(yf), _st()), "gags_decoder_layer")
     out = yf if f32 else y
     return (out, ypre) if premask else out
 
 
-def _wgrad(n_pix, dz, a1, a2, n, k):
-    lib = _lib.load()
+def _wgrad(n_pix, dz, a1, a2, n, k, mode=_BF16):
     dw = torch.empty(n, k, device=dz.device)
     db = torch.empty(n, device=dz.device)
-    nb = lib.gags_decoder_wgrad_scratch_bytes(n_pix, n, k)
+    nb = mode.fn("gags_decoder_wgrad_scratch_bytes")(n_pix, n, k)
     scratch = torch.empty(max(nb, 4), dtype=torch.uint8, device=dz.device)  # partial matrices per pixel chunk
-    check(lib.gags_decoder_wgrad(n_pix, n, k, ptr(dz), ptr(a1), ptr(a2), ptr(dw), ptr(db), ptr(scratch), nb, _st()),
+    check(mode.fn("gags_decoder_wgrad")(n_pix, n, k, ptr(dz), ptr(a1), ptr(a2), ptr(dw), ptr(db), ptr(scratch), nb, _st()),
           "gags_decoder_wgrad")
     return dw, db
 
@@ -85,12 +121,12 @@ def _wgrad(n_pix, dz, a1, a2, n, k):
 _PACK_CACHE = {}  # (id of the first weight) -> (versions, packed): decoders whose parameters did not change are not repacked
 
 
-def _pack_weights(weights, biases):
+def _pack_weights(weights, biases, mode=_BF16):
     """bf16 [N_pad, K_pad] weights and fp32 [N_pad] biases, every dimension zero-padded to a multiple of 32; each packed
     weight also carries its transpose (for the input-gradient GEMMs) and both in MFMA-fragment order (for the fused
     kernels) as attributes -- one gags_decoder_pack_layer launch per layer, and none while the parameters' version
     counters stand still (frozen decoders, the second use within one iteration's backward)."""
-    key = id(weights[0])
+    key = (id(weights[0]), mode.name)
     vers = tuple((t.data_ptr(), t._version) for t in list(weights) + list(biases))
     hit = _PACK_CACHE.get(key)
     # (the weak references tell a parameter from a later one that got the same id, address and version counter)
@@ -102,16 +138,16 @@ def _pack_weights(weights, biases):
         co, ci = wt.shape[:2]
         n, k = _pad32(co), _pad32(ci)
         dev = wt.device
-        w = torch.empty(n, k, device=dev, dtype=torch.bfloat16)
-        w_t = torch.empty(k, n, device=dev, dtype=torch.bfloat16)
-        wf = torch.empty(n // 32, k // 16, 2, 32, 8, device=dev, dtype=torch.bfloat16)
-        wtf = torch.empty(k // 32, n // 16, 2, 32, 8, device=dev, dtype=torch.bfloat16)
+        w = torch.empty(n, k, device=dev, dtype=mode.dtype)
+        w_t = torch.empty(k, n, device=dev, dtype=mode.dtype)
+        wf = torch.empty(n // 32, k // 16, 2, 32, 8, device=dev, dtype=mode.dtype)
+        wtf = torch.empty(k // 32, n // 16, 2, 32, 8, device=dev, dtype=mode.dtype)
         b = torch.empty(n, device=dev)
         src = wt.detach().reshape(co, ci)
         src = src if (src.is_contiguous() and src.dtype == torch.float32) else src.contiguous().float()
         bsrc = bs.detach()
         bsrc = bsrc if (bsrc.is_contiguous() and bsrc.dtype == torch.float32) else bsrc.contiguous().float()
-        check(lib.gags_decoder_pack_layer(co, ci, ptr(src), ptr(bsrc), ptr(w), ptr(w_t), ptr(wf), ptr(wtf), ptr(b), _st()),
+        check(mode.fn("gags_decoder_pack_layer")(co, ci, ptr(src), ptr(bsrc), ptr(w), ptr(w_t), ptr(wf), ptr(wtf), ptr(b), _st()),
               "gags_decoder_pack_layer")
         w._gags_frag, w._gags_t = wf, w_t
         w_t._gags_frag = wtf
@@ -288,65 +324,66 @@ def _scale_fusable(wb, c_in):
     return c_in <= 32 and [tuple(w.shape) for w, _ in wb] == _SCALE_SHAPES
 
 
-def _chain_forward(x, kind, params):
+def _chain_forward(x, kind, params, mode=_BF16):
     """The GEMM chain of a decoder up to its fp32 logits.  Returns (logits [P, ld], activations, packed weights, h, w,
     c_in)."""
     weights, biases = params[0::2], params[1::2]
-    wb = _pack_weights(weights, biases)
+    wb = _pack_weights(weights, biases, mode)
     xp, h, w = _pixel_major(x)
     p = h * w
-    a0 = torch.empty(p, wb[0][0].shape[1], dtype=torch.bfloat16, device=x.device)
+    a0 = torch.empty(p, wb[0][0].shape[1], dtype=mode.dtype, device=x.device)
+    _layer_m = lambda *a, **k: _layer(*a, mode=mode, **k)  # noqa: E731
     if kind == "scale" and FUSED and _scale_fusable(wb, xp.shape[1]):
         # the six layers in one kernel, a wave per 32-pixel tile (csrc/decoder_scale.hip): bit-identical to the chain below
         dev = x.device
-        acts = [a0] + [torch.empty(p, wgt.shape[0], dtype=torch.bfloat16, device=dev) for wgt, _ in wb[:5]]
+        acts = [a0] + [torch.empty(p, wgt.shape[0], dtype=mode.dtype, device=dev) for wgt, _ in wb[:5]]
         logits = torch.empty(p, 32, device=dev)
         arr = ctypes.c_void_p * 6
         wf = [_frag_layout(wgt) for wgt, _ in wb]
         masks = torch.empty(p, 11, dtype=torch.int32, device=dev)  # the ReLU decisions as bits, for the fused backward
-        check(_lib.load().gags_scale_decoder_fwd_fused(p, xp.shape[1], ptr(xp), arr(*[t.data_ptr() for t in wf]),
+        check(mode.fn("gags_scale_decoder_fwd_fused")(p, xp.shape[1], ptr(xp), arr(*[t.data_ptr() for t in wf]),
                                                        arr(*[b.data_ptr() for _, b in wb]), arr(*[t.data_ptr() for t in acts]),
                                                        ptr(masks), ptr(logits), _st()), "gags_scale_decoder_fwd_fused")
         return logits, acts + [masks], wb, h, w, xp.shape[1]
     fused = kind == "decoder" and FUSED and _fusable(wb, xp.shape[1])
     if not fused:  # (the fused kernel converts its input tile itself and keeps it as a0)
-        check(_lib.load().gags_decoder_pack_input(p, xp.shape[1], a0.shape[1], ptr(xp), ptr(a0), _st()), "gags_decoder_pack_input")
+        check(mode.fn("gags_decoder_pack_input")(p, xp.shape[1], a0.shape[1], ptr(xp), ptr(a0), _st()), "gags_decoder_pack_input")
     acts = [a0]
     if fused:
         # the nine layers in one kernel, activations resident in LDS (csrc/decoder_fused.hip): bit-identical to the chain below
         dev = x.device
-        acts = [a0] + [torch.empty(p, 256, dtype=torch.bfloat16, device=dev) for _ in range(8)]
+        acts = [a0] + [torch.empty(p, 256, dtype=mode.dtype, device=dev) for _ in range(8)]
         logits = torch.empty(p, wb[8][0].shape[0], device=dev)
         arr = ctypes.c_void_p * 9
         wf = [_frag_layout(wgt) for wgt, _ in wb]
         masks = torch.empty(8, p, 8, dtype=torch.int32, device=dev)  # the ReLU decisions as bits, for the fused backward
-        check(_lib.load().gags_decoder_fwd_fused(p, xp.shape[1], logits.shape[1], ptr(xp), arr(*[t.data_ptr() for t in wf]),
+        check(mode.fn("gags_decoder_fwd_fused")(p, xp.shape[1], logits.shape[1], ptr(xp), arr(*[t.data_ptr() for t in wf]),
                                                  arr(*[b.data_ptr() for _, b in wb]), arr(*[t.data_ptr() for t in acts]),
                                                  ptr(masks), ptr(logits), _st()), "gags_decoder_fwd_fused")
         return logits, acts + [masks], wb, h, w, xp.shape[1]
     if kind == "decoder":
-        x1 = _layer(p, *wb[0], a0)
-        t1 = _layer(p, *wb[1], x1)
-        x2 = _layer(p, *wb[2], t1)
-        x3 = _layer(p, *wb[3], x1, x2)   # conv(x1 + x2)
-        t4 = _layer(p, *wb[4], x3)
-        x4 = _layer(p, *wb[5], t4)
-        t6 = _layer(p, *wb[6], x3, x4)   # conv(x3 + x4)
-        t7 = _layer(p, *wb[7], t6)
-        logits = _layer(p, *wb[8], t7, relu=False, f32=True)
+        x1 = _layer_m(p, *wb[0], a0)
+        t1 = _layer_m(p, *wb[1], x1)
+        x2 = _layer_m(p, *wb[2], t1)
+        x3 = _layer_m(p, *wb[3], x1, x2)   # conv(x1 + x2)
+        t4 = _layer_m(p, *wb[4], x3)
+        x4 = _layer_m(p, *wb[5], t4)
+        t6 = _layer_m(p, *wb[6], x3, x4)   # conv(x3 + x4)
+        t7 = _layer_m(p, *wb[7], t6)
+        logits = _layer_m(p, *wb[8], t7, relu=False, f32=True)
         acts += [x1, t1, x2, x3, t4, x4, t6, t7]
     else:
         a = a0
         for i, (wt, b) in enumerate(wb):
             last = i + 1 == len(wb)
-            a = _layer(p, wt, b, a, relu=not last, f32=last)
+            a = _layer_m(p, wt, b, a, relu=not last, f32=last)
             if not last:
                 acts.append(a)
         logits = a
     return logits, acts, wb, h, w, xp.shape[1]
 
 
-def _chain_backward(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, need_w=None):
+def _chain_backward(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, need_w=None, mode=_BF16):
     """From the bf16 gradient of the logits dz [P, ld] back through the chain: (input gradient as a [C_in,H,W] view of
     [H,W,C_in] memory, weight / bias gradients in parameter order).  need_x / need_w: what autograd asked for."""
     p = h * w
@@ -356,21 +393,21 @@ def _chain_backward(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, need_w=
 
     def wg(i, dz_i, a1, a2=None):
         if need_w[i]:
-            dws[i] = _wgrad(p, dz_i, a1, a2, *wb[i][0].shape)
+            dws[i] = _wgrad(p, dz_i, a1, a2, *wb[i][0].shape, mode=mode)
 
     def dx(i, dz_i, mask_src=None, residual=None, premask=False):
-        return _layer(p, wt[i], None, dz_i, relu=False, mask_src=mask_src, residual=residual, premask=premask)
+        return _layer(p, wt[i], None, dz_i, relu=False, mask_src=mask_src, residual=residual, premask=premask, mode=mode)
 
     if kind == "decoder" and len(acts) == 10:  # the fused forward ran (its bit masks ride along as the tenth entry)
         # the nine input-gradient GEMMs in one kernel (csrc/decoder_fused.hip), then the weight gradients
         a0, x1, t1, s12, x3, t4, s34, t6, t7, masks = acts  # (the fused forward keeps x1 + x2 and x3 + x4 in place of x2 / x4)
         dev = dz.device
-        dzs = [torch.empty(p, 256, dtype=torch.bfloat16, device=dev) for _ in range(8)]
+        dzs = [torch.empty(p, 256, dtype=mode.dtype, device=dev) for _ in range(8)]
         gx = torch.empty(h, w, c_in, device=dev) if need_x else None
         arr = ctypes.c_void_p * 9
         arr8 = ctypes.c_void_p * 8
         wtf = [_frag_layout(t) for t in wt]
-        check(_lib.load().gags_decoder_bwd_fused(p, c_in, dz.shape[1], ptr(dz), arr(*[t.data_ptr() for t in wtf]), ptr(masks),
+        check(mode.fn("gags_decoder_bwd_fused")(p, c_in, dz.shape[1], ptr(dz), arr(*[t.data_ptr() for t in wtf]), ptr(masks),
                                                  arr8(*[t.data_ptr() for t in dzs]), ptr(gx), _st()), "gags_decoder_bwd_fused")
         wg(8, dz, t7); wg(7, dzs[7], t6); wg(6, dzs[6], s34); wg(5, dzs[5], t4); wg(4, dzs[4], x3)
         wg(3, dzs[3], s12); wg(2, dzs[2], t1); wg(1, dzs[1], x1); wg(0, dzs[0], a0)
@@ -403,10 +440,10 @@ def _chain_backward(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, need_w=
         smask = acts[len(wb)] if len(acts) == len(wb) + 1 else None  # the fused forward's ReLU bit masks (csrc/decoder_scale.hip)
         if smask is not None and FUSED and dz.shape[1] == 32:
             # the five input-gradient GEMMs in one kernel (bit-identical to the loop below), then the weight gradients
-            dzs = [torch.empty(p, wgt.shape[0], dtype=torch.bfloat16, device=dz.device) for wgt, _ in wb[:5]]
+            dzs = [torch.empty(p, wgt.shape[0], dtype=mode.dtype, device=dz.device) for wgt, _ in wb[:5]]
             arr6, arr5 = ctypes.c_void_p * 6, ctypes.c_void_p * 5
             wtf = [None] + [_frag_layout(t) for t in wt[1:]]
-            check(_lib.load().gags_scale_decoder_bwd_fused(p, ptr(dz), arr6(*[None if t is None else t.data_ptr() for t in wtf]),
+            check(mode.fn("gags_scale_decoder_bwd_fused")(p, ptr(dz), arr6(*[None if t is None else t.data_ptr() for t in wtf]),
                                                            ptr(smask), arr5(*[t.data_ptr() for t in dzs]), _st()),
                   "gags_scale_decoder_bwd_fused")
             for i in range(len(wb) - 1, -1, -1):
@@ -422,7 +459,7 @@ def _chain_backward(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, need_w=
     gx = None
     if gin is not None:
         gx = torch.empty(h, w, c_in, device=dz.device)
-        check(_lib.load().gags_decoder_unpack_grad(p, c_in, gin.shape[1], ptr(gin), ptr(gx), _st()), "gags_decoder_unpack_grad")
+        check(mode.fn("gags_decoder_unpack_grad")(p, c_in, gin.shape[1], ptr(gin), ptr(gx), _st()), "gags_decoder_unpack_grad")
         gx = gx.permute(2, 0, 1)
     grads = []
     for pair, shp in zip(dws, shapes):
@@ -448,8 +485,9 @@ class _DecoderFn(torch.autograd.Function):
     def forward(ctx, x, kind, c_out, precision, *params):
         exact = precision in ("exact", "bf16x2")  # fp32 tensors, split operands: three terms / two terms
         terms = 2 if precision == "bf16x2" else 3
+        h16 = _F16 if precision == "f16" else _BF16
         logits, acts, wb, h, w, c_in = (_chain_forward_exact(x, kind, params, terms) if exact
-                                        else _chain_forward(x, kind, params))
+                                        else _chain_forward(x, kind, params, h16))
         p = h * w
         # CNN_decoder's [C,H,W] output is a permuted view of PIXEL-major memory (like render()'s own output): the head
         # writes rows, the losses read rows, the reference's next step (.permute(1,2,0)) is free.  The 3-channel scale
@@ -461,7 +499,7 @@ class _DecoderFn(torch.autograd.Function):
         if pm:
             out = out.permute(2, 0, 1)
         ctx.kind, ctx.c_out, ctx.hw, ctx.c_in, ctx.exact, ctx.terms = kind, c_out, (h, w), c_in, exact, terms
-        ctx.wb = wb
+        ctx.wb, ctx.h16 = wb, h16
         ctx.shapes = [tuple(t.shape) for t in params[0::2]]
         ctx.save_for_backward(logits, *acts)
         return out
@@ -484,10 +522,17 @@ class _DecoderFn(torch.autograd.Function):
                                                   ptr(dz), ctx.c_out, _st()), "gags_decoder_head_bwd_exact")
             gx, grads = _chain_backward_exact(dz, acts, wb, kind, h, w, ctx.c_in, ctx.shapes, need_x, need_w, ctx.terms)
         else:
-            dz = torch.empty(p, logits.shape[1], dtype=torch.bfloat16, device=g.device)
-            check(lib.gags_decoder_head_bwd(p, ctx.c_out, logits.shape[1], mode, ptr(logits), ptr(g), ptr(dz),
-                                            1 if pm else 0, _st()), "gags_decoder_head_bwd")
-            gx, grads = _chain_backward(dz, acts, wb, kind, h, w, ctx.c_in, ctx.shapes, need_x, need_w)
+            h16, inv = ctx.h16, None
+            if h16 is _F16:  # the cotangent scaled into half's range by a power of two (exact), the results scaled back
+                s, inv = _pow2_scale(g.abs().amax())
+                g = g * s
+            dz = torch.empty(p, logits.shape[1], dtype=h16.dtype, device=g.device)
+            check(h16.fn("gags_decoder_head_bwd")(p, ctx.c_out, logits.shape[1], mode, ptr(logits), ptr(g), ptr(dz),
+                                                  1 if pm else 0, _st()), "gags_decoder_head_bwd")
+            gx, grads = _chain_backward(dz, acts, wb, kind, h, w, ctx.c_in, ctx.shapes, need_x, need_w, mode=h16)
+            if inv is not None:
+                gx = None if gx is None else gx * inv
+                grads = [None if t is None else t * inv for t in grads]
         return (gx, None, None, None, *grads)
 
 
@@ -499,9 +544,10 @@ class _DecoderDistillFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, img_embed, seg_map, scale_map, c_out, precision, *params):
         from .losses import _f
-        ctx.terms = {"exact": 3, "bf16x2": 2}.get(precision, 0)  # 0: the bf16 mode
+        ctx.terms = {"exact": 3, "bf16x2": 2}.get(precision, 0)  # 0: the 16-bit tensor modes
+        ctx.h16 = _F16 if precision == "f16" else _BF16
         logits, acts, wb, h, w, c_in = (_chain_forward_exact(x, "decoder", params, ctx.terms) if ctx.terms
-                                        else _chain_forward(x, "decoder", params))
+                                        else _chain_forward(x, "decoder", params, ctx.h16))
         e, seg, sc = _f(img_embed), _f(seg_map), _f(scale_map)
         if e.shape[1] != c_out or tuple(sc.shape) != (3, h, w) or seg.dim() != 3 or seg.shape[0] != 4:
             raise ValueError(f"embeddings {tuple(e.shape)}, seg_map {tuple(seg.shape)}, scale_map {tuple(sc.shape)} "
@@ -530,6 +576,18 @@ class _DecoderDistillFn(torch.autograd.Function):
                                                                 ptr(logits), ptr(e), ptr(seg), ptr(sc), ptr(_f(v_map)), ptr(dz),
                                                                 ptr(vs), _st()), "gags_decoder_head_distill_bwd_f32")
             gx, grads = _chain_backward_exact(dz, acts, ctx.wb, "decoder", h, w, ctx.c_in, ctx.shapes, need_x, need_w, ctx.terms)
+        elif ctx.h16 is _F16:
+            # the logits' gradient is about v_map / (c |logits|): scaled by a power of two chosen on the device from
+            # max |v_map| / c (half has 5 exponent bits), the chain's results scaled back; the scale map's gradient is fp32
+            vm = _f(v_map)
+            s, inv = _pow2_scale(vm.abs().amax() / c)
+            dz = torch.empty(h * w, logits.shape[1], dtype=torch.float16, device=logits.device)
+            check(_lib.load().gags_decoder_head_distill_bwd_h16(c, logits.shape[1], h, w, seg.shape[1], seg.shape[2], e.shape[0],
+                                                                ptr(logits), ptr(e), ptr(seg), ptr(sc), ptr(vm), ptr(dz), ptr(s),
+                                                                ptr(vs), _st()), "gags_decoder_head_distill_bwd_h16")
+            gx, grads = _chain_backward(dz, acts, ctx.wb, "decoder", h, w, ctx.c_in, ctx.shapes, need_x, need_w, mode=_F16)
+            gx = None if gx is None else gx * inv
+            grads = [None if t is None else t * inv for t in grads]
         else:
             dz = torch.empty(h * w, logits.shape[1], dtype=torch.bfloat16, device=logits.device)
             check(_lib.load().gags_decoder_head_distill_bwd(c, logits.shape[1], h, w, seg.shape[1], seg.shape[2], e.shape[0],
@@ -546,9 +604,10 @@ class _Stack(nn.Module):
 
     def __init__(self, dims_in, dims_out, precision="exact"):
         super().__init__()
-        if precision not in ("exact", "bf16x2", "bf16"):
+        if precision not in ("exact", "bf16x2", "f16", "bf16"):
             raise ValueError("precision must be 'exact' (fp32-equivalent, the default), 'bf16x2' (two-term split: 16 significand "
-                             "bits, still tighter than the TF32 the reference's convs run in) or 'bf16' (fast opt-in)")
+                             "bits, tighter than the TF32 the reference's convs run in), 'f16' (IEEE half operands: TF32's own "
+                             "11-bit significand, fp32 accumulation, power-of-two gradient scaling) or 'bf16' (8 bits, fast opt-in)")
         self.precision = precision
         layers = []
         for i, (ci, co) in enumerate(zip(dims_in, dims_out)):

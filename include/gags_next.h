@@ -230,6 +230,32 @@ int gags_relevancy_activate(int n_phrases, int h, int w, const float *valid_map,
                             float *avg, float *blended, float *output, unsigned char *mask_pred,
                             unsigned char *mask_smooth, float *stats, void *scratch, int64_t scratch_bytes, void *stream);
 
+
+/* ---- the "f16" decoder tier -------------------------------------------------------------------------------------------
+ * The SAME kernels compiled with IEEE half as their 16-bit operand type (csrc/half16.h; v_mfma_f32_32x32x16_f16, fp32
+ * accumulation): an 11-bit significand -- exactly the TF32 significand the reference's nn.Conv2d layers
+ * (models/networks.py:145-149,229-233) compute with under PyTorch's default torch.backends.cudnn.allow_tf32 = True --
+ * instead of bfloat16's 8.  Same signatures and semantics as the entry points above; every `*_bf16` pointer is a half
+ * tensor.  Half has 5 exponent bits: conversions saturate at +-65504 (never inf), and the caller multiplies the gradient
+ * entering a backward chain by a power of two (gags_amd/decoders.py does: precision="f16") and divides the results. */
+int gags_decoder_pack_layer_h16(int co, int ci, const float *w, const float *b, void *w_bf16, void *wt_bf16, void *w_frag, void *wt_frag, float *bias_pad, void *stream);
+int gags_decoder_pack_input_h16(int64_t n_pix, int c, int c_pad, const float *x, void *y_bf16, void *stream);
+int gags_decoder_layer_h16(int64_t n_pix, int n_out, int k_in, const void *a1, const void *a2, const void *w, const float *bias, int relu, const void *mask_src, const void *residual, void *y_bf16, void *y_premask_bf16, float *y_f32, void *stream);
+int gags_decoder_head_h16(int64_t n_pix, int c, int ld, int mode, const float *x, float *out, int layout, void *stream);
+int64_t gags_decoder_wgrad_scratch_bytes_h16(int64_t n_pix, int n_out, int k_in);
+int gags_decoder_wgrad_h16(int64_t n_pix, int n_out, int k_in, const void *dz, const void *a1, const void *a2, float *d_w, float *d_b, void *scratch, int64_t scratch_bytes, void *stream);
+int gags_decoder_head_bwd_h16(int64_t n_pix, int c, int ld, int mode, const float *x, const float *g, void *dz_bf16, int layout, void *stream);
+int gags_decoder_unpack_grad_h16(int64_t n_pix, int c, int ld, const void *x_bf16, float *y, void *stream);
+int gags_decoder_fwd_fused_h16(int64_t n_pix, int c_in, int n_last, const float *x, const void *const *w_bf16, const float *const *bias, void *const *acts_bf16, void *masks, float *logits, void *stream);
+int gags_decoder_bwd_fused_h16(int64_t n_pix, int c_in, int n_last, const void *dz_last_bf16, const void *const *wt_bf16, const void *masks, void *const *dz_bf16, float *gin, void *stream);
+int gags_scale_decoder_bwd_fused_h16(int64_t n_pix, const void *dz_last_bf16, const void *const *wt_bf16, const void *masks, void *const *dz_bf16, void *stream);
+/* the fused head + distillation L1 backward (gags_decoder_head_distill_bwd) with the logits' gradient as IEEE half, multiplied by
+ * the power of two dz_scale[0] (a DEVICE float: chosen by the caller without a host sync) and saturated at +-65504 */
+int gags_decoder_head_distill_bwd_h16(int c, int ld, int H, int W, int h, int w, int n_emb, const float *x,
+                                     const float *img_embed, const float *seg_map, const float *scale_map,
+                                     const float *v_map, void *dz_f16, const float *dz_scale, float *v_scale, void *stream);
+int gags_scale_decoder_fwd_fused_h16(int64_t n_pix, int c_in, const float *x, const void *const *w_bf16, const float *const *bias, void *const *acts_bf16, void *masks, float *logits, void *stream);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

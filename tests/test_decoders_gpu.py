@@ -319,7 +319,7 @@ def test_decoder_output_is_pixel_major_and_its_gradient_flows_without_transposes
     assert ((gw_a - gw_b).double().norm() / gw_b.double().norm()).item() <= tol
 
 
-@pytest.mark.parametrize("precision,gtol", [("bf16", 2e-2), ("exact", 5e-3), ("bf16x2", 5e-3)])
+@pytest.mark.parametrize("precision,gtol", [("bf16", 2e-2), ("exact", 5e-3), ("bf16x2", 5e-3), ("f16", 5e-3)])
 @pytest.mark.parametrize("H,W,h,w", [(96, 130, 96, 130), (60, 77, 30, 40)])
 def test_fused_head_and_distillation_loss_equals_the_two_step_route(H, W, h, w, precision, gtol):
     """CNN_decoder.distill_l1 (head fused into the loss: gags_decoder_head_distill_fwd / _bwd) against
@@ -416,15 +416,17 @@ def test_exact_head_backward_against_float64(c, ldx, layout, mode):
     assert ((dz.double() - xr.grad).norm() / xr.grad.norm()).item() <= 2e-6
 
 
-def test_fused_decoder_kernels_are_bit_identical_to_the_layer_by_layer_chain():
-    """bf16 mode: CNN_decoder's forward as ONE kernel (activations resident in LDS, csrc/decoder_fused.hip) and its input-
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+def test_fused_decoder_kernels_are_bit_identical_to_the_layer_by_layer_chain(precision):
+    """bf16 / f16 modes: CNN_decoder's forward as ONE kernel (activations resident in LDS, csrc/decoder_fused.hip) and its input-
     gradient chain as one kernel against the same chain run layer by layer through gags_decoder_layer: the arithmetic is
     the same (bf16 operands, fp32 accumulation in ascending k, one rounding per activation), so every output, every kept
     activation and every gradient must be IDENTICAL; ragged pixel count (not a multiple of the 64-pixel tile)."""
     from gags_amd import decoders as D
     from make_golden_next import decoder_weights
     wd, _ = decoder_weights(0)
-    dec = _load(D.CNN_decoder(16, 512, "bf16"), wd)
+    dec = _load(D.CNN_decoder(16, 512, precision), wd)
+    mode = D._F16 if precision == "f16" else D._BF16
     g = torch.Generator(device="cuda").manual_seed(21)
     H, W = 67, 93
     x = torch.randn(H, W, 16, device="cuda", generator=g).permute(2, 0, 1)
@@ -436,7 +438,7 @@ def test_fused_decoder_kernels_are_bit_identical_to_the_layer_by_layer_chain():
             xi = x.clone().requires_grad_(True)
             dec.zero_grad(set_to_none=True)
             params = [t for m in dec.convs() for t in (m.weight, m.bias)]
-            logits, acts, wb, h, w, c_in = D._chain_forward(xi.detach(), "decoder", params)
+            logits, acts, wb, h, w, c_in = D._chain_forward(xi.detach(), "decoder", params, mode)
             y = dec(xi)
             (y * G).sum().backward()
             res.append((logits.clone(), [a.clone() for a in acts], y.detach().clone(), xi.grad.clone(),
@@ -447,22 +449,24 @@ def test_fused_decoder_kernels_are_bit_identical_to_the_layer_by_layer_chain():
     assert torch.equal(a[0], b[0]), "logits"
     for i, (u, v) in enumerate(zip(a[1], b[1])):
         if i in (3, 6):  # the fused forward keeps the residual sums x1 + x2 / x3 + x4 (what layers 3 / 6 read) in place of x2 / x4
-            v = (b[1][i - 2].float() + v.float()).to(torch.bfloat16)
+            v = (b[1][i - 2].float() + v.float()).to(mode.dtype)
         assert torch.equal(u, v), f"activation {i}"
     assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
     for u, v in zip(a[4] + a[5], b[4] + b[5]):
         assert torch.equal(u, v)
 
 
-def test_fused_scale_decoder_kernels_are_bit_identical_to_the_layer_by_layer_chain():
-    """bf16 mode: CNN_scale_decoder's six layers as ONE kernel, a wave per 32-pixel tile (csrc/decoder_scale.hip), against
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+def test_fused_scale_decoder_kernels_are_bit_identical_to_the_layer_by_layer_chain(precision):
+    """bf16 / f16 modes: CNN_scale_decoder's six layers as ONE kernel, a wave per 32-pixel tile (csrc/decoder_scale.hip), against
     the same chain run layer by layer: logits, every kept activation, the softmax output, the input gradient and every
     weight / bias gradient IDENTICAL; ragged pixel count (not a multiple of the tile), and the ReLU bit masks the fused
     forward leaves behind equal [activation > 0]."""
     from gags_amd import decoders as D
     from make_golden_next import decoder_weights
     _, ws = decoder_weights(0)
-    sdec = _load(D.CNN_scale_decoder(16, 3, "bf16"), ws)
+    sdec = _load(D.CNN_scale_decoder(16, 3, precision), ws)
+    mode = D._F16 if precision == "f16" else D._BF16
     g = torch.Generator(device="cuda").manual_seed(22)
     H, W = 61, 97
     x = torch.randn(H, W, 16, device="cuda", generator=g).permute(2, 0, 1)
@@ -474,7 +478,7 @@ def test_fused_scale_decoder_kernels_are_bit_identical_to_the_layer_by_layer_cha
             xi = x.clone().requires_grad_(True)
             sdec.zero_grad(set_to_none=True)
             params = [t for m in sdec.convs() for t in (m.weight, m.bias)]
-            logits, acts, wb, h, w, c_in = D._chain_forward(xi.detach(), "scale", params)
+            logits, acts, wb, h, w, c_in = D._chain_forward(xi.detach(), "scale", params, mode)
             y = sdec(xi)
             (y * G).sum().backward()
             res.append((logits.clone(), [a.clone() for a in acts], y.detach().clone(), xi.grad.clone(),
@@ -531,3 +535,129 @@ def test_packed_weights_follow_in_place_updates():
     assert not torch.equal(y1, y2)
     D.invalidate_packed()
     assert torch.equal(sdec(x), y2)
+
+
+# ---------------------------------------------------------------- precision="f16": IEEE-half operands (TF32's significand)
+def _tf32(t):
+    """Round an fp32 tensor to TF32's 10 explicit significand bits (nearest even): what the reference's convs do to both
+    operands of every product on the GPU its README names (torch.backends.cudnn.allow_tf32 defaults to True)."""
+    i = t.contiguous().view(torch.int32)
+    i = (i + 0x0FFF + ((i >> 13) & 1)) & ~0x1FFF
+    return i.view(torch.float32)
+
+
+class _RoundedLinear(torch.autograd.Function):
+    """a @ W^T with `rnd` applied to both operands of every product, forward AND backward (cuDNN's TF32 convolutions round
+    the operands of the data- and weight-gradient convolutions as well)."""
+
+    @staticmethod
+    def forward(ctx, a, W, rnd):
+        ctx.rnd = rnd
+        ctx.save_for_backward(a, W)
+        return rnd(a) @ rnd(W).t()
+
+    @staticmethod
+    def backward(ctx, g):
+        a, W = ctx.saved_tensors
+        r = ctx.rnd
+        return r(g) @ r(W), r(g).t() @ r(a), None
+
+
+def _torch_chain(x, weights, kind, rnd):
+    """The reference modules' arithmetic (models/networks.py:189-218, 236-248) as torch matmuls with `rnd` applied to both
+    operands of every product (identity: fp32; _tf32: the reference's own convs on its GPU).  x [P, C] -> output [P, C_out]."""
+    def lin(a, i):
+        W, b = weights[i]
+        return _RoundedLinear.apply(a, W, rnd) + b
+    if kind == "decoder":
+        x1 = torch.relu(lin(x, 0)); x2 = torch.relu(lin(torch.relu(lin(x1, 1)), 2))
+        x3 = torch.relu(lin(x1 + x2, 3)); x4 = torch.relu(lin(torch.relu(lin(x3, 4)), 5))
+        t = torch.relu(lin(x3 + x4, 6)); t = torch.relu(lin(t, 7))
+        return torch.nn.functional.normalize(lin(t, 8), dim=1)
+    a = x
+    for i in range(6):
+        a = lin(a, i)
+        if i < 5:
+            a = torch.relu(a)
+    return torch.softmax(a, dim=1)
+
+
+def test_f16_tier_is_as_close_to_fp32_as_the_tf32_arithmetic_the_reference_runs():
+    """precision="f16": operands in IEEE half (11-bit significand = TF32's), fp32 accumulation.  Stated bound: outputs and
+    every gradient are as close to the reference modules' fp32 results (tests/golden/next_vectors.npz) as the SAME chain run
+    with TF32-rounded operands -- the arithmetic the reference's nn.Conv2d layers use on its own GPU -- within a factor 2
+    (the tiers round at different places: half also rounds the stored activations, TF32 rounds them on use; same bits)."""
+    from gags_amd.decoders import CNN_decoder, CNN_scale_decoder
+    from make_golden_next import decoder_weights
+    wd, ws = decoder_weights(0)
+    gen = torch.Generator(device="cuda").manual_seed(31)
+    for model, weights, pre, kind, c_out in ((CNN_decoder(16, 512, "f16"), wd, "dec", "decoder", 512),
+                                             (CNN_scale_decoder(16, 3, "f16"), ws, "sdec", "scale", 3)):
+        m = _load(model, weights)
+        with torch.no_grad():  # the reference fixture first (120 pixels)
+            assert rel_l2(m(torch.from_numpy(Z[f"{pre}_x"]).cuda()).cpu().numpy(), Z[f"{pre}_y"]) <= 1e-3
+        # a larger seeded input of the fixture's magnitude, so that the comparison of two roundings is not a 120-pixel accident
+        h, w = 48, 64
+        x0 = torch.randn(h, w, 16, device="cuda", generator=gen).permute(2, 0, 1) * float(np.abs(Z[f"{pre}_x"]).std())
+        G = torch.randn(c_out, h, w, device="cuda", generator=gen)
+        x = x0.clone().requires_grad_(True)
+        y = m(x)
+        (y * G).sum().backward()
+        got = [y.detach(), x.grad] + [t.grad[:, :, 0, 0] if t.dim() == 4 else t.grad for cv in m.convs() for t in (cv.weight, cv.bias)]
+        res = {}
+        for name, rnd in (("fp32", lambda t: t), ("tf32", _tf32)):
+            wt = [(W.clone().cuda().requires_grad_(True), b.clone().cuda().requires_grad_(True)) for W, b in weights]
+            xr = x0.clone().requires_grad_(True)
+            yr = _torch_chain(xr.reshape(16, -1).t(), wt, kind, rnd).t().reshape(-1, h, w)
+            (yr * G).sum().backward()
+            res[name] = [yr.detach(), xr.grad] + [t.grad for pair in wt for t in pair]
+        worst = (0.0, 0.0)
+        for i, (a, t32, f32) in enumerate(zip(got, res["tf32"], res["fp32"])):
+            ref = f32.double()
+            e_f16 = ((a.double() - ref).norm() / ref.norm()).item()
+            e_tf32 = ((t32.double() - ref).norm() / ref.norm()).item()
+            assert e_f16 <= 2.0 * e_tf32 + 1e-6, (pre, i, e_f16, e_tf32)
+            worst = max(worst, (e_f16, e_tf32))
+        print(pre, "f16 tier vs fp32: worst rel-L2 %.3e (TF32 emulation at the same tensor: %.3e)" % worst)
+
+
+def test_f16_gradient_scaling_is_exact_in_powers_of_two():
+    """The f16 tier multiplies the cotangent by a power of two chosen on the device from its magnitude and divides the results
+    by it: a cotangent scaled by 2^k must give every gradient scaled by exactly 2^k (bit-identical significands), from
+    magnitudes half could not hold unscaled (2^-40: flushed; 2^24: overflow) -- and nothing non-finite ever."""
+    from gags_amd.decoders import CNN_decoder
+    from make_golden_next import decoder_weights
+    wd, _ = decoder_weights(0)
+    dec = _load(CNN_decoder(16, 512, "f16"), wd)
+    x0 = torch.from_numpy(Z["dec_x"]).cuda()
+    G = torch.from_numpy(Z["dec_G"]).cuda()
+    out = []
+    for k in (0, -40, 24):
+        dec.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        (dec(x) * (G * 2.0 ** k)).sum().backward()
+        out.append([x.grad.clone()] + [t.grad.clone() for cv in dec.convs() for t in (cv.weight, cv.bias)])
+    for k, res in zip((-40, 24), out[1:]):
+        for a, b in zip(out[0], res):
+            assert torch.isfinite(b).all()
+            assert torch.equal(a * 2.0 ** k, b), k
+    assert all(float(t.abs().max()) > 0 for t in out[0])
+    # zero cotangent: scale 1, zero gradients, no NaN
+    dec.zero_grad(set_to_none=True)
+    x = x0.clone().requires_grad_(True)
+    (dec(x) * 0.0).sum().backward()
+    assert float(x.grad.abs().max()) == 0.0 and all(float(cv.weight.grad.abs().max()) == 0.0 for cv in dec.convs())
+
+
+def test_f16_conversions_saturate_instead_of_overflowing():
+    """Inputs far outside half's range (|x| up to 1e6) saturate at +-65504 in the packing kernel: the output stays finite
+    and unit-norm, the gradients finite."""
+    from gags_amd.decoders import CNN_decoder
+    from make_golden_next import decoder_weights
+    wd, _ = decoder_weights(0)
+    dec = _load(CNN_decoder(16, 512, "f16"), wd)
+    x = (torch.from_numpy(Z["dec_x"]).cuda() * 1e6).requires_grad_(True)
+    y = dec(x)
+    (y * torch.from_numpy(Z["dec_G"]).cuda()).sum().backward()
+    assert torch.isfinite(y).all() and torch.isfinite(x.grad).all()
+    np.testing.assert_allclose(y.detach().double().pow(2).sum(0).sqrt().cpu().numpy(), 1.0, rtol=1e-4)

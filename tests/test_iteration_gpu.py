@@ -106,3 +106,33 @@ def test_composed_iteration_in_the_bf16_mode_stays_within_its_stated_bound(tag, 
     assert abs(loss.item() - want) <= 2e-3 * abs(want)
     a, b = vf.double().flatten().cpu(), torch.from_numpy(Z[f"{tag}_vfmap"]).double().flatten()
     assert float((a @ b) / (a.norm() * b.norm())) >= 0.98
+
+
+@pytest.mark.parametrize("tag,iteration", [("early", 7000), ("late", 20000)])
+def test_composed_iteration_in_the_f16_tier(tag, iteration):
+    """precision="f16" (IEEE-half operands: TF32's significand; tests/test_decoders_gpu.py bounds it per tensor against an
+    emulated TF32 chain): through the composed loss -- loss within 5e-4, the feature map's gradient and every decoder gradient
+    within 0.1 rel-L2 / 0.995 cosine of the reference's fp32 autograd.  (The L1's sign flips for differences within rounding
+    of zero: 3.2e-3 per flipped element on this fixture, see the fp32 tiers' test above; at 11 significand bits ~300 of the
+    393 216 differences are that close -- measured 5.8e-2 -- whichever 11-bit format computes them.)"""
+    loss, terms, vf, dec, sdec = _run("f16", iteration)
+    want = float(Z[f"{tag}_loss"])
+    assert abs(loss.item() - want) <= 5e-4 * abs(want)
+    np.testing.assert_array_equal(terms["seg_map_trained"].cpu().numpy(), Z["seg_map_trained"])
+
+    def close(got, ref, what):
+        a, b = np.asarray(got, np.float64).ravel(), np.asarray(ref, np.float64).ravel()
+        cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
+        e = rel_l2(got, ref)
+        assert e <= 0.1 and cos >= 0.995, (what, e, cos)
+        return e
+
+    worst = close(vf.cpu().numpy(), Z[f"{tag}_vfmap"], "feature map")
+    for i, m in enumerate(dec.convs()):
+        want = Z[f"{tag}_dec_vw{i}"]
+        worst = max(worst, close(m.weight.grad[:want.shape[0], :, 0, 0].cpu().numpy(), want, ("dec w", i)))
+        worst = max(worst, close(m.bias.grad.cpu().numpy(), Z[f"{tag}_dec_vb{i}"], ("dec b", i)))
+    for i, m in enumerate(sdec.convs()):
+        worst = max(worst, close(m.weight.grad[:, :, 0, 0].cpu().numpy(), Z[f"{tag}_sdec_vw{i}"], ("sdec w", i)))
+        worst = max(worst, close(m.bias.grad.cpu().numpy(), Z[f"{tag}_sdec_vb{i}"], ("sdec b", i)))
+    print("f16 tier, composed iteration", tag, "worst gradient rel-L2", worst)

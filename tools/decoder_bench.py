@@ -25,7 +25,7 @@ cam = syn.make_camera(w, h, device=dev)
 bg = torch.zeros(3, device=dev)
 # default: fp32-equivalent ("exact"); --bf16x2: two-term split (16 significand bits; the reference's convs run in TF32);
 # --bf16: the fast opt-in mode
-PRECISION = "bf16" if "--bf16" in sys.argv else ("bf16x2" if "--bf16x2" in sys.argv else "exact")
+PRECISION = "bf16" if "--bf16" in sys.argv else ("bf16x2" if "--bf16x2" in sys.argv else ("f16" if "--f16" in sys.argv else "exact"))
 dec, sdec = CNN_decoder(16, 512, PRECISION).to(dev), CNN_scale_decoder(16, 3, PRECISION).to(dev)
 g = torch.Generator(device=dev).manual_seed(0)
 n_emb = 300
