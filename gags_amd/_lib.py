@@ -132,6 +132,8 @@ GAGS_BWD_ATOMIC = 4  # python-side: use the atomic colours-only backward instead
 GAGS_FEAT_F16 = 32  # forward: colors is an fp16 table (include/gags_raster.h)
 GAGS_BWD_F32MFMA = 64  # python-side: staged backward contracts with v_mfma_f32_32x32x2_f32 (round 1-2's kernel) instead of the
 #                        default fp32-equivalent split operands on the 16-bit matrix cores (csrc/raster_bwd_mfma.hip)
+GAGS_BWD_BLOCKWAVES = 4096  # python-side: the staged backward's rows kernel in round 4's shape (a wave per 8x8 pixel block, rows
+#                             merged in LDS: stage bit 512) instead of the default (a wave per 32 channels, rows merged in the accumulators)
 GAGS_BWD_F16SPLIT = 0   # (round 2's opt-in flag: that kernel, made exact, is the default now)
 GAGS_FWD_F16MFMA = 128  # python-side: fp16 feature table + D % 128 == 0: feature pass on the 16-bit matrix cores (opt-in; C flag 64)
 GAGS_FWD_EXACT = 2048  # fp32 table, D >= 128: feature pass on v_mfma_f32_32x32x2_f32, bit-identical to the sequential fmaf chain (the

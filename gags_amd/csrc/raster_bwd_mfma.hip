@@ -530,6 +530,8 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
 
 // capacity-sized row buffers: keys [total, cap) become sentinels (key n_gauss: past every Gaussian), so that the sort and
 // the segment offsets can run over the capacity without the host knowing the row count
+#include "raster_bwd_rows_cw.h"  // staged rows, channel waves (round 5; the default)
+
 __global__ __launch_bounds__(256) void row_tail_kernel(int64_t cap, const int32_t *__restrict__ total, int n_gauss,
                                                        uint32_t *__restrict__ row_key, int32_t *__restrict__ row_idx)
 {
@@ -817,7 +819,8 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
             if (ce - c >= 128) {
                 const int nsl = (ce - c) / 128;
                 if (stage_flags & 32) GAGS_ROWS_LAUNCH(raster_bwd_rows<4>, c, nsl);  // GAGS_BWD_F32MFMA: the fp32 matrix instructions
-                else GAGS_ROWS_LAUNCH(raster_bwd_rows_f16, c, nsl);  // default: 16-bit matrix cores, fp32-equivalent split operands
+                else if (stage_flags & 512) GAGS_ROWS_LAUNCH(raster_bwd_rows_f16, c, nsl);  // round 4's shape: a wave per pixel block, rows merged in LDS
+                else GAGS_ROWS_LAUNCH(raster_bwd_rows_cw, c, nsl);  // default: 16-bit matrix cores, fp32-equivalent split operands, a wave per 32 channels
                 c += 128 * nsl;
             }
             if (ce - c >= 64) {

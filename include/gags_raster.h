@@ -202,7 +202,9 @@ int gags_raster_bwd(int d, int width, int height, const float *means2d, const fl
  * stage: low 4 bits 0 = all, 1..3 = rows, sort, reduce (per-kernel timing, overlap of the zero-fill below).
  * The rows' contraction (128-channel slices) runs on the 16-bit matrix cores with fp32-equivalent split operands: weights
  * as three fp16 terms (exact), cotangent as two (one fp32 rounding), five MFMA terms per product, fp32 accumulation;
- * atomic-free and bit-reproducible.  bit 5 (32): the fp32 matrix instructions instead (rounds 1-2's kernel).
+ * atomic-free and bit-reproducible.  Shape since round 5: a wave per 32 channels of the slice, the four pixel blocks'
+ * contributions to a tile row meet in its accumulators (csrc/raster_bwd_rows_cw.h).  bit 5 (32): the fp32 matrix
+ * instructions instead (rounds 1-2's kernel).  bit 9 (512): round 4's shape (a wave per pixel block, rows merged in LDS).
  * bit 6 (64): v_colors points to an fp16 [N,D] tensor (the gradient of an fp16 feature table in the table's dtype;
  * sums are formed in fp32 and rounded once).
  * bit 7 (128): v_colors arrives ZERO-FILLED and the reduce stage skips the Gaussians that blended nothing (73 % at C3)

@@ -164,7 +164,7 @@ def test_overlapped_union_row_exchange_with_the_real_backward(tmp_path):
         for tag in ("ogr", "ogr_cap", "ogr_over"):   # exact count / capacity-sized padded block / over-capacity fallback
             np.testing.assert_array_equal(np.load(tmp_path / f"{tag}_{r}.npy"), ref)   # two addends per element: exact
         assert used == 1 and rows == union and 0 < union < N
-        assert union < padded < N and rows_last == union
+        assert union < padded < N and rows_last == -1   # (the over-capacity step re-sent ALL rows: rows_exchanged is None)
 
 
 @pytest.mark.parametrize("n,p", [(1, 1.0), (7, 0.5), (2048, 0.3), (2049, 0.01), (100_003, 0.27), (1_500_000, 0.3), (5000, 0.0)])

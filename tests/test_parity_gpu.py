@@ -1023,3 +1023,35 @@ def test_raw_parameter_projection_gradients_match_autograd_through_the_getters()
     for a, b, name in zip(res[True][2], res[False][2], ("xyz", "rotation", "scaling", "opacity")):
         assert a.shape == b.shape and float(b.abs().max()) > 0, name
         assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) <= 1e-6, name
+
+
+def test_both_shapes_of_the_rows_kernel_agree_and_are_reproducible():
+    """The staged backward's rows kernel, default shape (a wave per 32 channels, block contributions folded in the accumulators:
+    csrc/raster_bwd_rows_cw.h) against round 4's (a wave per pixel block, rows merged in LDS: GAGS_BWD_BLOCKWAVES): the same five
+    exact-product terms summed in a different order -- gradients within 2e-6 rel-L2 of each other, each bit-reproducible, each
+    within the oracle bound; a scene with a ragged image border, empty tiles and > 32 rows per tile."""
+    import torch
+    from gags_amd import _lib, synthetic as syn
+    from gags_amd.gaussian_renderer import render
+    w, h, n, d = 200, 138, 6000, 256
+    dev = torch.device("cuda", 0)
+    pc = syn.make_model(n, d, w, h, seed=4, device=dev, scale0=syn.SCALE0 * 5)
+    pc.training_setup()
+    cam = syn.make_camera(w, h, view=1, device=dev)
+    G = syn.make_cotangent(d, h, w, seed=2, device=dev)
+    out = {}
+    for name, fl in (("cw", 0), ("blockwaves", _lib.GAGS_BWD_BLOCKWAVES), ("f32", _lib.GAGS_BWD_F32MFMA)):
+        runs = []
+        for _ in range(2):
+            pc._semantic_feature.grad = None
+            pkg = render(cam, pc, None, torch.zeros(3, device=dev), feature_mode=True, raster_flags=fl)
+            (pkg["render"] * G).sum().backward()
+            runs.append(pc._semantic_feature.grad.clone())
+        assert torch.equal(runs[0], runs[1]), name
+        out[name] = runs[0].double()
+    ref = out["f32"]
+    assert float(ref.abs().max()) > 0
+    for name in ("cw", "blockwaves"):
+        e = float((out[name] - ref).norm() / ref.norm())
+        assert e <= 2e-6, (name, e)
+    assert float((out["cw"] - out["blockwaves"]).norm() / ref.norm()) <= 2e-6
