@@ -166,6 +166,9 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_cw(
                 At[blk][2][s4][lane] = __builtin_bit_cast(uint4, a2);
             }
         }
+        // the next chunk's rows: bookkeeping from the key window fetched a chunk ago, loads issued now: they travel under
+        // this chunk's MFMAs
+        if (r0 + 32 < R1) open_chunk(r0 + 32);
         __builtin_amdgcn_sched_barrier(0);
         gags_lds_barrier();  // A terms of the four blocks are in LDS
         __builtin_amdgcn_sched_barrier(0);
@@ -209,10 +212,6 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_cw(
             asm volatile("" : "+v"(tot));
             __builtin_amdgcn_sched_barrier(0);
         }
-        // the next chunk's rows: bookkeeping from the key window fetched a chunk ago, loads issued now (the other workgroup
-        // of the CU multiplies while they travel)
-        if (r0 + 32 < R1) open_chunk(r0 + 32);
-        __builtin_amdgcn_sched_barrier(0);
         gags_lds_barrier();  // A terms consumed: the next chunk may overwrite them
         __builtin_amdgcn_sched_barrier(0);
         // row addresses: a uniform base per row (scalar registers) + ONE per-lane offset; sixteen 64-bit pointers in
