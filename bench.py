@@ -579,7 +579,8 @@ def main():
                                                   "in registers (exact operands; fp32-equivalent, DESIGN.md 4)")
         if "bwd_rows" in kernels and not (args.raster_flags & _lib.GAGS_BWD_F32MFMA):
             kernels["bwd_rows"]["note"] = ("algorithmic fp32 flops (2 D Q_blend) against the fp32 matrix peak; the kernel issues them as "
-                                           "5 v_mfma_f32_32x32x16_f16 terms per product on split operands (fp32-equivalent, DESIGN.md 4)")
+                                           "5 v_mfma_f32_32x32x16_f16 terms per product on split operands (fp32-equivalent, DESIGN.md 4); 32-row MFMA tiles "
+                                           "are chunks of 32 consecutive tile rows x one 8x8 block (58 % of their rows are non-zero at C3)")
         dom = max(kernels, key=lambda k_: kernels[k_]["avg_launch_ms"])
         roof = dict(kernels[dom], kernel=dom, rocprof_name=STAGE_KERNELS.get(dom, (dom,))[0], traffic_source=traffic_src)
         line = {

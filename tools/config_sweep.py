@@ -70,7 +70,9 @@ CASES = [
     ("C3 1.5M/1080p/D=512 fp32 table (the bench line's workload)", C3 + (512,), {}),
     ("C3 1.5M/1080p/D=512 fp32 table, exact forward (GAGS_FWD_EXACT: fp32 matrix instructions, bit-identical to the oracle)", C3 + (512,), dict(flags=2048)),
     ("C3 1.5M/1080p/D=512 fp32 table, backward on the fp32 matrix instructions (GAGS_BWD_F32MFMA)", C3 + (512,), dict(flags=64)),
+    ("C3 1.5M/1080p/D=512 fp32 table, round 4's rows kernel (GAGS_BWD_BLOCKWAVES: a wave per pixel block, rows merged in LDS)", C3 + (512,), dict(flags=4096)),
     ("C3H 1.5M/1080p/D=512, SURVEY-literal splats (63 M intersections)", C3 + (512,), dict(scale0=syn.SCALE0_SURVEY, steps=4)),
+    ("C3H ..., round 4's rows kernel (GAGS_BWD_BLOCKWAVES)", C3 + (512,), dict(scale0=syn.SCALE0_SURVEY, steps=4, flags=4096)),
     ("C5H 4M/1080p/D=512 fp16 table, SURVEY-literal splats (169 M intersections)", C5 + (512,), dict(half=True, scale0=syn.SCALE0_SURVEY, steps=3)),
     ("C5 4M/1080p/D=513 (512+1) fp32", C5 + (513,), dict(steps=4)),
     ("C5 4M/1080p/D=513 (512+1) fp16 table -- BASELINE.json configs[4] as stated", C5 + (513,), dict(half=True, steps=4)),

@@ -19,10 +19,14 @@ cp "$O/pmc/traffic.json" "$O/${TAG}_c3_pmc_traffic.json" 2>/dev/null
 cd "$R"
 timeout 900 python bench.py --steps 20 --warmup 3 > "$O/${TAG}_c3_bench.json" 2> "$O/bench.err"
 timeout 300 python tools/chunk_stats.py C3 > "$O/${TAG}_c3_chunk_stats.txt" 2>&1
+timeout 300 python tools/row_mask_stats.py C3 > "$O/${TAG}_c3_row_mask_stats.txt" 2>&1
+timeout 300 python tools/row_mask_stats.py C3H >> "$O/${TAG}_c3_row_mask_stats.txt" 2>&1
 timeout 300 python tools/slot_support.py C3 > "$O/${TAG}_c3_slot_support.txt" 2>&1
 timeout 300 python tools/decoder_bench.py > "$O/${TAG}_d16_iteration_exact.json" 2>/dev/null
 timeout 300 python tools/decoder_bench.py --bf16x2 > "$O/${TAG}_d16_iteration_bf16x2.json" 2>/dev/null
+timeout 300 python tools/decoder_bench.py --f16 > "$O/${TAG}_d16_iteration_f16.json" 2>/dev/null
 timeout 300 python tools/decoder_bench.py --bf16 > "$O/${TAG}_d16_iteration.json" 2>/dev/null
+timeout 600 python tools/exp_fwd.py --config C3 --truth 16 > "$O/${TAG}_fwd_accuracy.json" 2>/dev/null
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$O/d16rstats" -o d16r --output-format csv -- \
     python "$R/tools/config_sweep.py" 'C3 geometry D=16$' > /dev/null 2>&1 )
 S=$(find "$O/d16rstats" -name '*kernel_stats.csv' | head -1)
