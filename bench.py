@@ -582,7 +582,9 @@ def main():
                                            "5 v_mfma_f32_32x32x16_f16 terms per product on split operands (fp32-equivalent, DESIGN.md 4); 32-row MFMA tiles "
                                            "are chunks of 32 consecutive tile rows x one 8x8 block (58 % of their rows are non-zero at C3)")
         dom = max(kernels, key=lambda k_: kernels[k_]["avg_launch_ms"])
-        roof = dict(kernels[dom], kernel=dom, rocprof_name=STAGE_KERNELS.get(dom, (dom,))[0], traffic_source=traffic_src)
+        prefix = STAGE_KERNELS.get(dom, (dom,))[0]
+        names = [k_ for k_ in traffic if k_.startswith(prefix)]  # the kernel's full short name in the committed profile
+        roof = dict(kernels[dom], kernel=dom, rocprof_name=names[0] if len(names) == 1 else prefix, traffic_source=traffic_src)
         line = {
             "metric": "feature-raster fwd+bwd views/s",
             "value": value, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
