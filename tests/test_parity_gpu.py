@@ -1025,17 +1025,19 @@ def test_raw_parameter_projection_gradients_match_autograd_through_the_getters()
         assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) <= 1e-6, name
 
 
-def test_both_shapes_of_the_rows_kernel_agree_and_are_reproducible():
+@pytest.mark.parametrize("w,h,n,d,scale", [(200, 138, 6000, 256, 5.0), (64, 48, 300, 128, 1.0), (333, 77, 20000, 384, 12.0),
+                                           (160, 160, 3000, 640, 3.0), (48, 33, 40, 128, 20.0)])
+def test_both_shapes_of_the_rows_kernel_agree_and_are_reproducible(w, h, n, d, scale):
     """The staged backward's rows kernel, default shape (a wave per 32 channels, block contributions folded in the accumulators:
     csrc/raster_bwd_rows_cw.h) against round 4's (a wave per pixel block, rows merged in LDS: GAGS_BWD_BLOCKWAVES): the same five
     exact-product terms summed in a different order -- gradients within 2e-6 rel-L2 of each other, each bit-reproducible, each
-    within the oracle bound; a scene with a ragged image border, empty tiles and > 32 rows per tile."""
+    within the oracle bound; scenes with ragged image borders, empty tiles, one to many chunks of rows per tile, one to five
+    128-channel slices (640 = 512 + 128) and splats that cover whole tiles."""
     import torch
     from gags_amd import _lib, synthetic as syn
     from gags_amd.gaussian_renderer import render
-    w, h, n, d = 200, 138, 6000, 256
     dev = torch.device("cuda", 0)
-    pc = syn.make_model(n, d, w, h, seed=4, device=dev, scale0=syn.SCALE0 * 5)
+    pc = syn.make_model(n, d, w, h, seed=4, device=dev, scale0=syn.SCALE0 * scale)
     pc.training_setup()
     cam = syn.make_camera(w, h, view=1, device=dev)
     G = syn.make_cotangent(d, h, w, seed=2, device=dev)
