@@ -579,7 +579,8 @@ def main():
                                                   "in registers (exact operands; fp32-equivalent, DESIGN.md 4)")
         if "bwd_rows" in kernels and not (args.raster_flags & _lib.GAGS_BWD_F32MFMA):
             kernels["bwd_rows"]["note"] = ("algorithmic fp32 flops (2 D Q_blend) against the fp32 matrix peak; the kernel issues them as "
-                                           "5 v_mfma_f32_32x32x16_f16 terms per product on split operands (fp32-equivalent, DESIGN.md 4); 32-row MFMA tiles "
+                                           "3 v_mfma_f32_32x32x16_f16 terms per product on two-term split operands (one fp32-level rounding per operand: as close "
+                                           "to float64 as fp32 matrix arithmetic, DESIGN.md 4); 32-row MFMA tiles "
                                            "are chunks of 32 consecutive tile rows x one 8x8 block (58 % of their rows are non-zero at C3)")
         dom = max(kernels, key=lambda k_: kernels[k_]["avg_launch_ms"])
         prefix = STAGE_KERNELS.get(dom, (dom,))[0]
@@ -652,8 +653,8 @@ def main():
             args.raster_flags = 0
             line["backward_f32mfma"] = {
                 "note": "same workload, forward unchanged; the backward contracts with v_mfma_f32_32x32x2_f32 (rounds 1-2's kernel) "
-                        "instead of the default: v_mfma_f32_32x32x16_f16 on split operands (weights as three fp16 terms: exact; "
-                        "cotangent as two: one fp32 rounding; five MFMA terms per product; vs float64 as close as this kernel)",
+                        "instead of the default: v_mfma_f32_32x32x16_f16 on split operands (weights and cotangent as two fp16 terms each: "
+                        "one fp32-level rounding per operand; three MFMA terms per product; vs float64 1.68e-7 against this kernel's 1.90e-7)",
                 "value": fsteps / fdt, "unit": "views/s", "ms_per_step": 1e3 * fdt / fsteps, "steps": fsteps}
         if world == 1 and not (args.no_heavy or args.raster_flags):
             # north_star's "feature / geometry gradients": the same workload with EVERY parameter requiring grad (joint

@@ -134,6 +134,8 @@ GAGS_BWD_F32MFMA = 64  # python-side: staged backward contracts with v_mfma_f32_
 #                        default fp32-equivalent split operands on the 16-bit matrix cores (csrc/raster_bwd_mfma.hip)
 GAGS_BWD_BLOCKWAVES = 4096  # python-side: the staged backward's rows kernel in round 4's shape (a wave per 8x8 pixel block, rows
 #                             merged in LDS: stage bit 512) instead of the default (a wave per 32 channels, rows merged in the accumulators)
+GAGS_BWD_EXACT_WEIGHTS = 8192  # python-side: the default rows kernel with the weights as THREE fp16 terms (exact) and five product terms
+#                                (stage bit 1024) instead of two terms / three product terms: 1.60e-7 instead of 1.68e-7 of float64, 1.33x the time
 GAGS_BWD_F16SPLIT = 0   # (round 2's opt-in flag: that kernel, made exact, is the default now)
 GAGS_FWD_F16MFMA = 128  # python-side: fp16 feature table + D % 128 == 0: feature pass on the 16-bit matrix cores (opt-in; C flag 64)
 GAGS_FWD_EXACT = 2048  # fp32 table, D >= 128: feature pass on v_mfma_f32_32x32x2_f32, bit-identical to the sequential fmaf chain (the

@@ -820,7 +820,8 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
                 const int nsl = (ce - c) / 128;
                 if (stage_flags & 32) GAGS_ROWS_LAUNCH(raster_bwd_rows<4>, c, nsl);  // GAGS_BWD_F32MFMA: the fp32 matrix instructions
                 else if (stage_flags & 512) GAGS_ROWS_LAUNCH(raster_bwd_rows_f16, c, nsl);  // round 4's shape: a wave per pixel block, rows merged in LDS
-                else GAGS_ROWS_LAUNCH(raster_bwd_rows_cw, c, nsl);  // default: 16-bit matrix cores, fp32-equivalent split operands, a wave per 32 channels
+                else if (stage_flags & 1024) GAGS_ROWS_LAUNCH((raster_bwd_rows_cw<3, 5>), c, nsl);  // weights as three terms (exact), five product terms
+                else GAGS_ROWS_LAUNCH((raster_bwd_rows_cw<2, 3>), c, nsl);  // default: 16-bit matrix cores, a wave per 32 channels, three product terms
                 c += 128 * nsl;
             }
             if (ce - c >= 64) {

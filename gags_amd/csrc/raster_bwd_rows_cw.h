@@ -12,10 +12,34 @@
 // block that does not hold the row contributes a row of zeros (scale 0).  So chunks are not negotiated (no candidate
 // exchange, no pos[] table), every wave does the same work between the two barriers of a chunk (A terms ready / A terms
 // consumed), and the rows leave straight from the accumulators, 128 B per half-wave.  Price: the 32-row tiles are as full as
-// the blocks are occupied (2.3 of 4 blocks per tile row at C3: 7.3 chunks of 4 x 20 MFMAs per tile and wave instead of 5.8
+// the blocks are occupied (2.3 of 4 blocks per tile row at C3: 7.3 chunks of 4 x 12 MFMAs per tile and wave instead of 5.8
 // bursts of 80), on a matrix pipe that was a quarter busy.
-// Arithmetic per product: the five-term scheme of raster_bwd_rows_f16, unchanged; scales are per (row, block) and per
-// (block, channel), applied when a block's accumulator is folded into the total.
+// Arithmetic per product (template <TA, NM>).  Default <2, 3>: BOTH operands as two fp16 terms after an exact power-of-two
+// scaling -- w rs = a0 + a1, v cs = b0 + b1, each with |residual| <= 2^-24 of the value (two round-to-nearest steps of an
+// 11-bit significand): ONE fp32-level rounding per operand -- and the three product terms of order <= 1,
+//     w v ~ a0 b0 + a0 b1 + a1 b0        (dropped: a1 b1 <= 2^-24 |w v|),
+// every partial product exact in the fp32 accumulator: a product enters the sum with a relative error <= 3 * 2^-24, typically
+// a third of that, which stays below what an fp32 dot product of these 64-pixel columns commits in its own additions.
+// Measured against float64 (tests/test_fullsize_gpu.py::test_colour_gradient_accuracy_against_float64): 1.68e-7 rel-L2, worst
+// channel 2.68e-7; the fp32 matrix instructions: 1.90e-7 / 2.71e-7; the exact-weight scheme <3, 5> of raster_bwd_rows_f16
+// (weights as three terms, five product terms; stage bit 1024): 1.60e-7 / 2.45e-7 for 1.33x the time.  Scales are per
+// (row, block) for the weights and per (tile, channel) for the cotangent, both powers of two, applied when a block's
+// accumulator is folded into the total / when the row is stored.
+__device__ __forceinline__ void split8x2(const float (&x)[8], float scale, f16x8 &hi, f16x8 &lo)
+{
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const f32x2v_t v = {x[i] * scale, x[i + 1] * scale};
+        const f16x2_t h = __builtin_convertvector(v, f16x2_t);
+        const f32x2v_t r = v - __builtin_convertvector(h, f32x2v_t);
+        const f16x2_t l = __builtin_convertvector(r, f16x2_t);
+        hi[i] = h[0]; hi[i + 1] = h[1];
+        lo[i] = l[0]; lo[i + 1] = l[1];
+    }
+}
+
+// TA = fp16 terms of a weight (2, or 3: exact), NM = product terms (3 = a0 b0 + a0 b1 + a1 b0; 5 with TA = 3)
+template <int TA, int NM>
 __global__ __launch_bounds__(256, 2) void raster_bwd_rows_cw(
     int d, int width, int height, int tile_w, int n_tiles, int ch_base, int n_slices,
     const float *__restrict__ v_render_colors, const int32_t *__restrict__ offsets, int n_isects,
@@ -24,7 +48,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_cw(
     uint32_t *__restrict__ row_key, int32_t *__restrict__ row_idx, int rows_cap)
 {
     constexpr int CW = 128;
-    __shared__ __attribute__((aligned(16))) uint4 At[4][3][4][64];  // A terms in fragment order
+    __shared__ __attribute__((aligned(16))) uint4 At[4][TA][4][64];  // A terms in fragment order
     __shared__ __attribute__((aligned(16))) float rinv_s[4][32];    // inverse row scales of the chunk, per block
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -160,10 +184,14 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_cw(
 #pragma unroll
                 for (int i = 0; i < 8; ++i) a8[i] = A[8 * s4 + i];
                 f16x8 a0, a1, a2;
-                split8x3(a8, rs, a0, a1, a2);
+                if constexpr (TA == 3) {
+                    split8x3(a8, rs, a0, a1, a2);
+                    At[blk][2][s4][lane] = __builtin_bit_cast(uint4, a2);
+                } else {
+                    split8x2(a8, rs, a0, a1);
+                }
                 At[blk][0][s4][lane] = __builtin_bit_cast(uint4, a0);
                 At[blk][1][s4][lane] = __builtin_bit_cast(uint4, a1);
-                At[blk][2][s4][lane] = __builtin_bit_cast(uint4, a2);
             }
         }
         // the next chunk's rows: bookkeeping from the key window fetched a chunk ago, loads issued now: they travel under
@@ -178,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_cw(
         f32x16 tot;
 #pragma unroll
         for (int r = 0; r < 16; ++r) tot[r] = 0.f;
-        uint4 u0 = At_l[(0 * 4 + 0) * 64], u1 = At_l[(1 * 4 + 0) * 64], u2 = At_l[(2 * 4 + 0) * 64];
+        uint4 u0 = At_l[(0 * 4 + 0) * 64], u1 = At_l[(1 * 4 + 0) * 64], u2 = At_l[((TA - 1) * 4 + 0) * 64];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             f32x16 acc;
@@ -188,14 +216,16 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_cw(
             for (int s4 = 0; s4 < 4; ++s4) {
                 const int nb = s4 == 3 ? b + 1 : b, ns = s4 == 3 ? 0 : s4 + 1;  // the step after this one
                 const bool more = nb < 4;
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, u2), Bh[b][s4], acc, 0, 0, 0);  // smallest terms first
-                if (more) u2 = At_l[((nb * 3 + 2) * 4 + ns) * 64];
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, u1), Bl[b][s4], acc, 0, 0, 0);
+                if constexpr (TA == 3) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, u2), Bh[b][s4], acc, 0, 0, 0);  // smallest terms first
+                    if (more) u2 = At_l[((nb * TA + 2) * 4 + ns) * 64];
+                }
+                if constexpr (NM != 3) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, u1), Bl[b][s4], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, u1), Bh[b][s4], acc, 0, 0, 0);
-                if (more) u1 = At_l[((nb * 3 + 1) * 4 + ns) * 64];
+                if (more) u1 = At_l[((nb * TA + 1) * 4 + ns) * 64];
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, u0), Bl[b][s4], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, u0), Bh[b][s4], acc, 0, 0, 0);
-                if (more) u0 = At_l[((nb * 3 + 0) * 4 + ns) * 64];
+                if (more) u0 = At_l[((nb * TA + 0) * 4 + ns) * 64];
                 __builtin_amdgcn_sched_barrier(0);
             }
             // accumulator row r = chunk row (r & 3) + 8 (r >> 2) + 4 k: unscale by the (row, block) scale and fold into the row total

@@ -457,7 +457,7 @@ class _Rasterize(torch.autograd.Function):
             # an fp16 table gets its gradient in fp16 straight from the reduce kernel (fp32 sums, rounded once): no fp32
             # tensor + cast pass (autograd wants the table's dtype; an fp32 master sits behind a .half() cast)
             v_colors = _backward_staged(lib, ctx.rctx, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height,
-                                        (32 if (flags & _lib.GAGS_BWD_F32MFMA) else 0) | (64 if ctx.half else 0) | (512 if (flags & _lib.GAGS_BWD_BLOCKWAVES) else 0),
+                                        (32 if (flags & _lib.GAGS_BWD_F32MFMA) else 0) | (64 if ctx.half else 0) | (512 if (flags & _lib.GAGS_BWD_BLOCKWAVES) else 0) | (1024 if (flags & _lib.GAGS_BWD_EXACT_WEIGHTS) else 0),
                                         flatten_ids, ctx.prezero)
             return None, None, v_colors, None, v_bg, None, None, None, None, None, None, None, None, None
         if need_geom and blk_rows is not None and ctx.geom_mfma:
@@ -465,7 +465,7 @@ class _Rasterize(torch.autograd.Function):
             v_colors = None
             if ctx.needs_input_grad[2]:
                 v_colors = _backward_staged(lib, ctx.rctx, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height,
-                                            (32 if (flags & _lib.GAGS_BWD_F32MFMA) else 0) | (64 if ctx.half else 0) | (512 if (flags & _lib.GAGS_BWD_BLOCKWAVES) else 0),
+                                            (32 if (flags & _lib.GAGS_BWD_F32MFMA) else 0) | (64 if ctx.half else 0) | (512 if (flags & _lib.GAGS_BWD_BLOCKWAVES) else 0) | (1024 if (flags & _lib.GAGS_BWD_EXACT_WEIGHTS) else 0),
                                             flatten_ids)
             if ctx.half:  # the geometry kernels read an fp32 table: widen the halves (exact) for this backward
                 colors = colors.float()

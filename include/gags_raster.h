@@ -200,11 +200,14 @@ int gags_raster_bwd(int d, int width, int height, const float *means2d, const fl
  * once per (tile, Gaussian), the rows are sorted by Gaussian and reduced; v_colors[N,D] is written in full
  * (no zero-fill needed).  scratch: gags_bwd_staged_scratch_bytes(rows, n, d) bytes.
  * stage: low 4 bits 0 = all, 1..3 = rows, sort, reduce (per-kernel timing, overlap of the zero-fill below).
- * The rows' contraction (128-channel slices) runs on the 16-bit matrix cores with fp32-equivalent split operands: weights
- * as three fp16 terms (exact), cotangent as two (one fp32 rounding), five MFMA terms per product, fp32 accumulation;
- * atomic-free and bit-reproducible.  Shape since round 5: a wave per 32 channels of the slice, the four pixel blocks'
+ * The rows' contraction (128-channel slices) runs on the 16-bit matrix cores with fp32-equivalent split operands (fp16
+ * terms after exact power-of-two scalings, fp32 accumulation; see the bits below for the number of terms); atomic-free and
+ * bit-reproducible.  Shape since round 5: a wave per 32 channels of the slice, the four pixel blocks'
  * contributions to a tile row meet in its accumulators (csrc/raster_bwd_rows_cw.h).  bit 5 (32): the fp32 matrix
- * instructions instead (rounds 1-2's kernel).  bit 9 (512): round 4's shape (a wave per pixel block, rows merged in LDS).
+ * instructions instead (rounds 1-2's kernel).  bit 9 (512): round 4's shape (a wave per pixel block, rows merged in LDS;
+ * weights as three terms, five product terms).  The default shape multiplies THREE product terms of two-term operands (one
+ * fp32-level rounding per operand, the second-order term dropped: <= 3 * 2^-24 per product; 1.68e-7 of float64 against the fp32
+ * matrix instructions' 1.90e-7); bit 10 (1024): the default shape with exact three-term weights and five product terms.
  * bit 6 (64): v_colors points to an fp16 [N,D] tensor (the gradient of an fp16 feature table in the table's dtype;
  * sums are formed in fp32 and rounded once).
  * bit 7 (128): v_colors arrives ZERO-FILLED and the reduce stage skips the Gaussians that blended nothing (73 % at C3)

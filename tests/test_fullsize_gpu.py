@@ -395,21 +395,29 @@ def test_colour_gradient_accuracy_against_float64(oracle):
     (out[0] * to_dev(v_out)).sum().backward()
     e_hip = rel_l2(cols.grad.cpu().numpy(), ref)
     e_gsplat = rel_l2(o_vc, ref)
-    # the DEFAULT above contracts on the 16-bit matrix cores with fp32-equivalent split operands (weights: three fp16 terms,
-    # exact; cotangent: two, one fp32 rounding); GAGS_BWD_F32MFMA is rounds 1-2's kernel on the fp32 matrix instructions
+    # the DEFAULT above contracts on the 16-bit matrix cores with split operands: weights and cotangent as two fp16 terms each (one
+    # fp32-level rounding per operand), three product terms (csrc/raster_bwd_rows_cw.h); GAGS_BWD_EXACT_WEIGHTS: weights as three
+    # terms (exact), five product terms; GAGS_BWD_F32MFMA is rounds 1-2's kernel on the fp32 matrix instructions
     from gags_amd import _lib
-    cols2 = to_dev(s["colors"]).requires_grad_(True)
-    out2, _, _ = rasterization(to_dev(s["means"]), to_dev(s["quats"]), to_dev(s["scales"]), to_dev(opac), cols2,
-                               to_dev(s["viewmat"])[None], to_dev(s["K"])[None], w, h, backgrounds=to_dev(bg)[None],
-                               raster_flags=_lib.GAGS_BWD_F32MFMA)
-    (out2[0] * to_dev(v_out)).sum().backward()
+
+    def grad_with(flags):
+        c_ = to_dev(s["colors"]).requires_grad_(True)
+        o_, _, _ = rasterization(to_dev(s["means"]), to_dev(s["quats"]), to_dev(s["scales"]), to_dev(opac), c_,
+                                 to_dev(s["viewmat"])[None], to_dev(s["K"])[None], w, h, backgrounds=to_dev(bg)[None], raster_flags=flags)
+        (o_[0] * to_dev(v_out)).sum().backward()
+        return c_
+
+    cols2 = grad_with(_lib.GAGS_BWD_F32MFMA)
     e_f32 = rel_l2(cols2.grad.cpu().numpy(), ref)
+    e_5 = rel_l2(grad_with(_lib.GAGS_BWD_EXACT_WEIGHTS).grad.cpu().numpy(), ref)
+    assert e_5 <= e_hip * 1.02, (e_5, e_hip)   # exact weights are never worse than the three-term default
     # per channel too: the split must not be worse than fp32 matrix arithmetic in ANY column
     ref64 = ref.astype(np.float64)
     den = np.maximum(np.linalg.norm(ref64, axis=0), 1e-300)
     ch_def = np.linalg.norm(cols.grad.cpu().numpy().astype(np.float64) - ref64, axis=0) / den
     ch_f32 = np.linalg.norm(cols2.grad.cpu().numpy().astype(np.float64) - ref64, axis=0) / den
-    print(f"colour gradient vs float64: default (split operands, 16-bit matrix cores) {e_hip:.2e} [worst channel {ch_def.max():.2e}], "
+    print(f"colour gradient vs float64: default (two-term operands, three product terms) {e_hip:.2e} [worst channel {ch_def.max():.2e}], "
+          f"exact weights / five terms {e_5:.2e}, "
           f"fp32 matrix instructions {e_f32:.2e} [worst channel {ch_f32.max():.2e}], gsplat-order fp32 {e_gsplat:.2e}")
     assert e_hip <= e_gsplat and e_f32 <= e_gsplat, (e_hip, e_f32, e_gsplat)
     assert e_hip <= 2e-6 and e_f32 <= 2e-6, (e_hip, e_f32)

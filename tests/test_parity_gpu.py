@@ -306,9 +306,9 @@ def test_fp16_table_with_geometry_gradients(oracle):
 
 
 def test_backward_kernels_on_both_matrix_pipes_are_within_tolerance(oracle):
-    """The staged backward's contraction: DEFAULT = v_mfma_f32_32x32x16_f16 with fp32-equivalent split operands (weights as
-    three fp16 terms after a per-row power-of-two scale: exact; cotangent as two after a per-column scale: one fp32
-    rounding), GAGS_BWD_F32MFMA = v_mfma_f32_32x32x2_f32.  Both inside the same 2e-5 gradient tolerance PER CHANNEL with
+    """The staged backward's contraction: DEFAULT = v_mfma_f32_32x32x16_f16 with fp32-equivalent split operands (weights and
+    cotangent as two fp16 terms each after a per-row / per-column power-of-two scale: one fp32-level rounding per operand;
+    three product terms), GAGS_BWD_F32MFMA = v_mfma_f32_32x32x2_f32.  Both inside the same 2e-5 gradient tolerance PER CHANNEL with
     cotangents spanning 12 orders of magnitude across channels (exercises the per-column scaling) and weights spanning
     the whole alpha*T range (per-row scaling), both reproducible bit for bit, and the forward is untouched."""
     from gags_amd import _lib
@@ -1029,8 +1029,9 @@ def test_raw_parameter_projection_gradients_match_autograd_through_the_getters()
                                            (160, 160, 3000, 640, 3.0), (48, 33, 40, 128, 20.0)])
 def test_both_shapes_of_the_rows_kernel_agree_and_are_reproducible(w, h, n, d, scale):
     """The staged backward's rows kernel, default shape (a wave per 32 channels, block contributions folded in the accumulators:
-    csrc/raster_bwd_rows_cw.h) against round 4's (a wave per pixel block, rows merged in LDS: GAGS_BWD_BLOCKWAVES): the same five
-    exact-product terms summed in a different order -- gradients within 2e-6 rel-L2 of each other, each bit-reproducible, each
+    csrc/raster_bwd_rows_cw.h; three product terms of two-term operands, or with GAGS_BWD_EXACT_WEIGHTS five terms of exact
+    three-term weights) against round 4's (a wave per pixel block, rows merged in LDS: GAGS_BWD_BLOCKWAVES; five terms) and the
+    fp32 matrix instructions -- gradients within 2e-6 rel-L2 of each other, each bit-reproducible, each
     within the oracle bound; scenes with ragged image borders, empty tiles, one to many chunks of rows per tile, one to five
     128-channel slices (640 = 512 + 128) and splats that cover whole tiles."""
     import torch
@@ -1042,7 +1043,8 @@ def test_both_shapes_of_the_rows_kernel_agree_and_are_reproducible(w, h, n, d, s
     cam = syn.make_camera(w, h, view=1, device=dev)
     G = syn.make_cotangent(d, h, w, seed=2, device=dev)
     out = {}
-    for name, fl in (("cw", 0), ("blockwaves", _lib.GAGS_BWD_BLOCKWAVES), ("f32", _lib.GAGS_BWD_F32MFMA)):
+    for name, fl in (("cw", 0), ("cw5", _lib.GAGS_BWD_EXACT_WEIGHTS), ("blockwaves", _lib.GAGS_BWD_BLOCKWAVES),
+                     ("f32", _lib.GAGS_BWD_F32MFMA)):
         runs = []
         for _ in range(2):
             pc._semantic_feature.grad = None
@@ -1053,7 +1055,9 @@ def test_both_shapes_of_the_rows_kernel_agree_and_are_reproducible(w, h, n, d, s
         out[name] = runs[0].double()
     ref = out["f32"]
     assert float(ref.abs().max()) > 0
-    for name in ("cw", "blockwaves"):
+    for name in ("cw", "cw5", "blockwaves"):
         e = float((out[name] - ref).norm() / ref.norm())
         assert e <= 2e-6, (name, e)
     assert float((out["cw"] - out["blockwaves"]).norm() / ref.norm()) <= 2e-6
+    # same operands, same five terms, same per-(row, block) scales as round 4's kernel, another summation order
+    assert float((out["cw5"] - out["blockwaves"]).norm() / ref.norm()) <= 5e-7
