@@ -1061,3 +1061,39 @@ def test_both_shapes_of_the_rows_kernel_agree_and_are_reproducible(w, h, n, d, s
     assert float((out["cw"] - out["blockwaves"]).norm() / ref.norm()) <= 2e-6
     # same operands, same five terms, same per-(row, block) scales as round 4's kernel, another summation order
     assert float((out["cw5"] - out["blockwaves"]).norm() / ref.norm()) <= 5e-7
+
+
+@pytest.mark.parametrize("flags_name", ["default", "GAGS_BWD_EXACT_WEIGHTS", "GAGS_BWD_BLOCKWAVES"])
+def test_colour_backward_is_exact_under_power_of_two_rescaling_and_linear(flags_name):
+    """Size-independent properties of the colours-only backward (linearity).  Every scale inside the rows kernels is a
+    power of two taken from the data (per weight row, per cotangent column), so multiplying the cotangent by 2^k -- a mean-reduced
+    loss at 1080p x 512 channels is 2^-30 -- must multiply the gradient by exactly 2^k, bit for bit, for magnitudes an unscaled
+    fp16 operand could not hold; per-channel factors likewise (column scales are per channel); and the gradient of G1 + G2 is the
+    sum of the gradients within fp32 rounding."""
+    import torch
+    from gags_amd import _lib, synthetic as syn
+    from gags_amd.gaussian_renderer import render
+    flags = 0 if flags_name == "default" else getattr(_lib, flags_name)
+    w, h, n, d = 176, 120, 5000, 256
+    dev = torch.device("cuda", 0)
+    pc = syn.make_model(n, d, w, h, seed=9, device=dev, scale0=syn.SCALE0 * 6)
+    pc.training_setup()
+    cam = syn.make_camera(w, h, view=3, device=dev)
+    G1 = syn.make_cotangent(d, h, w, seed=5, device=dev)
+    G2 = syn.make_cotangent(d, h, w, seed=6, device=dev)
+
+    def grad(G):
+        pc._semantic_feature.grad = None
+        pkg = render(cam, pc, None, torch.zeros(3, device=dev), feature_mode=True, raster_flags=flags)
+        pkg["render"].backward(G)
+        return pc._semantic_feature.grad.clone()
+
+    g1 = grad(G1)
+    assert float(g1.abs().max()) > 0
+    for k in (-30, -60, 40):
+        assert torch.equal(grad(G1 * 2.0 ** k), g1 * 2.0 ** k), k
+    per_ch = torch.exp2(torch.randint(-20, 21, (d, 1, 1), device=dev, generator=torch.Generator(device=dev).manual_seed(1)).float())
+    assert torch.equal(grad(G1 * per_ch), g1 * per_ch.reshape(1, d))
+    g2, g12 = grad(G2), grad(G1 + G2)
+    e = float((g12.double() - (g1.double() + g2.double())).norm() / g12.double().norm())
+    assert e <= 5e-7, e
