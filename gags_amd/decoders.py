@@ -524,7 +524,7 @@ class _DecoderFn(torch.autograd.Function):
         else:
             h16, inv = ctx.h16, None
             if h16 is _F16:  # the cotangent scaled into half's range by a power of two (exact), the results scaled back
-                s, inv = _pow2_scale(g.abs().amax())
+                s, inv = _pow2_scale(torch.linalg.vector_norm(g.reshape(-1), float("inf")))  # (max |g| without an |g| temporary)
                 g = g * s
             dz = torch.empty(p, logits.shape[1], dtype=h16.dtype, device=g.device)
             check(h16.fn("gags_decoder_head_bwd")(p, ctx.c_out, logits.shape[1], mode, ptr(logits), ptr(g), ptr(dz),
@@ -580,7 +580,7 @@ class _DecoderDistillFn(torch.autograd.Function):
             # the logits' gradient is about v_map / (c |logits|): scaled by a power of two chosen on the device from
             # max |v_map| / c (half has 5 exponent bits), the chain's results scaled back; the scale map's gradient is fp32
             vm = _f(v_map)
-            s, inv = _pow2_scale(vm.abs().amax() / c)
+            s, inv = _pow2_scale(torch.linalg.vector_norm(vm.reshape(-1), float("inf")) / c)
             dz = torch.empty(h * w, logits.shape[1], dtype=torch.float16, device=logits.device)
             check(_lib.load().gags_decoder_head_distill_bwd_h16(c, logits.shape[1], h, w, seg.shape[1], seg.shape[2], e.shape[0],
                                                                 ptr(logits), ptr(e), ptr(seg), ptr(sc), ptr(vm), ptr(dz), ptr(s),
