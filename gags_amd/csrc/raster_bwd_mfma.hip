@@ -1016,22 +1016,26 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_sdot(int d, int ch0, int dc
 
 // ---- the same dot pass on the fp16 matrix cores with split operands (round 3; the default) --------------------------------
 // S = <c_g, v_px> is a plain contraction over the channels, so the scheme of raster_bwd_rows_f16 applies with the roles
-// swapped: the FEATURE rows are the exact operand (three fp16 terms, one power-of-two scale per Gaussian row: largest
-// magnitude -> [2^14, 2^15)), the COTANGENT slab the rounded one (two terms, one scale per 8x8 block and pass -- the
-// geometry rows sum S over the block's 64 pixels, so an error relative to the block's largest cotangent is an error
-// relative to the row's largest term).  Five MFMA terms per product at the 16-bit rate instead of one at the fp32 rate.
+// swapped: the FEATURE rows get one power-of-two scale per Gaussian row (largest magnitude -> [2^14, 2^15)), the COTANGENT
+// slab one scale per 8x8 block and pass (the geometry rows sum S over the block's 64 pixels, so an error relative to the
+// block's largest cotangent is an error relative to the row's largest term).  Since round 5 both operands are TWO fp16 terms
+// (one fp32-level rounding each) and a product is a0 b0 + a0 b1 + a1 b0 (SF_TA = 2; rounds 3-4: feature rows as three terms,
+// exact, five product terms: SF_TA = 3) -- against float64 autograd the geometry gradients did not move (v_opacities 2.3e-7,
+// v_means2d 2.5e-7; five terms: 2.7e-7 / 2.4e-7), the pass went 1.37 -> 1.16 ms.  Matrix terms at the 16-bit rate
+// instead of one at the fp32 rate.
 // What bounds this pass is not the arithmetic but the GATHER of the feature rows: every lane of an A operand reads
 // another Gaussian's row, and the vector L1 looks up one 128-byte line per cycle -- 32x32 tiles (two lanes per row, 32 B
 // per row and instruction) delivered 16-32 B/clk/CU and ran SLOWER with the 16-bit cores than the fp32 kernel (3.0 vs
 // 2.1 ms per pass at C3).  Hence v_mfma_f32_16x16x32_f16: FOUR lanes per row, 64 contiguous bytes of one row per
 // instruction, 16 lines per wave load.
-//   feat_split_kernel: once per pass, every BLENDED Gaussian's 256-channel slice -> three fp16 terms in operand order
+//   feat_split_kernel: once per pass, every BLENDED Gaussian's 256-channel slice -> SF_TA fp16 terms in operand order
 //     ([32-channel step][term][32 halves]) + 1 / scale per row; the split costs ~13 VALU instructions per two values and
 //     a row is read by ~16 units, so it is done once, not per unit;
 //   raster_bwd_sdot_f16: slab -> registers -> block maximum -> two fp16 planes in LDS (67.6 KB: two workgroups per CU);
-//     units of 16 slots x 64 pixels (four 16x16 accumulators), per 32-channel step 3 x 16 B from the table (four steps
-//     ahead), 8 x 16 B from LDS, 20 MFMAs, no VALU work in the loop; the accumulators leave scaled back by
+//     units of 16 slots x 64 pixels (four 16x16 accumulators), per 32-channel step SF_TA x 16 B from the table (four steps
+//     ahead), 8 x 16 B from LDS, 12 MFMAs (20 with three terms), no VALU work in the loop; the accumulators leave scaled back by
 //     (row scale x block scale) -- S holds plain dot products, as before.
+constexpr int SF_TA = 2;    // fp16 terms of a feature value in the table (2: one fp32-level rounding; 3: exact, five product terms)
 constexpr int SF_PADH = 8;  // halves of padding per slab row (one 2-way conflict per ds_read_b128 lane group; 16 is conflict-free and measured the same)
 constexpr int SF_PF = 4;    // 32-channel steps of table rows in flight
 constexpr int SF_STAGE = 1024;  // slots of a block whose ids and scales are staged in LDS (8 KB; mean block: ~140 slots)
@@ -1062,11 +1066,15 @@ __global__ __launch_bounds__(256) void feat_split_kernel(int n_gauss, int d, int
     const float rs = sane ? __uint_as_float((unsigned)(268 - ebits) << 23) : 1.0f;  // 2^(14 - exponent)
     if (l < 4 * ks) {
         f16x8 t0, t1, t2;
-        split8x3(x, rs, t0, t1, t2);
-        uint4 *dst = table + (size_t)row * (12 * ks) + 12 * (l >> 2) + (l & 3);  // step l / 4, k quarter l % 4; term t: + 4 t
+        uint4 *dst = table + (size_t)row * (4 * SF_TA * ks) + 4 * SF_TA * (l >> 2) + (l & 3);  // step l / 4, k quarter l % 4; term t: + 4 t
+        if constexpr (SF_TA == 3) {
+            split8x3(x, rs, t0, t1, t2);
+            dst[8] = *reinterpret_cast<const uint4 *>(&t2);
+        } else {
+            split8x2(x, rs, t0, t1);
+        }
         dst[0] = *reinterpret_cast<const uint4 *>(&t0);
         dst[4] = *reinterpret_cast<const uint4 *>(&t1);
-        dst[8] = *reinterpret_cast<const uint4 *>(&t2);
     }
     if (l == 0) rinv[row] = sane ? __uint_as_float((unsigned)(ebits - 14) << 23) : 1.0f;
 }
@@ -1124,7 +1132,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_sdot_f16(int d, int ch0, in
     const int lr = lane >> 2, lq = lane & 3;
     const int perm_src = 4 * (4 * m + kq);  // ds_bpermute address: operand lane (m, kq) takes from request lane 4 m + kq
     if (wave < n_units) gid = slot_gid(wave * 16 + lr);  // the wave's first unit: its rows are requested before the slab is waited for
-    uint4 a[SF_PF][3];
+    uint4 a[SF_PF][SF_TA];
     float ibs;  // 1 / block scale
     {
         // the whole slab in registers (<= 16 float4 per thread, all requested at once), its largest magnitude, then
@@ -1149,11 +1157,11 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_sdot_f16(int d, int ch0, in
         }
         __builtin_amdgcn_sched_barrier(0);
         if (wave < n_units) {  // (the ids were requested before the slab: they are here first)
-            const uint4 *arow = table + (size_t)gid * (12 * ks) + lq;
+            const uint4 *arow = table + (size_t)gid * (4 * SF_TA * ks) + lq;
 #pragma unroll
             for (int u = 0; u < SF_PF; ++u)
 #pragma unroll
-                for (int t = 0; t < 3; ++t) a[u][t] = arow[12 * min(u, ks - 1) + 4 * t];
+                for (int t = 0; t < SF_TA; ++t) a[u][t] = arow[4 * SF_TA * min(u, ks - 1) + 4 * t];
         }
         float sr[SF_STAGE / 256];
 #pragma unroll
@@ -1222,8 +1230,8 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_sdot_f16(int d, int ch0, in
     int gid_n = unit_gid(wave + 4);
     for (int unit = wave; unit < n_units; unit += 4) {
         const int t0 = unit * 16;
-        const uint4 *arow = table + (size_t)gid * (12 * ks) + lq;      // step j, term t: + 12 j + 4 t
-        const uint4 *arow_n = table + (size_t)gid_n * (12 * ks) + lq;  // the wave's next unit (the last one: itself again)
+        const uint4 *arow = table + (size_t)gid * (4 * SF_TA * ks) + lq;      // step j, term t: + 4 SF_TA j + 4 t
+        const uint4 *arow_n = table + (size_t)gid_n * (4 * SF_TA * ks) + lq;  // the wave's next unit (the last one: itself again)
         const int jm = min(t0 + m, cnt - 1);
         const float ri = (jm < SF_STAGE ? rinvs[jm] : rinv[slot_gid(jm)]) * ibs;
         const int gid_nn = unit_gid(unit + 8);
@@ -1234,19 +1242,20 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_sdot_f16(int d, int ch0, in
         auto step = [&](int j, int u) __attribute__((always_inline)) {
             uint4 pa[3];
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
+            for (int t = 0; t < SF_TA; ++t) {
                 pa[t].x = (unsigned)__builtin_amdgcn_ds_bpermute(perm_src, (int)a[u][t].x);
                 pa[t].y = (unsigned)__builtin_amdgcn_ds_bpermute(perm_src, (int)a[u][t].y);
                 pa[t].z = (unsigned)__builtin_amdgcn_ds_bpermute(perm_src, (int)a[u][t].z);
                 pa[t].w = (unsigned)__builtin_amdgcn_ds_bpermute(perm_src, (int)a[u][t].w);
             }
+            if constexpr (SF_TA == 2) pa[2] = pa[1];
             const f16x8 a0 = *reinterpret_cast<const f16x8 *>(&pa[0]);
             const f16x8 a1 = *reinterpret_cast<const f16x8 *>(&pa[1]);
             const f16x8 a2 = *reinterpret_cast<const f16x8 *>(&pa[2]);
             {   // slot u next holds step j + SF_PF of this unit, or -- past its end -- step u of the next one
-                const uint4 *src = (j + SF_PF < ks) ? arow + 12 * (j + SF_PF) : arow_n + 12 * min(u, ks - 1);
+                const uint4 *src = (j + SF_PF < ks) ? arow + 4 * SF_TA * (j + SF_PF) : arow_n + 4 * SF_TA * min(u, ks - 1);
 #pragma unroll
-                for (int t = 0; t < 3; ++t) a[u][t] = src[4 * t];
+                for (int t = 0; t < SF_TA; ++t) a[u][t] = src[4 * t];
             }
             f16x8 bh[4], bl[4];
 #pragma unroll
@@ -1258,10 +1267,12 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_sdot_f16(int d, int ch0, in
             // rise into this step's MFMAs (and no further; without any fence every read of the unit went to the top: 96 spills).
             __builtin_amdgcn_sched_barrier(0);
             // smallest terms first; the four accumulators in turn (no MFMA waits for the one before it)
+            if constexpr (SF_TA == 3) {
 #pragma unroll
-            for (int pg = 0; pg < 4; ++pg) acc[pg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, bh[pg], acc[pg], 0, 0, 0);
+                for (int pg = 0; pg < 4; ++pg) acc[pg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, bh[pg], acc[pg], 0, 0, 0);
 #pragma unroll
-            for (int pg = 0; pg < 4; ++pg) acc[pg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bl[pg], acc[pg], 0, 0, 0);
+                for (int pg = 0; pg < 4; ++pg) acc[pg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bl[pg], acc[pg], 0, 0, 0);
+            }
 #pragma unroll
             for (int pg = 0; pg < 4; ++pg) acc[pg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bh[pg], acc[pg], 0, 0, 0);
 #pragma unroll
