@@ -181,3 +181,16 @@ def test_cpu_twins_share_the_c_abi_signatures(oracle):
     # error convention of the ABI: a bad argument is a code, not a crash
     assert fn["gags_raster_fwd"](0, n, w, h, None, None, None, None, None, None, None, 0, None, None, None, None, None, 0, None, 0,
                                  None) == -1
+
+
+def test_python_side_raster_flags_are_distinct_bits():
+    """render(..., raster_flags=) takes an OR of these: each selectable behaviour needs a bit of its own (two of them sharing one
+    would silently select both kernels' worth of behaviour), and the retired GAGS_BWD_F16SPLIT stays 0."""
+    from gags_amd import _lib
+    names = ["GAGS_BWD_COLORS_ONLY", "GAGS_FWD_NO_MFMA", "GAGS_BWD_ATOMIC", "GAGS_FWD_FUSED", "GAGS_FEAT_F16", "GAGS_BWD_F32MFMA",
+             "GAGS_FWD_F16MFMA", "GAGS_RECS_BY_GAUSSIAN", "GAGS_FWD_ONLY_WEIGHTS", "GAGS_FWD_ONLY_FEATURES", "GAGS_FWD_EXACT",
+             "GAGS_BWD_BLOCKWAVES", "GAGS_BWD_EXACT_WEIGHTS"]
+    vals = [getattr(_lib, n) for n in names]
+    assert all(v > 0 and v & (v - 1) == 0 for v in vals), dict(zip(names, vals))
+    assert len(set(vals)) == len(vals), dict(zip(names, vals))
+    assert _lib.GAGS_BWD_F16SPLIT == 0
