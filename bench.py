@@ -658,6 +658,22 @@ def main():
                         "instead of the default: v_mfma_f32_32x32x16_f16 on split operands (weights and cotangent as two fp16 terms each: "
                         "one fp32-level rounding per operand; three MFMA terms per product; vs float64 1.68e-7 against this kernel's 1.90e-7)",
                 "value": fsteps / fdt, "unit": "views/s", "ms_per_step": 1e3 * fdt / fsteps, "steps": fsteps}
+            # ... and with the weights of the default rows kernel kept exact (three fp16 terms, five product terms: rounds
+            # 3-4's arithmetic in round 5's kernel shape, gags_amd._lib.GAGS_BWD_EXACT_WEIGHTS)
+            args.raster_flags = _lib.GAGS_BWD_EXACT_WEIGHTS
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(fsteps):
+                step()
+            torch.cuda.synchronize()
+            fdt = time.perf_counter() - t0
+            args.raster_flags = 0
+            line["backward_exact_weights"] = {
+                "note": "same workload, same kernels, the backward's weights as three fp16 terms (exact) and five MFMA terms per product "
+                        "instead of two terms / three products: 1.60e-7 of float64 instead of 1.68e-7 (fp32 matrix arithmetic: 1.90e-7)",
+                "value": fsteps / fdt, "unit": "views/s", "ms_per_step": 1e3 * fdt / fsteps, "steps": fsteps}
         if world == 1 and not (args.no_heavy or args.raster_flags):
             # north_star's "feature / geometry gradients": the same workload with EVERY parameter requiring grad (joint
             # training; the reference's GAD stage freezes the geometry).  Reported next to `value`, never as `value`.
