@@ -5,9 +5,9 @@
 // slice for all four blocks of the tile -- its cotangent slab is the same 128 VGPRs: 4 blocks x 4 K-steps x (head, tail) --
 // and a tile row's four block contributions meet in the wave's own accumulator: block after block is multiplied into a
 // scratch accumulator and folded into the row total with one FMA per element (fixed order 0..3: bit-reproducible).  What the
-// waves share instead is the A operand: the weight rows of block b are loaded, scaled and split into their three fp16 terms
-// ONCE, by wave b, and left in LDS in fragment order (48 KB: [block][term][K-step][lane] x 16 B) for all four waves to read
-// -- the split stays at one block per wave and chunk, exactly what it was.
+// waves share instead is the A operand: the weight rows of block b are loaded, scaled and split into their fp16 terms
+// ONCE, by wave b, and left in LDS in fragment order (32 KB with two terms: [block][term][K-step][lane] x 16 B) for all four
+// waves to read -- the split stays at one block per wave and chunk, exactly what it was.
 // A chunk is 32 consecutive tile rows, whatever the blocks' run lengths: row i of the chunk is MFMA row i for every block, a
 // block that does not hold the row contributes a row of zeros (scale 0).  So chunks are not negotiated (no candidate
 // exchange, no pos[] table), every wave does the same work between the two barriers of a chunk (A terms ready / A terms

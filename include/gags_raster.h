@@ -225,8 +225,9 @@ int gags_bwd_rowmap(int64_t n_isects, int width, int height, const int32_t *isec
 /* K10, geometry part at wide D (D >= 32, D % 8 == 0) after a split gags_raster_fwd: v_geo[N][8] =
  * (v_conics[3], v_means2d[2], v_opacities[1], 0, 0) per Gaussian, written in full, no atomics, deterministic.
  * The D-proportional work -- <colors[g], v_render_colors[px]> for every (slot, pixel) of the forward -- runs on the
- * matrix cores: by default the 16-bit ones with split operands (feature rows as three fp16 terms, exact, one power-of-two
- * scale per Gaussian; the cotangent as two, one scale per 8x8 block: fp32-equivalent), with
+ * matrix cores: by default the 16-bit ones with split operands (feature rows and cotangent as two fp16 terms each after
+ * exact power-of-two scalings -- one per Gaussian row, one per 8x8 block -- and three product terms: as close to float64 as
+ * fp32 matrix arithmetic), with
  * flags bit 5 (32) the fp32 matrix instructions (rounds 1-2's kernel); the per-pair chain uses the forward's own weights (T = weight / alpha: front-to-back quantities,
  * not 1 - render_alpha rebuilt back to front).  Together with gags_raster_bwd_colors_staged this replaces
  * gags_raster_bwd when geometry needs grad at wide D (gsplat's rasterize_to_pixels backward [EXT]).

@@ -521,8 +521,8 @@ def test_wide_geometry_backward_matches_the_valu_kernel_and_is_deterministic():
 
 
 def test_wide_geometry_backward_on_both_matrix_pipes_and_under_rescaling():
-    """The dot pass of gags_raster_bwd_geom contracts on the 16-bit matrix cores with split operands (feature rows as
-    three fp16 terms, cotangent as two, power-of-two scales per Gaussian row and per 8x8 block); GAGS_BWD_F32MFMA keeps
+    """The dot pass of gags_raster_bwd_geom contracts on the 16-bit matrix cores with split operands (feature rows and
+    cotangent as two fp16 terms each, power-of-two scales per Gaussian row and per 8x8 block); GAGS_BWD_F32MFMA keeps
     rounds 1-2's fp32-MFMA kernel.  The two agree to fp32 rounding, and -- the scales being powers of two -- multiplying
     the cotangent by 2^-30 (a mean-reduced loss) or the features by 2^12 multiplies every geometry gradient by exactly
     that factor, bit for bit."""
