@@ -71,6 +71,15 @@ inline FwdScratch fwd_layout(int64_t n_isects, int width, int height)
     return L;
 }
 inline bool fused_width(int d) { return d >= 32 && d % 32 == 0; }  // single-kernel forward / atomic backward
+// Intersections of one view the raster kernels can index: the count itself below GAGS_MAX_ISECTS AND the slot space it
+// spans (4 I + 64 tiles + 64 slots, common.h) below 2^30 -- slot numbers are multiplied by 4 in unsigned 32-bit offsets
+// (the id gathers of the feature pass); near the cap the per-tile slack alone (0.5 M slots at 1080p) would wrap them.
+inline bool isects_ok(int64_t n_isects, int width, int height)
+{
+    if (n_isects < 0 || n_isects >= GAGS_MAX_ISECTS || width <= 0 || height <= 0) return false;
+    const int64_t tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
+    return gags_slot_count(n_isects, tile_w * tile_h) < (1ll << 30);
+}
 }  // namespace
 
 extern "C" int gags_pack_isects(int n, int64_t n_isects, const int32_t *flatten_ids, const float *means2d,
@@ -96,7 +105,7 @@ extern "C" int gags_raster_fwd(int d, int n, int width, int height, const float 
                                const void *packed, float *render_colors, float *render_alphas, int32_t *last_ids,
                                void *scratch, int64_t scratch_bytes, int32_t *blk_rows, int flags, void *stream)
 {
-    if (d <= 0 || n < 0 || width <= 0 || height <= 0 || n_isects < 0 || n_isects >= GAGS_MAX_ISECTS) return GAGS_EINVAL;
+    if (d <= 0 || n < 0 || width <= 0 || height <= 0 || !isects_ok(n_isects, width, height)) return GAGS_EINVAL;
     if (!isect_offsets || !render_colors || !render_alphas || !last_ids) return GAGS_EINVAL;
     if (n_isects > 0 && (!means2d || !conics || !opacities || !colors || !flatten_ids)) return GAGS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
@@ -136,7 +145,7 @@ extern "C" int gags_raster_bwd(int d, int width, int height, const float *means2
                                const float *v_render_colors, const float *v_render_alphas, float *v_colors,
                                float *v_opacities, float *v_means2d, float *v_conics, int flags, void *stream)
 {
-    if (d <= 0 || width <= 0 || height <= 0 || n_isects < 0 || n_isects >= GAGS_MAX_ISECTS) return GAGS_EINVAL;
+    if (d <= 0 || width <= 0 || height <= 0 || !isects_ok(n_isects, width, height)) return GAGS_EINVAL;
     if (n_isects == 0) return GAGS_OK;
     if (!means2d || !conics || !opacities || !colors || !isect_offsets || !flatten_ids || !render_alphas ||
         !last_ids || !v_render_colors || !v_colors)
@@ -189,7 +198,7 @@ extern "C" int gags_bwd_rowmap(int64_t n_isects, int width, int height, const in
                                int64_t scratch_bytes, void *stream)
 {
     GAGS_CLEAR_ERR();
-    if (n_isects < 0 || n_isects >= GAGS_MAX_ISECTS || width <= 0 || height <= 0 || !fwd_scratch || !rowmap || !total ||
+    if (!isects_ok(n_isects, width, height) || !fwd_scratch || !rowmap || !total ||
         !isect_offsets || !blk_rows)
         return GAGS_EINVAL;
     if (rowmap_elems < gags_bwd_rowmap_elems(n_isects, width, height)) return GAGS_ESCRATCH;
@@ -220,7 +229,7 @@ extern "C" int gags_raster_bwd_geom(int d, int n, int width, int height, const f
                                     float *v_geo, const int32_t *flatten_ids, const int32_t *row_base, int64_t n_rows,
                                     int flags, void *stream)
 {
-    if (d <= 0 || width <= 0 || height <= 0 || n < 0 || n_isects < 0 || n_isects >= GAGS_MAX_ISECTS) return GAGS_EINVAL;
+    if (d <= 0 || width <= 0 || height <= 0 || n < 0 || !isects_ok(n_isects, width, height)) return GAGS_EINVAL;
     if (n == 0) return GAGS_OK;
     if (!colors || !isect_offsets || !packed || !v_render_colors || !blk_rows || !fwd_scratch || !scratch || !v_geo)
         return GAGS_EINVAL;
@@ -239,7 +248,7 @@ extern "C" int gags_raster_bwd_geom(int d, int n, int width, int height, const f
 extern "C" int gags_blended_mask(int64_t n_isects, int width, int height, int n, const int32_t *flatten_ids,
                                  const void *fwd_scratch, int64_t fwd_scratch_bytes, unsigned char *mask, void *stream)
 {
-    if (n_isects < 0 || n_isects >= GAGS_MAX_ISECTS || width <= 0 || height <= 0 || n < 0) return GAGS_EINVAL;
+    if (!isects_ok(n_isects, width, height) || n < 0) return GAGS_EINVAL;
     if (n == 0) return GAGS_OK;
     if (!mask) return GAGS_EINVAL;
     if (hipMemsetAsync(mask, 0, (size_t)n, (hipStream_t)stream) != hipSuccess) return GAGS_ELAUNCH;
@@ -258,7 +267,7 @@ extern "C" int gags_raster_bwd_colors_staged_cap(int d, int n, int width, int he
                                                  float *v_colors, int stage, int ch_begin, int ch_count,
                                                  const int32_t *rows_dev, void *stream)
 {
-    if (d <= 0 || width <= 0 || height <= 0 || n < 0 || n_isects < 0 || n_isects >= GAGS_MAX_ISECTS || rows < 0 ||
+    if (d <= 0 || width <= 0 || height <= 0 || n < 0 || !isects_ok(n_isects, width, height) || rows < 0 ||
         rows >= (1ll << 31) || stage < 0 || (stage & 15) > 3)
         return GAGS_EINVAL;
     if (n == 0) return GAGS_OK;

@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
         for (int j = 0; j < NBR; ++j) {
             mx[j] = fmaxf(mx[j], __shfl_xor(mx[j], 32));  // the column's other 32 pixels live in the other half-wave
             // largest magnitude -> [2^14, 2^15); an all-zero (or non-finite) column keeps scale 1
-            const float cs = (mx[j] > 0.f && mx[j] < 3.0e38f) ? ldexpf(1.0f, 14 - ilogbf(mx[j])) : 1.0f;
+            const float cs = (mx[j] > 0.f && mx[j] < 3.0e38f) ? ldexpf(1.0f, min(14 - ilogbf(mx[j]), 126)) : 1.0f;  // (clamped: no inf scale for a column below 2^-112)
             inv[j] = 1.0f / cs;
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {

@@ -62,6 +62,15 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_cw(
     const int blk = wave;  // the block whose weight rows this wave prepares
     const int cnt = blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk];
     const int sb = gags_slot_base(start, end, tile, blk);
+    // a slot of this tile that the forward certainly WROTE: the first slot of its first non-empty block (R1 > R0: some
+    // intersection blended, so some block holds its slot).  Rows a block does not hold read it and get the scale 0; an
+    // unwritten slot (allocator garbage: the scratch is never cleared) could hold NaN / Inf bit patterns, and 0 * NaN = NaN
+    int dummy_sb;
+    {
+        const int32_t *br = blk_rows + tile * GAGS_BLOCKS_PER_TILE;
+        const int bf = br[0] > 0 ? 0 : (br[1] > 0 ? 1 : (br[2] > 0 ? 2 : 3));
+        dummy_sb = gags_slot_base(start, end, tile, bf);
+    }
     const int ch0 = ch_base + (logical % n_slices) * CW;
     const int chw = ch0 + 32 * wave + n;  // this lane's channel: column n of the wave's B operands and of its rows
     const int ty = tile / tile_w, tx = tile - ty * tile_w;
@@ -112,7 +121,8 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_cw(
 #pragma unroll
                 for (int i = 0; i < 8; ++i) mx = fmaxf(mx, fabsf(raw[b][s4][i]));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float cs = (mx > 0.f && mx < 3.0e38f) ? ldexpf(1.0f, 14 - ilogbf(mx)) : 1.0f;
+        // (exponent clamped: below 2^-112 the scale would overflow to inf -- v * inf, 0 * inf = NaN; such a column keeps 2^126)
+        const float cs = (mx > 0.f && mx < 3.0e38f) ? ldexpf(1.0f, min(14 - ilogbf(mx), 126)) : 1.0f;
         inv_cs = 1.0f / cs;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
@@ -149,8 +159,8 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_cw(
         }
         {
             // unconditional (a conditional load would keep A alive through the whole iteration: 32 registers): rows the block
-            // does not hold read some slot that exists -- the block's first, or slot 0 of the view -- and get the scale 0
-            const float4 *p4 = reinterpret_cast<const float4 *>(wt + (size_t)(present ? sb + src : (cnt > 0 ? sb : 0)) * 64 + k * 8);
+            // does not hold read a slot the forward wrote (finite weights in [0, 1]: dummy_sb above) and get the scale 0
+            const float4 *p4 = reinterpret_cast<const float4 *>(wt + (size_t)(present ? sb + src : dummy_sb) * 64 + k * 8);
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 const float4 u = p4[4 * s4], v = p4[4 * s4 + 1];
@@ -174,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_cw(
             wmx = fmaxf(wmx, __shfl_xor(wmx, 32));
             const int ebits = (int)((__float_as_uint(wmx) >> 23) & 0xffu);
             const bool sane = present && ebits >= 15 && ebits <= 200;  // alpha*T lies in (4e-7, 1]
-            // a row the block does not hold: scale 0 (its lanes hold some other slot's finite values)
+            // a row the block does not hold: scale 0 (its lanes hold the finite weights of a slot the forward wrote)
             const float rs = sane ? __uint_as_float((unsigned)(268 - ebits) << 23) : (present ? 1.0f : 0.0f);
             const float ri = sane ? __uint_as_float((unsigned)(ebits - 14) << 23) : 1.0f;
             if (k == 0) rinv_s[blk][n] = ri;

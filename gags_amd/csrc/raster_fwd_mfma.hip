@@ -736,7 +736,12 @@ int launch_feat_any(int d, int width, int height, int n_gauss, const float *colo
         } else if (!exact) {  // the default: 16-bit matrix cores on fp32-equivalent split operands
             const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
             const int n_tiles = tile_w * tile_h, n_slices = done / 128;
-            if ((int64_t)n_gauss * d * 4 + 4096 < (1ll << 32))
+            if ((int64_t)n_gauss * d + 1024 >= (1ll << 32)) {
+                // the BIG instantiation keeps row offsets in 32-bit float units: a table of 2^32 elements or more (16 GiB;
+                // 8.4 M x 512) would wrap them.  Such a table takes the fp32 matrix instructions (64-bit row offsets; the
+                // oracle's own chain) instead of reading the wrong rows
+                rc = launch_feat<4, HALF>(d, 0, done, ARGS);
+            } else if ((int64_t)n_gauss * d * 4 + 4096 < (1ll << 32))
                 hipLaunchKernelGGL(raster_fwd_feat_x16<false>, dim3(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices), dim3(64), 0, st, d,
                                    width, height, tile_w, n_tiles, n_slices, n_gauss, colors, backgrounds, offsets, n_isects,
                                    blk_rows, wt, gid_s, Tbuf, out);

@@ -317,7 +317,7 @@ def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height, conics=
         host = ctypes.c_int32(0)
         check(lib.gags_read_i32(ptr(total), ctypes.byref(host), st), "gags_read_i32")
         n_isects = int(host.value)
-        _check_isects(n_isects)
+        _check_isects(n_isects, n_tiles)
         size, count = n_isects, n_isects
     else:
         size, count = int(cap), _DeferredCount(total, context or default_context())
@@ -348,10 +348,11 @@ def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height, conics=
     return ids_s[:size], flat_s[:size], off_view, count, packed, offsets
 
 
-def _check_isects(n_isects):
-    if n_isects < 0 or n_isects >= MAX_ISECTS:  # the int32 prefix sum wrapped, or the slot space would
+def _check_isects(n_isects, n_tiles=0):
+    # the int32 prefix sum wrapped, or the slot space (4 I + 64 tiles + 64 slots, 32-bit byte offsets of its id table) would
+    if n_isects < 0 or n_isects >= MAX_ISECTS or 4 * n_isects + 64 * n_tiles + 64 >= (1 << 30):
         raise RuntimeError(f"gags_amd.rasterization: {n_isects if n_isects >= 0 else '> 2^31'} tile intersections in one "
-                           f"view; the kernels index at most 2^28 = {MAX_ISECTS} (INTEGRATION.md, memory model)")
+                           f"view; the kernels index at most 2^28 = {MAX_ISECTS} less 16 per tile (INTEGRATION.md, memory model)")
 
 
 def _mfma_width(d):
@@ -736,7 +737,7 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
     (isect_ids, flatten_ids, isect_offsets, n_isects, packed), (out, alphas, last_ids) = run(cap)
     if cap is not None:
         n_true = n_isects.get()  # (the scan that produced it finished long ago: everything above is already enqueued)
-        _check_isects(n_true)
+        _check_isects(n_true, ((width + TILE - 1) // TILE) * ((height + TILE - 1) // TILE))
         if n_true > cap:  # more intersections than the remembered capacity: nothing was written out of bounds; run again, exact
             (isect_ids, flatten_ids, isect_offsets, n_isects, packed), (out, alphas, last_ids) = run(None)
         else:

@@ -82,6 +82,32 @@ def test_argument_validation_returns_codes_without_launching(lib):
     assert lib.gags_decoder_wgrad_split(8, 4, 4, None, 4, None, None, 4, None, None, None, 0, 1, None) == -1            # terms = 1
 
 
+def test_intersection_cap_covers_the_slot_space(lib):
+    """GAGS_MAX_ISECTS alone is not the limit: the slot space of a view is 4 I + 64 tiles + 64 slots and its id table is
+    indexed with 32-bit BYTE offsets (slots < 2^30).  Near the cap the per-tile slack would wrap them: the raster
+    entries refuse such a count with GAGS_EINVAL before looking at anything else; a count that fits passes validation (and
+    stops at the scratch-size check here: nothing is launched)."""
+    import ctypes
+    dummy = ctypes.create_string_buffer(64)
+    P = ctypes.cast(dummy, ctypes.c_void_p)
+    w = h = 16  # one tile: slots = 4 I + 128
+
+    def fwd(n_isects):
+        return lib.gags_raster_fwd(16, 4, w, h, P, P, P, P, None, P, P, n_isects, P, P, P, P, P, 0, P, 0, None)
+    assert fwd((1 << 28) - 64) == -3      # GAGS_ESCRATCH: validated, scratch_bytes = 0 is too small
+    assert fwd((1 << 28) - 1) == -1       # below GAGS_MAX_ISECTS, slot space 2^30 + 124
+    assert fwd(1 << 28) == -1
+    # at 1080p (8160 tiles) the slack is 522 304 slots: 130 576 intersections below the cap
+    def fwd1080(n_isects):
+        return lib.gags_raster_fwd(16, 4, 1920, 1080, P, P, P, P, None, P, P, n_isects, P, P, P, P, P, 0, P, 0, None)
+    assert fwd1080((1 << 28) - 130_600) == -3
+    assert fwd1080((1 << 28) - 130_500) == -1
+    from gags_amd import rasterization
+    with pytest.raises(RuntimeError, match="tile intersections"):
+        rasterization._check_isects((1 << 28) - 130_500, 8160)
+    rasterization._check_isects((1 << 28) - 130_600, 8160)
+
+
 def test_missing_library_raises_loudly(monkeypatch, tmp_path):
     from gags_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)

@@ -213,10 +213,11 @@ def _nccl_worker(rank, world, port, q):
     ok1 = torch.allclose(g, expect, rtol=1e-6, atol=1e-6)
     g2 = grads[rank].to(dev)
     red = OverlappedGradReducer(mode="rs_ag")
-    with red:
+    with red:  # the hook the staged backward calls per channel range lives on the RasterContext (no module globals)
         from gags_amd import rasterization
+        alias = g2.detach()
         for c0 in range(0, d, 128):
-            rasterization.GRAD_RANGE_HOOK(g2.detach(), c0, c0 + 128)
+            rasterization.default_context().grad_range_hook(alias, c0, c0 + 128)
     used = red.finish(g2)
     torch.cuda.synchronize()
     ok2 = used and torch.allclose(g2, expect, rtol=1e-6, atol=1e-6)

@@ -195,7 +195,7 @@ def test_c3_heavy_splats_forward_and_gradient(oracle):
     assert st["n_isects"] > 10 * st["visible"] > 0
 
 
-def _heavy_tile_sample(oracle, n, w, h, d, step, fp16_table=False, min_isects_per_visible=10):
+def _heavy_tile_sample(oracle, n, w, h, d, step, fp16_table=False, min_isects_per_visible=10, scale0=None):
     """A heavy-splat view whose compositing the oracle can only afford on every `step`-th tile: projection, binning and
     sorting are checked in full; on the sampled tiles the exact render is bit-identical, the default render within
     FWD_SPLIT_TOL, and -- with a cotangent that is zero outside them, so that the gradient is exactly the sampled tiles'
@@ -204,7 +204,7 @@ def _heavy_tile_sample(oracle, n, w, h, d, step, fp16_table=False, min_isects_pe
     from gags_amd.rasterization import rasterization
     dev = torch.device("cuda", 0)
     torch.cuda.reset_peak_memory_stats()
-    t, vm, K, _, _ = _activated(n, d, w, h, 0, syn.SCALE0_SURVEY)
+    t, vm, K, _, _ = _activated(n, d, w, h, 0, syn.SCALE0_SURVEY if scale0 is None else scale0)
     table = t["colors"].half() if fp16_table else t["colors"]
     cols = table.clone().requires_grad_(True)
     bg = torch.full((d,), 0.25, device=dev)
@@ -275,6 +275,62 @@ def test_c5_heavy_splats_on_a_tile_sample(oracle):
     st = _heavy_tile_sample(oracle, c["n"], c["width"], c["height"], 512, step=32, fp16_table=True, min_isects_per_visible=30)
     print("C5H:", st)
     assert st["n_isects"] > (1 << 27)
+
+
+def test_c5_fp32_master_table_through_the_default_forward_on_a_tile_sample(oracle):
+    """BASELINE.json configs[4]'s scene with the table a TRAINING loop holds: 4 M x 512 fp32 (scene/gaussian_model.py:188-190:
+    `_semantic_feature` is an fp32 parameter) = 8 GiB, i.e. past the 32-bit byte offsets of the default feature pass --
+    raster_fwd_feat_x16<true>, the instantiation that keeps row offsets in float units.  Index tensors in full; on every 16th
+    tile the default render within FWD_SPLIT_TOL of the oracle's chain, the GAGS_FWD_EXACT render bit-identical to it, and
+    the colours gradient of a cotangent confined to those tiles within GRAD_TOL."""
+    from gags_amd import synthetic as syn
+    c = syn.CONFIGS["C5"]
+    assert c["n"] * 512 * 4 >= (1 << 32) > c["n"] * 512  # BIG offsets, below the 2^32-element fallback
+    st = _heavy_tile_sample(oracle, c["n"], c["width"], c["height"], 512, step=16, min_isects_per_visible=2, scale0=syn.SCALE0)
+    print("C5 fp32 table:", st)
+
+
+def test_table_of_two_to_the_32_elements_takes_the_64_bit_offsets(oracle):
+    """A feature table with N * D >= 2^32 elements (8.4 M x 512 fp32 = 16 GiB) is past what the default feature pass can
+    address (raster_fwd_feat_x16 keeps row offsets in 32 bits: bytes, or floats in its BIG instantiation): such a table is
+    routed to the fp32-matrix-instruction kernel with 64-bit row offsets instead of wrapping silently.  The visible
+    Gaussians are the LAST 3000 rows of the table -- offsets past 2^32 elements -- all others sit behind the camera; the
+    oracle renders those 3000 alone (same order, same depths): the default render must equal it bit for bit (it IS the
+    oracle's chain), the gradient lands in the last rows and nowhere else."""
+    from gags_amd.rasterization import rasterization
+    dev = torch.device("cuda", 0)
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 * 2 ** 30:
+        pytest.skip(f"needs ~45 GiB of device memory (free: {free / 2 ** 30:.0f} GiB)")
+    k, d, w, h = 3000, 512, 160, 112
+    n = (1 << 32) // d + 4096 + k
+    assert (n - k) * d >= (1 << 32)
+    s = scene_arrays(k, d, w, h, seed=9, scale_mult=4.0)
+    means = torch.zeros(n, 3, device=dev); means[:, 2] = -5.0  # behind the camera: culled
+    quats = torch.zeros(n, 4, device=dev); quats[:, 0] = 1.0
+    scales = torch.full((n, 3), 0.01, device=dev)
+    opac = torch.full((n,), 0.5, device=dev)
+    table = torch.zeros(n, d, device=dev)
+    means[n - k:], quats[n - k:], scales[n - k:] = to_dev(s["means"]), to_dev(s["quats"]), to_dev(s["scales"])
+    opac[n - k:], table[n - k:] = to_dev(s["opacities"]), to_dev(s["colors"])
+    cols = table.requires_grad_(True)
+    vm, K = to_dev(s["viewmat"]), to_dev(s["K"])
+    bg = np.full(d, 0.125, np.float32)
+    out, alphas, info = rasterization(means, quats, scales, opac, cols, vm[None], K[None], w, h, backgrounds=to_dev(bg)[None])
+    o_out, o_alpha, oi = oracle.rasterization(s["means"], s["quats"], s["scales"], s["opacities"], s["colors"], s["viewmat"],
+                                              s["K"], bg, w, h)
+    assert oi["n_isects"] > 0 and info["n_isects"] == oi["n_isects"]
+    np.testing.assert_array_equal(info["radii"][0, n - k:].cpu().numpy(), oi["radii"])
+    assert int((info["radii"][0, :n - k] != 0).sum()) == 0
+    np.testing.assert_array_equal(info["flatten_ids"].cpu().numpy(), oi["flatten_ids"] + (n - k))
+    np.testing.assert_array_equal(alphas[0, ..., 0].detach().cpu().numpy(), o_alpha)
+    np.testing.assert_array_equal(out[0].detach().cpu().numpy(), o_out)
+    v_out = torch.randn(h, w, d, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
+    (out[0] * v_out).sum().backward()
+    o_vf = oracle.raster_bwd_colors_fwdorder(oi["means2d"], oi["conics"], s["opacities"], d, w, h, oi["isect_offsets"],
+                                             oi["flatten_ids"], v_out.cpu().numpy(), k)
+    assert rel_l2(cols.grad[n - k:].cpu().numpy(), o_vf) <= GRAD_TOL
+    assert not bool(cols.grad[:n - k].any())
 
 
 @pytest.mark.parametrize("d", [512, 513])

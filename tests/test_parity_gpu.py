@@ -1097,3 +1097,61 @@ def test_colour_backward_is_exact_under_power_of_two_rescaling_and_linear(flags_
     g2, g12 = grad(G2), grad(G1 + G2)
     e = float((g12.double() - (g1.double() + g2.double())).norm() / g12.double().norm())
     assert e <= 5e-7, e
+
+
+def test_rows_kernel_never_multiplies_unwritten_scratch(oracle):
+    """ADVICE r5 (medium).  In the default rows kernel a block that does not hold a tile row loads SOME slot and gives it the
+    scale 0; that slot used to be slot 0 of the view when the block was empty -- written only if the view's top-left 8x8 block
+    blends something.  The forward scratch is torch.empty: an unwritten slot is allocator garbage, and 0 * NaN = NaN in every
+    row of the chunk.  Here nothing blends into the top-left tile (the Gaussians that touch it are made too faint to pass
+    alpha >= 1/255) and the caching allocator's free memory is poisoned with NaN before the render: the gradient must be
+    finite and equal to the oracle's."""
+    n, w, h, d = 1500, 128, 80, 256
+    s = scene_arrays(n, d, w, h, seed=21, view=None, scale_mult=5.0)
+    r, m2d, _, _ = oracle.project_fwd(s["means"], s["quats"], s["scales"], s["viewmat"], s["K"], w, h)
+    touches = (r > 0) & (m2d[:, 0] - r < 16) & (m2d[:, 1] - r < 16)
+    assert 0 < touches.sum() < n // 2
+    s["opacities"] = np.where(touches, np.float32(0.003), s["opacities"]).astype(np.float32)
+    v_out = np.random.default_rng(3).standard_normal((h, w, d)).astype(np.float32)
+    o_out, o_alpha, oi = oracle.rasterization(s["means"], s["quats"], s["scales"], s["opacities"], s["colors"], s["viewmat"],
+                                              s["K"], None, w, h)
+    assert not o_alpha[:16, :16].any() and oi["isect_offsets"].reshape(-1)[1] > 0  # tile 0: intersections, nothing blended
+    dev = torch.device("cuda", 0)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    junk = torch.full((1 << 28,), float("nan"), device=dev)  # 1 GiB of NaN bit patterns left behind in the allocator's pool
+    torch.cuda.synchronize()
+    del junk
+    from gags_amd import _lib
+    o_vf = oracle.raster_bwd_colors_fwdorder(oi["means2d"], oi["conics"], s["opacities"], d, w, h, oi["isect_offsets"],
+                                             oi["flatten_ids"], v_out, n)
+    for fl in (0, _lib.GAGS_BWD_EXACT_WEIGHTS):
+        _, alpha, info, grads = _run_gpu(s, w, h, s["colors"], None, v_out=v_out, flags=fl)
+        np.testing.assert_array_equal(alpha, o_alpha)
+        assert np.isfinite(grads["colors"]).all(), fl
+        assert rel_l2(grads["colors"], o_vf) <= GRAD_TOL
+
+
+def test_colour_backward_survives_cotangents_near_the_bottom_of_the_fp32_range():
+    """ADVICE r5 (low).  The cotangent's column scale is a power of two that brings the column's largest magnitude to
+    [2^14, 2^15); below ~2^-113 that power overflowed to inf (v * inf, 0 * inf = NaN).  It is clamped at 2^126 now: a cotangent
+    scaled by 2^-122 gives a finite gradient, equal to the scaled gradient up to the digits such magnitudes keep."""
+    from gags_amd import _lib, synthetic as syn
+    from gags_amd.gaussian_renderer import render
+    w, h, n, d = 176, 120, 5000, 256
+    dev = torch.device("cuda", 0)
+    pc = syn.make_model(n, d, w, h, seed=9, device=dev, scale0=syn.SCALE0 * 6)
+    pc.training_setup()
+    cam = syn.make_camera(w, h, view=3, device=dev)
+    G = syn.make_cotangent(d, h, w, seed=5, device=dev)
+    for fl in (0, _lib.GAGS_BWD_BLOCKWAVES):
+        def grad(Gx):
+            pc._semantic_feature.grad = None
+            pkg = render(cam, pc, None, torch.zeros(3, device=dev), feature_mode=True, raster_flags=fl)
+            pkg["render"].backward(Gx)
+            return pc._semantic_feature.grad.clone()
+        g1 = grad(G).double()
+        gs = grad(G * 2.0 ** -122)
+        assert bool(torch.isfinite(gs).all()), fl
+        e = float((gs.double() * 2.0 ** 122 - g1).norm() / g1.norm())
+        assert e <= 2e-2, (fl, e)
