@@ -732,8 +732,9 @@ def main():
             pdt = 1e3 * (time.perf_counter() - t0) / vsteps
             line["view_dp_overhead_ms"] = {
                 "note": "by-view step as rank 0 of 8 runs it, loop-back exchange (two device copies per 128-channel block instead of "
-                        "the collective): range-staged backward + gags_blended_mask + gags_compact_mask + pack / unpack of the "
-                        "union block, overlapped with the backward on a second stream; xGMI wire time not included",
+                        "the collective, out of place): range-staged backward (rows per 256 channels, reduce + exchange per 128) + "
+                        "gags_blended_mask + gags_compact_mask_pos + the reduce stage writing the union block itself + unpack, "
+                        "overlapped with the backward on a second stream; xGMI wire time not included",
                 "plain_step_ms": pdt, "view_dp_step_ms": vdt, "overhead_ms": vdt - pdt, "union_rows": red.rows_exchanged,
                 "exposed_ms_last_step": red.exposed_ms(), "range_exchange_ms_last_step": red.range_ms, "steps": vsteps}
             del red, G_dp

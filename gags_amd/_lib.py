@@ -62,6 +62,8 @@ SIGNATURES = {
                                                    _i64, _vp, _i32, _i32, _i32, _vp]),
     "gags_raster_bwd_colors_staged_cap": (_i32, [_i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
                                                  _i64, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "gags_raster_bwd_colors_staged_wire": (_i32, [_i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
+                                                  _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "gags_raster_stats": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "gags_project_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _vp, _vp]),
@@ -74,6 +76,7 @@ SIGNATURES = {
     "gags_unpack_rows": (_i32, [_i64, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "gags_compact_mask_scratch_bytes": (_i64, [_i32]),
     "gags_compact_mask": (_i32, [_i32, _vp, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "gags_compact_mask_pos": (_i32, [_i32, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     "gags_dot_scratch_bytes": (_i64, []),
     "gags_dot_f32": (_i32, [_i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     # include/gags_next.h

@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256) void cm_count_kernel(int n, const uint8_t *__r
 }
 
 __global__ __launch_bounds__(256) void cm_scatter_kernel(int n, const uint8_t *__restrict__ mask, const int32_t *__restrict__ block_offs,
-                                                         const int32_t *__restrict__ total, int64_t cap, int64_t *__restrict__ idx)
+                                                         const int32_t *__restrict__ total, int64_t cap, int64_t *__restrict__ idx,
+                                                         int32_t *__restrict__ inv)
 {
     __shared__ int smem[4];
     unsigned bits;
@@ -164,11 +165,12 @@ __global__ __launch_bounds__(256) void cm_scatter_kernel(int n, const uint8_t *_
     const int incl = gags_scan::block_incl_scan(c, tot, smem);
     int64_t pos = (int64_t)block_offs[blockIdx.x] + incl - c;
 #pragma unroll
-    for (int e = 0; e < CM_PER_THREAD; ++e)
-        if (bits & (1u << e)) {
-            if (pos < cap) idx[pos] = base + e;
-            ++pos;
-        }
+    for (int e = 0; e < CM_PER_THREAD; ++e) {
+        const bool set = (bits & (1u << e)) != 0;
+        if (set && pos < cap) idx[pos] = base + e;
+        if (inv && base + e < n) inv[base + e] = (set && pos < cap) ? (int32_t)pos : -1;  // the inverse map, written in full
+        if (set) ++pos;
+    }
     // padding behind the count: -1 (gags_pack_rows writes zeros for it, gags_unpack_rows skips it)
     const int64_t cnt = total[0];
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cap; i += (int64_t)gridDim.x * 256)
@@ -241,7 +243,13 @@ extern "C" int64_t gags_compact_mask_scratch_bytes(int n)
 extern "C" int gags_compact_mask(int n, const uint8_t *mask, int64_t cap, int64_t *idx, int32_t *count, void *scratch,
                                  int64_t scratch_bytes, void *stream)
 {
-    if (n < 0 || cap < 0 || !count || (cap > 0 && !idx)) return GAGS_EINVAL;
+    return gags_compact_mask_pos(n, mask, cap, idx, nullptr, count, scratch, scratch_bytes, stream);
+}
+
+extern "C" int gags_compact_mask_pos(int n, const uint8_t *mask, int64_t cap, int64_t *idx, int32_t *pos, int32_t *count,
+                                     void *scratch, int64_t scratch_bytes, void *stream)
+{
+    if (n < 0 || cap < 0 || cap >= (1ll << 31) || !count || (cap > 0 && !idx)) return GAGS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     GAGS_CLEAR_ERR();
     if (n == 0) {
@@ -256,7 +264,7 @@ extern "C" int gags_compact_mask(int n, const uint8_t *mask, int64_t cap, int64_
     int32_t *bs = (int32_t *)scratch;
     hipLaunchKernelGGL(cm_count_kernel, dim3(nb), dim3(256), 0, st, n, mask, bs);
     hipLaunchKernelGGL(gags_scan::scan_spine, dim3(1), dim3(gags_scan::SCAN_THREADS), 0, st, nb, bs, count);
-    hipLaunchKernelGGL(cm_scatter_kernel, dim3(nb), dim3(256), 0, st, n, mask, bs, count, cap, idx);
+    hipLaunchKernelGGL(cm_scatter_kernel, dim3(nb), dim3(256), 0, st, n, mask, bs, count, cap, idx, pos);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }

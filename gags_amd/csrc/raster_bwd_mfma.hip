@@ -591,8 +591,12 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(int n_gauss, int d, in
                                                           const int32_t *__restrict__ seg,
                                                           const int32_t *__restrict__ sorted_rows,
                                                           const float *__restrict__ prow, int prow_pitch,
-                                                          void *__restrict__ v_colors_, int sparse)
+                                                          void *__restrict__ v_colors_, int sparse,
+                                                          const int32_t *__restrict__ wire_pos, float *__restrict__ wire)
 {
+    // wire (by-view multi-GPU step, gags_amd/dist.py): the rows the ranks exchange -- wire_pos[g] >= 0: row wire_pos[g] of the
+    // dense [rows, ch_count] fp32 block -- leave from here, next to the gradient itself, instead of being re-read by a pack
+    // kernel (a union row this view did not touch gets its zeros here as well: every row of the block is written)
     const int lpg = ch_count / VW;  // lanes per Gaussian (channels ch_begin .. ch_begin + ch_count - 1 of its row)
     const int gpb = 256 / lpg;
     const int gl = threadIdx.x / lpg;
@@ -602,12 +606,19 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(int n_gauss, int d, in
     const int b = seg[g], e = seg[g + 1];
     // sparse: the caller zero-filled v_colors (on a second stream, under the rows kernel): a Gaussian without rows -- 73 % of
     // them at C3 -- costs nothing here instead of a 4 D-byte row of zeros
-    if (sparse && b == e) return;
+    if (sparse && b == e && !(wire && wire_pos[g] >= 0)) return;
+    const bool skip_grad = sparse && b == e;  // (only its wire row is due)
     if constexpr (VW == 1) {
         float acc = 0.f;
         for (int i = b; i < e; ++i) acc += prow[(size_t)sorted_rows[i] * prow_pitch + cl];
-        if constexpr (HALF) reinterpret_cast<__half *>(v_colors_)[(size_t)g * d + cl] = __float2half_rn(acc);
-        else reinterpret_cast<float *>(v_colors_)[(size_t)g * d + cl] = acc;
+        if (!skip_grad) {
+            if constexpr (HALF) reinterpret_cast<__half *>(v_colors_)[(size_t)g * d + cl] = __float2half_rn(acc);
+            else reinterpret_cast<float *>(v_colors_)[(size_t)g * d + cl] = acc;
+        }
+        if (wire) {
+            const int q = wire_pos[g];
+            if (q >= 0) wire[(size_t)q * ch_count + (cl - ch_begin)] = acc;
+        }
     } else {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         int i = b;
@@ -626,14 +637,20 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(int n_gauss, int d, in
             const float4 v0 = *reinterpret_cast<const float4 *>(prow + (size_t)sorted_rows[i] * prow_pitch + cl);
             acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
         }
-        if constexpr (HALF) {
-            const __half2 lo = __floats2half2_rn(acc.x, acc.y), hi = __floats2half2_rn(acc.z, acc.w);
-            uint2 w;
-            w.x = *reinterpret_cast<const unsigned *>(&lo);
-            w.y = *reinterpret_cast<const unsigned *>(&hi);
-            *reinterpret_cast<uint2 *>(reinterpret_cast<__half *>(v_colors_) + (size_t)g * d + cl) = w;
-        } else {
-            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(v_colors_) + (size_t)g * d + cl) = acc;
+        if (!skip_grad) {
+            if constexpr (HALF) {
+                const __half2 lo = __floats2half2_rn(acc.x, acc.y), hi = __floats2half2_rn(acc.z, acc.w);
+                uint2 w;
+                w.x = *reinterpret_cast<const unsigned *>(&lo);
+                w.y = *reinterpret_cast<const unsigned *>(&hi);
+                *reinterpret_cast<uint2 *>(reinterpret_cast<__half *>(v_colors_) + (size_t)g * d + cl) = w;
+            } else {
+                *reinterpret_cast<float4 *>(reinterpret_cast<float *>(v_colors_) + (size_t)g * d + cl) = acc;
+            }
+        }
+        if (wire) {
+            const int q = wire_pos[g];
+            if (q >= 0) *reinterpret_cast<float4 *>(wire + (size_t)q * ch_count + (cl - ch_begin)) = acc;
         }
     }
 }
@@ -783,7 +800,7 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
                                   const float *v_out, const int32_t *blk_rows, const int32_t *trow, int64_t rows,
                                   const float *wt, const int32_t *gid_s, const int32_t *trow_s, void *scratch,
                                   int64_t scratch_bytes, float *v_colors, int stage_flags, int ch_begin, int ch_count,
-                                  const int32_t *rows_dev, hipStream_t st)
+                                  const int32_t *rows_dev, const int32_t *wire_pos, float *wire, hipStream_t st)
 {
     // stage: 0 = everything; 1 = rows, 2 = sort + segment offsets, 3 = reduce (per-kernel timing)
     GAGS_CLEAR_ERR();
@@ -850,17 +867,18 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
         const bool half = (stage_flags & 64) != 0;  // v_colors is an fp16 tensor
         const int sparse = (stage_flags & 128) ? 1 : 0;  // v_colors arrives zero-filled: rows of Gaussians that blended nothing are skipped
         const int c4 = ch_count & ~3, c1 = ch_count & 3;  // float4 lanes + the 1-3 channels an odd width leaves over
+        if (wire && (c1 != 0 || !wire_pos)) return GAGS_EINVAL;  // the wire block is [rows, ch_count], ch_count % 4 == 0
         if (c4 > 0) {
             const int gpb = 256 / (c4 >> 2);
             const dim3 grid((n_gauss + gpb - 1) / gpb);
-            if (half) hipLaunchKernelGGL((reduce_rows_kernel<true, 4>), grid, dim3(256), 0, st, n_gauss, d, ch_begin, c4, seg, idx_s, prow, pp, (void *)v_colors, sparse);
-            else hipLaunchKernelGGL((reduce_rows_kernel<false, 4>), grid, dim3(256), 0, st, n_gauss, d, ch_begin, c4, seg, idx_s, prow, pp, (void *)v_colors, sparse);
+            if (half) hipLaunchKernelGGL((reduce_rows_kernel<true, 4>), grid, dim3(256), 0, st, n_gauss, d, ch_begin, c4, seg, idx_s, prow, pp, (void *)v_colors, sparse, wire_pos, wire);
+            else hipLaunchKernelGGL((reduce_rows_kernel<false, 4>), grid, dim3(256), 0, st, n_gauss, d, ch_begin, c4, seg, idx_s, prow, pp, (void *)v_colors, sparse, wire_pos, wire);
         }
         if (c1 > 0) {
             const int gpb = 256 / c1;
             const dim3 grid((n_gauss + gpb - 1) / gpb);
-            if (half) hipLaunchKernelGGL((reduce_rows_kernel<true, 1>), grid, dim3(256), 0, st, n_gauss, d, ch_begin + c4, c1, seg, idx_s, prow, pp, (void *)v_colors, sparse);
-            else hipLaunchKernelGGL((reduce_rows_kernel<false, 1>), grid, dim3(256), 0, st, n_gauss, d, ch_begin + c4, c1, seg, idx_s, prow, pp, (void *)v_colors, sparse);
+            if (half) hipLaunchKernelGGL((reduce_rows_kernel<true, 1>), grid, dim3(256), 0, st, n_gauss, d, ch_begin + c4, c1, seg, idx_s, prow, pp, (void *)v_colors, sparse, wire_pos, wire);
+            else hipLaunchKernelGGL((reduce_rows_kernel<false, 1>), grid, dim3(256), 0, st, n_gauss, d, ch_begin + c4, c1, seg, idx_s, prow, pp, (void *)v_colors, sparse, wire_pos, wire);
         }
     }
     GAGS_CHECK_LAUNCH();
@@ -1550,7 +1568,7 @@ int gags_raster_bwd_geom_launch(int d, int n_gauss, int width, int height, const
         hipLaunchKernelGGL(seg_fill_kernel, dim3((n_gauss + 1 + 255) / 256), dim3(256), 0, st, n_gauss, seg);
     }
     hipLaunchKernelGGL((reduce_rows_kernel<false, 4>), dim3((n_gauss + 127) / 128), dim3(256), 0, st, n_gauss, 8, 0, 8, seg, idx_s, grow, 8,
-                       (void *)v_geo, 0);
+                       (void *)v_geo, 0, (const int32_t *)nullptr, (float *)nullptr);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }

@@ -100,6 +100,38 @@ def reduce_feature_grad(grad, mode="rs_ag", average=False, bucket_bytes=BUCKET_B
     return grad
 
 
+def reduce_feature_grad_oop(src, mode="rs_ag", bucket_bytes=BUCKET_BYTES):
+    """Sum over ranks of `src` into a NEW tensor; `src` is left as it is.  The bucketed reduce-scatter + all-gather is out of
+    place by nature -- every bucket is reduce-scattered into a shard-sized buffer and all-gathered into the result -- so
+    keeping the local values costs no copy (the overlapped exchange needs them whenever autograd did not adopt the tensor its
+    hook saw: OverlappedGradReducer.finish).  mode "allreduce" copies first and reduces the copy."""
+    ws = world()
+    flat = src.reshape(-1)
+    if ws == 1:
+        return src.clone()
+    out = torch.empty_like(flat)
+    numel = flat.numel()
+    if mode == "allreduce":
+        out.copy_(flat)
+        step = max(1, bucket_bytes // flat.element_size())
+        works = [dist.all_reduce(out[o:o + step], async_op=True) for o in range(0, numel, step)]
+        for w in works:
+            w.wait()
+    elif mode == "rs_ag":
+        per = max(ws, min(bucket_bytes // flat.element_size(), numel) // ws * ws)
+        main = numel // per * per
+        for o in range(0, main, per):
+            shard = torch.empty(per // ws, dtype=flat.dtype, device=flat.device)
+            dist.reduce_scatter_tensor(shard, flat[o:o + per])
+            dist.all_gather_into_tensor(out[o:o + per], shard)
+        if main < numel:
+            out[main:].copy_(flat[main:])
+            dist.all_reduce(out[main:])
+    else:
+        raise ValueError(mode)
+    return out.view(src.shape)
+
+
 GEOMETRY_PARAMS = ("_xyz", "_rotation", "_scaling", "_opacity")  # [N,3] [N,4] [N,3] [N,1]: SURVEY 8e's [N, 3+4+3+1]
 
 
@@ -192,9 +224,11 @@ class OverlappedGradReducer:
     `_semantic_feature`: autograd sums the terms into a fresh tensor, or adds in place), accumulation over several views,
     a clone or a cast with unknown history -- the gradient holds terms that are not this backward's local rows, so
     finish() adds `sum over ranks - local` from the packed local rows it always keeps (one more fp32 rounding per element
-    than the assigned sum: grad + (sum - local) is not bit-identical to the sum; the copy costs a second [|union|, 128] block
-    per range until finish() -- whether autograd adopts the hook's tensor, and whether anybody writes to it in place
-    afterwards, is only known then); terms from other graph paths stay rank-local and are the caller's to reduce
+    than the assigned sum: grad + (sum - local) is not bit-identical to the sum).  Keeping them costs no copy since round 6:
+    the collective is out of place (reduce_feature_grad_oop: a bucket is reduce-scattered into a shard-sized buffer and
+    all-gathered into the RESULT block), so the packed block stays this rank's local rows -- whether autograd adopts the
+    hook's tensor, and whether anybody writes to it in place afterwards, is only known in finish(); terms from other graph
+    paths stay rank-local and are the caller's to reduce
     (reduce_feature_grad).  A gradient that has been reduced once is never
     reduced again.
 
@@ -233,6 +267,7 @@ class OverlappedGradReducer:
     def _reset(self):
         self._alias, self._covered, self._entries = None, 0, []
         self._mask, self._idx = None, None
+        self._pos, self._union_ev = None, None
         self._count, self._padded = None, None
         self._alias_version = None
 
@@ -243,35 +278,41 @@ class OverlappedGradReducer:
         # -- an evaluation view, another thread -- are not touched
         self._ctx = self.context if self.context is not None else rasterization.default_context()
         self._prev = (self._ctx.grad_range_hook, self._ctx.grad_rows_hook)
+        self._prev = self._prev + (self._ctx.grad_wire_hook,)
         self._ctx.grad_range_hook = self.on_range
         self._ctx.grad_rows_hook = self.on_rows if (self.rows == "union" and self._world() > 1) else None
+        self._ctx.grad_wire_hook = self.wire_for_range
         return self
 
     def __exit__(self, *exc):
-        self._ctx.grad_range_hook, self._ctx.grad_rows_hook = self._prev
+        self._ctx.grad_range_hook, self._ctx.grad_rows_hook, self._ctx.grad_wire_hook = self._prev
         return False
 
     def _world(self):
         return self.loopback[0] if self.loopback else world()
 
     def _collective(self, wire):
+        """Sum over the ranks of the block `wire`, OUT OF PLACE: returns a new block, `wire` keeps this rank's rows."""
         if self.loopback:  # two passes over the block, like the shard exchange of a reduce-scatter + all-gather
             tmp = torch.empty_like(wire)
             tmp.copy_(wire)
-            wire.copy_(tmp)
-        else:
-            reduce_feature_grad(wire, mode=self.mode, bucket_bytes=self.bucket_bytes)
+            out = torch.empty_like(wire)
+            out.copy_(tmp)
+            return out
+        return reduce_feature_grad_oop(wire, mode=self.mode, bucket_bytes=self.bucket_bytes)
 
     def _union_mask(self, mask):
         if not self.loopback:
             dist.all_reduce(mask, op=dist.ReduceOp.MAX)
             return
         # loop-back: rows of other ranks' views are emulated by marking further rows until the union has `union_rows`
+        # (all on the device: a host readback here would drain the launch queue right at the start of the backward -- a stall
+        # the real step, whose all-reduce is just another kernel on the exchange stream, does not have)
         want = int(self.loopback[1])
-        have = int(mask.sum().item()) if want else 0
-        if have < want:
-            free = torch.nonzero(mask == 0).squeeze(1)
-            mask[free[:want - have]] = 1
+        if want:
+            free = mask == 0
+            short = want - mask.sum(dtype=torch.int64)  # rows still missing (device scalar; <= 0: nothing to add)
+            mask |= (free & (torch.cumsum(free, 0, dtype=torch.int32) <= short)).to(mask.dtype)
 
     def on_rows(self, mask):
         """mask uint8 [N] of this rank's view; the union over the ranks is formed on the exchange stream right away
@@ -313,11 +354,16 @@ class OverlappedGradReducer:
         if self.sync_free and self._cap_hint.get(n):
             cap = min(n, int(self._cap_hint[n] * self.cap_margin) + self.cap_slack)
         idx = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
+        pos = torch.empty(max(n, 1), dtype=torch.int32, device=dev)  # the inverse: position of row g in idx, or -1
         count = torch.empty(1, dtype=torch.int32, device=dev)
         sb = lib.gags_compact_mask_scratch_bytes(n)
         scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
-        _lib.check(lib.gags_compact_mask(n, _lib.ptr(mask), cap, _lib.ptr(idx), _lib.ptr(count), _lib.ptr(scratch), sb,
-                                         torch.cuda.current_stream().cuda_stream), "gags_compact_mask")
+        _lib.check(lib.gags_compact_mask_pos(n, _lib.ptr(mask), cap, _lib.ptr(idx), _lib.ptr(pos), _lib.ptr(count),
+                                             _lib.ptr(scratch), sb, torch.cuda.current_stream().cuda_stream),
+                   "gags_compact_mask_pos")
+        self._pos = pos
+        self._union_ev = torch.cuda.Event()
+        self._union_ev.record()  # (on the exchange stream: the backward's reduce stage waits for it before it reads `pos`)
         if dev.index not in self._pinned:
             self._pinned[dev.index] = torch.empty(1, dtype=torch.int32).pin_memory()
         host = self._pinned[dev.index]
@@ -348,16 +394,39 @@ class OverlappedGradReducer:
         self.rows_exchanged = c
         return over
 
-    def _exchange(self, grad, c0, c1):
+    def wire_for_range(self, c0, c1):
+        """RasterContext.grad_wire_hook: called by the staged backward BEFORE the reduce stage of range [c0, c1).  Returns
+        (pos int32 [N], wire fp32 [|union|, c1 - c0]) -- the reduce kernel then writes the rows the ranks exchange straight
+        into `wire` (gags_raster_bwd_colors_staged_wire), next to the gradient itself: no pack kernel re-reads the range --
+        or None when the exchange packs for itself (all rows, the bf16 wire, host tensors).  The calling (compute) stream is
+        made to wait for the union's index list, which the exchange stream builds from the all-reduced mask; the host waits
+        for its COUNT here (it sizes the block) while the range's rows kernel is already queued."""
+        if (self._world() == 1 or self.wire == "bf16" or self.rows != "union" or self._mask is None
+                or not self._mask.is_cuda or self.comm is None):
+            return None
+        cur = torch.cuda.current_stream()
+        with torch.cuda.stream(self.comm):
+            idx = self._union_rows()
+        if idx is None or self._pos is None:
+            return None
+        cur.wait_event(self._union_ev)
+        self._pos.record_stream(cur)
+        wire = torch.empty(idx.numel(), c1 - c0, dtype=torch.float32, device=self._mask.device)
+        if self._padded is not None:
+            wire.zero_()  # sync_free: the rows between the union's count and the capacity the block was sized with
+        wire.record_stream(self.comm)
+        return self._pos, wire
+
+    def _exchange(self, grad, c0, c1, wire=None):
         idx = self._union_rows()
         if idx is None:
             self.rows_exchanged = None
-        wire = _pack_rows(grad, idx, c0, c1, torch.bfloat16 if self.wire == "bf16" else torch.float32)
-        local = wire.clone()  # always: whether autograd adopts the hook's tensor is only known in finish()
-        self._collective(wire)
-        return dict(c0=c0, c1=c1, wire=wire, local=local, idx=idx)
+        if wire is None:
+            wire = _pack_rows(grad, idx, c0, c1, torch.bfloat16 if self.wire == "bf16" else torch.float32)
+        # out of place: `wire` stays this rank's rows (finish() needs them whenever autograd did not adopt the hook's tensor)
+        return dict(c0=c0, c1=c1, wire=self._collective(wire), local=wire, idx=idx)
 
-    def on_range(self, grad, c0, c1):
+    def on_range(self, grad, c0, c1, wire=None):
         if any(e["c0"] < c1 and c0 < e["c1"] for e in self._entries) or (
                 self._alias is not None and self._alias.data_ptr() != grad.data_ptr()):
             raise RuntimeError("OverlappedGradReducer: one backward per `with` block (call finish() between views)")
@@ -377,12 +446,12 @@ class OverlappedGradReducer:
                 self.comm.wait_event(ev)
                 t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 t0.record()
-                e = self._exchange(grad, c0, c1)  # reads `grad`, writes private buffers only
+                e = self._exchange(grad, c0, c1, wire)  # reads `grad` (or the block the reduce stage wrote), writes private buffers only
                 t1.record()
                 e["ev"] = (t0, t1)
             grad.record_stream(self.comm)
         else:
-            e = self._exchange(grad, c0, c1)
+            e = self._exchange(grad, c0, c1, wire)
         self._entries.append(e)
 
     def finish(self, param_grad):
@@ -403,8 +472,7 @@ class OverlappedGradReducer:
             # decision on every rank (the union is identical): exchange every range again with all N rows, here
             for e in self._entries:
                 wire = _pack_rows(self._alias, None, e["c0"], e["c1"], e["wire"].dtype)
-                e.update(idx=None, local=wire.clone(), wire=wire)
-                self._collective(wire)
+                e.update(idx=None, local=wire, wire=self._collective(wire))
             self.rows_exchanged = None  # (all N rows went over the wire in the end)
         if used:
             # adopted: the parameter's gradient IS the tensor the hook saw (same storage, same shape) and no in-place op

@@ -31,6 +31,10 @@ MAX_ISECTS = 1 << 28  # GAGS_MAX_ISECTS of the C ABI (include/gags_raster.h: 32-
 ZERO_FILL_MIN_ELEMS = 1 << 24  # (below that the second stream's hand-over costs more than the zeros)
 GEOM_COMPACT_ROWS = True   # gags_raster_bwd_geom: per-slot rows numbered compactly (one prefix sum + a 4-byte readback)
 CAP_MARGIN = 1.05
+# Channel ranges of the range-staged backward of a by-view multi-GPU step (RasterContext.grad_range_channels): an int (uniform
+# ranges) or a tuple of widths (multiples of 128) applied in order, the last one repeated / cut to cover D.
+GRAD_RANGE_CHANNELS = 128
+GRAD_ROWS_GROUP = 256  # channels per launch of the rows kernel under the range-staged backward (whole ranges; see _backward_staged)
 PROW_MAX_BYTES = 24 << 30  # staged backward: partial rows beyond this are produced per 128-channel range (see _backward_staged)
 # Default of RasterContext.capacity_mode (GAGS_CAPACITY_MODE=1; OFF otherwise): see RasterContext.
 CAPACITY_MODE = os.environ.get("GAGS_CAPACITY_MODE", "0") == "1"
@@ -51,6 +55,11 @@ class RasterContext:
         the next (the alias shares storage with the tensor handed to autograd).  With grad_rows_hook also set, the backward
         first calls grad_rows_hook(mask uint8 [N]): mask[g] = 1 for every Gaussian that blended into a pixel of this view,
         i.e. the only rows of the gradient that can be non-zero ("gradients are sparse in rows").
+        With grad_wire_hook set, the backward asks it before the reduce stage of every range,
+            grad_wire_hook(ch_begin, ch_end) -> (pos int32 [N], wire fp32 [rows, ch_end - ch_begin]) or None,
+        and the reduce kernel writes row pos[g] of `wire` for every Gaussian with pos[g] >= 0 next to the gradient itself
+        (gags_raster_bwd_colors_staged_wire); grad_range_hook then gets `wire` as a fourth argument.  grad_range_channels: an
+        int or a tuple of range widths (see GRAD_RANGE_CHANNELS).
     capacity_mode, cap_isects, cap_rows
         Capacity mode (OFF by default): the two counts a view produces on the device -- tile intersections, partial
         gradient rows -- are NOT waited for before the kernels that need them are launched.  Buffers are sized by a capacity
@@ -74,7 +83,9 @@ class RasterContext:
     def __init__(self, capacity_mode=None, overlap_zero_fill=False):
         self.grad_range_hook = None
         self.grad_rows_hook = None
-        self.grad_range_channels = 128
+        self.grad_wire_hook = None
+        self.grad_range_channels = GRAD_RANGE_CHANNELS
+        self.grad_rows_group = GRAD_ROWS_GROUP
         self.capacity_mode = CAPACITY_MODE if capacity_mode is None else bool(capacity_mode)
         self.cap_isects = {}
         self.cap_rows = {}
@@ -527,6 +538,25 @@ def _offsets_with_count(offsets, n_tiles, n_isects):
     return full
 
 
+def _channel_ranges(d, spec):
+    """[(c0, c1), ...] covering [0, d) for the range-staged backward, or None when D is served in one piece.  spec: an int
+    (uniform ranges; D must be a multiple) or a tuple of widths, multiples of 128, applied in order -- the last one
+    repeats until D is covered, a range that would overshoot is cut at D (which must then be a multiple of 128)."""
+    if isinstance(spec, int):
+        if spec <= 0 or d % spec != 0 or d <= spec or spec % 32 != 0:
+            return None
+        return [(c, c + spec) for c in range(0, d, spec)]
+    widths = [int(w) for w in spec]
+    if not widths or any(w <= 0 or w % 128 != 0 for w in widths) or d % 128 != 0 or d <= widths[0]:
+        return None
+    out, c, i = [], 0, 0
+    while c < d:
+        w = min(widths[min(i, len(widths) - 1)], d - c)
+        out.append((c, c + w))
+        c, i = c + w, i + 1
+    return out
+
+
 def _geom_mfma_width(d):
     """Widths whose geometry gradients run through gags_raster_bwd_geom (below that the VALU kernel is faster)."""
     return d >= 16 and d % 8 == 0 and d <= 1024
@@ -550,7 +580,7 @@ def _backward_staged(lib, rctx, offsets, n_isects, blk_rows, fwd_scratch, v_out,
     sb = lib.gags_bwd_rowmap_scratch_bytes(n_isects)
     stmp = torch.empty(max(sb, 4), dtype=torch.uint8, device=dev)
     hook = rctx.grad_range_hook
-    rng = rctx.grad_range_channels
+    ranges = _channel_ranges(d, rctx.grad_range_channels) if hook is not None else None
     cap_key = (n, width, height, dev.index)
     pending = None
     with profiler.stage("bwd_rowcount"):
@@ -597,16 +627,38 @@ def _backward_staged(lib, rctx, offsets, n_isects, blk_rows, fwd_scratch, v_out,
                         d, n, width, height, ptr(offsets), n_isects, ptr(v_out), ptr(blk_rows), ptr(trow), rows,
                         ptr(fwd_scratch), fwd_scratch.numel(), ptr(scratch), nbytes, ptr(v_colors), stage | xflag | 256, c0,
                         128, st), "gags_raster_bwd_colors_staged_range")
-    elif hook is not None and d % rng == 0 and d > rng:
+    elif hook is not None and ranges is not None:
         alias = v_colors.detach()  # own TensorImpl, same storage: autograd may still adopt v_colors without a copy
-        for c0 in range(0, d, rng):
-            for stage in ((1, 2, 3) if c0 == 0 else (1, 3)):
-                with profiler.stage(("bwd_rows", "bwd_sort", "bwd_reduce")[stage - 1]):
-                    check(lib.gags_raster_bwd_colors_staged_range(
-                        d, n, width, height, ptr(offsets), n_isects, ptr(v_out), ptr(blk_rows), ptr(trow), rows,
-                        ptr(fwd_scratch), fwd_scratch.numel(), ptr(scratch), nbytes, ptr(v_colors), stage | xflag, c0,
-                        rng, st), "gags_raster_bwd_colors_staged_range")
-            hook(alias, c0, c0 + rng)
+        wire_hook = rctx.grad_wire_hook if not (xflag & 64) else None  # (the exchanged block is fp32)
+        # the partial rows are produced for `grad_rows_group` channels per launch (two ranges by default): every rows launch
+        # streams the view's weight tiles from HBM once for all of its 128-channel slices (they share them through L2), so a
+        # launch per 128-channel range read them four times -- most of what the range-staged backward cost on one GPU -- while
+        # the reduce stage and the exchange keep the narrower range (the wire starts early and stays busy)
+        group = max(int(rctx.grad_rows_group), 1)
+        rows_done = 0
+        for c0, c1 in ranges:
+            if c1 > rows_done:
+                g1 = rows_done
+                while g1 < c1 or (g1 - rows_done < group and g1 < d):
+                    g1 = next(b for a, b in ranges if a == g1)
+                for stage in ((1, 2) if rows_done == 0 else (1,)):
+                    with profiler.stage(("bwd_rows", "bwd_sort")[stage - 1]):
+                        check(lib.gags_raster_bwd_colors_staged_range(
+                            d, n, width, height, ptr(offsets), n_isects, ptr(v_out), ptr(blk_rows), ptr(trow), rows,
+                            ptr(fwd_scratch), fwd_scratch.numel(), ptr(scratch), nbytes, ptr(v_colors), stage | xflag, rows_done,
+                            g1 - rows_done, st), "gags_raster_bwd_colors_staged_range")
+                rows_done = g1
+            # the rows the ranks exchange leave from the reduce kernel itself (no pack pass over the range afterwards)
+            w = wire_hook(c0, c1) if wire_hook is not None else None
+            with profiler.stage("bwd_reduce"):
+                check(lib.gags_raster_bwd_colors_staged_wire(
+                    d, n, width, height, ptr(offsets), n_isects, ptr(v_out), ptr(blk_rows), ptr(trow), rows,
+                    ptr(fwd_scratch), fwd_scratch.numel(), ptr(scratch), nbytes, ptr(v_colors), 3 | xflag, c0, c1 - c0,
+                    ptr(w[0]) if w else None, ptr(w[1]) if w else None, st), "gags_raster_bwd_colors_staged_wire")
+            if w is not None:
+                hook(alias, c0, c1, w[1])
+            else:
+                hook(alias, c0, c1)
     elif profiler.ENABLED:  # one event pair per kernel (group), for the roofline line of bench.py
         for stage, name in enumerate(("bwd_rows", "bwd_sort", "bwd_reduce"), start=1):
             with profiler.stage(name):

@@ -279,6 +279,17 @@ int gags_raster_bwd_colors_staged_cap(int d, int n, int width, int height, const
                                       int64_t scratch_bytes, float *v_colors, int stage, int ch_begin, int ch_count,
                                       const int32_t *rows_dev, void *stream);
 
+/* gags_raster_bwd_colors_staged_range whose reduce stage ALSO writes the rows a by-view multi-GPU step exchanges
+ * (gags_amd/dist.py): wire[wire_pos[g], :] = the range's gradient row of Gaussian g for every g with
+ * wire_pos[g] >= 0 -- wire is a dense fp32 [union rows, ch_count] block (ch_count % 4 == 0), wire_pos the inverse of the
+ * union's row list (gags_compact_mask_pos).  Every row of the block is written (a union row this view did not touch gets
+ * zeros), so the block needs no clearing and no pack kernel re-reads the gradient.  v_colors is written as always. */
+int gags_raster_bwd_colors_staged_wire(int d, int n, int width, int height, const int32_t *isect_offsets, int64_t n_isects,
+                                       const float *v_render_colors, const int32_t *blk_rows, const int32_t *rowmap,
+                                       int64_t rows, const void *fwd_scratch, int64_t fwd_scratch_bytes, void *scratch,
+                                       int64_t scratch_bytes, float *v_colors, int stage, int ch_begin, int ch_count,
+                                       const int32_t *wire_pos, float *wire, void *stream);
+
 /* Diagnostics (roofline model): counts[0] += (pixel,Gaussian) pairs evaluated
  * before each pixel's stop, counts[1] += pairs blended.  counts[2] int64, zeroed by caller. */
 int gags_raster_stats(int width, int height, const float *means2d, const float *conics,
@@ -355,6 +366,11 @@ int gags_adam_step(int64_t numel, float *param, const float *grad, float *exp_av
 int64_t gags_compact_mask_scratch_bytes(int n);
 int gags_compact_mask(int n, const uint8_t *mask, int64_t cap, int64_t *idx, int32_t *count, void *scratch,
                       int64_t scratch_bytes, void *stream);
+/*   gags_compact_mask_pos: the same, and the inverse on the way: pos[r] (n int32, written in full) = the position of row r
+ *                     in idx, -1 for rows that are not set or whose position is >= cap (gags_raster_bwd_colors_staged_wire
+ *                     writes the exchanged rows through it). */
+int gags_compact_mask_pos(int n, const uint8_t *mask, int64_t cap, int64_t *idx, int32_t *pos, int32_t *count, void *scratch,
+                          int64_t scratch_bytes, void *stream);
 int gags_pack_rows(int64_t n_rows, const int64_t *idx, const void *grad, int grad_type, int d, int c0, int cw,
                    void *wire, int wire_type, void *stream);
 int gags_unpack_rows(int64_t n_rows, const int64_t *idx, const void *wire, int wire_type, const void *local,

@@ -39,6 +39,15 @@ def _worker(rank, world, port, mode, n, d, q):
     ok = ok and torch.allclose(g2, expect, rtol=1e-6, atol=1e-6)
     if mode == "rs_ag":
         ok = ok and calls == [n * d // world * world]
+    # the out-of-place form the overlapped exchange uses: the sum in a NEW tensor, the source left as it is (it stays the
+    # rank's local rows), bucketed and un-bucketed
+    from gags_amd.dist import reduce_feature_grad_oop
+    g3 = torch.randn(n, d, generator=torch.Generator().manual_seed(100 + rank))
+    keep = g3.clone()
+    for bb in (4096, 256 << 20):
+        s3 = reduce_feature_grad_oop(g3, mode=mode, bucket_bytes=bb)
+        ok = ok and torch.equal(g3, keep) and s3.data_ptr() != g3.data_ptr() and s3.shape == g3.shape
+        ok = ok and torch.allclose(s3, expect, rtol=1e-6, atol=1e-6)
     views = shard_views(8)
     q.put((rank, bool(ok), views))
     dist.barrier()

@@ -2,7 +2,9 @@
 """The by-view step's single-GPU overhead (bench.py's `view_dp_overhead_ms`) as a function of the width of the channel ranges
 the backward is asked for (RasterContext.grad_range_channels): loop-back exchange, rank 0 of 8, C3.
 
-    python tools/dp_overhead.py [128 256 512]"""
+    python tools/dp_overhead.py [128 256 512 256,128,128 ...]      (a comma list = a tuple of range widths, in order)
+    GAGS_DP_ROWS_GROUP=128|256|512: channels per launch of the rows kernel (RasterContext.grad_rows_group)
+    GAGS_DP_NO_WIRE=1: the round-5 exchange shape (pack kernel instead of the reduce stage writing the exchanged rows)"""
 import json
 import os
 import sys
@@ -45,9 +47,14 @@ def timed(fn, k=8):
 
 
 out = {"plain_ms": timed(plain)}
-for rng in [int(a) for a in sys.argv[1:]] or [128, 256, 512]:
+specs = [tuple(int(x) for x in a.split(",")) if "," in a else int(a) for a in sys.argv[1:]] or [128, 256, 512, (256, 128, 128)]
+for rng in specs:
     default_context().grad_range_channels = rng
+    if os.environ.get("GAGS_DP_ROWS_GROUP"):
+        default_context().grad_rows_group = int(os.environ["GAGS_DP_ROWS_GROUP"])
     red = OverlappedGradReducer(mode="rs_ag", rows="union", param=pc._semantic_feature, loopback=(8, union_rows))
+    if os.environ.get("GAGS_DP_NO_WIRE") == "1":
+        red.wire_for_range = lambda c0, c1: None
 
     def dp():
         pc._semantic_feature.grad = None
