@@ -674,6 +674,22 @@ def main():
                 "note": "same workload, same kernels, the backward's weights as three fp16 terms (exact) and five MFMA terms per product "
                         "instead of two terms / three products: 1.60e-7 of float64 instead of 1.68e-7 (fp32 matrix arithmetic: 1.90e-7)",
                 "value": fsteps / fdt, "unit": "views/s", "ms_per_step": 1e3 * fdt / fsteps, "steps": fsteps}
+            # ... and the strict-fp32 step as ONE number: forward on the fp32 matrix instructions (the oracle's fmaf chain, bit for
+            # bit) AND backward on the fp32 matrix instructions -- no split operands anywhere
+            args.raster_flags = _lib.GAGS_FWD_EXACT | _lib.GAGS_BWD_F32MFMA
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(fsteps):
+                step()
+            torch.cuda.synchronize()
+            fdt = time.perf_counter() - t0
+            args.raster_flags = 0
+            line["all_exact"] = {
+                "note": "same workload with GAGS_FWD_EXACT | GAGS_BWD_F32MFMA: both contractions on v_mfma_f32_32x32x2_f32 (forward "
+                        "bit-identical to the oracle's sequential chain, backward plain fp32 matrix arithmetic): the strict-fp32 step",
+                "value": fsteps / fdt, "unit": "views/s", "ms_per_step": 1e3 * fdt / fsteps, "steps": fsteps}
         if world == 1 and not (args.no_heavy or args.raster_flags):
             # north_star's "feature / geometry gradients": the same workload with EVERY parameter requiring grad (joint
             # training; the reference's GAD stage freezes the geometry).  Reported next to `value`, never as `value`.

@@ -190,6 +190,73 @@ def test_compact_mask_is_the_ascending_nonzero_list(n, p):
         k = min(c, cap)
         assert torch.equal(idx[:k], want[:k])
         assert bool((idx[k:cap] == -1).all()) and bool((idx[cap:] == 12345).all())
+        # ... and with the inverse map: pos[r] = position of row r in idx, -1 for unset rows and for rows past the capacity
+        idx2 = torch.full((cap + 4,), 12345, dtype=torch.int64, device=dev)
+        pos = torch.full((n + 3,), 777, dtype=torch.int32, device=dev)
+        _lib.check(lib.gags_compact_mask_pos(n, _lib.ptr(mask), cap, _lib.ptr(idx2), _lib.ptr(pos), _lib.ptr(count),
+                                             _lib.ptr(scratch), sb, None), "gags_compact_mask_pos")
+        torch.cuda.synchronize()
+        assert torch.equal(idx2, idx) and int(count.item()) == c
+        expect = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        expect[want[:k]] = torch.arange(k, dtype=torch.int32, device=dev)
+        assert torch.equal(pos[:n], expect) and bool((pos[n:] == 777).all())
+
+
+def test_reduce_stage_writes_the_exchanged_rows_itself():
+    """gags_raster_bwd_colors_staged_wire (round 6): under the by-view step the reduce kernel of a channel range also writes
+    the block the ranks exchange -- row pos[g] of a dense [union rows, range] fp32 block for every Gaussian of the union --
+    so no pack kernel re-reads the gradient.  Driven through the hooks of a RasterContext as gags_amd/dist.py drives them:
+    every block equals the gradient's rows (zeros for union rows this view did not touch), with 128- and 256-channel ranges
+    and with the rows kernel launched per range or per group of ranges; the gradient itself is bit-identical to the plain
+    backward's."""
+    from gags_amd import _lib, synthetic as syn
+    from gags_amd.gaussian_renderer import render
+    from gags_amd.rasterization import RasterContext
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    n, d, w, h = 6000, 512, 200, 138
+    pc = syn.make_model(n, d, w, h, seed=4, device=dev, scale0=syn.SCALE0 * 5)
+    pc.training_setup()
+    cam = syn.make_camera(w, h, view=1, device=dev)
+    G = syn.make_cotangent(d, h, w, seed=2, device=dev)
+    bg = torch.zeros(3, device=dev)
+    (render(cam, pc, None, bg, feature_mode=True)["render"] * G).sum().backward()
+    plain = pc._semantic_feature.grad.clone()
+    for spec, group in ((128, 256), (128, 128), (256, 256), ((256, 128, 128), 512)):
+        ctx = RasterContext()
+        ctx.grad_range_channels, ctx.grad_rows_group = spec, group
+        state = {"blocks": []}
+
+        def on_rows(mask):
+            extra = torch.zeros_like(mask)
+            extra[::7] = 1   # rows of "other ranks": in the union, untouched by this view
+            m = mask | extra
+            idx = torch.empty(n, dtype=torch.int64, device=dev)
+            pos = torch.empty(n, dtype=torch.int32, device=dev)
+            count = torch.zeros(1, dtype=torch.int32, device=dev)
+            sb = lib.gags_compact_mask_scratch_bytes(n)
+            scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
+            _lib.check(lib.gags_compact_mask_pos(n, _lib.ptr(m), n, _lib.ptr(idx), _lib.ptr(pos), _lib.ptr(count), _lib.ptr(scratch),
+                                                 sb, torch.cuda.current_stream().cuda_stream), "gags_compact_mask_pos")
+            c = int(count.item())
+            state.update(idx=idx[:c], pos=pos)
+
+        def wire_hook(c0, c1):
+            return state["pos"], torch.full((state["idx"].numel(), c1 - c0), float("nan"), device=dev)
+
+        def on_range(grad, c0, c1, wire=None):
+            assert wire is not None
+            state["blocks"].append((c0, c1, wire))
+
+        ctx.grad_rows_hook, ctx.grad_wire_hook, ctx.grad_range_hook = on_rows, wire_hook, on_range
+        pc._semantic_feature.grad = None
+        (render(cam, pc, None, bg, feature_mode=True, context=ctx)["render"] * G).sum().backward()
+        torch.cuda.synchronize()
+        g = pc._semantic_feature.grad
+        assert torch.equal(g, plain), (spec, group)
+        assert sum(c1 - c0 for c0, c1, _ in state["blocks"]) == d and 0 < state["idx"].numel() < n
+        for c0, c1, wire in state["blocks"]:
+            assert torch.equal(wire, g[state["idx"], c0:c1]), (spec, group, c0)
 
 
 def _nccl_worker(rank, world, port, q):
