@@ -13,6 +13,7 @@
 // epilogue stores 16 B per lane.  All D channels of a slice are composited in ONE walk of the list
 // (gsplat re-walks it ceil(D/32) times).
 #include <hip/hip_fp16.h>
+#include <type_traits>
 #include "raster_mfma_common.h"
 
 using namespace gags_mfma;
@@ -459,6 +460,44 @@ __device__ __forceinline__ void mfma6(f32x16 &acc, const Op3 &a, const Op3 &b)
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[0], b.t[0], acc, 0, 0, 0);
 }
 
+// fp16 feature table (BASELINE.json configs[4]): a half has an 11-bit significand, so TWO bf16 terms by truncation hold it
+// exactly (8 + 3 bits; bf16 has fp32's exponent range: no scale, half subnormals included) -- the B operand costs two terms
+// instead of three, a product five MFMA terms instead of six (a0 b2 does not exist), the split 8 instead of 11 VALU
+// instructions per pair of values, and the gather moves half the bytes.
+struct Op2 {
+    bf16x8 t[2];
+};
+
+__device__ __forceinline__ void split2_pair(float x, float y, unsigned &t0, unsigned &t1)
+{
+    const unsigned ux = __float_as_uint(x), uy = __float_as_uint(y);
+    t0 = __builtin_amdgcn_perm(uy, ux, 0x07060302u);
+    const float rx = x - __uint_as_float(ux & 0xffff0000u), ry = y - __uint_as_float(uy & 0xffff0000u);  // <= 3 bits left: a bf16
+    t1 = __builtin_amdgcn_perm(__float_as_uint(ry), __float_as_uint(rx), 0x07060302u);
+}
+
+__device__ __forceinline__ Op2 split_op_h(const float (&v)[8])
+{
+    union { bf16x8 v; unsigned u[4]; } o[2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) split2_pair(v[2 * q], v[2 * q + 1], o[0].u[q], o[1].u[q]);
+    Op2 r;
+    r.t[0] = o[0].v; r.t[1] = o[1].v;
+    return r;
+}
+
+__device__ __forceinline__ void mfma5(f32x16 &acc, const Op3 &a, const Op2 &b)
+{
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[2], b.t[0], acc, 0, 0, 0);  // smallest terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[1], b.t[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[1], b.t[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[0], b.t[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[0], b.t[0], acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ float half_lo(unsigned u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu)); }
+__device__ __forceinline__ float half_hi(unsigned u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16)); }
+
 // id of slot I (0..7) of the lane's half of the step, from a vector whose every 16-lane row holds the eight ids of its
 // half-wave twice (lane l: slot 8 (l >> 5) + (l & 7)): DPP row broadcast, fused by the compiler into the consuming add
 template <int I>
@@ -467,8 +506,9 @@ __device__ __forceinline__ unsigned row_bcast_add(unsigned v, unsigned add)
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + I, 0xf, 0xf, false) + add;
 }
 
-// BIG: the table does not fit 32-bit byte offsets (N D 4 >= 2^32): offsets in floats, widened per gather
-template <bool BIG>
+// BIG: the table does not fit 32-bit byte offsets (N D 4 >= 2^32; halves: N D 2): offsets in elements, widened per gather
+// HALF: `colors` is an fp16 table (two-term B operands, five product terms: above)
+template <bool BIG, bool HALF>
 __global__ __launch_bounds__(64, 2) void raster_fwd_feat_x16(
     int d, int width, int height, int tile_w, int n_tiles, int n_slices, int n_gauss,
     const float *__restrict__ colors, const float *__restrict__ backgrounds, const int32_t *__restrict__ offsets,
@@ -526,22 +566,24 @@ __global__ __launch_bounds__(64, 2) void raster_fwd_feat_x16(
 #pragma unroll
             for (int i = 0; i < 8; ++i) w[i] = *reinterpret_cast<const float2 *>(src + i * 64);
         };
-        const unsigned lane_off = BIG ? (unsigned)(ch0 + 4 * p) : (unsigned)(ch0 + 4 * p) * 4u;
-        const unsigned row_pitch = BIG ? (unsigned)d : (unsigned)d * 4u;
-        auto load_f = [&](unsigned idv, float4 (&f)[8]) {  // channels ch0 + 4 p .. + 3 of the eight rows
+        constexpr unsigned ESZ = HALF ? 2u : 4u;  // bytes per table element
+        using Row = typename std::conditional<HALF, uint2, float4>::type;  // the lane's four channels of one row
+        const unsigned lane_off = BIG ? (unsigned)(ch0 + 4 * p) : (unsigned)(ch0 + 4 * p) * ESZ;
+        const unsigned row_pitch = BIG ? (unsigned)d : (unsigned)d * ESZ;
+        auto load_f = [&](unsigned idv, Row (&f)[8]) {  // channels ch0 + 4 p .. + 3 of the eight rows
             const unsigned ro = min(idv, gmax) * row_pitch;  // (the zero slots carry id N)
             const unsigned o[8] = {row_bcast_add<0>(ro, lane_off), row_bcast_add<1>(ro, lane_off), row_bcast_add<2>(ro, lane_off),
                                    row_bcast_add<3>(ro, lane_off), row_bcast_add<4>(ro, lane_off), row_bcast_add<5>(ro, lane_off),
                                    row_bcast_add<6>(ro, lane_off), row_bcast_add<7>(ro, lane_off)};
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                if constexpr (BIG) f[i] = *reinterpret_cast<const float4 *>(colors + (size_t)o[i]);
-                else f[i] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(colors) + o[i]);
+                if constexpr (BIG) f[i] = *reinterpret_cast<const Row *>(reinterpret_cast<const char *>(colors) + (size_t)o[i] * ESZ);
+                else f[i] = *reinterpret_cast<const Row *>(reinterpret_cast<const char *>(colors) + o[i]);
             }
         };
         // software pipeline: rows and weights of step s + 1 are requested during step s, the ids two steps further ahead
         // (loads return in order: an id requested late would be waited for together with the rows issued before it)
-        float4 F[8];
+        Row F[8];
         float2 W[8];
         unsigned id1, id2;
         load_w(0, W);
@@ -559,34 +601,54 @@ __global__ __launch_bounds__(64, 2) void raster_fwd_feat_x16(
                 aB = split_op(wb);
             }
             // B operands of the four channel tiles; then the rows' registers are free for the next step's
-            Op3 b[NB];
+            using OpB = typename std::conditional<HALF, Op2, Op3>::type;
+            OpB b[NB];
             {
                 float x[8];
+                if constexpr (HALF) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) x[i] = F[i].x;
-                b[0] = split_op(x);
+                    for (int i = 0; i < 8; ++i) x[i] = half_lo(F[i].x);
+                    b[0] = split_op_h(x);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) x[i] = F[i].y;
-                b[1] = split_op(x);
+                    for (int i = 0; i < 8; ++i) x[i] = half_hi(F[i].x);
+                    b[1] = split_op_h(x);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) x[i] = F[i].z;
-                b[2] = split_op(x);
+                    for (int i = 0; i < 8; ++i) x[i] = half_lo(F[i].y);
+                    b[2] = split_op_h(x);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) x[i] = F[i].w;
-                b[3] = split_op(x);
+                    for (int i = 0; i < 8; ++i) x[i] = half_hi(F[i].y);
+                    b[3] = split_op_h(x);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) x[i] = F[i].x;
+                    b[0] = split_op(x);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) x[i] = F[i].y;
+                    b[1] = split_op(x);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) x[i] = F[i].z;
+                    b[2] = split_op(x);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) x[i] = F[i].w;
+                    b[3] = split_op(x);
+                }
             }
+            auto mm = [&](f32x16 &acc, const Op3 &a, const OpB &bb) __attribute__((always_inline)) {
+                if constexpr (HALF) mfma5(acc, a, bb);
+                else mfma6(acc, a, bb);
+            };
             __builtin_amdgcn_sched_barrier(0);
             load_f(id1, F);
             id1 = id2;
             id2 = load_ids(min(s + 3, steps - 1));
             __builtin_amdgcn_sched_barrier(0);
-            mfma6(accA[0], aA, b[0]); mfma6(accB[0], aB, b[0]);
-            mfma6(accA[1], aA, b[1]); mfma6(accB[1], aB, b[1]);
+            mm(accA[0], aA, b[0]); mm(accB[0], aB, b[0]);
+            mm(accA[1], aA, b[1]); mm(accB[1], aB, b[1]);
             __builtin_amdgcn_sched_barrier(0);
             load_w(min(s + 1, steps - 1), W);
             __builtin_amdgcn_sched_barrier(0);
-            mfma6(accA[2], aA, b[2]); mfma6(accB[2], aB, b[2]);
-            mfma6(accA[3], aA, b[3]); mfma6(accB[3], aB, b[3]);
+            mm(accA[2], aA, b[2]); mm(accB[2], aB, b[2]);
+            mm(accA[3], aA, b[3]); mm(accB[3], aB, b[3]);
         };
         for (int s = 0; s < steps; ++s) step(s);
     }
@@ -722,8 +784,23 @@ int launch_feat_any(int d, int width, int height, int n_gauss, const float *colo
 #define ARGS width, height, n_gauss, colors, backgrounds, offsets, n_isects, blk_rows, wt, gid_s, Tbuf, out, st
     if (d >= 128) {
         done = d / 128 * 128;
+        const int64_t table_elems = (int64_t)n_gauss * d;
         if constexpr (HALF) {
-            if (f16_mfma) {  // opt-in: the 16-bit matrix cores
+            if (!f16_mfma && !exact && table_elems + 1024 < (1ll << 32)) {
+                // the default since round 6: the bf16 matrix cores, B = the half as two exact bf16 terms, A = the weight as
+                // three (exact), five product terms -- fp32-equivalent like the fp32 table's default (raster_fwd_feat_x16)
+                const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
+                const int n_tiles = tile_w * tile_h, n_slices = done / 128;
+                if (table_elems * 2 + 4096 < (1ll << 32))
+                    hipLaunchKernelGGL((raster_fwd_feat_x16<false, true>), dim3(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices), dim3(64), 0, st, d,
+                                       width, height, tile_w, n_tiles, n_slices, n_gauss, colors, backgrounds, offsets, n_isects,
+                                       blk_rows, wt, gid_s, Tbuf, out);
+                else
+                    hipLaunchKernelGGL((raster_fwd_feat_x16<true, true>), dim3(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices), dim3(64), 0, st, d,
+                                       width, height, tile_w, n_tiles, n_slices, n_gauss, colors, backgrounds, offsets, n_isects,
+                                       blk_rows, wt, gid_s, Tbuf, out);
+                GAGS_CHECK_LAUNCH();
+            } else if (f16_mfma) {  // opt-in: the f16 matrix cores with a fixed weight scale (round 2's kernel)
                 const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
                 const int n_tiles = tile_w * tile_h, n_slices = done / 128;
                 hipLaunchKernelGGL(raster_fwd_feat_f16, dim3(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices), dim3(64), 0, st, d,
@@ -742,11 +819,11 @@ int launch_feat_any(int d, int width, int height, int n_gauss, const float *colo
                 // oracle's own chain) instead of reading the wrong rows
                 rc = launch_feat<4, HALF>(d, 0, done, ARGS);
             } else if ((int64_t)n_gauss * d * 4 + 4096 < (1ll << 32))
-                hipLaunchKernelGGL(raster_fwd_feat_x16<false>, dim3(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices), dim3(64), 0, st, d,
+                hipLaunchKernelGGL((raster_fwd_feat_x16<false, false>), dim3(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices), dim3(64), 0, st, d,
                                    width, height, tile_w, n_tiles, n_slices, n_gauss, colors, backgrounds, offsets, n_isects,
                                    blk_rows, wt, gid_s, Tbuf, out);
             else
-                hipLaunchKernelGGL(raster_fwd_feat_x16<true>, dim3(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices), dim3(64), 0, st, d,
+                hipLaunchKernelGGL((raster_fwd_feat_x16<true, false>), dim3(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices), dim3(64), 0, st, d,
                                    width, height, tile_w, n_tiles, n_slices, n_gauss, colors, backgrounds, offsets, n_isects,
                                    blk_rows, wt, gid_s, Tbuf, out);
             GAGS_CHECK_LAUNCH();

@@ -65,7 +65,9 @@ CASES = [
     ("C3 geometry D=256", C3 + (256,), {}),
     ("C5 4M/1080p/D=512 fp32 table", C5 + (512,), {}),
     ("C5 4M/1080p/D=512 fp16 table", C5 + (512,), dict(half=True)),
+    ("C5 4M/1080p/D=512 fp16 table, exact forward (GAGS_FWD_EXACT: halves widened, fp32 matrix instructions: round 5's default)", C5 + (512,), dict(half=True, flags=2048)),
     ("C5 4M/1080p/D=512 fp16 table, 16-bit matrix cores forward too (opt-in)", C5 + (512,), dict(half=True, flags=128)),
+    ("C3 1.5M/1080p/D=512 fp16 table", C3 + (512,), dict(half=True)),
     ("C3 1.5M/1080p/D=512 fp16 table, 16-bit matrix cores forward too (opt-in)", C3 + (512,), dict(half=True, flags=128)),
     ("C3 1.5M/1080p/D=512 fp32 table (the bench line's workload)", C3 + (512,), {}),
     ("C3 1.5M/1080p/D=512 fp32 table, exact forward (GAGS_FWD_EXACT: fp32 matrix instructions, bit-identical to the oracle)", C3 + (512,), dict(flags=2048)),
@@ -76,6 +78,7 @@ CASES = [
     ("C5H 4M/1080p/D=512 fp16 table, SURVEY-literal splats (169 M intersections)", C5 + (512,), dict(half=True, scale0=syn.SCALE0_SURVEY, steps=3)),
     ("C5 4M/1080p/D=513 (512+1) fp32", C5 + (513,), dict(steps=4)),
     ("C5 4M/1080p/D=513 (512+1) fp16 table -- BASELINE.json configs[4] as stated", C5 + (513,), dict(half=True, steps=4)),
+    ("C5 4M/1080p/D=513 (512+1) fp16 table, exact forward (GAGS_FWD_EXACT: round 5's default)", C5 + (513,), dict(half=True, flags=2048, steps=4)),
     ("C5 4M/1080p/D=513 (512+1) fp16 table, 16-bit matrix cores forward too (opt-in)", C5 + (513,), dict(half=True, flags=128, steps=4)),
     ("C3 1.5M/1080p/D=512, ALL gradients (features + means, quats, scales, opacities)", C3 + (512,), dict(full_grad=True)),
     ("C3 ALL gradients, fp32 matrix instructions (rounds 1-2's kernels)", C3 + (512,), dict(full_grad=True, flags=64)),
