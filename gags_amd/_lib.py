@@ -63,6 +63,8 @@ SIGNATURES = {
     "gags_raster_bwd_colors_staged_cap": (_i32, [_i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
                                                  _i64, _vp, _i32, _i32, _i32, _vp, _vp]),
     "gags_raster_bwd_colors_staged_wire": (_i32, [_i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
+                                                  _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "gags_raster_bwd_colors_staged_keep": (_i32, [_i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
                                                   _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "gags_raster_stats": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "gags_project_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp,

@@ -35,7 +35,8 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
                                   const float *v_out, const int32_t *blk_rows, const int32_t *trow, int64_t rows,
                                   const float *wt, const int32_t *gid_s, const int32_t *trow_s, void *scratch,
                                   int64_t scratch_bytes, float *v_colors, int stage, int ch_begin, int ch_count,
-                                  const int32_t *rows_dev, const int32_t *wire_pos, float *wire, hipStream_t st);
+                                  const int32_t *rows_dev, const int32_t *wire_pos, float *wire, const uint8_t *keep_prev,
+                                  uint8_t *keep_cur, hipStream_t st);
 int64_t gags_raster_bwd_geom_scratch_bytes_impl(int64_t n_isects, int width, int height, int n_gauss, int d, int64_t n_rows);
 int gags_raster_bwd_geom_launch(int d, int n_gauss, int width, int height, const float *colors, const float *backgrounds,
                                 const int32_t *offsets, int n_isects, const void *packed, const float *v_out,
@@ -265,7 +266,7 @@ int staged_entry(int d, int n, int width, int height, const int32_t *isect_offse
                  const float *v_render_colors, const int32_t *blk_rows, const int32_t *rowmap, int64_t rows,
                  const void *fwd_scratch, int64_t fwd_scratch_bytes, void *scratch, int64_t scratch_bytes, float *v_colors,
                  int stage, int ch_begin, int ch_count, const int32_t *rows_dev, const int32_t *wire_pos, float *wire,
-                 void *stream)
+                 const uint8_t *keep_prev, uint8_t *keep_cur, void *stream)
 {
     if (d <= 0 || width <= 0 || height <= 0 || n < 0 || !isects_ok(n_isects, width, height) || rows < 0 ||
         rows >= (1ll << 31) || stage < 0 || (stage & 15) > 3)
@@ -279,7 +280,7 @@ int staged_entry(int d, int n, int width, int height, const int32_t *isect_offse
     return gags_raster_bwd_staged_launch(d, width, height, n, isect_offsets, (int)n_isects, v_render_colors, blk_rows,
                                          rowmap, rows, (const float *)(fs + L.wt), (const int32_t *)(fs + L.gid),
                                          rowmap + rowmap_slot_off(n_isects), scratch, scratch_bytes, v_colors, stage,
-                                         ch_begin, ch_count, rows_dev, wire_pos, wire, (hipStream_t)stream);
+                                         ch_begin, ch_count, rows_dev, wire_pos, wire, keep_prev, keep_cur, (hipStream_t)stream);
 }
 }  // namespace
 
@@ -292,7 +293,7 @@ extern "C" int gags_raster_bwd_colors_staged_cap(int d, int n, int width, int he
 {
     return staged_entry(d, n, width, height, isect_offsets, n_isects, v_render_colors, blk_rows, rowmap, rows, fwd_scratch,
                         fwd_scratch_bytes, scratch, scratch_bytes, v_colors, stage, ch_begin, ch_count, rows_dev, nullptr, nullptr,
-                        stream);
+                        nullptr, nullptr, stream);
 }
 
 extern "C" int gags_raster_bwd_colors_staged_wire(int d, int n, int width, int height, const int32_t *isect_offsets,
@@ -300,12 +301,27 @@ extern "C" int gags_raster_bwd_colors_staged_wire(int d, int n, int width, int h
                                                   const int32_t *rowmap, int64_t rows, const void *fwd_scratch,
                                                   int64_t fwd_scratch_bytes, void *scratch, int64_t scratch_bytes,
                                                   float *v_colors, int stage, int ch_begin, int ch_count,
-                                                  const int32_t *wire_pos, float *wire, void *stream)
+                                                  const int32_t *wire_pos, float *wire, const uint8_t *keep_prev,
+                                                  uint8_t *keep_cur, void *stream)
 {
     if ((wire != nullptr) != (wire_pos != nullptr) || (wire && (stage & 64))) return GAGS_EINVAL;  // (the block is fp32)
+    if ((keep_prev != nullptr) != (keep_cur != nullptr) || (keep_cur && (keep_prev == keep_cur || (stage & 128)))) return GAGS_EINVAL;
     return staged_entry(d, n, width, height, isect_offsets, n_isects, v_render_colors, blk_rows, rowmap, rows, fwd_scratch,
                         fwd_scratch_bytes, scratch, scratch_bytes, v_colors, stage, ch_begin, ch_count, nullptr, wire_pos, wire,
-                        stream);
+                        keep_prev, keep_cur, stream);
+}
+
+extern "C" int gags_raster_bwd_colors_staged_keep(int d, int n, int width, int height, const int32_t *isect_offsets,
+                                                  int64_t n_isects, const float *v_render_colors, const int32_t *blk_rows,
+                                                  const int32_t *rowmap, int64_t rows, const void *fwd_scratch,
+                                                  int64_t fwd_scratch_bytes, void *scratch, int64_t scratch_bytes,
+                                                  float *v_colors, int stage, int ch_begin, int ch_count,
+                                                  const uint8_t *keep_prev, uint8_t *keep_cur, void *stream)
+{
+    if (!keep_prev || !keep_cur || keep_prev == keep_cur || (stage & 128)) return GAGS_EINVAL;
+    return staged_entry(d, n, width, height, isect_offsets, n_isects, v_render_colors, blk_rows, rowmap, rows, fwd_scratch,
+                        fwd_scratch_bytes, scratch, scratch_bytes, v_colors, stage, ch_begin, ch_count, nullptr, nullptr, nullptr,
+                        keep_prev, keep_cur, stream);
 }
 
 extern "C" int gags_raster_bwd_colors_staged_range(int d, int n, int width, int height, const int32_t *isect_offsets,

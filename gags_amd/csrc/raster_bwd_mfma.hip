@@ -592,8 +592,14 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(int n_gauss, int d, in
                                                           const int32_t *__restrict__ sorted_rows,
                                                           const float *__restrict__ prow, int prow_pitch,
                                                           void *__restrict__ v_colors_, int sparse,
-                                                          const int32_t *__restrict__ wire_pos, float *__restrict__ wire)
+                                                          const int32_t *__restrict__ wire_pos, float *__restrict__ wire,
+                                                          const uint8_t *__restrict__ keep_prev, uint8_t *__restrict__ keep_cur)
 {
+    // keep (round 6): v_colors is a PERSISTENT buffer of the caller's whose rows are zero except those the previous backward
+    // wrote (keep_prev[g] != 0).  This launch writes the rows that have partial rows now, re-zeroes the rows that had some
+    // last time and have none now, leaves every other row alone -- 73 % of the Gaussians blend nothing at C3: 2.2 GB of zero
+    // rows per step are not written -- and records keep_cur[g] for the next step (two arrays, swapped by the caller: the lanes
+    // of a Gaussian span two waves, a flag cleared in place could be read after it was cleared).
     // wire (by-view multi-GPU step, gags_amd/dist.py): the rows the ranks exchange -- wire_pos[g] >= 0: row wire_pos[g] of the
     // dense [rows, ch_count] fp32 block -- leave from here, next to the gradient itself, instead of being re-read by a pack
     // kernel (a union row this view did not touch gets its zeros here as well: every row of the block is written)
@@ -606,8 +612,16 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(int n_gauss, int d, in
     const int b = seg[g], e = seg[g + 1];
     // sparse: the caller zero-filled v_colors (on a second stream, under the rows kernel): a Gaussian without rows -- 73 % of
     // them at C3 -- costs nothing here instead of a 4 D-byte row of zeros
-    if (sparse && b == e && !(wire && wire_pos[g] >= 0)) return;
-    const bool skip_grad = sparse && b == e;  // (only its wire row is due)
+    const bool has = b != e;
+    bool write_grad = sparse ? has : true;
+    const bool on_wire = wire && wire_pos[g] >= 0;
+    if (keep_cur) {
+        // (a row of the exchanged block will be written by the caller once the ranks' sum is known: it counts as written)
+        if (threadIdx.x % lpg == 0) keep_cur[g] = (has || on_wire) ? 1 : 0;
+        write_grad = has || keep_prev[g] != 0;
+    }
+    if (!write_grad && !on_wire) return;
+    const bool skip_grad = !write_grad;  // (only its wire row is due)
     if constexpr (VW == 1) {
         float acc = 0.f;
         for (int i = b; i < e; ++i) acc += prow[(size_t)sorted_rows[i] * prow_pitch + cl];
@@ -800,7 +814,8 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
                                   const float *v_out, const int32_t *blk_rows, const int32_t *trow, int64_t rows,
                                   const float *wt, const int32_t *gid_s, const int32_t *trow_s, void *scratch,
                                   int64_t scratch_bytes, float *v_colors, int stage_flags, int ch_begin, int ch_count,
-                                  const int32_t *rows_dev, const int32_t *wire_pos, float *wire, hipStream_t st)
+                                  const int32_t *rows_dev, const int32_t *wire_pos, float *wire, const uint8_t *keep_prev,
+                                  uint8_t *keep_cur, hipStream_t st)
 {
     // stage: 0 = everything; 1 = rows, 2 = sort + segment offsets, 3 = reduce (per-kernel timing)
     GAGS_CLEAR_ERR();
@@ -871,14 +886,14 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
         if (c4 > 0) {
             const int gpb = 256 / (c4 >> 2);
             const dim3 grid((n_gauss + gpb - 1) / gpb);
-            if (half) hipLaunchKernelGGL((reduce_rows_kernel<true, 4>), grid, dim3(256), 0, st, n_gauss, d, ch_begin, c4, seg, idx_s, prow, pp, (void *)v_colors, sparse, wire_pos, wire);
-            else hipLaunchKernelGGL((reduce_rows_kernel<false, 4>), grid, dim3(256), 0, st, n_gauss, d, ch_begin, c4, seg, idx_s, prow, pp, (void *)v_colors, sparse, wire_pos, wire);
+            if (half) hipLaunchKernelGGL((reduce_rows_kernel<true, 4>), grid, dim3(256), 0, st, n_gauss, d, ch_begin, c4, seg, idx_s, prow, pp, (void *)v_colors, sparse, wire_pos, wire, keep_prev, keep_cur);
+            else hipLaunchKernelGGL((reduce_rows_kernel<false, 4>), grid, dim3(256), 0, st, n_gauss, d, ch_begin, c4, seg, idx_s, prow, pp, (void *)v_colors, sparse, wire_pos, wire, keep_prev, keep_cur);
         }
         if (c1 > 0) {
             const int gpb = 256 / c1;
             const dim3 grid((n_gauss + gpb - 1) / gpb);
-            if (half) hipLaunchKernelGGL((reduce_rows_kernel<true, 1>), grid, dim3(256), 0, st, n_gauss, d, ch_begin + c4, c1, seg, idx_s, prow, pp, (void *)v_colors, sparse, wire_pos, wire);
-            else hipLaunchKernelGGL((reduce_rows_kernel<false, 1>), grid, dim3(256), 0, st, n_gauss, d, ch_begin + c4, c1, seg, idx_s, prow, pp, (void *)v_colors, sparse, wire_pos, wire);
+            if (half) hipLaunchKernelGGL((reduce_rows_kernel<true, 1>), grid, dim3(256), 0, st, n_gauss, d, ch_begin + c4, c1, seg, idx_s, prow, pp, (void *)v_colors, sparse, wire_pos, wire, keep_prev, keep_cur);
+            else hipLaunchKernelGGL((reduce_rows_kernel<false, 1>), grid, dim3(256), 0, st, n_gauss, d, ch_begin + c4, c1, seg, idx_s, prow, pp, (void *)v_colors, sparse, wire_pos, wire, keep_prev, keep_cur);
         }
     }
     GAGS_CHECK_LAUNCH();
@@ -1568,7 +1583,7 @@ int gags_raster_bwd_geom_launch(int d, int n_gauss, int width, int height, const
         hipLaunchKernelGGL(seg_fill_kernel, dim3((n_gauss + 1 + 255) / 256), dim3(256), 0, st, n_gauss, seg);
     }
     hipLaunchKernelGGL((reduce_rows_kernel<false, 4>), dim3((n_gauss + 127) / 128), dim3(256), 0, st, n_gauss, 8, 0, 8, seg, idx_s, grow, 8,
-                       (void *)v_geo, 0, (const int32_t *)nullptr, (float *)nullptr);
+                       (void *)v_geo, 0, (const int32_t *)nullptr, (float *)nullptr, (const uint8_t *)nullptr, (uint8_t *)nullptr);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }

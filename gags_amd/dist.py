@@ -470,6 +470,8 @@ class OverlappedGradReducer:
         if used and self._resolve_count():
             # sync_free: this step's union outgrew the remembered capacity; the surplus rows were never packed.  Same
             # decision on every rank (the union is identical): exchange every range again with all N rows, here
+            # (the sum now lands in rows the backward's persistent-buffer flags do not cover: that buffer is not kept)
+            getattr(self._ctx, "forget_all_kept", lambda: None)()
             for e in self._entries:
                 wire = _pack_rows(self._alias, None, e["c0"], e["c1"], e["wire"].dtype)
                 e.update(idx=None, local=wire, wire=self._collective(wire))

@@ -36,6 +36,10 @@ CAP_MARGIN = 1.05
 GRAD_RANGE_CHANNELS = 128
 GRAD_ROWS_GROUP = 256  # channels per launch of the rows kernel under the range-staged backward (whole ranges; see _backward_staged)
 PROW_MAX_BYTES = 24 << 30  # staged backward: partial rows beyond this are produced per 128-channel range (see _backward_staged)
+# Persistent gradient buffer of the colours-only backward (_KeptGrad): default ON
+KEEP_GRAD = os.environ.get("GAGS_KEEP_GRAD", "1") != "0"
+KEEP_GRAD_MIN_ELEMS = 0   # (every shape: the small test scenes exercise the same path as C3)
+KEEP_GRAD_SHAPES = 2      # buffers a context keeps alive at once (least recently used shape is dropped)
 # Default of RasterContext.capacity_mode (GAGS_CAPACITY_MODE=1; OFF otherwise): see RasterContext.
 CAPACITY_MODE = os.environ.get("GAGS_CAPACITY_MODE", "0") == "1"
 
@@ -93,6 +97,38 @@ class RasterContext:
         self.k_cache = {}
         self._pinned = {}
         self._side = {}
+        # persistent gradient buffer of the colours-only backward (_KeptGrad): on unless GAGS_KEEP_GRAD=0
+        self.keep_grad_buffer = KEEP_GRAD
+        self._kept = {}        # (n, d, dtype, device) -> _KeptGrad, at most KEEP_GRAD_SHAPES shapes (least recently used out)
+        self._kept_fails = {}  # consecutive steps that found the buffer still referenced / written
+
+    def forget_kept(self, n, d, dtype, dev):
+        self._kept.pop((n, d, dtype, dev.index), None)
+
+    def forget_all_kept(self):
+        self._kept.clear()
+
+    def kept_grad(self, n, d, dtype, dev):
+        """(alias, flags_prev, flags_cur) of this shape's persistent gradient buffer, or None when it is not to be used."""
+        if not self.keep_grad_buffer or n * d < KEEP_GRAD_MIN_ELEMS:
+            return None
+        key = (n, d, dtype, dev.index)
+        if self._kept_fails.get(key, 0) >= 3:
+            return None
+        ent = self._kept.pop(key, None)
+        if ent is not None and not ent.untouched():
+            self._kept_fails[key] = self._kept_fails.get(key, 0) + 1  # the holder keeps that storage; a new one below
+            ent = None
+            if self._kept_fails[key] >= 3:
+                return None
+        elif ent is not None:
+            self._kept_fails[key] = 0
+        if ent is None:
+            ent = _KeptGrad(n, d, dtype, dev)
+        self._kept[key] = ent  # (re-inserted last: most recently used)
+        while len(self._kept) > KEEP_GRAD_SHAPES:
+            self._kept.pop(next(iter(self._kept)))
+        return ent.hand_out()
 
     def side_stream(self, dev):
         key = dev.index if dev.index is not None else torch.cuda.current_device()
@@ -116,6 +152,38 @@ def default_context():
     if ctx is None:
         ctx = _TLS.ctx = RasterContext()
     return ctx
+
+
+def _storage_refs(t):
+    return torch._C._storage_Use_Count(t.untyped_storage()._cdata)
+
+
+class _KeptGrad:
+    """The persistent gradient buffer of the colours-only backward (RasterContext.keep_grad_buffer).  d loss / d colors is a
+    dense [N, D] tensor of which 73 % of the rows are zero at C3 (Gaussians that blend nothing); written afresh every step
+    those zeros are 2.2 GB of HBM writes.  Here the context keeps ONE zero-initialised buffer per (N, D, dtype), every
+    backward hands autograd a fresh alias of it (own TensorImpl, same storage: autograd adopts it without a copy) and the
+    reduce stage only writes the rows that have partial rows now and re-zeroes the rows that had some in the previous step
+    (two flag arrays, gags_raster_bwd_colors_staged_keep).  The buffer is only reused when NOBODY else still refers to its
+    storage (reference count back at its baseline: the previous step's .grad was released, e.g. zero_grad(set_to_none=True)
+    or `.grad = None`) and nobody wrote to it in place through torch (version counter unchanged; the kernels write through raw
+    pointers and never bump it).  Otherwise the holder keeps the old storage and this step runs on a new buffer; after three
+    such steps in a row the mechanism switches itself off for the shape (a loop that accumulates into a live .grad)."""
+
+    def __init__(self, n, d, dtype, dev):
+        self.buf = torch.zeros(n, d, dtype=dtype, device=dev)
+        self.flags = torch.zeros(2, max(n, 1), dtype=torch.uint8, device=dev)
+        self.cur = 0
+        self.base = _storage_refs(self.buf)
+        self.version = self.buf._version
+
+    def untouched(self):
+        return _storage_refs(self.buf) <= self.base and self.buf._version == self.version
+
+    def hand_out(self):
+        prev, cur = self.flags[self.cur], self.flags[1 - self.cur]
+        self.cur ^= 1
+        return self.buf.detach(), prev, cur
 
 
 class _DeferredCount:
@@ -599,15 +667,33 @@ def _backward_staged(lib, rctx, offsets, n_isects, blk_rows, fwd_scratch, v_out,
     narrow = (hook is None and pending is None and d % 128 == 0 and d > 128 and rows * d * 4 > PROW_MAX_BYTES)
     nbytes = lib.gags_bwd_staged_scratch_bytes(rows, n, 128 if narrow else d)
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    v_colors = torch.empty(n, d, device=dev, dtype=torch.float16 if (xflag & 64) else torch.float32)
+    v_dtype = torch.float16 if (xflag & 64) else torch.float32
+    # the persistent buffer (rows of Gaussians that blend nothing are never written again): not under the exchange hooks (the
+    # ranks' sum lands in rows this view did not write), the capacity mode or the zero-fill experiment
+    # ... under the exchange hooks only when the reduce stage writes the exchanged block itself: its rows -- where finish()
+    # writes the ranks' sum -- then count as written (gags_raster_bwd_colors_staged_wire)
+    wire_hook = rctx.grad_wire_hook if (hook is not None and ranges is not None and not (xflag & 64)) else None
+    kept = None
+    if pending is None and prezero is None and (hook is None or (wire_hook is not None and rctx.grad_rows_hook is not None)):
+        kept = rctx.kept_grad(n, d, v_dtype, dev)
+    v_colors = kept[0] if kept is not None else torch.empty(n, d, device=dev, dtype=v_dtype)
     rows_dev = ptr(total) if pending is not None else None
 
+    def keep_or_range(stage, c0, cw):
+        """One staged call for channels [c0, c0 + cw): through the persistent buffer's entry when the call holds the reduce stage."""
+        if kept is not None and (stage & 15) in (0, 3):
+            check(lib.gags_raster_bwd_colors_staged_keep(
+                d, n, width, height, ptr(offsets), n_isects, ptr(v_out), ptr(blk_rows), ptr(trow), rows, ptr(fwd_scratch),
+                fwd_scratch.numel(), ptr(scratch), nbytes, ptr(v_colors), stage, c0, cw, ptr(kept[1]), ptr(kept[2]), st),
+                "gags_raster_bwd_colors_staged_keep")
+        else:
+            check(lib.gags_raster_bwd_colors_staged_cap(
+                d, n, width, height, ptr(offsets), n_isects, ptr(v_out), ptr(blk_rows), ptr(trow), rows, ptr(fwd_scratch),
+                fwd_scratch.numel(), ptr(scratch), nbytes, ptr(v_colors), stage, c0, cw, rows_dev, st),
+                "gags_raster_bwd_colors_staged_cap")
+
     def run(stage):
-        stage |= xflag
-        check(lib.gags_raster_bwd_colors_staged_cap(d, n, width, height, ptr(offsets), n_isects, ptr(v_out), ptr(blk_rows),
-                                                    ptr(trow), rows, ptr(fwd_scratch), fwd_scratch.numel(),
-                                                    ptr(scratch), nbytes, ptr(v_colors), stage, 0, d, rows_dev, st),
-              "gags_raster_bwd_colors_staged_cap")
+        keep_or_range(stage | xflag, 0, d)
 
     if prezero is not None and hook is None:
         # the forward started a zero-fill of this tensor on a second stream while the binning kernels (small, latency-bound:
@@ -623,13 +709,9 @@ def _backward_staged(lib, rctx, offsets, n_isects, blk_rows, fwd_scratch, v_out,
         for c0 in range(0, d, 128):
             for stage in ((1, 2, 3) if c0 == 0 else (1, 3)):
                 with profiler.stage(("bwd_rows", "bwd_sort", "bwd_reduce")[stage - 1]):
-                    check(lib.gags_raster_bwd_colors_staged_range(
-                        d, n, width, height, ptr(offsets), n_isects, ptr(v_out), ptr(blk_rows), ptr(trow), rows,
-                        ptr(fwd_scratch), fwd_scratch.numel(), ptr(scratch), nbytes, ptr(v_colors), stage | xflag | 256, c0,
-                        128, st), "gags_raster_bwd_colors_staged_range")
+                    keep_or_range(stage | xflag | 256, c0, 128)
     elif hook is not None and ranges is not None:
         alias = v_colors.detach()  # own TensorImpl, same storage: autograd may still adopt v_colors without a copy
-        wire_hook = rctx.grad_wire_hook if not (xflag & 64) else None  # (the exchanged block is fp32)
         # the partial rows are produced for `grad_rows_group` channels per launch (two ranges by default): every rows launch
         # streams the view's weight tiles from HBM once for all of its 128-channel slices (they share them through L2), so a
         # launch per 128-channel range read them four times -- most of what the range-staged backward cost on one GPU -- while
@@ -650,11 +732,17 @@ def _backward_staged(lib, rctx, offsets, n_isects, blk_rows, fwd_scratch, v_out,
                 rows_done = g1
             # the rows the ranks exchange leave from the reduce kernel itself (no pack pass over the range afterwards)
             w = wire_hook(c0, c1) if wire_hook is not None else None
+            if w is None and kept is not None:
+                # the exchange packs for itself after all (bf16 wire, all rows): its sum may land in rows the flags do not
+                # cover.  This step's reduce writes every row; the buffer is not kept
+                rctx.forget_kept(n, d, v_dtype, dev)
+                kept = None
             with profiler.stage("bwd_reduce"):
                 check(lib.gags_raster_bwd_colors_staged_wire(
                     d, n, width, height, ptr(offsets), n_isects, ptr(v_out), ptr(blk_rows), ptr(trow), rows,
                     ptr(fwd_scratch), fwd_scratch.numel(), ptr(scratch), nbytes, ptr(v_colors), 3 | xflag, c0, c1 - c0,
-                    ptr(w[0]) if w else None, ptr(w[1]) if w else None, st), "gags_raster_bwd_colors_staged_wire")
+                    ptr(w[0]) if w else None, ptr(w[1]) if w else None, ptr(kept[1]) if kept else None,
+                    ptr(kept[2]) if kept else None, st), "gags_raster_bwd_colors_staged_wire")
             if w is not None:
                 hook(alias, c0, c1, w[1])
             else:

@@ -283,12 +283,28 @@ int gags_raster_bwd_colors_staged_cap(int d, int n, int width, int height, const
  * (gags_amd/dist.py): wire[wire_pos[g], :] = the range's gradient row of Gaussian g for every g with
  * wire_pos[g] >= 0 -- wire is a dense fp32 [union rows, ch_count] block (ch_count % 4 == 0), wire_pos the inverse of the
  * union's row list (gags_compact_mask_pos).  Every row of the block is written (a union row this view did not touch gets
- * zeros), so the block needs no clearing and no pack kernel re-reads the gradient.  v_colors is written as always. */
+ * zeros), so the block needs no clearing and no pack kernel re-reads the gradient.  v_colors is written as always -- or,
+ * with keep_prev / keep_cur (both or neither; see gags_raster_bwd_colors_staged_keep below), as a persistent buffer whose
+ * rows count as written when they have partial rows OR lie in the exchanged block (the caller writes the ranks' sum there). */
 int gags_raster_bwd_colors_staged_wire(int d, int n, int width, int height, const int32_t *isect_offsets, int64_t n_isects,
                                        const float *v_render_colors, const int32_t *blk_rows, const int32_t *rowmap,
                                        int64_t rows, const void *fwd_scratch, int64_t fwd_scratch_bytes, void *scratch,
                                        int64_t scratch_bytes, float *v_colors, int stage, int ch_begin, int ch_count,
-                                       const int32_t *wire_pos, float *wire, void *stream);
+                                       const int32_t *wire_pos, float *wire, const uint8_t *keep_prev, uint8_t *keep_cur,
+                                       void *stream);
+
+/* gags_raster_bwd_colors_staged_range into a PERSISTENT gradient buffer (round 6): v_colors is a buffer the caller keeps
+ * between steps, all zeros except the rows the previous call wrote -- keep_prev[g] != 0 (n bytes; all zeros for a freshly
+ * zeroed buffer).  The reduce stage writes the rows that have partial rows now, re-zeroes the rows that had some last time
+ * and none now, touches nothing else (the rows of Gaussians that blend nothing -- 73 % at C3, 2.2 GB of zeros per step --
+ * are never written again), and leaves keep_cur[g] (n bytes, another array) for the next call.  Same values as the plain
+ * entry, bit for bit.  The caller must know that nobody else wrote the buffer in between (gags_amd/rasterization.py checks
+ * the storage's reference count and version counter and falls back to the plain entry otherwise). */
+int gags_raster_bwd_colors_staged_keep(int d, int n, int width, int height, const int32_t *isect_offsets, int64_t n_isects,
+                                       const float *v_render_colors, const int32_t *blk_rows, const int32_t *rowmap,
+                                       int64_t rows, const void *fwd_scratch, int64_t fwd_scratch_bytes, void *scratch,
+                                       int64_t scratch_bytes, float *v_colors, int stage, int ch_begin, int ch_count,
+                                       const uint8_t *keep_prev, uint8_t *keep_cur, void *stream);
 
 /* Diagnostics (roofline model): counts[0] += (pixel,Gaussian) pairs evaluated
  * before each pixel's stop, counts[1] += pairs blended.  counts[2] int64, zeroed by caller. */
