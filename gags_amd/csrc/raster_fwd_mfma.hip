@@ -418,37 +418,17 @@ __global__ __launch_bounds__(64, 2) void raster_fwd_feat_f16(
 // One wave per (tile, 8x8 block, 128-channel slice), K-steps of 16 slots: lane (p, kg) holds, as A operand, the weights of
 // pixel p (upper / lower half of the block) for slots 8 kg .. 8 kg + 7 of the step, and as B operand channel 4 p + j of
 // the same eight slots (tile j = channels ch0 + 4 n + j: the strided tiles of the fp32 kernel, same float4 epilogue).
-// The split is done in registers on the way (11 VALU instructions per pair of values and three terms: 264 per step), then the
-// next step's rows are requested into the registers the split has freed, then the 48 MFMAs run (four accumulators in
+// The split is done in registers on the way (per four values 8 v_and + 4 packed fp32 subtractions + 6 v_perm: 216 per step;
+// rounds 5's scalar subtractions: 264), then the next step's rows are requested into the registers the split has freed, then the 48 MFMAs run (four accumulators in
 // rotation).  The ids of a step's slots arrive as ONE vector load (each 16-lane row holds its half-wave's eight ids) and
 // reach the address arithmetic through DPP row broadcasts: one VALU instruction per gathered row.
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ void split3_pair(float x, float y, unsigned &t0, unsigned &t1, unsigned &t2)
-{
-    // {bf16 term of x | bf16 term of y << 16}: v_perm_b32 picks bytes 2, 3 of both
-    const unsigned ux = __float_as_uint(x), uy = __float_as_uint(y);
-    t0 = __builtin_amdgcn_perm(uy, ux, 0x07060302u);
-    const float rx = x - __uint_as_float(ux & 0xffff0000u), ry = y - __uint_as_float(uy & 0xffff0000u);
-    const unsigned vx = __float_as_uint(rx), vy = __float_as_uint(ry);
-    t1 = __builtin_amdgcn_perm(vy, vx, 0x07060302u);
-    const float qx = rx - __uint_as_float(vx & 0xffff0000u), qy = ry - __uint_as_float(vy & 0xffff0000u);
-    t2 = __builtin_amdgcn_perm(__float_as_uint(qy), __float_as_uint(qx), 0x07060302u);
-}
+typedef float f32x2s __attribute__((ext_vector_type(2)));
 
 struct Op3 {  // the three bf16 terms of one MFMA operand (8 K elements per lane)
     bf16x8 t[3];
 };
-
-__device__ __forceinline__ Op3 split_op(const float (&v)[8])
-{
-    union { bf16x8 v; unsigned u[4]; } o[3];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) split3_pair(v[2 * q], v[2 * q + 1], o[0].u[q], o[1].u[q], o[2].u[q]);
-    Op3 r;
-    r.t[0] = o[0].v; r.t[1] = o[1].v; r.t[2] = o[2].v;
-    return r;
-}
 
 __device__ __forceinline__ void mfma6(f32x16 &acc, const Op3 &a, const Op3 &b)
 {
@@ -468,24 +448,6 @@ struct Op2 {
     bf16x8 t[2];
 };
 
-__device__ __forceinline__ void split2_pair(float x, float y, unsigned &t0, unsigned &t1)
-{
-    const unsigned ux = __float_as_uint(x), uy = __float_as_uint(y);
-    t0 = __builtin_amdgcn_perm(uy, ux, 0x07060302u);
-    const float rx = x - __uint_as_float(ux & 0xffff0000u), ry = y - __uint_as_float(uy & 0xffff0000u);  // <= 3 bits left: a bf16
-    t1 = __builtin_amdgcn_perm(__float_as_uint(ry), __float_as_uint(rx), 0x07060302u);
-}
-
-__device__ __forceinline__ Op2 split_op_h(const float (&v)[8])
-{
-    union { bf16x8 v; unsigned u[4]; } o[2];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) split2_pair(v[2 * q], v[2 * q + 1], o[0].u[q], o[1].u[q]);
-    Op2 r;
-    r.t[0] = o[0].v; r.t[1] = o[1].v;
-    return r;
-}
-
 __device__ __forceinline__ void mfma5(f32x16 &acc, const Op3 &a, const Op2 &b)
 {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[2], b.t[0], acc, 0, 0, 0);  // smallest terms first
@@ -494,6 +456,34 @@ __device__ __forceinline__ void mfma5(f32x16 &acc, const Op3 &a, const Op2 &b)
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[0], b.t[1], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.t[0], b.t[0], acc, 0, 0, 0);
 }
+
+// The splits as the K loop issues them (round 6): the residuals of TWO values that sit in adjacent registers -- the (upper,
+// lower) weight pair of a slot, two neighbouring channels of a gathered row -- are formed by one packed fp32 subtraction
+// (v_pk_add_f32), and the bf16 terms of two consecutive SLOTS are packed afterwards: per four values 8 v_and + 4 v_pk_add +
+// 6 v_perm instead of 8 + 8 + 6 (the kernel is bound by its issue slots: 264 -> 216 split instructions per 16-slot step).
+__device__ __forceinline__ f32x2s trunc16(f32x2s v)
+{
+    return f32x2s{__uint_as_float(__float_as_uint(v[0]) & 0xffff0000u), __uint_as_float(__float_as_uint(v[1]) & 0xffff0000u)};
+}
+struct Res3 {  // a pair of values and what the first / the first two bf16 terms leave over
+    f32x2s v, r1, r2;
+};
+__device__ __forceinline__ Res3 res3(float a, float b)
+{
+    Res3 o;
+    o.v = f32x2s{a, b};
+    o.r1 = o.v - trunc16(o.v);
+    o.r2 = o.r1 - trunc16(o.r1);
+    return o;
+}
+__device__ __forceinline__ unsigned pack_hi(float a, float b)  // {top 16 bits of a | top 16 bits of b << 16}
+{
+    return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+union OpU {
+    bf16x8 v;
+    unsigned u[4];
+};
 
 __device__ __forceinline__ float half_lo(unsigned u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu)); }
 __device__ __forceinline__ float half_hi(unsigned u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16)); }
@@ -594,43 +584,48 @@ __global__ __launch_bounds__(64, 2) void raster_fwd_feat_x16(
             // A operands: the weights of the lane's pixel pair for its eight slots
             Op3 aA, aB;
             {
-                float wa[8], wb[8];
+                OpU oa[3], ob[3];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { wa[i] = W[i].x; wb[i] = W[i].y; }
-                aA = split_op(wa);
-                aB = split_op(wb);
+                for (int q = 0; q < 4; ++q) {
+                    const Res3 e = res3(W[2 * q].x, W[2 * q].y), o = res3(W[2 * q + 1].x, W[2 * q + 1].y);  // (upper, lower) of two slots
+                    oa[0].u[q] = pack_hi(e.v[0], o.v[0]); oa[1].u[q] = pack_hi(e.r1[0], o.r1[0]); oa[2].u[q] = pack_hi(e.r2[0], o.r2[0]);
+                    ob[0].u[q] = pack_hi(e.v[1], o.v[1]); ob[1].u[q] = pack_hi(e.r1[1], o.r1[1]); ob[2].u[q] = pack_hi(e.r2[1], o.r2[1]);
+                }
+#pragma unroll
+                for (int t = 0; t < 3; ++t) { aA.t[t] = oa[t].v; aB.t[t] = ob[t].v; }
             }
             // B operands of the four channel tiles; then the rows' registers are free for the next step's
             using OpB = typename std::conditional<HALF, Op2, Op3>::type;
             OpB b[NB];
             {
-                float x[8];
                 if constexpr (HALF) {
+                    OpU o[NB][2];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) x[i] = half_lo(F[i].x);
-                    b[0] = split_op_h(x);
+                    for (int q = 0; q < 4; ++q) {
+                        // channels (0, 1) and (2, 3) of slots 2 q and 2 q + 1; a half leaves at most 3 bits behind its first term
+                        const f32x2s e01 = {half_lo(F[2 * q].x), half_hi(F[2 * q].x)}, e23 = {half_lo(F[2 * q].y), half_hi(F[2 * q].y)};
+                        const f32x2s o01 = {half_lo(F[2 * q + 1].x), half_hi(F[2 * q + 1].x)}, o23 = {half_lo(F[2 * q + 1].y), half_hi(F[2 * q + 1].y)};
+                        const f32x2s re01 = e01 - trunc16(e01), re23 = e23 - trunc16(e23), ro01 = o01 - trunc16(o01), ro23 = o23 - trunc16(o23);
+                        o[0][0].u[q] = pack_hi(e01[0], o01[0]); o[0][1].u[q] = pack_hi(re01[0], ro01[0]);
+                        o[1][0].u[q] = pack_hi(e01[1], o01[1]); o[1][1].u[q] = pack_hi(re01[1], ro01[1]);
+                        o[2][0].u[q] = pack_hi(e23[0], o23[0]); o[2][1].u[q] = pack_hi(re23[0], ro23[0]);
+                        o[3][0].u[q] = pack_hi(e23[1], o23[1]); o[3][1].u[q] = pack_hi(re23[1], ro23[1]);
+                    }
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) x[i] = half_hi(F[i].x);
-                    b[1] = split_op_h(x);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) x[i] = half_lo(F[i].y);
-                    b[2] = split_op_h(x);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) x[i] = half_hi(F[i].y);
-                    b[3] = split_op_h(x);
+                    for (int j = 0; j < NB; ++j) { b[j].t[0] = o[j][0].v; b[j].t[1] = o[j][1].v; }
                 } else {
+                    OpU o[NB][3];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) x[i] = F[i].x;
-                    b[0] = split_op(x);
+                    for (int q = 0; q < 4; ++q) {
+                        const Res3 e01 = res3(F[2 * q].x, F[2 * q].y), e23 = res3(F[2 * q].z, F[2 * q].w);
+                        const Res3 o01 = res3(F[2 * q + 1].x, F[2 * q + 1].y), o23 = res3(F[2 * q + 1].z, F[2 * q + 1].w);
+                        o[0][0].u[q] = pack_hi(e01.v[0], o01.v[0]); o[0][1].u[q] = pack_hi(e01.r1[0], o01.r1[0]); o[0][2].u[q] = pack_hi(e01.r2[0], o01.r2[0]);
+                        o[1][0].u[q] = pack_hi(e01.v[1], o01.v[1]); o[1][1].u[q] = pack_hi(e01.r1[1], o01.r1[1]); o[1][2].u[q] = pack_hi(e01.r2[1], o01.r2[1]);
+                        o[2][0].u[q] = pack_hi(e23.v[0], o23.v[0]); o[2][1].u[q] = pack_hi(e23.r1[0], o23.r1[0]); o[2][2].u[q] = pack_hi(e23.r2[0], o23.r2[0]);
+                        o[3][0].u[q] = pack_hi(e23.v[1], o23.v[1]); o[3][1].u[q] = pack_hi(e23.r1[1], o23.r1[1]); o[3][2].u[q] = pack_hi(e23.r2[1], o23.r2[1]);
+                    }
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) x[i] = F[i].y;
-                    b[1] = split_op(x);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) x[i] = F[i].z;
-                    b[2] = split_op(x);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) x[i] = F[i].w;
-                    b[3] = split_op(x);
+                    for (int j = 0; j < NB; ++j) { b[j].t[0] = o[j][0].v; b[j].t[1] = o[j][1].v; b[j].t[2] = o[j][2].v; }
                 }
             }
             auto mm = [&](f32x16 &acc, const Op3 &a, const OpB &bb) __attribute__((always_inline)) {
