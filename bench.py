@@ -522,10 +522,14 @@ def main():
         # launch stream; algorithmic work per launch:
         #   raster_fwd  : 14*Q_eval + 2*D*Q_blend flops              (weights + feature passes; fp32 MFMA bound)
         #   bwd_rows    : 2*D*Q_blend flops                           (weight tile, MFMA, row stores)
-        #   bwd_reduce  : (V + N)*D*4 bytes: every visible Gaussian's gradient read at least once + written
-        #                 (HBM bound; the kernel actually reads one row per touched (tile, Gaussian))
+        #   bwd_reduce  : 2*B*D*4 bytes, B = Gaussians that blended anything: each one's gradient row formed from at least one
+        #                 partial row and written once (HBM bound; the kernel actually reads one row per touched (tile,
+        #                 Gaussian) -- 4.7 per blended Gaussian at C3 -- and, since round 6's persistent gradient buffer, no
+        #                 longer writes the zero rows of the other N - B Gaussians)
         #   raster_bwd  : 14*Q_eval + 2*D*Q_blend flops              (single-kernel atomic backward, if used)
         rows = profiler.notes().get("bwd_rows", 0)
+        g_last = pc._semantic_feature.grad
+        n_blended = int((g_last != 0).any(dim=1).sum().item()) if g_last is not None else 0  # rows of the gradient that are not zero
         blk = profiler.notes().get("fwd_blk_rows")
         slots = int(blk.sum().item()) if blk is not None else 0  # (block, Gaussian) pairs that blended: one weight row each
         dl = d_local  # feature width of one launch on this rank (D, or the rank's channel shard)
@@ -538,7 +542,7 @@ def main():
             "raster_weights": ("hbm", 40.0 * n_isects + 264.0 * slots + 12.0 * pix),
             "raster_fwd_feat": ("mfma", 2.0 * dl * q_blend),
             "bwd_rows": ("mfma", 2.0 * dl * q_blend),
-            "bwd_reduce": ("hbm", 4.0 * dl * (n_visible + n)),
+            "bwd_reduce": ("hbm", 8.0 * dl * n_blended),
             "raster_bwd": ("mfma", 14.0 * q_eval + 2.0 * dl * q_blend),
         }
         kernels = {}
@@ -606,7 +610,7 @@ def main():
                                                                           "the literal 0.004 constant is reported as heavy_workload"),
                        "isects_per_visible": n_isects / max(n_visible, 1),
                        "visible": n_visible, "n_isects": n_isects, "pairs_evaluated": q_eval,
-                       "pairs_blended": q_blend, "bwd_rows": rows,
+                       "pairs_blended": q_blend, "bwd_rows": rows, "gaussians_blended": n_blended,
                        "parallelism": (f"channel-shard{world} (no data-path collective)" if mode == "channel"
                                        else f"view-dp{world}" + ((" + RCCL all-reduce of the feature gradient" if args.grad_reduce == "allreduce"
                                                                   else " + RCCL reduce-scatter/all-gather of the feature gradient")
@@ -746,12 +750,30 @@ def main():
                 step()
             torch.cuda.synchronize()
             pdt = 1e3 * (time.perf_counter() - t0) / vsteps
+            # the same with the rows kernel launched per 256 channels (fewer re-reads of the weight tiles: cheaper on one GPU,
+            # but the first range -- and with it the first exchange -- is ready 0.6 ms later: DESIGN.md section 6)
+            from gags_amd.rasterization import default_context
+            g0 = default_context().grad_rows_group
+            default_context().grad_rows_group = 256
+            for _ in range(2):
+                dp_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(vsteps):
+                dp_step()
+            torch.cuda.synchronize()
+            vdt256 = 1e3 * (time.perf_counter() - t0) / vsteps
+            exposed256 = red.exposed_ms()
+            default_context().grad_rows_group = g0
+            dp_step()
+            torch.cuda.synchronize()
             line["view_dp_overhead_ms"] = {
                 "note": "by-view step as rank 0 of 8 runs it, loop-back exchange (two device copies per 128-channel block instead of "
-                        "the collective, out of place): range-staged backward (rows per 256 channels, reduce + exchange per 128) + "
+                        "the collective, out of place): range-staged backward (rows, reduce + exchange per 128 channels) + "
                         "gags_blended_mask + gags_compact_mask_pos + the reduce stage writing the union block itself + unpack, "
                         "overlapped with the backward on a second stream; xGMI wire time not included",
                 "plain_step_ms": pdt, "view_dp_step_ms": vdt, "overhead_ms": vdt - pdt, "union_rows": red.rows_exchanged,
+                "rows_per_256_channels": {"view_dp_step_ms": vdt256, "overhead_ms": vdt256 - pdt, "exposed_ms_last_step": exposed256},
                 "exposed_ms_last_step": red.exposed_ms(), "range_exchange_ms_last_step": red.range_ms, "steps": vsteps}
             del red, G_dp
         if world == 1 and args.config == "C3" and not (args.no_heavy or args.n or args.d):

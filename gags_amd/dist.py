@@ -461,7 +461,6 @@ class OverlappedGradReducer:
         if cuda:
             self._bwd_done = torch.cuda.Event(enable_timing=True)
             self._bwd_done.record()
-            torch.cuda.current_stream().wait_stream(self.comm)
         ws = self._world()
         used = ws > 1 and bool(self._entries) and self._covered == param_grad.shape[1]
         if self._entries and not used:
@@ -472,7 +471,10 @@ class OverlappedGradReducer:
             # decision on every rank (the union is identical): exchange every range again with all N rows, here
             # (the sum now lands in rows the backward's persistent-buffer flags do not cover: that buffer is not kept)
             getattr(self._ctx, "forget_all_kept", lambda: None)()
+            if cuda:
+                torch.cuda.current_stream().wait_stream(self.comm)
             for e in self._entries:
+                e.pop("ev", None)
                 wire = _pack_rows(self._alias, None, e["c0"], e["c1"], e["wire"].dtype)
                 e.update(idx=None, local=wire, wire=self._collective(wire))
             self.rows_exchanged = None  # (all N rows went over the wire in the end)
@@ -485,14 +487,24 @@ class OverlappedGradReducer:
             self.assigned = bool(adopted)
             for e in self._entries:
                 assign = adopted
+                # range by range: the compute stream waits for THIS range's exchange only, so the sums of the early ranges are
+                # written while the later ranges are still on the wire -- what stays exposed after the last exchange is one
+                # range's unpack, not four
+                if cuda and "ev" in e:
+                    torch.cuda.current_stream().wait_event(e["ev"][1])
+                elif cuda:
+                    torch.cuda.current_stream().wait_stream(self.comm)
                 _unpack_rows(param_grad, e["idx"], e["c0"], e["c1"], e["wire"], None if assign else e["local"])
                 if cuda:
                     e["wire"].record_stream(torch.cuda.current_stream())
                     if e["local"] is not None:
                         e["local"].record_stream(torch.cuda.current_stream())
         elif ws > 1 and not self.loopback:
+            if cuda:
+                torch.cuda.current_stream().wait_stream(self.comm)
             reduce_feature_grad(param_grad, mode=self.mode, bucket_bytes=self.bucket_bytes)
         if cuda:
+            torch.cuda.current_stream().wait_stream(self.comm)
             self._all_done = torch.cuda.Event(enable_timing=True)
             self._all_done.record()
         self._timed = [e["ev"] for e in self._entries if "ev" in e]

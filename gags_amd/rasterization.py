@@ -34,7 +34,11 @@ CAP_MARGIN = 1.05
 # Channel ranges of the range-staged backward of a by-view multi-GPU step (RasterContext.grad_range_channels): an int (uniform
 # ranges) or a tuple of widths (multiples of 128) applied in order, the last one repeated / cut to cover D.
 GRAD_RANGE_CHANNELS = 128
-GRAD_ROWS_GROUP = 256  # channels per launch of the rows kernel under the range-staged backward (whole ranges; see _backward_staged)
+# Channels per launch of the rows kernel under the range-staged backward (whole ranges; see _backward_staged).  256 costs 0.15-
+# 0.3 ms less on ONE GPU (the weight tiles travel from HBM twice instead of four times) but delivers the first range 0.6 ms
+# later; with ~1 ms of xGMI time per 128-channel range the exchange, not the GPU, paces the step at N = 8, and it is kept busy
+# earliest by one launch per range (DESIGN.md section 6 has the arithmetic; bench.py reports both).
+GRAD_ROWS_GROUP = 128
 PROW_MAX_BYTES = 24 << 30  # staged backward: partial rows beyond this are produced per 128-channel range (see _backward_staged)
 # Persistent gradient buffer of the colours-only backward (_KeptGrad): default ON
 KEEP_GRAD = os.environ.get("GAGS_KEEP_GRAD", "1") != "0"
@@ -712,10 +716,9 @@ def _backward_staged(lib, rctx, offsets, n_isects, blk_rows, fwd_scratch, v_out,
                     keep_or_range(stage | xflag | 256, c0, 128)
     elif hook is not None and ranges is not None:
         alias = v_colors.detach()  # own TensorImpl, same storage: autograd may still adopt v_colors without a copy
-        # the partial rows are produced for `grad_rows_group` channels per launch (two ranges by default): every rows launch
-        # streams the view's weight tiles from HBM once for all of its 128-channel slices (they share them through L2), so a
-        # launch per 128-channel range read them four times -- most of what the range-staged backward cost on one GPU -- while
-        # the reduce stage and the exchange keep the narrower range (the wire starts early and stays busy)
+        # the partial rows are produced for `grad_rows_group` channels per launch: every rows launch streams the view's weight
+        # tiles from HBM once for all of its 128-channel slices (they share them through L2), so wider groups re-read them less
+        # often -- and deliver their first range later; the reduce stage and the exchange keep the narrower range either way
         group = max(int(rctx.grad_rows_group), 1)
         rows_done = 0
         for c0, c1 in ranges:

@@ -38,5 +38,6 @@ S=$(find "$O/d16stats" -name '*kernel_stats.csv' | head -1)
 timeout 300 python tools/gemm_bench.py > "$O/${TAG}_decoder_gemm.json" 2>/dev/null
 timeout 900 python tools/config_sweep.py > "$O/${TAG}_config_sweep.json" 2>/dev/null
 timeout 300 python tools/union_rows.py C3 > "$O/${TAG}_union_rows.json" 2>/dev/null
+timeout 300 python tools/dp_overhead.py 128 256 512 256,128,128 > "$O/${TAG}_dp_overhead.json" 2>/dev/null
 tools/micro/run_all.sh > "$O/${TAG}_micro.txt" 2>&1
 tail -1 "$O/${TAG}_c3_bench.json" | cut -c1-600
