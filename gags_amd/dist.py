@@ -407,7 +407,7 @@ class OverlappedGradReducer:
         cur = torch.cuda.current_stream()
         with torch.cuda.stream(self.comm):
             idx = self._union_rows()
-        if idx is None or self._pos is None:
+        if idx is None or self._pos is None or idx.numel() == 0:  # (an empty union: nothing to write, the exchange packs 0 rows)
             return None
         cur.wait_event(self._union_ev)
         self._pos.record_stream(cur)

@@ -114,7 +114,7 @@ class RasterContext:
 
     def kept_grad(self, n, d, dtype, dev):
         """(alias, flags_prev, flags_cur) of this shape's persistent gradient buffer, or None when it is not to be used."""
-        if not self.keep_grad_buffer or n * d < KEEP_GRAD_MIN_ELEMS:
+        if not self.keep_grad_buffer or not _CAN_COUNT_REFS or n * d < KEEP_GRAD_MIN_ELEMS or n == 0:
             return None
         key = (n, d, dtype, dev.index)
         if self._kept_fails.get(key, 0) >= 3:
@@ -159,7 +159,12 @@ def default_context():
 
 
 def _storage_refs(t):
+    """References to `t`'s storage (the temporary made here included: only compared with a baseline taken the same way)."""
     return torch._C._storage_Use_Count(t.untyped_storage()._cdata)
+
+
+# (a private torch binding: without it nobody can tell whether a buffer is still held elsewhere, and the mechanism stays off)
+_CAN_COUNT_REFS = hasattr(torch._C, "_storage_Use_Count")
 
 
 class _KeptGrad:
