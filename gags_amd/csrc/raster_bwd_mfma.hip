@@ -593,8 +593,12 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(int n_gauss, int d, in
                                                           const float *__restrict__ prow, int prow_pitch,
                                                           void *__restrict__ v_colors_, int sparse,
                                                           const int32_t *__restrict__ wire_pos, float *__restrict__ wire,
-                                                          const uint8_t *__restrict__ keep_prev, uint8_t *__restrict__ keep_cur)
+                                                          const uint8_t *__restrict__ keep_prev, uint8_t *__restrict__ keep_cur,
+                                                          int tail)
 {
+    // tail (VW == 4 only): the 1-3 channels an odd width leaves behind its float4 columns (the 513th of BASELINE.json configs[4])
+    // ride along -- lane t < tail of a Gaussian's group also sums channel ch_begin + ch_count + t -- instead of a second launch
+    // with one lane per Gaussian walking the same row lists again (0.22 ms at C5).
     // keep (round 6): v_colors is a PERSISTENT buffer of the caller's whose rows are zero except those the previous backward
     // wrote (keep_prev[g] != 0).  This launch writes the rows that have partial rows now, re-zeroes the rows that had some
     // last time and have none now, leaves every other row alone -- 73 % of the Gaussians blend nothing at C3: 2.2 GB of zero
@@ -635,6 +639,10 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(int n_gauss, int d, in
         }
     } else {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int tl = threadIdx.x % lpg;
+        const bool has_tail = tl < tail;
+        const int ct = ch_begin + ch_count + (has_tail ? tl : 0);  // this lane's tail channel (same order of additions as the body)
+        float acc_t = 0.f;
         int i = b;
         for (; i + 3 < e; i += 4) {
             const int r0 = sorted_rows[i], r1 = sorted_rows[i + 1], r2 = sorted_rows[i + 2], r3 = sorted_rows[i + 3];
@@ -646,10 +654,20 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(int n_gauss, int d, in
             acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
             acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
             acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+            if (has_tail) {
+                acc_t += prow[(size_t)r0 * prow_pitch + ct]; acc_t += prow[(size_t)r1 * prow_pitch + ct];
+                acc_t += prow[(size_t)r2 * prow_pitch + ct]; acc_t += prow[(size_t)r3 * prow_pitch + ct];
+            }
         }
         for (; i < e; ++i) {
-            const float4 v0 = *reinterpret_cast<const float4 *>(prow + (size_t)sorted_rows[i] * prow_pitch + cl);
+            const int r0 = sorted_rows[i];
+            const float4 v0 = *reinterpret_cast<const float4 *>(prow + (size_t)r0 * prow_pitch + cl);
             acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+            if (has_tail) acc_t += prow[(size_t)r0 * prow_pitch + ct];
+        }
+        if (!skip_grad && has_tail) {
+            if constexpr (HALF) reinterpret_cast<__half *>(v_colors_)[(size_t)g * d + ct] = __float2half_rn(acc_t);
+            else reinterpret_cast<float *>(v_colors_)[(size_t)g * d + ct] = acc_t;
         }
         if (!skip_grad) {
             if constexpr (HALF) {
@@ -883,17 +901,19 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
         const int sparse = (stage_flags & 128) ? 1 : 0;  // v_colors arrives zero-filled: rows of Gaussians that blended nothing are skipped
         const int c4 = ch_count & ~3, c1 = ch_count & 3;  // float4 lanes + the 1-3 channels an odd width leaves over
         if (wire && (c1 != 0 || !wire_pos)) return GAGS_EINVAL;  // the wire block is [rows, ch_count], ch_count % 4 == 0
+        const bool ride = c4 >= 16 && c1 > 0;  // the 1-3 leftover channels ride along with the float4 columns' launch
         if (c4 > 0) {
             const int gpb = 256 / (c4 >> 2);
             const dim3 grid((n_gauss + gpb - 1) / gpb);
-            if (half) hipLaunchKernelGGL((reduce_rows_kernel<true, 4>), grid, dim3(256), 0, st, n_gauss, d, ch_begin, c4, seg, idx_s, prow, pp, (void *)v_colors, sparse, wire_pos, wire, keep_prev, keep_cur);
-            else hipLaunchKernelGGL((reduce_rows_kernel<false, 4>), grid, dim3(256), 0, st, n_gauss, d, ch_begin, c4, seg, idx_s, prow, pp, (void *)v_colors, sparse, wire_pos, wire, keep_prev, keep_cur);
+            const int tail = ride ? c1 : 0;
+            if (half) hipLaunchKernelGGL((reduce_rows_kernel<true, 4>), grid, dim3(256), 0, st, n_gauss, d, ch_begin, c4, seg, idx_s, prow, pp, (void *)v_colors, sparse, wire_pos, wire, keep_prev, keep_cur, tail);
+            else hipLaunchKernelGGL((reduce_rows_kernel<false, 4>), grid, dim3(256), 0, st, n_gauss, d, ch_begin, c4, seg, idx_s, prow, pp, (void *)v_colors, sparse, wire_pos, wire, keep_prev, keep_cur, tail);
         }
-        if (c1 > 0) {
+        if (c1 > 0 && !ride) {
             const int gpb = 256 / c1;
             const dim3 grid((n_gauss + gpb - 1) / gpb);
-            if (half) hipLaunchKernelGGL((reduce_rows_kernel<true, 1>), grid, dim3(256), 0, st, n_gauss, d, ch_begin + c4, c1, seg, idx_s, prow, pp, (void *)v_colors, sparse, wire_pos, wire, keep_prev, keep_cur);
-            else hipLaunchKernelGGL((reduce_rows_kernel<false, 1>), grid, dim3(256), 0, st, n_gauss, d, ch_begin + c4, c1, seg, idx_s, prow, pp, (void *)v_colors, sparse, wire_pos, wire, keep_prev, keep_cur);
+            if (half) hipLaunchKernelGGL((reduce_rows_kernel<true, 1>), grid, dim3(256), 0, st, n_gauss, d, ch_begin + c4, c1, seg, idx_s, prow, pp, (void *)v_colors, sparse, wire_pos, wire, keep_prev, keep_cur, 0);
+            else hipLaunchKernelGGL((reduce_rows_kernel<false, 1>), grid, dim3(256), 0, st, n_gauss, d, ch_begin + c4, c1, seg, idx_s, prow, pp, (void *)v_colors, sparse, wire_pos, wire, keep_prev, keep_cur, 0);
         }
     }
     GAGS_CHECK_LAUNCH();
@@ -1583,7 +1603,7 @@ int gags_raster_bwd_geom_launch(int d, int n_gauss, int width, int height, const
         hipLaunchKernelGGL(seg_fill_kernel, dim3((n_gauss + 1 + 255) / 256), dim3(256), 0, st, n_gauss, seg);
     }
     hipLaunchKernelGGL((reduce_rows_kernel<false, 4>), dim3((n_gauss + 127) / 128), dim3(256), 0, st, n_gauss, 8, 0, 8, seg, idx_s, grow, 8,
-                       (void *)v_geo, 0, (const int32_t *)nullptr, (float *)nullptr, (const uint8_t *)nullptr, (uint8_t *)nullptr);
+                       (void *)v_geo, 0, (const int32_t *)nullptr, (float *)nullptr, (const uint8_t *)nullptr, (uint8_t *)nullptr, 0);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }
