@@ -487,7 +487,12 @@ class _Rasterize(torch.autograd.Function):
                 scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             except torch.OutOfMemoryError:
                 # slot space (1 KB per intersection) does not fit even after the caching allocator gave its blocks
-                # back: scratch-free kernels, which read an fp32 table only
+                # back: scratch-free kernels, which read an fp32 table only.  Said out loud: they are several times slower
+                # (single-kernel forward, atomic backward) and the caller should know why
+                import warnings
+                warnings.warn(f"gags_amd.rasterization: {nbytes / 2 ** 30:.1f} GiB of forward scratch for {n_isects} tile "
+                              "intersections could not be allocated; this view runs on the scratch-free kernels "
+                              "(INTEGRATION.md, memory model)", RuntimeWarning, stacklevel=3)
                 split, nbytes, scratch = False, 0, None
                 if half:
                     half, colors = False, colors.float()

@@ -1227,3 +1227,34 @@ def test_persistent_gradient_buffer_is_bit_identical_and_gives_way_to_other_hold
     assert float((pc._semantic_feature.grad - expect).abs().max()) <= 1e-5 * float(expect.abs().max())
     assert max(acc_ctx._kept_fails.values()) <= 1
     pc._semantic_feature.grad = None
+
+
+def test_scratch_that_does_not_fit_falls_back_loudly(oracle, monkeypatch):
+    """INTEGRATION.md, memory model: when the forward's slot space (1 KB per tile intersection) cannot be allocated the view
+    runs on the scratch-free kernels (single-kernel forward, atomic backward) -- with a RuntimeWarning that says so (VERDICT r5:
+    "the silent OOM fallback"), the same render bit for bit, the same gradient within the atomic kernel's tolerance; an fp16
+    table is widened first (those kernels read fp32)."""
+    from gags_amd import _lib
+    from gags_amd.rasterization import rasterization
+    n, w, h, d = 3000, 160, 112, 128
+    s = scene_arrays(n, d, w, h, seed=14, view=2, scale_mult=5.0)
+    bg = np.full(d, 0.3, np.float32)
+    v_out = np.random.default_rng(8).standard_normal((h, w, d)).astype(np.float32)
+    o_out, o_alpha, oi = oracle.rasterization(s["means"], s["quats"], s["scales"], s["opacities"], s["colors"], s["viewmat"],
+                                              s["K"], bg, w, h)
+    o_vf = oracle.raster_bwd_colors_fwdorder(oi["means2d"], oi["conics"], s["opacities"], d, w, h, oi["isect_offsets"],
+                                             oi["flatten_ids"], v_out, n)
+    lib = _lib.load()
+    monkeypatch.setattr(lib, "gags_raster_fwd_scratch_bytes", lambda *a: 1 << 52)  # "does not fit"
+    args = [to_dev(s[k]) for k in ("means", "quats", "scales", "opacities")]
+    for table in (to_dev(s["colors"]), to_dev(s["colors"]).half()):
+        cols = table.clone().requires_grad_(True)
+        with pytest.warns(RuntimeWarning, match="scratch-free kernels"):
+            out, alphas, info = rasterization(*args, cols, to_dev(s["viewmat"])[None], to_dev(s["K"])[None], w, h,
+                                              backgrounds=to_dev(bg)[None])
+        np.testing.assert_array_equal(alphas[0, ..., 0].detach().cpu().numpy(), o_alpha)
+        if table.dtype == torch.float32:
+            np.testing.assert_array_equal(out[0].detach().cpu().numpy(), o_out)
+        (out[0] * to_dev(v_out)).sum().backward()
+        assert cols.grad.dtype == table.dtype
+        assert rel_l2(cols.grad.float().cpu().numpy(), o_vf) <= (GRAD_TOL if table.dtype == torch.float32 else 5e-4)
