@@ -66,6 +66,9 @@ SIGNATURES = {
                                                   _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "gags_raster_bwd_colors_staged_keep": (_i32, [_i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp,
                                                   _i64, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "gags_raster_list_need": (_i32, [_i32, _i32, _i32, _vp, _vp, _i64, _vp, _i32, _vp, _vp]),
+    "gags_trim_lists": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gags_trim_last_ids": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "gags_raster_stats": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "gags_project_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _vp, _vp]),

@@ -21,6 +21,13 @@ int gags_raster_weights_launch(int width, int height, int n_gauss, const void *p
                                const int32_t *flat, int n_isects, float *wt, int32_t *gid_s, int32_t *sidx_s,
                                int32_t *hit, int32_t *blk_rows, float *Tbuf, float *alphas, int32_t *last_ids,
                                hipStream_t st);
+int gags_list_need_launch(int width, int height, int n_gauss, const void *packed, int by_gauss, const int32_t *offsets,
+                          const int32_t *flat, int n_isects, int32_t *need, hipStream_t st);
+int gags_trim_offsets_launch(int n_tiles, const int32_t *cum, int32_t *off_new, hipStream_t st);
+int gags_trim_gather_launch(int n_tiles, const int32_t *off_old, const int32_t *off_new, const int32_t *flat_in, int32_t *flat_out,
+                            hipStream_t st);
+int gags_trim_last_ids_launch(int width, int height, const int32_t *off_old, const int32_t *off_new, const float *alphas,
+                              int32_t *last_ids, hipStream_t st);
 // raster_fwd_mfma.hip
 int gags_raster_fwd_feat_launch(int d, int width, int height, int n_gauss, const float *colors, int colors_f16, int exact,
                                 const float *backgrounds, const int32_t *offsets, int n_isects,
@@ -137,6 +144,34 @@ extern "C" int gags_raster_fwd(int d, int n, int width, int height, const float 
     }
     return gags_raster_fwd_valu(d, width, height, means2d, conics, opacities, colors, backgrounds, isect_offsets,
                                 flatten_ids, (int)n_isects, render_colors, render_alphas, last_ids, st);
+}
+
+// ---- list trimming (round 6; include/gags_raster.h) ---------------------------------------------------------------------
+extern "C" int gags_raster_list_need(int n, int width, int height, const int32_t *isect_offsets, const int32_t *flatten_ids,
+                                     int64_t n_isects, const void *packed, int flags, int32_t *need, void *stream)
+{
+    if (n < 0 || width <= 0 || height <= 0 || n_isects < 0 || n_isects >= (1ll << 31) || !need || !isect_offsets) return GAGS_EINVAL;
+    if (n_isects > 0 && (!flatten_ids || !packed || n == 0)) return GAGS_EINVAL;
+    return gags_list_need_launch(width, height, n, packed, (flags & GAGS_RECS_BY_GAUSSIAN) ? 1 : 0, isect_offsets, flatten_ids,
+                                 (int)n_isects, need, (hipStream_t)stream);
+}
+
+extern "C" int gags_trim_lists(int width, int height, const int32_t *isect_offsets, const int32_t *need_cum,
+                               const int32_t *flatten_ids, int32_t *offsets_out, int32_t *flatten_out, void *stream)
+{
+    if (width <= 0 || height <= 0 || !isect_offsets || !need_cum || !offsets_out) return GAGS_EINVAL;
+    const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
+    int rc = gags_trim_offsets_launch(tile_w * tile_h, need_cum, offsets_out, (hipStream_t)stream);
+    if (rc != GAGS_OK || !flatten_out) return rc;  // (flatten_out NULL: the offsets only)
+    if (!flatten_ids) return GAGS_EINVAL;
+    return gags_trim_gather_launch(tile_w * tile_h, isect_offsets, offsets_out, flatten_ids, flatten_out, (hipStream_t)stream);
+}
+
+extern "C" int gags_trim_last_ids(int width, int height, const int32_t *isect_offsets, const int32_t *offsets_trimmed,
+                                  const float *render_alphas, int32_t *last_ids, void *stream)
+{
+    if (width <= 0 || height <= 0 || !isect_offsets || !offsets_trimmed || !render_alphas || !last_ids) return GAGS_EINVAL;
+    return gags_trim_last_ids_launch(width, height, isect_offsets, offsets_trimmed, render_alphas, last_ids, (hipStream_t)stream);
 }
 
 extern "C" int gags_raster_bwd(int d, int width, int height, const float *means2d, const float *conics,

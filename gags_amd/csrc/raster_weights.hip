@@ -61,12 +61,17 @@ __global__ __launch_bounds__(256) void gather_grec_kernel(int n_isects, const in
     dst[0] = u; dst[1] = v;
 }
 
+// COUNT (round 6, list trimming): the same walk with NO output but need[tile] = how many entries of the tile's sorted list
+// any of its pixels reads before the tile is done (all pixels saturated, or the list exhausted).  Heavy views stop after a few
+// hundred of a tile's tens of thousands of entries; run on the list cut to need[tile], every pass below does exactly what it
+// does on the full list -- same hits, same pairs, same order -- while its scratch (1 KB per LIST ENTRY) shrinks by that factor.
+template <bool COUNT>
 __global__ __launch_bounds__(64, 8) void raster_weights_kernel(
     int width, int height, int tile_w, int n_tiles, int n_gauss, const GRec *__restrict__ packed,
     const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids, int n_isects,
     float *__restrict__ wt, int32_t *__restrict__ gid_s, int32_t *__restrict__ sidx_s, int32_t *__restrict__ hit,
     int32_t *__restrict__ blk_rows, float *__restrict__ Tbuf, float *__restrict__ render_alphas,
-    int32_t *__restrict__ last_ids, int by_gauss)
+    int32_t *__restrict__ last_ids, int by_gauss, int32_t *__restrict__ need)
 {
     __shared__ __attribute__((aligned(16))) HRec ring[RING];
 
@@ -91,6 +96,7 @@ __global__ __launch_bounds__(64, 8) void raster_weights_kernel(
     hs.init(ring, packed, flatten_ids, start, end, lane, g);
 
     int row = sb;
+    int stop = start;  // COUNT: one past the last list entry a K-step of this block consumed
     hs.refill(6);
     if (!__all(sA.done && sB.done) && hs.rd < hs.nq) {
         bool v_n;
@@ -117,6 +123,11 @@ __global__ __launch_bounds__(64, 8) void raster_weights_kernel(
             sB.cur = blB ? sidx_c : sB.cur;
             // a hit that blends into none of the block's pixels leaves no slot (its partner in the step may):
             // zero rows would be multiplied, stored, sorted and summed like any other -- they were 20 % of all rows
+            if constexpr (COUNT) {
+                // both hits of the step were consumed (an absent partner repeats the last produced hit: not beyond it)
+                stop = max(stop, sidx_c + 1);
+                return more && !__all(sA.done && sB.done);
+            }
             const unsigned long long nzm = __ballot(wA != 0.f || wB != 0.f);
             const bool nz0 = (nzm & 0xffffffffull) != 0, nz1 = (nzm >> 32) != 0;  // slot k = half-wave k
             if (k ? nz1 : nz0) {
@@ -133,6 +144,12 @@ __global__ __launch_bounds__(64, 8) void raster_weights_kernel(
             return more && !__all(sA.done && sB.done);
         };
         while (kstep()) {}
+    }
+    if constexpr (COUNT) {
+        const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)stop, (unsigned)stop, false, false);
+        stop = max((int)sw[0], (int)sw[1]);  // (stop is uniform within a half-wave: each holds its slot's sorted index)
+        if (lane == 0 && stop > start) atomicMax(&need[tile], stop - start);
+        return;
     }
     const int used = row - sb;
     const int cnt = (used + 1) & ~1;  // consumers take slots in pairs: an odd count is padded with one zero slot that belongs to no Gaussian
@@ -191,9 +208,86 @@ int gags_raster_weights_launch(int width, int height, int n_gauss, const void *p
     const int n_tiles = tile_w * tile_h;
     // hit[i] = 1 for every intersection that blends into at least one pixel of its tile (+1 entry: an empty view)
     if (hipMemsetAsync(hit, 0, sizeof(int32_t) * ((size_t)n_isects + 1), st) != hipSuccess) return GAGS_ELAUNCH;
-    hipLaunchKernelGGL(raster_weights_kernel, dim3(n_tiles * GAGS_BLOCKS_PER_TILE), dim3(64), 0, st, width, height, tile_w, n_tiles,
+    hipLaunchKernelGGL(raster_weights_kernel<false>, dim3(n_tiles * GAGS_BLOCKS_PER_TILE), dim3(64), 0, st, width, height, tile_w, n_tiles,
                        n_gauss, reinterpret_cast<const GRec *>(packed), offsets, flat, n_isects, wt, gid_s, sidx_s, hit,
-                       blk_rows, Tbuf, alphas, last_ids, by_gauss);
+                       blk_rows, Tbuf, alphas, last_ids, by_gauss, (int32_t *)nullptr);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+// ---- list trimming (round 6): need[tile], the cut lists, and the translation of last_ids back to the full lists -------------
+namespace {
+// one workgroup per tile: flat_out[off_new[t] + j] = flat_in[off_old[t] + j] for j < need[t]
+__global__ __launch_bounds__(256) void trim_gather_kernel(int n_tiles, const int32_t *__restrict__ off_old,
+                                                          const int32_t *__restrict__ off_new,
+                                                          const int32_t *__restrict__ flat_in, int32_t *__restrict__ flat_out)
+{
+    const int t = blockIdx.x;
+    const int a = off_new[t], cnt = off_new[t + 1] - a, b = off_old[t];
+    for (int j = threadIdx.x; j < cnt; j += 256) flat_out[a + j] = flat_in[b + j];
+}
+
+// off_new[0 .. n_tiles] = exclusive prefix sums of need (the inclusive sums `cum` shifted by one; entry n_tiles = the total)
+__global__ __launch_bounds__(256) void trim_offsets_kernel(int n_tiles, const int32_t *__restrict__ cum, int32_t *__restrict__ off_new)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t <= n_tiles) off_new[t] = t == 0 ? 0 : cum[t - 1];
+}
+
+// last_ids are sorted indices: those of the cut lists become those of the full lists again (a pixel that blended nothing --
+// alpha exactly 0 -- keeps its 0)
+__global__ __launch_bounds__(256) void trim_last_ids_kernel(int width, int height, int tile_w, const int32_t *__restrict__ off_old,
+                                                            const int32_t *__restrict__ off_new,
+                                                            const float *__restrict__ alphas, int32_t *__restrict__ last_ids)
+{
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= (int64_t)width * height) return;
+    const int i = (int)(p / width), j = (int)(p - (int64_t)i * width);
+    const int t = (i / GAGS_TILE) * tile_w + j / GAGS_TILE;
+    if (alphas[p] > 0.f) last_ids[p] += off_old[t] - off_new[t];
+}
+}  // namespace
+
+int gags_list_need_launch(int width, int height, int n_gauss, const void *packed, int by_gauss, const int32_t *offsets,
+                          const int32_t *flat, int n_isects, int32_t *need, hipStream_t st)
+{
+    GAGS_CLEAR_ERR();
+    const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
+    const int n_tiles = tile_w * tile_h;
+    if (hipMemsetAsync(need, 0, sizeof(int32_t) * (size_t)n_tiles, st) != hipSuccess) return GAGS_ELAUNCH;
+    hipLaunchKernelGGL(raster_weights_kernel<true>, dim3(n_tiles * GAGS_BLOCKS_PER_TILE), dim3(64), 0, st, width, height, tile_w, n_tiles,
+                       n_gauss, reinterpret_cast<const GRec *>(packed), offsets, flat, n_isects, (float *)nullptr, (int32_t *)nullptr,
+                       (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (float *)nullptr, (float *)nullptr,
+                       (int32_t *)nullptr, by_gauss, need);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+int gags_trim_offsets_launch(int n_tiles, const int32_t *cum, int32_t *off_new, hipStream_t st)
+{
+    GAGS_CLEAR_ERR();
+    hipLaunchKernelGGL(trim_offsets_kernel, dim3((n_tiles + 1 + 255) / 256), dim3(256), 0, st, n_tiles, cum, off_new);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+int gags_trim_gather_launch(int n_tiles, const int32_t *off_old, const int32_t *off_new, const int32_t *flat_in, int32_t *flat_out,
+                            hipStream_t st)
+{
+    GAGS_CLEAR_ERR();
+    hipLaunchKernelGGL(trim_gather_kernel, dim3(n_tiles), dim3(256), 0, st, n_tiles, off_old, off_new, flat_in, flat_out);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+int gags_trim_last_ids_launch(int width, int height, const int32_t *off_old, const int32_t *off_new, const float *alphas,
+                              int32_t *last_ids, hipStream_t st)
+{
+    GAGS_CLEAR_ERR();
+    const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE;
+    const int64_t pix = (int64_t)width * height;
+    hipLaunchKernelGGL(trim_last_ids_kernel, dim3((unsigned)((pix + 255) / 256)), dim3(256), 0, st, width, height, tile_w, off_old,
+                       off_new, alphas, last_ids);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }

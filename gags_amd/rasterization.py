@@ -40,6 +40,10 @@ GRAD_RANGE_CHANNELS = 128
 # earliest by one launch per range (DESIGN.md section 6 has the arithmetic; bench.py reports both).
 GRAD_ROWS_GROUP = 128
 PROW_MAX_BYTES = 24 << 30  # staged backward: partial rows beyond this are produced per 128-channel range (see _backward_staged)
+# List trimming (RasterContext.trim_lists; _trim_lists): None = automatic, for views whose forward scratch would exceed
+# TRIM_AUTO_BYTES; True / False force it on / off (GAGS_TRIM_LISTS=1 / 0)
+TRIM_LISTS = {"1": True, "0": False}.get(os.environ.get("GAGS_TRIM_LISTS", ""), None)
+TRIM_AUTO_BYTES = 48 << 30
 # Persistent gradient buffer of the colours-only backward (_KeptGrad): default ON
 KEEP_GRAD = os.environ.get("GAGS_KEEP_GRAD", "1") != "0"
 KEEP_GRAD_MIN_ELEMS = 0   # (every shape: the small test scenes exercise the same path as C3)
@@ -101,6 +105,8 @@ class RasterContext:
         self.k_cache = {}
         self._pinned = {}
         self._side = {}
+        # list trimming for heavy views (_trim_lists): None = automatic above TRIM_AUTO_BYTES of forward scratch
+        self.trim_lists = TRIM_LISTS
         # persistent gradient buffer of the colours-only backward (_KeptGrad): on unless GAGS_KEEP_GRAD=0
         self.keep_grad_buffer = KEEP_GRAD
         self._kept = {}        # (n, d, dtype, device) -> _KeptGrad, at most KEEP_GRAD_SHAPES shapes (least recently used out)
@@ -434,6 +440,35 @@ def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height, conics=
     # isect_offsets[tile + 1] as a tile's end.  Callers get gsplat's [tile_h, tile_w] view AND the buffer itself.
     off_view = offsets[:n_tiles].view(tile_h, tile_w)
     return ids_s[:size], flat_s[:size], off_view, count, packed, offsets
+
+
+def _trim_lists(lib, n, width, height, offsets_full, flatten_ids, n_isects, packed):
+    """Round 6, heavy views: every tile's sorted list cut to the entries its pixels actually read before the tile is done
+    (gags_raster_list_need: the weights pass's own walk, outputs dropped), so that the split forward's scratch -- ~1 KB per
+    list entry -- and every pass over the lists shrink by the same factor (C5H: 169 M entries, a few hundred of a tile's 20 k
+    are read).  Returns (offsets [n_tiles + 1] with the count, flatten_ids, count) of the trimmed lists: on them every raster
+    entry computes bit for bit what it computes on the full lists; only last_ids index the trimmed list
+    (gags_trim_last_ids translates a copy back).  One more 4-byte readback (the trimmed count sizes the id list)."""
+    st = _stream()
+    dev = flatten_ids.device
+    n_tiles = ((width + TILE - 1) // TILE) * ((height + TILE - 1) // TILE)
+    need = torch.empty(n_tiles, dtype=torch.int32, device=dev)
+    with profiler.stage("list_need"):
+        check(lib.gags_raster_list_need(n, width, height, ptr(offsets_full), ptr(flatten_ids), n_isects, ptr(packed),
+                                        _lib.GAGS_RECS_BY_GAUSSIAN, ptr(need), st), "gags_raster_list_need")
+    cum = torch.empty(n_tiles, dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.int32, device=dev)
+    sb = lib.gags_scan_scratch_bytes(n_tiles)
+    scratch = torch.empty(sb, dtype=torch.uint8, device=dev)
+    check(lib.gags_cumsum_i32(n_tiles, ptr(need), ptr(cum), ptr(total), ptr(scratch), sb, st), "gags_cumsum_i32")
+    host = ctypes.c_int32(0)
+    check(lib.gags_read_i32(ptr(total), ctypes.byref(host), st), "gags_read_i32")
+    t = int(host.value)
+    offs_t = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
+    flat_t = torch.empty(t, dtype=torch.int32, device=dev)
+    check(lib.gags_trim_lists(width, height, ptr(offsets_full), ptr(cum), ptr(flatten_ids), ptr(offs_t),
+                              ptr(flat_t) if t > 0 else None, st), "gags_trim_lists")
+    return offs_t, flat_t, t
 
 
 def _check_isects(n_isects, n_tiles=0):
@@ -878,21 +913,44 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
         with torch.no_grad(), profiler.stage("binning"):
             b = tile_binning(means2d, radii, depths, tiles, width, height, conics if wide else None,
                              _c(opacities) if wide else None, cap, records=records if wide else None, context=rctx)
+        offs, flat = b[5], b[1]
+        # heavy views: the lists cut to what their tiles read (_trim_lists) -- the raster passes, their scratch and the backward
+        # work on the cut lists; callers still get the full ones in `info`
+        trimmed = None
+        n_full = flat.shape[0]
+        if (cap is None and wide and b[4] is not None and n_full > 0 and rctx.trim_lists is not False
+                and not (raster_flags & (_lib.GAGS_FWD_NO_MFMA | _lib.GAGS_FWD_FUSED))):
+            lib_ = _lib.load()
+            if rctx.trim_lists or lib_.gags_raster_fwd_scratch_bytes(n_full, width, height) > TRIM_AUTO_BYTES:
+                with torch.no_grad():
+                    trimmed = _trim_lists(lib_, n, width, height, offs, flat, n_full, b[4])
+                offs, flat = trimmed[0], trimmed[1]
         # any width in ONE rasterization: 513 = 512 CLIP channels + 1 (BASELINE.json configs[4] "512-d feat + granularity")
         # is four 128-channel slices and one lane of a narrow slice on the same matrix-core kernels, into one output tensor
-        r = _Rasterize.apply(means2d, conics, cols, opacities, bg, b[5], b[1], b[4], width, height, int(raster_flags), prezero,
+        r = _Rasterize.apply(means2d, conics, cols, opacities, bg, offs, flat, b[4], width, height, int(raster_flags), prezero,
                              rctx, None)
+        if trimmed is not None:
+            # last_ids are sorted indices: a COPY goes back to the full lists' numbering for the caller (the autograd node keeps
+            # its own, which matches the lists it saved)
+            with torch.no_grad():
+                last_user = r[2].clone()
+                check(_lib.load().gags_trim_last_ids(width, height, ptr(b[5]), ptr(offs), ptr(r[1]), ptr(last_user), _stream()),
+                      "gags_trim_last_ids")
+            profiler.note("isects_trimmed", trimmed[2])
+            r = (r[0], r[1], last_user, trimmed[2])
+        else:
+            r = (r[0], r[1], r[2], None)
         return b[:5], r
 
     cap = None
     if rctx.capacity_mode and cap_key in rctx.cap_isects:
         cap = min(MAX_ISECTS - 1, int(rctx.cap_isects[cap_key] * CAP_MARGIN) + 4096)
-    (isect_ids, flatten_ids, isect_offsets, n_isects, packed), (out, alphas, last_ids) = run(cap)
+    (isect_ids, flatten_ids, isect_offsets, n_isects, packed), (out, alphas, last_ids, n_trimmed) = run(cap)
     if cap is not None:
         n_true = n_isects.get()  # (the scan that produced it finished long ago: everything above is already enqueued)
         _check_isects(n_true, ((width + TILE - 1) // TILE) * ((height + TILE - 1) // TILE))
         if n_true > cap:  # more intersections than the remembered capacity: nothing was written out of bounds; run again, exact
-            (isect_ids, flatten_ids, isect_offsets, n_isects, packed), (out, alphas, last_ids) = run(None)
+            (isect_ids, flatten_ids, isect_offsets, n_isects, packed), (out, alphas, last_ids, n_trimmed) = run(None)
         else:
             n_isects = n_true
             isect_ids, flatten_ids = isect_ids[:n_true], flatten_ids[:n_true]
@@ -913,5 +971,6 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
         "tiles_per_gauss": tiles[None], "isect_ids": isect_ids, "flatten_ids": flatten_ids,
         "isect_offsets": isect_offsets[None], "last_ids": last_ids, "width": width, "height": height,
         "tile_size": TILE, "n_cameras": 1, "n_isects": n_isects,
+        "n_isects_trimmed": n_trimmed,  # (not gsplat's: list entries the raster passes worked on when the lists were trimmed, else None)
     }
     return out[None], alphas[None, ..., None], info

@@ -174,6 +174,24 @@ int gags_raster_fwd(int d, int n, int width, int height, const float *means2d, c
                     void *scratch, int64_t scratch_bytes, int32_t *blk_rows,
                     int flags, void *stream);
 
+/* List trimming (round 6): a heavy view's tiles stop -- every pixel saturated -- after a few hundred of their tens of thousands
+ * of sorted entries, yet the split forward's scratch is ~1 KB per LIST ENTRY (C5H: 169 M entries = 173 GB).
+ *   gags_raster_list_need: need[tile] (n_tiles int32, written in full) = how many leading entries of the tile's list any of its
+ *       pixels reads before the tile is done: the weights pass's own walk (same records, extent test, pairs, stop rule) without
+ *       its outputs.  flags: GAGS_RECS_BY_GAUSSIAN as for gags_raster_fwd.
+ *   gags_trim_lists: from the INCLUSIVE prefix sums of need (gags_cumsum_i32; its total = the trimmed intersection count, which
+ *       sizes flatten_out) the trimmed offsets (n_tiles + 1 entries, the last one = the count) and the trimmed id list
+ *       (flatten_out NULL: offsets only).
+ * Every raster entry run on (offsets_out, flatten_out, trimmed count) computes bit for bit what it computes on the full
+ * lists -- same slots, weights, alphas, renders, gradients -- except that last_ids index the trimmed list:
+ *   gags_trim_last_ids: last_ids back to indices of the full sorted list, in place (pixels with alpha == 0 keep their 0). */
+int gags_raster_list_need(int n, int width, int height, const int32_t *isect_offsets, const int32_t *flatten_ids,
+                          int64_t n_isects, const void *packed, int flags, int32_t *need, void *stream);
+int gags_trim_lists(int width, int height, const int32_t *isect_offsets, const int32_t *need_cum,
+                    const int32_t *flatten_ids, int32_t *offsets_out, int32_t *flatten_out, void *stream);
+int gags_trim_last_ids(int width, int height, const int32_t *isect_offsets, const int32_t *offsets_trimmed,
+                       const float *render_alphas, int32_t *last_ids, void *stream);
+
 /* K10: rasterize backward (what autograd runs under train.py:174).
  * v_colors[N,D] (and, unless GAGS_BWD_COLORS_ONLY, v_opacities[N], v_means2d[N,2],
  * v_conics[N,3]) must be zero-filled by the caller; results are accumulated with

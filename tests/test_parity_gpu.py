@@ -1258,3 +1258,43 @@ def test_scratch_that_does_not_fit_falls_back_loudly(oracle, monkeypatch):
         (out[0] * to_dev(v_out)).sum().backward()
         assert cols.grad.dtype == table.dtype
         assert rel_l2(cols.grad.float().cpu().numpy(), o_vf) <= (GRAD_TOL if table.dtype == torch.float32 else 5e-4)
+
+
+@pytest.mark.parametrize("n,w,h,d,mult,geom", [(6000, 200, 138, 128, 14.0, False), (3000, 160, 112, 16, 20.0, False),
+                                               (20000, 333, 77, 256, 12.0, False), (2500, 144, 112, 64, 16.0, True),
+                                               (400, 64, 48, 128, 1.0, False)])
+def test_trimmed_lists_change_nothing(oracle, n, w, h, d, mult, geom):
+    """Round 6, list trimming (gags_raster_list_need / gags_trim_lists / gags_trim_last_ids; automatic for views whose forward
+    scratch would exceed 48 GiB, forced here): every tile's sorted list is cut to the entries its pixels read before the tile
+    is done, and the raster passes -- forward, staged backward, the wide geometry backward -- run on the cut lists.  With
+    opaque, large splats most of a list lies behind saturation (asserted: the cut is real); render, alphas, last_ids (in the
+    FULL lists' numbering) and every gradient are bit-identical to the untrimmed run, and the index tensors the caller sees are
+    the full ones, equal to the oracle's."""
+    from gags_amd.rasterization import RasterContext
+    s = scene_arrays(n, d, w, h, seed=77, view=4, scale_mult=mult)
+    s["opacities"] = np.clip(s["opacities"] * 0.4 + 0.6, 0.0, 0.99).astype(np.float32)  # opaque: tiles saturate early
+    bg = np.full(d, 0.2, np.float32)
+    rng = np.random.default_rng(5)
+    v_out = rng.standard_normal((h, w, d)).astype(np.float32)
+    v_alpha = rng.standard_normal((h, w)).astype(np.float32) if geom else None
+    res = {}
+    for name, trim in (("full", False), ("trimmed", True)):
+        ctx = RasterContext()
+        ctx.trim_lists = trim
+        res[name] = _run_gpu(s, w, h, s["colors"], bg, need_geom=geom, v_out=v_out, v_alpha=v_alpha, context=ctx)
+    (o0, a0, i0, g0), (o1, a1, i1, g1) = res["full"], res["trimmed"]
+    assert i0["n_isects_trimmed"] is None and i1["n_isects_trimmed"] is not None
+    assert i1["n_isects"] == i0["n_isects"]
+    assert i1["n_isects_trimmed"] <= i1["n_isects"]
+    if n >= 6000:  # (the dense scenes: most of a list lies behind saturation)
+        assert i1["n_isects_trimmed"] < 0.8 * i1["n_isects"], (i1["n_isects_trimmed"], i1["n_isects"])
+    np.testing.assert_array_equal(o1, o0)
+    np.testing.assert_array_equal(a1, a0)
+    for key in ("last_ids", "flatten_ids", "isect_ids", "isect_offsets"):
+        assert torch.equal(i1[key], i0[key]), key
+    for key in g0:
+        np.testing.assert_array_equal(g1[key], g0[key], err_msg=key)
+    o_out, o_alpha, oi = oracle.rasterization(s["means"], s["quats"], s["scales"], s["opacities"], s["colors"], s["viewmat"],
+                                              s["K"], bg, w, h)
+    _check_indices(i1, oi)
+    np.testing.assert_array_equal(a1, o_alpha)

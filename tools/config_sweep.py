@@ -50,6 +50,8 @@ def run(name, n, w, h, d, half=False, steps=8, flags=0, full_grad=False, scale0=
     dt = (time.perf_counter() - t0) / steps
     peak = torch.cuda.max_memory_allocated() / 2**30
     res = {"ms_per_step": round(1e3 * dt, 3), "views_per_s": round(1 / dt, 1), "n_isects": pkg["info"]["n_isects"], "peak_GiB": round(peak, 1)}
+    if pkg["info"].get("n_isects_trimmed") is not None:
+        res["n_isects_trimmed"] = pkg["info"]["n_isects_trimmed"]  # (heavy views: the lists cut to what their tiles read)
     del pc, G, pkg
     torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
     return name, res
