@@ -78,6 +78,17 @@ def test_argument_validation_returns_codes_without_launching(lib):
     assert lib.gags_compact_mask(-1, None, 0, None, None, None, 0, None) == -1
     assert lib.gags_compact_mask(8, None, 8, None, None, None, 0, None) == -1
     assert lib.gags_compact_mask_scratch_bytes(100000) >= 4 * 49
+    # round 6's entries: list trimming, the inverse row map, the reduce stage's wire / persistent-buffer flavours
+    assert lib.gags_raster_list_need(4, 16, 16, None, None, 10, None, 0, None, None) == -1
+    assert lib.gags_raster_list_need(-1, 16, 16, None, None, 0, None, 0, None, None) == -1
+    assert lib.gags_trim_lists(16, 16, None, None, None, None, None, None) == -1
+    assert lib.gags_trim_lists(0, 16, None, None, None, None, None, None) == -1
+    assert lib.gags_trim_last_ids(16, 16, None, None, None, None, None) == -1
+    assert lib.gags_compact_mask_pos(-1, None, 0, None, None, None, None, 0, None) == -1
+    assert lib.gags_compact_mask_pos(8, None, 1 << 31, None, None, None, None, 0, None) == -1   # capacity past int32 positions
+    staged = (128, 8, 16, 16, None, 0, None, None, None, 0, None, 0, None, 0, None, 3, 0, 128)
+    assert lib.gags_raster_bwd_colors_staged_wire(*staged, None, None, None, None, None) == -1
+    assert lib.gags_raster_bwd_colors_staged_keep(*staged, None, None, None) == -1            # both flag arrays are required
     assert lib.gags_decoder_layer_split(8, 4, 4, *([None] * 2), 4, *([None] * 2), 1, *([None] * 4), 4, 5, None) == -1   # terms = 5
     assert lib.gags_decoder_wgrad_split(8, 4, 4, None, 4, None, None, 4, None, None, None, 0, 1, None) == -1            # terms = 1
 
