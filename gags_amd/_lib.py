@@ -51,8 +51,6 @@ SIGNATURES = {
     "gags_bwd_rowmap_scratch_bytes": (_i64, [_i64]),
     "gags_bwd_rowmap_elems": (_i64, [_i64, _i32, _i32]),
     "gags_bwd_rowmap": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
-    "gags_bwd_rowmap_elems_ordered": (_i64, [_i64, _i32, _i32]),
-    "gags_bwd_rowmap_ordered": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
     "gags_raster_bwd_geom_scratch_bytes": (_i64, [_i64, _i32, _i32, _i32, _i32, _i64]),
     "gags_raster_bwd_geom": (_i32, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64,
                                     _vp, _vp, _vp, _i64, _i32, _vp]),

@@ -20,7 +20,7 @@ int gags_pack_isects_launch(int n, int n_isects, const int32_t *flat, const floa
 int gags_raster_weights_launch(int width, int height, int n_gauss, const void *packed, int by_gauss, const int32_t *offsets,
                                const int32_t *flat, int n_isects, float *wt, int32_t *gid_s, int32_t *sidx_s,
                                int32_t *hit, int32_t *blk_rows, float *Tbuf, float *alphas, int32_t *last_ids,
-                               uint8_t *bmask, hipStream_t st);
+                               hipStream_t st);
 int gags_list_need_launch(int width, int height, int n_gauss, const void *packed, int by_gauss, const int32_t *offsets,
                           const int32_t *flat, int n_isects, int32_t *need, hipStream_t st);
 int gags_trim_offsets_launch(int n_tiles, const int32_t *cum, int32_t *off_new, hipStream_t st);
@@ -43,7 +43,7 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
                                   const float *wt, const int32_t *gid_s, const int32_t *trow_s, void *scratch,
                                   int64_t scratch_bytes, float *v_colors, int stage, int ch_begin, int ch_count,
                                   const int32_t *rows_dev, const int32_t *wire_pos, float *wire, const uint8_t *keep_prev,
-                                  uint8_t *keep_cur, const int32_t *sor, hipStream_t st);
+                                  uint8_t *keep_cur, hipStream_t st);
 int64_t gags_raster_bwd_geom_scratch_bytes_impl(int64_t n_isects, int width, int height, int n_gauss, int d, int64_t n_rows);
 int gags_raster_bwd_geom_launch(int d, int n_gauss, int width, int height, const float *colors, const float *backgrounds,
                                 const int32_t *offsets, int n_isects, const void *packed, const float *v_out,
@@ -54,9 +54,6 @@ int gags_raster_bwd_geom_launch(int d, int n_gauss, int width, int height, const
 int gags_blended_mask_launch(int n_isects, const int32_t *hit, const int32_t *flatten_ids, unsigned char *mask, hipStream_t st);
 int gags_bwd_slot_rows_launch(int width, int height, int n_isects, const int32_t *offsets, const int32_t *blk_rows,
                               const int32_t *sidx_s, const int32_t *trow, int32_t *trow_s, hipStream_t st);
-int gags_bwd_rows_ordered_launch(int width, int height, int n_isects, const int32_t *offsets, const int32_t *blk_rows,
-                                 const int32_t *sidx_s, const int32_t *hit, const uint8_t *bmask, const int32_t *trow,
-                                 int32_t *trow_s, int32_t *trow2, int32_t *sor, hipStream_t st);
 int gags_raster_bwd_atomic_launch(int d, int width, int height, const void *packed, const int32_t *offsets,
                                   const int32_t *flat, int n_isects, const float *v_out, float *v_colors,
                                   int by_gauss, hipStream_t st);
@@ -64,7 +61,7 @@ int gags_raster_bwd_atomic_launch(int d, int width, int height, const void *pack
 namespace {
 inline int64_t al256(int64_t x) { return (x + 255) / 256 * 256; }
 struct FwdScratch {
-    int64_t wt, gid, sidx, hit, tbuf, bmask, total;
+    int64_t wt, gid, sidx, hit, tbuf, total;
 };
 // slot space: gags_slot_count() slots of 64 weights (common.h)
 inline FwdScratch fwd_layout(int64_t n_isects, int width, int height)
@@ -78,7 +75,6 @@ inline FwdScratch fwd_layout(int64_t n_isects, int width, int height)
     L.sidx = o; o += al256(slots * 4);
     L.hit = o; o += al256((n_isects + 1) * 4);
     L.tbuf = o; o += al256((int64_t)width * height * 4);
-    L.bmask = o; o += al256(n_isects * 4);  // four bytes per intersection: byte b = block b of its tile holds a slot of it
     L.total = o;
     return L;
 }
@@ -136,7 +132,7 @@ extern "C" int gags_raster_fwd(int d, int n, int width, int height, const float 
             if (!(flags & GAGS_FWD_ONLY_FEATURES))
                 rc = gags_raster_weights_launch(width, height, n, packed, (flags & GAGS_RECS_BY_GAUSSIAN) ? 1 : 0, isect_offsets, flatten_ids, (int)n_isects, wt,
                                                 gid_s, (int32_t *)(sb + L.sidx), (int32_t *)(sb + L.hit), blk_rows, tbuf,
-                                                render_alphas, last_ids, (uint8_t *)(sb + L.bmask), st);
+                                                render_alphas, last_ids, st);
             if (rc != GAGS_OK || (flags & GAGS_FWD_ONLY_WEIGHTS)) return rc;
             return gags_raster_fwd_feat_launch(d, width, height, n, colors, (flags & GAGS_FEAT_F16) ? ((flags & GAGS_FWD_F16MFMA) ? 2 : 1) : 0,
                                                (flags & GAGS_FWD_EXACT) ? 1 : 0, backgrounds, isect_offsets, (int)n_isects,
@@ -214,10 +210,6 @@ namespace {
 // rowmap = trow[n_isects + 1] (exclusive prefix sum of the forward's hit flags) followed, 256-B aligned, by
 // trow_s[slots] (tile row of every K-step slot of the forward's slot space)
 inline int64_t rowmap_slot_off(int64_t n_isects) { return al256((n_isects + 1) * 4) / 4; }
-// class-ordered rows (gags_bwd_rowmap_ordered): behind trow_s, trow2[n_isects] (the ordered row of every intersection) and
-// sor[4 * n_isects] (per ordered row: the slot offset of the row in each of the tile's four blocks, -1 = none); 256-B aligned
-inline int64_t rowmap_trow2_off(int64_t n_isects, int64_t slots) { return rowmap_slot_off(n_isects) + al256(slots * 4) / 4; }
-inline int64_t rowmap_sor_off(int64_t n_isects, int64_t slots) { return rowmap_trow2_off(n_isects, slots) + al256(n_isects * 4) / 4; }
 inline int64_t slot_count(int64_t n_isects, int width, int height)
 {
     const int64_t tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
@@ -231,29 +223,21 @@ extern "C" int64_t gags_bwd_rowmap_elems(int64_t n_isects, int width, int height
     return rowmap_slot_off(n_isects) + slot_count(n_isects, width, height);
 }
 
-extern "C" int64_t gags_bwd_rowmap_elems_ordered(int64_t n_isects, int width, int height)
-{
-    if (n_isects < 0 || width <= 0 || height <= 0) return 0;
-    return rowmap_sor_off(n_isects, slot_count(n_isects, width, height)) + 4 * n_isects + 4;
-}
-
 extern "C" int64_t gags_bwd_rowmap_scratch_bytes(int64_t n_isects)
 {
     return n_isects < 0 ? 0 : gags_scan::scratch_bytes(n_isects > 0 ? n_isects : 1);
 }
 
-namespace {
-int rowmap_impl(bool ordered, int64_t n_isects, int width, int height, const int32_t *isect_offsets,
-                const int32_t *blk_rows, const void *fwd_scratch, int64_t fwd_scratch_bytes,
-                int32_t *rowmap, int64_t rowmap_elems, int32_t *total, void *scratch,
-                int64_t scratch_bytes, void *stream)
+extern "C" int gags_bwd_rowmap(int64_t n_isects, int width, int height, const int32_t *isect_offsets,
+                               const int32_t *blk_rows, const void *fwd_scratch, int64_t fwd_scratch_bytes,
+                               int32_t *rowmap, int64_t rowmap_elems, int32_t *total, void *scratch,
+                               int64_t scratch_bytes, void *stream)
 {
     GAGS_CLEAR_ERR();
     if (!isects_ok(n_isects, width, height) || !fwd_scratch || !rowmap || !total ||
         !isect_offsets || !blk_rows)
         return GAGS_EINVAL;
-    if (rowmap_elems < (ordered ? gags_bwd_rowmap_elems_ordered(n_isects, width, height) : gags_bwd_rowmap_elems(n_isects, width, height)))
-        return GAGS_ESCRATCH;
+    if (rowmap_elems < gags_bwd_rowmap_elems(n_isects, width, height)) return GAGS_ESCRATCH;
     const FwdScratch L = fwd_layout(n_isects, width, height);
     if (fwd_scratch_bytes < L.total) return GAGS_ESCRATCH;
     hipStream_t st = (hipStream_t)stream;
@@ -264,34 +248,8 @@ int rowmap_impl(bool ordered, int64_t n_isects, int width, int height, const int
     const char *fs = (const char *)fwd_scratch;
     gags_scan::launch<false>((int)n_isects, (const int32_t *)(fs + L.hit), trow + 1, total, (int32_t *)scratch, st);
     GAGS_CHECK_LAUNCH();
-    if (ordered) {
-        const int64_t slots = slot_count(n_isects, width, height);
-        return gags_bwd_rows_ordered_launch(width, height, (int)n_isects, isect_offsets, blk_rows, (const int32_t *)(fs + L.sidx),
-                                            (const int32_t *)(fs + L.hit), (const uint8_t *)(fs + L.bmask), trow,
-                                            rowmap + rowmap_slot_off(n_isects), rowmap + rowmap_trow2_off(n_isects, slots),
-                                            rowmap + rowmap_sor_off(n_isects, slots), st);
-    }
     return gags_bwd_slot_rows_launch(width, height, (int)n_isects, isect_offsets, blk_rows,
                                      (const int32_t *)(fs + L.sidx), trow, rowmap + rowmap_slot_off(n_isects), st);
-}
-}  // namespace
-
-extern "C" int gags_bwd_rowmap(int64_t n_isects, int width, int height, const int32_t *isect_offsets,
-                               const int32_t *blk_rows, const void *fwd_scratch, int64_t fwd_scratch_bytes,
-                               int32_t *rowmap, int64_t rowmap_elems, int32_t *total, void *scratch,
-                               int64_t scratch_bytes, void *stream)
-{
-    return rowmap_impl(false, n_isects, width, height, isect_offsets, blk_rows, fwd_scratch, fwd_scratch_bytes, rowmap,
-                       rowmap_elems, total, scratch, scratch_bytes, stream);
-}
-
-extern "C" int gags_bwd_rowmap_ordered(int64_t n_isects, int width, int height, const int32_t *isect_offsets,
-                                       const int32_t *blk_rows, const void *fwd_scratch, int64_t fwd_scratch_bytes,
-                                       int32_t *rowmap, int64_t rowmap_elems, int32_t *total, void *scratch,
-                                       int64_t scratch_bytes, void *stream)
-{
-    return rowmap_impl(true, n_isects, width, height, isect_offsets, blk_rows, fwd_scratch, fwd_scratch_bytes, rowmap,
-                       rowmap_elems, total, scratch, scratch_bytes, stream);
 }
 
 extern "C" int64_t gags_raster_bwd_geom_scratch_bytes(int64_t n_isects, int width, int height, int n, int d, int64_t n_rows)
@@ -357,9 +315,7 @@ int staged_entry(int d, int n, int width, int height, const int32_t *isect_offse
     return gags_raster_bwd_staged_launch(d, width, height, n, isect_offsets, (int)n_isects, v_render_colors, blk_rows,
                                          rowmap, rows, (const float *)(fs + L.wt), (const int32_t *)(fs + L.gid),
                                          rowmap + rowmap_slot_off(n_isects), scratch, scratch_bytes, v_colors, stage,
-                                         ch_begin, ch_count, rows_dev, wire_pos, wire, keep_prev, keep_cur,
-                                         (stage & 2048) ? rowmap + rowmap_sor_off(n_isects, slot_count(n_isects, width, height)) : nullptr,
-                                         (hipStream_t)stream);
+                                         ch_begin, ch_count, rows_dev, wire_pos, wire, keep_prev, keep_cur, (hipStream_t)stream);
 }
 }  // namespace
 

@@ -530,8 +530,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_f16(
 
 // capacity-sized row buffers: keys [total, cap) become sentinels (key n_gauss: past every Gaussian), so that the sort and
 // the segment offsets can run over the capacity without the host knowing the row count
-#include "raster_bwd_rows_cw.h"
-#include "raster_bwd_rows_cwo.h"  // staged rows, channel waves (round 5; the default)
+#include "raster_bwd_rows_cw.h"  // staged rows, channel waves (round 5; the default)
 
 __global__ __launch_bounds__(256) void row_tail_kernel(int64_t cap, const int32_t *__restrict__ total, int n_gauss,
                                                        uint32_t *__restrict__ row_key, int32_t *__restrict__ row_idx)
@@ -557,73 +556,6 @@ __global__ __launch_bounds__(64) void slot_rows_kernel(int n_tiles, int n_isects
     for (int j = threadIdx.x; j < cnt; j += 64) {
         const int sx = sidx_s[sb + j];
         trow_s[sb + j] = sx >= 0 ? trow[sx] : 0x7fffffff;
-    }
-}
-
-// ---- class-ordered tile rows (round 6) ---------------------------------------------------------------------------------
-// The channel-wave rows kernel multiplies chunks of 32 consecutive tile rows against all four pixel blocks of the tile, and a
-// tile row touches 2.33 of them: 42 % of its MFMA rows are zeros.  Numbered in sorted (depth) order the rows of a chunk touch
-// every block between them; numbered by CLASS -- rows that touch only the tile's upper blocks (0, 1) first, then the mixed
-// ones, then those that touch only the lower blocks (2, 3) -- whole chunks at both ends of a tile need two blocks instead of
-// four, and the kernel skips the other two (raster_bwd_rows_cwo.h).  A row's value does not depend on its number, a
-// Gaussian still has at most one row per tile and tiles keep their order, so the gradient is the same bit for bit.
-//   tile_rows_ordered_kernel : trow2[i] = class-ordered row of sorted intersection i (hit ones), sor[row] = (-1, -1, -1, -1)
-//   slot_rows_ordered_kernel : trow_s[slot] = trow2[sidx]; sor[row][blk] = the slot's offset in its block's region
-__device__ __forceinline__ int row_class(unsigned m)  // m: byte b != 0 <=> block b holds the row
-{
-    const bool top = (m & 0x0000ffffu) != 0, bot = (m & 0xffff0000u) != 0;
-    return top && !bot ? 0 : (bot && !top ? 2 : 1);
-}
-
-__global__ __launch_bounds__(64) void tile_rows_ordered_kernel(int n_tiles, const int32_t *__restrict__ offsets,
-                                                               const int32_t *__restrict__ hit, const uint32_t *__restrict__ bmask,
-                                                               const int32_t *__restrict__ trow, int32_t *__restrict__ trow2,
-                                                               int4 *__restrict__ sor)
-{
-    const int tile = blockIdx.x, lane = threadIdx.x;
-    const int start = offsets[tile], end = offsets[tile + 1];
-    const int R0 = trow[start];
-    if (trow[end] == R0) return;
-    int c0 = 0, c1 = 0;
-    for (int c = start; c < end; c += 64) {
-        const int i = c + lane;
-        const bool h = i < end && hit[i] != 0;
-        const int cls = h ? row_class(bmask[i]) : 3;
-        c0 += __popcll(__ballot(cls == 0));
-        c1 += __popcll(__ballot(cls == 1));
-    }
-    int o[3] = {R0, R0 + c0, R0 + c0 + c1};
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    for (int c = start; c < end; c += 64) {
-        const int i = c + lane;
-        const bool h = i < end && hit[i] != 0;
-        const int cls = h ? row_class(bmask[i]) : 3;
-        const unsigned long long b0 = __ballot(cls == 0), b1 = __ballot(cls == 1), b2 = __ballot(cls == 2);
-        if (h) {
-            const int row = cls == 0 ? o[0] + __popcll(b0 & lt) : (cls == 1 ? o[1] + __popcll(b1 & lt) : o[2] + __popcll(b2 & lt));
-            trow2[i] = row;
-            sor[row] = make_int4(-1, -1, -1, -1);
-        }
-        o[0] += __popcll(b0); o[1] += __popcll(b1); o[2] += __popcll(b2);
-    }
-}
-
-__global__ __launch_bounds__(64) void slot_rows_ordered_kernel(int n_tiles, int n_isects, const int32_t *__restrict__ offsets,
-                                                               const int32_t *__restrict__ blk_rows,
-                                                               const int32_t *__restrict__ sidx_s,
-                                                               const int32_t *__restrict__ trow2, int32_t *__restrict__ trow_s,
-                                                               int32_t *__restrict__ sor)
-{
-    const int tile = blockIdx.x >> 2, blk = blockIdx.x & 3;
-    const int cnt = blk_rows[blockIdx.x];
-    const int start = offsets[tile];
-    const int end = offsets[tile + 1];
-    const int sb = gags_slot_base(start, end, tile, blk);
-    for (int j = threadIdx.x; j < cnt; j += 64) {
-        const int sx = sidx_s[sb + j];
-        const int row = sx >= 0 ? trow2[sx] : 0x7fffffff;
-        trow_s[sb + j] = row;
-        if (sx >= 0) sor[4 * (size_t)row + blk] = j;
     }
 }
 
@@ -895,28 +827,13 @@ int gags_bwd_slot_rows_launch(int width, int height, int n_isects, const int32_t
     return GAGS_OK;
 }
 
-int gags_bwd_rows_ordered_launch(int width, int height, int n_isects, const int32_t *offsets, const int32_t *blk_rows,
-                                 const int32_t *sidx_s, const int32_t *hit, const uint8_t *bmask, const int32_t *trow,
-                                 int32_t *trow_s, int32_t *trow2, int32_t *sor, hipStream_t st)
-{
-    GAGS_CLEAR_ERR();
-    const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
-    const int n_tiles = tile_w * tile_h;
-    hipLaunchKernelGGL(tile_rows_ordered_kernel, dim3(n_tiles), dim3(64), 0, st, n_tiles, offsets, hit,
-                       reinterpret_cast<const uint32_t *>(bmask), trow, trow2, reinterpret_cast<int4 *>(sor));
-    hipLaunchKernelGGL(slot_rows_ordered_kernel, dim3(n_tiles * GAGS_BLOCKS_PER_TILE), dim3(64), 0, st, n_tiles, n_isects, offsets,
-                       blk_rows, sidx_s, trow2, trow_s, sor);
-    GAGS_CHECK_LAUNCH();
-    return GAGS_OK;
-}
-
 // 1 = width not eligible
 int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, const int32_t *offsets, int n_isects,
                                   const float *v_out, const int32_t *blk_rows, const int32_t *trow, int64_t rows,
                                   const float *wt, const int32_t *gid_s, const int32_t *trow_s, void *scratch,
                                   int64_t scratch_bytes, float *v_colors, int stage_flags, int ch_begin, int ch_count,
                                   const int32_t *rows_dev, const int32_t *wire_pos, float *wire, const uint8_t *keep_prev,
-                                  uint8_t *keep_cur, const int32_t *sor, hipStream_t st)
+                                  uint8_t *keep_cur, hipStream_t st)
 {
     // stage: 0 = everything; 1 = rows, 2 = sort + segment offsets, 3 = reduce (per-kernel timing)
     GAGS_CLEAR_ERR();
@@ -949,19 +866,6 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
                        v_out, offsets, n_isects, blk_rows, trow, wt, gid_s, trow_s, prow, pp, key, idx, (int)rows)
             int c = ch_begin;
             const int ce = ch_begin + ch_count;
-            if (sor) {  // class-ordered rows (stage bit 2048, gags_bwd_rowmap_ordered): whole 128-channel slices, the default arithmetic
-                if ((ce - c) % 128 != 0 || (stage_flags & (32 | 512))) return GAGS_EINVAL;
-                const int nsl = (ce - c) / 128;
-                if (stage_flags & 1024)
-                    hipLaunchKernelGGL((raster_bwd_rows_cwo<3, 5>), dim3(n_tiles * nsl), dim3(256), 0, st, d, width, height, tile_w, n_tiles, c, nsl,
-                                       v_out, offsets, n_isects, blk_rows, trow, wt, gid_s, trow_s, prow, pp, key, idx, (int)rows,
-                                       reinterpret_cast<const int4 *>(sor));
-                else
-                    hipLaunchKernelGGL((raster_bwd_rows_cwo<2, 3>), dim3(n_tiles * nsl), dim3(256), 0, st, d, width, height, tile_w, n_tiles, c, nsl,
-                                       v_out, offsets, n_isects, blk_rows, trow, wt, gid_s, trow_s, prow, pp, key, idx, (int)rows,
-                                       reinterpret_cast<const int4 *>(sor));
-                c = ce;
-            }
             if (ce - c >= 128) {
                 const int nsl = (ce - c) / 128;
                 if (stage_flags & 32) GAGS_ROWS_LAUNCH(raster_bwd_rows<4>, c, nsl);  // GAGS_BWD_F32MFMA: the fp32 matrix instructions

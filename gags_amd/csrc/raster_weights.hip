@@ -71,7 +71,7 @@ __global__ __launch_bounds__(64, 8) void raster_weights_kernel(
     const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids, int n_isects,
     float *__restrict__ wt, int32_t *__restrict__ gid_s, int32_t *__restrict__ sidx_s, int32_t *__restrict__ hit,
     int32_t *__restrict__ blk_rows, float *__restrict__ Tbuf, float *__restrict__ render_alphas,
-    int32_t *__restrict__ last_ids, int by_gauss, int32_t *__restrict__ need, uint8_t *__restrict__ bmask)
+    int32_t *__restrict__ last_ids, int by_gauss, int32_t *__restrict__ need)
 {
     __shared__ __attribute__((aligned(16))) HRec ring[RING];
 
@@ -138,7 +138,6 @@ __global__ __launch_bounds__(64, 8) void raster_weights_kernel(
                     gid_s[pos] = gid_c;
                     sidx_s[pos] = sidx_c;
                     hit[sidx_c] = 1;  // up to four blocks store the same 1
-                    if (bmask) bmask[4 * (size_t)sidx_c + blk] = 1;  // ... and each its own byte: WHICH blocks of the tile the row touches
                 }
             }
             row += (int)nz0 + (int)nz1;
@@ -202,17 +201,16 @@ int gags_pack_isects_launch(int n, int n_isects, const int32_t *flat, const floa
 int gags_raster_weights_launch(int width, int height, int n_gauss, const void *packed, int by_gauss, const int32_t *offsets,
                                const int32_t *flat, int n_isects, float *wt, int32_t *gid_s, int32_t *sidx_s,
                                int32_t *hit, int32_t *blk_rows, float *Tbuf, float *alphas, int32_t *last_ids,
-                               uint8_t *bmask, hipStream_t st)
+                               hipStream_t st)
 {
     GAGS_CLEAR_ERR();
     const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
     const int n_tiles = tile_w * tile_h;
     // hit[i] = 1 for every intersection that blends into at least one pixel of its tile (+1 entry: an empty view)
     if (hipMemsetAsync(hit, 0, sizeof(int32_t) * ((size_t)n_isects + 1), st) != hipSuccess) return GAGS_ELAUNCH;
-    if (bmask && hipMemsetAsync(bmask, 0, 4 * (size_t)n_isects, st) != hipSuccess) return GAGS_ELAUNCH;
     hipLaunchKernelGGL(raster_weights_kernel<false>, dim3(n_tiles * GAGS_BLOCKS_PER_TILE), dim3(64), 0, st, width, height, tile_w, n_tiles,
                        n_gauss, reinterpret_cast<const GRec *>(packed), offsets, flat, n_isects, wt, gid_s, sidx_s, hit,
-                       blk_rows, Tbuf, alphas, last_ids, by_gauss, (int32_t *)nullptr, bmask);
+                       blk_rows, Tbuf, alphas, last_ids, by_gauss, (int32_t *)nullptr);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }
@@ -260,7 +258,7 @@ int gags_list_need_launch(int width, int height, int n_gauss, const void *packed
     hipLaunchKernelGGL(raster_weights_kernel<true>, dim3(n_tiles * GAGS_BLOCKS_PER_TILE), dim3(64), 0, st, width, height, tile_w, n_tiles,
                        n_gauss, reinterpret_cast<const GRec *>(packed), offsets, flat, n_isects, (float *)nullptr, (int32_t *)nullptr,
                        (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (float *)nullptr, (float *)nullptr,
-                       (int32_t *)nullptr, by_gauss, need, (uint8_t *)nullptr);
+                       (int32_t *)nullptr, by_gauss, need);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }

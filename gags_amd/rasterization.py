@@ -40,8 +40,6 @@ GRAD_RANGE_CHANNELS = 128
 # earliest by one launch per range (DESIGN.md section 6 has the arithmetic; bench.py reports both).
 GRAD_ROWS_GROUP = 128
 PROW_MAX_BYTES = 24 << 30  # staged backward: partial rows beyond this are produced per 128-channel range (see _backward_staged)
-# Class-ordered tile rows in the staged backward (gags_bwd_rowmap_ordered + stage bit 2048; RasterContext.ordered_rows)
-ORDERED_ROWS = os.environ.get("GAGS_BWD_ORDERED", "0") == "1"
 # List trimming (RasterContext.trim_lists; _trim_lists): None = automatic, for views whose forward scratch would exceed
 # TRIM_AUTO_BYTES; True / False force it on / off (GAGS_TRIM_LISTS=1 / 0)
 TRIM_LISTS = {"1": True, "0": False}.get(os.environ.get("GAGS_TRIM_LISTS", ""), None)
@@ -107,8 +105,6 @@ class RasterContext:
         self.k_cache = {}
         self._pinned = {}
         self._side = {}
-        # staged backward: a tile's rows numbered by the blocks they touch, blocks without a row in a chunk skipped (bit-identical)
-        self.ordered_rows = ORDERED_ROWS
         # list trimming for heavy views (_trim_lists): None = automatic above TRIM_AUTO_BYTES of forward scratch
         self.trim_lists = TRIM_LISTS
         # persistent gradient buffer of the colours-only backward (_KeptGrad): on unless GAGS_KEEP_GRAD=0
@@ -695,24 +691,18 @@ def _backward_staged(lib, rctx, offsets, n_isects, blk_rows, fwd_scratch, v_out,
         check(lib.gags_blended_mask(n_isects, width, height, n, ptr(flatten_ids), ptr(fwd_scratch), fwd_scratch.numel(),
                                     ptr(mask), st), "gags_blended_mask")
         rctx.grad_rows_hook(mask)  # before the readback below: the ranks agree on the union while the backward starts
-    hook = rctx.grad_range_hook
-    ranges = _channel_ranges(d, rctx.grad_range_channels) if hook is not None else None
-    cap_key = (n, width, height, dev.index)
-    pending = None
-    # class-ordered rows: every rows launch of this backward must be the channel-wave kernel on whole 128-channel slices
-    ordered = bool(rctx.ordered_rows and n_isects > 0 and d % 128 == 0 and not (xflag & (32 | 512))
-                   and (ranges is None or all((c1 - c0) % 128 == 0 for c0, c1 in ranges)))
-    if ordered:
-        xflag |= 2048
-    ne = (lib.gags_bwd_rowmap_elems_ordered if ordered else lib.gags_bwd_rowmap_elems)(n_isects, width, height)
+    ne = lib.gags_bwd_rowmap_elems(n_isects, width, height)
     trow = torch.empty(ne, dtype=torch.int32, device=dev)
     total = torch.empty(1, dtype=torch.int32, device=dev)
     sb = lib.gags_bwd_rowmap_scratch_bytes(n_isects)
     stmp = torch.empty(max(sb, 4), dtype=torch.uint8, device=dev)
+    hook = rctx.grad_range_hook
+    ranges = _channel_ranges(d, rctx.grad_range_channels) if hook is not None else None
+    cap_key = (n, width, height, dev.index)
+    pending = None
     with profiler.stage("bwd_rowcount"):
-        check((lib.gags_bwd_rowmap_ordered if ordered else lib.gags_bwd_rowmap)(
-            n_isects, width, height, ptr(offsets), ptr(blk_rows), ptr(fwd_scratch), fwd_scratch.numel(), ptr(trow), ne,
-            ptr(total), ptr(stmp), sb, st), "gags_bwd_rowmap")
+        check(lib.gags_bwd_rowmap(n_isects, width, height, ptr(offsets), ptr(blk_rows), ptr(fwd_scratch),
+                                  fwd_scratch.numel(), ptr(trow), ne, ptr(total), ptr(stmp), sb, st), "gags_bwd_rowmap")
         if rctx.capacity_mode and hook is None and cap_key in rctx.cap_rows and not exact_rows:
             # capacity mode (see RasterContext): the row count stays on the device until the backward is enqueued
             rows = min(max(n_isects, 1), int(rctx.cap_rows[cap_key] * CAP_MARGIN) + 1024)
@@ -817,7 +807,7 @@ def _backward_staged(lib, rctx, offsets, n_isects, blk_rows, fwd_scratch, v_out,
         true_rows = pending.get()
         if true_rows > rows:  # more rows than the remembered capacity (none was stored out of bounds): again, exact
             rctx.cap_rows[cap_key] = true_rows
-            return _backward_staged(lib, rctx, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height, xflag & ~(128 | 2048),
+            return _backward_staged(lib, rctx, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height, xflag & ~128,
                                     flatten_ids, None, exact_rows=True)
         rows = true_rows
     if hook is None and rctx.capacity_mode:

@@ -270,16 +270,6 @@ int gags_raster_bwd_geom(int d, int n, int width, int height, const float *color
  * exchanges only the union of these rows over the ranks (gags_amd/dist.py; SURVEY 8e "gradients are sparse in rows"). */
 int gags_blended_mask(int64_t n_isects, int width, int height, int n, const int32_t *flatten_ids,
                       const void *fwd_scratch, int64_t fwd_scratch_bytes, unsigned char *mask, void *stream);
-/* Class-ordered tile rows (round 6): gags_bwd_rowmap with the rows of a tile numbered by the blocks they touch -- upper blocks
- * only, mixed, lower blocks only -- instead of by depth, plus, per row, its slot offset in each of the tile's four blocks.  The
- * staged entries take such a rowmap with stage bit 2048 (whole 128-channel slices, the default or the exact-weight arithmetic:
- * not with bits 32 / 512) and skip the blocks no row of a chunk touches: same gradient bit for bit, 15 % fewer products at C3.
- * rowmap: gags_bwd_rowmap_elems_ordered(...) int32; the forward must have run since round 6 (it records the touched blocks). */
-int64_t gags_bwd_rowmap_elems_ordered(int64_t n_isects, int width, int height);
-int gags_bwd_rowmap_ordered(int64_t n_isects, int width, int height, const int32_t *isect_offsets,
-                            const int32_t *blk_rows, const void *fwd_scratch, int64_t fwd_scratch_bytes,
-                            int32_t *rowmap, int64_t rowmap_elems, int32_t *total, void *scratch,
-                            int64_t scratch_bytes, void *stream);
 int64_t gags_bwd_staged_scratch_bytes(int64_t rows, int n, int d);
 int gags_raster_bwd_colors_staged(int d, int n, int width, int height, const int32_t *isect_offsets,
                                   int64_t n_isects, const float *v_render_colors,

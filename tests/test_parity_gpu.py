@@ -1298,48 +1298,3 @@ def test_trimmed_lists_change_nothing(oracle, n, w, h, d, mult, geom):
                                               s["K"], bg, w, h)
     _check_indices(i1, oi)
     np.testing.assert_array_equal(a1, o_alpha)
-
-
-@pytest.mark.parametrize("w,h,n,d,scale", [(200, 138, 6000, 256, 5.0), (64, 48, 300, 128, 1.0), (333, 77, 20000, 384, 12.0),
-                                           (160, 160, 3000, 640, 3.0), (48, 33, 40, 128, 20.0), (256, 192, 30000, 512, 2.0)])
-def test_class_ordered_rows_give_the_same_bits(w, h, n, d, scale):
-    """Round 6: gags_bwd_rowmap_ordered numbers a tile's partial gradient rows by the blocks they touch (upper blocks only,
-    mixed, lower blocks only) and raster_bwd_rows_cwo skips the blocks no row of a 32-row chunk touches.  A row's value does not
-    depend on its number and a Gaussian's rows are still summed in tile order: the gradient is bit-identical to the
-    depth-ordered numbering's -- default arithmetic and exact three-term weights, ragged borders, empty tiles, one to many chunks
-    per tile, range-staged (by-view hooks) and through a range-sized scratch."""
-    from gags_amd import _lib, rasterization, synthetic as syn
-    from gags_amd.gaussian_renderer import render
-    from gags_amd.rasterization import RasterContext
-    dev = torch.device("cuda", 0)
-    pc = syn.make_model(n, d, w, h, seed=4, device=dev, scale0=syn.SCALE0 * scale)
-    pc.training_setup()
-    cam = syn.make_camera(w, h, view=1, device=dev)
-    G = syn.make_cotangent(d, h, w, seed=2, device=dev)
-    bg = torch.zeros(3, device=dev)
-
-    def grad(ctx, fl=0):
-        pc._semantic_feature.grad = None
-        (render(cam, pc, None, bg, feature_mode=True, raster_flags=fl, context=ctx)["render"] * G).sum().backward()
-        return pc._semantic_feature.grad.clone()
-
-    plain, ordered = RasterContext(), RasterContext()
-    plain.ordered_rows, ordered.ordered_rows = False, True
-    for fl in (0, _lib.GAGS_BWD_EXACT_WEIGHTS):
-        ref = grad(plain, fl)
-        assert float(ref.abs().max()) > 0
-        assert torch.equal(grad(ordered, fl), ref), fl
-        assert torch.equal(grad(ordered, fl), ref), fl  # (the persistent buffer's second step)
-    ref = grad(plain)
-    if d > 128:  # range by range, as the by-view exchange asks for it
-        seen = []
-        ordered.grad_range_hook = lambda g, c0, c1: seen.append((c0, c1))
-        ordered.grad_range_channels = 128
-        assert torch.equal(grad(ordered), ref) and len(seen) == d // 128
-        ordered.grad_range_hook = None
-        old = rasterization.PROW_MAX_BYTES
-        rasterization.PROW_MAX_BYTES = 1  # ... and through the [rows, 128] scratch of heavy views
-        try:
-            assert torch.equal(grad(ordered), ref)
-        finally:
-            rasterization.PROW_MAX_BYTES = old
