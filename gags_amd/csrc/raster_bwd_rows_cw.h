@@ -55,32 +55,21 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_cw(
     const int n = lane & 31, k = lane >> 5;
     const int logical = gags_xcd_remap(blockIdx.x, n_tiles * n_slices);
     const int tile = gags_tile_of_order(logical / n_slices, tile_w, n_tiles / tile_w);
-    const int start = offsets[tile];
-    const int end = offsets[tile + 1];
-    const int R0 = trow[start], R1 = trow[end];
-    if (R1 == R0) return;
-    const int blk = wave;  // the block whose weight rows this wave prepares
-    const int cnt = blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk];
-    const int sb = gags_slot_base(start, end, tile, blk);
-    // a slot of this tile that the forward certainly WROTE: the first slot of its first non-empty block (R1 > R0: some
-    // intersection blended, so some block holds its slot).  Rows a block does not hold read it and get the scale 0; an
-    // unwritten slot (allocator garbage: the scratch is never cleared) could hold NaN / Inf bit patterns, and 0 * NaN = NaN
-    int dummy_sb;
-    {
-        const int32_t *br = blk_rows + tile * GAGS_BLOCKS_PER_TILE;
-        const int bf = br[0] > 0 ? 0 : (br[1] > 0 ? 1 : (br[2] > 0 ? 2 : 3));
-        dummy_sb = gags_slot_base(start, end, tile, bf);
-    }
     const int ch0 = ch_base + (logical % n_slices) * CW;
     const int chw = ch0 + 32 * wave + n;  // this lane's channel: column n of the wave's B operands and of its rows
     const int ty = tile / tile_w, tx = tile - ty * tile_w;
-
+    // The workgroup's life opens with dependent round trips -- the tile's list bounds, the rows they name, the blocks' slot
+    // counts, the first key window, the first weight rows -- and with the 128 KB cotangent slab, whose addresses need nothing
+    // but the tile's position.  So the slab is requested FIRST, before anything is known about the tile, and the metadata
+    // chain (scalar loads: their own counter) runs underneath it; a tile without rows (returns below) has asked for bytes it
+    // does not use.  Round 6: the chain used to run ahead of the slab -- five scalar round trips of 0.5-2 us under load per
+    // ~36 us workgroup.
     // cotangent slab: B operands of the wave's 32 channels for the four blocks; K element e = 16 s + 8 k + i of a weight
     // row = pixel e >> 1 of the 8x4 half e & 1 (raster_weights.hip)
     f16x8 Bh[4][4], Bl[4][4];
     float inv_cs;  // ONE column scale per channel for the whole tile (256 pixels): the four blocks share an unscale
+    float raw[4][4][8];
     {
-        float raw[4][4][8];
         // pixel of K element e = 16 s + 8 k + i: row s (+ 4 for odd i) of the block, column 4 k + (i >> 1): the row is the
         // same for the whole wave, the column differs by the half-wave only -- inside the image the 128 addresses are one
         // per-lane offset plus wave-uniform terms (scalar registers / immediates); tiles cut by the image border clamp
@@ -113,23 +102,24 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_cw(
                     }
             }
         }
-        float mx = 0.f;
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) mx = fmaxf(mx, fabsf(raw[b][s4][i]));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        // (exponent clamped: below 2^-112 the scale would overflow to inf -- v * inf, 0 * inf = NaN; such a column keeps 2^126)
-        const float cs = (mx > 0.f && mx < 3.0e38f) ? ldexpf(1.0f, min(14 - ilogbf(mx), 126)) : 1.0f;
-        inv_cs = 1.0f / cs;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) split8(raw[b][s4], cs, Bh[b][s4], Bl[b][s4]);
-            __builtin_amdgcn_sched_barrier(0);  // block after block, in place: 128 raw values become 128 registers of terms
-        }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // (the slab's loads stay ahead of the metadata chain)
+    const int start = offsets[tile];
+    const int end = offsets[tile + 1];
+    // the four blocks' slot counts in ONE 16-byte scalar load (tile * 4 ints: aligned)
+    const int4 br4 = *reinterpret_cast<const int4 *>(blk_rows + (size_t)tile * GAGS_BLOCKS_PER_TILE);
+    const int R0 = trow[start], R1 = trow[end];
+    if (R1 == R0) return;
+    const int blk = wave;  // the block whose weight rows this wave prepares
+    const int cnt = blk == 0 ? br4.x : (blk == 1 ? br4.y : (blk == 2 ? br4.z : br4.w));
+    const int sb = gags_slot_base(start, end, tile, blk);
+    // a slot of this tile that the forward certainly WROTE: the first slot of its first non-empty block (R1 > R0: some
+    // intersection blended, so some block holds its slot).  Rows a block does not hold read it and get the scale 0; an
+    // unwritten slot (allocator garbage: the scratch is never cleared) could hold NaN / Inf bit patterns, and 0 * NaN = NaN
+    int dummy_sb;
+    {
+        const int bf = br4.x > 0 ? 0 : (br4.y > 0 ? 1 : (br4.z > 0 ? 2 : 3));
+        dummy_sb = gags_slot_base(start, end, tile, bf);
     }
 
     // bookkeeping of a chunk [r0, r0 + 32): which of the block's slots hold its rows (the block's list is ascending)
@@ -142,6 +132,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_cw(
             gid = gid_s[sb + first + n];
         }
     };
+    fetch_keys(0);
     float A[32];
     bool present = false;
     auto open_chunk = [&](int r0) __attribute__((always_inline)) {
@@ -171,8 +162,27 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_cw(
         pb += run;
         fetch_keys(pb);
     };
-    fetch_keys(0);
-    open_chunk(R0);
+    open_chunk(R0);  // (the first chunk's weight rows travel under the slab's conversion)
+    {
+        float mx = 0.f;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) mx = fmaxf(mx, fabsf(raw[b][s4][i]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        // (exponent clamped: below 2^-112 the scale would overflow to inf -- v * inf, 0 * inf = NaN; such a column keeps 2^126)
+        const float cs = (mx > 0.f && mx < 3.0e38f) ? ldexpf(1.0f, min(14 - ilogbf(mx), 126)) : 1.0f;
+        inv_cs = 1.0f / cs;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) split8(raw[b][s4], cs, Bh[b][s4], Bl[b][s4]);
+            __builtin_amdgcn_sched_barrier(0);  // block after block, in place: 128 raw values become 128 registers of terms
+        }
+    }
+
 
     const uint4 *At_l = &At[0][0][0][lane];  // this lane's 16 bytes of a (block, term, K-step): 64 uint4 per K-step
     for (int r0 = R0; r0 < R1; r0 += 32) {

@@ -13,6 +13,7 @@
 // epilogue stores 16 B per lane.  All D channels of a slice are composited in ONE walk of the list
 // (gsplat re-walks it ceil(D/32) times).
 #include <hip/hip_fp16.h>
+#include <cstdlib>
 #include <type_traits>
 #include "raster_mfma_common.h"
 
@@ -498,19 +499,26 @@ __device__ __forceinline__ unsigned row_bcast_add(unsigned v, unsigned add)
 
 // BIG: the table does not fit 32-bit byte offsets (N D 4 >= 2^32; halves: N D 2): offsets in elements, widened per gather
 // HALF: `colors` is an fp16 table (two-term B operands, five product terms: above)
-template <bool BIG, bool HALF>
+// BG: the view has a background (its rows take background * final transmittance; both parked in LDS during the K loops)
+template <bool BIG, bool HALF, bool BG>
 __global__ __launch_bounds__(64, 2) void raster_fwd_feat_x16(
-    int d, int width, int height, int tile_w, int n_tiles, int n_slices, int n_gauss,
+    int d, int width, int height, int tile_w, int n_tiles, int n_slices, int spw, int n_gauss,
     const float *__restrict__ colors, const float *__restrict__ backgrounds, const int32_t *__restrict__ offsets,
     int n_isects, const int32_t *__restrict__ blk_rows, const float *__restrict__ wt,
     const int32_t *__restrict__ gid_s, const float *__restrict__ Tbuf, float *__restrict__ render_colors)
 {
     constexpr int NB = 4, CS = 128;
-    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * GAGS_BLOCKS_PER_TILE * n_slices);
-    const int slice = logical % n_slices, rest = logical / n_slices;
+    GAGS_STAMP(0);
+    // A wave serves `spw` consecutive 128-channel slices of its (tile, block) one after the other (round 6): a wave's life
+    // opens with three dependent round trips -- list bounds and slot count, the ids of step 0, its gathered rows: ~9 us of a
+    // 37 us wave under load (tools/probe/feat16_probe.py) -- and a later slice of the same block needs none of them: its
+    // first rows are requested during the last step of the slice before and travel under that slice's stores.
+    const int n_groups = n_slices / spw;
+    const int logical = gags_xcd_remap(blockIdx.x, n_tiles * GAGS_BLOCKS_PER_TILE * n_groups);
+    const int grp = logical % n_groups, rest = logical / n_groups;
     const int blk = rest & 3;
     const int tile = gags_tile_of_order(rest >> 2, tile_w, n_tiles / tile_w);
-    const int ch0 = slice * CS;
+    const int ch_first = grp * spw * CS;
     const int lane = threadIdx.x;
     BlockGeom64 g;
     g.init(tile, blk, tile_w, width, height, lane);
@@ -520,20 +528,31 @@ __global__ __launch_bounds__(64, 2) void raster_fwd_feat_x16(
     const int sb = gags_slot_base(start, end, tile, blk);
     const int cnt = blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk];  // even
     const int steps = (cnt + 15) >> 4;
+#ifdef GAGS_PROBE
+    if (gags_probe_buf && threadIdx.x == 0) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        gags_probe_buf[(size_t)blockIdx.x * 8 + 6] = hw;
+        gags_probe_buf[(size_t)blockIdx.x * 8 + 7] = (unsigned)steps;  // (needs the metadata: stamp 1 = it has arrived)
+    }
+    GAGS_STAMP(1);
+#endif
 
     // The epilogue's inputs are requested first (see raster_fwd_feat) -- the final transmittance of the lane's OWN two
-    // pixels and the background of its channels -- and parked in LDS for the duration of the K loop, which needs every
-    // register (the epilogue then fetches the pixels of its accumulator rows from the lanes that own them: ds_bpermute).
-    __shared__ __attribute__((aligned(16))) float park[6 * 64];
-    const bool has_bg = backgrounds != nullptr;  // wave-uniform
-    {
-        float bgv0[NB];
-        fetch_bg<NB>(bgv0, backgrounds, ch0, p, d);
+    // pixels and the background of its channels -- and parked in LDS for the duration of the K loops, which need every
+    // register (the epilogue then reads the pixels of its accumulator rows from the lanes that own them).
+    constexpr int MAX_SPW = 4;
+    __shared__ __attribute__((aligned(16))) float park[BG ? (4 * MAX_SPW + 2) * 64 : 4];
+    if constexpr (BG) {
+        for (int j = 0; j < spw; ++j) {
+            float bgv0[NB];
+            fetch_bg<NB>(bgv0, backgrounds, ch_first + j * CS, p, d);
+            *reinterpret_cast<float4 *>(park + 256 * j + 4 * lane) = make_float4(bgv0[0], bgv0[1], bgv0[2], bgv0[3]);
+        }
         const int pjc = min(g.pj, width - 1);
-        const float tA = has_bg ? Tbuf[(size_t)min(g.piA, height - 1) * width + pjc] : 0.f;
-        const float tB = has_bg ? Tbuf[(size_t)min(g.piB, height - 1) * width + pjc] : 0.f;
-        *reinterpret_cast<float4 *>(park + 4 * lane) = make_float4(bgv0[0], bgv0[1], bgv0[2], bgv0[3]);
-        *reinterpret_cast<float2 *>(park + 256 + 2 * lane) = make_float2(tA, tB);
+        const float tA = Tbuf[(size_t)min(g.piA, height - 1) * width + pjc];
+        const float tB = Tbuf[(size_t)min(g.piB, height - 1) * width + pjc];
+        *reinterpret_cast<float2 *>(park + 256 * MAX_SPW + 2 * lane) = make_float2(tA, tB);
     }
 
     f32x16 accA[NB], accB[NB];
@@ -541,6 +560,56 @@ __global__ __launch_bounds__(64, 2) void raster_fwd_feat_x16(
     for (int j = 0; j < NB; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { accA[j][r] = 0.f; accB[j][r] = 0.f; }
+
+    // accumulator row r of lane (p, k) is pixel q = (r & 3) + 8 (r >> 2) + 4 k of a 8x4 half; its transmittance was parked by lane q
+    // Stores of a slice: row r of the accumulators is pixel (by0 + 4 hb + (r >> 2), bx0 + 4 k + (r & 3)) of the image -- a
+    // wave-uniform address (scalar registers) plus ONE per-lane offset; an image border cuts whole rows (uniform test) and
+    // the columns of a half-wave (four lane masks).  The next slice's first rows and weights are in flight meanwhile.
+    auto finish_slice = [&](int j) __attribute__((always_inline)) {
+        const int ch0 = ch_first + j * CS;
+        // (opaque copies: everything below is computed HERE, from three scalars -- left to the optimiser the sixteen row
+        // offsets and four column masks are hoisted out of the slice loop and live through the K loops in registers they need)
+        // (the lane id from mbcnt on an opaque mask: a thread id kept in a register through the K loops is one register too
+        // many -- its reload from scratch would wait for the next slice's rows, which are in flight here)
+        int w_ = width, d_ = d;
+        unsigned ones = ~0u;
+        asm volatile("" : "+s"(w_), "+s"(d_), "+s"(ones));
+        const int ln = (int)__builtin_amdgcn_mbcnt_hi(ones, __builtin_amdgcn_mbcnt_lo(ones, 0u));
+        const int kk = ln >> 5, pp = ln & 31;
+        const unsigned store_off = (unsigned)((4 * kk) * d_ + 4 * pp) * 4u;
+        const unsigned row_stride = (unsigned)w_ * (unsigned)d_ * 4u, px_stride = (unsigned)d_ * 4u;
+        bool col_ok[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) col_ok[c] = g.bx0 + 4 * kk + c < w_;
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            float Tq[16], bgv[NB];
+            if constexpr (BG) {
+                const float4 b4 = *reinterpret_cast<const float4 *>(park + 256 * j + 4 * ln);
+                bgv[0] = b4.x; bgv[1] = b4.y; bgv[2] = b4.z; bgv[3] = b4.w;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Tq[r] = park[256 * MAX_SPW + 2 * ((r & 3) + 8 * (r >> 2) + 4 * kk) + hb];
+            }
+            const char *blk_base = reinterpret_cast<const char *>(render_colors) +
+                                   (((size_t)(g.by0 + 4 * hb) * w_ + g.bx0) * d_ + ch0) * 4;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (g.by0 + 4 * hb + (r >> 2) >= height) continue;  // (uniform)
+                const unsigned uo = (unsigned)(r >> 2) * row_stride + (unsigned)(r & 3) * px_stride;  // (< 2^32: four rows of the image)
+                float4 v = hb ? make_float4(accB[0][r], accB[1][r], accB[2][r], accB[3][r])
+                              : make_float4(accA[0][r], accA[1][r], accA[2][r], accA[3][r]);
+                if constexpr (BG) {
+                    v.x = __builtin_fmaf(Tq[r], bgv[0], v.x); v.y = __builtin_fmaf(Tq[r], bgv[1], v.y);
+                    v.z = __builtin_fmaf(Tq[r], bgv[2], v.z); v.w = __builtin_fmaf(Tq[r], bgv[3], v.w);
+                }
+                if (col_ok[r & 3]) *reinterpret_cast<float4 *>(const_cast<char *>(blk_base) + (size_t)uo + store_off) = v;
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < NB; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accA[jj][r] = 0.f; accB[jj][r] = 0.f; }
+    };
 
     if (steps > 0) {
         const unsigned gmax = (unsigned)(n_gauss - 1);
@@ -550,17 +619,23 @@ __global__ __launch_bounds__(64, 2) void raster_fwd_feat_x16(
         auto load_ids = [&](int s) {
             return *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(gid_s) + (id_off + 64u * (unsigned)s));
         };
-        const float *wp = wt + (size_t)(sb + 8 * k) * 64 + 2 * p;
+        // (a wave-uniform base in scalar registers + ONE 32-bit per-lane offset: a 64-bit per-lane pointer is two registers
+        // the K loop does not have)
+        const char *wbase = reinterpret_cast<const char *>(wt) + (size_t)sb * 256;
+        const unsigned w_off = (unsigned)(8 * k * 64 + 2 * p) * 4u;
         auto load_w = [&](int s, float2 (&w)[8]) {
-            const float *src = wp + (size_t)s * (16 * 64);
+            const char *src = wbase + (size_t)s * (16 * 256);
+            unsigned wo = w_off;
+            asm volatile("" : "+v"(wo));  // (opaque: keeps `wbase + w_off` from being hoisted as a 64-bit per-lane pointer)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) w[i] = *reinterpret_cast<const float2 *>(src + i * 64);
+            for (int i = 0; i < 8; ++i) w[i] = *reinterpret_cast<const float2 *>(src + wo + i * 256);
         };
         constexpr unsigned ESZ = HALF ? 2u : 4u;  // bytes per table element
         using Row = typename std::conditional<HALF, uint2, float4>::type;  // the lane's four channels of one row
-        const unsigned lane_off = BIG ? (unsigned)(ch0 + 4 * p) : (unsigned)(ch0 + 4 * p) * ESZ;
+        const unsigned lane_off0 = BIG ? (unsigned)(ch_first + 4 * p) : (unsigned)(ch_first + 4 * p) * ESZ;
+        const unsigned slice_off = BIG ? (unsigned)CS : (unsigned)CS * ESZ;
         const unsigned row_pitch = BIG ? (unsigned)d : (unsigned)d * ESZ;
-        auto load_f = [&](unsigned idv, Row (&f)[8]) {  // channels ch0 + 4 p .. + 3 of the eight rows
+        auto load_f = [&](unsigned idv, Row (&f)[8], unsigned lane_off) {  // channels ch0 + 4 p .. + 3 of the eight rows
             const unsigned ro = min(idv, gmax) * row_pitch;  // (the zero slots carry id N)
             const unsigned o[8] = {row_bcast_add<0>(ro, lane_off), row_bcast_add<1>(ro, lane_off), row_bcast_add<2>(ro, lane_off),
                                    row_bcast_add<3>(ro, lane_off), row_bcast_add<4>(ro, lane_off), row_bcast_add<5>(ro, lane_off),
@@ -576,11 +651,21 @@ __global__ __launch_bounds__(64, 2) void raster_fwd_feat_x16(
         Row F[8];
         float2 W[8];
         unsigned id1, id2;
+        // the steps of the wave's slices form ONE sequence: (slice 0, step 0 .. steps - 1), (slice 1, step 0 ..), ...; the
+        // ids and weights of a step do not depend on the slice, so the prefetches simply wrap around (behind the last slice:
+        // redundant loads of valid addresses, as the clamped ones were)
         load_w(0, W);
-        load_f(load_ids(0), F);
-        id1 = load_ids(min(1, steps - 1));
-        id2 = load_ids(min(2, steps - 1));
-        auto step = [&](int s) {
+        load_f(load_ids(0), F, lane_off0);
+        int s3 = 1 % steps;  // step whose ids are requested next
+        id1 = load_ids(s3);
+        s3 = s3 + 1 == steps ? 0 : s3 + 1;
+        id2 = load_ids(s3);
+        s3 = s3 + 1 == steps ? 0 : s3 + 1;
+        GAGS_STAMP(2);  // ids of step 0 arrived, its rows and weights requested
+        auto step = [&](int s, int j) {
+#ifdef GAGS_PROBE
+            if (s == 1 && j == 0) GAGS_STAMP(3);  // step 0 multiplied: its operands had landed
+#endif
             // A operands: the weights of the lane's pixel pair for its eight slots
             Op3 aA, aB;
             {
@@ -633,38 +718,34 @@ __global__ __launch_bounds__(64, 2) void raster_fwd_feat_x16(
                 else mfma6(acc, a, bb);
             };
             __builtin_amdgcn_sched_barrier(0);
-            load_f(id1, F);
+            {
+                const bool wrap = s + 1 == steps;
+                const int jn = (wrap && j + 1 < spw) ? j + 1 : j;  // slice of the next step of the sequence
+                load_f(id1, F, lane_off0 + (unsigned)jn * slice_off);
+            }
             id1 = id2;
-            id2 = load_ids(min(s + 3, steps - 1));
+            id2 = load_ids(s3);
+            s3 = s3 + 1 == steps ? 0 : s3 + 1;
             __builtin_amdgcn_sched_barrier(0);
             mm(accA[0], aA, b[0]); mm(accB[0], aB, b[0]);
             mm(accA[1], aA, b[1]); mm(accB[1], aB, b[1]);
             __builtin_amdgcn_sched_barrier(0);
-            load_w(min(s + 1, steps - 1), W);
+            load_w(s + 1 == steps ? 0 : s + 1, W);  // (into the registers the first two channel tiles' operands have left: no others are free)
             __builtin_amdgcn_sched_barrier(0);
             mm(accA[2], aA, b[2]); mm(accB[2], aB, b[2]);
             mm(accA[3], aA, b[3]); mm(accB[3], aB, b[3]);
         };
-        for (int s = 0; s < steps; ++s) step(s);
-    }
-    // accumulator row r of lane (p, k) is pixel q = (r & 3) + 8 (r >> 2) + 4 k of a 8x4 half; its transmittance was parked by lane q
-    float TqA[16], TqB[16], bgv[NB];
-    {
-        const float4 b4 = *reinterpret_cast<const float4 *>(park + 4 * lane);
-        bgv[0] = b4.x; bgv[1] = b4.y; bgv[2] = b4.z; bgv[3] = b4.w;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int q = (r & 3) + 8 * (r >> 2) + 4 * k;
-            const float2 t = *reinterpret_cast<const float2 *>(park + 256 + 2 * q);
-            TqA[r] = t.x; TqB[r] = t.y;
+        for (int j = 0; j < spw; ++j) {
+            for (int s = 0; s < steps; ++s) step(s, j);
+#ifdef GAGS_PROBE
+            if (j == 0) GAGS_STAMP(4);
+#endif
+            finish_slice(j);
         }
+    } else {
+        for (int j = 0; j < spw; ++j) finish_slice(j);
     }
-    BlockGeom half;
-    half.p = p; half.k = k; half.bx0 = g.bx0;
-    half.by0 = g.by0;
-    store_rows<NB>(accA, half, width, height, d, ch0, has_bg, render_colors, bgv, TqA);
-    half.by0 = g.by0 + 4;
-    store_rows<NB>(accB, half, width, height, d, ch0, has_bg, render_colors, bgv, TqB);
+    GAGS_STAMP(5);
 }
 
 template <int NB>
@@ -770,6 +851,27 @@ int launch_feat(int d, int ch_base, int ch_count, int width, int height, int n_g
 // ragged (masked lanes) -- 513 = 512 CLIP channels + 1 (BASELINE.json configs[4]) is 4 wide slices + one lane of a
 // narrow one, all on the matrix cores and into ONE output tensor.  Rows of an odd width are only 4-byte (fp16 table:
 // 2-byte) aligned; vector loads / stores of global memory tolerate that on this part (unaligned access mode).
+template <bool BIG, bool HALF, typename... Args>
+static void launch_x16(bool bg, dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args)
+{
+    if (bg) hipLaunchKernelGGL((raster_fwd_feat_x16<BIG, HALF, true>), grid, block, lds, st, args...);
+    else hipLaunchKernelGGL((raster_fwd_feat_x16<BIG, HALF, false>), grid, block, lds, st, args...);
+}
+
+// 128-channel slices a wave of raster_fwd_feat_x16 serves one after the other (1, 2 or 4; must divide the slice count).
+// GAGS_FWD_SPW overrides (experiments; read once).
+static int fwd_slices_per_wave(int n_slices)
+{
+    static const int want = [] {
+        const char *e = getenv("GAGS_FWD_SPW");
+        const int v = e ? atoi(e) : 0;
+        return (v == 1 || v == 2 || v == 4) ? v : 0;
+    }();
+    int spw = want ? want : 2;  // (C3, one box: 1: 2.16 ms, 2: 2.08, 4: 2.13 -- longer waves, longer tail of the launch)
+    while (spw > 1 && n_slices % spw != 0) spw >>= 1;
+    return spw;
+}
+
 template <bool HALF>
 int launch_feat_any(int d, int width, int height, int n_gauss, const float *colors, int f16_mfma, int exact,
                     const float *backgrounds, const int32_t *offsets, int n_isects, const int32_t *blk_rows,
@@ -785,14 +887,14 @@ int launch_feat_any(int d, int width, int height, int n_gauss, const float *colo
                 // the default since round 6: the bf16 matrix cores, B = the half as two exact bf16 terms, A = the weight as
                 // three (exact), five product terms -- fp32-equivalent like the fp32 table's default (raster_fwd_feat_x16)
                 const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
-                const int n_tiles = tile_w * tile_h, n_slices = done / 128;
+                const int n_tiles = tile_w * tile_h, n_slices = done / 128, spw = fwd_slices_per_wave(n_slices);
                 if (table_elems * 2 + 4096 < (1ll << 32))
-                    hipLaunchKernelGGL((raster_fwd_feat_x16<false, true>), dim3(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices), dim3(64), 0, st, d,
-                                       width, height, tile_w, n_tiles, n_slices, n_gauss, colors, backgrounds, offsets, n_isects,
+                    launch_x16<false, true>(backgrounds != nullptr, dim3(n_tiles * GAGS_BLOCKS_PER_TILE * (n_slices / spw)), dim3(64), 0, st, d,
+                                       width, height, tile_w, n_tiles, n_slices, spw, n_gauss, colors, backgrounds, offsets, n_isects,
                                        blk_rows, wt, gid_s, Tbuf, out);
                 else
-                    hipLaunchKernelGGL((raster_fwd_feat_x16<true, true>), dim3(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices), dim3(64), 0, st, d,
-                                       width, height, tile_w, n_tiles, n_slices, n_gauss, colors, backgrounds, offsets, n_isects,
+                    launch_x16<true, true>(backgrounds != nullptr, dim3(n_tiles * GAGS_BLOCKS_PER_TILE * (n_slices / spw)), dim3(64), 0, st, d,
+                                       width, height, tile_w, n_tiles, n_slices, spw, n_gauss, colors, backgrounds, offsets, n_isects,
                                        blk_rows, wt, gid_s, Tbuf, out);
                 GAGS_CHECK_LAUNCH();
             } else if (f16_mfma) {  // opt-in: the f16 matrix cores with a fixed weight scale (round 2's kernel)
@@ -807,19 +909,19 @@ int launch_feat_any(int d, int width, int height, int n_gauss, const float *colo
             }
         } else if (!exact) {  // the default: 16-bit matrix cores on fp32-equivalent split operands
             const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
-            const int n_tiles = tile_w * tile_h, n_slices = done / 128;
+            const int n_tiles = tile_w * tile_h, n_slices = done / 128, spw = fwd_slices_per_wave(n_slices);
             if ((int64_t)n_gauss * d + 1024 >= (1ll << 32)) {
                 // the BIG instantiation keeps row offsets in 32-bit float units: a table of 2^32 elements or more (16 GiB;
                 // 8.4 M x 512) would wrap them.  Such a table takes the fp32 matrix instructions (64-bit row offsets; the
                 // oracle's own chain) instead of reading the wrong rows
                 rc = launch_feat<4, HALF>(d, 0, done, ARGS);
             } else if ((int64_t)n_gauss * d * 4 + 4096 < (1ll << 32))
-                hipLaunchKernelGGL((raster_fwd_feat_x16<false, false>), dim3(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices), dim3(64), 0, st, d,
-                                   width, height, tile_w, n_tiles, n_slices, n_gauss, colors, backgrounds, offsets, n_isects,
+                launch_x16<false, false>(backgrounds != nullptr, dim3(n_tiles * GAGS_BLOCKS_PER_TILE * (n_slices / spw)), dim3(64), 0, st, d,
+                                   width, height, tile_w, n_tiles, n_slices, spw, n_gauss, colors, backgrounds, offsets, n_isects,
                                    blk_rows, wt, gid_s, Tbuf, out);
             else
-                hipLaunchKernelGGL((raster_fwd_feat_x16<true, false>), dim3(n_tiles * GAGS_BLOCKS_PER_TILE * n_slices), dim3(64), 0, st, d,
-                                   width, height, tile_w, n_tiles, n_slices, n_gauss, colors, backgrounds, offsets, n_isects,
+                launch_x16<true, false>(backgrounds != nullptr, dim3(n_tiles * GAGS_BLOCKS_PER_TILE * (n_slices / spw)), dim3(64), 0, st, d,
+                                   width, height, tile_w, n_tiles, n_slices, spw, n_gauss, colors, backgrounds, offsets, n_isects,
                                    blk_rows, wt, gid_s, Tbuf, out);
             GAGS_CHECK_LAUNCH();
         } else {
