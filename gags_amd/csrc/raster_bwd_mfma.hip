@@ -14,6 +14,7 @@
 //   reduce  v_colors[g] = sum of its rows, written once (no zero-fill of v_colors needed).
 // The single-kernel atomic variant (recomputes alpha itself; needs neither scratch nor the forward's
 // slot counts) is kept as the fallback.
+#include <cstdlib>
 #include <hip/hip_fp16.h>
 #include "raster_mfma_common.h"
 
@@ -827,6 +828,13 @@ int gags_bwd_slot_rows_launch(int width, int height, int n_isects, const int32_t
     return GAGS_OK;
 }
 
+// GAGS_BWD_ROWSCALE=1 (experiments; read once): the rows kernel's weight scale per (row, block) instead of the view-wide 2^15
+static bool rows_scale_per_block()
+{
+    static const bool v = [] { const char *e = getenv("GAGS_BWD_ROWSCALE"); return e && e[0] == '1'; }();
+    return v;
+}
+
 // 1 = width not eligible
 int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, const int32_t *offsets, int n_isects,
                                   const float *v_out, const int32_t *blk_rows, const int32_t *trow, int64_t rows,
@@ -871,7 +879,8 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
                 if (stage_flags & 32) GAGS_ROWS_LAUNCH(raster_bwd_rows<4>, c, nsl);  // GAGS_BWD_F32MFMA: the fp32 matrix instructions
                 else if (stage_flags & 512) GAGS_ROWS_LAUNCH(raster_bwd_rows_f16, c, nsl);  // round 4's shape: a wave per pixel block, rows merged in LDS
                 else if (stage_flags & 1024) GAGS_ROWS_LAUNCH((raster_bwd_rows_cw<3, 5>), c, nsl);  // weights as three terms (exact), five product terms
-                else GAGS_ROWS_LAUNCH((raster_bwd_rows_cw<2, 3>), c, nsl);  // default: 16-bit matrix cores, a wave per 32 channels, three product terms
+                else if (rows_scale_per_block()) GAGS_ROWS_LAUNCH((raster_bwd_rows_cw<2, 3>), c, nsl);  // (GAGS_BWD_ROWSCALE=1: round 5's scale per (row, block))
+                else GAGS_ROWS_LAUNCH((raster_bwd_rows_cw<2, 3, true>), c, nsl);  // default: 16-bit matrix cores, a wave per 32 channels, three product terms, one weight scale
                 c += 128 * nsl;
             }
             if (ce - c >= 64) {

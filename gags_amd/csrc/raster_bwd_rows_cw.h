@@ -39,7 +39,17 @@ __device__ __forceinline__ void split8x2(const float (&x)[8], float scale, f16x8
 }
 
 // TA = fp16 terms of a weight (2, or 3: exact), NM = product terms (3 = a0 b0 + a0 b1 + a1 b0; 5 with TA = 3)
-template <int TA, int NM>
+// FIXS (round 6, the default with <2, 3>): ONE weight scale for the whole view, 2^15, instead of a power of two per (row, block).
+// A weight is alpha T with alpha in [1/255, 0.99] and T in (1e-4, 1]: it lies in [2^-21.3, 1), so w 2^15 lies in [2^-6.3, 2^15)
+// -- inside fp16's normal range (2^-14 .. 65504) without looking at the data.  The head term a0 is a normal half for every
+// weight; the tail a1 (<= 2^-11 a0) is a normal half down to w = 2^-18 (two terms = 22 bits, as before) and a subnormal one
+// (absolute spacing 2^-24 / 2^15 = 2^-39 in units of the weight) for the 3.3 binades below: those weights, < 3.8e-6, keep
+// 19-22 bits.  The error a product can carry is therefore <= 3 2^-24 |w v| + 2^-39 |v|, the second part a millionth of what
+// ONE fp32 rounding of a weight near 1 in the same 64-pixel column commits.  What it buys: no row maximum (32 max + shuffle),
+// no scale table in LDS, and -- the scale being common to the four blocks -- a block's sums join the row total by a plain
+// (packed) addition instead of an FMA with a scale read from LDS; 285 -> ~240 VALU and 63 -> 45 LDS instructions per chunk and
+// wave in a kernel whose VALU and MFMA times add (tools/micro/interleave.hip).
+template <int TA, int NM, bool FIXS = false>
 __global__ __launch_bounds__(256, 2) void raster_bwd_rows_cw(
     int d, int width, int height, int tile_w, int n_tiles, int ch_base, int n_slices,
     const float *__restrict__ v_render_colors, const int32_t *__restrict__ offsets, int n_isects,
@@ -174,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_cw(
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         // (exponent clamped: below 2^-112 the scale would overflow to inf -- v * inf, 0 * inf = NaN; such a column keeps 2^126)
         const float cs = (mx > 0.f && mx < 3.0e38f) ? ldexpf(1.0f, min(14 - ilogbf(mx), 126)) : 1.0f;
-        inv_cs = 1.0f / cs;
+        inv_cs = (FIXS ? (1.0f / 32768.0f) : 1.0f) / cs;  // (FIXS: the weights' common scale leaves with the column's)
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
 #pragma unroll
@@ -188,16 +198,22 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_cw(
     for (int r0 = R0; r0 < R1; r0 += 32) {
         // ---- this wave's block: scale and split the chunk's weight rows, leave the terms in LDS
         {
-            float wmx = 0.f;
+            float rs;
+            if constexpr (FIXS) {
+                // a row the block does not hold: scale 0 (its lanes hold the finite weights of a slot the forward wrote)
+                rs = present ? 32768.0f : 0.0f;
+            } else {
+                float wmx = 0.f;
 #pragma unroll
-            for (int i = 0; i < 32; ++i) wmx = fmaxf(wmx, A[i]);
-            wmx = fmaxf(wmx, __shfl_xor(wmx, 32));
-            const int ebits = (int)((__float_as_uint(wmx) >> 23) & 0xffu);
-            const bool sane = present && ebits >= 15 && ebits <= 200;  // alpha*T lies in (4e-7, 1]
-            // a row the block does not hold: scale 0 (its lanes hold the finite weights of a slot the forward wrote)
-            const float rs = sane ? __uint_as_float((unsigned)(268 - ebits) << 23) : (present ? 1.0f : 0.0f);
-            const float ri = sane ? __uint_as_float((unsigned)(ebits - 14) << 23) : 1.0f;
-            if (k == 0) rinv_s[blk][n] = ri;
+                for (int i = 0; i < 32; ++i) wmx = fmaxf(wmx, A[i]);
+                wmx = fmaxf(wmx, __shfl_xor(wmx, 32));
+                const int ebits = (int)((__float_as_uint(wmx) >> 23) & 0xffu);
+                const bool sane = present && ebits >= 15 && ebits <= 200;  // alpha*T lies in (4e-7, 1]
+                // a row the block does not hold: scale 0 (its lanes hold the finite weights of a slot the forward wrote)
+                rs = sane ? __uint_as_float((unsigned)(268 - ebits) << 23) : (present ? 1.0f : 0.0f);
+                const float ri = sane ? __uint_as_float((unsigned)(ebits - 14) << 23) : 1.0f;
+                if (k == 0) rinv_s[blk][n] = ri;
+            }
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 float a8[8];
@@ -229,9 +245,15 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_cw(
         uint4 u0 = At_l[(0 * 4 + 0) * 64], u1 = At_l[(1 * 4 + 0) * 64], u2 = At_l[((TA - 1) * 4 + 0) * 64];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            f32x16 acc;
+            // FIXS: one scale for the four blocks -- the first block's products accumulate in the row total itself, the others'
+            // in the scratch accumulator, added to the total as they are (the sums stay as short as they were: 64 pixels per
+            // chain, four chains per row -- one chain of 256 measured 2.14e-7 against float64 where this order gives 1.7e-7)
+            f32x16 acc_;
+            f32x16 &acc = (FIXS && b == 0) ? tot : acc_;
+            if (!(FIXS && b == 0)) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            }
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 const int nb = s4 == 3 ? b + 1 : b, ns = s4 == 3 ? 0 : s4 + 1;  // the step after this one
@@ -248,19 +270,27 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_cw(
                 if (more) u0 = At_l[((nb * TA + 0) * 4 + ns) * 64];
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // accumulator row r = chunk row (r & 3) + 8 (r >> 2) + 4 k: unscale by the (row, block) scale and fold into the row total
+            if constexpr (FIXS) {
+                if (b > 0) {
+                    tot += acc_;
+                    asm volatile("" : "+v"(tot));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                // accumulator row r = chunk row (r & 3) + 8 (r >> 2) + 4 k: unscale by the (row, block) scale and fold into the row total
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const float4 ri4 = *reinterpret_cast<const float4 *>(&rinv_s[b][8 * q4 + 4 * k]);
-                tot[4 * q4 + 0] = fmaf(acc[4 * q4 + 0], ri4.x, tot[4 * q4 + 0]);
-                tot[4 * q4 + 1] = fmaf(acc[4 * q4 + 1], ri4.y, tot[4 * q4 + 1]);
-                tot[4 * q4 + 2] = fmaf(acc[4 * q4 + 2], ri4.z, tot[4 * q4 + 2]);
-                tot[4 * q4 + 3] = fmaf(acc[4 * q4 + 3], ri4.w, tot[4 * q4 + 3]);
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const float4 ri4 = *reinterpret_cast<const float4 *>(&rinv_s[b][8 * q4 + 4 * k]);
+                    tot[4 * q4 + 0] = fmaf(acc[4 * q4 + 0], ri4.x, tot[4 * q4 + 0]);
+                    tot[4 * q4 + 1] = fmaf(acc[4 * q4 + 1], ri4.y, tot[4 * q4 + 1]);
+                    tot[4 * q4 + 2] = fmaf(acc[4 * q4 + 2], ri4.z, tot[4 * q4 + 2]);
+                    tot[4 * q4 + 3] = fmaf(acc[4 * q4 + 3], ri4.w, tot[4 * q4 + 3]);
+                }
+                // (pins the fold here: left alone, the optimiser sinks it behind the last block, with four accumulators and four
+                // sets of row scales alive -- 100 registers the kernel does not have)
+                asm volatile("" : "+v"(tot));
+                __builtin_amdgcn_sched_barrier(0);
             }
-            // (pins the fold here: left alone, the optimiser sinks it behind the last block, with four accumulators and four
-            // sets of row scales alive -- 100 registers the kernel does not have)
-            asm volatile("" : "+v"(tot));
-            __builtin_amdgcn_sched_barrier(0);
         }
         gags_lds_barrier();  // A terms consumed: the next chunk may overwrite them
         __builtin_amdgcn_sched_barrier(0);
