@@ -296,17 +296,23 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_cw(
         __builtin_amdgcn_sched_barrier(0);
         // row addresses: a uniform base per row (scalar registers) + ONE per-lane offset; sixteen 64-bit pointers in
         // vector registers are what pushed the kernel over its 256
-        float *base = prow + (size_t)r0 * prow_pitch;
-        const unsigned voff = (unsigned)(4 * k) * (unsigned)prow_pitch + (unsigned)chw;
+        // (byte offsets: a uniform 64-bit row base + ONE 32-bit per-lane offset is the store's own addressing mode; indexed as
+        // floats the offset is widened and shifted per store -- eighteen 64-bit vector additions per chunk)
+        char *base = reinterpret_cast<char *>(prow + (size_t)r0 * prow_pitch);
+        unsigned voff = ((unsigned)(4 * k) * (unsigned)prow_pitch + (unsigned)chw) * 4u;
+        const size_t pitch_b = (size_t)prow_pitch * 4;
         if (r0 + 32 <= R1 && r0 + 32 <= rows_cap) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) (base + (size_t)((r & 3) + 8 * (r >> 2)) * prow_pitch)[voff] = tot[r] * inv_cs;
+            for (int r = 0; r < 16; ++r) {
+                asm volatile("" : "+v"(voff));  // (opaque per store: `base + voff` is not to be formed once as a 64-bit vector value)
+                *reinterpret_cast<float *>(base + (size_t)((r & 3) + 8 * (r >> 2)) * pitch_b + voff) = tot[r] * inv_cs;
+            }
         } else {
             const int nrows = min(min(32, R1 - r0), rows_cap - r0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * k;
-                if (row < nrows) (base + (size_t)((r & 3) + 8 * (r >> 2)) * prow_pitch)[voff] = tot[r] * inv_cs;
+                if (row < nrows) *reinterpret_cast<float *>(base + (size_t)((r & 3) + 8 * (r >> 2)) * pitch_b + voff) = tot[r] * inv_cs;
             }
         }
     }

@@ -81,73 +81,64 @@ __global__ __launch_bounds__(64, 8) void raster_weights_kernel(
     const int lane = threadIdx.x;
     BlockGeom64 g;
     g.init(tile, blk, tile_w, width, height, lane);
-    const int p = g.p, k = g.k;
 
     const int start = offsets[tile];
     const int end = offsets[tile + 1]  /* n_tiles + 1 entries: the last one is the intersection count */;
     const int sb = gags_slot_base(start, end, tile, blk);
 
-    PixState sA, sB;  // the lane's two pixels (upper / lower half of the 8x8 block)
-    sA.T = 1.0f; sA.cur = 0; sA.done = !g.insideA;
-    sB.T = 1.0f; sB.cur = 0; sB.done = !g.insideB;
+    // One PIXEL per lane (round 6): lane e = 2 p + h owns pixel p of half h of the block -- element e of a weight row, so a
+    // slot's 64 weights leave as one 256-byte store -- and the wave takes the block's hits ONE at a time: alpha of the hit at
+    // the lane's pixel, then the transmittance step.  Until round 5 a lane owned a pixel PAIR and one of the two hits of a
+    // step (the A-operand layout of the fused matrix-core forward this pass was cut out of): every lane then ran the
+    // transmittance chain of both hits for both of its pixels -- each chain step twice per wave -- behind two half-wave
+    // swaps: 127 VALU instructions per 128 (hit, pixel) pairs; now ~45 per 64.  Same arithmetic per (hit, pixel), same slot
+    // order, same stop rule: weights, alphas and last_ids are bit-identical.
+    const int e = lane, pp = e >> 1, hh = e & 1;
+    const int pj = g.bx0 + (pp & 7), pi = g.by0 + (pp >> 3) + 4 * hh;
+    const bool inside = (pi < height) && (pj < width);
+    const float px = (float)pj + 0.5f, py = (float)pi + 0.5f;
+    float T = 1.0f;
+    int cur = 0;
+    bool done = !inside;
 
     HitStream hs;
     hs.by_gauss = by_gauss != 0;
     hs.init(ring, packed, flatten_ids, start, end, lane, g);
 
     int row = sb;
-    int stop = start;  // COUNT: one past the last list entry a K-step of this block consumed
-    hs.refill(6);
-    if (!__all(sA.done && sB.done) && hs.rd < hs.nq) {
-        bool v_n;
-        HRec h_n = hs.at(hs.rd, k, v_n);
-        float aA_n = eval_alpha(h_n, g.px, g.pyA, v_n), aB_n = eval_alpha(h_n, g.px, g.pyB, v_n);
-        int gid_n = v_n ? h_n.gid : n_gauss, sidx_n = h_n.sidx;
-        auto kstep = [&]() -> bool {
-            const float aA_c = aA_n, aB_c = aB_n;
-            const int gid_c = gid_n, sidx_c = sidx_n;
-            hs.rd += 2;
-            if ((hs.nq - hs.rd) < 6 && hs.pending) hs.refill(6);
-            const bool more = hs.rd < hs.nq;
-            h_n = hs.at(hs.rd, k, v_n);
-            aA_n = eval_alpha(h_n, g.px, g.pyA, v_n);  // one step ahead of the chains below
-            aB_n = eval_alpha(h_n, g.px, g.pyB, v_n);
-            gid_n = v_n ? h_n.gid : n_gauss;
-            sidx_n = h_n.sidx;
-            const auto swA = __builtin_amdgcn_permlane32_swap(__float_as_uint(aA_c), __float_as_uint(aA_c), false, false);
-            const auto swB = __builtin_amdgcn_permlane32_swap(__float_as_uint(aB_c), __float_as_uint(aB_c), false, false);
-            bool blA, blB;
-            const float wA = step_pair(sA, __uint_as_float(swA[0]), __uint_as_float(swA[1]), k, blA);
-            const float wB = step_pair(sB, __uint_as_float(swB[0]), __uint_as_float(swB[1]), k, blB);
-            sA.cur = blA ? sidx_c : sA.cur;
-            sB.cur = blB ? sidx_c : sB.cur;
-            // a hit that blends into none of the block's pixels leaves no slot (its partner in the step may):
-            // zero rows would be multiplied, stored, sorted and summed like any other -- they were 20 % of all rows
-            if constexpr (COUNT) {
-                // both hits of the step were consumed (an absent partner repeats the last produced hit: not beyond it)
-                stop = max(stop, sidx_c + 1);
-                return more && !__all(sA.done && sB.done);
+    int stop = start;  // COUNT: one past the last list entry this block consumed
+    hs.refill(4);
+    while (hs.rd < hs.nq && !__all(done)) {
+        const HRec h = ring[hs.rd & (RING - 1)];  // (the same record for every lane: a broadcast read)
+        hs.rd += 1;
+        if ((hs.nq - hs.rd) < 4 && hs.pending) hs.refill(4);
+        const float a = eval_alpha(h, px, py, true);
+        // skip / stop / blend, exactly step_pair's order of operations
+        const float t = T * (1.0f - a);
+        const bool ok = !done && a > 0.f;
+        const bool stp = ok && t <= GAGS_T_STOP;
+        const bool bl = ok && !stp;
+        const float w = bl ? a * T : 0.f;
+        T = bl ? t : T;
+        done = done || stp;
+        cur = bl ? h.sidx : cur;
+        if constexpr (COUNT) {
+            stop = h.sidx + 1;
+            continue;
+        }
+        // a hit that blends into none of the block's pixels leaves no slot: zero rows would be multiplied, stored, sorted and
+        // summed like any other -- they were 20 % of all rows
+        if (__ballot(w != 0.f) != 0ull) {
+            wt[(size_t)row * 64 + e] = w;
+            if (e == 0) {
+                gid_s[row] = h.gid;
+                sidx_s[row] = h.sidx;
+                hit[h.sidx] = 1;  // up to four blocks store the same 1
             }
-            const unsigned long long nzm = __ballot(wA != 0.f || wB != 0.f);
-            const bool nz0 = (nzm & 0xffffffffull) != 0, nz1 = (nzm >> 32) != 0;  // slot k = half-wave k
-            if (k ? nz1 : nz0) {
-                const int pos = row + ((k && nz0) ? 1 : 0);
-                // row = 32 (upper, lower) pairs: element 2p + h = pixel p of half h
-                *reinterpret_cast<float2 *>(wt + (size_t)pos * 64 + 2 * p) = make_float2(wA, wB);
-                if (p == 0) {
-                    gid_s[pos] = gid_c;
-                    sidx_s[pos] = sidx_c;
-                    hit[sidx_c] = 1;  // up to four blocks store the same 1
-                }
-            }
-            row += (int)nz0 + (int)nz1;
-            return more && !__all(sA.done && sB.done);
-        };
-        while (kstep()) {}
+            row += 1;
+        }
     }
     if constexpr (COUNT) {
-        const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)stop, (unsigned)stop, false, false);
-        stop = max((int)sw[0], (int)sw[1]);  // (stop is uniform within a half-wave: each holds its slot's sorted index)
         if (lane == 0 && stop > start) atomicMax(&need[tile], stop - start);
         return;
     }
@@ -155,25 +146,14 @@ __global__ __launch_bounds__(64, 8) void raster_weights_kernel(
     const int cnt = (used + 1) & ~1;  // consumers take slots in pairs: an odd count is padded with one zero slot that belongs to no Gaussian
     // ... and the region is filled with zero slots up to the next multiple of 16 (its capacity is one: gags_slot_base), so
     // that the 16-slot steps of the 16-bit matrix-core feature pass need neither a clamp nor a mask
-    for (int r = used + k; r < ((used + 15) & ~15); r += 2) {
-        *reinterpret_cast<float2 *>(wt + (size_t)(sb + r) * 64 + 2 * p) = make_float2(0.f, 0.f);
-        if (p == 0) { gid_s[sb + r] = n_gauss; sidx_s[sb + r] = -1; }
+    for (int r = used; r < ((used + 15) & ~15); ++r) {
+        wt[(size_t)(sb + r) * 64 + e] = 0.f;
+        if (e == 0) { gid_s[sb + r] = n_gauss; sidx_s[sb + r] = -1; }
     }
-    row = sb + cnt;
-    if (lane == 0) blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk] = row - sb;
-    {
-        const auto cA = __builtin_amdgcn_permlane32_swap((unsigned)sA.cur, (unsigned)sA.cur, false, false);
-        const auto cB = __builtin_amdgcn_permlane32_swap((unsigned)sB.cur, (unsigned)sB.cur, false, false);
-        sA.cur = max((int)cA[0], (int)cA[1]);  // sorted indices grow along the list
-        sB.cur = max((int)cB[0], (int)cB[1]);
-    }
-    if (k == 0 && g.insideA) {
-        const size_t pix = (size_t)g.piA * width + g.pj;
-        Tbuf[pix] = sA.T; render_alphas[pix] = 1.0f - sA.T; last_ids[pix] = sA.cur;
-    }
-    if (k == 0 && g.insideB) {
-        const size_t pix = (size_t)g.piB * width + g.pj;
-        Tbuf[pix] = sB.T; render_alphas[pix] = 1.0f - sB.T; last_ids[pix] = sB.cur;
+    if (lane == 0) blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk] = cnt;
+    if (inside) {
+        const size_t pix = (size_t)pi * width + pj;
+        Tbuf[pix] = T; render_alphas[pix] = 1.0f - T; last_ids[pix] = cur;
     }
 }
 
