@@ -587,6 +587,7 @@ __global__ void seg_fill_kernel(int n_keys, int32_t *__restrict__ seg)
 // 1: the 1-3 channels a width that is no multiple of 4 leaves over, e.g. the 513th).
 // HALF: the sum (formed in fp32) is stored as fp16 -- the gradient of an fp16 feature table in the table's own dtype,
 // instead of an fp32 tensor plus a cast pass over it (N x D x 6 bytes of traffic at C5).
+constexpr int REDUCE_ITER = 8;
 template <bool HALF, int VW>
 __global__ __launch_bounds__(256) void reduce_rows_kernel(int n_gauss, int d, int ch_begin, int ch_count,
                                                           const int32_t *__restrict__ seg,
@@ -608,82 +609,87 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(int n_gauss, int d, in
     // wire (by-view multi-GPU step, gags_amd/dist.py): the rows the ranks exchange -- wire_pos[g] >= 0: row wire_pos[g] of the
     // dense [rows, ch_count] fp32 block -- leave from here, next to the gradient itself, instead of being re-read by a pack
     // kernel (a union row this view did not touch gets its zeros here as well: every row of the block is written)
+    // (REDUCE_ITER groups of Gaussians per workgroup, one after the other: three of four Gaussians have no rows at C3 -- as one
+    // workgroup per group those were 550 k empty workgroups for the dispatcher)
     const int lpg = ch_count / VW;  // lanes per Gaussian (channels ch_begin .. ch_begin + ch_count - 1 of its row)
     const int gpb = 256 / lpg;
     const int gl = threadIdx.x / lpg;
-    const int g = blockIdx.x * gpb + gl;
     const int cl = ch_begin + (threadIdx.x % lpg) * VW;
-    if (gl >= gpb || g >= n_gauss) return;
-    const int b = seg[g], e = seg[g + 1];
-    // sparse: the caller zero-filled v_colors (on a second stream, under the rows kernel): a Gaussian without rows -- 73 % of
-    // them at C3 -- costs nothing here instead of a 4 D-byte row of zeros
-    const bool has = b != e;
-    bool write_grad = sparse ? has : true;
-    const bool on_wire = wire && wire_pos[g] >= 0;
-    if (keep_cur) {
-        // (a row of the exchanged block will be written by the caller once the ranks' sum is known: it counts as written)
-        if (threadIdx.x % lpg == 0) keep_cur[g] = (has || on_wire) ? 1 : 0;
-        write_grad = has || keep_prev[g] != 0;
-    }
-    if (!write_grad && !on_wire) return;
-    const bool skip_grad = !write_grad;  // (only its wire row is due)
-    if constexpr (VW == 1) {
-        float acc = 0.f;
-        for (int i = b; i < e; ++i) acc += prow[(size_t)sorted_rows[i] * prow_pitch + cl];
-        if (!skip_grad) {
-            if constexpr (HALF) reinterpret_cast<__half *>(v_colors_)[(size_t)g * d + cl] = __float2half_rn(acc);
-            else reinterpret_cast<float *>(v_colors_)[(size_t)g * d + cl] = acc;
+    if (gl >= gpb) return;
+    for (int it = 0; it < REDUCE_ITER; ++it) {
+    const int g = (blockIdx.x * REDUCE_ITER + it) * gpb + gl;
+    if (g >= n_gauss) return;
+        const int b = seg[g], e = seg[g + 1];
+        // sparse: the caller zero-filled v_colors (on a second stream, under the rows kernel): a Gaussian without rows -- 73 % of
+        // them at C3 -- costs nothing here instead of a 4 D-byte row of zeros
+        const bool has = b != e;
+        bool write_grad = sparse ? has : true;
+        const bool on_wire = wire && wire_pos[g] >= 0;
+        if (keep_cur) {
+            // (a row of the exchanged block will be written by the caller once the ranks' sum is known: it counts as written)
+            if (threadIdx.x % lpg == 0) keep_cur[g] = (has || on_wire) ? 1 : 0;
+            write_grad = has || keep_prev[g] != 0;
         }
-        if (wire) {
-            const int q = wire_pos[g];
-            if (q >= 0) wire[(size_t)q * ch_count + (cl - ch_begin)] = acc;
-        }
-    } else {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int tl = threadIdx.x % lpg;
-        const bool has_tail = tl < tail;
-        const int ct = ch_begin + ch_count + (has_tail ? tl : 0);  // this lane's tail channel (same order of additions as the body)
-        float acc_t = 0.f;
-        int i = b;
-        for (; i + 3 < e; i += 4) {
-            const int r0 = sorted_rows[i], r1 = sorted_rows[i + 1], r2 = sorted_rows[i + 2], r3 = sorted_rows[i + 3];
-            const float4 v0 = *reinterpret_cast<const float4 *>(prow + (size_t)r0 * prow_pitch + cl);
-            const float4 v1 = *reinterpret_cast<const float4 *>(prow + (size_t)r1 * prow_pitch + cl);
-            const float4 v2 = *reinterpret_cast<const float4 *>(prow + (size_t)r2 * prow_pitch + cl);
-            const float4 v3 = *reinterpret_cast<const float4 *>(prow + (size_t)r3 * prow_pitch + cl);
-            acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
-            acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
-            acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
-            acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
-            if (has_tail) {
-                acc_t += prow[(size_t)r0 * prow_pitch + ct]; acc_t += prow[(size_t)r1 * prow_pitch + ct];
-                acc_t += prow[(size_t)r2 * prow_pitch + ct]; acc_t += prow[(size_t)r3 * prow_pitch + ct];
+        if (!write_grad && !on_wire) continue;
+        const bool skip_grad = !write_grad;  // (only its wire row is due)
+        if constexpr (VW == 1) {
+            float acc = 0.f;
+            for (int i = b; i < e; ++i) acc += prow[(size_t)sorted_rows[i] * prow_pitch + cl];
+            if (!skip_grad) {
+                if constexpr (HALF) reinterpret_cast<__half *>(v_colors_)[(size_t)g * d + cl] = __float2half_rn(acc);
+                else reinterpret_cast<float *>(v_colors_)[(size_t)g * d + cl] = acc;
             }
-        }
-        for (; i < e; ++i) {
-            const int r0 = sorted_rows[i];
-            const float4 v0 = *reinterpret_cast<const float4 *>(prow + (size_t)r0 * prow_pitch + cl);
-            acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
-            if (has_tail) acc_t += prow[(size_t)r0 * prow_pitch + ct];
-        }
-        if (!skip_grad && has_tail) {
-            if constexpr (HALF) reinterpret_cast<__half *>(v_colors_)[(size_t)g * d + ct] = __float2half_rn(acc_t);
-            else reinterpret_cast<float *>(v_colors_)[(size_t)g * d + ct] = acc_t;
-        }
-        if (!skip_grad) {
-            if constexpr (HALF) {
-                const __half2 lo = __floats2half2_rn(acc.x, acc.y), hi = __floats2half2_rn(acc.z, acc.w);
-                uint2 w;
-                w.x = *reinterpret_cast<const unsigned *>(&lo);
-                w.y = *reinterpret_cast<const unsigned *>(&hi);
-                *reinterpret_cast<uint2 *>(reinterpret_cast<__half *>(v_colors_) + (size_t)g * d + cl) = w;
-            } else {
-                *reinterpret_cast<float4 *>(reinterpret_cast<float *>(v_colors_) + (size_t)g * d + cl) = acc;
+            if (wire) {
+                const int q = wire_pos[g];
+                if (q >= 0) wire[(size_t)q * ch_count + (cl - ch_begin)] = acc;
             }
-        }
-        if (wire) {
-            const int q = wire_pos[g];
-            if (q >= 0) *reinterpret_cast<float4 *>(wire + (size_t)q * ch_count + (cl - ch_begin)) = acc;
+        } else {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int tl = threadIdx.x % lpg;
+            const bool has_tail = tl < tail;
+            const int ct = ch_begin + ch_count + (has_tail ? tl : 0);  // this lane's tail channel (same order of additions as the body)
+            float acc_t = 0.f;
+            // Batches of eight rows, every load of a batch requested before the first is added: the row numbers (clamped to the
+            // Gaussian's last row: valid addresses, their values unused), then the rows.  A Gaussian has 4.7 rows on average at
+            // C3 -- two round trips instead of one per group of four plus one per leftover row.  Same order of additions.
+            for (int i = b; i < e; i += 8) {
+                int r[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = sorted_rows[min(i + j, e - 1)];
+                float4 v[8];
+                float vt[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    v[j] = *reinterpret_cast<const float4 *>(prow + (size_t)r[j] * prow_pitch + cl);
+                    vt[j] = has_tail ? prow[(size_t)r[j] * prow_pitch + ct] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (i + j < e) {
+                        acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w;
+                        acc_t += vt[j];
+                    }
+                }
+            }
+            if (!skip_grad && has_tail) {
+                if constexpr (HALF) reinterpret_cast<__half *>(v_colors_)[(size_t)g * d + ct] = __float2half_rn(acc_t);
+                else reinterpret_cast<float *>(v_colors_)[(size_t)g * d + ct] = acc_t;
+            }
+            if (!skip_grad) {
+                if constexpr (HALF) {
+                    const __half2 lo = __floats2half2_rn(acc.x, acc.y), hi = __floats2half2_rn(acc.z, acc.w);
+                    uint2 w;
+                    w.x = *reinterpret_cast<const unsigned *>(&lo);
+                    w.y = *reinterpret_cast<const unsigned *>(&hi);
+                    *reinterpret_cast<uint2 *>(reinterpret_cast<__half *>(v_colors_) + (size_t)g * d + cl) = w;
+                } else {
+                    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(v_colors_) + (size_t)g * d + cl) = acc;
+                }
+            }
+            if (wire) {
+                const int q = wire_pos[g];
+                if (q >= 0) *reinterpret_cast<float4 *>(wire + (size_t)q * ch_count + (cl - ch_begin)) = acc;
+            }
         }
     }
 }
@@ -913,14 +919,14 @@ int gags_raster_bwd_staged_launch(int d, int width, int height, int n_gauss, con
         const bool ride = c4 >= 16 && c1 > 0;  // the 1-3 leftover channels ride along with the float4 columns' launch
         if (c4 > 0) {
             const int gpb = 256 / (c4 >> 2);
-            const dim3 grid((n_gauss + gpb - 1) / gpb);
+            const dim3 grid((n_gauss + gpb * REDUCE_ITER - 1) / (gpb * REDUCE_ITER));
             const int tail = ride ? c1 : 0;
             if (half) hipLaunchKernelGGL((reduce_rows_kernel<true, 4>), grid, dim3(256), 0, st, n_gauss, d, ch_begin, c4, seg, idx_s, prow, pp, (void *)v_colors, sparse, wire_pos, wire, keep_prev, keep_cur, tail);
             else hipLaunchKernelGGL((reduce_rows_kernel<false, 4>), grid, dim3(256), 0, st, n_gauss, d, ch_begin, c4, seg, idx_s, prow, pp, (void *)v_colors, sparse, wire_pos, wire, keep_prev, keep_cur, tail);
         }
         if (c1 > 0 && !ride) {
             const int gpb = 256 / c1;
-            const dim3 grid((n_gauss + gpb - 1) / gpb);
+            const dim3 grid((n_gauss + gpb * REDUCE_ITER - 1) / (gpb * REDUCE_ITER));
             if (half) hipLaunchKernelGGL((reduce_rows_kernel<true, 1>), grid, dim3(256), 0, st, n_gauss, d, ch_begin + c4, c1, seg, idx_s, prow, pp, (void *)v_colors, sparse, wire_pos, wire, keep_prev, keep_cur, 0);
             else hipLaunchKernelGGL((reduce_rows_kernel<false, 1>), grid, dim3(256), 0, st, n_gauss, d, ch_begin + c4, c1, seg, idx_s, prow, pp, (void *)v_colors, sparse, wire_pos, wire, keep_prev, keep_cur, 0);
         }
@@ -1611,7 +1617,7 @@ int gags_raster_bwd_geom_launch(int d, int n_gauss, int width, int height, const
     } else {
         hipLaunchKernelGGL(seg_fill_kernel, dim3((n_gauss + 1 + 255) / 256), dim3(256), 0, st, n_gauss, seg);
     }
-    hipLaunchKernelGGL((reduce_rows_kernel<false, 4>), dim3((n_gauss + 127) / 128), dim3(256), 0, st, n_gauss, 8, 0, 8, seg, idx_s, grow, 8,
+    hipLaunchKernelGGL((reduce_rows_kernel<false, 4>), dim3((n_gauss + 128 * REDUCE_ITER - 1) / (128 * REDUCE_ITER)), dim3(256), 0, st, n_gauss, 8, 0, 8, seg, idx_s, grow, 8,
                        (void *)v_geo, 0, (const int32_t *)nullptr, (float *)nullptr, (const uint8_t *)nullptr, (uint8_t *)nullptr, 0);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
