@@ -78,10 +78,15 @@ __global__ __launch_bounds__(256) void dot_partial_kernel(int64_t n, const float
                                                           const float *__restrict__ y, double *__restrict__ partial)
 {
     __shared__ double sm[4];
-    const int64_t n4 = n >> 2, stride = (int64_t)DOT_BLOCKS * 256;
+    // every workgroup owns ONE contiguous chunk of both streams (round 6): 6.3 TB/s where the grid-stride traversal reached
+    // 6.0 (tools/micro/dot2.hip) -- a workgroup's requests then walk DRAM pages in order instead of touching 2 x 4 pages
+    // 8 MB apart per wave
+    const int64_t n4 = n >> 2, stride = 256;
+    const int64_t chunk = (n4 + DOT_BLOCKS - 1) / DOT_BLOCKS;
+    const int64_t i_end = min(n4, (int64_t)(blockIdx.x + 1) * chunk);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n4; i += 4 * stride) {  // eight 16-byte requests per thread in flight
+    int64_t i = (int64_t)blockIdx.x * chunk + threadIdx.x;
+    for (; i + 3 * stride < i_end; i += 4 * stride) {  // eight 16-byte requests per thread in flight
         float4 u[4], v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(256) void dot_partial_kernel(int64_t n, const float
             a0 = fmaf(u[q].x, v[q].x, a0); a1 = fmaf(u[q].y, v[q].y, a1); a2 = fmaf(u[q].z, v[q].z, a2); a3 = fmaf(u[q].w, v[q].w, a3);
         }
     }
-    for (; i < n4; i += stride) {
+    for (; i < i_end; i += stride) {
         const float4 u = reinterpret_cast<const float4 *>(x)[i], v = reinterpret_cast<const float4 *>(y)[i];
         a0 = fmaf(u.x, v.x, a0); a1 = fmaf(u.y, v.y, a1); a2 = fmaf(u.z, v.z, a2); a3 = fmaf(u.w, v.w, a3);
     }
