@@ -602,7 +602,9 @@ __global__ __launch_bounds__(64, 2) void raster_fwd_feat_x16(
                     v.x = __builtin_fmaf(Tq[r], bgv[0], v.x); v.y = __builtin_fmaf(Tq[r], bgv[1], v.y);
                     v.z = __builtin_fmaf(Tq[r], bgv[2], v.z); v.w = __builtin_fmaf(Tq[r], bgv[3], v.w);
                 }
-                if (col_ok[r & 3]) *reinterpret_cast<float4 *>(const_cast<char *>(blk_base) + (size_t)uo + store_off) = v;
+                unsigned so = store_off;
+                asm volatile("" : "+v"(so));  // (opaque per store: scalar row base + this offset is the store's own addressing mode)
+                if (col_ok[r & 3]) *reinterpret_cast<float4 *>(const_cast<char *>(blk_base) + (size_t)uo + so) = v;
             }
         }
 #pragma unroll
@@ -718,19 +720,22 @@ __global__ __launch_bounds__(64, 2) void raster_fwd_feat_x16(
                 else mfma6(acc, a, bb);
             };
             __builtin_amdgcn_sched_barrier(0);
-            {
-                const bool wrap = s + 1 == steps;
-                const int jn = (wrap && j + 1 < spw) ? j + 1 : j;  // slice of the next step of the sequence
-                load_f(id1, F, lane_off0 + (unsigned)jn * slice_off);
-            }
-            id1 = id2;
-            id2 = load_ids(s3);
-            s3 = s3 + 1 == steps ? 0 : s3 + 1;
+            // the next step's operands, in the order it consumes them: the weights (its A split comes first) ahead of the MFMAs,
+            // the rows in the middle of them -- into their own registers and those the first two channel tiles' operands have
+            // left (none else are free).  Round 5 had them the other way round: 2 % slower
+            load_w(s + 1 == steps ? 0 : s + 1, W);
             __builtin_amdgcn_sched_barrier(0);
             mm(accA[0], aA, b[0]); mm(accB[0], aB, b[0]);
             mm(accA[1], aA, b[1]); mm(accB[1], aB, b[1]);
             __builtin_amdgcn_sched_barrier(0);
-            load_w(s + 1 == steps ? 0 : s + 1, W);  // (into the registers the first two channel tiles' operands have left: no others are free)
+            {
+                const bool wrap = s + 1 == steps;
+                const int jn = (wrap && j + 1 < spw) ? j + 1 : j;  // slice of the next step of the sequence
+                load_f(id1, F, lane_off0 + (unsigned)jn * slice_off);
+                id1 = id2;
+                id2 = load_ids(s3);
+                s3 = s3 + 1 == steps ? 0 : s3 + 1;
+            }
             __builtin_amdgcn_sched_barrier(0);
             mm(accA[2], aA, b[2]); mm(accB[2], aB, b[2]);
             mm(accA[3], aA, b[3]); mm(accB[3], aB, b[3]);
