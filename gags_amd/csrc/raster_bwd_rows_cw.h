@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_cw(
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) split8(raw[b][s4], cs, Bh[b][s4], Bl[b][s4]);
+            for (int s4 = 0; s4 < 4; ++s4) split8x2(raw[b][s4], cs, Bh[b][s4], Bl[b][s4]);  // (packed conversions: 3 instead of 5 instructions per value, the same terms)
             __builtin_amdgcn_sched_barrier(0);  // block after block, in place: 128 raw values become 128 registers of terms
         }
     }
