@@ -149,8 +149,16 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_cw(
         // -> present (row n of the chunk is held by the block), A loads issued for it; keys written for the rows
         const int r1 = min(r0 + 32, R1);
         const bool mine = tr < r1;
+        // OR over the 32 entries (both half-waves hold the same 32): four DPP steps inside the rows of 16 lanes, lane 15's
+        // value into the next row, the result read from lane 31 into a SCALAR register -- a chain of five ds_bpermute
+        // (what __shfl_xor compiles to) is ~500 cycles of latency at the head of every chunk
         unsigned m = mine ? (1u << (tr - r0)) : 0u;
-        m |= __shfl_xor(m, 1); m |= __shfl_xor(m, 2); m |= __shfl_xor(m, 4); m |= __shfl_xor(m, 8); m |= __shfl_xor(m, 16);
+        m |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+        m |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+        m |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x141, 0xf, 0xf, false);  // row_half_mirror
+        m |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x140, 0xf, 0xf, false);  // row_mirror
+        m |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x142, 0xa, 0xf, false);  // row_bcast15 into rows 1 and 3
+        m = (unsigned)__builtin_amdgcn_readlane((int)m, 31);
         const int run = __popc(m);
         present = (m >> n) & 1u;
         const int src = pb + __popc(m & ((1u << n) - 1u));
