@@ -48,6 +48,8 @@ TRIM_AUTO_BYTES = 48 << 30
 KEEP_GRAD = os.environ.get("GAGS_KEEP_GRAD", "1") != "0"
 KEEP_GRAD_MIN_ELEMS = 0   # (every shape: the small test scenes exercise the same path as C3)
 KEEP_GRAD_SHAPES = 2      # buffers a context keeps alive at once (least recently used shape is dropped)
+# Row map of the colours-only backward at FORWARD time (RasterContext.early_rowmap; _early_rowmap): default ON
+EARLY_ROWMAP = os.environ.get("GAGS_EARLY_ROWMAP", "1") != "0"
 # Default of RasterContext.capacity_mode (GAGS_CAPACITY_MODE=1; OFF otherwise): see RasterContext.
 CAPACITY_MODE = os.environ.get("GAGS_CAPACITY_MODE", "0") == "1"
 
@@ -89,6 +91,13 @@ class RasterContext:
         reduce 1.27 -> 0.95 ms, but the fill kernel takes the CUs from whatever it runs beside -- under the rows kernel that
         kernel slowed by 0.38 ms, under the binning kernels the step grew by 1.7 ms.  The C-ABI flag stays for callers
         that own a zeroed buffer anyway.
+    early_rowmap
+        ON by default (GAGS_EARLY_ROWMAP=0): the staged backward begins by numbering the view's partial gradient rows (a prefix
+        sum over the forward's hit flags, gags_bwd_rowmap) and has to know their COUNT on the host before it can size its
+        scratch -- a 4-byte readback in the middle of the backward, with the launch queue drained around it (60-90 us).  None of
+        that depends on the cotangent: a forward that will be differentiated w.r.t. the colours alone enqueues the row map right
+        behind its own kernels and sends the count to pinned memory; by the time the loss has been computed it has long arrived
+        and the backward opens with the rows kernel.  A forward that is never differentiated has run 0.12 ms of small kernels for nothing.
     Also here: the pinned 4-byte buffers of the deferred count readbacks, the side streams, and render()'s cache of the
     intrinsics matrix."""
 
@@ -102,6 +111,9 @@ class RasterContext:
         self.cap_isects = {}
         self.cap_rows = {}
         self.overlap_zero_fill = bool(overlap_zero_fill)
+        # the backward's row map enqueued behind the forward, its count on the way to the host meanwhile (_early_rowmap)
+        self.early_rowmap = EARLY_ROWMAP
+        self._pinned_pool = {}
         self.k_cache = {}
         self._pinned = {}
         self._side = {}
@@ -145,6 +157,18 @@ class RasterContext:
         if key not in self._side:
             self._side[key] = torch.cuda.Stream(device=dev)
         return self._side[key]
+
+    def take_pinned(self, dev):
+        """A pinned int32 of the caller's own (returned with give_pinned): counts of several forwards may be in flight."""
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        pool = self._pinned_pool.setdefault(key, [])
+        return pool.pop() if pool else torch.empty(1, dtype=torch.int32).pin_memory()
+
+    def give_pinned(self, dev, t):
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        pool = self._pinned_pool.setdefault(key, [])
+        if len(pool) < 8:
+            pool.append(t)
 
     def pinned_i32(self, dev):
         key = dev.index if dev.index is not None else torch.cuda.current_device()
@@ -553,6 +577,12 @@ class _Rasterize(torch.autograd.Function):
         if split:
             profiler.note("fwd_blk_rows", blk_rows)
         need_geom = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[3]
+        rctx_ = rctx if rctx is not None else default_context()
+        early = None
+        if (split and n_isects > 0 and rctx_.early_rowmap and ctx.needs_input_grad[2] and not need_geom and _mfma_width(d)
+                and d <= 1024 and not (flags & _lib.GAGS_BWD_ATOMIC) and not rctx_.capacity_mode):
+            with profiler.stage("bwd_rowcount"):
+                early = _early_rowmap(lib, rctx_, offsets, blk_rows, scratch, n_isects, width, height, dev)
         # wide-D geometry gradients on the matrix cores (gags_raster_bwd_geom) also consume the forward's scratch
         geom_mfma = split and need_geom and _geom_mfma_width(d) and not (flags & _lib.GAGS_BWD_ATOMIC)
         staged = (split and _mfma_width(d) and d <= 1024 and (ctx.needs_input_grad[2] or geom_mfma)
@@ -564,6 +594,7 @@ class _Rasterize(torch.autograd.Function):
         ctx.half = half
         ctx.rctx = rctx if rctx is not None else default_context()
         ctx.prezero = prezero if staged else None
+        ctx.early = early if staged else None
         ctx.mark_non_differentiable(last_ids)
         return out, alphas, last_ids
 
@@ -587,7 +618,7 @@ class _Rasterize(torch.autograd.Function):
             # tensor + cast pass (autograd wants the table's dtype; an fp32 master sits behind a .half() cast)
             v_colors = _backward_staged(lib, ctx.rctx, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height,
                                         (32 if (flags & _lib.GAGS_BWD_F32MFMA) else 0) | (64 if ctx.half else 0) | (512 if (flags & _lib.GAGS_BWD_BLOCKWAVES) else 0) | (1024 if (flags & _lib.GAGS_BWD_EXACT_WEIGHTS) else 0),
-                                        flatten_ids, ctx.prezero)
+                                        flatten_ids, ctx.prezero, early=ctx.early)
             return None, None, v_colors, None, v_bg, None, None, None, None, None, None, None, None, None
         if need_geom and blk_rows is not None and ctx.geom_mfma:
             # wide D: colours through the staged backward, geometry through the matrix-core dot pass + scalar pass
@@ -679,8 +710,40 @@ def _geom_mfma_width(d):
     return d >= 16 and d % 8 == 0 and d <= 1024
 
 
+class _EarlyRowmap:
+    """The backward's row map, enqueued by the forward (RasterContext.early_rowmap): the map, and its total on the way to a
+    pinned buffer behind an event."""
+
+    def __init__(self, trow, total, stmp, host, ev, rctx, dev):
+        self.trow, self.total, self.stmp, self.host, self.ev, self.rctx, self.dev = trow, total, stmp, host, ev, rctx, dev
+        self._rows = None
+
+    def rows(self):
+        if self._rows is None:
+            self.ev.synchronize()  # (long passed by the time a backward asks)
+            self._rows = int(self.host[0])
+            self.rctx.give_pinned(self.dev, self.host)
+            self.host = None
+        return self._rows
+
+
+def _early_rowmap(lib, rctx, offsets, blk_rows, fwd_scratch, n_isects, width, height, dev):
+    ne = lib.gags_bwd_rowmap_elems(n_isects, width, height)
+    trow = torch.empty(ne, dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.int32, device=dev)
+    sb = lib.gags_bwd_rowmap_scratch_bytes(n_isects)
+    stmp = torch.empty(max(sb, 4), dtype=torch.uint8, device=dev)
+    check(lib.gags_bwd_rowmap(n_isects, width, height, ptr(offsets), ptr(blk_rows), ptr(fwd_scratch), fwd_scratch.numel(),
+                              ptr(trow), ne, ptr(total), ptr(stmp), sb, _stream()), "gags_bwd_rowmap")
+    host = rctx.take_pinned(dev)
+    host.copy_(total, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return _EarlyRowmap(trow, total, stmp, host, ev, rctx, dev)
+
+
 def _backward_staged(lib, rctx, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height, xflag=0,
-                     flatten_ids=None, prezero=None, exact_rows=False):
+                     flatten_ids=None, prezero=None, exact_rows=False, early=None):
     """Colours-only backward without atomics: hit flags of the forward -> prefix sum (one row per (tile, Gaussian)
     pair that blended anything) -> one 4-byte readback (total rows) -> merged partial rows -> sort by Gaussian ->
     segmented sum."""
@@ -691,26 +754,32 @@ def _backward_staged(lib, rctx, offsets, n_isects, blk_rows, fwd_scratch, v_out,
         check(lib.gags_blended_mask(n_isects, width, height, n, ptr(flatten_ids), ptr(fwd_scratch), fwd_scratch.numel(),
                                     ptr(mask), st), "gags_blended_mask")
         rctx.grad_rows_hook(mask)  # before the readback below: the ranks agree on the union while the backward starts
-    ne = lib.gags_bwd_rowmap_elems(n_isects, width, height)
-    trow = torch.empty(ne, dtype=torch.int32, device=dev)
-    total = torch.empty(1, dtype=torch.int32, device=dev)
-    sb = lib.gags_bwd_rowmap_scratch_bytes(n_isects)
-    stmp = torch.empty(max(sb, 4), dtype=torch.uint8, device=dev)
     hook = rctx.grad_range_hook
     ranges = _channel_ranges(d, rctx.grad_range_channels) if hook is not None else None
     cap_key = (n, width, height, dev.index)
     pending = None
-    with profiler.stage("bwd_rowcount"):
-        check(lib.gags_bwd_rowmap(n_isects, width, height, ptr(offsets), ptr(blk_rows), ptr(fwd_scratch),
-                                  fwd_scratch.numel(), ptr(trow), ne, ptr(total), ptr(stmp), sb, st), "gags_bwd_rowmap")
-        if rctx.capacity_mode and hook is None and cap_key in rctx.cap_rows and not exact_rows:
-            # capacity mode (see RasterContext): the row count stays on the device until the backward is enqueued
-            rows = min(max(n_isects, 1), int(rctx.cap_rows[cap_key] * CAP_MARGIN) + 1024)
-            pending = _DeferredCount(total, rctx)
-        else:
-            host = ctypes.c_int32(0)
-            check(lib.gags_read_i32(ptr(total), ctypes.byref(host), st), "gags_read_i32")
-            rows = int(host.value)
+    if early is not None:
+        # the forward enqueued the row map behind its own kernels and its count has reached the host meanwhile: no prefix sum,
+        # no readback, no drained queue here
+        trow, total, rows = early.trow, early.total, early.rows()
+    else:
+        ne = lib.gags_bwd_rowmap_elems(n_isects, width, height)
+        trow = torch.empty(ne, dtype=torch.int32, device=dev)
+        total = torch.empty(1, dtype=torch.int32, device=dev)
+        sb = lib.gags_bwd_rowmap_scratch_bytes(n_isects)
+        stmp = torch.empty(max(sb, 4), dtype=torch.uint8, device=dev)
+    if early is None:
+        with profiler.stage("bwd_rowcount"):
+            check(lib.gags_bwd_rowmap(n_isects, width, height, ptr(offsets), ptr(blk_rows), ptr(fwd_scratch),
+                                      fwd_scratch.numel(), ptr(trow), ne, ptr(total), ptr(stmp), sb, st), "gags_bwd_rowmap")
+            if rctx.capacity_mode and hook is None and cap_key in rctx.cap_rows and not exact_rows:
+                # capacity mode (see RasterContext): the row count stays on the device until the backward is enqueued
+                rows = min(max(n_isects, 1), int(rctx.cap_rows[cap_key] * CAP_MARGIN) + 1024)
+                pending = _DeferredCount(total, rctx)
+            else:
+                host = ctypes.c_int32(0)
+                check(lib.gags_read_i32(ptr(total), ctypes.byref(host), st), "gags_read_i32")
+                rows = int(host.value)
     # a heavy view's partial rows ([rows, D] fp32) can outgrow the device (C5H: 80 M rows x 2 KB): beyond PROW_MAX_BYTES the
     # gradient is produced one 128-channel range at a time through a [rows, 128] scratch (stage bit 256)
     narrow = (hook is None and pending is None and d % 128 == 0 and d > 128 and rows * d * 4 > PROW_MAX_BYTES)

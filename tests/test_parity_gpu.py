@@ -1298,3 +1298,45 @@ def test_trimmed_lists_change_nothing(oracle, n, w, h, d, mult, geom):
                                               s["K"], bg, w, h)
     _check_indices(i1, oi)
     np.testing.assert_array_equal(a1, o_alpha)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,w,h,d,trim", [(6000, 200, 138, 128, False), (3000, 160, 112, 16, False), (5000, 144, 112, 513, False),
+                                         (6000, 200, 138, 128, True), (40, 64, 48, 128, False)])
+def test_row_map_enqueued_by_the_forward_changes_nothing(oracle, n, w, h, d, trim):
+    """Round 6, RasterContext.early_rowmap (default ON): a forward that will be differentiated w.r.t. the colours enqueues the
+    backward's row map (gags_bwd_rowmap) behind its own kernels and sends the row count to pinned memory, so that the backward
+    needs neither the prefix sum nor a readback.  Render and gradient are bit-identical to the backward that does it all itself
+    (also on trimmed lists, and for two views whose forwards both ran before either backward); the gradient agrees with the
+    oracle's forward-order sum."""
+    from gags_amd.rasterization import RasterContext, rasterization
+    s = scene_arrays(n, d, w, h, seed=91, view=2, scale_mult=6.0)
+    rng = np.random.default_rng(9)
+    v_out = rng.standard_normal((h, w, d)).astype(np.float32)
+    res = {}
+    for name, on in (("backward", False), ("forward", True)):
+        ctx = RasterContext()
+        ctx.early_rowmap = on
+        ctx.trim_lists = trim
+        res[name] = _run_gpu(s, w, h, s["colors"], None, need_geom=False, v_out=v_out, v_alpha=None, context=ctx)
+    (o0, a0, i0, g0), (o1, a1, i1, g1) = res["backward"], res["forward"]
+    np.testing.assert_array_equal(o1, o0)
+    np.testing.assert_array_equal(a1, a0)
+    np.testing.assert_array_equal(g1["colors"], g0["colors"])
+    o_out, o_alpha, oi = oracle.rasterization(s["means"], s["quats"], s["scales"], s["opacities"], s["colors"], s["viewmat"],
+                                              s["K"], np.zeros(d, np.float32), w, h)
+    o_vf = oracle.raster_bwd_colors_fwdorder(oi["means2d"], oi["conics"], s["opacities"], d, w, h, oi["isect_offsets"],
+                                             oi["flatten_ids"], v_out, n)
+    assert rel_l2(g1["colors"], o_vf) <= GRAD_TOL
+    # two forwards in flight before the first backward: each keeps its own pinned count
+    ctx = RasterContext()
+    means, quats, scales, opac = (to_dev(s[k]) for k in ("means", "quats", "scales", "opacities"))
+    cols = to_dev(s["colors"]).requires_grad_(True)
+    outs = [rasterization(means, quats, scales, opac, cols, to_dev(s["viewmat"])[None], to_dev(s["K"])[None], w, h, context=ctx)[0]
+            for _ in range(2)]
+    (outs[0][0] * to_dev(v_out)).sum().backward()
+    g_first = cols.grad.clone()
+    cols.grad = None
+    (outs[1][0] * to_dev(v_out)).sum().backward()
+    assert torch.equal(cols.grad, g_first)
+    np.testing.assert_array_equal(g_first.cpu().numpy(), g0["colors"])
