@@ -598,9 +598,10 @@ def main():
             "dtype_note": "fp32 tensors and fp32(-equivalent) arithmetic: forward contraction on v_mfma_f32_32x32x16_bf16 with both operands "
                           "split into three bf16 terms (exact operands, six terms per product: as close to float64 as the fp32 chain; "
                           "GAGS_FWD_EXACT = v_mfma_f32_32x32x2_f32, bit-identical to the oracle); backward contraction on "
-                          "v_mfma_f32_32x32x16_f16 with both operands as two fp16 terms after exact power-of-two scalings and three product "
-                          "terms (<= 3 * 2^-24 per product; 1.68e-7 of float64 where fp32 matrix arithmetic gives 1.90e-7; exact "
-                          "three-term weights with five product terms: GAGS_BWD_EXACT_WEIGHTS); fp32 accumulation in both",
+                          "v_mfma_f32_32x32x16_f16 with both operands as two fp16 terms after exact power-of-two scalings (the cotangent's per "
+                          "(tile, channel), the weights' one constant 2^15: a weight lies in [2^-21.3, 1)) and three product terms (<= 3 * 2^-24 "
+                          "|w v| + 2^-39 |v| per product; 1.7e-7 of float64 where fp32 matrix arithmetic gives 1.90e-7; exact three-term "
+                          "weights with five product terms: GAGS_BWD_EXACT_WEIGHTS); fp32 accumulation in both",
             "config": {"workload": f"{args.config}: {n} Gaussians, {width}x{height}, D={d}, {world} view(s)/step"
                                    + (f", every GPU renders all {world} views for its {d_local} channels"
                                       if mode == "channel" else ", 1 view/GPU/step"),

@@ -22,9 +22,10 @@
 // a third of that, which stays below what an fp32 dot product of these 64-pixel columns commits in its own additions.
 // Measured against float64 (tests/test_fullsize_gpu.py::test_colour_gradient_accuracy_against_float64): 1.68e-7 rel-L2, worst
 // channel 2.68e-7; the fp32 matrix instructions: 1.90e-7 / 2.71e-7; the exact-weight scheme <3, 5> of raster_bwd_rows_f16
-// (weights as three terms, five product terms; stage bit 1024): 1.60e-7 / 2.45e-7 for 1.33x the time.  Scales are per
-// (row, block) for the weights and per (tile, channel) for the cotangent, both powers of two, applied when a block's
-// accumulator is folded into the total / when the row is stored.
+// (weights as three terms, five product terms; stage bit 1024): 1.60e-7 / 2.45e-7 for 1.33x the time.  Scales are powers of
+// two: per (tile, channel) for the cotangent, and for the weights ONE constant for the view since round 6 (FIXS below; until
+// round 5, and still with three-term weights or GAGS_BWD_ROWSCALE=1, one per (row, block), applied when a block's accumulator
+// is folded into the total); both leave when the row is stored.
 __device__ __forceinline__ void split8x2(const float (&x)[8], float scale, f16x8 &hi, f16x8 &lo)
 {
 #pragma unroll
@@ -85,7 +86,10 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_cw(
         // per-lane offset plus wave-uniform terms (scalar registers / immediates); tiles cut by the image border clamp
         const bool interior = (tx + 1) * GAGS_TILE <= width && (ty + 1) * GAGS_TILE <= height;
         if (interior) {
-            const float *lane0 = v_render_colors + ((size_t)(ty * GAGS_TILE) * width + tx * GAGS_TILE + 4 * k) * d + chw;
+            // (a uniform 64-bit base per pixel -- scalar registers, scalar additions -- plus ONE 32-bit lane offset, made opaque per
+            // load: formed once as a 64-bit per-lane pointer it costs a 64-bit vector addition per load, 140 per wave)
+            const char *tile0 = reinterpret_cast<const char *>(v_render_colors) + ((size_t)(ty * GAGS_TILE) * width + tx * GAGS_TILE) * d * 4;
+            const unsigned lane_off = ((unsigned)(4 * k) * (unsigned)d + (unsigned)chw) * 4u;
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -93,7 +97,9 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_cw(
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const int row = (b >> 1) * 8 + 4 * (i & 1) + s4, col = (b & 1) * 8 + (i >> 1);  // compile-time
-                        raw[b][s4][i] = lane0[((size_t)row * width + col) * d];
+                        unsigned lo = lane_off;
+                        asm volatile("" : "+v"(lo));
+                        raw[b][s4][i] = *reinterpret_cast<const float *>(tile0 + ((size_t)row * width + col) * d * 4 + lo);
                     }
         } else {
 #pragma unroll

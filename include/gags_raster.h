@@ -219,7 +219,8 @@ int gags_raster_bwd(int d, int width, int height, const float *means2d, const fl
  * (no zero-fill needed).  scratch: gags_bwd_staged_scratch_bytes(rows, n, d) bytes.
  * stage: low 4 bits 0 = all, 1..3 = rows, sort, reduce (per-kernel timing, overlap of the zero-fill below).
  * The rows' contraction (128-channel slices) runs on the 16-bit matrix cores with fp32-equivalent split operands (fp16
- * terms after exact power-of-two scalings, fp32 accumulation; see the bits below for the number of terms); atomic-free and
+ * terms after exact power-of-two scalings -- per (tile, channel) for the cotangent; for the weights, which lie in [2^-21.3, 1),
+ * the constant 2^15 since round 6 --, fp32 accumulation; see the bits below for the number of terms); atomic-free and
  * bit-reproducible.  Shape since round 5: a wave per 32 channels of the slice, the four pixel blocks'
  * contributions to a tile row meet in its accumulators (csrc/raster_bwd_rows_cw.h).  bit 5 (32): the fp32 matrix
  * instructions instead (rounds 1-2's kernel).  bit 9 (512): round 4's shape (a wave per pixel block, rows merged in LDS;
