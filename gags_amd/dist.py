@@ -244,7 +244,7 @@ class OverlappedGradReducer:
     untouched gradient.  `exposed_ms()` = time the compute stream spent on the exchange after the backward had finished."""
 
     def __init__(self, mode="rs_ag", wire=None, bucket_bytes=BUCKET_BYTES, rows="union", param=None, sync_free=False,
-                 cap_margin=1.1, cap_slack=1024, context=None, loopback=None):
+                 cap_margin=1.1, cap_slack=1024, context=None, loopback=None, early_unpack=True):
         if rows not in ("union", "all"):
             raise ValueError(rows)
         if wire not in (None, "fp32", "bf16"):
@@ -258,6 +258,12 @@ class OverlappedGradReducer:
         # bytes a reduce-scatter + all-gather move through this GPU's memory).  bench.py prices the N > 1 code path on one
         # GPU with it (`view_dp_overhead_ms`); the "sum" it returns is this rank's own gradient.
         self.loopback = loopback
+        # early_unpack (device tensors, not with sync_free): the sums of a range that left the wire two ranges ago are written
+        # into the gradient DURING the backward, on the compute stream, between the kernels of later ranges -- finish() is left
+        # with the last two ranges.  The tensor autograd will consume then already holds the ranks' sum in those columns, which
+        # is what every consumer is meant to see (an adopted gradient: as assigned by finish(); a copied / accumulated / cast one:
+        # the sum instead of the local rows + finish()'s `sum - local`); written in stream order, never from the exchange stream.
+        self.early_unpack = bool(early_unpack)
         self._cap_hint, self._pinned = {}, {}
         self.comm = torch.cuda.Stream() if torch.cuda.is_available() else None
         self.rows_exchanged = None  # |union| of the last step (None: all rows)
@@ -453,6 +459,15 @@ class OverlappedGradReducer:
         else:
             e = self._exchange(grad, c0, c1, wire)
         self._entries.append(e)
+        if grad.is_cuda and self.comm is not None and self.early_unpack and not self.sync_free:
+            cur = torch.cuda.current_stream()
+            for old in self._entries[:-2]:  # (two ranges old: its exchange has had two ranges' worth of kernels to finish)
+                if old.get("unpacked") or "ev" not in old:
+                    continue
+                cur.wait_event(old["ev"][1])
+                _unpack_rows(self._alias, old["idx"], old["c0"], old["c1"], old["wire"], None)
+                old["wire"].record_stream(cur)
+                old["unpacked"] = True
 
     def finish(self, param_grad):
         """Bring the sum over the ranks into `param_grad` on the compute stream; returns True if the overlapped exchange
@@ -486,6 +501,8 @@ class OverlappedGradReducer:
                        and param_grad._version == self._alias_version == self._alias._version)
             self.assigned = bool(adopted)
             for e in self._entries:
+                if e.get("unpacked"):  # (written during the backward: early_unpack)
+                    continue
                 assign = adopted
                 # range by range: the compute stream waits for THIS range's exchange only, so the sums of the early ranges are
                 # written while the later ranges are still on the wire -- what stays exposed after the last exchange is one

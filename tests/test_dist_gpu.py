@@ -167,6 +167,78 @@ def test_overlapped_union_row_exchange_with_the_real_backward(tmp_path):
         assert union < padded < N and rows_last == -1   # (the over-capacity step re-sent ALL rows: rows_exchanged is None)
 
 
+def _early_unpack_worker(rank, world, port, out_dir):
+    """D = 512: four 128-channel ranges, so that the sums of the first two are written into the gradient DURING the backward
+    (OverlappedGradReducer(early_unpack=True), the default) and finish() is left with the last two.  Four steps per rank:
+    {early, late} x {the gradient adopted by autograd, a second consumer of the parameter in the graph}."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gags_amd import synthetic as syn
+    from gags_amd.dist import OverlappedGradReducer
+    from gags_amd.gaussian_renderer import render
+    dev = torch.device("cuda", 0)
+    d = 512
+    pc = syn.make_model(N, d, W, H, seed=3, device=dev, gen_device=dev, scale0=syn.SCALE0 * 6.0)
+    pc.training_setup()
+    cam = syn.make_camera(W, H, view=rank + 2, device=dev)
+    G = syn.make_cotangent(d, H, W, seed=10 + rank, device=dev)
+    R = syn.make_cotangent(d, 1, N, seed=77, device=dev)[:, 0, :].t().contiguous()  # [N, d]: the second consumer's weights
+    bg = torch.zeros(3, device=dev)
+    for early in (True, False):
+        red = OverlappedGradReducer(mode="allreduce", rows="union", early_unpack=early)
+        for second in (False, True):
+            pc._semantic_feature.grad = None
+            loss = (render(cam, pc, None, bg, feature_mode=True)["render"] * G).sum()
+            if second:
+                loss = loss + (pc._semantic_feature * R).sum()
+            with red:
+                loss.backward()
+            used = red.finish(pc._semantic_feature.grad)
+            torch.cuda.synchronize()
+            assert used and (red.assigned is (not second))
+            np.save(os.path.join(out_dir, f"eu_{int(early)}_{int(second)}_{rank}.npy"), pc._semantic_feature.grad.detach().cpu().numpy())
+    np.save(os.path.join(out_dir, f"eu_R_{rank}.npy"), R.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sums_written_during_the_backward_equal_the_sums_written_by_finish(tmp_path):
+    from gags_amd import synthetic as syn
+    from gags_amd.gaussian_renderer import render
+    dev = torch.device("cuda", 0)
+    d = 512
+    pc = syn.make_model(N, d, W, H, seed=3, device=dev, gen_device=dev, scale0=syn.SCALE0 * 6.0)
+    pc.training_setup()
+    bg = torch.zeros(3, device=dev)
+    per_view = []
+    for v in range(2):
+        pc._semantic_feature.grad = None
+        cam = syn.make_camera(W, H, view=v + 2, device=dev)
+        G = syn.make_cotangent(d, H, W, seed=10 + v, device=dev)
+        (render(cam, pc, None, bg, feature_mode=True)["render"] * G).sum().backward()
+        per_view.append(pc._semantic_feature.grad.detach().clone())
+    ref = (per_view[0] + per_view[1]).cpu().numpy()
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_early_unpack_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    for r in range(world):
+        R = np.load(tmp_path / f"eu_R_{r}.npy")
+        for early in (0, 1):
+            np.testing.assert_array_equal(np.load(tmp_path / f"eu_{early}_0_{r}.npy"), ref)   # adopted: assigned sums, exact
+            # a second consumer: autograd sums the two terms itself; the regulariser's term stays rank-local.  The early ranges
+            # hold R + sum (one addition), the late ones (R + local) + (sum - local): equal up to an fp32 rounding or two
+            got = np.load(tmp_path / f"eu_{early}_1_{r}.npy")
+            np.testing.assert_allclose(got, ref + R, rtol=0, atol=4e-6 * max(1.0, float(np.abs(ref).max())))
+        # ... and where both write by assignment the two orders agree bit for bit
+        np.testing.assert_array_equal(np.load(tmp_path / f"eu_1_0_{r}.npy"), np.load(tmp_path / f"eu_0_0_{r}.npy"))
+
+
 @pytest.mark.parametrize("n,p", [(1, 1.0), (7, 0.5), (2048, 0.3), (2049, 0.01), (100_003, 0.27), (1_500_000, 0.3), (5000, 0.0)])
 def test_compact_mask_is_the_ascending_nonzero_list(n, p):
     """gags_compact_mask against torch.nonzero: ascending row numbers, -1 padding behind the count, a capacity below the
