@@ -309,6 +309,8 @@ int staged_entry(int d, int n, int width, int height, const int32_t *isect_offse
     if (n == 0) return GAGS_OK;
     if (!isect_offsets || !blk_rows || !rowmap || !fwd_scratch || !scratch || !v_colors || !v_render_colors)
         return GAGS_EINVAL;
+    // (the rows kernel reads a tile's four slot counts as ONE 16-byte scalar load)
+    if (reinterpret_cast<uintptr_t>(blk_rows) & 15) return GAGS_EINVAL;
     const FwdScratch L = fwd_layout(n_isects, width, height);
     if (fwd_scratch_bytes < L.total) return GAGS_ESCRATCH;
     const char *fs = (const char *)fwd_scratch;

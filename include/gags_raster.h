@@ -214,6 +214,7 @@ int gags_raster_bwd(int d, int width, int height, const float *means2d, const fl
  * row count `rows` (read it with gags_read_i32).  rowmap: gags_bwd_rowmap_elems(...) int32;
  * scratch: gags_bwd_rowmap_scratch_bytes(n_isects) bytes.
  *
+ * blk_rows (as gags_raster_fwd wrote it: four int32 per tile) must be 16-byte aligned: a tile's four counts are one load.
  * gags_raster_bwd_colors_staged: per tile the four pixel blocks' partial rows are merged on chip and stored
  * once per (tile, Gaussian), the rows are sorted by Gaussian and reduced; v_colors[N,D] is written in full
  * (no zero-fill needed).  scratch: gags_bwd_staged_scratch_bytes(rows, n, d) bytes.

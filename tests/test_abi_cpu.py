@@ -89,6 +89,15 @@ def test_argument_validation_returns_codes_without_launching(lib):
     staged = (128, 8, 16, 16, None, 0, None, None, None, 0, None, 0, None, 0, None, 3, 0, 128)
     assert lib.gags_raster_bwd_colors_staged_wire(*staged, None, None, None, None, None) == -1
     assert lib.gags_raster_bwd_colors_staged_keep(*staged, None, None, None) == -1            # both flag arrays are required
+    # the staged backward wants the forward's per-block slot counts 16-byte aligned (one scalar load per tile)
+    import ctypes
+    buf = (ctypes.c_int32 * 64)()
+    base = ctypes.addressof(buf)
+    al = base + (-base % 16)
+    P = ctypes.c_void_p
+    common = dict(pre=(128, 8, 16, 16, P(al), 0, P(al)), post=(P(al), 0, P(al), 0, P(al), 0, P(al), 3))
+    assert lib.gags_raster_bwd_colors_staged(*common["pre"], P(al + 4), *common["post"], None) == -1
+    assert lib.gags_raster_bwd_colors_staged(*common["pre"], P(al), *common["post"], None) == -3   # (aligned: on to the scratch-size check)
     assert lib.gags_decoder_layer_split(8, 4, 4, *([None] * 2), 4, *([None] * 2), 1, *([None] * 4), 4, 5, None) == -1   # terms = 5
     assert lib.gags_decoder_wgrad_split(8, 4, 4, None, 4, None, None, 4, None, None, None, 0, 1, None) == -1            # terms = 1
 
