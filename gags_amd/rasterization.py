@@ -726,6 +726,16 @@ class _EarlyRowmap:
             self.host = None
         return self._rows
 
+    def __del__(self):
+        # a forward that was never differentiated: its pinned word goes back to the pool (a later user's copy is enqueued behind
+        # this one's on the same stream, and is read behind its own event)
+        try:
+            if self.host is not None:
+                self.rctx.give_pinned(self.dev, self.host)
+                self.host = None
+        except Exception:
+            pass
+
 
 def _early_rowmap(lib, rctx, offsets, blk_rows, fwd_scratch, n_isects, width, height, dev):
     ne = lib.gags_bwd_rowmap_elems(n_isects, width, height)
