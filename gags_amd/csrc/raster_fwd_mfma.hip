@@ -416,12 +416,12 @@ __global__ __launch_bounds__(64, 2) void raster_fwd_feat_f16(
 // float64 statement as the fp32 matrix instructions (tests/test_parity_gpu.py::test_forward_x16_*), but NOT bit-identical
 // to the sequential fmaf chain of the oracle -- GAGS_FWD_EXACT selects raster_fwd_feat above, which is.
 // 48 MFMAs of 32 cycles per 16 slots x 64 pixels x 128 channels instead of 64 of 64 cycles.
-// One wave per (tile, 8x8 block, 128-channel slice), K-steps of 16 slots: lane (p, kg) holds, as A operand, the weights of
+// One wave per (tile, 8x8 block) and PAIR of 128-channel slices (round 6: see the kernel), K-steps of 16 slots: lane (p, kg) holds, as A operand, the weights of
 // pixel p (upper / lower half of the block) for slots 8 kg .. 8 kg + 7 of the step, and as B operand channel 4 p + j of
 // the same eight slots (tile j = channels ch0 + 4 n + j: the strided tiles of the fp32 kernel, same float4 epilogue).
 // The split is done in registers on the way (per four values 8 v_and + 4 packed fp32 subtractions + 6 v_perm: 216 per step;
-// rounds 5's scalar subtractions: 264), then the next step's rows are requested into the registers the split has freed, then the 48 MFMAs run (four accumulators in
-// rotation).  The ids of a step's slots arrive as ONE vector load (each 16-lane row holds its half-wave's eight ids) and
+// rounds 5's scalar subtractions: 264), then the 48 MFMAs run (four accumulators in rotation) with the next step's requests placed among them: its weights ahead
+// of them, its rows in the middle -- into the registers the first two channel tiles' operands have left.  The ids of a step's slots arrive as ONE vector load (each 16-lane row holds its half-wave's eight ids) and
 // reach the address arithmetic through DPP row broadcasts: one VALU instruction per gathered row.
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
