@@ -1,6 +1,7 @@
 // K8b + the WEIGHTS pass of the matrix-core rasterizer.
 //
-// raster_weights: one wave per (tile, 8x8 pixel block; each lane owns two pixels).  It does ALL the per-(pixel, Gaussian)
+// raster_weights: one wave per (tile, 8x8 pixel block), one PIXEL per lane, one hit at a time (round 6; before: a pixel pair per
+// lane and two hits per step).  It does ALL the per-(pixel, Gaussian)
 // scalar work of the view exactly once -- alpha, skip rule, transmittance chain, stop rule --
 // independent of the feature width, at high occupancy (no accumulators: ~45 VGPRs), and leaves
 // behind what the feature-width-proportional passes need as pure streams:
