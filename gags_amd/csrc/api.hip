@@ -1,6 +1,7 @@
 // C-ABI entry points of the raster stages: argument validation + dispatch onto the VALU kernels
 // (narrow / odd D, full geometry gradients) and the matrix-core kernels (D >= 16, D % 4 == 0;
 // the single-kernel fallbacks: D % 32 == 0).
+#include <cstdlib>
 #include "common.h"
 #include "scan.h"
 
@@ -20,7 +21,8 @@ int gags_pack_isects_launch(int n, int n_isects, const int32_t *flat, const floa
 int gags_raster_weights_launch(int width, int height, int n_gauss, const void *packed, int by_gauss, const int32_t *offsets,
                                const int32_t *flat, int n_isects, float *wt, int32_t *gid_s, int32_t *sidx_s,
                                int32_t *hit, int32_t *blk_rows, float *Tbuf, float *alphas, int32_t *last_ids,
-                               hipStream_t st);
+                               hipStream_t st, const float *colors16 = nullptr, const float *backgrounds = nullptr,
+                               float *render_colors = nullptr);
 int gags_list_need_launch(int width, int height, int n_gauss, const void *packed, int by_gauss, const int32_t *offsets,
                           const int32_t *flat, int n_isects, int32_t *need, hipStream_t st);
 int gags_trim_offsets_launch(int n_tiles, const int32_t *cum, int32_t *off_new, hipStream_t st);
@@ -107,6 +109,15 @@ extern "C" int64_t gags_raster_fwd_scratch_bytes(int64_t n_isects, int width, in
     return fwd_layout(n_isects, width, height).total;
 }
 
+namespace {
+// GAGS_FWD_D16_UNFUSED=1 (experiments; read once): the 16-channel feature pass as its own kernel
+bool fwd_d16_unfused()
+{
+    static const bool v = [] { const char *e = getenv("GAGS_FWD_D16_UNFUSED"); return e && e[0] == '1'; }();
+    return v;
+}
+}  // namespace
+
 extern "C" int gags_raster_fwd(int d, int n, int width, int height, const float *means2d, const float *conics,
                                const float *opacities, const float *colors, const float *backgrounds,
                                const int32_t *isect_offsets, const int32_t *flatten_ids, int64_t n_isects,
@@ -129,11 +140,15 @@ extern "C" int gags_raster_fwd(int d, int n, int width, int height, const float 
             int32_t *gid_s = (int32_t *)(sb + L.gid);
             float *tbuf = (float *)(sb + L.tbuf);
             int rc = GAGS_OK;
+            // an fp32 table of exactly 16 channels (the reference's own width, train.py:68): the feature pass rides along with
+            // the weights pass (bit-identical to the feature kernel: raster_weights.hip); the two ONLY_* flags keep the passes apart
+            const bool fuse16 = d == 16 && !(flags & (GAGS_FEAT_F16 | GAGS_FWD_ONLY_FEATURES | GAGS_FWD_ONLY_WEIGHTS)) && n_isects > 0 &&
+                                !(reinterpret_cast<uintptr_t>(render_colors) & 15) && !fwd_d16_unfused();
             if (!(flags & GAGS_FWD_ONLY_FEATURES))
                 rc = gags_raster_weights_launch(width, height, n, packed, (flags & GAGS_RECS_BY_GAUSSIAN) ? 1 : 0, isect_offsets, flatten_ids, (int)n_isects, wt,
                                                 gid_s, (int32_t *)(sb + L.sidx), (int32_t *)(sb + L.hit), blk_rows, tbuf,
-                                                render_alphas, last_ids, st);
-            if (rc != GAGS_OK || (flags & GAGS_FWD_ONLY_WEIGHTS)) return rc;
+                                                render_alphas, last_ids, st, fuse16 ? colors : nullptr, backgrounds, render_colors);
+            if (rc != GAGS_OK || (flags & GAGS_FWD_ONLY_WEIGHTS) || fuse16) return rc;
             return gags_raster_fwd_feat_launch(d, width, height, n, colors, (flags & GAGS_FEAT_F16) ? ((flags & GAGS_FWD_F16MFMA) ? 2 : 1) : 0,
                                                (flags & GAGS_FWD_EXACT) ? 1 : 0, backgrounds, isect_offsets, (int)n_isects,
                                                blk_rows, wt, gid_s, tbuf, render_colors, st);

@@ -66,14 +66,23 @@ __global__ __launch_bounds__(256) void gather_grec_kernel(int n_isects, const in
 // any of its pixels reads before the tile is done (all pixels saturated, or the list exhausted).  Heavy views stop after a few
 // hundred of a tile's tens of thousands of entries; run on the list cut to need[tile], every pass below does exactly what it
 // does on the full list -- same hits, same pairs, same order -- while its scratch (1 KB per LIST ENTRY) shrinks by that factor.
-template <bool COUNT>
+// FD (round 6): the feature pass of a table of exactly FD = 16 channels -- the width the reference itself rasterizes
+// (train.py:68) -- FUSED into this pass: with one pixel per lane the weight of a hit is in a register, the hit's feature row is
+// the same for the whole wave (sixteen floats: one scalar load), and  acc[c] = fmaf(f[c], w, acc[c])  in list order is the
+// oracle's own chain (a zero weight is an exact no-op): the render is bit-identical to raster_fwd_feat<1>'s, which streams
+// the 1.1 GB of weight tiles a second time for sixteen channels' worth of arithmetic.  The tiles are still written (the
+// backward reads them).
+template <bool COUNT, int FD = 0>
 __global__ __launch_bounds__(64, 8) void raster_weights_kernel(
     int width, int height, int tile_w, int n_tiles, int n_gauss, const GRec *__restrict__ packed,
     const int32_t *__restrict__ offsets, const int32_t *__restrict__ flatten_ids, int n_isects,
     float *__restrict__ wt, int32_t *__restrict__ gid_s, int32_t *__restrict__ sidx_s, int32_t *__restrict__ hit,
     int32_t *__restrict__ blk_rows, float *__restrict__ Tbuf, float *__restrict__ render_alphas,
-    int32_t *__restrict__ last_ids, int by_gauss, int32_t *__restrict__ need)
+    int32_t *__restrict__ last_ids, int by_gauss, int32_t *__restrict__ need,
+    const float *__restrict__ colors = nullptr, const float *__restrict__ backgrounds = nullptr,
+    float *__restrict__ render_colors = nullptr)
 {
+    static_assert(!(COUNT && FD > 0), "the count mode has no outputs");
     __shared__ __attribute__((aligned(16))) HRec ring[RING];
 
     const int logical = gags_xcd_remap(blockIdx.x, n_tiles * GAGS_BLOCKS_PER_TILE);
@@ -101,6 +110,9 @@ __global__ __launch_bounds__(64, 8) void raster_weights_kernel(
     float T = 1.0f;
     int cur = 0;
     bool done = !inside;
+    float facc[FD > 0 ? FD : 1];
+#pragma unroll
+    for (int c = 0; c < (FD > 0 ? FD : 1); ++c) facc[c] = 0.f;
 
     HitStream hs;
     hs.by_gauss = by_gauss != 0;
@@ -137,6 +149,12 @@ __global__ __launch_bounds__(64, 8) void raster_weights_kernel(
                 hit[h.sidx] = 1;  // up to four blocks store the same 1
             }
             row += 1;
+            if constexpr (FD > 0) {
+                // (the hit's Gaussian is the same for every lane: its row arrives by scalar loads)
+                const float *frow = colors + (size_t)__builtin_amdgcn_readfirstlane(h.gid) * FD;
+#pragma unroll
+                for (int c = 0; c < FD; ++c) facc[c] = __builtin_fmaf(frow[c], w, facc[c]);
+            }
         }
     }
     if constexpr (COUNT) {
@@ -155,6 +173,15 @@ __global__ __launch_bounds__(64, 8) void raster_weights_kernel(
     if (inside) {
         const size_t pix = (size_t)pi * width + pj;
         Tbuf[pix] = T; render_alphas[pix] = 1.0f - T; last_ids[pix] = cur;
+        if constexpr (FD > 0) {
+            if (backgrounds != nullptr) {  // (wave-uniform)
+#pragma unroll
+                for (int c = 0; c < FD; ++c) facc[c] = __builtin_fmaf(T, backgrounds[c], facc[c]);
+            }
+            float4 *o = reinterpret_cast<float4 *>(render_colors + pix * FD);
+#pragma unroll
+            for (int c = 0; c < FD; c += 4) o[c >> 2] = make_float4(facc[c], facc[c + 1], facc[c + 2], facc[c + 3]);
+        }
     }
 }
 
@@ -182,16 +209,22 @@ int gags_pack_isects_launch(int n, int n_isects, const int32_t *flat, const floa
 int gags_raster_weights_launch(int width, int height, int n_gauss, const void *packed, int by_gauss, const int32_t *offsets,
                                const int32_t *flat, int n_isects, float *wt, int32_t *gid_s, int32_t *sidx_s,
                                int32_t *hit, int32_t *blk_rows, float *Tbuf, float *alphas, int32_t *last_ids,
-                               hipStream_t st)
+                               hipStream_t st, const float *colors16, const float *backgrounds, float *render_colors)
 {
     GAGS_CLEAR_ERR();
     const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
     const int n_tiles = tile_w * tile_h;
     // hit[i] = 1 for every intersection that blends into at least one pixel of its tile (+1 entry: an empty view)
     if (hipMemsetAsync(hit, 0, sizeof(int32_t) * ((size_t)n_isects + 1), st) != hipSuccess) return GAGS_ELAUNCH;
-    hipLaunchKernelGGL(raster_weights_kernel<false>, dim3(n_tiles * GAGS_BLOCKS_PER_TILE), dim3(64), 0, st, width, height, tile_w, n_tiles,
-                       n_gauss, reinterpret_cast<const GRec *>(packed), offsets, flat, n_isects, wt, gid_s, sidx_s, hit,
-                       blk_rows, Tbuf, alphas, last_ids, by_gauss, (int32_t *)nullptr);
+    if (colors16)  // the 16-channel feature pass rides along (render_colors [H, W, 16] written here)
+        hipLaunchKernelGGL((raster_weights_kernel<false, 16>), dim3(n_tiles * GAGS_BLOCKS_PER_TILE), dim3(64), 0, st, width, height, tile_w,
+                           n_tiles, n_gauss, reinterpret_cast<const GRec *>(packed), offsets, flat, n_isects, wt, gid_s, sidx_s, hit,
+                           blk_rows, Tbuf, alphas, last_ids, by_gauss, (int32_t *)nullptr, colors16, backgrounds, render_colors);
+    else
+        hipLaunchKernelGGL(raster_weights_kernel<false>, dim3(n_tiles * GAGS_BLOCKS_PER_TILE), dim3(64), 0, st, width, height, tile_w, n_tiles,
+                           n_gauss, reinterpret_cast<const GRec *>(packed), offsets, flat, n_isects, wt, gid_s, sidx_s, hit,
+                           blk_rows, Tbuf, alphas, last_ids, by_gauss, (int32_t *)nullptr, (const float *)nullptr, (const float *)nullptr,
+                           (float *)nullptr);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }
@@ -239,7 +272,7 @@ int gags_list_need_launch(int width, int height, int n_gauss, const void *packed
     hipLaunchKernelGGL(raster_weights_kernel<true>, dim3(n_tiles * GAGS_BLOCKS_PER_TILE), dim3(64), 0, st, width, height, tile_w, n_tiles,
                        n_gauss, reinterpret_cast<const GRec *>(packed), offsets, flat, n_isects, (float *)nullptr, (int32_t *)nullptr,
                        (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (float *)nullptr, (float *)nullptr,
-                       (int32_t *)nullptr, by_gauss, need);
+                       (int32_t *)nullptr, by_gauss, need, (const float *)nullptr, (const float *)nullptr, (float *)nullptr);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }
