@@ -164,7 +164,8 @@ int gags_pack_isects(int n, int64_t n_isects, const int32_t *flatten_ids, const 
  * narrow one) when `scratch` (gags_raster_fwd_scratch_bytes) and `blk_rows` ([tile_h*tile_w*4] int32, written: slots per
  * 8x8 pixel block) are provided, else (D % 32 == 0) as one fused kernel; anything else runs the
  * VALU kernels.  The scratch and blk_rows of a split forward are what
- * gags_raster_bwd_colors_staged consumes, so keep them alive until the backward. * An fp32 table of exactly 16 channels (the reference's own width) is composited by the weights pass itself (round 6: one
+ * gags_raster_bwd_colors_staged consumes, so keep them alive until the backward.
+ * An fp32 table of exactly 16 channels (the reference's own width) is composited by the weights pass itself (round 6: one
  * kernel, bit-identical to the separate feature pass; not with GAGS_FWD_ONLY_WEIGHTS / _ONLY_FEATURES).
  */
 int64_t gags_raster_fwd_scratch_bytes(int64_t n_isects, int width, int height);
