@@ -131,6 +131,13 @@ extern "C" int gags_raster_fwd(int d, int n, int width, int height, const float 
     const bool split = scratch && blk_rows && gags_mfma_width(d);
     if ((flags & GAGS_FEAT_F16) && (!split || (flags & GAGS_FWD_NO_MFMA) || !packed || n <= 0))
         return GAGS_EINVAL;  // an fp16 feature table is only read by the feature pass of the split forward
+    if (d == 16 && !scratch && !blk_rows && packed && n > 0 && n_isects > 0 && !(flags & (GAGS_FWD_NO_MFMA | GAGS_FEAT_F16)) &&
+        !(reinterpret_cast<uintptr_t>(render_colors) & 15) && !fwd_d16_unfused()) {
+        // a 16-channel render without scratch (nobody will differentiate it): the fused weights + feature pass alone, no tiles
+        return gags_raster_weights_launch(width, height, n, packed, (flags & GAGS_RECS_BY_GAUSSIAN) ? 1 : 0, isect_offsets, flatten_ids,
+                                          (int)n_isects, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, render_alphas, last_ids, st,
+                                          colors, backgrounds, render_colors);
+    }
     if (!(flags & GAGS_FWD_NO_MFMA) && (split || fused_width(d)) && (packed || n_isects == 0) && n > 0) {
         if (split) {  // split forward: weights once, then the feature stream
             const FwdScratch L = fwd_layout(n_isects, width, height);

@@ -142,11 +142,13 @@ __global__ __launch_bounds__(64, 8) void raster_weights_kernel(
         // a hit that blends into none of the block's pixels leaves no slot: zero rows would be multiplied, stored, sorted and
         // summed like any other -- they were 20 % of all rows
         if (__ballot(w != 0.f) != 0ull) {
-            wt[(size_t)row * 64 + e] = w;
-            if (e == 0) {
-                gid_s[row] = h.gid;
-                sidx_s[row] = h.sidx;
-                hit[h.sidx] = 1;  // up to four blocks store the same 1
+            if (FD == 0 || wt != nullptr) {  // (FD > 0 without tiles: a render nobody differentiates -- nothing but the image leaves)
+                wt[(size_t)row * 64 + e] = w;
+                if (e == 0) {
+                    gid_s[row] = h.gid;
+                    sidx_s[row] = h.sidx;
+                    hit[h.sidx] = 1;  // up to four blocks store the same 1
+                }
             }
             row += 1;
             if constexpr (FD > 0) {
@@ -165,14 +167,18 @@ __global__ __launch_bounds__(64, 8) void raster_weights_kernel(
     const int cnt = (used + 1) & ~1;  // consumers take slots in pairs: an odd count is padded with one zero slot that belongs to no Gaussian
     // ... and the region is filled with zero slots up to the next multiple of 16 (its capacity is one: gags_slot_base), so
     // that the 16-slot steps of the 16-bit matrix-core feature pass need neither a clamp nor a mask
-    for (int r = used; r < ((used + 15) & ~15); ++r) {
-        wt[(size_t)(sb + r) * 64 + e] = 0.f;
-        if (e == 0) { gid_s[sb + r] = n_gauss; sidx_s[sb + r] = -1; }
+    const bool tiles = FD == 0 || wt != nullptr;  // (wave-uniform)
+    if (tiles) {
+        for (int r = used; r < ((used + 15) & ~15); ++r) {
+            wt[(size_t)(sb + r) * 64 + e] = 0.f;
+            if (e == 0) { gid_s[sb + r] = n_gauss; sidx_s[sb + r] = -1; }
+        }
+        if (lane == 0) blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk] = cnt;
     }
-    if (lane == 0) blk_rows[tile * GAGS_BLOCKS_PER_TILE + blk] = cnt;
     if (inside) {
         const size_t pix = (size_t)pi * width + pj;
-        Tbuf[pix] = T; render_alphas[pix] = 1.0f - T; last_ids[pix] = cur;
+        if (tiles) Tbuf[pix] = T;
+        render_alphas[pix] = 1.0f - T; last_ids[pix] = cur;
         if constexpr (FD > 0) {
             if (backgrounds != nullptr) {  // (wave-uniform)
 #pragma unroll
@@ -215,7 +221,7 @@ int gags_raster_weights_launch(int width, int height, int n_gauss, const void *p
     const int tile_w = (width + GAGS_TILE - 1) / GAGS_TILE, tile_h = (height + GAGS_TILE - 1) / GAGS_TILE;
     const int n_tiles = tile_w * tile_h;
     // hit[i] = 1 for every intersection that blends into at least one pixel of its tile (+1 entry: an empty view)
-    if (hipMemsetAsync(hit, 0, sizeof(int32_t) * ((size_t)n_isects + 1), st) != hipSuccess) return GAGS_ELAUNCH;
+    if (hit && hipMemsetAsync(hit, 0, sizeof(int32_t) * ((size_t)n_isects + 1), st) != hipSuccess) return GAGS_ELAUNCH;
     if (colors16)  // the 16-channel feature pass rides along (render_colors [H, W, 16] written here)
         hipLaunchKernelGGL((raster_weights_kernel<false, 16>), dim3(n_tiles * GAGS_BLOCKS_PER_TILE), dim3(64), 0, st, width, height, tile_w,
                            n_tiles, n_gauss, reinterpret_cast<const GRec *>(packed), offsets, flat, n_isects, wt, gid_s, sidx_s, hit,

@@ -517,11 +517,14 @@ class _Rasterize(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, packed, width, height,
-                flags, prezero=None, rctx=None, n_isects=None):
+                flags, prezero=None, rctx=None, n_isects=None, grad_on=True):
         """offsets: the buffer of n_tiles + 1 int32 entries tile_binning returns as `offsets_full` (last entry = the
         intersection count), or a gsplat-style [tile_h, tile_w] tensor together with `n_isects` (the count is then attached
         here).  rctx: the RasterContext of the call."""
         lib = _lib.load()
+        # (ctx.needs_input_grad says what requires grad, not whether a graph is being recorded: under torch.no_grad() it is
+        # still True -- `grad_on` is torch.is_grad_enabled() at the call, taken by rasterization() outside this forward)
+        needs = tuple(bool(g) and bool(grad_on) for g in ctx.needs_input_grad)
         means2d, conics, opacities = _c(means2d), _c(conics), _c(opacities)
         # an fp16 feature table (BASELINE.json configs[4]) is read as it is by the matrix-core feature pass: widened
         # exactly, same fp32 arithmetic; every other kernel gets fp32
@@ -540,7 +543,11 @@ class _Rasterize(torch.autograd.Function):
         split = n > 0 and packed is not None and not (flags & (_lib.GAGS_FWD_NO_MFMA | _lib.GAGS_FWD_FUSED))
         scratch = blk_rows = None
         nbytes = 0
-        if split:
+        # a 16-channel fp32 render that nothing will be differentiated through (evaluation: render.py, the relevancy queries):
+        # the fused weights + feature pass alone (csrc/raster_weights.hip) -- no weight tiles, no 1 KB per intersection of scratch
+        lean16 = (split and d == 16 and not half and n_isects > 0 and not any(needs)
+                  and not (flags & _lib.GAGS_FWD_EXACT) and not profiler.ENABLED)
+        if split and not lean16:
             nbytes = lib.gags_raster_fwd_scratch_bytes(n_isects, width, height)
             try:
                 scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -555,6 +562,8 @@ class _Rasterize(torch.autograd.Function):
                 split, nbytes, scratch = False, 0, None
                 if half:
                     half, colors = False, colors.float()
+        if lean16:
+            split = False
         if split:
             blk_rows = torch.empty(n_tiles * 4, dtype=torch.int32, device=dev)  # per 8x8 pixel block
         cflags = ((flags & 3) | (flags & _lib.GAGS_FWD_EXACT) | _lib.GAGS_RECS_BY_GAUSSIAN | (_lib.GAGS_FEAT_F16 if half else 0)
@@ -576,16 +585,16 @@ class _Rasterize(torch.autograd.Function):
                 launch()
         if split:
             profiler.note("fwd_blk_rows", blk_rows)
-        need_geom = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[3]
+        need_geom = needs[0] or needs[1] or needs[3]
         rctx_ = rctx if rctx is not None else default_context()
         early = None
-        if (split and n_isects > 0 and rctx_.early_rowmap and ctx.needs_input_grad[2] and not need_geom and _mfma_width(d)
+        if (split and n_isects > 0 and rctx_.early_rowmap and needs[2] and not need_geom and _mfma_width(d)
                 and d <= 1024 and not (flags & _lib.GAGS_BWD_ATOMIC) and not rctx_.capacity_mode):
             with profiler.stage("bwd_rowcount"):
                 early = _early_rowmap(lib, rctx_, offsets, blk_rows, scratch, n_isects, width, height, dev)
         # wide-D geometry gradients on the matrix cores (gags_raster_bwd_geom) also consume the forward's scratch
         geom_mfma = split and need_geom and _geom_mfma_width(d) and not (flags & _lib.GAGS_BWD_ATOMIC)
-        staged = (split and _mfma_width(d) and d <= 1024 and (ctx.needs_input_grad[2] or geom_mfma)
+        staged = (split and _mfma_width(d) and d <= 1024 and (needs[2] or geom_mfma)
                   and not (flags & _lib.GAGS_BWD_ATOMIC))
         ctx.geom_mfma = bool(geom_mfma and staged)
         ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds, offsets, flatten_ids, packed, alphas,
@@ -619,7 +628,7 @@ class _Rasterize(torch.autograd.Function):
             v_colors = _backward_staged(lib, ctx.rctx, offsets, n_isects, blk_rows, fwd_scratch, v_out, n, d, width, height,
                                         (32 if (flags & _lib.GAGS_BWD_F32MFMA) else 0) | (64 if ctx.half else 0) | (512 if (flags & _lib.GAGS_BWD_BLOCKWAVES) else 0) | (1024 if (flags & _lib.GAGS_BWD_EXACT_WEIGHTS) else 0),
                                         flatten_ids, ctx.prezero, early=ctx.early)
-            return None, None, v_colors, None, v_bg, None, None, None, None, None, None, None, None, None
+            return None, None, v_colors, None, v_bg, None, None, None, None, None, None, None, None, None, None
         if need_geom and blk_rows is not None and ctx.geom_mfma:
             # wide D: colours through the staged backward, geometry through the matrix-core dot pass + scalar pass
             v_colors = None
@@ -649,7 +658,7 @@ class _Rasterize(torch.autograd.Function):
                                                _stream()),
                       "gags_raster_bwd_geom")
             v_con, v_m2d, v_opac = v_geo[:, 0:3].contiguous(), v_geo[:, 3:5].contiguous(), v_geo[:, 5].contiguous()
-            return v_m2d, v_con, v_colors, v_opac, v_bg, None, None, None, None, None, None, None, None, None
+            return v_m2d, v_con, v_colors, v_opac, v_bg, None, None, None, None, None, None, None, None, None, None
         if ctx.half:  # VALU / atomic kernels read an fp32 table: widen the halves (exact); gradient returned in the table's dtype
             colors = colors.float()
         v_colors = torch.zeros(n, d, device=dev)
@@ -668,7 +677,7 @@ class _Rasterize(torch.autograd.Function):
                                       ptr(v_opac), ptr(v_m2d), ptr(v_con), bflags, _stream()), "gags_raster_bwd")
         if ctx.half:
             v_colors = v_colors.half()
-        return v_m2d, v_con, v_colors, v_opac, v_bg, None, None, None, None, None, None, None, None, None
+        return v_m2d, v_con, v_colors, v_opac, v_bg, None, None, None, None, None, None, None, None, None, None
 
 
 def _offsets_with_count(offsets, n_tiles, n_isects):
@@ -1007,7 +1016,7 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, 
         # any width in ONE rasterization: 513 = 512 CLIP channels + 1 (BASELINE.json configs[4] "512-d feat + granularity")
         # is four 128-channel slices and one lane of a narrow slice on the same matrix-core kernels, into one output tensor
         r = _Rasterize.apply(means2d, conics, cols, opacities, bg, offs, flat, b[4], width, height, int(raster_flags), prezero,
-                             rctx, None)
+                             rctx, None, torch.is_grad_enabled())
         if trimmed is not None:
             # last_ids are sorted indices: a COPY goes back to the full lists' numbering for the caller (the autograd node keeps
             # its own, which matches the lists it saved)

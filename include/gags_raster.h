@@ -167,6 +167,8 @@ int gags_pack_isects(int n, int64_t n_isects, const int32_t *flatten_ids, const 
  * gags_raster_bwd_colors_staged consumes, so keep them alive until the backward.
  * An fp32 table of exactly 16 channels (the reference's own width) is composited by the weights pass itself (round 6: one
  * kernel, bit-identical to the separate feature pass; not with GAGS_FWD_ONLY_WEIGHTS / _ONLY_FEATURES).
+ * The same table with `scratch` and `blk_rows` both NULL (a render nobody differentiates) runs that kernel without writing
+ * weight tiles: no scratch needed, same pixels bit for bit, ~20 % less time; there is then nothing for a backward to consume.
  */
 int64_t gags_raster_fwd_scratch_bytes(int64_t n_isects, int width, int height);
 int gags_raster_fwd(int d, int n, int width, int height, const float *means2d, const float *conics,

@@ -1340,3 +1340,40 @@ def test_row_map_enqueued_by_the_forward_changes_nothing(oracle, n, w, h, d, tri
     (outs[1][0] * to_dev(v_out)).sum().backward()
     assert torch.equal(cols.grad, g_first)
     np.testing.assert_array_equal(g_first.cpu().numpy(), g0["colors"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_bg", [False, True])
+def test_sixteen_channel_render_without_a_backward_needs_no_scratch(oracle, with_bg):
+    """Round 6: at D = 16 (the reference's own width, train.py:68) the feature pass rides along with the weights pass, and a
+    render nothing will be differentiated through (torch.no_grad: render.py, the relevancy queries) runs that one kernel
+    WITHOUT weight tiles -- no 1 KB per intersection of scratch.  Render, alphas and last_ids are bit-identical to the
+    differentiable render's and to the oracle's; the peak allocation is a fraction."""
+    n, w, h, d = 20000, 333, 210, 16
+    s = scene_arrays(n, d, w, h, seed=5, view=1, scale_mult=5.0)
+    bg = np.full(d, 0.3, np.float32) if with_bg else None
+    o_out, o_alpha, oi = oracle.rasterization(s["means"], s["quats"], s["scales"], s["opacities"], s["colors"], s["viewmat"],
+                                              s["K"], bg if with_bg else np.zeros(d, np.float32), w, h)
+    rng = np.random.default_rng(3)
+    v_out = rng.standard_normal((h, w, d)).astype(np.float32)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    out_g, alpha_g, info_g, _ = _run_gpu(s, w, h, s["colors"], bg, v_out=v_out)
+    peak_grad = torch.cuda.max_memory_allocated() - base
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    with torch.no_grad():
+        out_n, alpha_n, info_n, _ = _run_gpu(s, w, h, s["colors"], bg)
+    peak_lean = torch.cuda.max_memory_allocated() - base
+    np.testing.assert_array_equal(out_n, out_g)
+    np.testing.assert_array_equal(alpha_n, alpha_g)
+    assert torch.equal(info_n["last_ids"], info_g["last_ids"])
+    np.testing.assert_array_equal(out_n, o_out)
+    np.testing.assert_array_equal(alpha_n, o_alpha)
+    _check_indices(info_n, oi)
+    n_isects = int(info_n["n_isects"])
+    assert peak_grad - peak_lean > 900 * n_isects, (peak_grad, peak_lean, n_isects)   # (the slot space: ~1 KB per intersection)
