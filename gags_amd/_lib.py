@@ -88,6 +88,7 @@ SIGNATURES = {
     "gags_trained_seg": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp]),
     "gags_entropy_fwd": (_i32, [_i64, _vp, _vp, _vp]),
     "gags_entropy_bwd": (_i32, [_i64, _vp, _f32, _vp, _vp]),
+    "gags_entropy_bwd_dev": (_i32, [_i64, _vp, _vp, _vp, _vp]),
     "gags_segment_stats": (_i32, [_i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "gags_segment_stats_multi": (_i32, [_i64, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "gags_region_var_bwd_layout": (_i32, [_i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp]),
@@ -105,6 +106,7 @@ SIGNATURES = {
     "gags_decoder_layer": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_decoder_wgrad_scratch_bytes": (_i64, [_i64, _i32, _i32]),
     "gags_decoder_wgrad": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "gags_decoder_wgrad_out": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i64, _vp]),
     "gags_decoder_head_bwd": (_i32, [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "gags_decoder_unpack_grad": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp]),
     "gags_decoder_head": (_i32, [_i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
@@ -120,7 +122,8 @@ SIGNATURES = {
     "gags_decoder_head_bwd_exact": (_i32, [_i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp]),
     # the "f16" decoder tier: the same kernels with IEEE half operands (include/gags_next.h), same signatures
     **{name + "_h16": None for name in ("gags_decoder_pack_layer", "gags_decoder_pack_input", "gags_decoder_layer", "gags_decoder_head",
-                                        "gags_decoder_wgrad_scratch_bytes", "gags_decoder_wgrad", "gags_decoder_head_bwd",
+                                        "gags_decoder_wgrad_scratch_bytes", "gags_decoder_wgrad", "gags_decoder_wgrad_out",
+                                        "gags_decoder_head_bwd",
                                         "gags_decoder_unpack_grad", "gags_decoder_fwd_fused", "gags_decoder_bwd_fused",
                                         "gags_scale_decoder_fwd_fused", "gags_scale_decoder_bwd_fused")},
     "gags_decoder_head_distill_bwd_h16": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

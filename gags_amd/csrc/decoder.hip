@@ -460,6 +460,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(int64_t P, int N, int K
 // rows of column l of a [4 pixels][16 channels] block.  Row pitches of 64 B mod 256 B put the four pixel rows of a
 // read on four different quarters of the 64 banks.  The LDS image is double-buffered (one barrier per 32-pixel
 // step) and the operands of the step after next are in flight in registers meanwhile; two workgroups per CU.
+struct GagsTrue { static constexpr bool value = true; };
+struct GagsFalse { static constexpr bool value = false; };
 constexpr int W2P = 32;                       // pixels per step
 constexpr int W2ZP = 128 * 2 + 64;            // bytes per pixel row, dz image (128 channels)
 constexpr int W2XP = 256 * 2 + 64;            // bytes per pixel row, activation image (256 channels)
@@ -499,29 +501,55 @@ __global__ __launch_bounds__(256, 2) void wgrad256_kernel(int64_t P, int N, cons
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     // loads: dz piece tid & 15 (8 channels) of rows tid / 16 + 16 q; activation piece tid & 31 of rows tid / 32 + 8 q
     const int zc = (tid & 15) * 8, zr = tid >> 4, xc = (tid & 31) * 8, xr = tid >> 5;
+    // a step that lies inside the chunk (all but the last one of the last chunk) is addressed by ONE uniform base per stream and
+    // the lane's six fixed 32-bit byte offsets (round 6: the per-row form cost ~100 VALU instructions per step, quarter-rate
+    // 64-bit multiplies among them, on the SIMD whose matrix pipe waits meanwhile), without clamps and without row masks
     uint4 rz[2], rx[4], rx2[TWO ? 4 : 1];
-    auto fetch = [&](int64_t p0) __attribute__((always_inline)) {
+    unsigned zo[2], xo[4];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) rz[q] = *reinterpret_cast<const uint4 *>(dz + min(p0 + zr + 16 * q, pb - 1) * N + n0 + zc);
+    for (int q = 0; q < 2; ++q) zo[q] = (unsigned)(((zr + 16 * q) * N + zc) * 2);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int64_t o = min(p0 + xr + 8 * q, pb - 1) * K + xc;
-            rx[q] = *reinterpret_cast<const uint4 *>(a1 + o);
-            if constexpr (TWO) rx2[q] = *reinterpret_cast<const uint4 *>(a2 + o);
+    for (int q = 0; q < 4; ++q) xo[q] = (unsigned)(((xr + 8 * q) * K + xc) * 2);
+    auto fetch = [&](auto whole, int64_t p0) __attribute__((always_inline)) {
+        if constexpr (decltype(whole)::value) {
+            const char *zb = reinterpret_cast<const char *>(dz + p0 * N + n0), *xb = reinterpret_cast<const char *>(a1 + p0 * K);
+            const char *xb2 = TWO ? reinterpret_cast<const char *>(a2 + p0 * K) : nullptr;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                unsigned o = zo[q];
+                asm volatile("" : "+v"(o));  // (opaque: keeps the scalar-base + lane-offset form of the load)
+                rz[q] = *reinterpret_cast<const uint4 *>(zb + o);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned o = xo[q];
+                asm volatile("" : "+v"(o));
+                rx[q] = *reinterpret_cast<const uint4 *>(xb + o);
+                if constexpr (TWO) rx2[q] = *reinterpret_cast<const uint4 *>(xb2 + o);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) rz[q] = *reinterpret_cast<const uint4 *>(dz + min(p0 + zr + 16 * q, pb - 1) * N + n0 + zc);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t o = min(p0 + xr + 8 * q, pb - 1) * K + xc;
+                rx[q] = *reinterpret_cast<const uint4 *>(a1 + o);
+                if constexpr (TWO) rx2[q] = *reinterpret_cast<const uint4 *>(a2 + o);
+            }
         }
     };
-    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const bool do_bias = db != nullptr;
-    auto commit = [&](int buf, int64_t p0) __attribute__((always_inline)) {
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // (summed whether or not db is wanted: 24 instructions, no branch)
+    auto commit = [&](auto whole, int buf, int64_t p0) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const unsigned keep = p0 + zr + 16 * q < pb ? 0xffffffffu : 0u;  // rows beyond the chunk contribute zero
-            const uint4 v = make_uint4(rz[q].x & keep, rz[q].y & keep, rz[q].z & keep, rz[q].w & keep);
-            *reinterpret_cast<uint4 *>(&Zi[buf][(zr + 16 * q) * W2ZP + zc * 2]) = v;
-            if (do_bias) {
-                bsum[0] += bf_lo(v.x); bsum[1] += bf_hi(v.x); bsum[2] += bf_lo(v.y); bsum[3] += bf_hi(v.y);
-                bsum[4] += bf_lo(v.z); bsum[5] += bf_hi(v.z); bsum[6] += bf_lo(v.w); bsum[7] += bf_hi(v.w);
+            uint4 v = rz[q];
+            if constexpr (!decltype(whole)::value) {
+                const unsigned keep = p0 + zr + 16 * q < pb ? 0xffffffffu : 0u;  // rows beyond the chunk contribute zero
+                v = make_uint4(v.x & keep, v.y & keep, v.z & keep, v.w & keep);
             }
+            *reinterpret_cast<uint4 *>(&Zi[buf][(zr + 16 * q) * W2ZP + zc * 2]) = v;
+            bsum[0] += bf_lo(v.x); bsum[1] += bf_hi(v.x); bsum[2] += bf_lo(v.y); bsum[3] += bf_hi(v.y);
+            bsum[4] += bf_lo(v.z); bsum[5] += bf_hi(v.z); bsum[6] += bf_lo(v.w); bsum[7] += bf_hi(v.w);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -531,6 +559,8 @@ __global__ __launch_bounds__(256, 2) void wgrad256_kernel(int64_t P, int N, cons
             *reinterpret_cast<uint4 *>(&Xi[buf][(xr + 8 * q) * W2XP + xc * 2]) = v;  // (dz rows are zero there: no mask needed)
         }
     };
+    constexpr GagsTrue yes{};
+    constexpr GagsFalse no{};
     // fragment addresses of this lane inside an image (bytes): pixel row 8 (l >> 5) + ((l & 15) >> 2), channel
     // 16 ((l >> 4) & 1) + 4 (l & 3) of the 32-channel block; + 4 rows for the second half, + 16 rows for the second k step
     const int frow = 8 * (lane >> 5) + ((lane & 15) >> 2), fcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
@@ -561,18 +591,26 @@ __global__ __launch_bounds__(256, 2) void wgrad256_kernel(int64_t P, int N, cons
                 for (int j = 0; j < 4; ++j) acc[i][j] = h16_mfma(af[i], bf[j], acc[i][j]);
         }
     };
-    const int64_t steps = (pb - pa + W2P - 1) / W2P;
-    fetch(pa);
-    commit(0, pa);
-    if (steps > 1) fetch(pa + W2P);
+    const int64_t steps = (pb - pa + W2P - 1) / W2P, n_whole = (pb - pa) / W2P;
+    if (n_whole > 0) fetch(yes, pa); else fetch(no, pa);
+    if (n_whole > 0) commit(yes, 0, pa); else commit(no, 0, pa);
+    if (n_whole > 1) fetch(yes, pa + W2P); else if (steps > 1) fetch(no, pa + W2P);
     __syncthreads();
     // step s computes on image s & 1 while the registers (step s + 1) go to the other image and are refilled for s + 2
-    for (int64_t s = 0; s < steps; ++s) {
+    int64_t s = 0;
+    for (; s + 2 < n_whole; ++s) {
         const int buf = (int)(s & 1);
-        if (s + 1 < steps) commit(buf ^ 1, pa + (s + 1) * W2P);
-        if (s + 2 < steps) fetch(pa + (s + 2) * W2P);
+        commit(yes, buf ^ 1, pa + (s + 1) * W2P);
+        fetch(yes, pa + (s + 2) * W2P);
         compute(buf);
         gags_lds_barrier();  // (not __syncthreads(): that would land the fetch above before every step)
+    }
+    for (; s < steps; ++s) {  // the last two steps, and the chunk's ragged one
+        const int buf = (int)(s & 1);
+        if (s + 1 < steps) commit(no, buf ^ 1, pa + (s + 1) * W2P);
+        if (s + 2 < steps) fetch(no, pa + (s + 2) * W2P);
+        compute(buf);
+        gags_lds_barrier();
     }
     // accumulator: column = lane & 31 -> k, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -> n; 32 lanes = 128 contiguous bytes
 #pragma unroll
@@ -586,7 +624,7 @@ __global__ __launch_bounds__(256, 2) void wgrad256_kernel(int64_t P, int N, cons
                 dW[((size_t)ck * N + n) * K + k] = acc[i][j][r];  // this pixel chunk's partial matrix
             }
         }
-    if (do_bias) {
+    if (db != nullptr) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) bsh[zr][zc + q] = bsum[q];
         __syncthreads();
@@ -771,6 +809,44 @@ __global__ __launch_bounds__(1024) void sum_wparts_kernel(int n_parts, int64_t e
 #pragma unroll
         for (int i = 1; i < 16; ++i) r += sm[i][l];
         out[e] = r;
+    }
+}
+
+// The same sums for a weight matrix AND its bias row in one launch, written in the parameter's own shape (round 6): the partial
+// matrices are [n, k] (padded to multiples of 32), the outputs out_w[co, ci] and out_b[co]; every sum is multiplied by scale[0]
+// when given (the f16 tier's power of two: exact).  Blocks [0, wb) sum the matrix, the rest the bias.  Same chunk order per
+// element as sum_wparts_kernel: the same bits.
+__global__ __launch_bounds__(1024) void sum_wparts_out_kernel(int n_parts, int n, int k, int co, int ci, unsigned wb,
+                                                              const float *__restrict__ part_w, const float *__restrict__ part_b,
+                                                              float *__restrict__ out_w, float *__restrict__ out_b,
+                                                              const float *__restrict__ scale)
+{
+    __shared__ float sm[16][64];
+    const int g = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const bool bias = blockIdx.x >= wb;
+    const int64_t n_el = bias ? co : (int64_t)co * ci, stride = bias ? n : (int64_t)n * k;
+    const float *part = bias ? part_b : part_w;
+    const int64_t e = (int64_t)(bias ? blockIdx.x - wb : blockIdx.x) * 64 + l;
+    const int64_t ec = min(e, n_el - 1);
+    const int64_t src = bias ? ec : (ec / ci) * k + ec % ci;
+    float t = 0.f;
+    int c = g;
+    for (; c + 16 * 15 < n_parts; c += 16 * 16) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = part[(size_t)(c + 16 * i) * stride + src];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += v[i];
+    }
+    for (; c < n_parts; c += 16) t += part[(size_t)c * stride + src];
+    sm[g][l] = t;
+    __syncthreads();
+    if (g == 0 && e < n_el) {
+        float r = sm[0][l];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) r += sm[i][l];
+        if (scale) r *= scale[0];
+        (bias ? out_b : out_w)[e] = r;
     }
 }
 
@@ -1193,15 +1269,18 @@ extern "C" int64_t GAGS_DEC(gags_decoder_wgrad_scratch_bytes)(int64_t n_pix, int
     return (parts * ((int64_t)n_out * k_in + n_out) * 4 + 255) / 256 * 256;
 }
 
-extern "C" int GAGS_DEC(gags_decoder_wgrad)(int64_t n_pix, int n_out, int k_in, const void *dz, const void *a1, const void *a2,
-                                  float *d_w, float *d_b, void *scratch, int64_t scratch_bytes, void *stream)
+namespace {
+int wgrad_impl(int64_t n_pix, int n_out, int k_in, const void *dz, const void *a1, const void *a2, float *d_w, float *d_b, int co,
+               int ci, const float *out_scale, void *scratch, int64_t scratch_bytes, void *stream)
 {
     GAGS_CLEAR_ERR();
-    if (n_pix < 0 || n_out <= 0 || k_in <= 0 || n_out % 16 != 0 || k_in % 16 != 0 || !dz || !a1 || !d_w) return GAGS_EINVAL;
+    if (n_pix < 0 || n_out <= 0 || k_in <= 0 || n_out % 16 != 0 || k_in % 16 != 0 || !dz || !a1 || !d_w || co <= 0 || ci <= 0 ||
+        co > n_out || ci > k_in)
+        return GAGS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (n_pix == 0) {
-        if (hipMemsetAsync(d_w, 0, sizeof(float) * (size_t)n_out * k_in, st) != hipSuccess) return GAGS_ELAUNCH;
-        if (d_b && hipMemsetAsync(d_b, 0, sizeof(float) * (size_t)n_out, st) != hipSuccess) return GAGS_ELAUNCH;
+        if (hipMemsetAsync(d_w, 0, sizeof(float) * (size_t)co * ci, st) != hipSuccess) return GAGS_ELAUNCH;
+        if (d_b && hipMemsetAsync(d_b, 0, sizeof(float) * (size_t)co, st) != hipSuccess) return GAGS_ELAUNCH;
         return GAGS_OK;
     }
     if (!scratch || scratch_bytes < gags_decoder_wgrad_scratch_bytes(n_pix, n_out, k_in)) return GAGS_ESCRATCH;
@@ -1233,13 +1312,26 @@ extern "C" int GAGS_DEC(gags_decoder_wgrad)(int64_t n_pix, int n_out, int k_in, 
                            dim3(256), 0, st, n_pix, n_out, k_in, (const unsigned short *)dz, (const unsigned short *)a1,
                            (const unsigned short *)a2, pw, pb);
     }
-    const int64_t elems = (int64_t)n_out * k_in;
-    hipLaunchKernelGGL(sum_wparts_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(1024), 0, st, (int)parts, elems, pw, d_w);
-    if (d_b)
-        hipLaunchKernelGGL(sum_wparts_kernel, dim3((unsigned)((n_out + 63) / 64)), dim3(1024), 0, st, (int)parts, (int64_t)n_out, pb,
-                           d_b);
+    // one launch sums the matrix and the bias row, in the caller's [co, ci] shape
+    const unsigned wb = (unsigned)(((int64_t)co * ci + 63) / 64), bb = d_b ? (unsigned)((co + 63) / 64) : 0u;
+    hipLaunchKernelGGL(sum_wparts_out_kernel, dim3(wb + bb), dim3(1024), 0, st, (int)parts, n_out, k_in, co, ci, wb, pw, pb, d_w, d_b,
+                       out_scale);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
+}
+}  // namespace
+
+extern "C" int GAGS_DEC(gags_decoder_wgrad)(int64_t n_pix, int n_out, int k_in, const void *dz, const void *a1, const void *a2,
+                                  float *d_w, float *d_b, void *scratch, int64_t scratch_bytes, void *stream)
+{
+    return wgrad_impl(n_pix, n_out, k_in, dz, a1, a2, d_w, d_b, n_out, k_in, nullptr, scratch, scratch_bytes, stream);
+}
+
+extern "C" int GAGS_DEC(gags_decoder_wgrad_out)(int64_t n_pix, int n_out, int k_in, const void *dz, const void *a1, const void *a2,
+                                      float *d_w, float *d_b, int co, int ci, const float *out_scale, void *scratch,
+                                      int64_t scratch_bytes, void *stream)
+{
+    return wgrad_impl(n_pix, n_out, k_in, dz, a1, a2, d_w, d_b, co, ci, out_scale, scratch, scratch_bytes, stream);
 }
 
 extern "C" int GAGS_DEC(gags_decoder_head_bwd)(int64_t n_pix, int c, int ld, int mode, const float *x, const float *g, void *dz_bf16,

@@ -54,6 +54,18 @@ __global__ __launch_bounds__(256) void entropy_bwd_kernel(int64_t n, const float
     vs[i] = -(logf(x + 1e-6f) + x / (x + 1e-6f)) * v;
 }
 
+// (the cotangent as a device scalar: no host readback in the middle of a backward pass; the factor is formed as the host
+// formed it -- the quotient in double, rounded to float once)
+__global__ __launch_bounds__(256) void entropy_bwd_dev_kernel(int64_t n, const float *__restrict__ s, const float *__restrict__ v,
+                                                              float *__restrict__ vs)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float f = (float)((double)v[0] / (double)n);
+    const float x = s[i];
+    vs[i] = -(logf(x + 1e-6f) + x / (x + 1e-6f)) * f;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // per-segment moments.  One wave = 64 consecutive pixels.
 // wave64 sum on the VALU (DPP: a pairwise tree, total in lane 63), returned wave-uniform
@@ -749,6 +761,16 @@ extern "C" int gags_entropy_bwd(int64_t n, const float *s, float v_over_n, float
     if (n < 0 || (n > 0 && (!s || !v_s))) return GAGS_EINVAL;
     if (n == 0) return GAGS_OK;
     hipLaunchKernelGGL(entropy_bwd_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, n, s, v_over_n, v_s);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+extern "C" int gags_entropy_bwd_dev(int64_t n, const float *s, const float *v, float *v_s, void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (n < 0 || (n > 0 && (!s || !v || !v_s))) return GAGS_EINVAL;
+    if (n == 0) return GAGS_OK;
+    hipLaunchKernelGGL(entropy_bwd_dev_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, n, s, v, v_s);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }

@@ -108,13 +108,17 @@ def _layer(n_pix, w, b, a1, a2=None, relu=True, f32=False, mask_src=None, residu
     return (out, ypre) if premask else out
 
 
-def _wgrad(n_pix, dz, a1, a2, n, k, mode=_BF16):
-    dw = torch.empty(n, k, device=dz.device)
-    db = torch.empty(n, device=dz.device)
+def _wgrad(n_pix, dz, a1, a2, n, k, mode=_BF16, shape=None, scale=None):
+    """Weight and bias gradient of one layer from the padded operands.  shape = the parameter's own (co, ci, ...): the gradient
+    is written in that shape (gags_decoder_wgrad_out: no slice copy afterwards); scale: a device scalar every sum is multiplied
+    by (the f16 tier's power of two)."""
+    co, ci = (n, k) if shape is None else (shape[0], shape[1])
+    dw = torch.empty((co, ci) if shape is None else shape, device=dz.device)
+    db = torch.empty(co, device=dz.device)
     nb = mode.fn("gags_decoder_wgrad_scratch_bytes")(n_pix, n, k)
     scratch = torch.empty(max(nb, 4), dtype=torch.uint8, device=dz.device)  # partial matrices per pixel chunk
-    check(mode.fn("gags_decoder_wgrad")(n_pix, n, k, ptr(dz), ptr(a1), ptr(a2), ptr(dw), ptr(db), ptr(scratch), nb, _st()),
-          "gags_decoder_wgrad")
+    check(mode.fn("gags_decoder_wgrad_out")(n_pix, n, k, ptr(dz), ptr(a1), ptr(a2), ptr(dw), ptr(db), co, ci, ptr(scale),
+                                            ptr(scratch), nb, _st()), "gags_decoder_wgrad_out")
     return dw, db
 
 
@@ -383,7 +387,7 @@ def _chain_forward(x, kind, params, mode=_BF16):
     return logits, acts, wb, h, w, xp.shape[1]
 
 
-def _chain_backward(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, need_w=None, mode=_BF16):
+def _chain_backward(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, need_w=None, mode=_BF16, scale=None):
     """From the bf16 gradient of the logits dz [P, ld] back through the chain: (input gradient as a [C_in,H,W] view of
     [H,W,C_in] memory, weight / bias gradients in parameter order).  need_x / need_w: what autograd asked for."""
     p = h * w
@@ -392,8 +396,8 @@ def _chain_backward(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, need_w=
     dws = [None] * len(wb)
 
     def wg(i, dz_i, a1, a2=None):
-        if need_w[i]:
-            dws[i] = _wgrad(p, dz_i, a1, a2, *wb[i][0].shape, mode=mode)
+        if need_w[i]:  # (written in the parameter's shape, times `scale`: nothing left to do per parameter afterwards)
+            dws[i] = _wgrad(p, dz_i, a1, a2, *wb[i][0].shape, mode=mode, shape=shapes[i], scale=scale)
 
     def dx(i, dz_i, mask_src=None, residual=None, premask=False):
         return _layer(p, wt[i], None, dz_i, relu=False, mask_src=mask_src, residual=residual, premask=premask, mode=mode)
@@ -412,9 +416,8 @@ def _chain_backward(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, need_w=
         wg(8, dz, t7); wg(7, dzs[7], t6); wg(6, dzs[6], s34); wg(5, dzs[5], t4); wg(4, dzs[4], x3)
         wg(3, dzs[3], s12); wg(2, dzs[2], t1); wg(1, dzs[1], x1); wg(0, dzs[0], a0)
         grads = []
-        for pair, shp in zip(dws, shapes):
-            co, ci = shp[:2]
-            grads += [None, None] if pair is None else [pair[0][:co, :ci].reshape(shp).contiguous(), pair[1][:co].contiguous()]
+        for pair in dws:
+            grads += [None, None] if pair is None else [pair[0], pair[1]]
         return (None if gx is None else gx.permute(2, 0, 1)), grads
     if kind == "decoder":
         a0, x1, t1, x2, x3, t4, x4, t6, t7 = acts
@@ -462,12 +465,8 @@ def _chain_backward(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, need_w=
         check(mode.fn("gags_decoder_unpack_grad")(p, c_in, gin.shape[1], ptr(gin), ptr(gx), _st()), "gags_decoder_unpack_grad")
         gx = gx.permute(2, 0, 1)
     grads = []
-    for pair, shp in zip(dws, shapes):
-        co, ci = shp[:2]
-        if pair is None:
-            grads += [None, None]
-        else:
-            grads += [pair[0][:co, :ci].reshape(shp).contiguous(), pair[1][:co].contiguous()]
+    for pair in dws:
+        grads += [None, None] if pair is None else [pair[0], pair[1]]
     return gx, grads
 
 
@@ -529,10 +528,9 @@ class _DecoderFn(torch.autograd.Function):
             dz = torch.empty(p, logits.shape[1], dtype=h16.dtype, device=g.device)
             check(h16.fn("gags_decoder_head_bwd")(p, ctx.c_out, logits.shape[1], mode, ptr(logits), ptr(g), ptr(dz),
                                                   1 if pm else 0, _st()), "gags_decoder_head_bwd")
-            gx, grads = _chain_backward(dz, acts, wb, kind, h, w, ctx.c_in, ctx.shapes, need_x, need_w, mode=h16)
-            if inv is not None:
+            gx, grads = _chain_backward(dz, acts, wb, kind, h, w, ctx.c_in, ctx.shapes, need_x, need_w, mode=h16, scale=inv)
+            if inv is not None:  # (the parameter gradients left their sums already multiplied)
                 gx = None if gx is None else gx * inv
-                grads = [None if t is None else t * inv for t in grads]
         return (gx, None, None, None, *grads)
 
 
@@ -585,9 +583,8 @@ class _DecoderDistillFn(torch.autograd.Function):
             check(_lib.load().gags_decoder_head_distill_bwd_h16(c, logits.shape[1], h, w, seg.shape[1], seg.shape[2], e.shape[0],
                                                                 ptr(logits), ptr(e), ptr(seg), ptr(sc), ptr(vm), ptr(dz), ptr(s),
                                                                 ptr(vs), _st()), "gags_decoder_head_distill_bwd_h16")
-            gx, grads = _chain_backward(dz, acts, ctx.wb, "decoder", h, w, ctx.c_in, ctx.shapes, need_x, need_w, mode=_F16)
+            gx, grads = _chain_backward(dz, acts, ctx.wb, "decoder", h, w, ctx.c_in, ctx.shapes, need_x, need_w, mode=_F16, scale=inv)
             gx = None if gx is None else gx * inv
-            grads = [None if t is None else t * inv for t in grads]
         else:
             dz = torch.empty(h * w, logits.shape[1], dtype=torch.bfloat16, device=logits.device)
             check(_lib.load().gags_decoder_head_distill_bwd(c, logits.shape[1], h, w, seg.shape[1], seg.shape[2], e.shape[0],

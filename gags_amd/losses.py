@@ -17,6 +17,7 @@ on [n_seg]-sized tensors.  Only the variants train.py reaches are implemented (m
 anything else raises.  GPU tensors only: there is no CPU path.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -34,9 +35,28 @@ def _f(t):
     return t if (t.is_contiguous() and t.dtype == torch.float32) else t.contiguous().float()
 
 
+_NSEG_CACHE = {}  # id(tensor) -> (weak reference, data_ptr, version counter, n_seg)
+
+
 def _n_seg(seg_map):
-    # ids are small non-negative integers stored as floats; one readback sizes the statistics tables
-    return max(int(seg_map.max().item()) + 1, 1)
+    """Size of the per-segment tables: any bound above the largest id gives the same sums (rows nobody hits stay empty, ids
+    outside [0, n_seg) are skipped by the kernels).  ids are small non-negative integers stored as floats; the bound costs ONE
+    readback per segmentation map, not one per iteration (a host sync in the middle of an iteration drains the queue: the
+    dozens of small launches behind it then run at the host's pace -- ~0.5 ms each time at 1080p): a view's SAM map does not
+    change between iterations, so the answer is kept per tensor (identity, address and version counter), and
+    get_trained_seg hands the bound of its source map on to the map it makes (`_gags_n_seg`)."""
+    hint = getattr(seg_map, "_gags_n_seg", None)
+    if hint is not None:
+        return hint
+    key = id(seg_map)
+    hit = _NSEG_CACHE.get(key)
+    if hit is not None and hit[0]() is seg_map and hit[1] == seg_map.data_ptr() and hit[2] == seg_map._version:
+        return hit[3]
+    n = max(int(seg_map.max().item()) + 1, 1)
+    if len(_NSEG_CACHE) > 4096:
+        _NSEG_CACHE.clear()
+    _NSEG_CACHE[key] = (weakref.ref(seg_map), seg_map.data_ptr(), seg_map._version, n)
+    return n
 
 
 def l1_loss(network_output, gt):
@@ -60,7 +80,8 @@ class _Entropy(torch.autograd.Function):
     def backward(ctx, v):
         (s,) = ctx.saved_tensors
         vs = torch.empty_like(s)
-        check(_lib.load().gags_entropy_bwd(s.numel(), ptr(s), float(v.item()) / s.numel(), ptr(vs), _st()), "gags_entropy_bwd")
+        vd = v.detach().reshape(1).float().contiguous()  # (read on the device: no readback inside the backward pass)
+        check(_lib.load().gags_entropy_bwd_dev(s.numel(), ptr(s), ptr(vd), ptr(vs), _st()), "gags_entropy_bwd_dev")
         return vs
 
 
@@ -89,7 +110,7 @@ class _ScaleBalance(torch.autograd.Function):
     @staticmethod
     def forward(ctx, loss_map, seg_map):
         lm, seg = _f(loss_map), _f(seg_map)
-        n_seg = _n_seg(seg)
+        n_seg = _n_seg(seg_map)
         s1, _, cnt = _segment_stats(lm.reshape(1, -1), seg.reshape(-1), n_seg)
         present = cnt > 0
         k = present.sum().clamp(min=1)
@@ -124,7 +145,7 @@ class _RegionVar(torch.autograd.Function):
         # copying 132 MB into channel-major order every iteration
         pm = x.is_cuda and x.dtype == torch.float32 and not x.is_contiguous() and x.permute(1, 2, 0).is_contiguous()
         x = x.permute(1, 2, 0) if pm else _f(x)
-        n_seg = _n_seg(seg)
+        n_seg = _n_seg(seg_map)
         s1, s2, cnt = _segment_stats(x.reshape(-1, c) if pm else x.reshape(c, -1), seg.reshape(-1), n_seg, pixel_major=pm)
         n = cnt.double()
         ok = cnt >= 2  # segments of 0 or 1 pixels are skipped (loss_utils.py:124-125)
@@ -164,6 +185,7 @@ def get_trained_seg(seg_map, scale_map):
     _, h, w = seg.shape
     out = torch.empty(h, w, device=seg.device)
     check(_lib.load().gags_trained_seg(h, w, ptr(seg), ptr(sc), ptr(out), _st()), "gags_trained_seg")
+    out._gags_n_seg = _n_seg(seg_map)  # (every id of the result is an id of seg_map)
     return out
 
 

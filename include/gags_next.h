@@ -28,6 +28,8 @@ int gags_trained_seg(int h, int w, const float *seg_map, const float *scale_map,
  * double, zeroed by the caller; loss = acc / n).  Backward: v_s[i] = -(log(s + eps) + s / (s + eps)) * v_over_n. */
 int gags_entropy_fwd(int64_t n, const float *s, double *acc, void *stream);
 int gags_entropy_bwd(int64_t n, const float *s, float v_over_n, float *v_s, void *stream);
+/* the same with the cotangent v[0] read on the device (v_over_n = v[0] / n): no host readback inside a backward pass */
+int gags_entropy_bwd_dev(int64_t n, const float *s, const float *v, float *v_s, void *stream);
 
 /* Per-segment first and second moments of a channel-major map x[c, n_pix] under the segment map seg[n_pix]
  * (ids in [0, n_seg), anything negative = no segment): s1[n_seg, c], s2[n_seg, c] (double) and cnt[n_seg], all
@@ -119,6 +121,13 @@ int gags_decoder_layer(int64_t n_pix, int n_out, int k_in, const void *a1, const
 int64_t gags_decoder_wgrad_scratch_bytes(int64_t n_pix, int n_out, int k_in);
 int gags_decoder_wgrad(int64_t n_pix, int n_out, int k_in, const void *dz, const void *a1, const void *a2, float *d_w,
                        float *d_b, void *scratch, int64_t scratch_bytes, void *stream);
+/* The same gradient written in the parameter's own shape (round 6): d_w[co, ci] and d_b[co] are the leading co x ci block of the
+ * padded [n_out, k_in] product (co <= n_out, ci <= k_in: what nn.Conv2d(ci, co, 1).weight.grad holds, models/networks.py:145-149),
+ * every sum multiplied by out_scale[0] when given (a device scalar: the f16 tier's power of two) -- no slice copy and no
+ * element-wise multiply per parameter after the call.  Same sums, same order, same bits as gags_decoder_wgrad. */
+int gags_decoder_wgrad_out(int64_t n_pix, int n_out, int k_in, const void *dz, const void *a1, const void *a2, float *d_w,
+                           float *d_b, int co, int ci, const float *out_scale, void *scratch, int64_t scratch_bytes,
+                           void *stream);
 
 /* Backward of gags_decoder_head: cotangent g (layout 0: [c, n_pix], 1: [n_pix, c]) + the saved logits x[n_pix, ld] ->
  * pixel-major bf16 dz[n_pix, ld]. */
@@ -244,6 +253,7 @@ int gags_decoder_layer_h16(int64_t n_pix, int n_out, int k_in, const void *a1, c
 int gags_decoder_head_h16(int64_t n_pix, int c, int ld, int mode, const float *x, float *out, int layout, void *stream);
 int64_t gags_decoder_wgrad_scratch_bytes_h16(int64_t n_pix, int n_out, int k_in);
 int gags_decoder_wgrad_h16(int64_t n_pix, int n_out, int k_in, const void *dz, const void *a1, const void *a2, float *d_w, float *d_b, void *scratch, int64_t scratch_bytes, void *stream);
+int gags_decoder_wgrad_out_h16(int64_t n_pix, int n_out, int k_in, const void *dz, const void *a1, const void *a2, float *d_w, float *d_b, int co, int ci, const float *out_scale, void *scratch, int64_t scratch_bytes, void *stream);
 int gags_decoder_head_bwd_h16(int64_t n_pix, int c, int ld, int mode, const float *x, const float *g, void *dz_bf16, int layout, void *stream);
 int gags_decoder_unpack_grad_h16(int64_t n_pix, int c, int ld, const void *x_bf16, float *y, void *stream);
 int gags_decoder_fwd_fused_h16(int64_t n_pix, int c_in, int n_last, const float *x, const void *const *w_bf16, const float *const *bias, void *const *acts_bf16, void *masks, float *logits, void *stream);

@@ -54,23 +54,25 @@ def iteration(times=None):
         m.zero_grad(set_to_none=True)
     pc._semantic_feature.grad = None
     loss.backward(); marks.append(ev())
-    if times is not None:
-        torch.cuda.synchronize()
-        for k, (a, b) in zip(("render16", "decoders_and_losses_fwd", "backward"), zip(marks, marks[1:])):
-            times.setdefault(k, []).append(a.elapsed_time(b))
+    if times is not None:  # (read after the loop's one synchronize: a sync per iteration would drain the queue every time)
+        times.append(marks)
     return loss
 
 
 for _ in range(2):
     iteration()
 torch.cuda.synchronize()
-times = {}
+all_marks = []
 t0 = time.perf_counter()
-K = 5
+K = 8
 for _ in range(K):
-    iteration(times)
+    iteration(all_marks)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
+times = {}
+for marks in all_marks:
+    for k, (a, b) in zip(("render16", "decoders_and_losses_fwd", "backward"), zip(marks, marks[1:])):
+        times.setdefault(k, []).append(a.elapsed_time(b))
 print(json.dumps({"fused_head_loss": FUSED, "decoder_precision": PRECISION,
                   "workload": "train.py:142-174 iteration, 1.5M Gaussians, 1920x1080, D=16 -> CNN decoders -> losses",
                   "ms_per_iteration": 1e3 * dt, "iterations_per_s": 1 / dt,

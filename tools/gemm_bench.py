@@ -26,6 +26,7 @@ a, a2, m = rnd(P, 256), rnd(P, 256), rnd(P, 256)
 w256, w512 = rnd(256, 256), rnd(512, 256)
 b256, b512 = torch.zeros(256, device=dev), torch.zeros(512, device=dev)
 w32 = rnd(32, 256)
+z512 = rnd(P, 512)
 b32 = torch.zeros(32, device=dev)
 
 
@@ -49,6 +50,7 @@ cases = {
     "dgrad_256x256_mask_residual": (lambda: D._layer(P, w256, None, a, relu=False, mask_src=m, residual=a2), 2 * P * 256 * 256, P * 256 * 8),
     "dgrad_32x256": (lambda: D._layer(P, w32, None, a, relu=False), 2 * P * 32 * 256, P * (512 + 64)),
     "wgrad_256x256": (lambda: D._wgrad(P, a, a2, None, 256, 256), 2 * P * 256 * 256, P * 256 * 4),
+    "wgrad_512x256": (lambda: D._wgrad(P, z512, a2, None, 512, 256), 2 * P * 512 * 256, P * (1024 + 512)),
     "wgrad_256x256_two_sources": (lambda: D._wgrad(P, a, a2, m, 256, 256), 2 * P * 256 * 256, P * 256 * 6),
 }
 # the fp32-tensor tiers (csrc/decoder_exact.hip): operands split into 3 ("exact") or 2 ("bf16x2") bf16 terms
