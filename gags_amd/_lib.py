@@ -91,6 +91,8 @@ SIGNATURES = {
     "gags_entropy_bwd_dev": (_i32, [_i64, _vp, _vp, _vp, _vp]),
     "gags_segment_stats": (_i32, [_i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "gags_segment_stats_multi": (_i32, [_i64, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "gags_segment_stats_runs_copies": (_i32, [_i64, _i32, _i32, _i32]),
+    "gags_segment_stats_runs": (_i32, [_i64, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "gags_region_var_bwd_layout": (_i32, [_i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp]),
     "gags_region_var_bwd": (_i32, [_i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "gags_gather_seg_coef": (_i32, [_i64, _vp, _i32, _vp, _vp, _vp]),

@@ -785,37 +785,9 @@ void launch_wgrad_narrow(int64_t n_pix, const void *dz, const void *a1, const vo
 // workgroup take the chunks g, g + 16, ... of 64 consecutive elements (up to 16 loads in flight each), their sums are
 // added in group order.  (One thread per element walking all 768 chunks of a narrow layer was a chain of 48 round trips:
 // 17-28 us for a 4 KB matrix, 0.5 ms per iteration over the thirty sums.)
-__global__ __launch_bounds__(1024) void sum_wparts_kernel(int n_parts, int64_t elems, const float *__restrict__ part,
-                                                          float *__restrict__ out)
-{
-    __shared__ float sm[16][64];
-    const int g = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int64_t e = (int64_t)blockIdx.x * 64 + l;
-    const int64_t ec = min(e, elems - 1);
-    float t = 0.f;
-    int c = g;
-    for (; c + 16 * 15 < n_parts; c += 16 * 16) {
-        float v[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = part[(size_t)(c + 16 * i) * elems + ec];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) t += v[i];
-    }
-    for (; c < n_parts; c += 16) t += part[(size_t)c * elems + ec];
-    sm[g][l] = t;
-    __syncthreads();
-    if (g == 0 && e < elems) {
-        float r = sm[0][l];
-#pragma unroll
-        for (int i = 1; i < 16; ++i) r += sm[i][l];
-        out[e] = r;
-    }
-}
-
-// The same sums for a weight matrix AND its bias row in one launch, written in the parameter's own shape (round 6): the partial
-// matrices are [n, k] (padded to multiples of 32), the outputs out_w[co, ci] and out_b[co]; every sum is multiplied by scale[0]
-// when given (the f16 tier's power of two: exact).  Blocks [0, wb) sum the matrix, the rest the bias.  Same chunk order per
-// element as sum_wparts_kernel: the same bits.
+// A weight matrix AND its bias row in one launch, written in the parameter's own shape (round 6; one launch per tensor
+// before): the partial matrices are [n, k] (padded to multiples of 32), the outputs out_w[co, ci] and out_b[co]; every sum is
+// multiplied by scale[0] when given (the f16 tier's power of two: exact).  Blocks [0, wb) sum the matrix, the rest the bias.
 __global__ __launch_bounds__(1024) void sum_wparts_out_kernel(int n_parts, int n, int k, int co, int ci, unsigned wb,
                                                               const float *__restrict__ part_w, const float *__restrict__ part_b,
                                                               float *__restrict__ out_w, float *__restrict__ out_b,

@@ -17,6 +17,7 @@ on [n_seg]-sized tensors.  Only the variants train.py reaches are implemented (m
 anything else raises.  GPU tensors only: there is no CPU path.
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -90,6 +91,7 @@ def scale_regulation_loss(scale_map):
     return _Entropy.apply(scale_map)
 
 
+RUNS = os.environ.get("GAGS_SEGMENT_RUNS", "1") != "0"  # 0: the wave-sum + double-atomic kernel for every shape
 _STAT_COPIES = 16  # private accumulator sets of gags_segment_stats_multi (the double atomics serialize per address)
 
 
@@ -97,6 +99,15 @@ def _segment_stats(x, seg_map, n_seg, pixel_major=False):
     """x: [c, n_pix], or [n_pix, c] with pixel_major."""
     n_pix = seg_map.numel()
     c = x.shape[1] if pixel_major else x.shape[0]
+    lib = _lib.load()
+    k = lib.gags_segment_stats_runs_copies(n_pix, c, n_seg, 1 if pixel_major else 0) if RUNS else 0
+    if k > 0:  # sums by runs of equal ids into one private table per workgroup: no global atomics (csrc/losses.hip)
+        s1 = torch.empty(k, n_seg, c, dtype=torch.float64, device=x.device)
+        s2 = torch.empty_like(s1)
+        cnt = torch.empty(k, n_seg, dtype=torch.int32, device=x.device)
+        check(lib.gags_segment_stats_runs(n_pix, c, ptr(x), ptr(seg_map), n_seg, k, ptr(s1), ptr(s2), ptr(cnt),
+                                          1 if pixel_major else 0, _st()), "gags_segment_stats_runs")
+        return s1.sum(0), s2.sum(0), cnt.sum(0, dtype=torch.int32)
     k = _STAT_COPIES if n_seg * c * _STAT_COPIES <= (1 << 22) else 1
     s1 = torch.zeros(k, n_seg, c, dtype=torch.float64, device=x.device)
     s2 = torch.zeros_like(s1)

@@ -44,6 +44,14 @@ int gags_segment_stats(int64_t n_pix, int c, const float *x, const float *seg, i
  * layout 1: x is pixel-major [n_pix, c] (the rasterizer's own memory under the [C,H,W] view: no `.contiguous()` copy). */
 int gags_segment_stats_multi(int64_t n_pix, int c, const float *x, const float *seg, int n_seg, int copies, double *s1,
                              double *s2, int32_t *cnt, int layout, void *stream);
+/* The same moments by runs of equal ids (round 6; csrc/losses.hip segment_stats_runs_kernel): no atomics in global memory, the
+ * cost per pixel independent of how finely the map is cut.  Serves c == 16 pixel-major (layout 1) and c == 1 with
+ * n_seg * (16 c + 4) <= 150 KB; gags_segment_stats_runs_copies returns the number of private copies s1 / s2 / cnt must hold
+ * ([copies, n_seg, c], [copies, n_seg]; every element is written: no zero fill), or 0 when the shape is not served -- use
+ * gags_segment_stats_multi then.  The caller sums the copies. */
+int gags_segment_stats_runs_copies(int64_t n_pix, int c, int n_seg, int layout);
+int gags_segment_stats_runs(int64_t n_pix, int c, const float *x, const float *seg, int n_seg, int copies, double *s1,
+                            double *s2, int32_t *cnt, int layout, void *stream);
 /* Backward of the region-variance loss: v_x[c, p] = coef[seg(p)] * (x[c, p] - mean[seg(p), c]), 0 outside segments. */
 int gags_region_var_bwd(int64_t n_pix, int c, const float *x, const float *seg, int n_seg, const float *mean,
                         const float *coef, float *v_x, void *stream);
