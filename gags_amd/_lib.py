@@ -93,6 +93,7 @@ SIGNATURES = {
     "gags_segment_stats_multi": (_i32, [_i64, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "gags_segment_stats_runs_copies": (_i32, [_i64, _i32, _i32, _i32]),
     "gags_segment_stats_runs": (_i32, [_i64, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "gags_segment_loss": (_i32, [_i32, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_region_var_bwd_layout": (_i32, [_i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp]),
     "gags_region_var_bwd": (_i32, [_i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "gags_gather_seg_coef": (_i32, [_i64, _vp, _i32, _vp, _vp, _vp]),
@@ -128,6 +129,7 @@ SIGNATURES = {
                                         "gags_decoder_head_bwd",
                                         "gags_decoder_unpack_grad", "gags_decoder_fwd_fused", "gags_decoder_bwd_fused",
                                         "gags_scale_decoder_fwd_fused", "gags_scale_decoder_bwd_fused")},
+    "gags_pow2_scale": (_i32, [_vp, _f32, _f32, _vp, _vp]),
     "gags_decoder_head_distill_bwd_h16": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_relevancy": (_i32, [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "gags_relevancy_activate_scratch_bytes": (_i64, [_i32, _i32, _i32]),

@@ -250,6 +250,102 @@ __global__ __launch_bounds__(256) void segment_stats_runs_kernel(int64_t n_pix, 
     for (int i = tid; i < n_seg; i += 256) cnt[i] = tc[i];
 }
 
+// The two segment losses from the moments, in two launches instead of the ~20 element-wise / reduce launches the same
+// arithmetic took as torch expressions on [n_seg] tensors (round 6: ~5 us of GPU time each, back to back on the critical path):
+// (1) the private copies summed in copy order: sixteen groups of a workgroup take the copies g, g + 16, ... of 64 consecutive
+// elements, their sums are added in group order (reproducible);
+__global__ __launch_bounds__(1024) void seg_sum_copies_kernel(int k, int n1, int n_seg, unsigned b1, const double *__restrict__ s1c,
+                                                              const double *__restrict__ s2c, const int32_t *__restrict__ cntc,
+                                                              double *__restrict__ s1, double *__restrict__ s2,
+                                                              int32_t *__restrict__ cnt)
+{
+    __shared__ double sm[2][16][64];
+    const int g = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (blockIdx.x >= b1) {  // counts
+        const int e = (int)(blockIdx.x - b1) * 64 + l, ec = min(e, n_seg - 1);
+        int t = 0;
+        for (int cp = g; cp < k; cp += 16) t += cntc[(size_t)cp * n_seg + ec];
+        sm[0][g][l] = (double)t;  // (exact: counts are below 2^31)
+        __syncthreads();
+        if (g == 0 && e < n_seg) {
+            double r = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) r += sm[0][i][l];
+            cnt[e] = (int32_t)r;
+        }
+        return;
+    }
+    const int e = (int)blockIdx.x * 64 + l, ec = min(e, n1 - 1);
+    double a = 0.0, b = 0.0;
+    for (int cp = g; cp < k; cp += 16) { a += s1c[(size_t)cp * n1 + ec]; b += s2c[(size_t)cp * n1 + ec]; }
+    sm[0][g][l] = a; sm[1][g][l] = b;
+    __syncthreads();
+    if (g == 0 && e < n1) {
+        double ra = 0.0, rb = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { ra += sm[0][i][l]; rb += sm[1][i][l]; }
+        s1[e] = ra; s2[e] = rb;
+    }
+}
+
+__device__ __forceinline__ double block_sum_1024(double v, double *sm16)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm16[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r += sm16[i];
+    return r;
+}
+
+// (2) one workgroup: the loss and the per-segment tables its backward gathers from.
+//   mode 0, Scale_balance_loss (utils/loss_utils.py:32-57, mix_seg): mean over the PRESENT segments of the segment's mean;
+//           coef[i] = 1 / (n_i K) for the backward (K = present segments, at least 1)
+//   mode 1, scale_region_regulation_loss (:103-136): sum over segments of >= 2 pixels of n_i mean_c var_c (unbiased) / (H W);
+//           mean[i][c] and coef[i] = 2 n_i / ((n_i - 1) c H W) for the backward
+__global__ __launch_bounds__(1024) void seg_loss_finalize_kernel(int mode, int n_seg, int c, double hw, const double *__restrict__ s1,
+                                                                 const double *__restrict__ s2, const int32_t *__restrict__ cnt,
+                                                                 float *__restrict__ loss, float *__restrict__ coef,
+                                                                 float *__restrict__ mean)
+{
+    __shared__ double sm16[16];
+    const int tid = threadIdx.x;
+    if (mode == 0) {
+        double present = 0.0, msum = 0.0;
+        for (int i = tid; i < n_seg; i += 1024) {
+            const int n = cnt[i];
+            if (n > 0) { present += 1.0; msum += s1[i] / (double)n; }
+        }
+        const double K = fmax(block_sum_1024(present, sm16), 1.0);
+        const double total = block_sum_1024(msum, sm16);
+        for (int i = tid; i < n_seg; i += 1024) {
+            const int n = cnt[i];
+            coef[i] = n > 0 ? (float)(1.0 / ((double)n * K)) : 0.f;
+        }
+        if (tid == 0) loss[0] = (float)(total / K);
+        return;
+    }
+    double acc = 0.0;
+    for (int i = tid; i < n_seg; i += 1024) {
+        const int n = cnt[i];
+        const bool ok = n >= 2;  // segments of 0 or 1 pixels are skipped (loss_utils.py:124-125)
+        const double nn = ok ? (double)n : 2.0;
+        double vs = 0.0;
+        for (int ch = 0; ch < c; ++ch) {
+            const double m = s1[(size_t)i * c + ch] / nn;
+            // unbiased, as torch.var; the moments arrive accurately summed in double, and a variance is never negative
+            vs += fmax((s2[(size_t)i * c + ch] - nn * m * m) / (nn - 1.0), 0.0);
+            mean[(size_t)i * c + ch] = (float)m;
+        }
+        if (ok) acc += nn * (vs / (double)c);
+        coef[i] = ok ? (float)(2.0 * nn / ((nn - 1.0) * (double)c * hw)) : 0.f;
+    }
+    const double total = block_sum_1024(acc, sm16);
+    if (tid == 0) loss[0] = (float)(total / hw);
+}
+
 // pixel-major [n_pix, c], c % 4 == 0: one lane per float4, consecutive lanes on consecutive 16 bytes of the tensor
 __global__ __launch_bounds__(256) void region_var_bwd_pm_kernel(int64_t n_pix, int c, const float *__restrict__ x,
                                                                 const float *__restrict__ seg, int n_seg,
@@ -900,6 +996,25 @@ extern "C" int gags_segment_stats_runs(int64_t n_pix, int c, const float *x, con
     else
         hipLaunchKernelGGL(segment_stats_runs_kernel<1>, dim3((unsigned)copies), dim3(256), (size_t)lds, (hipStream_t)stream, n_pix, x,
                            seg, n_seg, s1, s2, cnt);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+extern "C" int gags_segment_loss(int mode, int n_seg, int c, int copies, int64_t n_pix, const double *s1c, const double *s2c,
+                                 const int32_t *cntc, double *s1, double *s2, int32_t *cnt, float *loss, float *coef, float *mean,
+                                 void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if ((mode != 0 && mode != 1) || n_seg <= 0 || c <= 0 || copies <= 0 || n_pix <= 0 || (mode == 0 && c != 1) || !s1c || !s2c ||
+        !cntc || !s1 || !s2 || !cnt || !loss || !coef || (mode == 1 && !mean))
+        return GAGS_EINVAL;
+    const int64_t n1 = (int64_t)n_seg * c;
+    if (n1 > (1 << 24)) return GAGS_EINVAL;
+    const unsigned b1 = (unsigned)((n1 + 63) / 64), b2 = (unsigned)((n_seg + 63) / 64);
+    hipLaunchKernelGGL(seg_sum_copies_kernel, dim3(b1 + b2), dim3(1024), 0, (hipStream_t)stream, copies, (int)n1, n_seg, b1, s1c, s2c,
+                       cntc, s1, s2, cnt);
+    hipLaunchKernelGGL(seg_loss_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mode, n_seg, c, (double)n_pix, s1, s2,
+                       cnt, loss, coef, mean);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }

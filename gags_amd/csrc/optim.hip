@@ -3,6 +3,7 @@
 // written per element, pure HBM streaming (the torch optimizer makes several passes over the same 3 GB
 // tensors).  Same operation order as torch's single-tensor Adam; scalars formed in double on the host.
 #include "common.h"
+#include "gags_next.h"
 
 namespace {
 
@@ -136,6 +137,32 @@ extern "C" int gags_dot_f32(int64_t numel, const float *x, const float *y, float
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(dot_partial_kernel, dim3(DOT_BLOCKS), dim3(256), 0, st, numel, x, y, (double *)scratch);
     hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(256), 0, st, (const double *)scratch, out);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+// ---- the f16 decoder tier's gradient scale (gags_amd/decoders.py::_pow2_scale) ----------------------------------------------
+// out[0] = S = 2^floor(target_log2 - log2(amax[0] / div)) (exponent clamped to +-100; 1 when amax is 0 or not finite),
+// out[1] = 1 / S: one launch of one thread instead of a dozen element-wise launches on a scalar, no host readback.
+namespace {
+__global__ void pow2_scale_kernel(const float *__restrict__ amax, float div, float target_log2, float *__restrict__ out)
+{
+    const float a = amax[0] / div;
+    float s = 1.0f;
+    if (isfinite(a) && a > 0.f) {
+        const float e = fminf(fmaxf(floorf(target_log2 - log2f(a)), -100.f), 100.f);
+        s = ldexpf(1.0f, (int)e);
+    }
+    out[0] = s;
+    out[1] = 1.0f / s;
+}
+}  // namespace
+
+extern "C" int gags_pow2_scale(const float *amax, float div, float target_log2, float *out, void *stream)
+{
+    if (!amax || !out || !(div > 0.f)) return GAGS_EINVAL;
+    GAGS_CLEAR_ERR();
+    hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, amax, div, target_log2, out);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }

@@ -73,12 +73,14 @@ _F16 = _H16Mode("f16", "_h16", torch.float16)
 F16_TARGET_LOG2 = 8.0
 
 
-def _pow2_scale(amax, target_log2=F16_TARGET_LOG2):
-    """Device scalars (S, 1 / S), S = 2^floor(target - log2(amax)) (1 when amax is 0 or not finite); no host sync."""
-    ok = torch.isfinite(amax) & (amax > 0)
-    e = torch.floor(target_log2 - torch.log2(torch.where(ok, amax, torch.ones_like(amax)))).clamp(-100.0, 100.0)
-    s = torch.where(ok, torch.exp2(e), torch.ones_like(amax)).float().reshape(1)
-    return s, 1.0 / s
+def _pow2_scale(amax, target_log2=F16_TARGET_LOG2, div=1.0):
+    """Device scalars (S, 1 / S), S = 2^floor(target - log2(amax / div)) (1 when amax is 0 or not finite); no host sync, one
+    launch (gags_pow2_scale)."""
+    a = amax.detach().reshape(1)
+    a = a if a.dtype == torch.float32 else a.float()
+    out = torch.empty(2, device=a.device)
+    check(_lib.load().gags_pow2_scale(ptr(a), float(div), float(target_log2), ptr(out), _st()), "gags_pow2_scale")
+    return out[0:1], out[1:2]
 
 
 def _pad32(n):
@@ -578,7 +580,7 @@ class _DecoderDistillFn(torch.autograd.Function):
             # the logits' gradient is about v_map / (c |logits|): scaled by a power of two chosen on the device from
             # max |v_map| / c (half has 5 exponent bits), the chain's results scaled back; the scale map's gradient is fp32
             vm = _f(v_map)
-            s, inv = _pow2_scale(torch.linalg.vector_norm(vm.reshape(-1), float("inf")) / c)
+            s, inv = _pow2_scale(torch.linalg.vector_norm(vm.reshape(-1), float("inf")), div=c)
             dz = torch.empty(h * w, logits.shape[1], dtype=torch.float16, device=logits.device)
             check(_lib.load().gags_decoder_head_distill_bwd_h16(c, logits.shape[1], h, w, seg.shape[1], seg.shape[2], e.shape[0],
                                                                 ptr(logits), ptr(e), ptr(seg), ptr(sc), ptr(vm), ptr(dz), ptr(s),

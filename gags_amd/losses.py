@@ -95,8 +95,9 @@ RUNS = os.environ.get("GAGS_SEGMENT_RUNS", "1") != "0"  # 0: the wave-sum + doub
 _STAT_COPIES = 16  # private accumulator sets of gags_segment_stats_multi (the double atomics serialize per address)
 
 
-def _segment_stats(x, seg_map, n_seg, pixel_major=False):
-    """x: [c, n_pix], or [n_pix, c] with pixel_major."""
+def _segment_copies(x, seg_map, n_seg, pixel_major=False):
+    """Per-segment moments of x ([c, n_pix], or [n_pix, c] with pixel_major) as private copies: s1, s2 [k, n_seg, c] doubles
+    and counts [k, n_seg]; the caller sums over k."""
     n_pix = seg_map.numel()
     c = x.shape[1] if pixel_major else x.shape[0]
     lib = _lib.load()
@@ -107,14 +108,38 @@ def _segment_stats(x, seg_map, n_seg, pixel_major=False):
         cnt = torch.empty(k, n_seg, dtype=torch.int32, device=x.device)
         check(lib.gags_segment_stats_runs(n_pix, c, ptr(x), ptr(seg_map), n_seg, k, ptr(s1), ptr(s2), ptr(cnt),
                                           1 if pixel_major else 0, _st()), "gags_segment_stats_runs")
-        return s1.sum(0), s2.sum(0), cnt.sum(0, dtype=torch.int32)
+        return s1, s2, cnt
     k = _STAT_COPIES if n_seg * c * _STAT_COPIES <= (1 << 22) else 1
     s1 = torch.zeros(k, n_seg, c, dtype=torch.float64, device=x.device)
     s2 = torch.zeros_like(s1)
     cnt = torch.zeros(k, n_seg, dtype=torch.int32, device=x.device)
-    check(_lib.load().gags_segment_stats_multi(n_pix, c, ptr(x), ptr(seg_map), n_seg, k, ptr(s1), ptr(s2), ptr(cnt),
-                                               1 if pixel_major else 0, _st()), "gags_segment_stats_multi")
+    check(lib.gags_segment_stats_multi(n_pix, c, ptr(x), ptr(seg_map), n_seg, k, ptr(s1), ptr(s2), ptr(cnt),
+                                       1 if pixel_major else 0, _st()), "gags_segment_stats_multi")
+    return s1, s2, cnt
+
+
+def _segment_stats(x, seg_map, n_seg, pixel_major=False):
+    """The moments summed over the copies: s1, s2 [n_seg, c], counts [n_seg]."""
+    s1, s2, cnt = _segment_copies(x, seg_map, n_seg, pixel_major)
     return s1.sum(0), s2.sum(0), cnt.sum(0, dtype=torch.int32)
+
+
+def _segment_loss(mode, x, seg_map, n_seg, pixel_major=False):
+    """(loss [1] float, coef [n_seg] float, mean [n_seg, c] float or None) of gags_segment_loss: mode 0 = Scale_balance_loss,
+    1 = scale_region_regulation_loss -- the copies' sum and all of the double-precision arithmetic on [n_seg] vectors in two
+    launches."""
+    s1c, s2c, cntc = _segment_copies(x, seg_map, n_seg, pixel_major)
+    k, _, c = s1c.shape
+    dev = x.device
+    s1 = torch.empty(n_seg, c, dtype=torch.float64, device=dev)
+    s2 = torch.empty_like(s1)
+    cnt = torch.empty(n_seg, dtype=torch.int32, device=dev)
+    loss = torch.empty(1, device=dev)
+    coef = torch.empty(n_seg, device=dev)
+    mean = torch.empty(n_seg, c, device=dev) if mode == 1 else None
+    check(_lib.load().gags_segment_loss(mode, n_seg, c, k, seg_map.numel(), ptr(s1c), ptr(s2c), ptr(cntc), ptr(s1), ptr(s2),
+                                        ptr(cnt), ptr(loss), ptr(coef), ptr(mean), _st()), "gags_segment_loss")
+    return loss, coef, mean
 
 
 class _ScaleBalance(torch.autograd.Function):
@@ -122,13 +147,10 @@ class _ScaleBalance(torch.autograd.Function):
     def forward(ctx, loss_map, seg_map):
         lm, seg = _f(loss_map), _f(seg_map)
         n_seg = _n_seg(seg_map)
-        s1, _, cnt = _segment_stats(lm.reshape(1, -1), seg.reshape(-1), n_seg)
-        present = cnt > 0
-        k = present.sum().clamp(min=1)
-        means = torch.where(present, s1[:, 0] / cnt.clamp(min=1), torch.zeros_like(s1[:, 0]))
-        ctx.save_for_backward(seg, (present.double() / (cnt.clamp(min=1).double() * k)).float())
+        loss, coef, _ = _segment_loss(0, lm.reshape(1, -1), seg.reshape(-1), n_seg)
+        ctx.save_for_backward(seg, coef)
         ctx.n_seg = n_seg
-        return (means.sum() / k).float()
+        return loss[0]
 
     @staticmethod
     def backward(ctx, v):
@@ -157,20 +179,13 @@ class _RegionVar(torch.autograd.Function):
         pm = x.is_cuda and x.dtype == torch.float32 and not x.is_contiguous() and x.permute(1, 2, 0).is_contiguous()
         x = x.permute(1, 2, 0) if pm else _f(x)
         n_seg = _n_seg(seg_map)
-        s1, s2, cnt = _segment_stats(x.reshape(-1, c) if pm else x.reshape(c, -1), seg.reshape(-1), n_seg, pixel_major=pm)
-        n = cnt.double()
-        ok = cnt >= 2  # segments of 0 or 1 pixels are skipped (loss_utils.py:124-125)
-        nn = torch.where(ok, n, torch.full_like(n, 2.0))
-        mean = s1 / nn[:, None]
-        # unbiased, as torch.var; the moments are accumulated in double about a member of each group (csrc/losses.hip), so the
-        # subtraction below is a double-precision one on accurately summed terms -- and a variance is never negative
-        var = ((s2 - nn[:, None] * mean * mean) / (nn[:, None] - 1.0)).clamp_min(0.0)
-        per_seg = torch.where(ok, nn * var.mean(dim=1), torch.zeros_like(nn))
-        loss = per_seg.sum() / (hh * ww)
-        coef = torch.where(ok, 2.0 * nn / ((nn - 1.0) * c * hh * ww), torch.zeros_like(nn))
-        ctx.save_for_backward(x, seg, mean.float().contiguous(), coef.float())
+        # unbiased variances (torch.var) from moments accumulated in double about a member of each group (csrc/losses.hip): the
+        # subtraction is a double-precision one on accurately summed terms; segments of 0 or 1 pixels are skipped
+        # (loss_utils.py:124-125); copies' sum, variances, loss and the backward's tables in two launches (gags_segment_loss)
+        loss, coef, mean = _segment_loss(1, x.reshape(-1, c) if pm else x.reshape(c, -1), seg.reshape(-1), n_seg, pixel_major=pm)
+        ctx.save_for_backward(x, seg, mean, coef)
         ctx.n_seg, ctx.pm, ctx.c = n_seg, pm, c
-        return loss.float()
+        return loss[0]
 
     @staticmethod
     def backward(ctx, v):

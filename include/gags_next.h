@@ -52,6 +52,16 @@ int gags_segment_stats_multi(int64_t n_pix, int c, const float *x, const float *
 int gags_segment_stats_runs_copies(int64_t n_pix, int c, int n_seg, int layout);
 int gags_segment_stats_runs(int64_t n_pix, int c, const float *x, const float *seg, int n_seg, int copies, double *s1,
                             double *s2, int32_t *cnt, int layout, void *stream);
+/* The two segment losses from the moments' private copies ([copies, n_seg, c] doubles, [copies, n_seg] counts, as left by
+ * gags_segment_stats_multi / _runs), in two launches: the copies summed in copy order into s1 / s2 [n_seg, c] and cnt [n_seg], then
+ *   mode 0 (c == 1), Scale_balance_loss (utils/loss_utils.py:32-57, mix_seg=True): loss[0] = mean over the present segments of
+ *           the segment's mean; coef[i] = 1 / (n_i K), 0 for an absent segment (K = present segments, at least 1);
+ *   mode 1, scale_region_regulation_loss (:103-136, mix_seg=True): loss[0] = sum over segments of >= 2 pixels of
+ *           n_i mean_c var_c / n_pix (unbiased variance, clamped at 0); mean[n_seg, c] and coef[i] = 2 n_i / ((n_i - 1) c n_pix).
+ * All arithmetic in double, results rounded to float once. */
+int gags_segment_loss(int mode, int n_seg, int c, int copies, int64_t n_pix, const double *s1c, const double *s2c,
+                      const int32_t *cntc, double *s1, double *s2, int32_t *cnt, float *loss, float *coef, float *mean,
+                      void *stream);
 /* Backward of the region-variance loss: v_x[c, p] = coef[seg(p)] * (x[c, p] - mean[seg(p), c]), 0 outside segments. */
 int gags_region_var_bwd(int64_t n_pix, int c, const float *x, const float *seg, int n_seg, const float *mean,
                         const float *coef, float *v_x, void *stream);
@@ -255,6 +265,9 @@ int gags_relevancy_activate(int n_phrases, int h, int w, const float *valid_map,
  * instead of bfloat16's 8.  Same signatures and semantics as the entry points above; every `*_bf16` pointer is a half
  * tensor.  Half has 5 exponent bits: conversions saturate at +-65504 (never inf), and the caller multiplies the gradient
  * entering a backward chain by a power of two (gags_amd/decoders.py does: precision="f16") and divides the results. */
+/* The tier's gradient scale from the cotangent's magnitude, on the device: out[0] = S = 2^floor(target_log2 - log2(amax[0] / div))
+ * (exponent clamped to +-100; S = 1 when amax is 0 or not finite), out[1] = 1 / S. */
+int gags_pow2_scale(const float *amax, float div, float target_log2, float *out, void *stream);
 int gags_decoder_pack_layer_h16(int co, int ci, const float *w, const float *b, void *w_bf16, void *wt_bf16, void *w_frag, void *wt_frag, float *bias_pad, void *stream);
 int gags_decoder_pack_input_h16(int64_t n_pix, int c, int c_pad, const float *x, void *y_bf16, void *stream);
 int gags_decoder_layer_h16(int64_t n_pix, int n_out, int k_in, const void *a1, const void *a2, const void *w, const float *bias, int relu, const void *mask_src, const void *residual, void *y_bf16, void *y_premask_bf16, float *y_f32, void *stream);
