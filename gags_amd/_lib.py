@@ -106,6 +106,7 @@ SIGNATURES = {
     "gags_decoder_head_distill_bwd_f32": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_decoder_pack_input": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp]),
     "gags_decoder_pack_layer": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gags_decoder_pack_layers": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_decoder_layer": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_decoder_wgrad_scratch_bytes": (_i64, [_i64, _i32, _i32]),
     "gags_decoder_wgrad": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
@@ -115,6 +116,7 @@ SIGNATURES = {
     "gags_decoder_head": (_i32, [_i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "gags_decoder_fwd_fused": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_decoder_bwd_fused": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gags_decoder_bwd_fused_scaled": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_scale_decoder_fwd_fused": (_i32, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_scale_decoder_bwd_fused": (_i32, [_i64, _vp, _vp, _vp, _vp, _vp]),
     "gags_decoder_layer_exact": (_i32, [_i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
@@ -124,10 +126,10 @@ SIGNATURES = {
     "gags_decoder_wgrad_exact": (_i32, [_i64, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp]),
     "gags_decoder_head_bwd_exact": (_i32, [_i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp]),
     # the "f16" decoder tier: the same kernels with IEEE half operands (include/gags_next.h), same signatures
-    **{name + "_h16": None for name in ("gags_decoder_pack_layer", "gags_decoder_pack_input", "gags_decoder_layer", "gags_decoder_head",
+    **{name + "_h16": None for name in ("gags_decoder_pack_layer", "gags_decoder_pack_layers", "gags_decoder_pack_input", "gags_decoder_layer", "gags_decoder_head",
                                         "gags_decoder_wgrad_scratch_bytes", "gags_decoder_wgrad", "gags_decoder_wgrad_out",
                                         "gags_decoder_head_bwd",
-                                        "gags_decoder_unpack_grad", "gags_decoder_fwd_fused", "gags_decoder_bwd_fused",
+                                        "gags_decoder_unpack_grad", "gags_decoder_fwd_fused", "gags_decoder_bwd_fused", "gags_decoder_bwd_fused_scaled",
                                         "gags_scale_decoder_fwd_fused", "gags_scale_decoder_bwd_fused")},
     "gags_pow2_scale": (_i32, [_vp, _f32, _f32, _vp, _vp]),
     "gags_decoder_head_distill_bwd_h16": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -1151,6 +1151,55 @@ extern "C" int GAGS_DEC(gags_decoder_pack_layer)(int co, int ci, const float *w,
     return GAGS_OK;
 }
 
+// every layer of a decoder in ONE launch (round 6: nine + six launches of ~5 us per iteration before): blockIdx.y = layer
+namespace {
+constexpr int PACK_MAX_LAYERS = 12;
+struct PackArgs {
+    int co[PACK_MAX_LAYERS], ci[PACK_MAX_LAYERS];
+    const float *w[PACK_MAX_LAYERS], *b[PACK_MAX_LAYERS];
+    unsigned short *wr[PACK_MAX_LAYERS], *wtr[PACK_MAX_LAYERS], *wf[PACK_MAX_LAYERS], *wtf[PACK_MAX_LAYERS];
+    float *bp[PACK_MAX_LAYERS];
+};
+__global__ __launch_bounds__(256) void pack_layers_kernel(PackArgs a)
+{
+    const int L = blockIdx.y;
+    const int co = a.co[L], ci = a.ci[L], np = (co + 31) / 32 * 32, kp = (ci + 31) / 32 * 32;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < np) a.bp[L][e] = e < co ? a.b[L][e] : 0.f;
+    if (e >= np * kp) return;
+    const int n = e / kp, k = e - n * kp;
+    const float v = (n < co && k < ci) ? a.w[L][(size_t)n * ci + k] : 0.f;
+    const unsigned short h = gags_h16::h16_from(v);
+    a.wr[L][(size_t)n * kp + k] = h;
+    a.wtr[L][(size_t)k * np + n] = h;
+    a.wf[L][((((size_t)(n >> 5) * (kp >> 4) + (k >> 4)) * 2 + ((k >> 3) & 1)) * 32 + (n & 31)) * 8 + (k & 7)] = h;
+    a.wtf[L][((((size_t)(k >> 5) * (np >> 4) + (n >> 4)) * 2 + ((n >> 3) & 1)) * 32 + (k & 31)) * 8 + (n & 7)] = h;
+}
+}  // namespace
+
+extern "C" int GAGS_DEC(gags_decoder_pack_layers)(int n_layers, const int *co, const int *ci, const float *const *w, const float *const *b,
+                                        void *const *w_bf16, void *const *wt_bf16, void *const *w_frag, void *const *wt_frag,
+                                        float *const *bias_pad, void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (n_layers <= 0 || n_layers > PACK_MAX_LAYERS || !co || !ci || !w || !b || !w_bf16 || !wt_bf16 || !w_frag || !wt_frag || !bias_pad)
+        return GAGS_EINVAL;
+    PackArgs a;
+    int most = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        if (co[i] <= 0 || ci[i] <= 0 || !w[i] || !b[i] || !w_bf16[i] || !wt_bf16[i] || !w_frag[i] || !wt_frag[i] || !bias_pad[i])
+            return GAGS_EINVAL;
+        a.co[i] = co[i]; a.ci[i] = ci[i]; a.w[i] = w[i]; a.b[i] = b[i];
+        a.wr[i] = (unsigned short *)w_bf16[i]; a.wtr[i] = (unsigned short *)wt_bf16[i];
+        a.wf[i] = (unsigned short *)w_frag[i]; a.wtf[i] = (unsigned short *)wt_frag[i]; a.bp[i] = bias_pad[i];
+        const int np = (co[i] + 31) / 32 * 32, kp = (ci[i] + 31) / 32 * 32;
+        most = np * kp > most ? np * kp : most;
+    }
+    hipLaunchKernelGGL(pack_layers_kernel, dim3((unsigned)((most + 255) / 256), (unsigned)n_layers), dim3(256), 0, (hipStream_t)stream, a);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
 extern "C" int GAGS_DEC(gags_decoder_pack_input)(int64_t n_pix, int c, int c_pad, const float *x, void *y_bf16, void *stream)
 {
     GAGS_CLEAR_ERR();

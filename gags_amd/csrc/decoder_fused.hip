@@ -343,6 +343,7 @@ struct BwdArgs {
     const unsigned *mask[9];      // [1..8]: ReLU bit masks [P, 8] of x1, t1, x2, x3, t4, x4, t6, t7
     unsigned short *dz[8];        // dz0 .. dz7 [P, 256] out
     float *gin;                   // [P, c_in] fp32 out, or null
+    const float *gin_scale;       // optional device scalar gin is multiplied by (the f16 tier's power of two: exact)
     int64_t P;
     int c_in, n_last;
 };
@@ -503,13 +504,14 @@ __global__ __launch_bounds__(256 * PH, 2 / PH) void decoder_bwd_fused_kernel(Bwd
             c = h16_mfma(wf, bf, c);
         }
         const int64_t pg = p0 + poff + 32 * wave + (lane & 31);
+        const float gs = a.gin_scale ? a.gin_scale[0] : 1.0f;
         if (pg < a.P) {
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int ch = 8 * g + 4 * (lane >> 5) + e;
-                    if (ch < a.c_in) a.gin[pg * a.c_in + ch] = flo(fpack(c[4 * g + e], 0.f));
+                    if (ch < a.c_in) a.gin[pg * a.c_in + ch] = flo(fpack(c[4 * g + e], 0.f)) * gs;
                 }
         }
     }
@@ -549,8 +551,19 @@ extern "C" int GAGS_DEC(gags_decoder_fwd_fused)(int64_t n_pix, int c_in, int n_l
     return GAGS_OK;
 }
 
+extern "C" int GAGS_DEC(gags_decoder_bwd_fused_scaled)(int64_t n_pix, int c_in, int n_last, const void *dz_last_bf16,
+                                             const void *const *wt_bf16, const void *masks, void *const *dz_bf16, float *gin,
+                                             const float *gin_scale, void *stream);
+
 extern "C" int GAGS_DEC(gags_decoder_bwd_fused)(int64_t n_pix, int c_in, int n_last, const void *dz_last_bf16, const void *const *wt_bf16,
                                       const void *masks, void *const *dz_bf16, float *gin, void *stream)
+{
+    return GAGS_DEC(gags_decoder_bwd_fused_scaled)(n_pix, c_in, n_last, dz_last_bf16, wt_bf16, masks, dz_bf16, gin, nullptr, stream);
+}
+
+extern "C" int GAGS_DEC(gags_decoder_bwd_fused_scaled)(int64_t n_pix, int c_in, int n_last, const void *dz_last_bf16,
+                                             const void *const *wt_bf16, const void *masks, void *const *dz_bf16, float *gin,
+                                             const float *gin_scale, void *stream)
 {
     GAGS_CLEAR_ERR();
     if (n_pix < 0 || c_in <= 0 || c_in > 32 || n_last <= 0 || n_last % FH != 0 || !dz_last_bf16 || !wt_bf16 || !masks || !dz_bf16)
@@ -558,7 +571,7 @@ extern "C" int GAGS_DEC(gags_decoder_bwd_fused)(int64_t n_pix, int c_in, int n_l
     if (n_pix == 0) return GAGS_OK;
     BwdArgs a;
     a.dz8 = (const unsigned short *)dz_last_bf16;
-    a.gin = gin; a.P = n_pix; a.c_in = c_in; a.n_last = n_last;
+    a.gin = gin; a.gin_scale = gin_scale; a.P = n_pix; a.c_in = c_in; a.n_last = n_last;
     for (int i = 0; i < 9; ++i) {
         if (!wt_bf16[i]) return GAGS_EINVAL;
         a.Wt[i] = (const unsigned short *)wt_bf16[i];

@@ -130,7 +130,7 @@ _PACK_CACHE = {}  # (id of the first weight) -> (versions, packed): decoders who
 def _pack_weights(weights, biases, mode=_BF16):
     """bf16 [N_pad, K_pad] weights and fp32 [N_pad] biases, every dimension zero-padded to a multiple of 32; each packed
     weight also carries its transpose (for the input-gradient GEMMs) and both in MFMA-fragment order (for the fused
-    kernels) as attributes -- one gags_decoder_pack_layer launch per layer, and none while the parameters' version
+    kernels) as attributes -- one gags_decoder_pack_layers launch for the whole decoder, and none while the parameters' version
     counters stand still (frozen decoders, the second use within one iteration's backward)."""
     key = (id(weights[0]), mode.name)
     vers = tuple((t.data_ptr(), t._version) for t in list(weights) + list(biases))
@@ -138,8 +138,7 @@ def _pack_weights(weights, biases, mode=_BF16):
     # (the weak references tell a parameter from a later one that got the same id, address and version counter)
     if hit is not None and hit[0] == vers and all(r() is t for r, t in zip(hit[2], list(weights) + list(biases))):
         return hit[1]
-    lib = _lib.load()
-    out = []
+    out, srcs, bsrcs, dims = [], [], [], []
     for wt, bs in zip(weights, biases):
         co, ci = wt.shape[:2]
         n, k = _pad32(co), _pad32(ci)
@@ -150,14 +149,23 @@ def _pack_weights(weights, biases, mode=_BF16):
         wtf = torch.empty(k // 32, n // 16, 2, 32, 8, device=dev, dtype=mode.dtype)
         b = torch.empty(n, device=dev)
         src = wt.detach().reshape(co, ci)
-        src = src if (src.is_contiguous() and src.dtype == torch.float32) else src.contiguous().float()
+        srcs.append(src if (src.is_contiguous() and src.dtype == torch.float32) else src.contiguous().float())
         bsrc = bs.detach()
-        bsrc = bsrc if (bsrc.is_contiguous() and bsrc.dtype == torch.float32) else bsrc.contiguous().float()
-        check(mode.fn("gags_decoder_pack_layer")(co, ci, ptr(src), ptr(bsrc), ptr(w), ptr(w_t), ptr(wf), ptr(wtf), ptr(b), _st()),
-              "gags_decoder_pack_layer")
+        bsrcs.append(bsrc if (bsrc.is_contiguous() and bsrc.dtype == torch.float32) else bsrc.contiguous().float())
+        dims.append((co, ci))
         w._gags_frag, w._gags_t = wf, w_t
         w_t._gags_frag = wtf
         out.append((w, b))
+    for i0 in range(0, len(out), 12):  # one launch per twelve layers (gags_decoder_pack_layers)
+        sl = slice(i0, i0 + 12)
+        m = len(out[sl])
+        ints, ptrs = ctypes.c_int * m, ctypes.c_void_p * m
+        check(mode.fn("gags_decoder_pack_layers")(
+            m, ints(*[d[0] for d in dims[sl]]), ints(*[d[1] for d in dims[sl]]), ptrs(*[t.data_ptr() for t in srcs[sl]]),
+            ptrs(*[t.data_ptr() for t in bsrcs[sl]]), ptrs(*[w.data_ptr() for w, _ in out[sl]]),
+            ptrs(*[w._gags_t.data_ptr() for w, _ in out[sl]]), ptrs(*[w._gags_frag.data_ptr() for w, _ in out[sl]]),
+            ptrs(*[w._gags_t._gags_frag.data_ptr() for w, _ in out[sl]]), ptrs(*[b.data_ptr() for _, b in out[sl]]), _st()),
+            "gags_decoder_pack_layers")
     if len(_PACK_CACHE) > 16:
         _PACK_CACHE.clear()
     _PACK_CACHE[key] = (vers, out, [weakref.ref(t) for t in list(weights) + list(biases)])
@@ -391,7 +399,9 @@ def _chain_forward(x, kind, params, mode=_BF16):
 
 def _chain_backward(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, need_w=None, mode=_BF16, scale=None):
     """From the bf16 gradient of the logits dz [P, ld] back through the chain: (input gradient as a [C_in,H,W] view of
-    [H,W,C_in] memory, weight / bias gradients in parameter order).  need_x / need_w: what autograd asked for."""
+    [H,W,C_in] memory, weight / bias gradients in parameter order, whether the input gradient already carries `scale`).
+    need_x / need_w: what autograd asked for; scale: a device scalar the parameter gradients (and, in the fused kernel, the
+    input gradient) are multiplied by on their way out."""
     p = h * w
     need_w = need_w or [True] * len(wb)
     wt = [_transposed(wgt) for wgt, _ in wb]  # [K_pad, N_pad]: the input-gradient GEMM contracts over N
@@ -413,14 +423,16 @@ def _chain_backward(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, need_w=
         arr = ctypes.c_void_p * 9
         arr8 = ctypes.c_void_p * 8
         wtf = [_frag_layout(t) for t in wt]
-        check(mode.fn("gags_decoder_bwd_fused")(p, c_in, dz.shape[1], ptr(dz), arr(*[t.data_ptr() for t in wtf]), ptr(masks),
-                                                 arr8(*[t.data_ptr() for t in dzs]), ptr(gx), _st()), "gags_decoder_bwd_fused")
+        check(mode.fn("gags_decoder_bwd_fused_scaled")(p, c_in, dz.shape[1], ptr(dz), arr(*[t.data_ptr() for t in wtf]), ptr(masks),
+                                                        arr8(*[t.data_ptr() for t in dzs]), ptr(gx), ptr(scale), _st()),
+              "gags_decoder_bwd_fused_scaled")
+        scaled_gx = True
         wg(8, dz, t7); wg(7, dzs[7], t6); wg(6, dzs[6], s34); wg(5, dzs[5], t4); wg(4, dzs[4], x3)
         wg(3, dzs[3], s12); wg(2, dzs[2], t1); wg(1, dzs[1], x1); wg(0, dzs[0], a0)
         grads = []
         for pair in dws:
             grads += [None, None] if pair is None else [pair[0], pair[1]]
-        return (None if gx is None else gx.permute(2, 0, 1)), grads
+        return (None if gx is None else gx.permute(2, 0, 1)), grads, scaled_gx
     if kind == "decoder":
         a0, x1, t1, x2, x3, t4, x4, t6, t7 = acts
         wg(8, dz, t7)
@@ -469,7 +481,7 @@ def _chain_backward(dz, acts, wb, kind, h, w, c_in, shapes, need_x=True, need_w=
     grads = []
     for pair in dws:
         grads += [None, None] if pair is None else [pair[0], pair[1]]
-    return gx, grads
+    return gx, grads, False
 
 
 def _needs(ctx, first_param):
@@ -530,8 +542,8 @@ class _DecoderFn(torch.autograd.Function):
             dz = torch.empty(p, logits.shape[1], dtype=h16.dtype, device=g.device)
             check(h16.fn("gags_decoder_head_bwd")(p, ctx.c_out, logits.shape[1], mode, ptr(logits), ptr(g), ptr(dz),
                                                   1 if pm else 0, _st()), "gags_decoder_head_bwd")
-            gx, grads = _chain_backward(dz, acts, wb, kind, h, w, ctx.c_in, ctx.shapes, need_x, need_w, mode=h16, scale=inv)
-            if inv is not None:  # (the parameter gradients left their sums already multiplied)
+            gx, grads, done = _chain_backward(dz, acts, wb, kind, h, w, ctx.c_in, ctx.shapes, need_x, need_w, mode=h16, scale=inv)
+            if inv is not None and not done:  # (the parameter gradients left their sums already multiplied)
                 gx = None if gx is None else gx * inv
         return (gx, None, None, None, *grads)
 
@@ -585,14 +597,15 @@ class _DecoderDistillFn(torch.autograd.Function):
             check(_lib.load().gags_decoder_head_distill_bwd_h16(c, logits.shape[1], h, w, seg.shape[1], seg.shape[2], e.shape[0],
                                                                 ptr(logits), ptr(e), ptr(seg), ptr(sc), ptr(vm), ptr(dz), ptr(s),
                                                                 ptr(vs), _st()), "gags_decoder_head_distill_bwd_h16")
-            gx, grads = _chain_backward(dz, acts, ctx.wb, "decoder", h, w, ctx.c_in, ctx.shapes, need_x, need_w, mode=_F16, scale=inv)
-            gx = None if gx is None else gx * inv
+            gx, grads, done = _chain_backward(dz, acts, ctx.wb, "decoder", h, w, ctx.c_in, ctx.shapes, need_x, need_w, mode=_F16,
+                                              scale=inv)
+            gx = gx if (gx is None or done) else gx * inv
         else:
             dz = torch.empty(h * w, logits.shape[1], dtype=torch.bfloat16, device=logits.device)
             check(_lib.load().gags_decoder_head_distill_bwd(c, logits.shape[1], h, w, seg.shape[1], seg.shape[2], e.shape[0],
                                                             ptr(logits), ptr(e), ptr(seg), ptr(sc), ptr(_f(v_map)), ptr(dz), ptr(vs),
                                                             _st()), "gags_decoder_head_distill_bwd")
-            gx, grads = _chain_backward(dz, acts, ctx.wb, "decoder", h, w, ctx.c_in, ctx.shapes, need_x, need_w)
+            gx, grads, _ = _chain_backward(dz, acts, ctx.wb, "decoder", h, w, ctx.c_in, ctx.shapes, need_x, need_w)
         return (gx, None, None, vs, None, None, *grads)
 
 

@@ -120,6 +120,10 @@ int gags_decoder_pack_input(int64_t n_pix, int c, int c_pad, const float *x, voi
  * contiguous kilobyte) for the fused kernels, and the padded fp32 bias.  Round-to-nearest-even, as torch's cast. */
 int gags_decoder_pack_layer(int co, int ci, const float *w, const float *b, void *w_bf16, void *wt_bf16, void *w_frag,
                             void *wt_frag, float *bias_pad, void *stream);
+/* Every layer of a decoder in one launch: the arguments of gags_decoder_pack_layer as arrays of n_layers (<= 12) entries. */
+int gags_decoder_pack_layers(int n_layers, const int *co, const int *ci, const float *const *w, const float *const *b,
+                             void *const *w_bf16, void *const *wt_bf16, void *const *w_frag, void *const *wt_frag,
+                             float *const *bias_pad, void *stream);
 
 /* One 1x1-convolution layer as a GEMM on the 16-bit matrix cores (bf16 operands, fp32 accumulate):
  *     y[p, n] = act( sum_k (a1[p, k] + a2[p, k]) * w[n, k] + bias[n] ) * (mask_src[p, n] > 0) + residual[p, n]
@@ -181,6 +185,9 @@ int gags_decoder_fwd_fused(int64_t n_pix, int c_in, int n_last, const float *x, 
  * [256, 256], [256, n_last]) in the same fragment order; masks: the bit masks gags_decoder_fwd_fused kept (the two skip gradients stay in registers).  Bit-identical to the chain of gags_decoder_layer calls with mask_src / residual / y_premask. */
 int gags_decoder_bwd_fused(int64_t n_pix, int c_in, int n_last, const void *dz_last_bf16, const void *const *wt_bf16,
                            const void *masks, void *const *dz_bf16, float *gin, void *stream);
+/* (the same with the input gradient multiplied by the device scalar gin_scale[0] on its way out -- the f16 tier's 1 / S) */
+int gags_decoder_bwd_fused_scaled(int64_t n_pix, int c_in, int n_last, const void *dz_last_bf16, const void *const *wt_bf16,
+                                  const void *masks, void *const *dz_bf16, float *gin, const float *gin_scale, void *stream);
 
 /* CNN_scale_decoder (models/networks.py:220-248: 16 -> 64 -> 128 -> 64 -> 32 -> 16 -> 3) as one kernel, bf16 mode: x
  * [n_pix, c_in <= 32] fp32; w_bf16[6]: the padded matrices [64,32] [128,64] [64,128] [32,64] [32,32] [32,32] in MFMA-
@@ -269,6 +276,7 @@ int gags_relevancy_activate(int n_phrases, int h, int w, const float *valid_map,
  * (exponent clamped to +-100; S = 1 when amax is 0 or not finite), out[1] = 1 / S. */
 int gags_pow2_scale(const float *amax, float div, float target_log2, float *out, void *stream);
 int gags_decoder_pack_layer_h16(int co, int ci, const float *w, const float *b, void *w_bf16, void *wt_bf16, void *w_frag, void *wt_frag, float *bias_pad, void *stream);
+int gags_decoder_pack_layers_h16(int n_layers, const int *co, const int *ci, const float *const *w, const float *const *b, void *const *w_bf16, void *const *wt_bf16, void *const *w_frag, void *const *wt_frag, float *const *bias_pad, void *stream);
 int gags_decoder_pack_input_h16(int64_t n_pix, int c, int c_pad, const float *x, void *y_bf16, void *stream);
 int gags_decoder_layer_h16(int64_t n_pix, int n_out, int k_in, const void *a1, const void *a2, const void *w, const float *bias, int relu, const void *mask_src, const void *residual, void *y_bf16, void *y_premask_bf16, float *y_f32, void *stream);
 int gags_decoder_head_h16(int64_t n_pix, int c, int ld, int mode, const float *x, float *out, int layout, void *stream);
@@ -279,6 +287,7 @@ int gags_decoder_head_bwd_h16(int64_t n_pix, int c, int ld, int mode, const floa
 int gags_decoder_unpack_grad_h16(int64_t n_pix, int c, int ld, const void *x_bf16, float *y, void *stream);
 int gags_decoder_fwd_fused_h16(int64_t n_pix, int c_in, int n_last, const float *x, const void *const *w_bf16, const float *const *bias, void *const *acts_bf16, void *masks, float *logits, void *stream);
 int gags_decoder_bwd_fused_h16(int64_t n_pix, int c_in, int n_last, const void *dz_last_bf16, const void *const *wt_bf16, const void *masks, void *const *dz_bf16, float *gin, void *stream);
+int gags_decoder_bwd_fused_scaled_h16(int64_t n_pix, int c_in, int n_last, const void *dz_last_bf16, const void *const *wt_bf16, const void *masks, void *const *dz_bf16, float *gin, const float *gin_scale, void *stream);
 int gags_scale_decoder_bwd_fused_h16(int64_t n_pix, const void *dz_last_bf16, const void *const *wt_bf16, const void *masks, void *const *dz_bf16, void *stream);
 /* the fused head + distillation L1 backward (gags_decoder_head_distill_bwd) with the logits' gradient as IEEE half, multiplied by
  * the power of two dz_scale[0] (a DEVICE float: chosen by the caller without a host sync) and saturated at +-65504 */
