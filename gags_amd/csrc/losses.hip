@@ -778,7 +778,8 @@ __global__ __launch_bounds__(256, 3) void head_distill_kernel(int H, int W, int 
             const l_f32x2 x2 = {xe[q], xe[q + 1]}, f0 = {f[0][q], f[0][q + 1]}, f1 = {f[1][q], f[1][q + 1]}, f2 = {f[2][q], f[2][q + 1]};
             const l_f32x2 y2 = x2 * inv;  // (x * (1 / n): within an ulp of F.normalize's x / n)
             const l_f32x2 gt2 = (f0 * s0 + f1 * s1) + f2 * s2;
-            const l_f32x2 d2 = y2 * m - gt2 * m;
+            // (m is 0 or 1: y m - gt m = (y - gt) m exactly; the factor rides on the pixel's sum / on v m instead of on every element)
+            const l_f32x2 d2 = y2 - gt2;
             if (!BWD) {
                 a0 += fabsf(d2[0]);
                 a0 += fabsf(d2[1]);
@@ -807,7 +808,7 @@ __global__ __launch_bounds__(256, 3) void head_distill_kernel(int H, int W, int 
     a0 += __shfl_xor(a0, 1); a0 += __shfl_xor(a0, 2); a0 += __shfl_xor(a0, 4);
     if (!BWD) {
         if ((tid & 7) == 0 && pr < HW) {
-            l1_map[pr] = a0 / (float)c;
+            l1_map[pr] = (a0 * m) / (float)c;
             mask_out[pr] = m;
         }
         return;

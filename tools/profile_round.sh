@@ -32,9 +32,11 @@ timeout 600 python tools/exp_fwd.py --config C3 --truth 16 > "$O/${TAG}_fwd_accu
 S=$(find "$O/d16rstats" -name '*kernel_stats.csv' | head -1)
 [ -n "$S" ] && python "$R/tools/trim_stats.py" "$S" "$O/${TAG}_d16_raster_kernel_stats.csv" 45
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$O/d16stats" -o d16 --output-format csv -- \
-    python "$R/tools/decoder_bench.py" --bf16 > /dev/null 2>&1 )
+    python "$R/tools/decoder_bench.py" --f16 > /dev/null 2>&1 )
 S=$(find "$O/d16stats" -name '*kernel_stats.csv' | head -1)
 [ -n "$S" ] && python "$R/tools/trim_stats.py" "$S" "$O/${TAG}_d16_iteration_kernel_stats.csv" 40
+T=$(find "$O/d16stats" -name '*kernel_trace.csv' | head -1)
+[ -n "$T" ] && python "$R/tools/iter_timeline.py" "$T" > "$O/${TAG}_d16_iteration_timeline.txt" 2>&1
 timeout 300 python tools/gemm_bench.py > "$O/${TAG}_decoder_gemm.json" 2>/dev/null
 timeout 900 python tools/config_sweep.py > "$O/${TAG}_config_sweep.json" 2>/dev/null
 timeout 300 python tools/union_rows.py C3 > "$O/${TAG}_union_rows.json" 2>/dev/null
