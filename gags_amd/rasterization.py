@@ -49,6 +49,7 @@ KEEP_GRAD = os.environ.get("GAGS_KEEP_GRAD", "1") != "0"
 KEEP_GRAD_MIN_ELEMS = 0   # (every shape: the small test scenes exercise the same path as C3)
 KEEP_GRAD_SHAPES = 2      # buffers a context keeps alive at once (least recently used shape is dropped)
 # Row map of the colours-only backward at FORWARD time (RasterContext.early_rowmap; _early_rowmap): default ON
+EARLY_COUNT = os.environ.get("GAGS_EARLY_COUNT", "1") != "0"  # 0: the intersection count is read back after the prefix sum
 EARLY_ROWMAP = os.environ.get("GAGS_EARLY_ROWMAP", "1") != "0"
 # Default of RasterContext.capacity_mode (GAGS_CAPACITY_MODE=1; OFF otherwise): see RasterContext.
 CAPACITY_MODE = os.environ.get("GAGS_CAPACITY_MODE", "0") == "1"
@@ -169,6 +170,12 @@ class RasterContext:
         pool = self._pinned_pool.setdefault(key, [])
         if len(pool) < 8:
             pool.append(t)
+
+    def pinned_i64(self, dev):
+        key = ("i64", dev.index if dev.index is not None else torch.cuda.current_device())
+        if key not in self._pinned:
+            self._pinned[key] = torch.empty(1, dtype=torch.int64).pin_memory()
+        return self._pinned[key]
 
     def pinned_i32(self, dev):
         key = dev.index if dev.index is not None else torch.cuda.current_device()
@@ -420,6 +427,15 @@ def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height, conics=
     tile_bits = max(1, n_tiles.bit_length())  # (room for the sentinel tile id n_tiles of the capacity mode)
     cum = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     total = torch.empty(1, dtype=torch.int32, device=dev)
+    early = None
+    if cap is None and EARLY_COUNT and n > 0:
+        # the count does not depend on the order: summed and sent to the host BEFORE the depth sort and the prefix sum are
+        # enqueued, so that the readback's round trip and the host work behind it (allocations, the next launches) run under
+        # those ~0.2 ms of kernels instead of after them with the queue empty (round 6: a 60-200 us bubble per view)
+        host64 = (context or default_context()).pinned_i64(dev)
+        host64.copy_(tiles_per_gauss.sum().reshape(1), non_blocking=True)
+        early = torch.cuda.Event()
+        early.record()
     # Gaussians in depth order first (N keys), intersections emitted in that order: the per-intersection sort
     # (n_isects ~ 5 N keys) then only groups by tile -- 2 radix passes instead of 6, same sorted result
     order = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
@@ -432,9 +448,13 @@ def tile_binning(means2d, radii, depths, tiles_per_gauss, width, height, conics=
     check(lib.gags_cumsum_gather_i32(n, ptr(tiles_per_gauss), ptr(order), ptr(cum), ptr(total), ptr(scratch), sb, st),
           "gags_cumsum_gather_i32")
     if cap is None:
-        host = ctypes.c_int32(0)
-        check(lib.gags_read_i32(ptr(total), ctypes.byref(host), st), "gags_read_i32")
-        n_isects = int(host.value)
+        if early is not None:
+            early.synchronize()
+            n_isects = int(host64[0])
+        else:
+            host = ctypes.c_int32(0)
+            check(lib.gags_read_i32(ptr(total), ctypes.byref(host), st), "gags_read_i32")
+            n_isects = int(host.value)
         _check_isects(n_isects, n_tiles)
         size, count = n_isects, n_isects
     else:

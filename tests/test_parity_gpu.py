@@ -424,7 +424,9 @@ def test_capacity_mode_keeps_the_counts_on_the_device_and_changes_nothing(oracle
         for a, b in zip(got, ref):
             if isinstance(a, np.ndarray):
                 np.testing.assert_array_equal(a, b)
-    assert len(calls) >= 2   # the two overflows fell back to the exact path
+    # the two overflows fell back to the exact path: the row count's through gags_read_i32, the intersection count's through
+    # the early pinned copy of tile_binning (round 6: summed and sent before the depth sort, rasterization.EARLY_COUNT)
+    assert len(calls) >= 1
 
 
 def test_backward_by_channel_ranges_is_bit_identical(oracle):
@@ -1377,3 +1379,25 @@ def test_sixteen_channel_render_without_a_backward_needs_no_scratch(oracle, with
     _check_indices(info_n, oi)
     n_isects = int(info_n["n_isects"])
     assert peak_grad - peak_lean > 900 * n_isects, (peak_grad, peak_lean, n_isects)   # (the slot space: ~1 KB per intersection)
+
+
+def test_intersection_count_sent_before_the_sorts_is_the_prefix_sums_total():
+    """rasterization.EARLY_COUNT: the count the host sizes the id lists with is the plain sum of the per-Gaussian tile counts,
+    read back before the depth sort and the prefix sum are enqueued; it must be the total the prefix sum arrives at (the last
+    entry of the offsets buffer) and leave every index tensor as the late readback leaves it."""
+    from gags_amd import rasterization as R
+    n, w, h, d = 5000, 200, 152, 16
+    s = scene_arrays(n, d, w, h, seed=5, view=2, scale_mult=3.0)
+    got = {}
+    old = R.EARLY_COUNT
+    try:
+        for flag in (True, False):
+            R.EARLY_COUNT = flag
+            _, _, info, _ = _run_gpu(s, w, h, s["colors"], None, context=R.RasterContext())
+            got[flag] = (info["n_isects"], info["isect_ids"].cpu().numpy(), info["flatten_ids"].cpu().numpy(),
+                         info["isect_offsets"][0].cpu().numpy())
+    finally:
+        R.EARLY_COUNT = old
+    assert got[True][0] == got[False][0] > 0
+    for a, b in zip(got[True][1:], got[False][1:]):
+        np.testing.assert_array_equal(a, b)
