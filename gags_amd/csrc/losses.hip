@@ -10,24 +10,37 @@ namespace {
 
 // ---------------------------------------------------------------------------------------------------------------
 // get_trained_seg (utils/loss_utils.py:138-154)
+// A workgroup = 64 x 4 pixels; the three planes' (64 + 4) x (4 + 4) patches go through LDS once (zero outside the image) and
+// every pixel adds its 25 taps in the order of the direct form (rows, then columns; a zero tap adds exactly nothing): the same
+// bits as one bounds-checked global load per tap, 94 -> ~20 us at 1080p (round 6).
+constexpr int TSW = 64, TSH = 4;
 __global__ __launch_bounds__(256) void trained_seg_kernel(int h, int w, const float *__restrict__ seg_map,
                                                           const float *__restrict__ scale_map, float *__restrict__ out)
 {
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= h * w) return;
-    const int y = p / w, x = p - y * w;
+    __shared__ float patch[3][TSH + 4][TSW + 4];
+    const int x0 = blockIdx.x * TSW, y0 = blockIdx.y * TSH;
+    for (int i = threadIdx.x; i < 3 * (TSH + 4) * (TSW + 4); i += 256) {
+        const int ch = i / ((TSH + 4) * (TSW + 4)), r = i - ch * ((TSH + 4) * (TSW + 4));
+        const int py = r / (TSW + 4), px = r - py * (TSW + 4);
+        const int yy = y0 + py - 2, xx = x0 + px - 2;
+        patch[ch][py][px] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? scale_map[((size_t)ch * h + yy) * w + xx] : 0.f;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & (TSW - 1), ly = threadIdx.x / TSW;
+    const int x = x0 + lx, y = y0 + ly;
+    if (x >= w || y >= h) return;
     float best = 0.f;
     int arg = 0;
+#pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         float s = 0.f;  // conv2d with a 5x5 kernel of 1/25, zero padding 2
-        for (int dy = -2; dy <= 2; ++dy)
-            for (int dx = -2; dx <= 2; ++dx) {
-                const int yy = y + dy, xx = x + dx;
-                if (yy >= 0 && yy < h && xx >= 0 && xx < w) s = fmaf(scale_map[((size_t)ch * h + yy) * w + xx], 0.04f, s);
-            }
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 5; ++dx) s = fmaf(patch[ch][ly + dy][lx + dx], 0.04f, s);
         if (ch == 0 || s > best) { best = s; arg = ch; }  // first maximum wins, as torch.argmax
     }
-    out[p] = seg_map[((size_t)(1 + arg) * h + y) * w + x];
+    out[(size_t)y * w + x] = seg_map[((size_t)(1 + arg) * h + y) * w + x];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -905,8 +918,8 @@ extern "C" int gags_trained_seg(int h, int w, const float *seg_map, const float 
 {
     GAGS_CLEAR_ERR();
     if (h <= 0 || w <= 0 || !seg_map || !scale_map || !out) return GAGS_EINVAL;
-    hipLaunchKernelGGL(trained_seg_kernel, dim3(nblk((int64_t)h * w)), dim3(256), 0, (hipStream_t)stream, h, w, seg_map,
-                       scale_map, out);
+    hipLaunchKernelGGL(trained_seg_kernel, dim3((unsigned)((w + TSW - 1) / TSW), (unsigned)((h + TSH - 1) / TSH)), dim3(256), 0,
+                       (hipStream_t)stream, h, w, seg_map, scale_map, out);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }
