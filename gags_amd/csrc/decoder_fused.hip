@@ -22,7 +22,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float ff32x2_t __attribute__((ext_vector_type(2)));
 using gags_h16::h16_mfma;
-__device__ __forceinline__ unsigned fpack(float lo, float hi) { return gags_h16::h16_pack(lo, hi); }
+__device__ __forceinline__ unsigned fpack(float lo, float hi) { return gags_h16::h16_pack_sat(lo, hi); }  // (both kernels set the mode)
 __device__ __forceinline__ float flo(unsigned u) { return gags_h16::h16_lo(u); }
 __device__ __forceinline__ float fhi(unsigned u) { return gags_h16::h16_hi(u); }
 
@@ -117,8 +117,8 @@ __device__ __forceinline__ void epilogue_hidden(const f32x16 (&acc)[2][2], const
             for (int j = 0; j < 2; ++j) {
                 const ff32x2_t a01 = {acc[i][j][4 * g], acc[i][j][4 * g + 1]}, a23 = {acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                 const ff32x2_t v01 = a01 + b01, v23 = a23 + b23;
-                unsigned u0 = gags_h16::h16_clamp_hi(gags_h16::h16_pack_raw(v01[0], v01[1]));  // (the ReLU below removes the negative side)
-                unsigned u1 = gags_h16::h16_clamp_hi(gags_h16::h16_pack_raw(v23[0], v23[1]));
+                unsigned u0 = gags_h16::h16_pack_sat(v01[0], v01[1]);
+                unsigned u1 = gags_h16::h16_pack_sat(v23[0], v23[1]);
                 unsigned m0, m1;
                 asm("v_pk_max_i16 %0, %1, 0" : "=v"(u0) : "v"(u0));
                 asm("v_pk_max_i16 %0, %1, 0" : "=v"(u1) : "v"(u1));
@@ -200,6 +200,7 @@ struct FwdArgs {
 template <int PH>
 __global__ __launch_bounds__(256 * PH, 2 / PH) void decoder_fwd_fused_kernel(FwdArgs a)
 {
+    gags_h16::h16_saturate_mode();  // (f16 tier: conversions saturate in hardware; half16.h)
     __shared__ __attribute__((aligned(16))) unsigned short bufA[FT * PH][FLD];
     __shared__ __attribute__((aligned(16))) unsigned short bufB[FT * PH][FLD];
     constexpr int TP = FT * PH, NT = 256 * PH;  // pixels per tile, threads: PH groups of four waves, 64 pixels each
@@ -414,6 +415,7 @@ __device__ __forceinline__ void epilogue_dgrad(const f32x16 (&acc)[2][2], int n_
 template <int PH>
 __global__ __launch_bounds__(256 * PH, 2 / PH) void decoder_bwd_fused_kernel(BwdArgs a)
 {
+    gags_h16::h16_saturate_mode();  // (f16 tier: conversions saturate in hardware; half16.h)
     __shared__ __attribute__((aligned(16))) unsigned short bufA[FT * PH][FLD];
     __shared__ __attribute__((aligned(16))) unsigned short bufB[FT * PH][FLD];
     Tile X = bufA, Y = bufB;

@@ -102,8 +102,8 @@ __device__ __forceinline__ void sepilogue(const f32x16 (&acc)[4], const float *_
             const float4 b = *reinterpret_cast<const float4 *>(bias + n);
             const sf32x2_t v01 = sf32x2_t{acc[t][4 * g], acc[t][4 * g + 1]} + sf32x2_t{b.x, b.y};
             const sf32x2_t v23 = sf32x2_t{acc[t][4 * g + 2], acc[t][4 * g + 3]} + sf32x2_t{b.z, b.w};
-            unsigned u0 = gags_h16::h16_clamp_hi(gags_h16::h16_pack_raw(v01[0], v01[1]));
-            unsigned u1 = gags_h16::h16_clamp_hi(gags_h16::h16_pack_raw(v23[0], v23[1]));
+            unsigned u0 = gags_h16::h16_pack_sat(v01[0], v01[1]);
+            unsigned u1 = gags_h16::h16_pack_sat(v23[0], v23[1]);
             unsigned m0, m1;
             asm("v_pk_max_i16 %0, %1, 0" : "=v"(u0) : "v"(u0));
             asm("v_pk_max_i16 %0, %1, 0" : "=v"(u1) : "v"(u1));
@@ -123,6 +123,7 @@ __device__ __forceinline__ void sepilogue(const f32x16 (&acc)[4], const float *_
 
 __global__ __launch_bounds__(256, 2) void sdec_fwd_fused_kernel(SFwdArgs a)
 {
+    gags_h16::h16_saturate_mode();  // (f16 tier: conversions saturate in hardware; half16.h)
     __shared__ __attribute__((aligned(16))) unsigned short buf[4][2][SP][SLD];  // per wave: two ping-pong tiles (2 x 8.5 KB)
     __shared__ __attribute__((aligned(16))) float bias_s[352];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void sdec_fwd_fused_kernel(SFwdArgs a)
                 const int e = lane + 64 * q, row = e >> 5, c = e & 31;
                 const float v = (p0 + row < a.P && c < a.c_in) ? xv[q] : 0.f;
                 const sf32x2_t pr = {v, 0.f};
-                A[row][c] = (unsigned short)(gags_h16::h16_pack(pr[0], pr[1]) & 0xffffu);
+                A[row][c] = (unsigned short)(gags_h16::h16_pack_sat(pr[0], pr[1]) & 0xffffu);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -207,8 +208,8 @@ __device__ __forceinline__ void sepilogue_dgrad(const f32x16 (&acc)[4], const un
             const unsigned nib = mw[t] >> (8 * g + 4 * h);
             const float v0 = (nib & 1u) ? acc[t][4 * g] : 0.f, v1 = (nib & 2u) ? acc[t][4 * g + 1] : 0.f;
             const float v2 = (nib & 4u) ? acc[t][4 * g + 2] : 0.f, v3 = (nib & 8u) ? acc[t][4 * g + 3] : 0.f;
-            const unsigned u0 = gags_h16::h16_pack(v0, v1);
-            const unsigned u1 = gags_h16::h16_pack(v2, v3);
+            const unsigned u0 = gags_h16::h16_pack_sat(v0, v1);
+            const unsigned u1 = gags_h16::h16_pack_sat(v2, v3);
             *reinterpret_cast<uint2 *>(&out[p][n]) = make_uint2(u0, u1);
         }
 }
@@ -217,6 +218,7 @@ __device__ __forceinline__ void sepilogue_dgrad(const f32x16 (&acc)[4], const un
 // layer i's "weight" is the transposed matrix Wt_i [K_i, N_i]: output width SK[i], contraction over SN[i].
 __global__ __launch_bounds__(256, 2) void sdec_bwd_fused_kernel(SBwdArgs a)
 {
+    gags_h16::h16_saturate_mode();  // (f16 tier: conversions saturate in hardware; half16.h)
     __shared__ __attribute__((aligned(16))) unsigned short buf[4][2][SP][SLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     STile A = buf[wave][0], B = buf[wave][1];
