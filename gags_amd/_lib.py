@@ -118,6 +118,8 @@ SIGNATURES = {
     "gags_decoder_bwd_fused": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_decoder_bwd_fused_scaled": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_scale_decoder_fwd_fused": (_i32, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gags_scale_decoder_fwd_fused_head": (_i32, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "gags_softmax_head_bwd_y": (_i32, [_i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "gags_scale_decoder_bwd_fused": (_i32, [_i64, _vp, _vp, _vp, _vp, _vp]),
     "gags_decoder_layer_exact": (_i32, [_i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp]),
     "gags_decoder_layer_split": (_i32, [_i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
@@ -130,7 +132,8 @@ SIGNATURES = {
                                         "gags_decoder_wgrad_scratch_bytes", "gags_decoder_wgrad", "gags_decoder_wgrad_out",
                                         "gags_decoder_head_bwd",
                                         "gags_decoder_unpack_grad", "gags_decoder_fwd_fused", "gags_decoder_bwd_fused", "gags_decoder_bwd_fused_scaled",
-                                        "gags_scale_decoder_fwd_fused", "gags_scale_decoder_bwd_fused")},
+                                        "gags_scale_decoder_fwd_fused", "gags_scale_decoder_bwd_fused", "gags_scale_decoder_fwd_fused_head",
+                                        "gags_softmax_head_bwd_y")},
     "gags_pow2_scale": (_i32, [_vp, _f32, _f32, _vp, _vp]),
     "gags_decoder_head_distill_bwd_h16": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_relevancy": (_i32, [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),

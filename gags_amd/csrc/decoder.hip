@@ -1105,6 +1105,30 @@ __global__ __launch_bounds__(256) void head_bwd_small_kernel(int64_t P, int C, i
     for (int q = 1; q < ld / 8; ++q) dst[q] = make_uint4(0u, 0u, 0u, 0u);
 }
 
+// backward of the softmax head from its OUTPUT y [C, P] (what the fused scale-decoder forward leaves: no logits are kept):
+// dz = y (g - <y, g>), the same operations in the same order as head_bwd_small_kernel from its y onwards
+__global__ __launch_bounds__(256) void softmax_bwd_small_y_kernel(int64_t P, int C, int ld, const float *__restrict__ Y,
+                                                                  const float *__restrict__ G, unsigned short *__restrict__ dz)
+{
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    float g[4] = {0.f, 0.f, 0.f, 0.f}, y[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < HS_MAXC; ++c)
+        if (c < C) { g[c] = G[(size_t)c * P + p]; y[c] = Y[(size_t)c * P + p]; }
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < HS_MAXC; ++c)
+        if (c < C) dot = fmaf(y[c], g[c], dot);
+    float d[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < HS_MAXC; ++c)
+        if (c < C) d[c] = y[c] * (g[c] - dot);
+    uint4 *dst = reinterpret_cast<uint4 *>(dz + p * ld);
+    dst[0] = make_uint4(pack_bf16(d[0], d[1]), pack_bf16(d[2], d[3]), 0u, 0u);
+    for (int q = 1; q < ld / 8; ++q) dst[q] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 // bf16 [P, ld] -> fp32 [P, C] (first C columns): the input gradient in the rasterizer's [H, W, D] layout
 __global__ __launch_bounds__(256) void unpack_f32_kernel(int64_t P, int C, int ld, const unsigned short *__restrict__ x,
                                                          float *__restrict__ y)
@@ -1377,6 +1401,17 @@ extern "C" int GAGS_DEC(gags_decoder_head_bwd)(int64_t n_pix, int c, int ld, int
     else
         hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((n_pix + 63) / 64)), dim3(256), 0, (hipStream_t)stream, n_pix, c, ld, mode,
                            x, g, (unsigned short *)dz_bf16);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
+extern "C" int GAGS_DEC(gags_softmax_head_bwd_y)(int64_t n_pix, int c, int ld, const float *y, const float *g, void *dz_bf16, void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (n_pix < 0 || c <= 0 || c > HS_MAXC || ld < 8 || ld % 8 != 0 || (n_pix > 0 && (!y || !g || !dz_bf16))) return GAGS_EINVAL;
+    if (n_pix == 0) return GAGS_OK;
+    hipLaunchKernelGGL(softmax_bwd_small_y_kernel, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_pix, c, ld,
+                       y, g, (unsigned short *)dz_bf16);
     GAGS_CHECK_LAUNCH();
     return GAGS_OK;
 }

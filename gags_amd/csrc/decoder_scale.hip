@@ -37,7 +37,8 @@ struct SFwdArgs {
     const float *b[SNL];         // fp32 [N]
     unsigned short *act[SNL];    // a0 [P, 32], a1 [P, 64], a2 [P, 128], a3 [P, 64], a4 [P, 32], a5 [P, 32] (null: not kept)
     unsigned *mask;              // [P, 11] ReLU bits of a1 .. a5 (null: not kept)
-    float *logits;               // [P, 32] fp32 (3 real columns)
+    float *logits;               // [P, 32] fp32 (3 real columns), or null with `soft`
+    float *soft;                 // [3, P] fp32 channel-major: softmax over the three real logits (the head fused in), or null
     int64_t P;
     int c_in;
 };
@@ -181,7 +182,21 @@ __global__ __launch_bounds__(256, 2) void sdec_fwd_fused_kernel(SFwdArgs a)
         slayer_mma<SK[5], 1>(acc, a.W[5], B, lane);
         {
             const int p = lane & 31, h = lane >> 5;
-            if (p0 + p < a.P) {
+            if (a.soft) {
+                // CNN_scale_decoder's head (models/networks.py:248, softmax over the 3 channels) on the accumulator itself: the
+                // three real logits of pixel p sit in lane p (h == 0), elements 0..2.  Same operations in the same order as
+                // head_small_kernel (csrc/decoder.hip) on the stored logits: the same bits, without writing 128 B per pixel
+                // of padded fp32 logits and reading them back (round 6)
+                if (h == 0 && p0 + p < a.P) {
+                    const float e0 = acc[0][0] + bias_s[SBOFF[5]], e1 = acc[0][1] + bias_s[SBOFF[5] + 1], e2 = acc[0][2] + bias_s[SBOFF[5] + 2];
+                    const float m = fmaxf(fmaxf(fmaxf(-3.0e38f, e0), e1), e2);
+                    float z = 0.f;
+                    z += expf(e0 - m); z += expf(e1 - m); z += expf(e2 - m);
+                    a.soft[p0 + p] = expf(e0 - m) / z;
+                    a.soft[(size_t)a.P + p0 + p] = expf(e1 - m) / z;
+                    a.soft[2 * (size_t)a.P + p0 + p] = expf(e2 - m) / z;
+                }
+            } else if (p0 + p < a.P) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int n = 8 * g + 4 * h;
@@ -285,15 +300,27 @@ extern "C" int GAGS_DEC(gags_scale_decoder_bwd_fused)(int64_t n_pix, const void 
     return GAGS_OK;
 }
 
+extern "C" int GAGS_DEC(gags_scale_decoder_fwd_fused_head)(int64_t n_pix, int c_in, const float *x, const void *const *w_bf16,
+                                                 const float *const *bias, void *const *acts_bf16, void *masks, float *logits,
+                                                 float *softmax3, void *stream);
+
 extern "C" int GAGS_DEC(gags_scale_decoder_fwd_fused)(int64_t n_pix, int c_in, const float *x, const void *const *w_bf16,
                                             const float *const *bias, void *const *acts_bf16, void *masks, float *logits,
                                             void *stream)
 {
+    if (!logits) return GAGS_EINVAL;
+    return GAGS_DEC(gags_scale_decoder_fwd_fused_head)(n_pix, c_in, x, w_bf16, bias, acts_bf16, masks, logits, nullptr, stream);
+}
+
+extern "C" int GAGS_DEC(gags_scale_decoder_fwd_fused_head)(int64_t n_pix, int c_in, const float *x, const void *const *w_bf16,
+                                                 const float *const *bias, void *const *acts_bf16, void *masks, float *logits,
+                                                 float *softmax3, void *stream)
+{
     GAGS_CLEAR_ERR();
-    if (n_pix < 0 || c_in <= 0 || c_in > 32 || !w_bf16 || !bias || !logits || (n_pix > 0 && !x)) return GAGS_EINVAL;
+    if (n_pix < 0 || c_in <= 0 || c_in > 32 || !w_bf16 || !bias || (!logits && !softmax3) || (n_pix > 0 && !x)) return GAGS_EINVAL;
     if (n_pix == 0) return GAGS_OK;
     SFwdArgs a;
-    a.x = x; a.logits = logits; a.P = n_pix; a.c_in = c_in; a.mask = (unsigned *)masks;
+    a.x = x; a.logits = logits; a.soft = softmax3; a.P = n_pix; a.c_in = c_in; a.mask = (unsigned *)masks;
     for (int i = 0; i < SNL; ++i) {
         if (!w_bf16[i] || !bias[i]) return GAGS_EINVAL;
         a.W[i] = (const unsigned short *)w_bf16[i];

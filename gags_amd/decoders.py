@@ -338,9 +338,10 @@ def _scale_fusable(wb, c_in):
     return c_in <= 32 and [tuple(w.shape) for w, _ in wb] == _SCALE_SHAPES
 
 
-def _chain_forward(x, kind, params, mode=_BF16):
+def _chain_forward(x, kind, params, mode=_BF16, head_out=None):
     """The GEMM chain of a decoder up to its fp32 logits.  Returns (logits [P, ld], activations, packed weights, h, w,
-    c_in)."""
+    c_in).  head_out (a [3, H, W] fp32 tensor): the fused CNN_scale_decoder kernel writes its softmax head there itself and
+    `logits` comes back None (nothing reads them: the head's backward works from its output)."""
     weights, biases = params[0::2], params[1::2]
     wb = _pack_weights(weights, biases, mode)
     xp, h, w = _pixel_major(x)
@@ -351,13 +352,14 @@ def _chain_forward(x, kind, params, mode=_BF16):
         # the six layers in one kernel, a wave per 32-pixel tile (csrc/decoder_scale.hip): bit-identical to the chain below
         dev = x.device
         acts = [a0] + [torch.empty(p, wgt.shape[0], dtype=mode.dtype, device=dev) for wgt, _ in wb[:5]]
-        logits = torch.empty(p, 32, device=dev)
+        logits = torch.empty(p, 32, device=dev) if head_out is None else None
         arr = ctypes.c_void_p * 6
         wf = [_frag_layout(wgt) for wgt, _ in wb]
         masks = torch.empty(p, 11, dtype=torch.int32, device=dev)  # the ReLU decisions as bits, for the fused backward
-        check(mode.fn("gags_scale_decoder_fwd_fused")(p, xp.shape[1], ptr(xp), arr(*[t.data_ptr() for t in wf]),
-                                                       arr(*[b.data_ptr() for _, b in wb]), arr(*[t.data_ptr() for t in acts]),
-                                                       ptr(masks), ptr(logits), _st()), "gags_scale_decoder_fwd_fused")
+        check(mode.fn("gags_scale_decoder_fwd_fused_head")(p, xp.shape[1], ptr(xp), arr(*[t.data_ptr() for t in wf]),
+                                                            arr(*[b.data_ptr() for _, b in wb]), arr(*[t.data_ptr() for t in acts]),
+                                                            ptr(masks), ptr(logits), ptr(head_out), _st()),
+              "gags_scale_decoder_fwd_fused_head")
         return logits, acts + [masks], wb, h, w, xp.shape[1]
     fused = kind == "decoder" and FUSED and _fusable(wb, xp.shape[1])
     if not fused:  # (the fused kernel converts its input tile itself and keeps it as a0)
@@ -499,9 +501,19 @@ class _DecoderFn(torch.autograd.Function):
         exact = precision in ("exact", "bf16x2")  # fp32 tensors, split operands: three terms / two terms
         terms = 2 if precision == "bf16x2" else 3
         h16 = _F16 if precision == "f16" else _BF16
+        head_out = None
+        if not exact and kind == "scale" and c_out == 3 and x.dim() == 3:
+            head_out = torch.empty(3, x.shape[1], x.shape[2], device=x.device)  # (used when the fused kernel serves the shape)
         logits, acts, wb, h, w, c_in = (_chain_forward_exact(x, kind, params, terms) if exact
-                                        else _chain_forward(x, kind, params, h16))
+                                        else _chain_forward(x, kind, params, h16, head_out=head_out))
         p = h * w
+        ctx.kind, ctx.c_out, ctx.hw, ctx.c_in, ctx.exact, ctx.terms = kind, c_out, (h, w), c_in, exact, terms
+        ctx.wb, ctx.h16 = wb, h16
+        ctx.shapes = [tuple(t.shape) for t in params[0::2]]
+        ctx.from_output = logits is None
+        if logits is None:  # the fused scale decoder wrote its softmax head itself; the backward starts from this output
+            ctx.save_for_backward(head_out, *acts)
+            return head_out
         # CNN_decoder's [C,H,W] output is a permuted view of PIXEL-major memory (like render()'s own output): the head
         # writes rows, the losses read rows, the reference's next step (.permute(1,2,0)) is free.  The 3-channel scale
         # map stays channel-major (its consumers index it by plane).
@@ -523,6 +535,19 @@ class _DecoderFn(torch.autograd.Function):
         wb, (h, w), kind = ctx.wb, ctx.hw, ctx.kind
         p = h * w
         lib = _lib.load()
+        if ctx.from_output:  # `logits` is the softmax output y [3, H, W]: dz = y (g - <y, g>) (gags_softmax_head_bwd_y)
+            y, h16, inv = logits, ctx.h16, None
+            g = g if (g.is_contiguous() and g.dtype == torch.float32) else g.contiguous().float()
+            if h16 is _F16:
+                s, inv = _pow2_scale(torch.linalg.vector_norm(g.reshape(-1), float("inf")))
+                g = g * s
+            dz = torch.empty(p, 32, dtype=h16.dtype, device=g.device)
+            check(h16.fn("gags_softmax_head_bwd_y")(p, ctx.c_out, 32, ptr(y), ptr(g), ptr(dz), _st()), "gags_softmax_head_bwd_y")
+            need_x, need_w = _needs(ctx, 4)
+            gx, grads, done = _chain_backward(dz, acts, wb, kind, h, w, ctx.c_in, ctx.shapes, need_x, need_w, mode=h16, scale=inv)
+            if inv is not None and not done:
+                gx = None if gx is None else gx * inv
+            return (gx, None, None, None, *grads)
         gp = g.permute(1, 2, 0)
         pm = (g.dtype == torch.float32 and gp.is_contiguous() and not g.is_contiguous() and ctx.c_out % 4 == 0
               and logits.shape[1] <= 512)  # the cotangent came back in the output's own pixel-major layout

@@ -197,6 +197,15 @@ int gags_decoder_bwd_fused_scaled(int64_t n_pix, int c_in, int n_last, const voi
  * fp32 (3 real columns).  Bit-identical to the same chain run through gags_decoder_layer. */
 int gags_scale_decoder_fwd_fused(int64_t n_pix, int c_in, const float *x, const void *const *w_bf16,
                                  const float *const *bias, void *const *acts_bf16, void *masks, float *logits, void *stream);
+/* The same with the decoder's head fused in (round 6): softmax3 [3, n_pix] fp32 channel-major = softmax over the three real
+ * logits (CNN_scale_decoder.forward's last line, models/networks.py:248), bit-identical to gags_decoder_head(mode 1) on the
+ * logits; `logits` may then be NULL (nothing needs them: gags_softmax_head_bwd_y works from the output). */
+int gags_scale_decoder_fwd_fused_head(int64_t n_pix, int c_in, const float *x, const void *const *w_bf16,
+                                      const float *const *bias, void *const *acts_bf16, void *masks, float *logits,
+                                      float *softmax3, void *stream);
+/* Backward of a softmax head of c <= 4 channels from its output: y, g [c, n_pix] fp32 -> dz [n_pix, ld] 16-bit (columns >= c
+ * zero), dz = y (g - <y, g>): what gags_decoder_head_bwd(mode 1, layout 0) computes from the logits, bit for bit. */
+int gags_softmax_head_bwd_y(int64_t n_pix, int c, int ld, const float *y, const float *g, void *dz_bf16, void *stream);
 
 /* ... and the five input-gradient GEMMs of its backward in one kernel: dz_last [n_pix, 32] bf16 (from the head's backward)
  * -> dz_bf16[0..4] = the gradients at the outputs of layers 0..4 ([n_pix, 64 / 128 / 64 / 32 / 32] bf16: what the weight
@@ -295,6 +304,8 @@ int gags_decoder_head_distill_bwd_h16(int c, int ld, int H, int W, int h, int w,
                                      const float *img_embed, const float *seg_map, const float *scale_map,
                                      const float *v_map, void *dz_f16, const float *dz_scale, float *v_scale, void *stream);
 int gags_scale_decoder_fwd_fused_h16(int64_t n_pix, int c_in, const float *x, const void *const *w_bf16, const float *const *bias, void *const *acts_bf16, void *masks, float *logits, void *stream);
+int gags_scale_decoder_fwd_fused_head_h16(int64_t n_pix, int c_in, const float *x, const void *const *w_bf16, const float *const *bias, void *const *acts_bf16, void *masks, float *logits, float *softmax3, void *stream);
+int gags_softmax_head_bwd_y_h16(int64_t n_pix, int c, int ld, const float *y, const float *g, void *dz_bf16, void *stream);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus
