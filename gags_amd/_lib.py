@@ -95,6 +95,7 @@ SIGNATURES = {
     "gags_segment_stats_runs": (_i32, [_i64, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "gags_segment_loss": (_i32, [_i32, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gags_region_var_bwd_layout": (_i32, [_i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "gags_region_var_bwd_add": (_i32, [_i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "gags_region_var_bwd": (_i32, [_i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "gags_gather_seg_coef": (_i32, [_i64, _vp, _i32, _vp, _vp, _vp]),
     "gags_sam_clip_feature": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),

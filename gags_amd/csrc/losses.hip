@@ -363,7 +363,7 @@ __global__ __launch_bounds__(1024) void seg_loss_finalize_kernel(int mode, int n
 __global__ __launch_bounds__(256) void region_var_bwd_pm_kernel(int64_t n_pix, int c, const float *__restrict__ x,
                                                                 const float *__restrict__ seg, int n_seg,
                                                                 const float *__restrict__ mean, const float *__restrict__ coef,
-                                                                float *__restrict__ vx)
+                                                                float *__restrict__ vx, const float *__restrict__ add)
 {
     const int q4 = c >> 2;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -378,6 +378,10 @@ __global__ __launch_bounds__(256) void region_var_bwd_pm_kernel(int64_t n_pix, i
         const float k = coef[id];
         const float4 mv = *reinterpret_cast<const float4 *>(mean + (size_t)id * c + ch);
         o = make_float4(k * (xv.x - mv.x), k * (xv.y - mv.y), k * (xv.z - mv.z), k * (xv.w - mv.w));
+    }
+    if (add) {  // another consumer's gradient of the same map, added here instead of by a separate pass over both tensors
+        const float4 g = *reinterpret_cast<const float4 *>(add + (size_t)p * c + ch);
+        o = make_float4(o.x + g.x, o.y + g.y, o.z + g.z, o.w + g.w);
     }
     *reinterpret_cast<float4 *>(vx + (size_t)p * c + ch) = o;
 }
@@ -1039,6 +1043,21 @@ extern "C" int gags_segment_stats(int64_t n_pix, int c, const float *x, const fl
     return gags_segment_stats_multi(n_pix, c, x, seg, n_seg, 1, s1, s2, cnt, 0, stream);
 }
 
+extern "C" int gags_region_var_bwd_add(int64_t n_pix, int c, const float *x, const float *seg, int n_seg, const float *mean,
+                                       const float *coef, const float *add, float *v_x, void *stream)
+{
+    GAGS_CLEAR_ERR();
+    if (n_pix < 0 || c <= 0 || (c & 3) != 0 || n_seg <= 0 || (n_pix > 0 && (!x || !seg || !mean || !coef || !add || !v_x)) ||
+        ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(v_x) | reinterpret_cast<uintptr_t>(mean) |
+          reinterpret_cast<uintptr_t>(add)) & 15) != 0)
+        return GAGS_EINVAL;
+    if (n_pix == 0) return GAGS_OK;
+    hipLaunchKernelGGL(region_var_bwd_pm_kernel, dim3(nblk(n_pix * (c >> 2))), dim3(256), 0, (hipStream_t)stream, n_pix, c, x, seg, n_seg,
+                       mean, coef, v_x, add);
+    GAGS_CHECK_LAUNCH();
+    return GAGS_OK;
+}
+
 extern "C" int gags_region_var_bwd_layout(int64_t n_pix, int c, const float *x, const float *seg, int n_seg, const float *mean,
                                           const float *coef, float *v_x, int layout, void *stream)
 {
@@ -1048,7 +1067,7 @@ extern "C" int gags_region_var_bwd_layout(int64_t n_pix, int c, const float *x, 
     if (n_pix == 0) return GAGS_OK;
     if (layout == 1 && (c & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(v_x) | reinterpret_cast<uintptr_t>(mean)) & 15) == 0)
         hipLaunchKernelGGL(region_var_bwd_pm_kernel, dim3(nblk(n_pix * (c >> 2))), dim3(256), 0, (hipStream_t)stream, n_pix, c, x, seg,
-                           n_seg, mean, coef, v_x);
+                           n_seg, mean, coef, v_x, (const float *)nullptr);
     else
         hipLaunchKernelGGL(region_var_bwd_kernel, dim3(nblk(n_pix)), dim3(256), 0, (hipStream_t)stream, n_pix, c, x, seg, n_seg,
                            mean, coef, v_x, layout);

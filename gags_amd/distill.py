@@ -33,7 +33,10 @@ def distillation_loss(feature_map, seg_map, img_embed, cnn_decoder, cnn_scale_de
     scale_map = cnn_scale_decoder(feature_map.detach())                                  # train.py:149
     seg_map_trained = L.get_trained_seg(seg_map, scale_map)                              # :152
     late = iteration >= scale_regulation_iteration
-    regionvar = L.scale_region_regulation_loss(feature_map, seg_map_trained, mix_seg=True) if late else None   # :153
+    regionvar = None
+    if late:                                                                             # :153
+        # (the map travels on through the loss's node: its gradient and the decoder's are then summed by ONE kernel)
+        regionvar, feature_map = L.scale_region_regulation_loss_tee(feature_map, seg_map_trained)
     ce = L.scale_regulation_loss(scale_map)                                              # :156
     if iteration < scale_balance_iteration:                                              # :161-163  L_distill
         pred = cnn_decoder(feature_map) if speedup else feature_map

@@ -197,6 +197,38 @@ class _RegionVar(torch.autograd.Function):
         return (vx.permute(2, 0, 1) if ctx.pm else vx), None
 
 
+class _RegionVarTee(torch.autograd.Function):
+    """_RegionVar that also hands its input on: (loss, x') with x' an alias of x for the NEXT consumer of the map.  The
+    backward then receives that consumer's gradient together with the loss's cotangent and adds the two in the kernel that
+    forms the loss's own gradient (gags_region_var_bwd_add) -- autograd's separate sum of two 132 MB maps per 1080p iteration
+    is gone.  Same values: one fp32 addition per element either way."""
+
+    @staticmethod
+    def forward(ctx, x, seg_map):
+        loss = _RegionVar.forward(ctx, x, seg_map)
+        return loss, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, v, g_next):
+        if g_next is None:
+            return _RegionVar.backward(ctx, v)
+        x, seg, mean, coef = ctx.saved_tensors
+        gp = g_next.permute(1, 2, 0) if ctx.pm else g_next
+        if not (ctx.pm and ctx.c % 4 == 0 and gp.is_contiguous() and gp.dtype == torch.float32):
+            vx, _ = _RegionVar.backward(ctx, v)
+            return vx + g_next, None
+        vx = torch.empty_like(x)
+        check(_lib.load().gags_region_var_bwd_add(seg.numel(), ctx.c, ptr(x), ptr(seg), ctx.n_seg, ptr(mean),
+                                                  ptr((coef * v).contiguous()), ptr(gp), ptr(vx), _st()), "gags_region_var_bwd_add")
+        return vx.permute(2, 0, 1), None
+
+
+def scale_region_regulation_loss_tee(scale_map, seg_map):
+    """(scale_region_regulation_loss(scale_map, seg_map, mix_seg=True), scale_map'): use scale_map' wherever the map is
+    consumed afterwards (gags_amd/distill.py feeds it to CNN_decoder) and the two gradients are summed in one kernel."""
+    return _RegionVarTee.apply(scale_map, seg_map)
+
+
 def scale_region_regulation_loss(scale_map, seg_map, scale_bal_idx=1, mix_seg=False):
     """sum over segments of n_seg * mean_c(var_c) / (H*W) of the map [C,H,W] under seg_map [H,W]
     (utils/loss_utils.py:103-136 with mix_seg=True; train.py:153 feeds it the rasterized feature map)."""

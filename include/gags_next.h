@@ -68,6 +68,10 @@ int gags_region_var_bwd(int64_t n_pix, int c, const float *x, const float *seg, 
 /* ... with x and v_x pixel-major [n_pix, c] when layout = 1. */
 int gags_region_var_bwd_layout(int64_t n_pix, int c, const float *x, const float *seg, int n_seg, const float *mean,
                                const float *coef, float *v_x, int layout, void *stream);
+/* The same for a pixel-major map (c % 4 == 0, 16-byte aligned) with another consumer's gradient of that map added on the way
+ * out: v_x = add + coef[seg] (x - mean[seg]) -- one pass instead of this kernel's and an element-wise sum's. */
+int gags_region_var_bwd_add(int64_t n_pix, int c, const float *x, const float *seg, int n_seg, const float *mean,
+                            const float *coef, const float *add, float *v_x, void *stream);
 /* Backward of the segment-balanced mean: out[p] = coef[seg(p)], 0 outside segments. */
 int gags_gather_seg_coef(int64_t n_pix, const float *seg, int n_seg, const float *coef, float *out, void *stream);
 
