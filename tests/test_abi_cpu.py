@@ -100,6 +100,26 @@ def test_argument_validation_returns_codes_without_launching(lib):
     assert lib.gags_raster_bwd_colors_staged(*common["pre"], P(al), *common["post"], None) == -3   # (aligned: on to the scratch-size check)
     assert lib.gags_decoder_layer_split(8, 4, 4, *([None] * 2), 4, *([None] * 2), 1, *([None] * 4), 4, 5, None) == -1   # terms = 5
     assert lib.gags_decoder_wgrad_split(8, 4, 4, None, 4, None, None, 4, None, None, None, 0, 1, None) == -1            # terms = 1
+    # round 6, second half: the iteration's entries
+    P8 = P(al)
+    assert lib.gags_decoder_wgrad_out(8, 32, 32, P8, P8, None, P8, None, 33, 16, None, None, 0, None) == -1              # co > n_out
+    assert lib.gags_decoder_wgrad_out_h16(8, 32, 32, P8, P8, None, P8, None, 16, 0, None, None, 0, None) == -1           # ci = 0
+    assert lib.gags_decoder_pack_layers(13, P8, P8, P8, P8, P8, P8, P8, P8, P8, None) == -1                              # > 12 layers
+    assert lib.gags_decoder_bwd_fused_scaled(8, 64, 512, P8, P8, P8, P8, None, None, None) == -1                         # c_in > 32
+    assert lib.gags_scale_decoder_fwd_fused_head(8, 16, P8, P8, P8, None, None, None, None, None) == -1                  # no output at all
+    assert lib.gags_softmax_head_bwd_y(8, 5, 32, P8, P8, P8, None) == -1                                                 # more than 4 channels
+    assert lib.gags_pow2_scale(None, 1.0, 12.0, P8, None) == -1 and lib.gags_pow2_scale(P8, 0.0, 12.0, P8, None) == -1
+    assert lib.gags_entropy_bwd_dev(8, P8, None, P8, None) == -1
+    assert lib.gags_segment_loss(0, 4, 2, 1, 64, P8, P8, P8, P8, P8, P8, P8, P8, None, None) == -1                       # mode 0 is c == 1
+    assert lib.gags_segment_loss(1, 4, 2, 1, 64, P8, P8, P8, P8, P8, P8, P8, P8, None, None) == -1                       # mode 1 needs `mean`
+    assert lib.gags_region_var_bwd_add(8, 6, P8, P8, 4, P8, P8, P8, P8, None) == -1                                      # c % 4
+    # (host arithmetic only) the run-length moments kernel: copies = workgroups, 0 = shape not served
+    assert lib.gags_segment_stats_runs_copies(1920 * 1080, 16, 300, 1) == 512
+    assert lib.gags_segment_stats_runs_copies(1920 * 1080, 1, 300, 0) == 254
+    assert lib.gags_segment_stats_runs_copies(1000, 16, 300, 1) == 1
+    assert lib.gags_segment_stats_runs_copies(1920 * 1080, 16, 300, 0) == 0        # channel-major 16 channels
+    assert lib.gags_segment_stats_runs_copies(1920 * 1080, 16, 20000, 1) == 0      # table beyond LDS
+    assert lib.gags_segment_stats_runs(64, 16, P8, P8, 300, 7, P8, P8, P8, 1, None) == -1   # copies must be what _copies says
 
 
 def test_intersection_cap_covers_the_slot_space(lib):
