@@ -661,3 +661,49 @@ def test_f16_conversions_saturate_instead_of_overflowing():
     (y * torch.from_numpy(Z["dec_G"]).cuda()).sum().backward()
     assert torch.isfinite(y).all() and torch.isfinite(x.grad).all()
     np.testing.assert_allclose(y.detach().double().pow(2).sum(0).sqrt().cpu().numpy(), 1.0, rtol=1e-4)
+
+
+def test_head_and_distillation_backward_treats_exact_ties_as_torch_sign_does():
+    """torch.sign(0) = 0: an element whose normalised prediction EQUALS the ground truth contributes nothing.  The fused head +
+    loss backward takes copysign(1, diff) on its fast path (round 6) and must notice exact ties (about one fp32 element in 10^7
+    on real data) and redo the pixel in the {-1, 0, +1} form: pixels built to tie in all 512 channels (logits = an embedding of
+    norm exactly 1, scale map (1, 0, 0)), in all but one, and ordinary pixels, against fp32 autograd through torch.sign."""
+    import ctypes
+    from gags_amd import _lib, losses as L
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(21)
+    H, W, n_emb, c = 16, 24, 7, 512
+    emb = torch.nn.functional.normalize(torch.randn(n_emb, c, device="cuda", generator=g), dim=-1)
+    emb[0] = 0.0
+    emb[0, :4] = 0.5                                   # |e0| = 1 exactly
+    seg = torch.randint(0, n_emb, (4, H, W), device="cuda", generator=g).float()
+    sc = torch.softmax(torch.randn(3, H, W, device="cuda", generator=g), 0)
+    x = torch.randn(H * W, c, device="cuda", generator=g)
+    tie_all, tie_most = [5, 40, 41, 200], [9, 77, 300]
+    for p in tie_all + tie_most:
+        seg[1].view(-1)[p] = 0
+        sc.view(3, -1)[:, p] = torch.tensor([1.0, 0.0, 0.0], device="cuda")
+        x[p] = emb[0] * (2.0 if p % 2 else 1.0)        # y = x / |x| = e0 exactly
+    for p in tie_most:
+        x[p, 3] = -x[p, 3]                             # one channel off, the 511 others tie
+    v = torch.rand(H, W, device="cuda", generator=g) + 0.5
+    # fp32 autograd through torch.sign
+    xr, scr = x.clone().requires_grad_(True), sc.clone().requires_grad_(True)
+    y = xr / xr.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    feat, mask = L.read_sam_clip_feature(emb, seg, scr)
+    m = mask.float()
+    l1 = (y.t().reshape(c, H, W) * m - feat * m).abs().mean(0)
+    (l1 * v).sum().backward()
+    assert float(xr.grad[tie_all].abs().max()) == 0.0  # (the reference: nothing flows through a pixel that ties everywhere)
+    dz = torch.empty(H * W, c, device="cuda")
+    vs = torch.empty(3, H, W, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    assert lib.gags_decoder_head_distill_bwd_f32(c, c, H, W, H, W, n_emb, P(x), P(emb), P(seg), P(sc), P(v), P(dz), P(vs), st) == 0
+    torch.cuda.synchronize()
+    assert float(dz[tie_all].abs().max()) == 0.0 and float(vs.view(3, -1)[:, tie_all].abs().max()) == 0.0
+    # (elsewhere the two routes differ by an ulp in y = x / |x|: a sign may flip where |diff| is below that, 1 / 512 of a pixel)
+    assert rel_l2(dz.cpu().numpy(), xr.grad.cpu().numpy()) <= 2e-3
+    assert rel_l2(vs.cpu().numpy(), scr.grad.cpu().numpy()) <= 2e-3
+    one = tie_most[0]  # 511 ties and one channel that differs: only that channel carries a sign
+    np.testing.assert_allclose(dz[one].cpu().numpy(), xr.grad[one].cpu().numpy(), rtol=1e-4, atol=1e-9)
