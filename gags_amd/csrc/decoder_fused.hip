@@ -94,7 +94,8 @@ __device__ __forceinline__ void layer_main(f32x16 (&acc)[2][2], WFrag &f, const 
 
 // accumulator element (i, j, 4 g + e) of lane (p = lane & 31, h = lane >> 5): pixel 32 j + p, channel n_base + 32 i + 8 g + 4 h + e
 // hidden-layer epilogue: out[p][n] = bf16(relu(acc + bias[n])); and, for the backward, the ReLU decisions as BITS:
-// mask[(p0 + pixel) * 8 + n / 32] bit n % 32 = [out > 0] -- 32 bytes per pixel and layer instead of the 512-byte activation row
+// mask[(p0 + pixel) * 8 + n / 32] holds [out > 0] of the word's 32 channels (channel 8 g + 4 h + e of the word at bit
+// 8 h + 2 g + (e >> 1) + 16 (e & 1): private to these two kernels) -- 32 bytes per pixel and layer instead of the 512-byte activation row
 // the input-gradient chain would otherwise re-read just for its sign.
 __device__ __forceinline__ void epilogue_hidden(const f32x16 (&acc)[2][2], const float *__restrict__ bias, int n_base, Tile out,
                                                 int lane, unsigned *__restrict__ mask, int64_t p0, int64_t P, int poff)
@@ -125,9 +126,11 @@ __device__ __forceinline__ void epilogue_hidden(const f32x16 (&acc)[2][2], const
                 asm("v_pk_min_u16 %0, %1, %2" : "=v"(m0) : "v"(u0), "v"(one2));
                 asm("v_pk_min_u16 %0, %1, %2" : "=v"(m1) : "v"(u1), "v"(one2));
                 *reinterpret_cast<uint2 *>(&out[poff + 32 * j + p][n]) = make_uint2(u0, u1);
-                // m = bit 0 and bit 16 -> nibble bits 0..3
-                const unsigned nib = ((m0 | (m0 >> 15)) & 3u) | (((m1 | (m1 >> 15)) & 3u) << 2);
-                bits[i][j] |= nib << (8 * g);
+                // m0 / m1 carry the decisions of elements (0, 1) / (2, 3) at bits 0 and 16: shifted in as they are, two
+                // v_lshl_or per group (round 6; assembling a nibble per group first cost eight) -- the word's layout is private to
+                // the two fused kernels: element e of group g of half h at bit 8 h + 2 g + (e >> 1) + 16 (e & 1)
+                bits[i][j] |= m0 << (2 * g);
+                bits[i][j] |= m1 << (2 * g + 1);
             }
         }
     if (mask) {
@@ -135,7 +138,7 @@ __device__ __forceinline__ void epilogue_hidden(const f32x16 (&acc)[2][2], const
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const unsigned mine = bits[i][j] << (4 * h);  // this half-wave's nibbles sit at bits 8 g + 4 h
+                const unsigned mine = bits[i][j] << (8 * h);  // this half-wave's bits sit at 8 h + 0..7 and 8 h + 16..23
                 const auto sw = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
                 const unsigned word = sw[0] | sw[1];
                 const int64_t pg = p0 + poff + 32 * j + p;
@@ -386,6 +389,11 @@ __device__ __forceinline__ void epilogue_dgrad(const f32x16 (&acc)[2][2], int n_
                                                uint2 (&keep)[2][4][2], int lane, int poff)
 {
     const int p = lane & 31, h = lane >> 5;
+    unsigned wh[2][2];  // this half-wave's bits of the four words, at 2 g + (e >> 1) + 16 (e & 1) (epilogue_hidden's layout)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) wh[i][j] = mw[i][j] >> (8 * h);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -400,10 +408,9 @@ __device__ __forceinline__ void epilogue_dgrad(const f32x16 (&acc)[2][2], int n_
                 }
                 const unsigned u0 = fpack(v0, v1), u1 = fpack(v2, v3);
                 if constexpr (KEEP) keep[i][g][j] = make_uint2(u0, u1);
-                // the ReLU decisions applied to the PACKED pairs: bits (b0, b1) -> the halves' multipliers {0, 1} -> v_pk_mul_lo_u16
-                // (4 instructions per pair instead of a compare + select per value; a bf16 times 1 or 0 as integers is itself or +0)
-                const unsigned nib = mw[i][j] >> (8 * g + 4 * h);
-                const unsigned k0 = (nib & 1u) | ((nib & 2u) << 15), k1 = ((nib >> 2) & 1u) | ((nib & 8u) << 13);
+                // the ReLU decisions applied to the PACKED pairs: the pair's two bits sit 16 apart in the word -> the halves'
+                // multipliers {0, 1} by one shift + one and -> v_pk_mul_lo_u16 (a bf16 times 1 or 0 as integers is itself or +0)
+                const unsigned k0 = (wh[i][j] >> (2 * g)) & 0x00010001u, k1 = (wh[i][j] >> (2 * g + 1)) & 0x00010001u;
                 unsigned w0, w1;
                 asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(w0) : "v"(u0), "v"(k0));
                 asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(w1) : "v"(u1), "v"(k1));
