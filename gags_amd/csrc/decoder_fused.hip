@@ -26,12 +26,31 @@ __device__ __forceinline__ unsigned fpack(float lo, float hi) { return gags_h16:
 __device__ __forceinline__ float flo(unsigned u) { return gags_h16::h16_lo(u); }
 __device__ __forceinline__ float fhi(unsigned u) { return gags_h16::h16_hi(u); }
 
+#ifndef GAGS_ABL
+#define GAGS_ABL 0  // timing-only ablations of the fused kernels (tools/chain_bench.py; results are WRONG with any of them): 1 no HBM
+                    // stores (64 masks / 128 tiles / 256 logits alone), 2 no weight refills, 4 no MFMAs, 16 no B reads, 32 plain stores
+#endif
 constexpr int FT = 64;        // pixels per tile and group of four waves; a workgroup holds PH such groups (tile = 64 PH pixels)
 constexpr int FH = 256;       // hidden width
 constexpr int FLD = FH + 8;   // LDS row pitch in bf16 (528 B: 16-byte aligned rows, consecutive rows 4 banks apart)
 constexpr int FPD = 8;        // weight fragments are requested this many K-steps ahead
 
 typedef unsigned short (*Tile)[FLD];
+
+// the tiles' HBM stores are non-temporal (`nt`): 10.6 GB per 1080p forward that nothing reads before the kernel ends stream past
+// the L2 the weight fragments live in (round 6: -2 %; GAGS_ABL & 32 restores plain stores)
+typedef unsigned nt_u32x4 __attribute__((ext_vector_type(4)));
+typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void stream_store(uint4 *dst, uint4 v)
+{
+    if (!(GAGS_ABL & 32)) __builtin_nontemporal_store(nt_u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_u32x4 *>(dst));
+    else *dst = v;
+}
+__device__ __forceinline__ void stream_store(float4 *dst, float4 v)
+{
+    if (!(GAGS_ABL & 32)) __builtin_nontemporal_store(nt_f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_f32x4 *>(dst));
+    else *dst = v;
+}
 
 // Weights arrive in MFMA-FRAGMENT order (gags_amd/decoders.py: _frag_layout): Wf[n_tile][k_step][lane][8] with lane =
 // 32 kh + n and the eight values k = 16 k_step + 8 kh + 0..7 of row 32 n_tile + n -- the A operand of one MFMA is one
@@ -77,15 +96,22 @@ __device__ __forceinline__ void layer_main(f32x16 (&acc)[2][2], WFrag &f, const 
             const int ks = k0 + q;
             const bf16x8 c0 = f.a0[q], c1 = f.a1[q];
             const int kn = min(ks + FPD, ksteps - 1);  // (past the end: a harmless re-read)
+            if (!(GAGS_ABL & 2)) {
             f.a0[q] = *reinterpret_cast<const bf16x8 *>(w0 + 512 * kn);
             f.a1[q] = *reinterpret_cast<const bf16x8 *>(w1 + 512 * kn);
+            }
             if (ks < ksteps) {  // (uniform)
-                const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(&in[poff + (lane & 31)][16 * ks + 8 * (lane >> 5)]);
-                const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(&in[poff + 32 + (lane & 31)][16 * ks + 8 * (lane >> 5)]);
+                bf16x8 b0 = c0, b1 = c1;
+                if (!(GAGS_ABL & 16)) {
+                b0 = *reinterpret_cast<const bf16x8 *>(&in[poff + (lane & 31)][16 * ks + 8 * (lane >> 5)]);
+                b1 = *reinterpret_cast<const bf16x8 *>(&in[poff + 32 + (lane & 31)][16 * ks + 8 * (lane >> 5)]);
+                }
+                if (!(GAGS_ABL & 4)) {
                 acc[0][0] = h16_mfma(c0, b0, acc[0][0]);
                 acc[0][1] = h16_mfma(c0, b1, acc[0][1]);
                 acc[1][0] = h16_mfma(c1, b0, acc[1][0]);
                 acc[1][1] = h16_mfma(c1, b1, acc[1][1]);
+                } else { acc[0][0][0] += (float)b0[0] + (float)c0[0]; acc[1][1][0] += (float)b1[0] + (float)c1[0]; }
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetch FPD steps ahead (the scheduler sinks loads to their use)
         }
@@ -94,8 +120,8 @@ __device__ __forceinline__ void layer_main(f32x16 (&acc)[2][2], WFrag &f, const 
 
 // accumulator element (i, j, 4 g + e) of lane (p = lane & 31, h = lane >> 5): pixel 32 j + p, channel n_base + 32 i + 8 g + 4 h + e
 // hidden-layer epilogue: out[p][n] = bf16(relu(acc + bias[n])); and, for the backward, the ReLU decisions as BITS:
-// mask[(p0 + pixel) * 8 + n / 32] holds [out > 0] of the word's 32 channels (channel 8 g + 4 h + e of the word at bit
-// 8 h + 2 g + (e >> 1) + 16 (e & 1): private to these two kernels) -- 32 bytes per pixel and layer instead of the 512-byte activation row
+// word n / 32 of a pixel holds [out > 0] of 32 channels (channel 8 g + 4 h + e of the word at bit 8 h + 2 g + (e >> 1) + 16 (e & 1));
+// words are stored word-major inside 64-pixel groups, mask[(group * 8 + word) * 64 + pixel % 64]: both private to these two kernels -- 32 bytes per pixel and layer instead of the 512-byte activation row
 // the input-gradient chain would otherwise re-read just for its sign.
 __device__ __forceinline__ void epilogue_hidden(const f32x16 (&acc)[2][2], const float *__restrict__ bias, int n_base, Tile out,
                                                 int lane, unsigned *__restrict__ mask, int64_t p0, int64_t P, int poff)
@@ -142,7 +168,10 @@ __device__ __forceinline__ void epilogue_hidden(const f32x16 (&acc)[2][2], const
                 const auto sw = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
                 const unsigned word = sw[0] | sw[1];
                 const int64_t pg = p0 + poff + 32 * j + p;
-                if (h == 0 && pg < P) mask[pg * 8 + (n_base >> 5) + i] = word;
+                // word-major inside a 64-pixel group (round 6): the 32 lanes of a store write 128 contiguous bytes (pixel-major,
+                // 8 words per pixel, they wrote 4 bytes every 32: the masks were 5 % of the kernel's bytes and 5 % of its time)
+                if (h == 0 && pg < P && !(GAGS_ABL & (1 | 64)))
+                    mask[(((p0 + poff) >> 6) * 8 + (n_base >> 5) + i) * 64 + 32 * j + p] = word;
             }
     }
 }
@@ -151,11 +180,11 @@ __device__ __forceinline__ void epilogue_hidden(const f32x16 (&acc)[2][2], const
 template <int NT>
 __device__ __forceinline__ void store_tile(unsigned short *__restrict__ dst, int64_t p0, int64_t P, Tile src, int tid)
 {
-    if (!dst) return;
+    if (!dst || (GAGS_ABL & (1 | 128))) return;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int id = tid + NT * q, row = id >> 5, c = (id & 31) * 8;
-        if (p0 + row < P) *reinterpret_cast<uint4 *>(dst + (size_t)(p0 + row) * FH + c) = *reinterpret_cast<const uint4 *>(&src[row][c]);
+        if (p0 + row < P) stream_store(reinterpret_cast<uint4 *>(dst + (size_t)(p0 + row) * FH + c), *reinterpret_cast<const uint4 *>(&src[row][c]));
     }
 }
 
@@ -173,7 +202,7 @@ __device__ __forceinline__ void add_store_tile(Tile dst, Tile add, unsigned shor
         const uint4 sum = make_uint4(fpack(flo(x.x) + flo(y.x), fhi(x.x) + fhi(y.x)), fpack(flo(x.y) + flo(y.y), fhi(x.y) + fhi(y.y)),
                                      fpack(flo(x.z) + flo(y.z), fhi(x.z) + fhi(y.z)), fpack(flo(x.w) + flo(y.w), fhi(x.w) + fhi(y.w)));
         *reinterpret_cast<uint4 *>(&dst[row][c]) = sum;
-        if (keep && p0 + row < P) *reinterpret_cast<uint4 *>(keep + (size_t)(p0 + row) * FH + c) = sum;
+        if (keep && p0 + row < P && !(GAGS_ABL & (1 | 128))) stream_store(reinterpret_cast<uint4 *>(keep + (size_t)(p0 + row) * FH + c), sum);
     }
 }
 template <int NT>
@@ -323,9 +352,9 @@ __global__ __launch_bounds__(256 * PH, 2 / PH) void decoder_fwd_fused_kernel(Fwd
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int id = tid + NT * q, row = id >> 5, c = (id & 31) * 4;
-                if (p0 + row < a.P)
-                    *reinterpret_cast<float4 *>(a.logits + (size_t)(p0 + row) * a.n_last + nb + 128 * half + c) =
-                        *reinterpret_cast<const float4 *>(&patch[row][c]);
+                if (p0 + row < a.P && !(GAGS_ABL & (1 | 256)))
+                    stream_store(reinterpret_cast<float4 *>(a.logits + (size_t)(p0 + row) * a.n_last + nb + 128 * half + c),
+                                 *reinterpret_cast<const float4 *>(&patch[row][c]));
             }
             __syncthreads();
         }
@@ -379,7 +408,7 @@ __device__ __forceinline__ void fetch_mask(unsigned (&mw)[2][2], const unsigned 
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) mw[i][j] = mask[min(p0 + poff + 32 * j + (lane & 31), P - 1) * 8 + 2 * wave + i];
+        for (int j = 0; j < 2; ++j) mw[i][j] = mask[(((p0 + poff) >> 6) * 8 + 2 * wave + i) * 64 + 32 * j + (lane & 31)];  // (padded to whole groups)
 }
 
 // out[p][n] = bf16(acc (+ res)) * [mask bit];  KEEP: the value before the mask stays in `keep` (packed bf16: a skip gradient);
@@ -550,7 +579,7 @@ extern "C" int GAGS_DEC(gags_decoder_fwd_fused)(int64_t n_pix, int c_in, int n_l
         a.W[i] = (const unsigned short *)w_bf16[i];
         a.b[i] = bias[i];
         a.act[i] = acts_bf16 ? (unsigned short *)acts_bf16[i] : nullptr;
-        a.mask[i] = (masks && i > 0) ? (unsigned *)masks + (size_t)(i - 1) * n_pix * 8 : nullptr;
+        a.mask[i] = (masks && i > 0) ? (unsigned *)masks + (size_t)(i - 1) * ((n_pix + 63) / 64 * 64) * 8 : nullptr;
     }
     if (fused_ph() == 2)
         hipLaunchKernelGGL(decoder_fwd_fused_kernel<2>, dim3((unsigned)((n_pix + 2 * FT - 1) / (2 * FT))), dim3(512), 0, (hipStream_t)stream, a);
@@ -584,7 +613,7 @@ extern "C" int GAGS_DEC(gags_decoder_bwd_fused_scaled)(int64_t n_pix, int c_in, 
     for (int i = 0; i < 9; ++i) {
         if (!wt_bf16[i]) return GAGS_EINVAL;
         a.Wt[i] = (const unsigned short *)wt_bf16[i];
-        a.mask[i] = i > 0 ? (const unsigned *)masks + (size_t)(i - 1) * n_pix * 8 : nullptr;
+        a.mask[i] = i > 0 ? (const unsigned *)masks + (size_t)(i - 1) * ((n_pix + 63) / 64 * 64) * 8 : nullptr;
     }
     for (int i = 0; i < 8; ++i) {
         if (!dz_bf16[i]) return GAGS_EINVAL;

@@ -372,7 +372,8 @@ def _chain_forward(x, kind, params, mode=_BF16, head_out=None):
         logits = torch.empty(p, wb[8][0].shape[0], device=dev)
         arr = ctypes.c_void_p * 9
         wf = [_frag_layout(wgt) for wgt, _ in wb]
-        masks = torch.empty(8, p, 8, dtype=torch.int32, device=dev)  # the ReLU decisions as bits, for the fused backward
+        masks = torch.empty(8, (p + 63) // 64 * 64, 8, dtype=torch.int32, device=dev)  # the ReLU decisions as bits, for the fused
+        # backward: 8 layers x whole 64-pixel groups x 8 words (an opaque buffer: the two kernels' own layout)
         check(mode.fn("gags_decoder_fwd_fused")(p, xp.shape[1], logits.shape[1], ptr(xp), arr(*[t.data_ptr() for t in wf]),
                                                  arr(*[b.data_ptr() for _, b in wb]), arr(*[t.data_ptr() for t in acts]),
                                                  ptr(masks), ptr(logits), _st()), "gags_decoder_fwd_fused")

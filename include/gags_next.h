@@ -180,7 +180,7 @@ int gags_decoder_head(int64_t n_pix, int c, int ld, int mode, const float *x, fl
  * Bit-identical to the same chain run through gags_decoder_layer. */
 int gags_decoder_fwd_fused(int64_t n_pix, int c_in, int n_last, const float *x, const void *const *w_bf16,
                            const float *const *bias, void *const *acts_bf16, void *masks, float *logits, void *stream);
-/* (masks, optional: uint32 [8, n_pix, 8] -- the ReLU decisions [activation > 0] of the eight hidden activations as bits, word
+/* (masks, optional: uint32 [8, n_pix rounded up to a multiple of 64, 8] -- the ReLU decisions [activation > 0] of the eight hidden activations as bits, word
  * n / 32 of a pixel for channel n; the bit order inside a word is private to this kernel and gags_decoder_bwd_fused, which
  * reads the words instead of the activations themselves: an opaque buffer to the caller.) */
 
