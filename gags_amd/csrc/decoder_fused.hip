@@ -28,7 +28,7 @@ __device__ __forceinline__ float fhi(unsigned u) { return gags_h16::h16_hi(u); }
 
 #ifndef GAGS_ABL
 #define GAGS_ABL 0  // timing-only ablations of the fused kernels (tools/chain_bench.py; results are WRONG with any of them): 1 no HBM
-                    // stores (64 masks / 128 tiles / 256 logits alone), 2 no weight refills, 4 no MFMAs, 16 no B reads, 32 plain stores
+                    // stores (64 masks / 128 tiles / 256 logits alone), 2 no weight refills, 4 no MFMAs, 16 no B reads, 32 plain stores, 512 tile stores into 2 MB per tensor
 #endif
 constexpr int FT = 64;        // pixels per tile and group of four waves; a workgroup holds PH such groups (tile = 64 PH pixels)
 constexpr int FH = 256;       // hidden width
@@ -181,6 +181,7 @@ template <int NT>
 __device__ __forceinline__ void store_tile(unsigned short *__restrict__ dst, int64_t p0, int64_t P, Tile src, int tid)
 {
     if (!dst || (GAGS_ABL & (1 | 128))) return;
+    if (GAGS_ABL & 512) p0 = (p0 / 64 % 64) * 64;  // (every tile's stores land in the same 2 MB of its tensor: they stay in L2)
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int id = tid + NT * q, row = id >> 5, c = (id & 31) * 8;
