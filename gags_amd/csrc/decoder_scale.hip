@@ -81,7 +81,11 @@ __device__ __forceinline__ void stile_store(unsigned short *__restrict__ dst, in
 #pragma unroll
     for (int q = 0; q < SP * C8 / 64; ++q) {
         const int id = lane + 64 * q, row = id / C8, c = (id - row * C8) * 8;
-        if (p0 + row < P) *reinterpret_cast<uint4 *>(dst + (size_t)(p0 + row) * N + c) = *reinterpret_cast<const uint4 *>(&src[row][c]);
+        if (p0 + row < P) {  // (streaming store: read next by a weight-gradient kernel, from HBM either way)
+            typedef unsigned nt_u4 __attribute__((ext_vector_type(4)));
+            const uint4 v = *reinterpret_cast<const uint4 *>(&src[row][c]);
+            __builtin_nontemporal_store(nt_u4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_u4 *>(dst + (size_t)(p0 + row) * N + c));
+        }
     }
 }
 

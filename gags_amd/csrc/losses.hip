@@ -899,10 +899,14 @@ __global__ __launch_bounds__(256, 3) void head_distill_kernel(int H, int W, int 
             pk[q >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(dq2, l_bf16x2));
             df[q] = dq2[0]; df[q + 1] = dq2[1];
         }
+        // (streaming stores: 2.1 GB that the input-gradient chain and the last layer's weight gradient read from HBM later)
+        typedef float nt_f4 __attribute__((ext_vector_type(4)));
+        typedef unsigned nt_u2 __attribute__((ext_vector_type(2)));
         if constexpr (DZM == 1)
-            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(dz) + (size_t)pr * c + c0 + 32 * j) = make_float4(df[0], df[1], df[2], df[3]);
+            __builtin_nontemporal_store(nt_f4{df[0], df[1], df[2], df[3]},
+                                        reinterpret_cast<nt_f4 *>(reinterpret_cast<float *>(dz) + (size_t)pr * c + c0 + 32 * j));
         else
-            *reinterpret_cast<uint2 *>(dz + (size_t)pr * c + c0 + 32 * j) = make_uint2(pk[0], pk[1]);
+            __builtin_nontemporal_store(nt_u2{pk[0], pk[1]}, reinterpret_cast<nt_u2 *>(dz + (size_t)pr * c + c0 + 32 * j));
     }
     };
     if (exact_signs) pass2(GagsLossTrue{});  // (rare: the pixel met an exact tie)

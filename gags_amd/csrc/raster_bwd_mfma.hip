@@ -683,7 +683,9 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(int n_gauss, int d, in
                     w.y = *reinterpret_cast<const unsigned *>(&hi);
                     *reinterpret_cast<uint2 *>(reinterpret_cast<__half *>(v_colors_) + (size_t)g * d + cl) = w;
                 } else {
-                    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(v_colors_) + (size_t)g * d + cl) = acc;
+                    typedef float nt_f4 __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(nt_f4{acc.x, acc.y, acc.z, acc.w},
+                                                reinterpret_cast<nt_f4 *>(reinterpret_cast<float *>(v_colors_) + (size_t)g * d + cl));
                 }
             }
             if (wire) {

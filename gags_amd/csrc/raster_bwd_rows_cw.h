@@ -319,14 +319,14 @@ __global__ __launch_bounds__(256, 2) void raster_bwd_rows_cw(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 asm volatile("" : "+v"(voff));  // (opaque per store: `base + voff` is not to be formed once as a 64-bit vector value)
-                *reinterpret_cast<float *>(base + (size_t)((r & 3) + 8 * (r >> 2)) * pitch_b + voff) = tot[r] * inv_cs;
+                __builtin_nontemporal_store(tot[r] * inv_cs, reinterpret_cast<float *>(base + (size_t)((r & 3) + 8 * (r >> 2)) * pitch_b + voff));
             }
         } else {
             const int nrows = min(min(32, R1 - r0), rows_cap - r0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * k;
-                if (row < nrows) *reinterpret_cast<float *>(base + (size_t)((r & 3) + 8 * (r >> 2)) * pitch_b + voff) = tot[r] * inv_cs;
+                if (row < nrows) __builtin_nontemporal_store(tot[r] * inv_cs, reinterpret_cast<float *>(base + (size_t)((r & 3) + 8 * (r >> 2)) * pitch_b + voff));
             }
         }
     }

@@ -604,7 +604,9 @@ __global__ __launch_bounds__(64, 2) void raster_fwd_feat_x16(
                 }
                 unsigned so = store_off;
                 asm volatile("" : "+v"(so));  // (opaque per store: scalar row base + this offset is the store's own addressing mode)
-                if (col_ok[r & 3]) *reinterpret_cast<float4 *>(const_cast<char *>(blk_base) + (size_t)uo + so) = v;
+                typedef float nt_f4 __attribute__((ext_vector_type(4)));
+                if (col_ok[r & 3])
+                    __builtin_nontemporal_store(nt_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_f4 *>(const_cast<char *>(blk_base) + (size_t)uo + so));
             }
         }
 #pragma unroll

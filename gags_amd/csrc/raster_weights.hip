@@ -143,7 +143,7 @@ __global__ __launch_bounds__(64, 8) void raster_weights_kernel(
         // summed like any other -- they were 20 % of all rows
         if (__ballot(w != 0.f) != 0ull) {
             if (FD == 0 || wt != nullptr) {  // (FD > 0 without tiles: a render nobody differentiates -- nothing but the image leaves)
-                wt[(size_t)row * 64 + e] = w;
+                __builtin_nontemporal_store(w, &wt[(size_t)row * 64 + e]);
                 if (e == 0) {
                     gid_s[row] = h.gid;
                     sidx_s[row] = h.sidx;
